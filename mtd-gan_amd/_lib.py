@@ -1,0 +1,145 @@
+"""ctypes binding of libmtdgan_hip.so (include/mtdgan_hip.h).  There is NO fallback: if the library is
+missing or a call fails, this raises.  The CPU oracle under oracle/ is never imported from here."""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  -- must come first: torch's bundled HIP runtime has to be the one in the global scope
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmtdgan_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+
+
+class Geom(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "B", "IH", "IW", "OH", "OW", "in_sy", "in_sx", "off_y", "off_x", "tap_dy", "tap_dx",
+        "TH", "TW", "KW", "ky0", "kx0", "ky_step", "kx_step", "OHF", "OWF", "out_sy", "out_sx", "out_oy", "out_ox")]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("g", Geom),
+                ("inp", C.c_void_p), ("in_ld", C.c_int), ("C", C.c_int),
+                ("w", C.c_void_p), ("w_sn", C.c_longlong), ("w_sc", C.c_longlong),
+                ("N", C.c_int),
+                ("out", C.c_void_p), ("out_ld", C.c_int),
+                ("scale", C.c_void_p), ("bias", C.c_void_p),
+                ("add1", C.c_void_p), ("add1_ld", C.c_int),
+                ("add2", C.c_void_p), ("add2_ld", C.c_int),
+                ("act", C.c_int),
+                ("mask", C.c_void_p), ("mask_ld", C.c_int), ("mask_slope", C.c_float),
+                ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("g", Geom),
+                ("p", C.c_void_p), ("p_ld", C.c_int), ("N", C.c_int),
+                ("q", C.c_void_p), ("q_ld", C.c_int), ("C", C.c_int),
+                ("dw", C.c_void_p), ("w_sn", C.c_longlong), ("w_sc", C.c_longlong),
+                ("db", C.c_void_p), ("accumulate", C.c_int),
+                ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
+
+
+class SnLayer(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("sigma", C.c_void_p),
+                ("u_save", C.c_void_p), ("v_save", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int)]
+
+
+class SnGradLayer(C.Structure):
+    _fields_ = [("G", C.c_void_p), ("w", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("sigma", C.c_void_p),
+                ("g_out", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("accumulate", C.c_int)]
+
+
+class LossTerm(C.Structure):
+    _fields_ = [("kind", C.c_int), ("a", C.c_void_p), ("b", C.c_void_p), ("tconst", C.c_float),
+                ("mx", C.c_void_p), ("my", C.c_void_p), ("n", C.c_longlong), ("scale", C.c_float), ("eps", C.c_float),
+                ("grad_out", C.c_void_p), ("coef", C.c_float), ("accumulate", C.c_int)]
+
+
+class AdamwTensor(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_longlong)]
+
+
+_lib = None
+
+
+def _preload_torch_hip_runtime():
+    """libmtdgan_hip.so links libamdhip64.so.7 (ROCm), PyTorch ships its own libamdhip64.so.  Streams and
+    device pointers come from PyTorch, so the kernels must be launched through PyTorch's runtime: load it
+    into the global symbol scope before the library so every hip* symbol binds there."""
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(tl):
+        C.CDLL(tl, mode=C.RTLD_GLOBAL)
+
+
+def lib():
+    """Load the HIP library or fail loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the MTD-GAN HIP kernels are not built. Run `python -c 'import "
+            "__graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback in this package.")
+    _preload_torch_hip_runtime()
+    L = C.CDLL(LIB_PATH)
+    vp, ci, cf, ll, sz = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
+
+    def sig(name, res, *args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = list(args)
+
+    sig("mtd_version", C.c_char_p)
+    sig("mtd_conv_igemm_ws_bytes", sz, C.POINTER(ConvArgs))
+    sig("mtd_conv_igemm", ci, C.POINTER(ConvArgs), vp)
+    sig("mtd_conv_direct", ci, C.POINTER(ConvArgs), vp)
+    sig("mtd_conv_wgrad_ws_bytes", sz, C.POINTER(WgradArgs))
+    sig("mtd_conv_wgrad", ci, C.POINTER(WgradArgs), vp)
+    sig("mtd_rfft_rows", ci, vp, ci, vp, ci, ci, vp)
+    sig("mtd_spec_mix_fwd", ci, vp, vp, vp, vp, vp, vp, ci, vp)
+    sig("mtd_spec_mix_bwd_ws_bytes", sz, ci)
+    sig("mtd_spec_mix_bwd", ci, vp, vp, vp, vp, vp, vp, ci, vp)
+    sig("mtd_spec_mix_wgrad_reduce", ci, vp, ci, vp, vp, ci, vp)
+    sig("mtd_irfft_rows", ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, ci, vp)
+    sig("mtd_transpose64", ci, vp, vp, vp)
+    sig("mtd_act_grad", ci, vp, ci, vp, ci, vp, ci, ll, ci, cf, vp)
+    sig("mtd_copy_channels", ci, vp, ci, vp, ci, ll, ci, ci, vp)
+    sig("mtd_upsample2x_fwd", ci, vp, ci, vp, ci, ci, ci, ci, ci, vp)
+    sig("mtd_upsample2x_bwd", ci, vp, ci, vp, ci, ci, ci, ci, ci, vp)
+    sig("mtd_pixel_shuffle2_fwd", ci, vp, ci, vp, ci, ci, ci, ci, ci, vp)
+    sig("mtd_pixel_shuffle2_bwd", ci, vp, ci, vp, ci, ci, ci, ci, ci, vp)
+    sig("mtd_mul", ci, vp, vp, vp, ll, vp)
+    sig("mtd_sn_ws_bytes", sz, vp, ci)
+    sig("mtd_sn_power_iter", ci, vp, vp, ci, ci, vp, vp)
+    sig("mtd_sn_grad_ws_bytes", sz, vp, ci)
+    sig("mtd_sn_grad", ci, vp, vp, ci, vp, vp)
+    sig("mtd_pcgrad_ws_bytes", sz, ll, ci)
+    sig("mtd_pcgrad_gram", ci, vp, vp, vp, vp, ci, ll, vp, vp, vp)
+    sig("mtd_pcgrad_combine", ci, vp, vp, vp, vp, ci, ll, vp, vp, vp, vp, vp)
+    sig("mtd_adamw_multi", ci, vp, vp, ci, cf, cf, cf, cf, cf, ci, vp)
+    sig("mtd_loss_terms_ws_bytes", sz, ci)
+    sig("mtd_loss_terms", ci, vp, ci, vp, vp, vp)
+    sig("mtd_loss_term_grads", ci, vp, ci, vp)
+    sig("mtd_clip01", ci, vp, vp, ll, vp)
+    sig("mtd_clip01_bwd", ci, vp, vp, vp, ll, vp)
+    sig("mtd_edge_loss_ws_bytes", sz, ci)
+    sig("mtd_edge_loss", ci, vp, vp, ci, cf, cf, vp, vp, cf, ci, vp, vp)
+    _lib = L
+    return L
+
+
+EXPORTS = [
+    "mtd_version", "mtd_conv_igemm_ws_bytes", "mtd_conv_igemm", "mtd_conv_direct", "mtd_conv_wgrad_ws_bytes",
+    "mtd_conv_wgrad", "mtd_rfft_rows", "mtd_spec_mix_fwd", "mtd_spec_mix_bwd_ws_bytes", "mtd_spec_mix_bwd",
+    "mtd_spec_mix_wgrad_reduce", "mtd_irfft_rows", "mtd_transpose64", "mtd_act_grad", "mtd_copy_channels",
+    "mtd_upsample2x_fwd", "mtd_upsample2x_bwd", "mtd_pixel_shuffle2_fwd", "mtd_pixel_shuffle2_bwd", "mtd_mul",
+    "mtd_sn_ws_bytes", "mtd_sn_power_iter", "mtd_sn_grad_ws_bytes", "mtd_sn_grad", "mtd_pcgrad_ws_bytes",
+    "mtd_pcgrad_gram", "mtd_pcgrad_combine", "mtd_adamw_multi", "mtd_loss_terms_ws_bytes", "mtd_loss_terms",
+    "mtd_loss_term_grads", "mtd_clip01", "mtd_clip01_bwd", "mtd_edge_loss_ws_bytes", "mtd_edge_loss",
+]
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"libmtdgan_hip: {what} failed with code {rc}")

@@ -1,0 +1,347 @@
+"""MI355X-native mirror of the reference's `arch/Ours/networks.py` hot-path surface.
+
+Same class names, constructor arguments, attribute names and state_dict keys as the reference
+(arch/Ours/networks.py:15-36 FFT_ConvBlock, :38-164 ResFFT_Generator, :166-175 UpsampleBlock, :177-474
+Multi_Task_Discriminator_Skip, :1940-2009 MTD_GAN_Method), so `from arch.Ours.networks import *`
+call sites (models.py:15,52-53) can be pointed here.  Tensors are NCHW fp32 at this surface, exactly
+like the reference; internally everything is NHWC and every arithmetic op is a hand-written gfx950
+kernel from libmtdgan_hip.so.  There is no eager/CPU fallback: a CPU tensor or a missing library
+raises.
+"""
+from itertools import chain
+from typing import Iterator
+
+import torch
+import torch.nn as nn
+
+from ... import generator_path as GP
+
+
+def _require_cuda(t, who):
+    if not t.is_cuda:
+        raise RuntimeError(f"{who}: this implementation runs on MI355X HIP kernels only; got a {t.device} tensor "
+                           "(there is no CPU fallback -- use the reference for CPU runs)")
+
+
+# =================================================================================================
+# Res-FFT-Conv block
+# =================================================================================================
+class _BlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_img, b_img, w_fft, b_fft):
+        # x: NHWC contiguous (B,64,64,32)
+        need = any(ctx.needs_input_grad)
+        out, saved = GP.block_forward(x, w_img, b_img, w_fft, b_fft, need)
+        if need:
+            ctx.saved = saved
+            ctx.w = (w_img, w_fft)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w_img, w_fft = ctx.w
+        grads = {"dw_img": torch.empty_like(w_img), "db_img": torch.empty(w_img.shape[0], device=g.device),
+                 "dw_fft": torch.empty_like(w_fft), "db_fft": torch.empty(w_fft.shape[0], device=g.device)}
+        gx = GP.block_backward(g.contiguous(), ctx.saved, w_img, w_fft, grads, False)
+        return gx, grads["dw_img"], grads["db_img"], grads["dw_fft"], grads["db_fft"]
+
+
+class FFT_ConvBlock(nn.Module):
+    """x + relu(conv3x3(x)) + irfft2(relu(conv1x1([Re;Im] rfft2(x))))  -- reference networks.py:15-36."""
+
+    def __init__(self, out_channels):
+        super().__init__()
+        self.img_conv = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        self.fft_conv = nn.Conv2d(out_channels * 2, out_channels * 2, kernel_size=1, stride=1, padding=0)
+
+    def forward(self, x):
+        _require_cuda(x, "FFT_ConvBlock")
+        if x.shape[1] != 32 or x.shape[2] != 64 or x.shape[3] != 64:
+            raise NotImplementedError("FFT_ConvBlock HIP path: 32 channels, 64x64 patches (training hot path)")
+        xn = x.permute(0, 2, 3, 1).contiguous()                 # layout plumbing only
+        out = _BlockFn.apply(xn, self.img_conv.weight, self.img_conv.bias, self.fft_conv.weight, self.fft_conv.bias)
+        return out.permute(0, 3, 1, 2)
+
+
+# =================================================================================================
+# Generator
+# =================================================================================================
+class _GeneratorFn(torch.autograd.Function):
+    """Whole generator as one autograd node: forward and backward are explicit kernel schedules."""
+
+    @staticmethod
+    def forward(ctx, x, nlayers, *params):
+        P = _unflatten_gen(params, nlayers)
+        need = any(ctx.needs_input_grad)
+        xn = x.reshape(x.shape[0], x.shape[2], x.shape[3], 1)    # C == 1: NCHW and NHWC coincide
+        out, tape = GP.generator_forward(xn, P, need)
+        if need:
+            ctx.tape, ctx.P, ctx.nlayers = tape, P, nlayers
+        return out.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        P, nlayers = ctx.P, ctx.nlayers
+        flat = _flatten_gen(P)
+        gflat = [torch.empty_like(p) for p in flat]
+        G = _unflatten_gen(gflat, nlayers, as_grad=True)
+        gn = g.contiguous().reshape(g.shape[0], g.shape[2], g.shape[3], 1)
+        GP.generator_backward(gn, ctx.tape, P, G)
+        ctx.tape = None
+        return (None, None) + tuple(gflat)
+
+
+def _flatten_gen(P):
+    flat = []
+    for w, b in zip(P.enc_w, P.enc_b):
+        flat += [w, b]
+    for w, b in zip(P.dec_w, P.dec_b):
+        flat += [w, b]
+    for blk in P.blk:
+        flat += list(blk)
+    return flat
+
+
+def _unflatten_gen(flat, nlayers, as_grad=False):
+    n = nlayers + 1
+    enc_w, enc_b = list(flat[0:2 * n:2]), list(flat[1:2 * n:2])
+    dec_w, dec_b = list(flat[2 * n:4 * n:2]), list(flat[2 * n + 1:4 * n:2])
+    rest = flat[4 * n:]
+    blk = []
+    for i in range(0, len(rest), 4):
+        if as_grad:
+            blk.append({"dw_img": rest[i], "db_img": rest[i + 1], "dw_fft": rest[i + 2], "db_fft": rest[i + 3]})
+        else:
+            blk.append((rest[i], rest[i + 1], rest[i + 2], rest[i + 3]))
+    return GP.GenParams(enc_w, enc_b, dec_w, dec_b, blk)
+
+
+class ResFFT_Generator(nn.Module):
+    """Reference networks.py:38-164.  RED-CNN-style 11 conv + 11 conv-transpose (stride 1) with additive
+    skips and 21 Res-FFT-Conv blocks.  HIP path covers the MTD-GAN configuration (1, 32, 10, 3, 1)."""
+
+    def __init__(self, in_channels=1, out_channels=96, num_layers=10, kernel_size=5, padding=0):
+        super().__init__()
+        encoder = [nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=1, padding=padding)]
+        decoder = [nn.ConvTranspose2d(out_channels, in_channels, kernel_size=kernel_size, stride=1, padding=padding)]
+        for _ in range(num_layers):
+            encoder.append(nn.Conv2d(out_channels, out_channels, kernel_size=kernel_size, stride=1, padding=padding))
+            decoder.append(nn.ConvTranspose2d(out_channels, out_channels, kernel_size=kernel_size, stride=1, padding=padding))
+        self.encoder = nn.ModuleList(encoder)
+        self.decoder = nn.ModuleList(decoder)
+        self.enforce = nn.ModuleList([FFT_ConvBlock(out_channels) for _ in range(21)])
+        self._cfg = (in_channels, out_channels, num_layers, kernel_size, padding)
+        self.__init_weights()
+
+    def __init_weights(self):
+        # reference quirk: only Conv2d / Linear are re-initialised, ConvTranspose2d keeps
+        # PyTorch's default init
+        for m in self.modules():
+            if type(m) in {nn.Conv2d, nn.Linear}:
+                m.weight.data.normal_(0, 0.01)
+                if hasattr(m.bias, "data"):
+                    m.bias.data.fill_(0)
+
+    def shared_parameters(self) -> Iterator[nn.parameter.Parameter]:
+        return chain(*[self.encoder[i].parameters() for i in range(11)],
+                     *[self.decoder[-i].parameters() for i in range(1, 12)])
+
+    def task_specific_parameters(self):
+        return None
+
+    def last_shared_parameters(self) -> Iterator[nn.parameter.Parameter]:
+        return self.decoder[-11].parameters()
+
+    def _flat_params(self):
+        flat = []
+        for m in self.encoder:
+            flat += [m.weight, m.bias]
+        for m in self.decoder:
+            flat += [m.weight, m.bias]
+        for blk in self.enforce:
+            flat += [blk.img_conv.weight, blk.img_conv.bias, blk.fft_conv.weight, blk.fft_conv.bias]
+        return flat
+
+    def forward(self, x: torch.Tensor):
+        _require_cuda(x, "ResFFT_Generator")
+        if self._cfg != (1, 32, 10, 3, 1):
+            raise NotImplementedError("ResFFT_Generator HIP path is built for MTD_GAN_Method's (1,32,10,3,1) configuration")
+        if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] != 64 or x.shape[3] != 64:
+            raise NotImplementedError(f"ResFFT_Generator HIP path expects (B,1,64,64) patches, got {tuple(x.shape)}")
+        return _GeneratorFn.apply(x.contiguous().float(), self._cfg[2], *self._flat_params())
+
+
+# =================================================================================================
+# Discriminator
+# =================================================================================================
+from ... import discriminator_path as DP  # noqa: E402
+from ... import kernels as K  # noqa: E402
+from ...losses import CharbonnierLoss, EdgeLoss, NDS_Loss, ls_gan  # noqa: E402
+
+
+class UpsampleBlock(nn.Module):
+    """1x1 conv to C*scale^2 channels + PixelShuffle -- reference networks.py:166-175."""
+
+    def __init__(self, scale, input_channels, output_channels):
+        super().__init__()
+        self.upsample = nn.Sequential(
+            nn.Conv2d(input_channels, output_channels * (scale ** 2), kernel_size=1, stride=1, padding=0),
+            nn.PixelShuffle(upscale_factor=scale))
+
+    def forward(self, input):
+        raise RuntimeError("UpsampleBlock is executed inside Multi_Task_Discriminator_Skip's fused HIP schedule")
+
+
+class _DiscFn(torch.autograd.Function):
+    """One whole discriminator pass as an autograd node (generic use; the training step drives the same
+    schedules directly, see train_step.py)."""
+
+    @staticmethod
+    def forward(ctx, x, module, train, mask, need_rec, *params):
+        ctx.set_materialize_grads(False)
+        names = module._param_names
+        P = dict(zip(names, params))
+        P.update(module._buffer_dict())
+        xn = x.reshape(x.shape[0], 64, 64, 1)
+        need = any(ctx.needs_input_grad)
+        (enc, dec, rec), tape = DP.disc_forward(P, xn, train, mask, need_rec, need)
+        if need:
+            ctx.tape, ctx.P, ctx.module, ctx.names = tape, P, module, names
+        B = x.shape[0]
+        outs = (enc.reshape(B, 1), dec.reshape(B, 1, 64, 64), rec.reshape(B, 1, 64, 64) if rec is not None else None)
+        if rec is None:
+            ctx.mark_non_differentiable()
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_enc, g_dec, g_rec):
+        B = ctx.tape.B
+        names, P = ctx.names, ctx.P
+        needs = ctx.needs_input_grad[5:]
+        sink_t = {n: torch.zeros_like(P[n]) for n, need in zip(names, needs) if need}
+        f = lambda g, shape: g.contiguous().reshape(shape) if g is not None else None
+        gin = DP.disc_backward(ctx.module._rt, P, ctx.tape, f(g_enc, (B, 1, 1, 1)), f(g_dec, (B, 64, 64, 1)), f(g_rec, (B, 64, 64, 1)),
+                               DP.GradSink(sink_t) if sink_t else None, ctx.needs_input_grad[0])
+        gx = gin.reshape(B, 1, 64, 64) if gin is not None else None
+        return (gx, None, None, None, None) + tuple(sink_t.get(n) for n in names)
+
+
+class Multi_Task_Discriminator_Skip(nn.Module):
+    """Reference networks.py:177-474: spectral-norm conv trunk 64x64 -> 1x1 (skips x1..x6), CLS head,
+    bilinear SEG decoder, PixelShuffle REC decoder.  Attribute / parameter / buffer names follow the
+    reference (`<layer>.bias`, `.weight_orig`, `.weight_u`, `.weight_v`, `r_up{k}.upsample.0.*`)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        if (in_channels, out_channels) != (1, 64):
+            raise NotImplementedError("HIP path is built for MTD_GAN_Method's (1, 64) configuration")
+        sn = nn.utils.spectral_norm
+        c = out_channels
+        chans = [c, c * 2, c * 4, c * 8, c * 8, c * 8]
+        cin = in_channels
+        for l, co in enumerate(chans, start=1):
+            setattr(self, f"conv{l}1", sn(nn.Conv2d(cin, co, 3, 1, 1)))
+            setattr(self, f"relu{l}1", nn.LeakyReLU(0.2))
+            setattr(self, f"conv{l}2", sn(nn.Conv2d(co, co, 3, 1, 1)))
+            setattr(self, f"relu{l}2", nn.LeakyReLU(0.2))
+            setattr(self, f"down{l}", sn(nn.Conv2d(co, co, 4, 2, 1)))
+            cin = co
+        self.bconv1 = sn(nn.Conv2d(c * 8, c * 8, 1, 1, 0))
+        self.brelu1 = nn.LeakyReLU(0.2)
+        self.bconv2 = sn(nn.Conv2d(c * 8, c * 8, 1, 1, 0))
+        self.brelu2 = nn.LeakyReLU(0.2)
+        self.c_flatten = nn.Flatten()
+        self.c_fc = sn(nn.Linear(512, 512, True))
+        self.c_relu = nn.LeakyReLU(0.2)
+        self.c_drop = nn.Dropout(p=0.3)
+        for pre in ("s", "r"):
+            for l, (ci, co) in enumerate(DP.DEC, start=1):
+                if pre == "s":
+                    setattr(self, f"s_up{l}", nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False))
+                else:
+                    setattr(self, f"r_up{l}", UpsampleBlock(2, DP.RUP[l - 1][0], DP.RUP[l - 1][1]))
+                setattr(self, f"{pre}_dconv{l}1", sn(nn.Conv2d(ci, co, 3, 1, 1)))
+                setattr(self, f"{pre}_drelu{l}1", nn.LeakyReLU(0.2))
+                setattr(self, f"{pre}_dconv{l}2", sn(nn.Conv2d(co, co, 3, 1, 1)))
+                setattr(self, f"{pre}_drelu{l}2", nn.LeakyReLU(0.2))
+        self.enc_out = nn.Linear(512, 1)
+        self.dec_out = nn.Conv2d(in_channels, 1, 1)
+        self.rec_out = nn.Conv2d(in_channels, 1, 1)
+        self.__init_weights()
+        self._rt = DP.DiscRuntime()
+        self._param_names = [n for n, _ in self.named_parameters()]
+        self._inject_masks = []          # tests: dropout multipliers (B,512) consumed one per forward
+
+    def __init_weights(self):
+        for m in self.modules():
+            if type(m) in {nn.Conv2d, nn.Linear}:
+                m.weight.data.normal_(0, 0.01)
+                if hasattr(m.bias, "data"):
+                    m.bias.data.fill_(0)
+
+    # ---- parameter partition (reference networks.py:318-380; `c_fc` is in neither list) ----------
+    def shared_parameters(self) -> Iterator[nn.parameter.Parameter]:
+        names = [f"{k}{l}{j}" if k == "conv" else f"down{l}" for l in range(1, 7) for k, j in (("conv", 1), ("conv", 2), ("down", ""))]
+        return chain(*[getattr(self, n).parameters() for n in names], self.bconv1.parameters(), self.bconv2.parameters())
+
+    def task_specific_parameters(self) -> Iterator[nn.parameter.Parameter]:
+        mods = [getattr(self, f"s_dconv{l}{j}") for l in range(1, 7) for j in (1, 2)]
+        for l in range(1, 7):
+            mods += [getattr(self, f"r_up{l}"), getattr(self, f"r_dconv{l}1"), getattr(self, f"r_dconv{l}2")]
+        mods += [self.enc_out, self.dec_out, self.rec_out]
+        return chain(*[m.parameters() for m in mods])
+
+    def last_shared_parameters(self) -> Iterator[nn.parameter.Parameter]:
+        return self.bconv2.parameters()
+
+    # ---- plumbing ------------------------------------------------------------------------------------
+    def _buffer_dict(self):
+        return {n: b for n, b in self.named_buffers()}
+
+    def _param_dict(self):
+        P = {n: p for n, p in self.named_parameters()}
+        P.update(self._buffer_dict())
+        return P
+
+    def _next_mask(self, B, device):
+        if not self.training:
+            return None
+        if self._inject_masks:
+            return self._inject_masks.pop(0).to(device)
+        p = self.c_drop.p
+        if p == 0.0:
+            return None
+        return (torch.rand(B, 512, device=device) >= p).to(torch.float32) / (1.0 - p)     # RNG draw only
+
+    def forward(self, input, need_rec=True):
+        _require_cuda(input, "Multi_Task_Discriminator_Skip")
+        if input.dim() != 4 or tuple(input.shape[1:]) != (1, 64, 64):
+            raise NotImplementedError(f"discriminator expects (B,1,64,64) (Linear(512,512) after the 1x1 bottleneck), got {tuple(input.shape)}")
+        x = input.contiguous().float()
+        mask = self._next_mask(x.shape[0], x.device)
+        params = [p for _, p in self.named_parameters()]
+        return _DiscFn.apply(x, self, self.training, mask, need_rec, *params)
+
+
+# =================================================================================================
+# MTD-GAN (reference networks.py:1940-2009)
+# =================================================================================================
+class MTD_GAN_Method(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.Generator = ResFFT_Generator(in_channels=1, out_channels=32, num_layers=10, kernel_size=3, padding=1)
+        self.Discriminator = Multi_Task_Discriminator_Skip(in_channels=1, out_channels=64)
+        self.gan_metric_cls = ls_gan
+        self.gan_metric_seg = NDS_Loss
+        self.pixel_loss = CharbonnierLoss()
+        self.edge_loss = EdgeLoss()
+
+    def d_loss(self, x, y):
+        """Returns (stack[disc, rec, consist], details).  The stacked tensor carries the recorded
+        discriminator passes (`_mtd_tape`), which WeightMethods('pcgrad').backward consumes."""
+        from ... import train_step as TS
+        return TS.d_loss(self, x, y)
+
+    def g_loss(self, x, y):
+        from ... import train_step as TS
+        return TS.g_loss(self, x, y)

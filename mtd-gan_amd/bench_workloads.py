@@ -1,0 +1,56 @@
+"""Workloads timed by bench.py.  Each exposes step() (one pass of the hot path over one resident batch),
+config(), extra() and cpu_baseline_spec()."""
+import torch
+import torch.distributed as dist
+
+from .data import synthetic_ldct
+
+
+class GeneratorWorkload:
+    """BASELINE config 2: generator-only Res-FFT-Conv forward + backward, 32 x 1 x 64 x 64 fp32 per GPU.
+    Algorithmic work 10.72 GFLOP/patch."""
+
+    name = "generator_fwd_bwd"
+    gflop_per_patch = 10.72
+
+    def __init__(self, dev, rank, world, batch):
+        from .arch.Ours.networks import ResFFT_Generator
+        torch.manual_seed(2024)
+        self.G = ResFFT_Generator(1, 32, 10, 3, 1).to(dev)
+        x, y = synthetic_ldct(batch, seed=1234 + rank)
+        self.x, self.y = x.to(dev), y.to(dev)
+        self.world, self.batch = world, batch
+        self.params = [p for p in self.G.parameters()]
+        self.flat = None
+
+    def step(self):
+        for p in self.params:
+            p.grad = None
+        out = self.G(self.x)
+        out.backward(self.y)          # cotangent = fixed tensor (out.mean().backward() semantics up to scale)
+        if self.world > 1:
+            flat = torch.cat([p.grad.reshape(-1) for p in self.params])
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+            self.flat = flat
+
+    def config(self, world):
+        return {"workload": "Generator-only Res-FFT-Conv fwd+bwd (BASELINE configs[1])", "per_gpu_batch": self.batch,
+                "global_batch": self.batch * world, "patch": "1x64x64", "parallelism": f"dp{world}"}
+
+    def extra(self):
+        return {"algorithmic_gflop_per_patch": self.gflop_per_patch}
+
+
+def make(name, dev, rank, world, batch):
+    if name in ("auto", "generator", "generator_fwd_bwd"):
+        try:
+            if name == "auto":
+                from .train_step import FullStepWorkload   # becomes the default once the full step exists
+                return FullStepWorkload(dev, rank, world, batch)
+        except ImportError:
+            pass
+        return GeneratorWorkload(dev, rank, world, batch)
+    if name == "full_step":
+        from .train_step import FullStepWorkload
+        return FullStepWorkload(dev, rank, world, batch)
+    raise ValueError(f"unknown workload {name}")

@@ -1,0 +1,31 @@
+// Shared device helpers for the gfx950 kernels of libmtdgan_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mtdgan_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MTD_LAUNCH_CHECK()                      \
+    do {                                        \
+        hipError_t e__ = hipGetLastError();     \
+        if (e__ != hipSuccess) return (int)e__; \
+    } while (0)
+
+// v_mfma_f32_32x32x2_f32: D(32x32) += A(32x2) * B(2x32), exact f32 FMA chain.
+// lane l holds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
+// result register r of lane l is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == MTD_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == MTD_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
+    return v;
+}
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+static inline long long geom_pixels(const mtd_geom& g) { return (long long)g.B * g.OH * g.OW; }

@@ -1,0 +1,326 @@
+// Implicit-GEMM convolution / data-gradient on fp32 MFMA for gfx950 (MI355X).
+//
+//   out[pix, n] = epilogue( sum_{tap} sum_{c} in[gather(pix, tap), c] * W(n, c, tap) )
+//
+// GEMM view: M = B*OH*OW pixels, N output channels, K = taps * C.  One workgroup (4 waves) owns a
+// BM x BN output tile; K is walked as (tap, 32-channel chunk).  Per chunk the A tile (im2col gather,
+// zero-filled outside the image) and the B tile (weights, read straight from the PyTorch OIHW / IOHW
+// storage through element strides) are staged global -> registers -> LDS, k-major so that the
+// v_mfma_f32_32x32x2_f32 operand reads (lane = row / column) are conflict-free ds_read_b32.
+// The next chunk's global loads are issued before the current chunk's MFMAs (register prefetch), so
+// HBM/L2 latency hides under the 64-cycle MFMAs.  Taps that fall outside the image for every pixel of
+// the tile (2x2 / 1x1 feature maps of the discriminator) are skipped for the whole workgroup.
+// Small-M layers use split-K over channel ranges (slabs in the caller's workspace + a fused
+// reduce/epilogue kernel) so the grid still fills 256 CUs; the sum order is fixed => deterministic.
+//
+// Roofline: fp32 MFMA, 64 FLOP/clk/SIMD (157 TFLOP/s chip).  Algorithmic flops = 2*M*N*K.
+#include "common.h"
+
+namespace {
+
+constexpr int KC = 32;   // channels per K chunk
+
+struct IgemmParams {
+    mtd_conv_args a;
+    int M;
+    int splitk;
+    int c_per_split;
+    int b_cfast;       // weight tile: c varies fastest across lanes (w_sc < w_sn)
+    int out_identity;  // output pixel index == launch-grid pixel index
+};
+
+__device__ __forceinline__ long long out_pixel(const mtd_geom& g, int m, int identity) {
+    if (identity) return m;
+    int ox = m % g.OW;
+    int t = m / g.OW;
+    int oy = t % g.OH;
+    int b = t / g.OH;
+    return ((long long)b * g.OHF + (oy * g.out_sy + g.out_oy)) * g.OWF + (ox * g.out_sx + g.out_ox);
+}
+
+__device__ __forceinline__ float epilogue_value(const mtd_conv_args& a, float acc, float sc, float bias_n,
+                                                long long pix, int n) {
+    float v = acc * sc + bias_n;
+    if (a.add1) v += a.add1[pix * a.add1_ld + n];
+    if (a.add2) v += a.add2[pix * a.add2_ld + n];
+    v = apply_act(v, a.act);
+    if (a.mask) v *= (a.mask[pix * a.mask_ld + n] > 0.f) ? 1.f : a.mask_slope;
+    return v;
+}
+
+template <int WM, int WN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+    constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN;
+    constexpr int LDA = BM + 1, LDB = BN + 1;
+    constexpr int PA = BM / 32;     // A rows staged per thread
+    constexpr int PB = BN / 8;      // B elements staged per thread
+    __shared__ float As[KC * LDA];
+    __shared__ float Bs[KC * LDB];
+
+    const mtd_conv_args& a = p.a;
+    const mtd_geom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int cbeg = blockIdx.z * p.c_per_split;
+    const int cend = min(a.C, cbeg + p.c_per_split);
+    const int q = tid & 7, r = tid >> 3;
+
+    // launch-grid coordinates of the PA pixels this thread stages
+    int pb[PA], py[PA], px[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        int m = m0 + i * 32 + r;
+        if (m < p.M) {
+            int ox = m % g.OW;
+            int t = m / g.OW;
+            int oy = t % g.OH;
+            pb[i] = t / g.OH;
+            py[i] = oy * g.in_sy + g.off_y;
+            px[i] = ox * g.in_sx + g.off_x;
+        } else {
+            pb[i] = 0;
+            py[i] = -(1 << 28);
+            px[i] = -(1 << 28);
+        }
+    }
+    // which taps touch the image for at least one pixel of this tile
+    const int T = g.TH * g.TW;
+    unsigned vmask = 0;
+    for (int t = 0; t < T; ++t) {
+        int ty = t / g.TW, tx = t % g.TW;
+        int any = 0;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            int iy = py[i] + ty * g.tap_dy, ix = px[i] + tx * g.tap_dx;
+            any |= ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
+        }
+        if (__syncthreads_or(any)) vmask |= 1u << t;
+    }
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // K iterator state
+    int tap = -1, c0 = cend, kidx = 0;
+    const float* src[PA];
+    f32x4 av[PA];
+    float bv[PB];
+
+    auto advance = [&]() -> bool {
+        c0 += KC;
+        if (c0 < cend) return true;
+        do { ++tap; } while (tap < T && !((vmask >> tap) & 1u));
+        if (tap >= T) return false;
+        c0 = cbeg;
+        int ty = tap / g.TW, tx = tap % g.TW;
+        kidx = (g.ky0 + ty * g.ky_step) * g.KW + (g.kx0 + tx * g.kx_step);
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            int iy = py[i] + ty * g.tap_dy, ix = px[i] + tx * g.tap_dx;
+            bool ok = ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
+            src[i] = ok ? a.in + (((long long)pb[i] * g.IH + iy) * g.IW + ix) * a.in_ld + 4 * q : nullptr;
+        }
+        return c0 < cend;
+    };
+    auto load = [&]() {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            if (src[i]) av[i] = *reinterpret_cast<const f32x4*>(src[i] + c0);
+            else av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            int e = tid + i * 256, n, c;
+            if (p.b_cfast) { c = e & (KC - 1); n = e / KC; }
+            else { n = e % BN; c = e / BN; }
+            bv[i] = a.w[(long long)(n0 + n) * a.w_sn + (long long)(c0 + c) * a.w_sc + kidx];
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            int ml = i * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) As[(4 * q + e) * LDA + ml] = av[i][e];
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            int e = tid + i * 256, n, c;
+            if (p.b_cfast) { c = e & (KC - 1); n = e / KC; }
+            else { n = e % BN; c = e / BN; }
+            Bs[c * LDB + n] = bv[i];
+        }
+    };
+
+    bool more = advance();
+    if (more) load();
+    while (more) {
+        __syncthreads();
+        store();
+        __syncthreads();
+        more = advance();
+        if (more) load();
+        const int kh = lane >> 5, l31 = lane & 31;
+#pragma unroll
+        for (int kk = 0; kk < KC / 2; ++kk) {
+            float af[WM], bf[WN];
+            const int k = 2 * kk + kh;
+#pragma unroll
+            for (int i = 0; i < WM; ++i) af[i] = As[k * LDA + (wm * WM + i) * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bf[j] = Bs[k * LDB + (wn * WN + j) * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+        }
+    }
+
+    // epilogue
+    const int l31 = lane & 31;
+    if (p.splitk > 1) {
+        float* slab = a.ws + (long long)blockIdx.z * p.M * a.N;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                int n = n0 + (wn * WN + j) * 32 + l31;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    int m = m0 + (wm * WM + i) * 32 + mfma32_row(e, lane);
+                    if (m < p.M) slab[(long long)m * a.N + n] = acc[i][j][e];
+                }
+            }
+        return;
+    }
+    const float sc = a.scale ? *a.scale : 1.f;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            int n = n0 + (wn * WN + j) * 32 + l31;
+            float bias_n = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int m = m0 + (wm * WM + i) * 32 + mfma32_row(e, lane);
+                if (m < p.M) {
+                    long long pix = out_pixel(g, m, p.out_identity);
+                    a.out[pix * a.out_ld + n] = epilogue_value(a, acc[i][j][e], sc, bias_n, pix, n);
+                }
+            }
+        }
+}
+
+// sum the split-K slabs in order, then the same epilogue
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IgemmParams p) {
+    const mtd_conv_args& a = p.a;
+    const long long total = (long long)p.M * a.N;
+    const float sc = a.scale ? *a.scale : 1.f;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        int n = (int)(idx % a.N);
+        int m = (int)(idx / a.N);
+        float s = 0.f;
+        for (int z = 0; z < p.splitk; ++z) s += a.ws[(long long)z * total + idx];
+        long long pix = out_pixel(a.g, m, p.out_identity);
+        float bias_n = a.bias ? a.bias[n] : 0.f;
+        a.out[pix * a.out_ld + n] = epilogue_value(a, s, sc, bias_n, pix, n);
+    }
+}
+
+struct Plan { int cfg, BM, BN, splitk, c_per_split; };
+
+Plan make_plan(const mtd_conv_args& a) {
+    const long long M = geom_pixels(a.g);
+    Plan pl{};
+    if (a.N % 128 == 0) {
+        if (M > 64) { pl.cfg = 4; pl.BM = 128; pl.BN = 128; }
+        else { pl.cfg = 5; pl.BM = 32; pl.BN = 128; }
+    } else if (a.N % 64 == 0) {
+        if (M >= 1024) { pl.cfg = 2; pl.BM = 256; pl.BN = 64; }
+        else { pl.cfg = 3; pl.BM = 64; pl.BN = 64; }
+    } else {
+        if (M >= 1024) { pl.cfg = 0; pl.BM = 256; pl.BN = 32; }
+        else { pl.cfg = 1; pl.BM = 128; pl.BN = 32; }
+    }
+    long long blocks = ((M + pl.BM - 1) / pl.BM) * (a.N / pl.BN);
+    int chunks = a.C / KC;
+    int want = (int)((768 + blocks - 1) / blocks);
+    int sk = want < 1 ? 1 : want;
+    if (sk > chunks) sk = chunks;
+    if (sk > 32) sk = 32;
+    int cps = ((chunks + sk - 1) / sk);
+    sk = (chunks + cps - 1) / cps;
+    pl.splitk = sk;
+    pl.c_per_split = cps * KC;
+    return pl;
+}
+
+int check_args(const mtd_conv_args& a) {
+    if (!a.in || !a.w || !a.out) return MTD_EINVAL;
+    if (a.C <= 0 || a.N <= 0 || (a.C % 32) || (a.N % 32)) return MTD_EINVAL;
+    const mtd_geom& g = a.g;
+    if (g.B <= 0 || g.IH <= 0 || g.IW <= 0 || g.OH <= 0 || g.OW <= 0) return MTD_EINVAL;
+    if (g.TH <= 0 || g.TW <= 0 || g.TH * g.TW > 16) return MTD_EINVAL;
+    if (geom_pixels(g) > (1ll << 30)) return MTD_EINVAL;
+    if (a.in_ld < a.C || a.out_ld < a.N || (a.in_ld % 4)) return MTD_EINVAL;
+    if (!aligned16(a.in)) return MTD_EALIGN;
+    if (a.add1 && a.add1_ld < a.N) return MTD_EINVAL;
+    if (a.add2 && a.add2_ld < a.N) return MTD_EINVAL;
+    if (a.mask && a.mask_ld < a.N) return MTD_EINVAL;
+    // the furthest output pixel must stay inside the OHF x OWF image
+    if ((g.OH - 1) * g.out_sy + g.out_oy >= g.OHF || (g.OW - 1) * g.out_sx + g.out_ox >= g.OWF) return MTD_EINVAL;
+    return MTD_OK;
+}
+
+}  // namespace
+
+extern "C" size_t mtd_conv_igemm_ws_bytes(const mtd_conv_args* a) {
+    if (!a || check_args(*a) != MTD_OK) return 0;
+    Plan pl = make_plan(*a);
+    if (pl.splitk <= 1) return 0;
+    return (size_t)pl.splitk * (size_t)geom_pixels(a->g) * a->N * sizeof(float);
+}
+
+extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
+    if (!a) return MTD_EINVAL;
+    int rc = check_args(*a);
+    if (rc != MTD_OK) return rc;
+    Plan pl = make_plan(*a);
+    IgemmParams p;
+    p.a = *a;
+    p.M = (int)geom_pixels(a->g);
+    p.splitk = pl.splitk;
+    p.c_per_split = pl.c_per_split;
+    p.b_cfast = (a->w_sc < a->w_sn) ? 1 : 0;
+    const mtd_geom& g = a->g;
+    p.out_identity = (g.out_sy == 1 && g.out_sx == 1 && g.out_oy == 0 && g.out_ox == 0 && g.OHF == g.OH && g.OWF == g.OW);
+    if (pl.splitk > 1) {
+        size_t need = (size_t)pl.splitk * (size_t)p.M * a->N * sizeof(float);
+        if (!a->ws || a->ws_bytes < need) return MTD_EWS;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((p.M + pl.BM - 1) / pl.BM, a->N / pl.BN, pl.splitk);
+    switch (pl.cfg) {
+        case 0: hipLaunchKernelGGL((igemm_kernel<2, 1, 4, 1>), grid, dim3(256), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((igemm_kernel<1, 1, 4, 1>), grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((igemm_kernel<2, 2, 4, 1>), grid, dim3(256), 0, s, p); break;
+        case 3: hipLaunchKernelGGL((igemm_kernel<1, 1, 2, 2>), grid, dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((igemm_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL((igemm_kernel<1, 1, 1, 4>), grid, dim3(256), 0, s, p); break;
+    }
+    MTD_LAUNCH_CHECK();
+    if (pl.splitk > 1) {
+        long long total = (long long)p.M * a->N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, p);
+        MTD_LAUNCH_CHECK();
+    }
+    return MTD_OK;
+}

@@ -1,0 +1,358 @@
+// Weight-gradient of a convolution on fp32 MFMA for gfx950.
+//
+//   dW(n, c, tap) (+)= sum_pix P[pix, n] * Q[gather(pix, tap), c]        db[n] (+)= sum_pix P[pix, n]
+//
+// GEMM view: output (N x C) per tap, reduction over M = B*OH*OW pixels.  With NHWC tensors both MFMA
+// operands are read in their natural order (lane = channel, k = pixel), so LDS tiles are straight
+// copies of 32-pixel row groups: P tile [32 px][32*WN], Q tile [32 px][32*WC] gathered per tap with
+// zero fill.  A wave owns a (32*WN x 32*WC) output block for up to TG taps (accumulators stay in
+// registers across its whole pixel range) and the four waves of a workgroup split the pixel range;
+// they are summed through LDS at the end, so one slab per workgroup goes to the workspace.  Slabs are
+// then summed in a fixed order by reduce kernels (deterministic) which also scatter into the
+// OIHW / IOHW strided view of the parameter gradient.  db falls out of the A-operand registers.
+//
+// Roofline: fp32 MFMA.  Algorithmic flops = 2*M*N*C*taps.
+#include "common.h"
+
+namespace {
+
+struct WgradParams {
+    mtd_wgrad_args a;
+    int M;          // pixels
+    int ppw;        // pixels per wave (multiple of 32)
+    int nCt;        // number of c tiles
+    int T;          // taps
+    int nslab;
+    long long slab_stride;   // floats per slab = T*N*C + N
+};
+
+template <int WN, int WC, int TG>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+    constexpr int PLD = 32 * WN, QLD = 32 * WC;
+    constexpr int UP = 4 * WN, UQ = 4 * WC;   // float4 units staged per lane
+    constexpr int WAVE_FLOATS = 32 * (PLD + QLD);
+    __shared__ __attribute__((aligned(16))) float Ls[4 * WAVE_FLOATS];
+
+    const mtd_wgrad_args& a = p.a;
+    const mtd_geom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int ntile = blockIdx.y / p.nCt, ctile = blockIdx.y % p.nCt;
+    const int n0 = ntile * 32 * WN, c0 = ctile * 32 * WC;
+    const int tap0 = blockIdx.z * TG;
+    const int ntap = min(TG, p.T - tap0);
+    float* Ps = Ls + wave * WAVE_FLOATS;
+    float* Qs = Ps + 32 * PLD;
+    const int mwave0 = (blockIdx.x * 4 + wave) * p.ppw;
+    const bool do_bias = (a.db != nullptr) && ctile == 0 && blockIdx.z == 0;
+
+    f32x16 acc[TG][WN][WC];
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int c = 0; c < WC; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][j][c][e] = 0.f;
+    float bsum[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) bsum[j] = 0.f;
+
+    for (int mc = 0; mc < p.ppw; mc += 32) {
+        const int mbase = mwave0 + mc;
+        // ---- P tile (rows = pixels mbase..mbase+31, identity pixel mapping)
+        f32x4 pv[UP];
+#pragma unroll
+        for (int i = 0; i < UP; ++i) {
+            int u = lane + 64 * i;
+            int row = u / (8 * WN), quad = u % (8 * WN);
+            int m = mbase + row;
+            if (m < p.M) pv[i] = *reinterpret_cast<const f32x4*>(a.p + (long long)m * a.p_ld + n0 + 4 * quad);
+            else pv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // ---- launch-grid coordinates of the Q rows this lane stages
+        int qb[UQ], qy[UQ], qx[UQ];
+#pragma unroll
+        for (int i = 0; i < UQ; ++i) {
+            int u = lane + 64 * i;
+            int row = u / (8 * WC);
+            int m = mbase + row;
+            if (m < p.M) {
+                int ox = m % g.OW;
+                int t2 = m / g.OW;
+                int oy = t2 % g.OH;
+                qb[i] = t2 / g.OH;
+                qy[i] = oy * g.in_sy + g.off_y;
+                qx[i] = ox * g.in_sx + g.off_x;
+            } else {
+                qb[i] = 0;
+                qy[i] = -(1 << 28);
+                qx[i] = -(1 << 28);
+            }
+        }
+        auto loadq = [&](int tap, f32x4 (&qv)[UQ]) {
+            int ty = tap / g.TW, tx = tap % g.TW;
+#pragma unroll
+            for (int i = 0; i < UQ; ++i) {
+                int u = lane + 64 * i;
+                int quad = u % (8 * WC);
+                int iy = qy[i] + ty * g.tap_dy, ix = qx[i] + tx * g.tap_dx;
+                bool ok = ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
+                if (ok) qv[i] = *reinterpret_cast<const f32x4*>(a.q + (((long long)qb[i] * g.IH + iy) * g.IW + ix) * a.q_ld + c0 + 4 * quad);
+                else qv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        f32x4 qv[UQ];
+        loadq(tap0, qv);
+        __syncthreads();   // previous chunk's MFMA reads are done
+#pragma unroll
+        for (int i = 0; i < UP; ++i) {
+            int u = lane + 64 * i;
+            *reinterpret_cast<f32x4*>(Ps + 4 * u) = pv[i];   // row*(32*WN) + 4*quad == 4*u
+        }
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+            if (t < ntap) {
+#pragma unroll
+                for (int i = 0; i < UQ; ++i) {
+                    int u = lane + 64 * i;
+                    *reinterpret_cast<f32x4*>(Qs + 4 * u) = qv[i];
+                }
+                __syncthreads();
+                if (t + 1 < ntap) loadq(tap0 + t + 1, qv);
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {
+                    const int k = 2 * kk + kh;
+                    float af[WN], bf[WC];
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) af[j] = Ps[k * PLD + j * 32 + l31];
+#pragma unroll
+                    for (int c = 0; c < WC; ++c) bf[c] = Qs[k * QLD + c * 32 + l31];
+                    if (t == 0) {
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) bsum[j] += af[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+#pragma unroll
+                        for (int c = 0; c < WC; ++c) acc[t][j][c] = mfma32(af[j], bf[c], acc[t][j][c]);
+                }
+                __syncthreads();   // Q tile free for the next tap
+            }
+        }
+    }
+
+    // ---- sum the four waves through LDS (tile by tile), wave 0 writes the workgroup's slab
+    float* slab = a.ws + (long long)blockIdx.x * p.slab_stride;
+    float* red = Ls;   // 3 * 1024 floats
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+        if (t < ntap) {
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int c = 0; c < WC; ++c) {
+                    __syncthreads();
+                    if (wave > 0) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) red[(wave - 1) * 1024 + e * 64 + lane] = acc[t][j][c][e];
+                    }
+                    __syncthreads();
+                    if (wave == 0) {
+                        const int tap = tap0 + t;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            float v = acc[t][j][c][e] + red[e * 64 + lane] + red[1024 + e * 64 + lane] + red[2048 + e * 64 + lane];
+                            int n = n0 + j * 32 + mfma32_row(e, lane);
+                            int cc = c0 + c * 32 + l31;
+                            slab[((long long)tap * a.N + n) * a.C + cc] = v;
+                        }
+                    }
+                }
+        }
+    }
+    if (do_bias) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < WN; ++j) red[(wave * WN + j) * 64 + lane] = bsum[j];
+        __syncthreads();
+        if (wave == 0 && lane < 32) {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                float s = 0.f;
+                for (int w = 0; w < 4; ++w) s += red[(w * WN + j) * 64 + lane] + red[(w * WN + j) * 64 + lane + 32];
+                slab[(long long)p.T * a.N * a.C + n0 + j * 32 + lane] = s;
+            }
+        }
+    }
+}
+
+// out[g][idx] = sum_{s in group g} in[s][idx]     (group size gs), fixed order
+__global__ __launch_bounds__(256) void slab_group_sum_kernel(const float* in, float* out, int nslab, int gs, long long count,
+                                                             long long stride_in, long long stride_out) {
+    const int grp = blockIdx.y;
+    const int s0 = grp * gs, s1 = min(nslab, s0 + gs);
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < count; idx += (long long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = s0; k < s1; ++k) s += in[(long long)k * stride_in + idx];
+        out[(long long)grp * stride_out + idx] = s;
+    }
+}
+
+// final: sum <= gs slabs and scatter into the strided weight-gradient view (+ bias gradient)
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const WgradParams p, const float* in, int nslab, long long stride_in) {
+    const mtd_wgrad_args& a = p.a;
+    const mtd_geom& g = a.g;
+    const long long nw = (long long)p.T * a.N * a.C;
+    const long long count = nw + (a.db ? a.N : 0);
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < count; idx += (long long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < nslab; ++k) s += in[(long long)k * stride_in + idx];
+        if (idx < nw) {
+            int c = (int)(idx % a.C);
+            long long t2 = idx / a.C;
+            int n = (int)(t2 % a.N);
+            int tap = (int)(t2 / a.N);
+            int ty = tap / g.TW, tx = tap % g.TW;
+            int kidx = (g.ky0 + ty * g.ky_step) * g.KW + (g.kx0 + tx * g.kx_step);
+            float* dst = a.dw + (long long)n * a.w_sn + (long long)c * a.w_sc + kidx;
+            *dst = (a.accumulate & 1) ? (*dst + s) : s;
+        } else {
+            float* dst = a.db + (idx - nw);
+            *dst = (a.accumulate & 2) ? (*dst + s) : s;
+        }
+    }
+}
+
+struct WPlan { int cfg, WN, WC, TG, ppw, nsplit, ntg; };
+
+WPlan make_wplan(const mtd_wgrad_args& a) {
+    WPlan pl{};
+    const int T = a.g.TH * a.g.TW;
+    const long long M = geom_pixels(a.g);
+    if (T == 1 && a.N % 64 == 0 && a.C % 64 == 0) { pl.cfg = 2; pl.WN = 2; pl.WC = 2; pl.TG = 1; }
+    else if (T <= 4) { pl.cfg = 1; pl.WN = 1; pl.WC = 1; pl.TG = 4; }
+    else if (T <= 9) { pl.cfg = 0; pl.WN = 1; pl.WC = 1; pl.TG = 9; }
+    else { pl.cfg = 3; pl.WN = 1; pl.WC = 1; pl.TG = 8; }
+    pl.ntg = (T + pl.TG - 1) / pl.TG;
+    long long tiles = (long long)(a.N / (32 * pl.WN)) * (a.C / (32 * pl.WC)) * pl.ntg;
+    // aim for >= 512 workgroups; every wave gets a multiple of 32 pixels
+    long long want_splits = (512 + tiles - 1) / tiles;
+    long long max_splits = (M + 127) / 128;             // at least 32 px per wave
+    long long ns = want_splits < 1 ? 1 : want_splits;
+    if (ns > max_splits) ns = max_splits;
+    long long ppw = (M + ns * 4 - 1) / (ns * 4);
+    ppw = ((ppw + 31) / 32) * 32;
+    ns = (M + ppw * 4 - 1) / (ppw * 4);
+    pl.ppw = (int)ppw;
+    pl.nsplit = (int)ns;
+    return pl;
+}
+
+bool is_direct(const mtd_wgrad_args& a) { return (a.N % 32) || (a.C % 32); }
+
+int check_wargs(const mtd_wgrad_args& a) {
+    if (!a.p || !a.q || !a.dw) return MTD_EINVAL;
+    if (a.N <= 0 || a.C <= 0) return MTD_EINVAL;
+    if (is_direct(a)) {
+        if (a.N != 1 && a.C != 1) return MTD_EINVAL;
+        const mtd_geom& g = a.g;
+        if (g.B <= 0 || g.TH <= 0 || g.TW <= 0 || g.TH * g.TW > 16) return MTD_EINVAL;
+        if (a.p_ld < a.N || a.q_ld < a.C) return MTD_EINVAL;
+        return MTD_OK;
+    }
+    const mtd_geom& g = a.g;
+    if (g.B <= 0 || g.IH <= 0 || g.IW <= 0 || g.OH <= 0 || g.OW <= 0) return MTD_EINVAL;
+    if (g.TH <= 0 || g.TW <= 0 || g.TH * g.TW > 16) return MTD_EINVAL;
+    if (geom_pixels(g) > (1ll << 30)) return MTD_EINVAL;
+    if (a.p_ld < a.N || a.q_ld < a.C || (a.p_ld % 4) || (a.q_ld % 4)) return MTD_EINVAL;
+    if (!aligned16(a.p) || !aligned16(a.q)) return MTD_EALIGN;
+    return MTD_OK;
+}
+
+constexpr int GS = 32;   // slabs summed per reduce stage
+
+size_t wgrad_ws_floats(const mtd_wgrad_args& a, int nsplit) {
+    const long long T = a.g.TH * a.g.TW;
+    const long long stride = T * a.N * a.C + a.N;
+    long long total = (long long)nsplit * stride;
+    long long ns = nsplit;
+    while (ns > GS) {           // intermediate stages
+        ns = (ns + GS - 1) / GS;
+        total += ns * stride;
+    }
+    return (size_t)total;
+}
+
+}  // namespace
+
+int mtd_direct_wgrad_launch(const mtd_wgrad_args* a, int* nslab_out, long long slab_stride, void* stream);
+int mtd_direct_wgrad_nslab(const mtd_wgrad_args* a);
+
+extern "C" size_t mtd_conv_wgrad_ws_bytes(const mtd_wgrad_args* a) {
+    if (!a || check_wargs(*a) != MTD_OK) return 0;
+    if (is_direct(*a)) return wgrad_ws_floats(*a, mtd_direct_wgrad_nslab(a)) * sizeof(float);
+    WPlan pl = make_wplan(*a);
+    return wgrad_ws_floats(*a, pl.nsplit) * sizeof(float);
+}
+
+extern "C" int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream) {
+    if (!a) return MTD_EINVAL;
+    int rc = check_wargs(*a);
+    if (rc != MTD_OK) return rc;
+    const bool direct = is_direct(*a);
+    WPlan pl{};
+    int nsplit;
+    if (direct) nsplit = mtd_direct_wgrad_nslab(a);
+    else { pl = make_wplan(*a); nsplit = pl.nsplit; }
+    if (!a->ws || a->ws_bytes < wgrad_ws_floats(*a, nsplit) * sizeof(float)) return MTD_EWS;
+    WgradParams p;
+    p.a = *a;
+    p.M = (int)geom_pixels(a->g);
+    p.T = a->g.TH * a->g.TW;
+    p.nslab = nsplit;
+    p.slab_stride = (long long)p.T * a->N * a->C + a->N;
+    hipStream_t s = (hipStream_t)stream;
+    if (direct) {
+        p.ppw = 0;
+        p.nCt = 1;
+        int ns2 = 0;
+        rc = mtd_direct_wgrad_launch(a, &ns2, p.slab_stride, stream);
+        if (rc != MTD_OK) return rc;
+        if (ns2 != nsplit) return MTD_EINVAL;
+    } else {
+        p.ppw = pl.ppw;
+        p.nCt = a->C / (32 * pl.WC);
+        dim3 grid(pl.nsplit, (a->N / (32 * pl.WN)) * p.nCt, pl.ntg);
+        switch (pl.cfg) {
+            case 0: hipLaunchKernelGGL((wgrad_kernel<1, 1, 9>), grid, dim3(256), 0, s, p); break;
+            case 1: hipLaunchKernelGGL((wgrad_kernel<1, 1, 4>), grid, dim3(256), 0, s, p); break;
+            case 2: hipLaunchKernelGGL((wgrad_kernel<2, 2, 1>), grid, dim3(256), 0, s, p); break;
+            default: hipLaunchKernelGGL((wgrad_kernel<1, 1, 8>), grid, dim3(256), 0, s, p); break;
+        }
+        MTD_LAUNCH_CHECK();
+    }
+    // staged, order-fixed reduction of the slabs
+    const float* cur = a->ws;
+    int ns = nsplit;
+    float* next = a->ws + (long long)ns * p.slab_stride;
+    const long long count = p.slab_stride;
+    while (ns > GS) {
+        int ng = (ns + GS - 1) / GS;
+        int bx = (int)((count + 255) / 256);
+        if (bx > 1024) bx = 1024;
+        hipLaunchKernelGGL(slab_group_sum_kernel, dim3(bx, ng), dim3(256), 0, s, cur, next, ns, GS, count, p.slab_stride, p.slab_stride);
+        MTD_LAUNCH_CHECK();
+        cur = next;
+        next = next + (long long)ng * p.slab_stride;
+        ns = ng;
+    }
+    {
+        int bx = (int)((count + 255) / 256);
+        if (bx > 2048) bx = 2048;
+        hipLaunchKernelGGL(wgrad_finish_kernel, dim3(bx), dim3(256), 0, s, p, cur, ns, p.slab_stride);
+        MTD_LAUNCH_CHECK();
+    }
+    return MTD_OK;
+}

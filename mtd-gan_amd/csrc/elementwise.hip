@@ -1,0 +1,223 @@
+// HBM-bound element-wise kernels of the MTD-GAN step: activation-gradient masks, channel-slice copies
+// (torch.cat / chunk at networks.py:421-465), bilinear x2 up-sampling (nn.Upsample, align_corners =
+// False) with its adjoint, PixelShuffle(2) with its adjoint.  All NHWC with explicit leading
+// dimensions; lanes run over channels so every access is a contiguous run of the pixel's channels
+// (16 B per lane where channel counts allow).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void act_grad_kernel(const float* __restrict__ g, int g_ld, const float* __restrict__ y, int y_ld,
+                                                       float* __restrict__ out, int out_ld, long long total, int C, float slope) {
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long p = idx / C;
+        const int c = (int)(idx % C);
+        const float gv = g[p * g_ld + c];
+        out[p * out_ld + c] = y[p * y_ld + c] > 0.f ? gv : gv * slope;
+    }
+}
+
+__global__ __launch_bounds__(256) void act_grad4_kernel(const float* __restrict__ g, int g_ld, const float* __restrict__ y, int y_ld,
+                                                        float* __restrict__ out, int out_ld, long long total4, int C4, float slope) {
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long long)gridDim.x * 256) {
+        const long long p = idx / C4;
+        const int c = (int)(idx % C4) * 4;
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + p * g_ld + c);
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + p * y_ld + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = yv[e] > 0.f ? gv[e] : gv[e] * slope;
+        *reinterpret_cast<f32x4*>(out + p * out_ld + c) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ a, int a_ld, float* __restrict__ out, int out_ld,
+                                                            long long total, int C, int accumulate) {
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long p = idx / C;
+        const int c = (int)(idx % C);
+        const float v = a[p * a_ld + c];
+        float* d = out + p * out_ld + c;
+        *d = accumulate ? *d + v : v;
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_channels4_kernel(const float* __restrict__ a, int a_ld, float* __restrict__ out, int out_ld,
+                                                             long long total4, int C4, int accumulate) {
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long long)gridDim.x * 256) {
+        const long long p = idx / C4;
+        const int c = (int)(idx % C4) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(a + p * a_ld + c);
+        f32x4* d = reinterpret_cast<f32x4*>(out + p * out_ld + c);
+        if (accumulate) {
+            f32x4 o = *d;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += o[e];
+        }
+        *d = v;
+    }
+}
+
+// bilinear x2, align_corners=False: out[2i] = .25 in[i-1] + .75 in[i], out[2i+1] = .75 in[i] + .25 in[i+1], clamped
+__device__ __forceinline__ void up_src(int o, int n, int& i0, int& i1, float& w0, float& w1) {
+    const int i = o >> 1;
+    if (o & 1) { i0 = i; i1 = min(i + 1, n - 1); w0 = 0.75f; w1 = 0.25f; }
+    else { i0 = max(i - 1, 0); i1 = i; w0 = 0.25f; w1 = 0.75f; }
+}
+
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __restrict__ in, int in_ld, float* __restrict__ out, int out_ld,
+                                                             int B, int H, int W, int C) {
+    const long long total = (long long)B * 2 * H * 2 * W * C;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        long long t = idx / C;
+        const int ox = (int)(t % (2 * W));
+        t /= 2 * W;
+        const int oy = (int)(t % (2 * H));
+        const int b = (int)(t / (2 * H));
+        int y0, y1, x0, x1;
+        float wy0, wy1, wx0, wx1;
+        up_src(oy, H, y0, y1, wy0, wy1);
+        up_src(ox, W, x0, x1, wx0, wx1);
+        const float* base = in + (long long)b * H * W * in_ld + c;
+        const float v00 = base[((long long)y0 * W + x0) * in_ld], v01 = base[((long long)y0 * W + x1) * in_ld];
+        const float v10 = base[((long long)y1 * W + x0) * in_ld], v11 = base[((long long)y1 * W + x1) * in_ld];
+        out[(((long long)b * 2 * H + oy) * 2 * W + ox) * out_ld + c] = wy0 * (wx0 * v00 + wx1 * v01) + wy1 * (wx0 * v10 + wx1 * v11);
+    }
+}
+
+// adjoint: gin[i] = sum over the (<= 4 per axis) outputs that read i.  Gather form => deterministic.
+__device__ __forceinline__ int up_adj(int i, int n, int (&o)[4], float (&w)[4]) {
+    // outputs reading input i:  o=2i (w .75), o=2i+1 (w .75), o=2i+2 (w .25, via i0=i), o=2i-1 (w .25, via i1=i)
+    // plus the clamped edges: o=0 reads in[0] with extra .25, o=2n-1 reads in[n-1] with extra .25
+    int k = 0;
+    o[k] = 2 * i; w[k++] = 0.75f;
+    o[k] = 2 * i + 1; w[k++] = 0.75f;
+    if (i + 1 <= n - 1) { o[k] = 2 * i + 2; w[k++] = 0.25f; } else { o[k] = 2 * i + 1; w[k++] = 0.25f; }   // clamp at the end
+    if (i - 1 >= 0) { o[k] = 2 * i - 1; w[k++] = 0.25f; } else { o[k] = 0; w[k++] = 0.25f; }                  // clamp at the start
+    return k;
+}
+
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ gout, int gout_ld, float* __restrict__ gin, int gin_ld,
+                                                             int B, int H, int W, int C) {
+    const long long total = (long long)B * H * W * C;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        long long t = idx / C;
+        const int x = (int)(t % W);
+        t /= W;
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        int oy[4], ox[4];
+        float wy[4], wx[4];
+        const int ny = up_adj(y, H, oy, wy), nx = up_adj(x, W, ox, wx);
+        const float* base = gout + (long long)b * 4 * H * W * gout_ld + c;
+        float s = 0.f;
+        for (int i = 0; i < ny; ++i) {
+            float r = 0.f;
+            for (int j = 0; j < nx; ++j) r += wx[j] * base[((long long)oy[i] * 2 * W + ox[j]) * gout_ld];
+            s += wy[i] * r;
+        }
+        gin[(((long long)b * H + y) * W + x) * gin_ld + c] = s;
+    }
+}
+
+// PixelShuffle(2): out[b, 2h+i, 2w+j, c] = in[b, h, w, 4c + 2i + j]
+__global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const float* __restrict__ src, int src_ld, float* __restrict__ dst, int dst_ld,
+                                                             int B, int H, int W, int C, int inverse) {
+    const long long total = (long long)B * 2 * H * 2 * W * C;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        long long t = idx / C;
+        const int ox = (int)(t % (2 * W));
+        t /= 2 * W;
+        const int oy = (int)(t % (2 * H));
+        const int b = (int)(t / (2 * H));
+        const long long big = (((long long)b * 2 * H + oy) * 2 * W + ox);           // pixel in the 2H x 2W image
+        const long long small = (((long long)b * H + (oy >> 1)) * W + (ox >> 1));  // pixel in the H x W image
+        const int cs = 4 * c + 2 * (oy & 1) + (ox & 1);
+        if (!inverse) dst[big * dst_ld + c] = src[small * src_ld + cs];
+        else dst[small * dst_ld + cs] = src[big * src_ld + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = a[i] * b[i];
+}
+
+inline unsigned grid_for(long long n) {
+    long long b = (n + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int mtd_act_grad(const float* g, int g_ld, const float* y, int y_ld, float* out, int out_ld, long long npix, int C,
+                            float slope, void* stream) {
+    if (!g || !y || !out || npix <= 0 || C <= 0 || g_ld < C || y_ld < C || out_ld < C) return MTD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if ((C % 4 == 0) && (g_ld % 4 == 0) && (y_ld % 4 == 0) && (out_ld % 4 == 0) && aligned16(g) && aligned16(y) && aligned16(out)) {
+        long long total4 = npix * (C / 4);
+        hipLaunchKernelGGL(act_grad4_kernel, dim3(grid_for(total4)), dim3(256), 0, s, g, g_ld, y, y_ld, out, out_ld, total4, C / 4, slope);
+    } else {
+        long long total = npix * C;
+        hipLaunchKernelGGL(act_grad_kernel, dim3(grid_for(total)), dim3(256), 0, s, g, g_ld, y, y_ld, out, out_ld, total, C, slope);
+    }
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_mul(const float* a, const float* b, float* out, long long n, void* stream) {
+    if (!a || !b || !out || n <= 0) return MTD_EINVAL;
+    hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_copy_channels(const float* a, int a_ld, float* out, int out_ld, long long npix, int C, int accumulate, void* stream) {
+    if (!a || !out || npix <= 0 || C <= 0 || a_ld < C || out_ld < C) return MTD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if ((C % 4 == 0) && (a_ld % 4 == 0) && (out_ld % 4 == 0) && aligned16(a) && aligned16(out)) {
+        long long total4 = npix * (C / 4);
+        hipLaunchKernelGGL(copy_channels4_kernel, dim3(grid_for(total4)), dim3(256), 0, s, a, a_ld, out, out_ld, total4, C / 4, accumulate);
+    } else {
+        long long total = npix * C;
+        hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(total)), dim3(256), 0, s, a, a_ld, out, out_ld, total, C, accumulate);
+    }
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_upsample2x_fwd(const float* in, int in_ld, float* out, int out_ld, int B, int H, int W, int C, void* stream) {
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || in_ld < C || out_ld < C) return MTD_EINVAL;
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for((long long)B * 4 * H * W * C)), dim3(256), 0, (hipStream_t)stream, in, in_ld,
+                       out, out_ld, B, H, W, C);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_upsample2x_bwd(const float* gout, int gout_ld, float* gin, int gin_ld, int B, int H, int W, int C, void* stream) {
+    if (!gout || !gin || B <= 0 || H <= 0 || W <= 0 || C <= 0 || gout_ld < C || gin_ld < C) return MTD_EINVAL;
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((long long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, gout, gout_ld,
+                       gin, gin_ld, B, H, W, C);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_pixel_shuffle2_fwd(const float* in, int in_ld, float* out, int out_ld, int B, int H, int W, int C, void* stream) {
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || in_ld < 4 * C || out_ld < C) return MTD_EINVAL;
+    hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(grid_for((long long)B * 4 * H * W * C)), dim3(256), 0, (hipStream_t)stream, in, in_ld,
+                       out, out_ld, B, H, W, C, 0);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_pixel_shuffle2_bwd(const float* gout, int gout_ld, float* gin, int gin_ld, int B, int H, int W, int C, void* stream) {
+    if (!gout || !gin || B <= 0 || H <= 0 || W <= 0 || C <= 0 || gout_ld < C || gin_ld < 4 * C) return MTD_EINVAL;
+    hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(grid_for((long long)B * 4 * H * W * C)), dim3(256), 0, (hipStream_t)stream, gout,
+                       gout_ld, gin, gin_ld, B, H, W, C, 1);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}

@@ -1,0 +1,469 @@
+// Spectral path of the Res-FFT-Conv block (arch/Ours/networks.py:21-30) for 64x64 patches, 32 ch.
+//
+//   y = irfft2( relu( W2 . [Re;Im] rfft2(x) + b2 ) ),  ortho normalisation both ways.
+//
+// The 2-D transform is split so that the channel mix -- which needs all 64 [Re;Im] channels of one
+// frequency -- sits between the two column transforms of ONE kernel:
+//   mtd_rfft_rows     rows  : real FFT along W.        x[B][64][64][32] -> R[B][33 kw][64 h][2][32]
+//   mtd_spec_mix_fwd  cols  : FFT along H, 64x64 channel mix on fp32 MFMA (+bias, ReLU), IFFT along H.
+//   mtd_irfft_rows    rows  : c2r along W (+ residual / conv-branch adds fused into the store).
+// With NHWC data the 32 channels of a pixel are contiguous, so a lane owns one channel and performs a
+// whole 64-point transform in registers (radix-2 DIF, fully unrolled, twiddles are immediates): no
+// LDS exchange, no shuffles, and every global access is a 128-byte row of channels.  Two real rows
+// are packed into one complex transform.  LDS is used only to re-shape spectra into MFMA operands.
+// The backward pass reuses the same three kernels' structure:
+//   irfft2 backward = w(kw) * rfft2(g)   (w = 1,2,...,2,1)      -> mtd_rfft_rows(col_weight=1)
+//   rfft2  backward = c2r with columns 1..31 halved             -> halving folded into mtd_spec_mix_bwd
+//
+// Rooflines: rows kernels are HBM-bound (read 16 MiB + write 16.5 MiB per 32 patches);
+// the column/mix kernel is fp32-MFMA-bound (2*64*64 flops per frequency) with VALU FFTs beside it.
+#include "common.h"
+
+namespace {
+
+__device__ __constant__ const float COS64[32] = {
+    1.f, 0.995184727f, 0.98078528f, 0.956940336f, 0.923879533f, 0.881921264f, 0.831469612f, 0.773010453f,
+    0.707106781f, 0.634393284f, 0.555570233f, 0.471396737f, 0.382683432f, 0.290284677f, 0.195090322f, 0.0980171403f,
+    0.f, -0.0980171403f, -0.195090322f, -0.290284677f, -0.382683432f, -0.471396737f, -0.555570233f, -0.634393284f,
+    -0.707106781f, -0.773010453f, -0.831469612f, -0.881921264f, -0.923879533f, -0.956940336f, -0.98078528f, -0.995184727f};
+__device__ __constant__ const float SIN64[32] = {
+    0.f, 0.0980171403f, 0.195090322f, 0.290284677f, 0.382683432f, 0.471396737f, 0.555570233f, 0.634393284f,
+    0.707106781f, 0.773010453f, 0.831469612f, 0.881921264f, 0.923879533f, 0.956940336f, 0.98078528f, 0.995184727f,
+    1.f, 0.995184727f, 0.98078528f, 0.956940336f, 0.923879533f, 0.881921264f, 0.831469612f, 0.773010453f,
+    0.707106781f, 0.634393284f, 0.555570233f, 0.471396737f, 0.382683432f, 0.290284677f, 0.195090322f, 0.0980171403f};
+
+__host__ __device__ constexpr int brev6(int k) {
+    return ((k & 1) << 5) | ((k & 2) << 3) | ((k & 4) << 1) | ((k & 8) >> 1) | ((k & 16) >> 3) | ((k & 32) >> 5);
+}
+
+// In-place 64-point complex DFT, X[k] = sum_n x[n] e^{SIGN * 2 pi i k n / 64}, unnormalised.
+// Radix-2 decimation in frequency: the result for frequency k is left at index brev6(k).
+template <int SIGN>
+__device__ __forceinline__ void fft64(float (&re)[64], float (&im)[64]) {
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int half = 32 >> s;
+        const int tstep = 1 << s;
+#pragma unroll
+        for (int blk = 0; blk < 64; blk += 2 * half) {
+#pragma unroll
+            for (int j = 0; j < half; ++j) {
+                const int i0 = blk + j, i1 = i0 + half;
+                const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+                re[i0] = ar + br;
+                im[i0] = ai + bi;
+                const float dr = ar - br, di = ai - bi;
+                const int tw = j * tstep;
+                if (tw == 0) {
+                    re[i1] = dr;
+                    im[i1] = di;
+                } else if (tw == 16) {
+                    if (SIGN < 0) { re[i1] = di; im[i1] = -dr; }
+                    else { re[i1] = -di; im[i1] = dr; }
+                } else {
+                    const float c = COS64[tw];
+                    const float sn = (SIGN < 0) ? -SIN64[tw] : SIN64[tw];
+                    re[i1] = dr * c - di * sn;
+                    im[i1] = dr * sn + di * c;
+                }
+            }
+        }
+    }
+}
+
+constexpr int NKW = 33;
+constexpr int XLD = 65;   // LDS row stride (floats) of the [frequency][64 channel] operand image
+
+// ---------------------------------------------------------------------------------------------
+// rows forward: two image rows (h, h+1) of one channel per thread
+__global__ __launch_bounds__(256) void rfft_rows_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ R,
+                                                        int npairs, int col_weight) {
+    const int c = threadIdx.x & 31;
+    const int pair = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (pair >= npairs) return;
+    const int b = pair >> 5, h = (pair & 31) * 2;
+    float re[64], im[64];
+    const float* r0 = x + ((long long)(b * 64 + h) * 64) * x_ld + c;
+    const float* r1 = r0 + (long long)64 * x_ld;
+#pragma unroll
+    for (int w = 0; w < 64; ++w) {
+        re[w] = r0[(long long)w * x_ld];
+        im[w] = r1[(long long)w * x_ld];
+    }
+    fft64<-1>(re, im);
+    float* o0 = R + ((long long)(b * NKW) * 64 + h) * 64 + c;
+#pragma unroll
+    for (int kw = 0; kw <= 32; ++kw) {
+        const int km = (64 - kw) & 63;
+        const float zkr = re[brev6(kw)], zki = im[brev6(kw)];
+        const float zmr = re[brev6(km)], zmi = im[brev6(km)];
+        float sc = 0.125f * 0.5f;
+        if (col_weight && kw != 0 && kw != 32) sc *= 2.f;
+        const float ar = (zkr + zmr) * sc, ai = (zki - zmi) * sc;      // row h   : (Z[k] + conj Z[-k]) / 2
+        const float br = (zki + zmi) * sc, bi = (zmr - zkr) * sc;      // row h+1 : (Z[k] - conj Z[-k]) / 2i
+        float* o = o0 + (long long)kw * 64 * 64;
+        o[0] = ar;
+        o[32] = ai;
+        o[64] = br;
+        o[64 + 32] = bi;
+    }
+}
+
+// rows backward (c2r): two rows per thread, fused epilogue
+__global__ __launch_bounds__(256) void irfft_rows_kernel(const float* __restrict__ T, float* __restrict__ out, int out_ld,
+                                                         const float* __restrict__ add1, int add1_ld,
+                                                         const float* __restrict__ add2, int add2_ld,
+                                                         const float* __restrict__ mask, int mask_ld, int npairs) {
+    const int c = threadIdx.x & 31;
+    const int pair = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (pair >= npairs) return;
+    const int b = pair >> 5, h = (pair & 31) * 2;
+    float re[64], im[64];
+    const float* t0 = T + ((long long)(b * NKW) * 64 + h) * 64 + c;
+#pragma unroll
+    for (int kw = 0; kw <= 32; ++kw) {
+        const float* t = t0 + (long long)kw * 64 * 64;
+        const float ar = t[0], ai = t[32], br = t[64], bi = t[64 + 32];
+        if (kw == 0 || kw == 32) {
+            re[kw] = ar;       // imaginary parts of columns 0 and W/2 are ignored by c2r
+            im[kw] = br;
+        } else {
+            re[kw] = ar - bi;
+            im[kw] = ai + br;
+            re[64 - kw] = ar + bi;
+            im[64 - kw] = br - ai;
+        }
+    }
+    fft64<+1>(re, im);
+    const long long p0 = (long long)(b * 64 + h) * 64;
+#pragma unroll
+    for (int w = 0; w < 64; ++w) {
+        float va = re[brev6(w)] * 0.125f, vb = im[brev6(w)] * 0.125f;
+        const long long pa = p0 + w, pb = p0 + 64 + w;
+        if (add1) { va += add1[pa * add1_ld + c]; vb += add1[pb * add1_ld + c]; }
+        if (add2) { va += add2[pa * add2_ld + c]; vb += add2[pb * add2_ld + c]; }
+        if (mask) {
+            va = mask[pa * mask_ld + c] > 0.f ? va : 0.f;
+            vb = mask[pb * mask_ld + c] > 0.f ? vb : 0.f;
+        }
+        out[pa * out_ld + c] = va;
+        out[pb * out_ld + c] = vb;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// columns + channel mix, forward.  One wave per workgroup, two kw columns per wave.
+__global__ __launch_bounds__(64) void spec_mix_fwd_kernel(const float* __restrict__ R, const float* __restrict__ w2t,
+                                                          const float* __restrict__ b2, float* __restrict__ T,
+                                                          float* __restrict__ S_save, float* __restrict__ Z_save) {
+    __shared__ float Xs[2 * 64 * XLD];
+    const int lane = threadIdx.x, kwl = lane >> 5, c = lane & 31, l31 = lane & 31, kh2 = lane >> 5;
+    const int b = blockIdx.y;
+    const int kw = 2 * blockIdx.x + kwl;
+    const bool valid = kw < NKW;
+    float re[64], im[64];
+    const long long colbase = ((long long)(b * NKW + (valid ? kw : 0)) * 64) * 64;
+    {
+        const float* src = R + colbase + c;
+#pragma unroll
+        for (int h = 0; h < 64; ++h) {
+            re[h] = valid ? src[h * 64] : 0.f;
+            im[h] = valid ? src[h * 64 + 32] : 0.f;
+        }
+    }
+    fft64<-1>(re, im);
+#pragma unroll
+    for (int kh = 0; kh < 64; ++kh) {
+        const float sr = re[brev6(kh)] * 0.125f, si = im[brev6(kh)] * 0.125f;
+        Xs[(kwl * 64 + kh) * XLD + c] = sr;
+        Xs[(kwl * 64 + kh) * XLD + 32 + c] = si;
+        if (S_save && valid) {
+            S_save[colbase + kh * 64 + c] = sr;
+            S_save[colbase + kh * 64 + 32 + c] = si;
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int k2 = 0; k2 < 2; ++k2) {
+        const int kw2 = 2 * blockIdx.x + k2;
+        if (kw2 >= NKW) break;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll 4
+        for (int kk = 0; kk < 32; ++kk) {
+            const int k = 2 * kk + kh2;
+            const float a0 = Xs[(k2 * 64 + l31) * XLD + k];
+            const float a1 = Xs[(k2 * 64 + 32 + l31) * XLD + k];
+            const float b0 = w2t[k * 64 + l31];
+            const float b1 = w2t[k * 64 + 32 + l31];
+            acc[0][0] = mfma32(a0, b0, acc[0][0]);
+            acc[0][1] = mfma32(a0, b1, acc[0][1]);
+            acc[1][0] = mfma32(a1, b0, acc[1][0]);
+            acc[1][1] = mfma32(a1, b1, acc[1][1]);
+        }
+        __syncthreads();   // all operand reads of this column's rows are done before they are overwritten
+        const long long cb2 = ((long long)(b * NKW + kw2) * 64) * 64;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int o = j * 32 + l31;
+            const float bo = b2[o];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int kh = i * 32 + mfma32_row(e, lane);
+                    const float z = acc[i][j][e] + bo;
+                    if (Z_save) Z_save[cb2 + kh * 64 + o] = z;
+                    Xs[(k2 * 64 + kh) * XLD + o] = z > 0.f ? z : 0.f;
+                }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kh = 0; kh < 64; ++kh) {
+        re[kh] = Xs[(kwl * 64 + kh) * XLD + c];
+        im[kh] = Xs[(kwl * 64 + kh) * XLD + 32 + c];
+    }
+    fft64<+1>(re, im);
+    if (valid) {
+        float* dst = T + colbase + c;
+#pragma unroll
+        for (int h = 0; h < 64; ++h) {
+            dst[h * 64] = re[brev6(h)] * 0.125f;
+            dst[h * 64 + 32] = im[brev6(h)] * 0.125f;
+        }
+    }
+}
+
+constexpr int MIX_SLAB = 64 * 64 + 128;   // dW2 partial + two db2 partial rows per workgroup
+
+// columns + channel mix, backward
+__global__ __launch_bounds__(64) void spec_mix_bwd_kernel(const float* __restrict__ gR, const float* __restrict__ w2,
+                                                          const float* __restrict__ S_save, const float* __restrict__ Z_save,
+                                                          float* __restrict__ gT, float* __restrict__ ws) {
+    __shared__ float Gs[2 * 64 * XLD];
+    const int lane = threadIdx.x, kwl = lane >> 5, c = lane & 31, l31 = lane & 31, kh2 = lane >> 5;
+    const int b = blockIdx.y;
+    const int kw = 2 * blockIdx.x + kwl;
+    const bool valid = kw < NKW;
+    float* slab = ws + ((long long)b * gridDim.x + blockIdx.x) * MIX_SLAB;
+    float re[64], im[64];
+    const long long colbase = ((long long)(b * NKW + (valid ? kw : 0)) * 64) * 64;
+    {
+        const float* src = gR + colbase + c;
+#pragma unroll
+        for (int h = 0; h < 64; ++h) {
+            re[h] = valid ? src[h * 64] : 0.f;
+            im[h] = valid ? src[h * 64 + 32] : 0.f;
+        }
+    }
+    fft64<-1>(re, im);
+    float dbr = 0.f, dbi = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 64; ++kh) {
+        float gr = re[brev6(kh)] * 0.125f, gi = im[brev6(kh)] * 0.125f;
+        const float zr = valid ? Z_save[colbase + kh * 64 + c] : 0.f;
+        const float zi = valid ? Z_save[colbase + kh * 64 + 32 + c] : 0.f;
+        gr = zr > 0.f ? gr : 0.f;
+        gi = zi > 0.f ? gi : 0.f;
+        dbr += gr;
+        dbi += gi;
+        Gs[(kwl * 64 + kh) * XLD + c] = gr;
+        Gs[(kwl * 64 + kh) * XLD + 32 + c] = gi;
+    }
+    slab[64 * 64 + kwl * 64 + c] = dbr;
+    slab[64 * 64 + kwl * 64 + 32 + c] = dbi;
+    __syncthreads();
+    f32x16 accw[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) accw[i][j][e] = 0.f;
+#pragma unroll 1
+    for (int k2 = 0; k2 < 2; ++k2) {
+        const int kw2 = 2 * blockIdx.x + k2;
+        if (kw2 >= NKW) break;
+        const long long cb2 = ((long long)(b * NKW + kw2) * 64) * 64;
+        f32x16 accd[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) accd[i][j][e] = 0.f;
+        // data gradient  gS[f][k] = sum_o gZ[f][o] W2[o][k]
+#pragma unroll 4
+        for (int kk = 0; kk < 32; ++kk) {
+            const int o = 2 * kk + kh2;
+            const float a0 = Gs[(k2 * 64 + l31) * XLD + o];
+            const float a1 = Gs[(k2 * 64 + 32 + l31) * XLD + o];
+            const float b0 = w2[o * 64 + l31];
+            const float b1 = w2[o * 64 + 32 + l31];
+            accd[0][0] = mfma32(a0, b0, accd[0][0]);
+            accd[0][1] = mfma32(a0, b1, accd[0][1]);
+            accd[1][0] = mfma32(a1, b0, accd[1][0]);
+            accd[1][1] = mfma32(a1, b1, accd[1][1]);
+        }
+        // weight gradient  dW2[o][k] += sum_f gZ[f][o] S[f][k]
+#pragma unroll 4
+        for (int kk = 0; kk < 32; ++kk) {
+            const int f = 2 * kk + kh2;
+            const float a0 = Gs[(k2 * 64 + f) * XLD + l31];
+            const float a1 = Gs[(k2 * 64 + f) * XLD + 32 + l31];
+            const float b0 = S_save[cb2 + f * 64 + l31];
+            const float b1 = S_save[cb2 + f * 64 + 32 + l31];
+            accw[0][0] = mfma32(a0, b0, accw[0][0]);
+            accw[0][1] = mfma32(a0, b1, accw[0][1]);
+            accw[1][0] = mfma32(a1, b0, accw[1][0]);
+            accw[1][1] = mfma32(a1, b1, accw[1][1]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int kh = i * 32 + mfma32_row(e, lane);
+                    Gs[(k2 * 64 + kh) * XLD + j * 32 + l31] = accd[i][j][e];
+                }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) slab[(i * 32 + mfma32_row(e, lane)) * 64 + j * 32 + l31] = accw[i][j][e];
+#pragma unroll
+    for (int kh = 0; kh < 64; ++kh) {
+        re[kh] = Gs[(kwl * 64 + kh) * XLD + c];
+        im[kh] = Gs[(kwl * 64 + kh) * XLD + 32 + c];
+    }
+    fft64<+1>(re, im);
+    if (valid) {
+        const float sc = (kw == 0 || kw == 32) ? 0.125f : 0.0625f;   // rfft2 backward: columns 1..31 halved
+        float* dst = gT + colbase + c;
+#pragma unroll
+        for (int h = 0; h < 64; ++h) {
+            dst[h * 64] = re[brev6(h)] * sc;
+            dst[h * 64 + 32] = im[brev6(h)] * sc;
+        }
+    }
+}
+
+// stage 1: out[g][idx] = sum over slabs of group g ; stage 2 (final) folds the two bias rows
+__global__ __launch_bounds__(256) void mix_slab_sum_kernel(const float* __restrict__ in, float* __restrict__ out, int nslab, int gs) {
+    const int grp = blockIdx.y;
+    const int s0 = grp * gs, s1 = min(nslab, s0 + gs);
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < MIX_SLAB; idx += gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = s0; k < s1; ++k) s += in[(long long)k * MIX_SLAB + idx];
+        out[(long long)grp * MIX_SLAB + idx] = s;
+    }
+}
+__global__ __launch_bounds__(256) void mix_finish_kernel(const float* __restrict__ in, int nslab, float* __restrict__ dw2,
+                                                         float* __restrict__ db2, int accumulate) {
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < 64 * 64 + 64; idx += gridDim.x * 256) {
+        float s = 0.f;
+        if (idx < 4096) {
+            for (int k = 0; k < nslab; ++k) s += in[(long long)k * MIX_SLAB + idx];
+            dw2[idx] = accumulate ? dw2[idx] + s : s;
+        } else {
+            const int o = idx - 4096;
+            for (int k = 0; k < nslab; ++k) s += in[(long long)k * MIX_SLAB + 4096 + o] + in[(long long)k * MIX_SLAB + 4096 + 64 + o];
+            db2[o] = accumulate ? db2[o] + s : s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose64_kernel(const float* __restrict__ src, float* __restrict__ dst) {
+    __shared__ float t[64 * 65];
+    for (int i = threadIdx.x; i < 4096; i += 256) t[(i >> 6) * 65 + (i & 63)] = src[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += 256) dst[i] = t[(i & 63) * 65 + (i >> 6)];
+}
+
+constexpr int MIX_GS = 32;
+
+}  // namespace
+
+extern "C" int mtd_rfft_rows(const float* x, int x_ld, float* R, int B, int col_weight, void* stream) {
+    if (!x || !R || B <= 0 || x_ld < 32) return MTD_EINVAL;
+    const int npairs = B * 32;
+    hipLaunchKernelGGL(rfft_rows_kernel, dim3((npairs + 7) / 8), dim3(256), 0, (hipStream_t)stream, x, x_ld, R, npairs, col_weight);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_irfft_rows(const float* T, float* out, int out_ld, const float* add1, int add1_ld, const float* add2,
+                              int add2_ld, const float* mask, int mask_ld, int B, void* stream) {
+    if (!T || !out || B <= 0 || out_ld < 32) return MTD_EINVAL;
+    if ((add1 && add1_ld < 32) || (add2 && add2_ld < 32) || (mask && mask_ld < 32)) return MTD_EINVAL;
+    const int npairs = B * 32;
+    hipLaunchKernelGGL(irfft_rows_kernel, dim3((npairs + 7) / 8), dim3(256), 0, (hipStream_t)stream, T, out, out_ld, add1, add1_ld,
+                       add2, add2_ld, mask, mask_ld, npairs);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_spec_mix_fwd(const float* R, const float* w2t, const float* b2, float* T, float* S_save, float* Z_save, int B,
+                                void* stream) {
+    if (!R || !w2t || !b2 || !T || B <= 0) return MTD_EINVAL;
+    hipLaunchKernelGGL(spec_mix_fwd_kernel, dim3(17, B), dim3(64), 0, (hipStream_t)stream, R, w2t, b2, T, S_save, Z_save);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+static size_t mix_ws_floats(int B) {
+    long long ns = (long long)B * 17;
+    long long total = ns * MIX_SLAB;
+    while (ns > MIX_GS) {
+        ns = (ns + MIX_GS - 1) / MIX_GS;
+        total += ns * MIX_SLAB;
+    }
+    return (size_t)total;
+}
+
+extern "C" size_t mtd_spec_mix_bwd_ws_bytes(int B) { return B > 0 ? mix_ws_floats(B) * sizeof(float) : 0; }
+
+extern "C" int mtd_spec_mix_bwd(const float* gR, const float* w2, const float* S_save, const float* Z_save, float* gT, float* ws,
+                                int B, void* stream) {
+    if (!gR || !w2 || !S_save || !Z_save || !gT || !ws || B <= 0) return MTD_EINVAL;
+    hipLaunchKernelGGL(spec_mix_bwd_kernel, dim3(17, B), dim3(64), 0, (hipStream_t)stream, gR, w2, S_save, Z_save, gT, ws);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_spec_mix_wgrad_reduce(const float* ws, int B, float* dw2, float* db2, int accumulate, void* stream) {
+    if (!ws || !dw2 || !db2 || B <= 0) return MTD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    int ns = B * 17;
+    const float* cur = ws;
+    float* next = const_cast<float*>(ws) + (long long)ns * MIX_SLAB;
+    while (ns > MIX_GS) {
+        int ng = (ns + MIX_GS - 1) / MIX_GS;
+        hipLaunchKernelGGL(mix_slab_sum_kernel, dim3((MIX_SLAB + 255) / 256, ng), dim3(256), 0, s, cur, next, ns, MIX_GS);
+        MTD_LAUNCH_CHECK();
+        cur = next;
+        next += (long long)ng * MIX_SLAB;
+        ns = ng;
+    }
+    hipLaunchKernelGGL(mix_finish_kernel, dim3((4096 + 64 + 255) / 256), dim3(256), 0, s, cur, ns, dw2, db2, accumulate);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_transpose64(const float* src, float* dst, void* stream) {
+    if (!src || !dst) return MTD_EINVAL;
+    hipLaunchKernelGGL(transpose64_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, src, dst);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}

@@ -1,0 +1,278 @@
+// Spectral normalisation (torch.nn.utils.spectral_norm, 1 power iteration, eps 1e-12) for all 45
+// normalised layers of the multi-task discriminator in four launches per forward, HBM-bound:
+//   t = W^T u                (column pass, coalesced over columns)        -> v = t / max(|t|, eps)
+//   s = W v                  (row pass, one wave per row)                 -> u = s / max(|s|, eps)
+//   sigma = u . s ; 1/sigma                                               (conv epilogues read 1/sigma)
+// W is weight_orig viewed as (Cout, Cin*kh*kw) -- exactly PyTorch's OIHW storage, no repack; the
+// normalised weight W/sigma is never materialised (the conv kernels scale their accumulators).
+// Reductions are staged through fixed-order partial sums => bit-reproducible u, v, sigma.
+// Backward:  g_orig = G/sigma - <G, W>/sigma^2 * u v^T  in three launches.
+#include "common.h"
+
+namespace {
+
+constexpr float SN_EPS = 1e-12f;
+constexpr int COLS_PER_BLOCK = 256;
+constexpr int MAX_CHUNKS = 64;         // cols <= 16384
+constexpr int ELEMS_PER_BLOCK = 4096;
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// find (layer, local block) for a flat block index given per-layer block counts
+template <typename F>
+__device__ __forceinline__ bool locate(int n_layers, int bid, F count_of, int& layer, int& local) {
+    int acc = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        int c = count_of(l);
+        if (bid < acc + c) { layer = l; local = bid - acc; return true; }
+        acc += c;
+    }
+    return false;
+}
+
+struct SnWs { float* t; float* partial; float* wv; };
+
+__device__ __forceinline__ long long col_offset(const mtd_sn_layer* L, int layer) {
+    long long o = 0;
+    for (int l = 0; l < layer; ++l) o += L[l].cols;
+    return o;
+}
+__device__ __forceinline__ long long row_offset(const mtd_sn_layer* L, int layer) {
+    long long o = 0;
+    for (int l = 0; l < layer; ++l) o += L[l].rows;
+    return o;
+}
+
+__global__ __launch_bounds__(256) void sn_wtu_kernel(const mtd_sn_layer* __restrict__ L, int n_layers, SnWs ws) {
+    __shared__ float red[256];
+    int layer, chunk;
+    if (!locate(n_layers, blockIdx.x, [&](int l) { return (L[l].cols + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK; }, layer, chunk)) return;
+    const mtd_sn_layer ly = L[layer];
+    const int k = chunk * COLS_PER_BLOCK + threadIdx.x;
+    float t = 0.f;
+    if (k < ly.cols) {
+        const float* w = ly.w + k;
+        for (int r = 0; r < ly.rows; ++r) t = fmaf(w[(long long)r * ly.cols], ly.u[r], t);
+        ws.t[col_offset(L, layer) + k] = t;
+    }
+    float s = block_sum(t * t, red);
+    if (threadIdx.x == 0) ws.partial[layer * MAX_CHUNKS + chunk] = s;
+}
+
+__global__ __launch_bounds__(256) void sn_norm_v_kernel(const mtd_sn_layer* __restrict__ L, int n_layers, SnWs ws) {
+    int layer, chunk;
+    if (!locate(n_layers, blockIdx.x, [&](int l) { return (L[l].cols + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK; }, layer, chunk)) return;
+    const mtd_sn_layer ly = L[layer];
+    const int nchunk = (ly.cols + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK;
+    float n2 = 0.f;
+    for (int c = 0; c < nchunk; ++c) n2 += ws.partial[layer * MAX_CHUNKS + c];
+    const float inv = 1.f / fmaxf(sqrtf(n2), SN_EPS);
+    const int k = chunk * COLS_PER_BLOCK + threadIdx.x;
+    if (k < ly.cols) {
+        const float v = ws.t[col_offset(L, layer) + k] * inv;
+        ly.v[k] = v;
+        if (ly.v_save) ly.v_save[k] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void sn_copy_v_kernel(const mtd_sn_layer* __restrict__ L, int n_layers) {
+    int layer, chunk;
+    if (!locate(n_layers, blockIdx.x, [&](int l) { return (L[l].cols + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK; }, layer, chunk)) return;
+    const mtd_sn_layer ly = L[layer];
+    const int k = chunk * COLS_PER_BLOCK + threadIdx.x;
+    if (k < ly.cols && ly.v_save) ly.v_save[k] = ly.v[k];
+}
+
+// one wave per row: s[r] = W[r,:] . v
+__global__ __launch_bounds__(256) void sn_wv_kernel(const mtd_sn_layer* __restrict__ L, int n_layers, SnWs ws) {
+    int layer, local;
+    if (!locate(n_layers, blockIdx.x, [&](int l) { return (L[l].rows + 3) / 4; }, layer, local)) return;
+    const mtd_sn_layer ly = L[layer];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = local * 4 + wave;
+    if (r >= ly.rows) return;
+    const float* w = ly.w + (long long)r * ly.cols;
+    float s = 0.f;
+    for (int k = lane; k < ly.cols; k += 64) s = fmaf(w[k], ly.v[k], s);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) ws.wv[row_offset(L, layer) + r] = s;
+}
+
+__global__ __launch_bounds__(256) void sn_finish_kernel(const mtd_sn_layer* __restrict__ L, int n_layers, SnWs ws, int train) {
+    __shared__ float red[256];
+    const int layer = blockIdx.x;
+    if (layer >= n_layers) return;
+    const mtd_sn_layer ly = L[layer];
+    const float* wv = ws.wv + row_offset(L, layer);
+    float sigma;
+    if (train) {
+        float p = 0.f;
+        for (int r = threadIdx.x; r < ly.rows; r += 256) p += wv[r] * wv[r];
+        const float n2 = block_sum(p, red);
+        const float inv = 1.f / fmaxf(sqrtf(n2), SN_EPS);
+        float q = 0.f;
+        for (int r = threadIdx.x; r < ly.rows; r += 256) {
+            const float u = wv[r] * inv;
+            ly.u[r] = u;
+            if (ly.u_save) ly.u_save[r] = u;
+            q += u * wv[r];
+        }
+        sigma = block_sum(q, red);
+    } else {
+        float q = 0.f;
+        for (int r = threadIdx.x; r < ly.rows; r += 256) {
+            const float u = ly.u[r];
+            if (ly.u_save) ly.u_save[r] = u;
+            q += u * wv[r];
+        }
+        sigma = block_sum(q, red);
+    }
+    if (threadIdx.x == 0) {
+        ly.sigma[0] = sigma;
+        ly.sigma[1] = 1.f / sigma;
+    }
+}
+
+// ---- backward -----------------------------------------------------------------------------------
+struct SnGradWs { float* partial; float* dot; };
+
+__device__ __forceinline__ int grad_blocks(const mtd_sn_grad_layer& l) {
+    return (int)(((long long)l.rows * l.cols + ELEMS_PER_BLOCK - 1) / ELEMS_PER_BLOCK);
+}
+__device__ __forceinline__ long long grad_block_offset(const mtd_sn_grad_layer* L, int layer) {
+    long long o = 0;
+    for (int l = 0; l < layer; ++l) o += grad_blocks(L[l]);
+    return o;
+}
+
+__global__ __launch_bounds__(256) void sn_grad_dot_kernel(const mtd_sn_grad_layer* __restrict__ L, int n_layers, SnGradWs ws) {
+    __shared__ float red[256];
+    int layer, local;
+    if (!locate(n_layers, blockIdx.x, [&](int l) { return grad_blocks(L[l]); }, layer, local)) return;
+    const mtd_sn_grad_layer ly = L[layer];
+    const long long total = (long long)ly.rows * ly.cols;
+    const long long base = (long long)local * ELEMS_PER_BLOCK;
+    float p = 0.f;
+    for (int i = threadIdx.x; i < ELEMS_PER_BLOCK; i += 256) {
+        long long e = base + i;
+        if (e < total) p = fmaf(ly.G[e], ly.w[e], p);
+    }
+    const float s = block_sum(p, red);
+    if (threadIdx.x == 0) ws.partial[grad_block_offset(L, layer) + local] = s;
+}
+
+__global__ __launch_bounds__(256) void sn_grad_sum_kernel(const mtd_sn_grad_layer* __restrict__ L, int n_layers, SnGradWs ws) {
+    __shared__ float red[256];
+    const int layer = blockIdx.x;
+    if (layer >= n_layers) return;
+    const int nb = grad_blocks(L[layer]);
+    const float* part = ws.partial + grad_block_offset(L, layer);
+    float p = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) p += part[i];
+    const float s = block_sum(p, red);
+    if (threadIdx.x == 0) ws.dot[layer] = s;
+}
+
+__global__ __launch_bounds__(256) void sn_grad_apply_kernel(const mtd_sn_grad_layer* __restrict__ L, int n_layers, SnGradWs ws) {
+    int layer, local;
+    if (!locate(n_layers, blockIdx.x, [&](int l) { return grad_blocks(L[l]); }, layer, local)) return;
+    const mtd_sn_grad_layer ly = L[layer];
+    const long long total = (long long)ly.rows * ly.cols;
+    const long long base = (long long)local * ELEMS_PER_BLOCK;
+    const float inv = ly.sigma[1];
+    const float coef = ws.dot[layer] * inv * inv;
+    for (int i = threadIdx.x; i < ELEMS_PER_BLOCK; i += 256) {
+        long long e = base + i;
+        if (e < total) {
+            const int r = (int)(e / ly.cols), k = (int)(e % ly.cols);
+            const float g = ly.G[e] * inv - coef * ly.u[r] * ly.v[k];
+            ly.g_out[e] = ly.accumulate ? ly.g_out[e] + g : g;
+        }
+    }
+}
+
+size_t sn_ws_floats(const mtd_sn_layer* h, int n, long long* cols_total, long long* rows_total) {
+    long long c = 0, r = 0;
+    for (int i = 0; i < n; ++i) { c += h[i].cols; r += h[i].rows; }
+    if (cols_total) *cols_total = c;
+    if (rows_total) *rows_total = r;
+    return (size_t)(c + (long long)n * MAX_CHUNKS + r);
+}
+
+}  // namespace
+
+extern "C" size_t mtd_sn_ws_bytes(const mtd_sn_layer* layers_host, int n_layers) {
+    if (!layers_host || n_layers <= 0) return 0;
+    return sn_ws_floats(layers_host, n_layers, nullptr, nullptr) * sizeof(float);
+}
+
+extern "C" int mtd_sn_power_iter(const mtd_sn_layer* layers_dev, const mtd_sn_layer* layers_host, int n_layers, int train, float* ws,
+                                 void* stream) {
+    if (!layers_dev || !layers_host || n_layers <= 0 || !ws) return MTD_EINVAL;
+    long long ctot = 0, rtot = 0;
+    sn_ws_floats(layers_host, n_layers, &ctot, &rtot);
+    int col_blocks = 0, row_blocks = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        if (layers_host[i].cols > COLS_PER_BLOCK * MAX_CHUNKS || layers_host[i].rows <= 0 || layers_host[i].cols <= 0) return MTD_EINVAL;
+        col_blocks += (layers_host[i].cols + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK;
+        row_blocks += (layers_host[i].rows + 3) / 4;
+    }
+    SnWs w;
+    w.t = ws;
+    w.partial = ws + ctot;
+    w.wv = w.partial + (long long)n_layers * MAX_CHUNKS;
+    hipStream_t s = (hipStream_t)stream;
+    if (train) {
+        hipLaunchKernelGGL(sn_wtu_kernel, dim3(col_blocks), dim3(256), 0, s, layers_dev, n_layers, w);
+        MTD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(sn_norm_v_kernel, dim3(col_blocks), dim3(256), 0, s, layers_dev, n_layers, w);
+        MTD_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(sn_copy_v_kernel, dim3(col_blocks), dim3(256), 0, s, layers_dev, n_layers);
+        MTD_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(sn_wv_kernel, dim3(row_blocks), dim3(256), 0, s, layers_dev, n_layers, w);
+    MTD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sn_finish_kernel, dim3(n_layers), dim3(256), 0, s, layers_dev, n_layers, w, train);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+static long long sn_grad_blocks_host(const mtd_sn_grad_layer* h, int n) {
+    long long b = 0;
+    for (int i = 0; i < n; ++i) b += ((long long)h[i].rows * h[i].cols + ELEMS_PER_BLOCK - 1) / ELEMS_PER_BLOCK;
+    return b;
+}
+
+extern "C" size_t mtd_sn_grad_ws_bytes(const mtd_sn_grad_layer* layers_host, int n_layers) {
+    if (!layers_host || n_layers <= 0) return 0;
+    return (size_t)(sn_grad_blocks_host(layers_host, n_layers) + n_layers) * sizeof(float);
+}
+
+extern "C" int mtd_sn_grad(const mtd_sn_grad_layer* layers_dev, const mtd_sn_grad_layer* layers_host, int n_layers, float* ws,
+                           void* stream) {
+    if (!layers_dev || !layers_host || n_layers <= 0 || !ws) return MTD_EINVAL;
+    const long long nb = sn_grad_blocks_host(layers_host, n_layers);
+    SnGradWs w;
+    w.partial = ws;
+    w.dot = ws + nb;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sn_grad_dot_kernel, dim3((unsigned)nb), dim3(256), 0, s, layers_dev, n_layers, w);
+    MTD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sn_grad_sum_kernel, dim3(n_layers), dim3(256), 0, s, layers_dev, n_layers, w);
+    MTD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sn_grad_apply_kernel, dim3((unsigned)nb), dim3(256), 0, s, layers_dev, n_layers, w);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}

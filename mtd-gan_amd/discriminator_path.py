@@ -1,0 +1,349 @@
+"""Forward / backward kernel schedules of Multi_Task_Discriminator_Skip on the HIP kernels.
+
+Mirrors the reference's arch/Ours/networks.py:383-474 (forward) and spells out its autograd transpose
+so that a whole discriminator pass is one node: a pass is recorded on a tape, and `disc_backward` replays
+it for any combination of output cotangents (image-level score, pixel-level map, restoration), writing
+parameter gradients straight into caller-owned buffers (this is what lets PCGrad keep one flat gradient
+vector per task).  Spectral norm: sigma per pass comes from mtd_sn_power_iter; convolutions read
+weight_orig in place and scale their accumulators by 1/sigma; the weight gradient correction
+ is one batched mtd_sn_grad per backward.  NHWC fp32 throughout.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from . import kernels as K
+from .kernels import ACT_LRELU, ACT_NONE
+
+CH = [64, 128, 256, 512, 512, 512]                    # trunk channels per level (out_channels = 64)
+DEC = [(1024, 512), (1024, 512), (1024, 256), (512, 128), (256, 64), (128, 1)]   # (cat channels, out) per decoder level
+RUP = [(512, 512), (512, 512), (512, 512), (256, 256), (128, 128), (64, 64)]      # r_up{l}: cin -> cout' (conv to 4*cout')
+
+
+def sn_layer_specs():
+    """(name, rows, cols) of the 45 spectral-normalised layers in a fixed order."""
+    out = []
+    cin = 1
+    for l, co in enumerate(CH, start=1):
+        out.append((f"conv{l}1", co, cin * 9))
+        out.append((f"conv{l}2", co, co * 9))
+        out.append((f"down{l}", co, co * 16))
+        cin = co
+    out += [("bconv1", 512, 512), ("bconv2", 512, 512), ("c_fc", 512, 512)]
+    for pre in ("s", "r"):
+        for l, (ci, co) in enumerate(DEC, start=1):
+            out.append((f"{pre}_dconv{l}1", co, ci * 9))
+            out.append((f"{pre}_dconv{l}2", co, co * 9))
+    return out
+
+
+SN_SPECS = sn_layer_specs()
+SN_INDEX = {n: i for i, (n, _, _) in enumerate(SN_SPECS)}
+SN_ROW_OFF, SN_COL_OFF = [], []
+_r = _c = 0
+for _n, _rows, _cols in SN_SPECS:
+    SN_ROW_OFF.append(_r)
+    SN_COL_OFF.append(_c)
+    _r += _rows
+    _c += _cols
+SN_ROWS_TOTAL, SN_COLS_TOTAL = _r, _c
+SN_W_OFF = []
+_o = 0
+for _n, _rows, _cols in SN_SPECS:
+    SN_W_OFF.append(_o)
+    _o += _rows * _cols
+SN_W_TOTAL = _o
+
+
+class DiscRuntime:
+    """Per-module scratch: the raw weight-gradient temp (one flat buffer shared by all SN layers)."""
+
+    def __init__(self):
+        self._gtemp = None
+
+    def gtemp(self, name, device):
+        if self._gtemp is None or self._gtemp.device != device:
+            self._gtemp = torch.empty(SN_W_TOTAL, dtype=torch.float32, device=device)
+        i = SN_INDEX[name]
+        return self._gtemp[SN_W_OFF[i]:SN_W_OFF[i] + SN_SPECS[i][1] * SN_SPECS[i][2]]
+
+
+class Tape:
+    pass
+
+
+def _sn_forward(P, train, device):
+    """Power iteration + sigma for all 45 layers (4 launches).  Returns (sig[45,2], u_save, v_save)."""
+    L = _lib.lib()
+    sig = torch.empty((len(SN_SPECS), 2), dtype=torch.float32, device=device)
+    u_save = torch.empty(SN_ROWS_TOTAL, dtype=torch.float32, device=device)
+    v_save = torch.empty(SN_COLS_TOTAL, dtype=torch.float32, device=device)
+    structs = []
+    for i, (n, rows, cols) in enumerate(SN_SPECS):
+        s = _lib.SnLayer()
+        s.w = P[n + ".weight_orig"].data_ptr()
+        s.u = P[n + ".weight_u"].data_ptr()
+        s.v = P[n + ".weight_v"].data_ptr()
+        s.sigma = sig.data_ptr() + 8 * i
+        s.u_save = u_save.data_ptr() + 4 * SN_ROW_OFF[i]
+        s.v_save = v_save.data_ptr() + 4 * SN_COL_OFF[i]
+        s.rows, s.cols = rows, cols
+        structs.append(s)
+    dev_tab, host_arr = K.device_table(structs, device)
+    need = L.mtd_sn_ws_bytes(C.cast(host_arr, C.c_void_p), len(structs))
+    ws = K.workspace(need, device)
+    K.check(L.mtd_sn_power_iter(dev_tab.data_ptr(), C.cast(host_arr, C.c_void_p), len(structs), 1 if train else 0, ws.data_ptr(),
+                                K.stream_ptr()), "mtd_sn_power_iter")
+    return sig, u_save, v_save
+
+
+def _inv_sigma(tape, name):
+    i = SN_INDEX[name]
+    return tape.sig[i, 1:2]
+
+
+def _sn_conv(P, tape, name, x, out, geom, N, Cc, k, act):
+    return K.conv(x, P[name + ".weight_orig"], geom, N, Cc, Cc * k * k, k * k, out, scale=_inv_sigma(tape, name),
+                  bias=P[name + ".bias"], act=act)
+
+
+def disc_forward(P, x, train, drop_mask, need_rec, save):
+    """x: (B,64,64,1) NHWC.  P: dict name -> tensor (reference state_dict names).  drop_mask: (B,512)
+    multiplier or None.  Returns ((enc (B,1,1,1), dec (B,64,64,1), rec or None), tape)."""
+    B = x.shape[0]
+    dev = x.device
+    tp = Tape()
+    tp.sig, tp.u_save, tp.v_save = _sn_forward(P, train, dev)
+    tp.x_in, tp.B, tp.drop_mask, tp.need_rec = x, B, drop_mask, need_rec
+    tp.tin, tp.a, tp.xs = {}, {}, {}
+    t, h, cin = x, 64, 1
+    for l, co in enumerate(CH, start=1):
+        g3 = K.geom_fwd(B, h, h, 3, 1, 1)
+        a = K.empty_nhwc(B, h, h, co, x)
+        _sn_conv(P, tp, f"conv{l}1", t, a, g3, co, cin, 3, ACT_LRELU)
+        xl = K.empty_nhwc(B, h, h, co, x)
+        _sn_conv(P, tp, f"conv{l}2", a, xl, g3, co, co, 3, ACT_LRELU)
+        d = K.empty_nhwc(B, h // 2, h // 2, co, x)
+        _sn_conv(P, tp, f"down{l}", xl, d, K.geom_fwd(B, h, h, 4, 2, 1), co, co, 4, ACT_NONE)
+        tp.tin[l], tp.a[l], tp.xs[l] = t, a, xl
+        t, h, cin = d, h // 2, co
+    g1 = K.geom_fwd(B, 1, 1, 1, 1, 0)
+    tp.d6 = t
+    tp.b1 = K.empty_nhwc(B, 1, 1, 512, x)
+    _sn_conv(P, tp, "bconv1", t, tp.b1, g1, 512, 512, 1, ACT_LRELU)
+    tp.bot = K.empty_nhwc(B, 1, 1, 512, x)
+    _sn_conv(P, tp, "bconv2", tp.b1, tp.bot, g1, 512, 512, 1, ACT_LRELU)
+    # ---- CLS head (networks.py:414-417, 470)
+    tp.c = K.empty_nhwc(B, 1, 1, 512, x)
+    _sn_conv(P, tp, "c_fc", tp.bot, tp.c, g1, 512, 512, 1, ACT_LRELU)
+    tp.cm = K.mul(tp.c, drop_mask.reshape(B, 1, 1, 512)) if drop_mask is not None else tp.c
+    enc = K.empty_nhwc(B, 1, 1, 1, x)
+    K.conv(tp.cm, P["enc_out.weight"], g1, 1, 512, 512, 1, enc, bias=P["enc_out.bias"])
+    # ---- SEG decoder (networks.py:420-442)
+    tp.s_cat, tp.s_o1, tp.s_o2, tp.s_in = {}, {}, {}, {}
+    t, r = tp.bot, 1
+    for lvl in range(1, 7):
+        r *= 2
+        cprev = t.shape[3]
+        skip = tp.xs[7 - lvl]
+        ccat, co = DEC[lvl - 1]
+        cat = K.empty_nhwc(B, r, r, ccat, x)
+        K.upsample2x_fwd(t, cat[..., :cprev])
+        K.copy_channels(skip, cat[..., cprev:])
+        g3 = K.geom_fwd(B, r, r, 3, 1, 1)
+        o1 = K.empty_nhwc(B, r, r, co, x)
+        _sn_conv(P, tp, f"s_dconv{lvl}1", cat, o1, g3, co, ccat, 3, ACT_LRELU)
+        o2 = K.empty_nhwc(B, r, r, co, x)
+        _sn_conv(P, tp, f"s_dconv{lvl}2", o1, o2, g3, co, co, 3, ACT_LRELU)
+        tp.s_in[lvl], tp.s_cat[lvl], tp.s_o1[lvl], tp.s_o2[lvl] = t, cat, o1, o2
+        t = o2
+    g64 = K.geom_fwd(B, 64, 64, 1, 1, 0)
+    dec = K.empty_nhwc(B, 64, 64, 1, x)
+    K.conv(t, P["dec_out.weight"], g64, 1, 1, 1, 1, dec, bias=P["dec_out.bias"])
+    # ---- REC decoder (networks.py:445-467)
+    rec = None
+    if need_rec:
+        tp.r_cat, tp.r_o1, tp.r_o2, tp.r_in = {}, {}, {}, {}
+        t, r = tp.bot, 1
+        for lvl in range(1, 7):
+            cin_up, cup = RUP[lvl - 1]
+            up = K.empty_nhwc(B, r, r, 4 * cup, x)
+            K.conv(t, P[f"r_up{lvl}.upsample.0.weight"], K.geom_fwd(B, r, r, 1, 1, 0), 4 * cup, cin_up, cin_up, 1, up,
+                   bias=P[f"r_up{lvl}.upsample.0.bias"])
+            r *= 2
+            skip = tp.xs[7 - lvl]
+            ccat, co = DEC[lvl - 1]
+            cat = K.empty_nhwc(B, r, r, ccat, x)
+            K.pixel_shuffle2_fwd(up, cat[..., :cup])
+            K.copy_channels(skip, cat[..., cup:])
+            g3 = K.geom_fwd(B, r, r, 3, 1, 1)
+            o1 = K.empty_nhwc(B, r, r, co, x)
+            _sn_conv(P, tp, f"r_dconv{lvl}1", cat, o1, g3, co, ccat, 3, ACT_LRELU)
+            o2 = K.empty_nhwc(B, r, r, co, x)
+            _sn_conv(P, tp, f"r_dconv{lvl}2", o1, o2, g3, co, co, 3, ACT_LRELU)
+            tp.r_in[lvl], tp.r_cat[lvl], tp.r_o1[lvl], tp.r_o2[lvl] = t, cat, o1, o2
+            t = o2
+        rec = K.empty_nhwc(B, 64, 64, 1, x)
+        K.conv(t, P["rec_out.weight"], g64, 1, 1, 1, 1, rec, bias=P["rec_out.bias"])
+    return (enc, dec, rec), (tp if save else None)
+
+
+class GradSink:
+    """Where a backward pass accumulates parameter gradients: name -> pre-zeroed tensor (same shape as the
+    parameter).  Names that are absent get no gradient (their weight-gradient kernels are skipped)."""
+
+    def __init__(self, tensors):
+        self.t = tensors
+
+    def get(self, name):
+        return self.t.get(name)
+
+
+def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad):
+    """Replay one recorded pass.  g_enc (B,1,1,1) / g_dec (B,64,64,1) / g_rec (B,64,64,1): output
+    cotangents (any may be None).  sink: GradSink or None.  All parameter gradients are ACCUMULATED."""
+    B = tp.B
+    x = tp.x_in
+    dev = x.device
+    sn_touched = []
+
+    def want(name):
+        return sink is not None and sink.get(name) is not None
+
+    def wgrad_sn(name, p, q, geom, N, Cc, k):
+        wn, bn = name + ".weight_orig", name + ".bias"
+        if want(wn):
+            K.wgrad(p, q, geom, N, Cc, rt.gtemp(name, dev), Cc * k * k, k * k, db=sink.get(bn), accumulate=False,
+                    accumulate_bias=True)
+            sn_touched.append(name)
+        elif want(bn):
+            raise NotImplementedError("bias-only gradient request")
+
+    def dgrad_s1(name, gpre, r, N, Cc, out, k=3, mask=None, add1=None):
+        # data gradient of a stride-1 SN conv with N input channels (outputs of this launch), Cc output channels
+        return K.conv(gpre, P[name + ".weight_orig"], K.geom_dgrad_s1(B, r, r, k, (k - 1) // 2), N, Cc, k * k, N * k * k, out,
+                      scale=_inv_sigma(tp, name), add1=add1, mask=mask, mask_slope=0.2)
+
+    g_bot_parts = []
+    g_skip = {l: [] for l in range(1, 7)}
+    g1 = K.geom_fwd(B, 1, 1, 1, 1, 0)
+    g64 = K.geom_fwd(B, 64, 64, 1, 1, 0)
+
+    def decoder_backward(pre, g_out, cats, o1s, o2s, ins, head):
+        """shared by the SEG ('s') and REC ('r') decoders; returns the gradient of x_bot"""
+        t6 = o2s[6]
+        if want(head + ".weight"):
+            K.wgrad(g_out, t6, g64, 1, 1, sink.get(head + ".weight"), 1, 1, db=sink.get(head + ".bias"), accumulate=True)
+        g = K.empty_nhwc(B, 64, 64, 1, x)
+        K.conv(g_out, P[head + ".weight"], g64, 1, 1, 1, 1, g)
+        for lvl in range(6, 0, -1):
+            r = 2 ** lvl
+            ccat, co = DEC[lvl - 1]
+            o2, o1, cat, tin = o2s[lvl], o1s[lvl], cats[lvl], ins[lvl]
+            g3 = K.geom_fwd(B, r, r, 3, 1, 1)
+            gpre2 = K.act_grad(g, o2, 0.2)
+            wgrad_sn(f"{pre}_dconv{lvl}2", gpre2, o1, g3, co, co, 3)
+            gpre1 = K.empty_nhwc(B, r, r, co, x)
+            dgrad_s1(f"{pre}_dconv{lvl}2", gpre2, r, co, co, gpre1, mask=o1)
+            wgrad_sn(f"{pre}_dconv{lvl}1", gpre1, cat, g3, co, ccat, 3)
+            gcat = K.empty_nhwc(B, r, r, ccat, x)
+            dgrad_s1(f"{pre}_dconv{lvl}1", gpre1, r, ccat, co, gcat)
+            cprev = tin.shape[3] if pre == "s" else RUP[lvl - 1][1]
+            g_skip[7 - lvl].append(gcat[..., cprev:])
+            if pre == "s":
+                g = K.empty_nhwc(B, r // 2, r // 2, cprev, x)
+                K.upsample2x_bwd(gcat[..., :cprev], g)
+            else:
+                cin_up, cup = RUP[lvl - 1]
+                gr = K.empty_nhwc(B, r // 2, r // 2, 4 * cup, x)
+                K.pixel_shuffle2_bwd(gcat[..., :cup], gr)
+                gq = K.geom_fwd(B, r // 2, r // 2, 1, 1, 0)
+                wn = f"r_up{lvl}.upsample.0.weight"
+                if want(wn):
+                    K.wgrad(gr, tin, gq, 4 * cup, cin_up, sink.get(wn), cin_up, 1, db=sink.get(f"r_up{lvl}.upsample.0.bias"), accumulate=True)
+                g = K.empty_nhwc(B, r // 2, r // 2, cin_up, x)
+                K.conv(gr, P[wn], gq, cin_up, 4 * cup, 1, cin_up, g)
+        return g
+
+    if g_rec is not None:
+        g_bot_parts.append(decoder_backward("r", g_rec, tp.r_cat, tp.r_o1, tp.r_o2, tp.r_in, "rec_out"))
+    if g_dec is not None:
+        g_bot_parts.append(decoder_backward("s", g_dec, tp.s_cat, tp.s_o1, tp.s_o2, tp.s_in, "dec_out"))
+    if g_enc is not None:
+        if want("enc_out.weight"):
+            K.wgrad(g_enc, tp.cm, g1, 1, 512, sink.get("enc_out.weight"), 512, 1, db=sink.get("enc_out.bias"), accumulate=True)
+        gcm = K.empty_nhwc(B, 1, 1, 512, x)
+        K.conv(g_enc, P["enc_out.weight"], g1, 512, 1, 1, 512, gcm)
+        gc = K.mul(gcm, tp.drop_mask.reshape(B, 1, 1, 512)) if tp.drop_mask is not None else gcm
+        gpre = K.act_grad(gc, tp.c, 0.2)
+        wn = "c_fc.weight_orig"
+        if want(wn):
+            K.wgrad(gpre, tp.bot, g1, 512, 512, rt.gtemp("c_fc", dev), 512, 1, db=sink.get("c_fc.bias"), accumulate=False,
+                    accumulate_bias=True)
+            sn_touched.append("c_fc")
+        gb = K.empty_nhwc(B, 1, 1, 512, x)
+        K.conv(gpre, P[wn], g1, 512, 512, 1, 512, gb, scale=_inv_sigma(tp, "c_fc"))
+        g_bot_parts.append(gb)
+
+    # ---- bottleneck
+    gbot = g_bot_parts[0]
+    for extra in g_bot_parts[1:]:
+        K.copy_channels(extra, gbot, accumulate=True)
+    gpre = K.act_grad(gbot, tp.bot, 0.2)
+    wgrad_sn("bconv2", gpre, tp.b1, g1, 512, 512, 1)
+    gpre1 = K.empty_nhwc(B, 1, 1, 512, x)
+    K.conv(gpre, P["bconv2.weight_orig"], g1, 512, 512, 1, 512, gpre1, scale=_inv_sigma(tp, "bconv2"), mask=tp.b1, mask_slope=0.2)
+    wgrad_sn("bconv1", gpre1, tp.d6, g1, 512, 512, 1)
+    g = K.empty_nhwc(B, 1, 1, 512, x)
+    K.conv(gpre1, P["bconv1.weight_orig"], g1, 512, 512, 1, 512, g, scale=_inv_sigma(tp, "bconv1"))
+
+    # ---- trunk, levels 6..1
+    g_in = None
+    for l in range(6, 0, -1):
+        h = 64 >> (l - 1)
+        co = CH[l - 1]
+        ci = 1 if l == 1 else CH[l - 2]
+        xl, a, tin = tp.xs[l], tp.a[l], tp.tin[l]
+        wgrad_sn(f"down{l}", g, xl, K.geom_fwd(B, h, h, 4, 2, 1), co, co, 4)
+        gpre2 = K.empty_nhwc(B, h, h, co, x)
+        adds = g_skip[l]
+        add1 = adds[0] if len(adds) > 0 else None
+        add2 = adds[1] if len(adds) > 1 else None
+        wd = P[f"down{l}.weight_orig"]
+        for py in range(2):
+            for px in range(2):
+                K.conv(g, wd, K.geom_dgrad_s2(B, h, h, py, px), co, co, 16, co * 16, gpre2, scale=_inv_sigma(tp, f"down{l}"),
+                       add1=add1, add2=add2, mask=xl, mask_slope=0.2)
+        g3 = K.geom_fwd(B, h, h, 3, 1, 1)
+        wgrad_sn(f"conv{l}2", gpre2, a, g3, co, co, 3)
+        gpre1 = K.empty_nhwc(B, h, h, co, x)
+        dgrad_s1(f"conv{l}2", gpre2, h, co, co, gpre1, mask=a)
+        wgrad_sn(f"conv{l}1", gpre1, tin, g3, co, ci, 3)
+        if l > 1:
+            g = K.empty_nhwc(B, h, h, ci, x)
+            dgrad_s1(f"conv{l}1", gpre1, h, ci, co, g)
+        elif want_input_grad:
+            g_in = K.empty_nhwc(B, h, h, 1, x)
+            dgrad_s1("conv11", gpre1, h, 1, co, g_in)
+
+    # ---- spectral-norm correction of the raw weight gradients, accumulated into the sink
+    if sn_touched:
+        L = _lib.lib()
+        structs = []
+        for name in sn_touched:
+            i = SN_INDEX[name]
+            s = _lib.SnGradLayer()
+            s.G = rt.gtemp(name, dev).data_ptr()
+            s.w = P[name + ".weight_orig"].data_ptr()
+            s.u = tp.u_save.data_ptr() + 4 * SN_ROW_OFF[i]
+            s.v = tp.v_save.data_ptr() + 4 * SN_COL_OFF[i]
+            s.sigma = tp.sig.data_ptr() + 8 * i
+            s.g_out = sink.get(name + ".weight_orig").data_ptr()
+            s.rows, s.cols, s.accumulate = SN_SPECS[i][1], SN_SPECS[i][2], 1
+            structs.append(s)
+        dev_tab, host_arr = K.device_table(structs, dev)
+        need = L.mtd_sn_grad_ws_bytes(C.cast(host_arr, C.c_void_p), len(structs))
+        ws = K.workspace(need, dev)
+        K.check(L.mtd_sn_grad(dev_tab.data_ptr(), C.cast(host_arr, C.c_void_p), len(structs), ws.data_ptr(), K.stream_ptr()), "mtd_sn_grad")
+    return g_in

@@ -1,0 +1,137 @@
+"""Forward / backward schedules of the Res-FFT-Conv block and the ResFFT generator on the HIP kernels.
+
+Mirrors arch/Ours/networks.py:21-36 (FFT_ConvBlock.forward) and :95-164 (ResFFT_Generator.forward) of
+the reference; the backward schedules are their autograd transposes written out by hand so that one
+`torch.autograd.Function` covers the whole generator (no per-op autograd bookkeeping on the host).
+All activations are NHWC fp32.  Every arithmetic op is a libmtdgan_hip.so kernel (see kernels.py).
+"""
+import torch
+
+from . import kernels as K
+from .kernels import ACT_NONE, ACT_RELU
+
+CH = 32
+
+
+# ------------------------------------------------------------------------------------------------ block
+def block_forward(x, w_img, b_img, w_fft, b_fft, save):
+    """x: (B,64,64,32).  Returns (out, saved) with saved = (x, img, S, Z) when save."""
+    B, H, W, _ = x.shape
+    g = K.geom_fwd(B, H, W, 3, 1, 1)
+    img = K.empty_nhwc(B, H, W, CH, x)
+    K.conv(x, w_img, g, CH, CH, CH * 9, 9, img, bias=b_img, act=ACT_RELU)          # relu(conv3x3(x)+b)
+    R = K.rfft_rows(x, 0)
+    w2t = K.transpose64(w_fft)
+    T, S, Z = K.spec_mix_fwd(R, w2t, b_fft, save)
+    out = K.empty_nhwc(B, H, W, CH, x)
+    K.irfft_rows(T, out, add1=x, add2=img)                                          # x + img + irfft2(...)
+    return out, ((x, img, S, Z) if save else None)
+
+
+def block_backward(g, saved, w_img, w_fft, grads, premask):
+    """g: grad of the block output.  grads: dict with tensors dw_img, db_img, dw_fft, db_fft (written).
+    premask: multiply the input gradient by (x > 0) -- x is always a ReLU output inside the generator,
+    so the result is the gradient w.r.t. the producer's pre-activation."""
+    x, img, S, Z = saved
+    B, H, W, _ = x.shape
+    gm = K.act_grad(g, img, 0.0)                                                    # g * (img > 0)
+    K.wgrad(gm, x, K.geom_fwd(B, H, W, 3, 1, 1), CH, CH, grads["dw_img"], CH * 9, 9, db=grads["db_img"])
+    gR = K.rfft_rows(g, 1)                                                          # irfft2 backward
+    gT = K.spec_mix_bwd(gR, w_fft, S, Z, grads["dw_fft"], grads["db_fft"])
+    d1 = K.empty_nhwc(B, H, W, CH, x)
+    K.conv(gm, w_img, K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, d1, add1=g)  # dgrad(img branch) + residual
+    gx = K.empty_nhwc(B, H, W, CH, x)
+    K.irfft_rows(gT, gx, add1=d1, mask=x if premask else None)
+    return gx
+
+
+# ------------------------------------------------------------------------------------------------ generator
+class GenParams:
+    """Views of the generator parameters in the order the schedules use them."""
+
+    def __init__(self, enc_w, enc_b, dec_w, dec_b, blk):
+        self.enc_w, self.enc_b, self.dec_w, self.dec_b, self.blk = enc_w, enc_b, dec_w, dec_b, blk   # blk[i] = (w_img,b_img,w_fft,b_fft)
+
+
+def generator_forward(x, P, save):
+    """x: (B,64,64,1) NHWC.  Returns (out (B,64,64,1), tape)."""
+    B, H, W, _ = x.shape
+    L = len(P.enc_w) - 1                                   # 10
+    gf = K.geom_fwd(B, H, W, 3, 1, 1)
+    gt = K.geom_dgrad_s1(B, H, W, 3, 1)                    # ConvTranspose2d(k3,s1,p1) gathers like a stride-1 dgrad
+    tape = {"t": [], "e": [], "blk": [], "d": [], "u": []}
+    t = K.empty_nhwc(B, H, W, CH, x)
+    K.conv(x, P.enc_w[0], gf, CH, 1, 9, 9, t, bias=P.enc_b[0], act=ACT_RELU)
+    e = None
+    for i in range(L + 1):
+        e, sv = block_forward(t, *P.blk[i], save)
+        if save:
+            tape["t"].append(t)
+            tape["blk"].append(sv)
+            tape["e"].append(e)
+        else:
+            tape["e"].append(e)
+        if i < L:
+            t = K.empty_nhwc(B, H, W, CH, x)
+            K.conv(e, P.enc_w[i + 1], gf, CH, CH, CH * 9, 9, t, bias=P.enc_b[i + 1], act=ACT_RELU)
+    # e list: e1..e10, xb  (index 0..10)
+    cur = e                                                # x_b
+    for j in range(L, 0, -1):                              # decoder[j], j = 10..1
+        d = K.empty_nhwc(B, H, W, CH, x)
+        K.conv(cur, P.dec_w[j], gt, CH, CH, 9, CH * 9, d, bias=P.dec_b[j], add1=tape["e"][j - 1], act=ACT_RELU)
+        u, sv = block_forward(d, *P.blk[2 * L + 1 - j], save)   # enforce[11] after decoder[-1] ... enforce[20] after decoder[-10]
+        if save:
+            tape["u"].append(cur)                          # input of decoder[j]
+            tape["d"].append(d)
+            tape["blk"].append(sv)
+        cur = u
+    out = K.empty_nhwc(B, H, W, 1, x)
+    K.conv(cur, P.dec_w[0], gt, 1, CH, 9, 9, out, bias=P.dec_b[0], add1=x, act=ACT_RELU)
+    if save:
+        tape["u"].append(cur)
+        tape["x"] = x
+        tape["out"] = out
+    return out, (tape if save else None)
+
+
+def generator_backward(g_out, tape, P, G):
+    """g_out: grad of the output (B,64,64,1).  G: GenParams-shaped container of gradient tensors
+    (enc_w[i] ... blk[i] = dict(dw_img, db_img, dw_fft, db_fft)); all are overwritten."""
+    x = tape["x"]
+    B, H, W, _ = x.shape
+    L = len(P.enc_w) - 1
+    gf = K.geom_fwd(B, H, W, 3, 1, 1)
+    gt = K.geom_dgrad_s1(B, H, W, 3, 1)
+    # output ReLU
+    gpre = K.act_grad(g_out, tape["out"], 0.0)
+    # decoder[0]: ConvTranspose 32 -> 1
+    u0 = tape["u"][L]
+    K.wgrad(gpre, u0, gt, 1, CH, G.dec_w[0], 9, 9, db=G.dec_b[0])
+    gu = K.empty_nhwc(B, H, W, CH, x)
+    K.conv(gpre, P.dec_w[0], gf, CH, 1, 9, 9, gu)          # d/du0: plain conv with W_t read as OIHW [32][1][3][3]
+    skip = [None] * (L + 1)
+    # blocks 20..11 and decoders 1..10 (tape order: d/u/blk appended for j = 10..1)
+    for j in range(1, L + 1):
+        k = L - j                                           # position in the tape lists for decoder[j]
+        gpre_d = block_backward(gu, tape["blk"][L + 1 + k], *_blk_w(P, 2 * L + 1 - j), G.blk[2 * L + 1 - j], True)
+        skip[j] = gpre_d                                    # flows unchanged into e_j
+        uj = tape["u"][k]                                   # input of decoder[j]
+        K.wgrad(gpre_d, uj, gt, CH, CH, G.dec_w[j], 9, CH * 9, db=G.dec_b[j])
+        gu = K.empty_nhwc(B, H, W, CH, x)
+        K.conv(gpre_d, P.dec_w[j], gf, CH, CH, CH * 9, 9, gu)
+    # gu is now the gradient of x_b (output of block 10)
+    g_e = gu
+    for i in range(L, -1, -1):                              # blocks 10..0, encoders 10..0
+        gpre_t = block_backward(g_e, tape["blk"][i], *_blk_w(P, i), G.blk[i], True)
+        if i > 0:
+            e_prev = tape["e"][i - 1]
+            K.wgrad(gpre_t, e_prev, gf, CH, CH, G.enc_w[i], CH * 9, 9, db=G.enc_b[i])
+            g_e = K.empty_nhwc(B, H, W, CH, x)
+            K.conv(gpre_t, P.enc_w[i], K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, g_e, add1=skip[i])
+        else:
+            K.wgrad(gpre_t, x, gf, CH, 1, G.enc_w[0], 9, 9, db=G.enc_b[0])
+
+
+def _blk_w(P, i):
+    w_img, b_img, w_fft, b_fft = P.blk[i]
+    return w_img, w_fft

@@ -1,0 +1,331 @@
+"""Tensor-level launch helpers over the C ABI (include/mtdgan_hip.h).  PyTorch supplies device memory and
+the current HIP stream; every arithmetic op below runs in libmtdgan_hip.so.  NHWC activations are torch
+tensors of shape (B, H, W, C) whose last-dim stride is 1 and whose pixel stride (`ld`) may exceed C
+(channel slices of a concat buffer)."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ConvArgs, Geom, WgradArgs, check  # noqa: F401
+
+_ws = {}
+PROFILE = None      # bench.py sets this to a list to collect (tag, start_event, end_event) per conv launch
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per (device, stream).  Stream order makes reuse safe."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def _chk_nhwc(t, name):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and t.stride(3) == 1):
+        raise ValueError(f"{name}: expected a CUDA fp32 NHWC tensor with unit channel stride, got {tuple(t.shape)} {t.stride()} {t.dtype} {t.device}")
+    B, H, W, _ = t.shape
+    ld = t.stride(2)
+    if (H > 1 and t.stride(1) != W * ld) or (B > 1 and t.stride(0) != H * W * ld):
+        if not (W == 1 and H == 1):
+            raise ValueError(f"{name}: pixels are not uniformly strided: {tuple(t.shape)} {t.stride()}")
+    return ld if (W > 1 or H > 1 or B > 1) else max(ld, t.shape[3])
+
+
+def ld_of(t):
+    """pixel stride of an NHWC tensor (for 1x1 images fall back to the batch stride)."""
+    B, H, W, Cc = t.shape
+    if W > 1:
+        return t.stride(2)
+    if H > 1:
+        return t.stride(1)
+    if B > 1:
+        return t.stride(0)
+    return Cc
+
+
+def empty_nhwc(B, H, W, Cc, like):
+    return torch.empty((B, H, W, Cc), dtype=torch.float32, device=like.device)
+
+
+# ---------------------------------------------------------------------------------------------- geometry
+def geom_fwd(B, IH, IW, k, s, p):
+    OH, OW = (IH + 2 * p - k) // s + 1, (IW + 2 * p - k) // s + 1
+    return Geom(B, IH, IW, OH, OW, s, s, -p, -p, 1, 1, k, k, k, 0, 0, 1, 1, OH, OW, 1, 1, 0, 0)
+
+
+def geom_dgrad_s1(B, H, W, k, p):
+    """stride-1 conv with input (H, W): gathers the conv OUTPUT-sized tensor at iy = y + p - ky."""
+    GH, GW = H + 2 * p - k + 1, W + 2 * p - k + 1
+    return Geom(B, GH, GW, H, W, 1, 1, p, p, -1, -1, k, k, k, 0, 0, 1, 1, H, W, 1, 1, 0, 0)
+
+
+def geom_dgrad_s2(B, H, W, py, px):
+    """k=4, s=2, p=1 conv with input (H, W) (even): one launch per input parity (py, px)."""
+    ky0, kx0 = (py + 1) & 1, (px + 1) & 1
+    oy, ox = (py + 1 - ky0) // 2, (px + 1 - kx0) // 2
+    return Geom(B, H // 2, W // 2, H // 2, W // 2, 1, 1, oy, ox, -1, -1, 2, 2, 4, ky0, kx0, 2, 2, H, W, 2, 2, py, px)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+# ---------------------------------------------------------------------------------------------- conv
+def conv(x, w, geom, N, Cc, w_sn, w_sc, out, scale=None, bias=None, add1=None, add2=None, act=ACT_NONE,
+         mask=None, mask_slope=0.0):
+    """out = epilogue(conv(x, W-view)).  `out` is an NHWC tensor (B, OHF, OWF, >=N view)."""
+    L = _lib.lib()
+    a = ConvArgs()
+    a.g = geom
+    a.inp, a.in_ld, a.C = x.data_ptr(), ld_of(x), Cc
+    a.w, a.w_sn, a.w_sc, a.N = w.data_ptr(), w_sn, w_sc, N
+    a.out, a.out_ld = out.data_ptr(), ld_of(out)
+    a.scale, a.bias = _ptr(scale), _ptr(bias)
+    a.add1, a.add1_ld = _ptr(add1), (ld_of(add1) if add1 is not None else 0)
+    a.add2, a.add2_ld = _ptr(add2), (ld_of(add2) if add2 is not None else 0)
+    a.act = act
+    a.mask, a.mask_ld, a.mask_slope = _ptr(mask), (ld_of(mask) if mask is not None else 0), mask_slope
+    a.ws, a.ws_bytes = None, 0
+    if (Cc % 32 == 0) and (N % 32 == 0):
+        need = L.mtd_conv_igemm_ws_bytes(C.byref(a))
+        if need:
+            ws = workspace(need, x.device)
+            a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+        prof = PROFILE is not None and not need
+        if prof:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        check(L.mtd_conv_igemm(C.byref(a), stream_ptr()), "mtd_conv_igemm")
+        if prof:
+            e1.record()
+            PROFILE.append((f"igemm_{geom.TH}x{geom.TW}_c{Cc}_n{N}", e0, e1))
+    else:
+        check(L.mtd_conv_direct(C.byref(a), stream_ptr()), "mtd_conv_direct")
+    return out
+
+
+def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumulate_bias=None):
+    L = _lib.lib()
+    a = WgradArgs()
+    a.g = geom
+    a.p, a.p_ld, a.N = p.data_ptr(), ld_of(p), N
+    a.q, a.q_ld, a.C = q.data_ptr(), ld_of(q), Cc
+    a.dw, a.w_sn, a.w_sc = dw.data_ptr(), w_sn, w_sc
+    a.db = _ptr(db)
+    if accumulate_bias is None:
+        accumulate_bias = accumulate
+    a.accumulate = (1 if accumulate else 0) | (2 if accumulate_bias else 0)
+    a.ws, a.ws_bytes = None, 0
+    need = L.mtd_conv_wgrad_ws_bytes(C.byref(a))
+    if need == 0:
+        raise RuntimeError(f"mtd_conv_wgrad: unsupported arguments N={N} C={Cc}")
+    ws = workspace(need, p.device)
+    a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+    check(L.mtd_conv_wgrad(C.byref(a), stream_ptr()), "mtd_conv_wgrad")
+
+
+# ---------------------------------------------------------------------------------------------- spectral path
+def rfft_rows(x, col_weight):
+    B = x.shape[0]
+    R = torch.empty((B, 33, 64, 64), dtype=torch.float32, device=x.device)
+    check(_lib.lib().mtd_rfft_rows(x.data_ptr(), ld_of(x), R.data_ptr(), B, int(col_weight), stream_ptr()), "mtd_rfft_rows")
+    return R
+
+
+def spec_mix_fwd(R, w2t, b2, save):
+    B = R.shape[0]
+    T = torch.empty_like(R)
+    S = torch.empty_like(R) if save else None
+    Z = torch.empty_like(R) if save else None
+    check(_lib.lib().mtd_spec_mix_fwd(R.data_ptr(), w2t.data_ptr(), b2.data_ptr(), T.data_ptr(), _ptr(S), _ptr(Z), B, stream_ptr()),
+          "mtd_spec_mix_fwd")
+    return T, S, Z
+
+
+def spec_mix_bwd(gR, w2, S, Z, dw2, db2, accumulate=False):
+    L = _lib.lib()
+    B = gR.shape[0]
+    gT = torch.empty_like(gR)
+    ws = workspace(L.mtd_spec_mix_bwd_ws_bytes(B), gR.device)
+    check(L.mtd_spec_mix_bwd(gR.data_ptr(), w2.data_ptr(), S.data_ptr(), Z.data_ptr(), gT.data_ptr(), ws.data_ptr(), B, stream_ptr()),
+          "mtd_spec_mix_bwd")
+    check(L.mtd_spec_mix_wgrad_reduce(ws.data_ptr(), B, dw2.data_ptr(), db2.data_ptr(), 1 if accumulate else 0, stream_ptr()),
+          "mtd_spec_mix_wgrad_reduce")
+    return gT
+
+
+def irfft_rows(T, out, add1=None, add2=None, mask=None):
+    B = T.shape[0]
+    check(_lib.lib().mtd_irfft_rows(T.data_ptr(), out.data_ptr(), ld_of(out), _ptr(add1), ld_of(add1) if add1 is not None else 0,
+                                    _ptr(add2), ld_of(add2) if add2 is not None else 0, _ptr(mask),
+                                    ld_of(mask) if mask is not None else 0, B, stream_ptr()), "mtd_irfft_rows")
+    return out
+
+
+def transpose64(src):
+    dst = torch.empty((64, 64), dtype=torch.float32, device=src.device)
+    check(_lib.lib().mtd_transpose64(src.data_ptr(), dst.data_ptr(), stream_ptr()), "mtd_transpose64")
+    return dst
+
+
+# ---------------------------------------------------------------------------------------------- element-wise
+def act_grad(g, y, slope, out=None):
+    B, H, W, Cc = g.shape
+    if out is None:
+        out = torch.empty((B, H, W, Cc), dtype=torch.float32, device=g.device)
+    check(_lib.lib().mtd_act_grad(g.data_ptr(), ld_of(g), y.data_ptr(), ld_of(y), out.data_ptr(), ld_of(out), B * H * W, Cc,
+                                  float(slope), stream_ptr()), "mtd_act_grad")
+    return out
+
+
+def copy_channels(a, out, accumulate=False):
+    B, H, W, Cc = a.shape
+    check(_lib.lib().mtd_copy_channels(a.data_ptr(), ld_of(a), out.data_ptr(), ld_of(out), B * H * W, Cc, 1 if accumulate else 0,
+                                       stream_ptr()), "mtd_copy_channels")
+    return out
+
+
+def upsample2x_fwd(x, out):
+    B, H, W, Cc = x.shape
+    check(_lib.lib().mtd_upsample2x_fwd(x.data_ptr(), ld_of(x), out.data_ptr(), ld_of(out), B, H, W, Cc, stream_ptr()), "mtd_upsample2x_fwd")
+    return out
+
+
+def upsample2x_bwd(gout, gin):
+    B, H, W, Cc = gin.shape
+    check(_lib.lib().mtd_upsample2x_bwd(gout.data_ptr(), ld_of(gout), gin.data_ptr(), ld_of(gin), B, H, W, Cc, stream_ptr()), "mtd_upsample2x_bwd")
+    return gin
+
+
+def pixel_shuffle2_fwd(x, out):
+    B, H, W, C4 = x.shape
+    check(_lib.lib().mtd_pixel_shuffle2_fwd(x.data_ptr(), ld_of(x), out.data_ptr(), ld_of(out), B, H, W, C4 // 4, stream_ptr()),
+          "mtd_pixel_shuffle2_fwd")
+    return out
+
+
+def pixel_shuffle2_bwd(gout, gin):
+    B, H, W, C4 = gin.shape
+    check(_lib.lib().mtd_pixel_shuffle2_bwd(gout.data_ptr(), ld_of(gout), gin.data_ptr(), ld_of(gin), B, H, W, C4 // 4, stream_ptr()),
+          "mtd_pixel_shuffle2_bwd")
+    return gin
+
+
+def mul(a, b, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    check(_lib.lib().mtd_mul(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), stream_ptr()), "mtd_mul")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- descriptor tables
+_desc_cache = {}
+
+
+def device_table(structs, device):
+    """Upload an array of ctypes structs once per distinct content (pointers included); returns
+    (device tensor, host ctypes array).  Keeps the host array alive for the C call."""
+    n = len(structs)
+    arr = (type(structs[0]) * n)(*structs)
+    raw = bytes(arr)
+    key = (device.index, raw)
+    hit = _desc_cache.get(key)
+    if hit is None:
+        if len(_desc_cache) > 512:
+            _desc_cache.clear()
+        host = torch.frombuffer(bytearray(raw), dtype=torch.uint8).pin_memory()
+        dev = host.to(device, non_blocking=True)
+        hit = (dev, arr, host)
+        _desc_cache[key] = hit
+    return hit[0], hit[1]
+
+
+# ---------------------------------------------------------------------------------------------- losses
+def loss_terms(terms, device):
+    """terms: list of _lib.LossTerm.  Returns a float tensor [len(terms)] of scale * sum(term)."""
+    L = _lib.lib()
+    tab, _host = device_table(terms, device)
+    out = torch.empty(len(terms), dtype=torch.float32, device=device)
+    ws = workspace(L.mtd_loss_terms_ws_bytes(len(terms)), device)
+    check(L.mtd_loss_terms(tab.data_ptr(), len(terms), out.data_ptr(), ws.data_ptr(), stream_ptr()), "mtd_loss_terms")
+    return out
+
+
+def loss_term_grads(terms, device):
+    tab, _host = device_table(terms, device)
+    check(_lib.lib().mtd_loss_term_grads(tab.data_ptr(), len(terms), stream_ptr()), "mtd_loss_term_grads")
+
+
+def make_term(kind, a, b=None, tconst=0.0, mx=None, my=None, scale=1.0, eps=0.0, grad_out=None, coef=0.0, accumulate=False):
+    t = _lib.LossTerm()
+    t.kind = kind
+    t.a, t.b, t.tconst = a.data_ptr(), (b.data_ptr() if b is not None else None), float(tconst)
+    t.mx, t.my = (mx.data_ptr() if mx is not None else None), (my.data_ptr() if my is not None else None)
+    t.n, t.scale, t.eps = a.numel(), float(scale), float(eps)
+    t.grad_out = grad_out.data_ptr() if grad_out is not None else None
+    t.coef, t.accumulate = float(coef), 1 if accumulate else 0
+    return t
+
+
+def clip01(x):
+    out = torch.empty_like(x)
+    check(_lib.lib().mtd_clip01(x.data_ptr(), out.data_ptr(), x.numel(), stream_ptr()), "mtd_clip01")
+    return out
+
+
+def clip01_bwd(g, x):
+    out = torch.empty_like(x)
+    check(_lib.lib().mtd_clip01_bwd(g.data_ptr(), x.data_ptr(), out.data_ptr(), x.numel(), stream_ptr()), "mtd_clip01_bwd")
+    return out
+
+
+def edge_loss(a, b, scale, eps=1e-3, grad_out=None, coef=0.0, accumulate=False):
+    """a, b: (B,64,64,1) contiguous.  Returns a 1-element tensor scale * sum sqrt(lap(a-b)^2+eps^2)."""
+    L = _lib.lib()
+    B = a.shape[0]
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    ws = workspace(L.mtd_edge_loss_ws_bytes(B), a.device)
+    check(L.mtd_edge_loss(a.data_ptr(), b.data_ptr(), B, float(scale), float(eps), out.data_ptr(),
+                          grad_out.data_ptr() if grad_out is not None else None, float(coef), 1 if accumulate else 0,
+                          ws.data_ptr(), stream_ptr()), "mtd_edge_loss")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- PCGrad / AdamW
+def pcgrad_gram(vecs):
+    L = _lib.lib()
+    T, n = len(vecs), vecs[0].numel()
+    gram = torch.empty(T * T, dtype=torch.float64, device=vecs[0].device)
+    ws = workspace(L.mtd_pcgrad_ws_bytes(n, T), vecs[0].device)
+    ptrs = [v.data_ptr() for v in vecs] + [None] * (4 - T)
+    check(L.mtd_pcgrad_gram(ptrs[0], ptrs[1], ptrs[2], ptrs[3], T, n, gram.data_ptr(), ws.data_ptr(), stream_ptr()), "mtd_pcgrad_gram")
+    return gram
+
+
+def pcgrad_combine(vecs, gram, orders_dev, merged):
+    L = _lib.lib()
+    T, n = len(vecs), vecs[0].numel()
+    coeff = torch.empty(4, dtype=torch.float32, device=vecs[0].device)
+    ptrs = [v.data_ptr() for v in vecs] + [None] * (4 - T)
+    check(L.mtd_pcgrad_combine(ptrs[0], ptrs[1], ptrs[2], ptrs[3], T, n, gram.data_ptr(), orders_dev.data_ptr(), merged.data_ptr(),
+                               coeff.data_ptr(), stream_ptr()), "mtd_pcgrad_combine")
+    return coeff
+
+
+def adamw_multi(params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, wd):
+    L = _lib.lib()
+    structs = []
+    for p, g, m, v in zip(params, grads, exp_avg, exp_avg_sq):
+        t = _lib.AdamwTensor()
+        t.p, t.g, t.m, t.v, t.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+        structs.append(t)
+    tab, host = device_table(structs, params[0].device)
+    check(L.mtd_adamw_multi(tab.data_ptr(), C.cast(host, C.c_void_p), len(structs), float(lr), float(beta1), float(beta2), float(eps),
+                            float(wd), int(step), stream_ptr()), "mtd_adamw_multi")

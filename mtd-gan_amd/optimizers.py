@@ -1,0 +1,41 @@
+"""Fused multi-tensor AdamW with torch.optim.AdamW's update rule as the reference wires it
+(train.py:122-126, optimizers.py:8-9: lr, betas (0.9, 0.999), eps 1e-8, weight_decay 5e-4, no amsgrad).
+One HIP launch per step() over every parameter that has a gradient; parameters whose .grad is None are
+skipped exactly like torch.optim (this is what keeps the reference's `c_fc` frozen)."""
+import torch
+
+from . import kernels as K
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            by_step = {}
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise RuntimeError("FusedAdamW: HIP path needs CUDA parameters")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                by_step.setdefault(st["step"], []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
+            for step, items in by_step.items():
+                b1, b2 = group["betas"]
+                K.adamw_multi([i[0] for i in items], [i[1] for i in items], [i[2] for i in items], [i[3] for i in items],
+                              step, group["lr"], b1, b2, group["eps"], group["weight_decay"])
+
+
+def get_optimizer(name, model, lr):
+    """reference optimizers.py:4-14 ('adamw' is what train.py uses for both networks)."""
+    if name == "adamw":
+        return FusedAdamW(model.parameters(), lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+    raise KeyError(name)

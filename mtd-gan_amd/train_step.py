@@ -1,0 +1,250 @@
+"""The fused discriminator / generator steps behind MTD_GAN_Method.d_loss / .g_loss and
+WeightMethods('pcgrad').backward (reference: arch/Ours/networks.py:1957-2009, module/weight_methods.py:
+429-468, engine.py:33-55).
+
+d_loss records the four discriminator passes on tapes and returns the stacked task losses; the PCGrad
+step then replays the tapes once per task (un-stacked: no zero-cotangent traversals), writing
+each task's shared-parameter gradient into its own flat vector and the task-specific gradients (only their
+sum is needed) into one set of buffers; a Gram pass + a combine pass implement the projection.  g_loss is
+one autograd node: G forward, one D pass without the restoration decoder, loss kernels; its backward
+replays D for the input gradient only (the reference's D weight gradients in the G step are discarded by
+the next zero_grad) and then the generator.  Nothing here synchronises with the host.
+"""
+import random
+
+import torch
+
+from . import discriminator_path as DP
+from . import generator_path as GP
+from . import kernels as K
+
+NPIX = 64 * 64
+
+
+def _nhwc1(t):
+    return t.contiguous().reshape(t.shape[0], 64, 64, 1)
+
+
+# ================================================================================================ D step
+class DStepTape:
+    def __init__(self, method, P, passes, outs, x, y, fake):
+        self.method, self.P, self.passes, self.outs = method, P, passes, outs
+        self.x, self.y, self.fake = x, y, fake
+        self.consumed = False
+
+    def run_pcgrad(self, shared_params, task_specific_params, reduction="sum", dp=None):
+        """Per-task backward + PCGrad projection.  Writes .grad of every listed parameter.
+        dp: optional data-parallel hook with .all_reduce_avg(flat_tensor) (see parallel.py)."""
+        D = self.method.Discriminator
+        dev = self.x.device
+        B = self.x.shape[0]
+        n = B * NPIX
+        by_id = {id(p): nme for nme, p in D.named_parameters()}
+        sh_names = [by_id[id(p)] for p in shared_params]
+        ts_names = [by_id[id(p)] for p in (task_specific_params or [])]
+        sizes = [D.get_parameter(nme).numel() for nme in sh_names]
+        total = sum(sizes)
+        S = torch.zeros((4, total), dtype=torch.float32, device=dev)       # 3 task vectors + merged
+        TSbuf = {nme: torch.zeros_like(D.get_parameter(nme)) for nme in ts_names}
+        sinks = []
+        for i in range(3):
+            t, ofs = dict(TSbuf), 0
+            for nme, sz in zip(sh_names, sizes):
+                t[nme] = S[i, ofs:ofs + sz]
+                ofs += sz
+            sinks.append(DP.GradSink(t))
+        (re, rd, rr), (fe, fd, fr), (rre, rrd), (rfe, rfd) = self.outs
+        t1, t2, t3, t4 = self.passes
+        rt, P = D._rt, self.P
+        e = lambda: torch.empty((B, 1, 1, 1), dtype=torch.float32, device=dev)
+        m = lambda: torch.empty((B, 64, 64, 1), dtype=torch.float32, device=dev)
+        x, y, fake = self.x, self.y, self.fake
+        # ---- all output cotangents of the three tasks in one launch
+        g = {k: (e() if k.endswith("e") else m()) for k in
+             ("d_re", "d_fe", "c_re", "c_fe", "c_rre", "c_rfe", "d_rd", "d_fd", "r_rr", "r_fr", "c_rd", "c_fd", "c_rrd", "c_rfd")}
+        T = K.make_term
+        K.loss_term_grads([
+            T(0, re, tconst=1.0, grad_out=g["d_re"], coef=1.0 / B), T(0, fe, tconst=0.0, grad_out=g["d_fe"], coef=1.0 / B),
+            T(0, rd, tconst=1.0, mx=x, my=y, grad_out=g["d_rd"], coef=1.0 / n), T(0, fd, tconst=0.0, mx=x, my=y, grad_out=g["d_fd"], coef=1.0 / n),
+            T(1, rr, y, grad_out=g["r_rr"], coef=1.0 / n), T(1, fr, fake, grad_out=g["r_fr"], coef=1.0 / n),
+            T(0, re, rre, grad_out=g["c_re"], coef=1.0 / B), T(0, rre, re, grad_out=g["c_rre"], coef=1.0 / B),
+            T(0, rd, rrd, grad_out=g["c_rd"], coef=1.0 / n), T(0, rrd, rd, grad_out=g["c_rrd"], coef=1.0 / n),
+            T(0, fe, rfe, grad_out=g["c_fe"], coef=1.0 / B), T(0, rfe, fe, grad_out=g["c_rfe"], coef=1.0 / B),
+            T(0, fd, rfd, grad_out=g["c_fd"], coef=1.0 / n), T(0, rfd, fd, grad_out=g["c_rfd"], coef=1.0 / n)], dev)
+        # ---- task 0: adversarial (image-level + pixel-level)
+        DP.disc_backward(rt, P, t1, g["d_re"], g["d_rd"], None, sinks[0], False)
+        DP.disc_backward(rt, P, t2, g["d_fe"], g["d_fd"], None, sinks[0], False)
+        self._sync_task(dp, S, 0)
+        # ---- task 1: restoration
+        DP.disc_backward(rt, P, t1, None, None, g["r_rr"], sinks[1], False)
+        DP.disc_backward(rt, P, t2, None, None, g["r_fr"], sinks[1], False)
+        self._sync_task(dp, S, 1)
+        # ---- task 2: consistency (through D(real_rec.clip) back into the restoration decoder of pass 1)
+        gin3 = DP.disc_backward(rt, P, t3, g["c_rre"], g["c_rrd"], None, sinks[2], True)
+        DP.disc_backward(rt, P, t1, g["c_re"], g["c_rd"], K.clip01_bwd(gin3, rr), sinks[2], False)
+        gin4 = DP.disc_backward(rt, P, t4, g["c_rfe"], g["c_rfd"], None, sinks[2], True)
+        DP.disc_backward(rt, P, t2, g["c_fe"], g["c_fd"], K.clip01_bwd(gin4, fr), sinks[2], False)
+        self._sync_task(dp, S, 2)
+        if dp is not None and ts_names:
+            dp.all_reduce_avg_list([TSbuf[nme] for nme in ts_names])
+        if dp is not None:
+            dp.wait()
+        # ---- PCGrad: Gram of the original task gradients, replay of the projections, combine
+        orders = shuffle_orders(3)
+        orders_dev = torch.tensor([j for o in orders for j in o], dtype=torch.int32).to(dev, non_blocking=True)
+        vecs = [S[0], S[1], S[2]]
+        gram = K.pcgrad_gram(vecs)
+        coeff = K.pcgrad_combine(vecs, gram, orders_dev, S[3])
+        merged = S[3]
+        if reduction == "mean":
+            merged = merged / 3.0
+        ofs = 0
+        for p, sz in zip(shared_params, sizes):
+            p.grad = merged[ofs:ofs + sz].view_as(p)
+            ofs += sz
+        for p, nme in zip(task_specific_params or [], ts_names):
+            p.grad = TSbuf[nme]
+        self.gram, self.coeff, self.orders, self.task_vectors = gram, coeff, orders, S
+        self.consumed = True
+
+    @staticmethod
+    def _sync_task(dp, S, i):
+        if dp is not None:
+            dp.all_reduce_avg(S[i])            # overlaps with the next task's backward (separate stream)
+
+
+def shuffle_orders(T):
+    """Index orders produced by the reference's cumulative in-place `random.shuffle(grads)` per i
+    (module/weight_methods.py:452): same consumption of Python's `random` stream."""
+    idx = list(range(T))
+    out = []
+    for _ in range(T):
+        random.shuffle(idx)
+        out.append(list(idx))
+    return out
+
+
+def d_loss(method, x, y):
+    D, G = method.Discriminator, method.Generator
+    if not x.is_cuda:
+        raise RuntimeError("MTD_GAN_Method.d_loss: HIP path needs CUDA tensors")
+    B, dev = x.shape[0], x.device
+    with torch.no_grad():
+        fake = G(x)                                       # networks.py:1958 (.detach())
+    xn, yn, fn = _nhwc1(x.float()), _nhwc1(y.float()), _nhwc1(fake)
+    P = D._param_dict()
+    train = D.training
+    (re, rd, rr), t1 = DP.disc_forward(P, yn, train, D._next_mask(B, dev), True, True)
+    (fe, fd, fr), t2 = DP.disc_forward(P, fn, train, D._next_mask(B, dev), True, True)
+    (rre, rrd, _), t3 = DP.disc_forward(P, K.clip01(rr), train, D._next_mask(B, dev), False, True)
+    (rfe, rfd, _), t4 = DP.disc_forward(P, K.clip01(fr), train, D._next_mask(B, dev), False, True)
+    n = B * NPIX
+    T = K.make_term
+    v = K.loss_terms([
+        T(0, re, tconst=1.0, scale=1.0 / B), T(0, fe, tconst=0.0, scale=1.0 / B),
+        T(0, rd, tconst=1.0, mx=xn, my=yn, scale=1.0 / n), T(0, fd, tconst=0.0, mx=xn, my=yn, scale=1.0 / n),
+        T(1, rr, yn, scale=1.0 / n), T(1, fr, fn, scale=1.0 / n),
+        T(0, re, rre, scale=1.0 / B), T(0, rd, rrd, scale=1.0 / n), T(0, fe, rfe, scale=1.0 / B), T(0, fd, rfd, scale=1.0 / n)], dev)
+    losses = torch.stack([v[0:4].sum(), v[4:6].sum(), v[6:10].sum()])        # 10 scalars: host-side bookkeeping
+    keys = ["D/real_enc", "D/fake_enc", "D/real_dec", "D/fake_dec", "D/rec_loss_real", "D/rec_loss_fake",
+            "D/consist_loss_real_enc", "D/consist_loss_real_dec", "D/consist_loss_fake_enc", "D/consist_loss_fake_dec"]
+    details = {k: v[i] for i, k in enumerate(keys)}
+    losses._mtd_tape = DStepTape(method, P, (t1, t2, t3, t4), ((re, rd, rr), (fe, fd, fr), (rre, rrd), (rfe, rfd)), xn, yn, fn)
+    return losses, details
+
+
+# ================================================================================================ G step
+class _GStepFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, method, nlayers, *gparams):
+        from .arch.Ours import networks as N
+        D = method.Discriminator
+        B, dev = x.shape[0], x.device
+        xn, yn = _nhwc1(x.float()), _nhwc1(y.float())
+        GPm = N._unflatten_gen(gparams, nlayers)
+        need = any(ctx.needs_input_grad)
+        fake, gtape = GP.generator_forward(xn, GPm, need)
+        P = D._param_dict()
+        (ge, gd, _), dtape = DP.disc_forward(P, fake, D.training, D._next_mask(B, dev), False, need)
+        n = B * NPIX
+        T = K.make_term
+        v = K.loss_terms([T(0, ge, tconst=1.0, scale=1.0 / B), T(0, gd, tconst=1.0, mx=xn, my=yn, scale=1.0 / n),
+                          T(2, fake, yn, scale=50.0 / n, eps=method.pixel_loss.eps)], dev)
+        edge = K.edge_loss(fake, yn, 50.0 / n, method.edge_loss.loss.eps)
+        total = v.sum() + edge[0]
+        if need:
+            ctx.state = (method, GPm, nlayers, gtape, dtape, P, ge, gd, fake, xn, yn)
+        ctx.mark_non_differentiable(v, edge)
+        return total, v, edge
+
+    @staticmethod
+    def backward(ctx, g_total, _gv, _ge):
+        from .arch.Ours import networks as N
+        method, GPm, nlayers, gtape, dtape, P, ge, gd, fake, xn, yn = ctx.state
+        D = method.Discriminator
+        B, dev = xn.shape[0], xn.device
+        n = B * NPIX
+        g_e = torch.empty((B, 1, 1, 1), dtype=torch.float32, device=dev)
+        g_d = torch.empty((B, 64, 64, 1), dtype=torch.float32, device=dev)
+        T = K.make_term
+        K.loss_term_grads([T(0, ge, tconst=1.0, grad_out=g_e, coef=1.0 / B), T(0, gd, tconst=1.0, mx=xn, my=yn, grad_out=g_d, coef=1.0 / n)], dev)
+        g_fake = DP.disc_backward(D._rt, P, dtape, g_e, g_d, None, None, True)        # input gradient only
+        K.loss_term_grads([T(2, fake, yn, eps=method.pixel_loss.eps, grad_out=g_fake, coef=50.0 / n, accumulate=True)], dev)
+        K.edge_loss(fake, yn, 50.0 / n, method.edge_loss.loss.eps, grad_out=g_fake, coef=50.0 / n, accumulate=True)
+        g_fake = g_fake * g_total                                                        # upstream scalar (== 1 from .backward())
+        flat = N._flatten_gen(GPm)
+        gflat = [torch.empty_like(p) for p in flat]
+        GP.generator_backward(g_fake, gtape, GPm, N._unflatten_gen(gflat, nlayers, as_grad=True))
+        ctx.state = None
+        return (None, None, None, None) + tuple(gflat)
+
+
+def g_loss(method, x, y):
+    G = method.Generator
+    if not x.is_cuda:
+        raise RuntimeError("MTD_GAN_Method.g_loss: HIP path needs CUDA tensors")
+    total, v, edge = _GStepFn.apply(x, y, method, G._cfg[2], *G._flat_params())
+    details = {"G/gen_enc": v[0], "G/gen_dec": v[1], "G/pix_loss": v[2], "G/edge_loss": edge[0]}
+    return total, details
+
+
+# ================================================================================================ bench workload
+class FullStepWorkload:
+    """BASELINE config 3: full G + D + PCGrad training iteration (engine.train_MTD_GAN_Ours body) on
+    32 patches per GPU; for N > 1 the per-task gradients are all-reduced before the projection so the
+    result equals the single-process large-batch step."""
+
+    name = "full_step"
+    gflop_per_patch = 105.6
+
+    def __init__(self, dev, rank, world, batch):
+        from .arch.Ours.networks import MTD_GAN_Method
+        from .data import synthetic_ldct
+        from .module.weight_methods import WeightMethods
+        from .optimizers import FusedAdamW
+        from . import parallel
+        torch.manual_seed(2024)
+        random.seed(2024)
+        self.model = MTD_GAN_Method().to(dev)
+        self.model.train()
+        x, y = synthetic_ldct(batch, seed=1234 + rank)
+        self.x, self.y = x.to(dev), y.to(dev)
+        self.world, self.batch = world, batch
+        self.wm = WeightMethods("pcgrad", n_tasks=3, device=dev)
+        self.oD = FusedAdamW(self.model.Discriminator.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+        self.oG = FusedAdamW(self.model.Generator.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+        self.dp = parallel.DataParallelSync(dev) if world > 1 else None
+        if self.dp is not None:
+            self.dp.broadcast_module(self.model)
+            self.wm.method.dp = self.dp
+
+    def step(self):
+        from . import engine
+        engine.train_iteration(self.model, self.x, self.y, self.oG, self.oD, self.wm, self.dp)
+
+    def config(self, world):
+        return {"workload": "Full G+D+PCGrad train step (BASELINE configs[2]; configs[3] when N>1)", "per_gpu_batch": self.batch,
+                "global_batch": self.batch * world, "patch": "1x64x64", "parallelism": f"dp{world}"}
+
+    def extra(self):
+        return {"algorithmic_gflop_per_patch": self.gflop_per_patch}

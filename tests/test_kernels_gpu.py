@@ -1,0 +1,234 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against plain PyTorch CPU fp32
+references of the same op (conv2d / conv_transpose2d / autograd / interpolate / pixel_shuffle) and the
+oracle's spectral path.  Tolerance: 1e-3 relative to the tensor's max-abs (north_star), most land ~1e-6."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def nhwc(t):   # NCHW cpu -> NHWC cuda
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):   # NHWC cuda -> NCHW cpu
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def relerr(a, b):
+    return (a.double() - b.double()).abs().max().item() / (b.double().abs().max().item() + 1e-30)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+CONV_CASES = [
+    # B, Cin, Cout, H, W, k, s, p
+    (2, 32, 32, 64, 64, 3, 1, 1),     # generator conv, cfg 256x32
+    (1, 32, 32, 8, 8, 3, 1, 1),       # small-M 128x32, split-K
+    (2, 64, 64, 32, 32, 3, 1, 1),     # 256x64
+    (2, 64, 64, 16, 16, 4, 2, 1),     # strided 4x4, 64x64 tile
+    (2, 64, 128, 16, 16, 3, 1, 1),    # 128x128
+    (3, 256, 512, 4, 4, 3, 1, 1),     # deep layer, M=48 -> 32x128 tiles, split-K, tap skipping
+    (2, 512, 512, 2, 2, 3, 1, 1),
+    (2, 512, 512, 2, 2, 4, 2, 1),     # -> 1x1
+    (2, 512, 512, 1, 1, 1, 1, 0),     # bconv (1x1)
+    (2, 128, 256, 8, 8, 1, 1, 0),
+    (2, 1, 32, 64, 64, 3, 1, 1),      # direct: Cin = 1
+    (2, 128, 1, 16, 16, 3, 1, 1),     # direct: Cout = 1
+    (2, 1, 1, 16, 16, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(hip_lib, case):
+    from mtd_gan_amd import kernels as K
+    B, Ci, Co, H, W, k, s, p = case
+    x = rnd(B, Ci, H, W, seed=1).requires_grad_(True)
+    w = rnd(Co, Ci, k, k, seed=2, scale=(Ci * k * k) ** -0.5).requires_grad_(True)
+    b = rnd(Co, seed=3, scale=0.1).requires_grad_(True)
+    y = F.conv2d(x, w, b, stride=s, padding=p)
+    ref = F.leaky_relu(y * 0.7, 0.2)     # exercises scale + bias + act (bias is added after the scale)
+    # library computes act(scale*conv + bias): fold so both agree
+    ref = F.leaky_relu(F.conv2d(x, w, None, stride=s, padding=p) * 0.7 + b.view(1, -1, 1, 1), 0.2)
+    cot = rnd(*ref.shape, seed=4)
+    (ref * cot).sum().backward()
+    OH, OW = y.shape[2:]
+    xd, wd, bd = nhwc(x.detach()), w.detach().cuda(), b.detach().cuda()
+    scale = torch.tensor([0.7], device="cuda")
+    out = torch.empty(B, OH, OW, Co, device="cuda")
+    K.conv(xd, wd, K.geom_fwd(B, H, W, k, s, p), Co, Ci, Ci * k * k, k * k, out, scale=scale, bias=bd, act=K.ACT_LRELU)
+    assert relerr(nchw(out), ref.detach()) < TOL
+    # gradient w.r.t. pre-activation, then dgrad / wgrad
+    gpre = K.act_grad(nhwc(cot), out, 0.2)
+    gpre_ref = cot * torch.where(ref.detach() > 0, 1.0, 0.2)
+    assert relerr(nchw(gpre), gpre_ref) < TOL
+    dx = torch.empty(B, H, W, Ci, device="cuda")
+    if s == 1:
+        K.conv(gpre, wd, K.geom_dgrad_s1(B, H, W, k, p), Ci, Co, k * k, Ci * k * k, dx, scale=scale)
+    else:
+        for py in range(2):
+            for px in range(2):
+                K.conv(gpre, wd, K.geom_dgrad_s2(B, H, W, py, px), Ci, Co, k * k, Ci * k * k, dx, scale=scale)
+    assert relerr(nchw(dx), x.grad) < TOL
+    dw = torch.empty_like(wd)
+    db = torch.empty_like(bd)
+    K.wgrad(gpre, xd, K.geom_fwd(B, H, W, k, s, p), Co, Ci, dw, Ci * k * k, k * k, db=db)
+    assert relerr(dw.cpu() * 0.7, w.grad) < TOL
+    assert relerr(db.cpu(), b.grad) < TOL
+    # accumulate mode
+    K.wgrad(gpre, xd, K.geom_fwd(B, H, W, k, s, p), Co, Ci, dw, Ci * k * k, k * k, db=db, accumulate=True)
+    assert relerr(dw.cpu() * 0.35, w.grad) < TOL
+
+
+def test_conv_epilogue_adds_and_mask(hip_lib):
+    from mtd_gan_amd import kernels as K
+    B, C, H, W = 2, 32, 16, 16
+    x, w = rnd(B, C, H, W, seed=5), rnd(C, C, 3, 3, seed=6, scale=0.06)
+    a1, a2, m = rnd(B, C, H, W, seed=7), rnd(B, C, H, W, seed=8), rnd(B, C, H, W, seed=9)
+    ref = (F.conv2d(x, w, padding=1) + a1 + a2) * torch.where(m > 0, 1.0, 0.2)
+    out = torch.empty(B, H, W, C, device="cuda")
+    K.conv(nhwc(x), w.cuda(), K.geom_fwd(B, H, W, 3, 1, 1), C, C, C * 9, 9, out, add1=nhwc(a1), add2=nhwc(a2), mask=nhwc(m), mask_slope=0.2)
+    assert relerr(nchw(out), ref) < TOL
+    # channel-slice views (concat buffers): input read from, and output written into, wider tensors
+    wide_in = torch.zeros(B, H, W, 96, device="cuda")
+    wide_in[..., 32:64] = nhwc(x)
+    wide_out = torch.zeros(B, H, W, 64, device="cuda")
+    K.conv(wide_in[..., 32:64], w.cuda(), K.geom_fwd(B, H, W, 3, 1, 1), C, C, C * 9, 9, wide_out[..., 32:64])
+    assert relerr(nchw(wide_out[..., 32:64]), F.conv2d(x, w, padding=1)) < TOL
+    assert wide_out[..., :32].abs().max().item() == 0.0
+
+
+def test_conv_transpose_views(hip_lib):
+    """ConvTranspose2d(k3,s1,p1) forward / dgrad / wgrad through the strided IOHW weight view."""
+    from mtd_gan_amd import kernels as K
+    B, Ci, Co, H, W = 2, 32, 32, 16, 16
+    for Co in (32, 1):
+        x = rnd(B, Ci, H, W, seed=11).requires_grad_(True)
+        wt = rnd(Ci, Co, 3, 3, seed=12, scale=0.06).requires_grad_(True)
+        ref = F.conv_transpose2d(x, wt, padding=1)
+        cot = rnd(*ref.shape, seed=13)
+        (ref * cot).sum().backward()
+        out = torch.empty(B, H, W, Co, device="cuda")
+        gt, gf = K.geom_dgrad_s1(B, H, W, 3, 1), K.geom_fwd(B, H, W, 3, 1, 1)
+        K.conv(nhwc(x.detach()), wt.detach().cuda(), gt, Co, Ci, 9, Co * 9, out)
+        assert relerr(nchw(out), ref.detach()) < TOL
+        dx = torch.empty(B, H, W, Ci, device="cuda")
+        K.conv(nhwc(cot), wt.detach().cuda(), gf, Ci, Co, Co * 9, 9, dx)
+        assert relerr(nchw(dx), x.grad) < TOL
+        dw = torch.empty(Ci, Co, 3, 3, device="cuda")
+        K.wgrad(nhwc(cot), nhwc(x.detach()), gt, Co, Ci, dw, 9, Co * 9)
+        assert relerr(dw.cpu(), wt.grad) < TOL
+
+
+def test_linear_as_1x1(hip_lib):
+    from mtd_gan_amd import kernels as K
+    B = 32
+    x = rnd(B, 512, seed=21).requires_grad_(True)
+    w = rnd(512, 512, seed=22, scale=0.04).requires_grad_(True)
+    b = rnd(512, seed=23, scale=0.1)
+    ref = F.linear(x, w, b)
+    cot = rnd(B, 512, seed=24)
+    (ref * cot).sum().backward()
+    xd = x.detach().cuda().reshape(B, 1, 1, 512)
+    out = torch.empty(B, 1, 1, 512, device="cuda")
+    g = K.geom_fwd(B, 1, 1, 1, 1, 0)
+    K.conv(xd, w.detach().cuda(), g, 512, 512, 512, 1, out, bias=b.cuda())
+    assert relerr(out.cpu().reshape(B, 512), ref.detach()) < TOL
+    dx = torch.empty(B, 1, 1, 512, device="cuda")
+    K.conv(cot.cuda().reshape(B, 1, 1, 512), w.detach().cuda(), g, 512, 512, 1, 512, dx)
+    assert relerr(dx.cpu().reshape(B, 512), x.grad) < TOL
+    dw = torch.empty(512, 512, device="cuda")
+    K.wgrad(cot.cuda().reshape(B, 1, 1, 512), xd, g, 512, 512, dw, 512, 1)
+    assert relerr(dw.cpu(), w.grad) < TOL
+    # Linear 512 -> 1 (enc_out): direct path
+    w1 = rnd(1, 512, seed=25, scale=0.04).requires_grad_(True)
+    x2 = x.detach().clone().requires_grad_(True)
+    r1 = F.linear(x2, w1)
+    c1 = rnd(B, 1, seed=26)
+    (r1 * c1).sum().backward()
+    o1 = torch.empty(B, 1, 1, 1, device="cuda")
+    K.conv(xd, w1.detach().cuda(), g, 1, 512, 512, 1, o1)
+    assert relerr(o1.cpu().reshape(B, 1), r1.detach()) < TOL
+    dw1 = torch.empty(1, 512, device="cuda")
+    db1 = torch.empty(1, device="cuda")
+    K.wgrad(c1.cuda().reshape(B, 1, 1, 1), xd, g, 1, 512, dw1, 512, 1, db=db1)
+    assert relerr(dw1.cpu(), w1.grad) < TOL
+    assert relerr(db1.cpu(), c1.sum().reshape(1)) < TOL
+    dx1 = torch.empty(B, 1, 1, 512, device="cuda")
+    K.conv(c1.cuda().reshape(B, 1, 1, 1), w1.detach().cuda(), g, 512, 1, 1, 512, dx1)
+    assert relerr(dx1.cpu().reshape(B, 512), x2.grad) < TOL
+
+
+def test_upsample_and_pixel_shuffle(hip_lib):
+    from mtd_gan_amd import kernels as K
+    for (B, C, H, W) in [(2, 64, 1, 1), (2, 32, 2, 2), (2, 16, 8, 8), (1, 8, 5, 3)]:
+        x = rnd(B, C, H, W, seed=31).requires_grad_(True)
+        ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+        cot = rnd(*ref.shape, seed=32)
+        (ref * cot).sum().backward()
+        out = torch.empty(B, 2 * H, 2 * W, C, device="cuda")
+        K.upsample2x_fwd(nhwc(x.detach()), out)
+        assert relerr(nchw(out), ref.detach()) < 1e-6
+        gin = torch.empty(B, H, W, C, device="cuda")
+        K.upsample2x_bwd(nhwc(cot), gin)
+        assert relerr(nchw(gin), x.grad) < 1e-6
+    x = rnd(2, 64, 4, 4, seed=33)
+    ref = F.pixel_shuffle(x, 2)
+    out = torch.empty(2, 8, 8, 16, device="cuda")
+    K.pixel_shuffle2_fwd(nhwc(x), out)
+    assert torch.equal(nchw(out), ref)
+    back = torch.empty(2, 4, 4, 64, device="cuda")
+    K.pixel_shuffle2_bwd(out, back)
+    assert torch.equal(nchw(back), x)
+    # strided copy into a concat buffer
+    cat = torch.zeros(2, 8, 8, 48, device="cuda")
+    K.copy_channels(out, cat[..., 32:48])
+    assert torch.equal(cat[..., 32:48].cpu(), out.cpu())
+    K.copy_channels(out, cat[..., 32:48], accumulate=True)
+    assert torch.equal(cat[..., 32:48].cpu(), 2 * out.cpu())
+
+
+def test_spectral_path_kernels(hip_lib):
+    """rows -> columns+mix -> rows against torch.fft on the CPU (forward and backward)."""
+    from mtd_gan_amd import kernels as K
+    B = 2
+    x = rnd(B, 32, 64, 64, seed=41, scale=0.5).requires_grad_(True)
+    w2 = rnd(64, 64, 1, 1, seed=42, scale=0.125).requires_grad_(True)
+    b2 = rnd(64, seed=43, scale=0.1).requires_grad_(True)
+    f = torch.fft.rfft2(x, s=(64, 64), dim=(2, 3), norm="ortho")
+    cat = torch.cat([f.real, f.imag], dim=1)
+    z = F.conv2d(cat, w2, b2)
+    zr, zi = torch.chunk(F.relu(z), 2, dim=1)
+    y = torch.fft.irfft2(torch.complex(zr, zi), s=(64, 64), dim=(2, 3), norm="ortho")
+    cot = rnd(*y.shape, seed=44)
+    (y * cot).sum().backward()
+    xd = nhwc(x.detach())
+    R = K.rfft_rows(xd, 0)
+    # rows check: R[b, kw, h, 0/1, c] = rfft along W / 8
+    fr = torch.fft.rfft(x.detach(), dim=3, norm="ortho")          # (B, C, H, 33)
+    Rr = R.cpu().reshape(B, 33, 64, 2, 32)
+    assert relerr(Rr[:, :, :, 0, :], fr.real.permute(0, 3, 2, 1)) < 1e-5
+    assert relerr(Rr[:, :, :, 1, :], fr.imag.permute(0, 3, 2, 1)) < 1e-5
+    w2d = w2.detach().cuda().reshape(64, 64)
+    T, S, Z = K.spec_mix_fwd(R, K.transpose64(w2d), b2.detach().cuda(), True)
+    Sr = S.cpu().reshape(B, 33, 64, 64)                           # [b, kw, kh, cat]
+    assert relerr(Sr, cat.detach().permute(0, 3, 2, 1)) < 1e-5
+    assert relerr(Z.cpu().reshape(B, 33, 64, 64), z.detach().permute(0, 3, 2, 1)) < 1e-5
+    out = torch.empty(B, 64, 64, 32, device="cuda")
+    K.irfft_rows(T, out)
+    assert relerr(nchw(out), y.detach()) < 1e-5
+    # backward
+    gR = K.rfft_rows(nhwc(cot), 1)
+    dw2 = torch.empty(64, 64, device="cuda")
+    db2 = torch.empty(64, device="cuda")
+    gT = K.spec_mix_bwd(gR, w2d, S, Z, dw2, db2)
+    gx = torch.empty(B, 64, 64, 32, device="cuda")
+    K.irfft_rows(gT, gx)
+    assert relerr(nchw(gx), x.grad) < 1e-4
+    assert relerr(dw2.cpu(), w2.grad.reshape(64, 64)) < 1e-4
+    assert relerr(db2.cpu(), b2.grad) < 1e-4

@@ -1,0 +1,112 @@
+"""CPU tests: the oracle (oracle/mtdgan_oracle.py) against the committed golden vectors that
+oracle/pin_against_reference.py generated from the real reference.  Runs anywhere (no GPU, no reference)."""
+import json
+import os
+import random
+
+import numpy as np
+import torch
+
+import mtdgan_oracle as orc
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+
+
+def test_block_matches_reference_vectors():
+    z = np.load(os.path.join(GOLD, "block.npz"))
+    st = {k: v.clone().requires_grad_(True) for k, v in orc.seeded_fill(orc.g_param_shapes(), seed=7).items() if k.startswith("enforce.0.")}
+    gen = torch.Generator().manual_seed(11)
+    x = (torch.randn(2, 32, 64, 64, generator=gen) * 0.5).requires_grad_(True)
+    out = orc._blk(st, 0, x)
+    cot = torch.randn(out.shape, generator=gen)
+    (out * cot).sum().backward()
+    assert rel(out.detach()[:, ::8, ::4, ::4], z["out_sample"]) < 1e-5
+    assert abs(out.detach().double().sum().item() - float(z["out_sum"])) < 1e-3 * float(z["out_abs"]) * 1e-3
+    assert rel(x.grad[:, ::8, ::4, ::4], z["dx_sample"]) < 1e-5
+    assert rel(st["enforce.0.fft_conv.weight"].grad, z["g_fft_conv_weight"]) < 1e-4
+    assert rel(st["enforce.0.img_conv.weight"].grad.double().norm(), z["gn_img_conv_weight"]) < 1e-5
+    # the explicit irfft2 formula (what the HIP rows kernel implements) agrees as well
+    out_e = orc._blk(st, 0, x, explicit_irfft=True)
+    assert rel(out_e.detach(), out.detach()) < 1e-5
+
+
+def test_generator_matches_reference_vectors():
+    z = np.load(os.path.join(GOLD, "generator.npz"))
+    gs = {k: v.clone().requires_grad_(True) for k, v in orc.seeded_fill(orc.g_param_shapes(), seed=7).items()}
+    x, y = orc.synthetic_ldct(2, seed=1234)
+    assert rel(x[0, 0, 0, :4], z["x_head"]) < 1e-6
+    out = orc.generator_forward(gs, x)
+    assert rel(out.detach(), z["out"]) < 1e-5
+    (out * torch.from_numpy(z["cot"])).sum().backward()
+    for n, gn in zip(z["grad_names"], z["grad_norms"]):
+        assert abs(gs[str(n)].grad.double().norm().item() - gn) <= 1e-4 * gn + 1e-12, n
+    assert abs(float(orc.psnr(out.detach().clip(0, 1), y)) - float(z["psnr"])) < 1e-3
+    assert abs(float(orc.ssim(out.detach().clip(0, 1), y)) - float(z["ssim"])) < 1e-5
+    assert abs(float(orc.rmse(out.detach().clip(0, 1), y)) - float(z["rmse"])) < 1e-6
+
+
+def test_discriminator_matches_reference_vectors():
+    z = np.load(os.path.join(GOLD, "discriminator.npz"))
+    dstate = orc.seeded_fill(orc.d_state_shapes(), seed=9)
+    _, y = orc.synthetic_ldct(2, seed=1234)
+    with torch.no_grad():
+        e, s, r = orc.discriminator_forward(dict(dstate), y, train=False)
+    assert rel(e, z["eval_enc"]) < 1e-5 and rel(s, z["eval_dec"]) < 1e-5 and rel(r, z["eval_rec"]) < 1e-5
+    g = torch.Generator().manual_seed(21)
+    masks = [(torch.rand(2, 512, generator=g) >= 0.3).float() / 0.7 for _ in range(2)]
+    ds = {k: v.clone() for k, v in dstate.items()}
+    names = orc.d_shared_names() + orc.d_task_specific_names() + ["c_fc.bias", "c_fc.weight_orig"]
+    for n in names:
+        ds[n] = ds[n].requires_grad_(True)
+    leaves = {n: ds[n] for n in names}
+    yin = y.clone().requires_grad_(True)
+    for it in range(2):
+        outs = orc.discriminator_forward(ds, yin, train=True, drop_mask=masks[it])
+    assert rel(outs[0].detach(), z["train_enc"]) < 1e-5
+    assert rel(outs[1].detach(), z["train_dec"]) < 1e-5
+    assert rel(outs[2].detach(), z["train_rec"]) < 1e-5
+    cots = [torch.from_numpy(z[k]) for k in ("cot_enc", "cot_dec", "cot_rec")]
+    sum((o * c).sum() for o, c in zip(outs, cots)).backward()
+    assert rel(yin.grad, z["dinput"]) < 1e-4
+    for n, gn in zip(z["grad_names"], z["grad_norms"]):
+        assert abs(leaves[str(n)].grad.double().norm().item() - gn) <= 1e-4 * gn + 1e-12, n
+    assert rel(ds["conv11.weight_u"], z["u_conv11"]) < 1e-5
+    assert rel(ds["bconv2.weight_u"], z["u_bconv2"]) < 1e-5
+    assert rel(ds["c_fc.weight_v"], z["v_c_fc"]) < 1e-5
+
+
+def test_pcgrad_gram_form_matches_reference_vectors():
+    cases = json.load(open(os.path.join(GOLD, "pcgrad.json")))
+    for c in cases:
+        random.seed(c["seed"])
+        assert orc.shuffle_orders(3) == c["orders"]
+        w = orc.pcgrad_coefficients(c["gram"], c["orders"])
+        assert max(abs(a - b) for a, b in zip(w, c["w"])) < 1e-12
+
+
+def test_full_step_matches_reference_vectors():
+    z = json.load(open(os.path.join(GOLD, "step_seeded.json")))
+    full = {"Generator." + k: v for k, v in orc.seeded_fill(orc.g_param_shapes(), seed=z["gfill"]).items()}
+    full.update({"Discriminator." + k: v for k, v in orc.seeded_fill(orc.d_state_shapes(), seed=z["dfill"]).items()})
+    x, y = orc.synthetic_ldct(z["batch"], seed=z["data_seed"])
+    g = torch.Generator().manual_seed(z["mask_seed"])
+    masks = [(torch.rand(z["batch"], 512, generator=g) >= 0.3).float() / 0.7 for _ in range(5)]
+    res = orc.train_step(full, {}, x, y, masks, z["orders"], lr=z["lr"])
+    assert rel(res["d_losses"], z["d_losses"]) < 1e-5
+    assert abs(res["g_loss"] - z["stats"]["g_loss"]) < 1e-4
+    for k, v in {**res["d_details"], **res["g_details"]}.items():
+        assert abs(v - z["stats"][k]) <= 2e-4 * abs(z["stats"][k]) + 2e-7, k
+    assert rel(torch.tensor(res["gram"]), torch.tensor(z["gram"])) < 1e-6
+    for k, samples in z["post_samples"].items():
+        t = full[k].reshape(-1)
+        n = t.numel()
+        for i, s in enumerate(samples):
+            idx = (i * 2654435761 + 12345) % n
+            assert abs(t[idx].item() - s) <= 1e-5 * abs(s) + 1e-8, (k, i)
+    assert torch.equal(full["Discriminator.c_fc.weight_orig"],
+                       orc.seeded_fill(orc.d_state_shapes(), seed=z["dfill"])["c_fc.weight_orig"])   # frozen (quirk 1)
