@@ -42,10 +42,12 @@ def cpu_baseline(wl):
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mtdgan_oracle as orc
-    cores = os.cpu_count() or 1
+    # torch's CPU conv / FFT paths stop scaling (and on a 256-thread host collapse: 0.08 img/s measured with
+    # every hardware thread) well before a full socket; 32 threads is the fastest setting found
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     if wl.name == "generator_fwd_bwd":
-        nb, iters = 16, 2
+        nb, iters = 8, 2
         x, y = orc.synthetic_ldct(nb, seed=1234)
         gs = {k: v.clone().requires_grad_(True) for k, v in orc.seeded_fill(orc.g_param_shapes(), seed=7).items()}
         def run():

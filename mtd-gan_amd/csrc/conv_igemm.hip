@@ -2,30 +2,33 @@
 //
 //   out[pix, n] = epilogue( sum_{tap} sum_{c} in[gather(pix, tap), c] * W(n, c, tap) )
 //
-// GEMM view: M = B*OH*OW pixels, N output channels, K = taps * C.  One workgroup (4 waves) owns a
-// BM x BN output tile; K is walked as (tap, 32-channel chunk).  Per chunk the A tile (im2col gather,
-// zero-filled outside the image) and the B tile (weights, read straight from the PyTorch OIHW / IOHW
-// storage through element strides) are staged global -> registers -> LDS, k-major so that the
-// v_mfma_f32_32x32x2_f32 operand reads (lane = row / column) are conflict-free ds_read_b32.
-// The next chunk's global loads are issued before the current chunk's MFMAs (register prefetch), so
-// HBM/L2 latency hides under the 64-cycle MFMAs.  Taps that fall outside the image for every pixel of
-// the tile (2x2 / 1x1 feature maps of the discriminator) are skipped for the whole workgroup.
-// Small-M layers use split-K over channel ranges (slabs in the caller's workspace + a fused
-// reduce/epilogue kernel) so the grid still fills 256 CUs; the sum order is fixed => deterministic.
+// GEMM view: M = B*OH*OW pixels, N output channels, K = taps * C, walked as (tap, 32-channel chunk).
+// v_mfma_f32_32x32x2_f32 takes, per lane, A[row = lane&31][k = lane>>5] and B[k = lane>>5][col = lane&31].
+// The K order inside a chunk is free, so k-step kk (0..15) is defined to use channels (kk, 16+kk): lane
+// (m, kh) then needs channels kh*16 .. kh*16+15 of ITS OWN pixel -- 64 contiguous bytes of the NHWC
+// tensor.  The A operand is therefore loaded straight from global memory into registers (4 x 16-byte
+// loads per 32-pixel tile and chunk, zero-filled outside the image), with the next chunk's loads in
+// flight under the current chunk's 64-cycle MFMAs: no LDS round trip, no barrier for A.  Only the weight
+// tile (shared by all waves) goes through LDS: [BN][32 (+4 pad)] floats, double-buffered, one barrier
+// per chunk, read back as conflict-free ds_read_b128.  Weights are read in place from PyTorch's OIHW /
+// IOHW storage through element strides.  Taps that fall outside the image for every pixel of the tile
+// (2x2 / 1x1 feature maps) are skipped for the whole workgroup; small-M layers use split-K over channel
+// ranges (slabs in the caller's workspace + a fused reduce/epilogue kernel, fixed order => deterministic).
 //
-// Roofline: fp32 MFMA, 64 FLOP/clk/SIMD (157 TFLOP/s chip).  Algorithmic flops = 2*M*N*K.
+// Roofline: fp32 MFMA, 64 FLOP/clk/SIMD (157.3 TFLOP/s chip).  Algorithmic flops = 2*M*N*K.
 #include "common.h"
 
 namespace {
 
-constexpr int KC = 32;   // channels per K chunk
+constexpr int KC = 32;      // channels per K chunk
+constexpr int BLD = 36;     // LDS row stride of the weight tile (floats): 16-B aligned, conflict-free b128
 
 struct IgemmParams {
     mtd_conv_args a;
     int M;
     int splitk;
     int c_per_split;
-    int b_cfast;       // weight tile: c varies fastest across lanes (w_sc < w_sn)
+    int b_cfast;       // weight tile staging: c varies fastest across lanes (w_sc < w_sn)
     int out_identity;  // output pixel index == launch-grid pixel index
 };
 
@@ -51,52 +54,45 @@ __device__ __forceinline__ float epilogue_value(const mtd_conv_args& a, float ac
 template <int WM, int WN, int WGM, int WGN>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN;
-    constexpr int LDA = BM + 1, LDB = BN + 1;
-    constexpr int PA = BM / 32;     // A rows staged per thread
-    constexpr int PB = BN / 8;      // B elements staged per thread
-    __shared__ float As[KC * LDA];
-    __shared__ float Bs[KC * LDB];
+    constexpr int PB = BN / 8;      // weight elements staged per thread and chunk
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * BLD];
 
     const mtd_conv_args& a = p.a;
     const mtd_geom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
     const int wm = wave / WGN, wn = wave % WGN;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int cbeg = blockIdx.z * p.c_per_split;
     const int cend = min(a.C, cbeg + p.c_per_split);
-    const int q = tid & 7, r = tid >> 3;
-
-    // launch-grid coordinates of the PA pixels this thread stages
-    int pb[PA], py[PA], px[PA];
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-        int m = m0 + i * 32 + r;
-        if (m < p.M) {
-            int ox = m % g.OW;
-            int t = m / g.OW;
-            int oy = t % g.OH;
-            pb[i] = t / g.OH;
-            py[i] = oy * g.in_sy + g.off_y;
-            px[i] = ox * g.in_sx + g.off_x;
-        } else {
-            pb[i] = 0;
-            py[i] = -(1 << 28);
-            px[i] = -(1 << 28);
-        }
-    }
-    // which taps touch the image for at least one pixel of this tile
     const int T = g.TH * g.TW;
-    unsigned vmask = 0;
-    for (int t = 0; t < T; ++t) {
-        int ty = t / g.TW, tx = t % g.TW;
-        int any = 0;
+
+    // ---- per-lane pixels (one per M tile): element offset of tap (0,0), and the set of taps inside the image
+    long long base[WM];
+    unsigned okmask[WM];
+    unsigned anymask = 0;
 #pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            int iy = py[i] + ty * g.tap_dy, ix = px[i] + tx * g.tap_dx;
-            any |= ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
+    for (int i = 0; i < WM; ++i) {
+        const int m = m0 + (wm * WM + i) * 32 + l31;
+        okmask[i] = 0;
+        base[i] = 0;
+        if (m < p.M) {
+            const int ox = m % g.OW;
+            const int t2 = m / g.OW;
+            const int oy = t2 % g.OH;
+            const int b = t2 / g.OH;
+            const int py = oy * g.in_sy + g.off_y, px = ox * g.in_sx + g.off_x;
+            base[i] = (((long long)b * g.IH + py) * g.IW + px) * a.in_ld + kh * 16;
+            for (int t = 0; t < T; ++t) {
+                const int iy = py + (t / g.TW) * g.tap_dy, ix = px + (t % g.TW) * g.tap_dx;
+                if (((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW)) okmask[i] |= 1u << t;
+            }
         }
-        if (__syncthreads_or(any)) vmask |= 1u << t;
+        anymask |= okmask[i];
     }
+    unsigned vmask = 0;      // taps used by at least one pixel of the workgroup's tile
+    for (int t = 0; t < T; ++t)
+        if (__syncthreads_or((anymask >> t) & 1u)) vmask |= 1u << t;
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -106,94 +102,100 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // K iterator state
+    // ---- K iterator (workgroup-uniform)
     int tap = -1, c0 = cend, kidx = 0;
-    const float* src[PA];
-    f32x4 av[PA];
-    float bv[PB];
-
+    long long tapdelta = 0;
     auto advance = [&]() -> bool {
         c0 += KC;
         if (c0 < cend) return true;
         do { ++tap; } while (tap < T && !((vmask >> tap) & 1u));
         if (tap >= T) return false;
         c0 = cbeg;
-        int ty = tap / g.TW, tx = tap % g.TW;
+        const int ty = tap / g.TW, tx = tap % g.TW;
         kidx = (g.ky0 + ty * g.ky_step) * g.KW + (g.kx0 + tx * g.kx_step);
-#pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            int iy = py[i] + ty * g.tap_dy, ix = px[i] + tx * g.tap_dx;
-            bool ok = ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
-            src[i] = ok ? a.in + (((long long)pb[i] * g.IH + iy) * g.IW + ix) * a.in_ld + 4 * q : nullptr;
-        }
+        tapdelta = ((long long)(ty * g.tap_dy) * g.IW + tx * g.tap_dx) * a.in_ld;
         return c0 < cend;
     };
+    f32x4 an[WM][4];     // next chunk's A fragments (global -> registers)
+    float bn[PB];        // next chunk's weight elements
     auto load = [&]() {
 #pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            if (src[i]) av[i] = *reinterpret_cast<const f32x4*>(src[i] + c0);
-            else av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < WM; ++i) {
+            if ((okmask[i] >> tap) & 1u) {
+                const float* src = a.in + (base[i] + tapdelta + c0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) an[i][j] = *reinterpret_cast<const f32x4*>(src + 4 * j);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) an[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            int e = tid + i * 256, n, c;
+            const int e = tid + i * 256;
+            int n, c;
             if (p.b_cfast) { c = e & (KC - 1); n = e / KC; }
             else { n = e % BN; c = e / BN; }
-            bv[i] = a.w[(long long)(n0 + n) * a.w_sn + (long long)(c0 + c) * a.w_sc + kidx];
+            bn[i] = a.w[(long long)(n0 + n) * a.w_sn + (long long)(c0 + c) * a.w_sc + kidx];
         }
     };
-    auto store = [&]() {
-#pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            int ml = i * 32 + r;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) As[(4 * q + e) * LDA + ml] = av[i][e];
-        }
+    auto store_b = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            int e = tid + i * 256, n, c;
+            const int e = tid + i * 256;
+            int n, c;
             if (p.b_cfast) { c = e & (KC - 1); n = e / KC; }
             else { n = e % BN; c = e / BN; }
-            Bs[c * LDB + n] = bv[i];
+            Bs[buf][n * BLD + c] = bn[i];
         }
     };
 
     bool more = advance();
-    if (more) load();
+    int buf = 0;
+    if (more) {
+        load();
+        store_b(0);
+    }
+    __syncthreads();
     while (more) {
-        __syncthreads();
-        store();
-        __syncthreads();
+        // current chunk: A fragments move from the prefetch registers, B fragments come from LDS
+        f32x4 ac[WM][4];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ac[i][j] = an[i][j];
+        f32x4 bc[WN][4];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const float* row = &Bs[buf][((wn * WN + j) * 32 + l31) * BLD + kh * 16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bc[j][q] = *reinterpret_cast<const f32x4*>(row + 4 * q);
+        }
         more = advance();
-        if (more) load();
-        const int kh = lane >> 5, l31 = lane & 31;
+        if (more) load();                      // next chunk's global loads fly under this chunk's MFMAs
 #pragma unroll
-        for (int kk = 0; kk < KC / 2; ++kk) {
-            float af[WM], bf[WN];
-            const int k = 2 * kk + kh;
-#pragma unroll
-            for (int i = 0; i < WM; ++i) af[i] = As[k * LDA + (wm * WM + i) * 32 + l31];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) bf[j] = Bs[k * LDB + (wn * WN + j) * 32 + l31];
+        for (int kk = 0; kk < 16; ++kk) {
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < WN; ++j) acc[i][j] = mfma32(ac[i][kk >> 2][kk & 3], bc[j][kk >> 2][kk & 3], acc[i][j]);
         }
+        if (more) store_b(buf ^ 1);            // the other buffer was last read one barrier ago
+        __syncthreads();
+        buf ^= 1;
     }
 
-    // epilogue
-    const int l31 = lane & 31;
+    // ---- epilogue
     if (p.splitk > 1) {
         float* slab = a.ws + (long long)blockIdx.z * p.M * a.N;
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
-                int n = n0 + (wn * WN + j) * 32 + l31;
+                const int n = n0 + (wn * WN + j) * 32 + l31;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    int m = m0 + (wm * WM + i) * 32 + mfma32_row(e, lane);
+                    const int m = m0 + (wm * WM + i) * 32 + mfma32_row(e, lane);
                     if (m < p.M) slab[(long long)m * a.N + n] = acc[i][j][e];
                 }
             }
@@ -204,13 +206,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
-            int n = n0 + (wn * WN + j) * 32 + l31;
-            float bias_n = a.bias ? a.bias[n] : 0.f;
+            const int n = n0 + (wn * WN + j) * 32 + l31;
+            const float bias_n = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                int m = m0 + (wm * WM + i) * 32 + mfma32_row(e, lane);
+                const int m = m0 + (wm * WM + i) * 32 + mfma32_row(e, lane);
                 if (m < p.M) {
-                    long long pix = out_pixel(g, m, p.out_identity);
+                    const long long pix = out_pixel(g, m, p.out_identity);
                     a.out[pix * a.out_ld + n] = epilogue_value(a, acc[i][j][e], sc, bias_n, pix, n);
                 }
             }
@@ -223,12 +225,12 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IgemmParams 
     const long long total = (long long)p.M * a.N;
     const float sc = a.scale ? *a.scale : 1.f;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        int n = (int)(idx % a.N);
-        int m = (int)(idx / a.N);
+        const int n = (int)(idx % a.N);
+        const int m = (int)(idx / a.N);
         float s = 0.f;
         for (int z = 0; z < p.splitk; ++z) s += a.ws[(long long)z * total + idx];
-        long long pix = out_pixel(a.g, m, p.out_identity);
-        float bias_n = a.bias ? a.bias[n] : 0.f;
+        const long long pix = out_pixel(a.g, m, p.out_identity);
+        const float bias_n = a.bias ? a.bias[n] : 0.f;
         a.out[pix * a.out_ld + n] = epilogue_value(a, s, sc, bias_n, pix, n);
     }
 }

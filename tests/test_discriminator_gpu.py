@@ -1,0 +1,117 @@
+"""GPU parity of the multi-task discriminator (module surface -> C ABI -> HIP kernels) against the CPU
+oracle and the reference-generated golden vectors: eval / train forward (spectral-norm state evolution,
+injected dropout masks), input gradient and all 108 parameter gradients."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import mtdgan_oracle as orc
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-3
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+
+
+def _disc(seed=9):
+    from mtd_gan_amd.arch.Ours.networks import Multi_Task_Discriminator_Skip
+    dstate = orc.seeded_fill(orc.d_state_shapes(), seed=seed)
+    D = Multi_Task_Discriminator_Skip(1, 64)
+    assert set(D.state_dict().keys()) == set(orc.d_state_shapes().keys())
+    D.load_state_dict(dstate)
+    return D.cuda(), dstate
+
+
+def _masks(n, batch, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.rand(batch, 512, generator=g) >= 0.3).float() / 0.7 for _ in range(n)]
+
+
+def test_partition_lists_match_reference_order(hip_lib):
+    D, _ = _disc()
+    names = {id(p): n for n, p in D.named_parameters()}
+    assert [names[id(p)] for p in D.shared_parameters()] == orc.d_shared_names()
+    assert [names[id(p)] for p in D.task_specific_parameters()] == orc.d_task_specific_names()
+    assert [names[id(p)] for p in D.last_shared_parameters()] == ["bconv2.bias", "bconv2.weight_orig"]
+    assert sum(p.numel() for p in D.parameters()) == 68432027
+
+
+def test_eval_forward_vs_golden(hip_lib):
+    z = np.load(os.path.join(GOLD, "discriminator.npz"))
+    D, _ = _disc()
+    D.eval()
+    _, y = orc.synthetic_ldct(2, seed=1234)
+    with torch.no_grad():
+        e, s, r = D(y.cuda())
+    assert rel(e, z["eval_enc"]) < TOL and rel(s, z["eval_dec"]) < TOL and rel(r, z["eval_rec"]) < TOL
+
+
+def test_train_forward_backward_vs_oracle_and_golden(hip_lib):
+    z = np.load(os.path.join(GOLD, "discriminator.npz"))
+    D, dstate = _disc()
+    D.train()
+    masks = _masks(2, 2, seed=21)
+    D._inject_masks = [m.clone() for m in masks]
+    _, y = orc.synthetic_ldct(2, seed=1234)
+    yin = y.cuda().requires_grad_(True)
+    for it in range(2):                               # two train-mode forwards: u / v evolve
+        outs = D(yin)
+    assert rel(outs[0].detach(), z["train_enc"]) < TOL
+    assert rel(outs[1].detach(), z["train_dec"]) < TOL
+    assert rel(outs[2].detach(), z["train_rec"]) < TOL
+    sd = D.state_dict()
+    assert rel(sd["conv11.weight_u"], z["u_conv11"]) < TOL
+    assert rel(sd["bconv2.weight_u"], z["u_bconv2"]) < TOL
+    assert rel(sd["c_fc.weight_v"], z["v_c_fc"]) < TOL
+    cots = [torch.from_numpy(z[k]) for k in ("cot_enc", "cot_dec", "cot_rec")]
+    sum((o * c.cuda()).sum() for o, c in zip(outs, cots)).backward()
+    assert rel(yin.grad, z["dinput"]) < TOL
+    # float64 oracle as the arbiter for the parameter gradients (see test_generator_gpu.py)
+    grads = {}
+    for dt in (torch.float32, torch.float64):
+        ds = {k: v.to(dt).clone() for k, v in dstate.items()}
+        names = orc.d_shared_names() + orc.d_task_specific_names() + ["c_fc.bias", "c_fc.weight_orig"]
+        for n in names:
+            ds[n] = ds[n].requires_grad_(True)
+        leaves = {n: ds[n] for n in names}
+        yo = y.to(dt).clone().requires_grad_(True)
+        for it in range(2):
+            o = orc.discriminator_forward(ds, yo, train=True, drop_mask=masks[it].to(dt))
+        sum((a * c.to(dt)).sum() for a, c in zip(o, cots)).backward()
+        grads[dt] = {n: leaves[n].grad for n in names}
+    worst = 0.0
+    for n, p in D.named_parameters():
+        ref = grads[torch.float64][n]
+        cpu32 = rel(grads[torch.float32][n], ref)
+        e = rel(p.grad, ref)
+        worst = max(worst, e)
+        assert e < max(TOL, 2 * cpu32), (n, e, cpu32)
+    for n, gn in zip(z["grad_names"], z["grad_norms"]):
+        mine = dict(D.named_parameters())[str(n)].grad.double().norm().item()
+        assert abs(mine - gn) <= 5e-3 * gn + 1e-12, (n, mine, gn)
+
+
+def test_spectral_norm_kernels_vs_torch(hip_lib):
+    """mtd_sn_power_iter / mtd_sn_grad on their own against the explicit formulas."""
+    from mtd_gan_amd import discriminator_path as DP
+    D, dstate = _disc(seed=5)
+    P = D._param_dict()
+    sig, us, vs = DP._sn_forward(P, True, torch.device("cuda"))
+    torch.cuda.synchronize()
+    for i, (n, rows, cols) in enumerate(DP.SN_SPECS):
+        w = dstate[n + ".weight_orig"].reshape(rows, cols).double()
+        u0 = dstate[n + ".weight_u"].double()
+        v = torch.nn.functional.normalize(w.t() @ u0, dim=0, eps=1e-12)
+        u = torch.nn.functional.normalize(w @ v, dim=0, eps=1e-12)
+        sigma = torch.dot(u, w @ v)
+        assert rel(P[n + ".weight_v"], v) < 1e-4, n
+        assert rel(P[n + ".weight_u"], u) < 1e-4, n
+        assert abs(sig[i, 0].item() - sigma.item()) < 1e-4 * abs(sigma.item()), n
+        assert abs(sig[i, 1].item() * sigma.item() - 1.0) < 1e-4, n
+        assert rel(us[DP.SN_ROW_OFF[i]:DP.SN_ROW_OFF[i] + rows], u) < 1e-4

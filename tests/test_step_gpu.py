@@ -1,0 +1,214 @@
+"""GPU parity of the full training iteration (engine.train_MTD_GAN_Ours semantics: D step with PCGrad,
+AdamW, G step, AdamW) against the CPU oracle and the reference-generated golden step, plus the loss,
+PCGrad and AdamW kernels on their own."""
+import json
+import os
+import random
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import mtdgan_oracle as orc
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-3
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+
+
+def test_loss_kernels_vs_torch(hip_lib):
+    from mtd_gan_amd import losses as L
+    g = torch.Generator().manual_seed(3)
+    a = torch.rand(4, 1, 64, 64, generator=g)
+    b = torch.rand(4, 1, 64, 64, generator=g)
+    x, y = orc.synthetic_ldct(4, seed=9)
+    s = torch.randn(4, 1, generator=g)
+    for name, hip, ref in [
+        ("ls_gan", lambda t: L.ls_gan(t, 1.0), lambda t: orc.ls_gan(t, 1.0)),
+        ("nds", lambda t: L.NDS_Loss(t, 1.0, (x - y).to(t.device)), lambda t: orc.nds_loss(t, 1.0, x - y)),
+        ("l1", lambda t: L.l1_loss(t, b.to(t.device)), lambda t: F.l1_loss(t, b)),
+        ("mse", lambda t: L.mse_loss(t, b.to(t.device)), lambda t: F.mse_loss(t, b)),
+        ("charb", lambda t: L.CharbonnierLoss()(t, b.to(t.device)), lambda t: orc.charbonnier(t, b)),
+        ("edge", lambda t: L.EdgeLoss()(t, b.to(t.device)), lambda t: orc.edge_loss(t, b)),
+    ]:
+        ac = a.clone().requires_grad_(True)
+        ad = a.cuda().requires_grad_(True)
+        lr_, lh = ref(ac), hip(ad)
+        lr_.backward()
+        lh.backward()
+        assert abs(lh.item() - lr_.item()) < 1e-5 * abs(lr_.item()) + 1e-8, name
+        assert rel(ad.grad, ac.grad) < 1e-4, name
+    sc, sd = s.clone().requires_grad_(True), s.cuda().requires_grad_(True)
+    orc.ls_gan(sc, 0.0).backward()
+    L.ls_gan(sd, 0.0).backward()
+    assert rel(sd.grad, sc.grad) < 1e-5
+
+
+def test_pcgrad_kernels_vs_gram_form(hip_lib):
+    from mtd_gan_amd import kernels as K
+    cases = json.load(open(os.path.join(GOLD, "pcgrad.json")))
+    g = torch.Generator().manual_seed(5)
+    n = 1_000_003
+    for trial in range(4):
+        base = torch.randn(3, n, generator=g)
+        if trial % 2 == 0:
+            base[1] = -0.7 * base[0] + 0.3 * base[1]
+        if trial == 3:
+            base[2] = -0.2 * base[1] + 0.05 * base[2]
+        orders = cases[trial]["orders"]
+        vecs = [base[i].cuda().contiguous() for i in range(3)]
+        gram = K.pcgrad_gram(vecs)
+        ref_gram = (base.double() @ base.double().t())
+        assert rel(gram.reshape(3, 3), ref_gram) < 1e-5
+        merged = torch.empty(n, device="cuda")
+        od = torch.tensor([j for o in orders for j in o], dtype=torch.int32, device="cuda")
+        coeff = K.pcgrad_combine(vecs, gram, od, merged)
+        w = orc.pcgrad_coefficients(ref_gram.tolist(), orders)
+        assert rel(coeff[:3], torch.tensor(w)) < 1e-4
+        ref = sum(wk * base[k].double() for k, wk in enumerate(w))
+        assert rel(merged, ref) < 1e-4
+        random.seed(cases[trial]["seed"])
+        lit = orc.pcgrad_merge([base[i].double() for i in range(3)])      # literal reference algorithm, same shuffle stream
+        assert rel(merged, lit) < 1e-4
+
+
+def test_fused_adamw_vs_torch(hip_lib):
+    from mtd_gan_amd.optimizers import FusedAdamW
+    g = torch.Generator().manual_seed(1)
+    shapes = [(64, 32, 3, 3), (513,), (1,), (512, 512)]
+    ps = [torch.randn(s, generator=g) for s in shapes]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    mine = [p.clone().cuda().requires_grad_(True) for p in ps]
+    o_ref = torch.optim.AdamW(ref, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+    o_mine = FusedAdamW(mine, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+    for it in range(3):
+        for r, m in zip(ref, mine):
+            gr = torch.randn(r.shape, generator=g)
+            r.grad = gr.clone()
+            m.grad = gr.cuda()
+        if it == 1:
+            ref[1].grad = None
+            mine[1].grad = None                 # skipped parameter keeps its step count (torch semantics)
+        o_ref.step()
+        o_mine.step()
+    for r, m in zip(ref, mine):
+        assert rel(m.detach(), r.detach()) < 1e-6
+
+
+def _model(batch):
+    from mtd_gan_amd.arch.Ours.networks import MTD_GAN_Method
+    z = json.load(open(os.path.join(GOLD, "step_seeded.json")))
+    full = {"Generator." + k: v for k, v in orc.seeded_fill(orc.g_param_shapes(), seed=z["gfill"]).items()}
+    full.update({"Discriminator." + k: v for k, v in orc.seeded_fill(orc.d_state_shapes(), seed=z["dfill"]).items()})
+    m = MTD_GAN_Method()
+    assert set(m.state_dict().keys()) == set(full.keys()) and len(full) == 326
+    m.load_state_dict(full)
+    m.cuda().train()
+    g = torch.Generator().manual_seed(z["mask_seed"])
+    masks = [(torch.rand(batch, 512, generator=g) >= 0.3).float() / 0.7 for _ in range(5)]
+    return m, full, masks, z
+
+
+def test_full_step_vs_golden_and_oracle(hip_lib):
+    from mtd_gan_amd import engine
+    from mtd_gan_amd.module.weight_methods import WeightMethods
+    from mtd_gan_amd.optimizers import FusedAdamW
+    m, full, masks, z = _model(2)
+    m.Discriminator._inject_masks = [k.clone() for k in masks]
+    x, y = orc.synthetic_ldct(z["batch"], seed=z["data_seed"])
+    wm = WeightMethods("pcgrad", n_tasks=3, device=torch.device("cuda"))
+    oD = FusedAdamW(m.Discriminator.parameters(), lr=z["lr"], betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+    oG = FusedAdamW(m.Generator.parameters(), lr=z["lr"], betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+    random.seed(77)                                    # the seed the golden step was generated with
+    stats = engine.train_MTD_GAN_Ours(m, [dict(n_20=x, n_100=y)], oG, oD, torch.device("cuda"), 0, 0, 2, wm)
+    # ---- the 17 logged scalars against the reference's own output
+    for k, v in z["stats"].items():
+        assert abs(stats[k] - v) <= TOL * abs(v) + 2e-6, (k, stats[k], v)
+    # ---- updated parameters / spectral-norm state against the reference's post-step state_dict samples
+    post = m.state_dict()
+    # an AdamW step moves every weight by ~lr regardless of gradient scale, so compare the *updates*
+    bad = []
+    for k, samples in z["post_samples"].items():
+        t = post[k].reshape(-1).cpu()
+        t0 = full[k].reshape(-1)
+        nel = t.numel()
+        for i, s in enumerate(samples):
+            idx = (i * 2654435761 + 12345) % nel
+            if k.endswith(("weight_u", "weight_v")):
+                ok = abs(t[idx].item() - s) <= TOL * max(abs(s), 1e-3)
+            else:
+                ok = abs((t[idx].item() - t0[idx].item()) - (s - t0[idx].item())) <= 0.05 * z["lr"] + 1e-9
+            if not ok:
+                bad.append((k, i, t[idx].item(), s))
+    assert len(bad) <= 0.01 * 4 * len(z["post_samples"]), bad[:10]      # sign flips of ~0 gradients are the only tolerated misses
+    assert torch.equal(post["Discriminator.c_fc.weight_orig"].cpu(), full["Discriminator.c_fc.weight_orig"])   # frozen (quirk 1)
+
+
+def test_d_step_task_gradients_vs_oracle(hip_lib):
+    """The three per-task shared gradients (what PCGrad projects), their Gram matrix and the merged
+    gradient against the float64 oracle."""
+    from mtd_gan_amd.module.weight_methods import WeightMethods
+    m, full, masks, z = _model(2)
+    m.Discriminator._inject_masks = [k.clone() for k in masks[:4]]
+    x, y = orc.synthetic_ldct(2, seed=1234)
+    wm = WeightMethods("pcgrad", n_tasks=3, device=torch.device("cuda"))
+    random.seed(77)
+    losses, details = m.d_loss(x.cuda(), y.cuda())
+    D = m.Discriminator
+    wm.backward(losses=losses, shared_parameters=list(D.shared_parameters()), task_specific_parameters=list(D.task_specific_parameters()),
+                last_shared_parameters=list(D.last_shared_parameters()))
+    tape = losses._mtd_tape
+    # oracle, fp64
+    st = {k: v.double().clone() for k, v in full.items()}
+    shared = ["Discriminator." + n for n in orc.d_shared_names()]
+    tspec = ["Discriminator." + n for n in orc.d_task_specific_names()]
+    for n in shared + tspec:
+        st[n] = st[n].requires_grad_(True)
+    lo, _, _ = orc.d_loss(st, x.double(), y.double(), [k.double() for k in masks[:4]])
+    assert rel(losses, lo.detach()) < TOL
+    sp = [st[n] for n in shared]
+    flat = [torch.cat([g.reshape(-1) for g in torch.autograd.grad(lo[i], sp, retain_graph=True)]) for i in range(3)]
+    ts = torch.autograd.grad(lo.sum(), [st[n] for n in tspec])
+    for i in range(3):
+        assert rel(tape.task_vectors[i], flat[i]) < 5e-3, i
+    gram_ref = torch.stack([torch.stack([torch.dot(a, b) for b in flat]) for a in flat])
+    scale = torch.sqrt(torch.outer(gram_ref.diag(), gram_ref.diag()))
+    assert ((tape.gram.reshape(3, 3).cpu() - gram_ref).abs() / scale).max().item() < 5e-3        # relative to |g_a||g_b|
+    assert tape.orders == z["orders"]
+    w = orc.pcgrad_coefficients(gram_ref.tolist(), tape.orders)
+    merged_ref = sum(wk * f for wk, f in zip(w, flat))
+    assert rel(tape.task_vectors[3], merged_ref) < 5e-3
+    names = {id(p): n for n, p in D.named_parameters()}
+    for p, g in zip(D.task_specific_parameters(), ts):
+        assert rel(p.grad, g) < 5e-3, names[id(p)]
+    assert D.c_fc.weight_orig.grad is None
+
+
+def test_full_batch_step_runs_and_is_finite(hip_lib):
+    """BASELINE size (32 patches): one complete iteration; losses finite, every listed parameter gets a
+    finite gradient / update, spectral-norm vectors stay unit length."""
+    from mtd_gan_amd import engine
+    from mtd_gan_amd.arch.Ours.networks import MTD_GAN_Method
+    from mtd_gan_amd.module.weight_methods import WeightMethods
+    from mtd_gan_amd.optimizers import FusedAdamW
+    torch.manual_seed(0)
+    m = MTD_GAN_Method().cuda().train()
+    x, y = orc.synthetic_ldct(32, seed=1234)
+    wm = WeightMethods("pcgrad", n_tasks=3, device=torch.device("cuda"))
+    oD = FusedAdamW(m.Discriminator.parameters(), lr=1e-4, weight_decay=5e-4)
+    oG = FusedAdamW(m.Generator.parameters(), lr=1e-4, weight_decay=5e-4)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    stats = engine.train_MTD_GAN_Ours(m, [dict(n_20=x, n_100=y)], oG, oD, torch.device("cuda"), 0, 0, 4, wm)
+    assert len(stats) == 17 and all(v == v and abs(v) < 1e6 for v in stats.values())
+    after = m.state_dict()
+    moved = sum(int(not torch.equal(before[k], after[k])) for k in before)
+    assert moved >= 320, moved                       # everything but c_fc.{weight_orig,bias} (frozen) moves
+    for k, v in after.items():
+        assert torch.isfinite(v).all(), k
+        if k.endswith("weight_u") or k.endswith("weight_v"):
+            assert abs(v.norm().item() - 1.0) < 1e-4, k
