@@ -28,6 +28,10 @@ struct IgemmParams {
     int M;
     int splitk;
     int c_per_split;
+    unsigned in_bytes; // extent of the input view in bytes (buffer-load range check)
+    int tap_dy[16], tap_dx[16];     // input displacement of tap t (validity test)
+    int tap_delta[16];              // byte displacement of tap t in the NHWC input
+    int tap_kidx[16];               // index of tap t in the kh*kw plane of the weights
     int b_cfast;       // weight tile staging: c varies fastest across lanes (w_sc < w_sn)
     int out_identity;  // output pixel index == launch-grid pixel index
 };
@@ -52,7 +56,7 @@ __device__ __forceinline__ float epilogue_value(const mtd_conv_args& a, float ac
 }
 
 template <int WM, int WN, int WGM, int WGN>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(const IgemmParams p) {
     constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN;
     constexpr int PB = BN / 8;      // weight elements staged per thread and chunk
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * BLD];
@@ -67,32 +71,41 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const int cend = min(a.C, cbeg + p.c_per_split);
     const int T = g.TH * g.TW;
 
-    // ---- per-lane pixels (one per M tile): element offset of tap (0,0), and the set of taps inside the image
-    long long base[WM];
+    // ---- per-lane pixels (one per M tile): byte offset of tap (0,0) (mod 2^32; a valid tap always lands
+    //      inside [0, in_bytes)), and the set of taps inside the image.  A is read with buffer loads:
+    //      32-bit offsets, and an out-of-range offset returns 0, which gives the zero padding for free.
+    unsigned boff[WM];
     unsigned okmask[WM];
     unsigned anymask = 0;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int m = m0 + (wm * WM + i) * 32 + l31;
         okmask[i] = 0;
-        base[i] = 0;
+        boff[i] = 0;
         if (m < p.M) {
             const int ox = m % g.OW;
             const int t2 = m / g.OW;
             const int oy = t2 % g.OH;
             const int b = t2 / g.OH;
             const int py = oy * g.in_sy + g.off_y, px = ox * g.in_sx + g.off_x;
-            base[i] = (((long long)b * g.IH + py) * g.IW + px) * a.in_ld + kh * 16;
+            boff[i] = (unsigned)(((((long long)b * g.IH + py) * g.IW + px) * a.in_ld + kh * 16) * 4);
             for (int t = 0; t < T; ++t) {
-                const int iy = py + (t / g.TW) * g.tap_dy, ix = px + (t % g.TW) * g.tap_dx;
+                const int iy = py + p.tap_dy[t], ix = px + p.tap_dx[t];
                 if (((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW)) okmask[i] |= 1u << t;
             }
         }
         anymask |= okmask[i];
     }
-    unsigned vmask = 0;      // taps used by at least one pixel of the workgroup's tile
-    for (int t = 0; t < T; ++t)
-        if (__syncthreads_or((anymask >> t) & 1u)) vmask |= 1u << t;
+    // taps used by at least one pixel of the workgroup's tile (one LDS atomic per wave, one barrier)
+    __shared__ unsigned vmask_s;
+    if (tid == 0) vmask_s = 0;
+    __syncthreads();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) anymask |= __shfl_xor(anymask, off, 64);
+    if (lane == 0) atomicOr(&vmask_s, anymask);
+    __syncthreads();
+    const unsigned vmask = vmask_s;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)p.in_bytes, 0x00020000);
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -103,76 +116,55 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // ---- K iterator (workgroup-uniform)
-    int tap = -1, c0 = cend, kidx = 0;
-    long long tapdelta = 0;
+    int tap = -1, c0 = cend, kidx = 0;      // c0 = cend: the first advance() opens the first valid tap
+    // per-thread element offsets of the weight elements it stages (chunk / tap terms are uniform adds)
+    int woff[PB], wlds[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int e = tid + i * 256;
+        int n, c;
+        if (p.b_cfast) { c = e & (KC - 1); n = e / KC; }
+        else { n = e % BN; c = e / BN; }
+        woff[i] = (int)((long long)(n0 + n) * a.w_sn + (long long)c * a.w_sc);
+        wlds[i] = n * BLD + c;
+    }
+    unsigned tapdelta = 0;
+    // moves to the next valid (tap, chunk); on exhaustion returns false and leaves the state on the last
+    // valid chunk so that the (masked) trailing prefetch still forms in-range weight addresses
     auto advance = [&]() -> bool {
-        c0 += KC;
-        if (c0 < cend) return true;
-        do { ++tap; } while (tap < T && !((vmask >> tap) & 1u));
-        if (tap >= T) return false;
+        if (c0 + KC < cend) { c0 += KC; return true; }
+        const unsigned done = (tap < 0) ? 0u : ((tap >= 31) ? 0xFFFFFFFFu : ((2u << tap) - 1u));
+        const unsigned rem = vmask & ~done;                                        // taps after the current one
+        if (rem == 0u || cbeg >= cend) return false;
+        tap = __builtin_ctz(rem);
         c0 = cbeg;
-        const int ty = tap / g.TW, tx = tap % g.TW;
-        kidx = (g.ky0 + ty * g.ky_step) * g.KW + (g.kx0 + tx * g.kx_step);
-        tapdelta = ((long long)(ty * g.tap_dy) * g.IW + tx * g.tap_dx) * a.in_ld;
-        return c0 < cend;
+        kidx = p.tap_kidx[tap];
+        tapdelta = (unsigned)p.tap_delta[tap];
+        return true;
     };
     f32x4 an[WM][4];     // next chunk's A fragments (global -> registers)
     float bn[PB];        // next chunk's weight elements
-    auto load = [&]() {
+    auto load = [&](bool live) {
+        const unsigned lm = 0u - (unsigned)live;        // all ones while chunks remain: keeps the loads branch-free
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
-            if ((okmask[i] >> tap) & 1u) {
-                const float* src = a.in + (base[i] + tapdelta + c0);
+            const unsigned voff = ((okmask[i] >> tap) & lm & 1u) ? (boff[i] + tapdelta + (unsigned)c0 * 4u) : 0x80000000u;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) an[i][j] = *reinterpret_cast<const f32x4*>(src + 4 * j);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) an[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int j = 0; j < 4; ++j)
+                an[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 16 * j, 0));
         }
+        const int wchunk = (int)((long long)c0 * a.w_sc) + kidx;
 #pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            const int e = tid + i * 256;
-            int n, c;
-            if (p.b_cfast) { c = e & (KC - 1); n = e / KC; }
-            else { n = e % BN; c = e / BN; }
-            bn[i] = a.w[(long long)(n0 + n) * a.w_sn + (long long)(c0 + c) * a.w_sc + kidx];
-        }
+        for (int i = 0; i < PB; ++i) bn[i] = a.w[woff[i] + wchunk];
     };
     auto store_b = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            const int e = tid + i * 256;
-            int n, c;
-            if (p.b_cfast) { c = e & (KC - 1); n = e / KC; }
-            else { n = e % BN; c = e / BN; }
-            Bs[buf][n * BLD + c] = bn[i];
-        }
+        for (int i = 0; i < PB; ++i) Bs[buf][wlds[i]] = bn[i];
     };
 
-    bool more = advance();
-    int buf = 0;
-    if (more) {
-        load();
-        store_b(0);
-    }
-    __syncthreads();
-    while (more) {
-        // current chunk: A fragments move from the prefetch registers, B fragments come from LDS
-        f32x4 ac[WM][4];
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ac[i][j] = an[i][j];
-        f32x4 bc[WN][4];
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const float* row = &Bs[buf][((wn * WN + j) * 32 + l31) * BLD + kh * 16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bc[j][q] = *reinterpret_cast<const f32x4*>(row + 4 * q);
-        }
-        more = advance();
-        if (more) load();                      // next chunk's global loads fly under this chunk's MFMAs
+    f32x4 ac[WM][4];
+    f32x4 bc[WN][4];
+    auto mfma_chunk = [&]() {
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
 #pragma unroll
@@ -180,9 +172,36 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
                 for (int j = 0; j < WN; ++j) acc[i][j] = mfma32(ac[i][kk >> 2][kk & 3], bc[j][kk >> 2][kk & 3], acc[i][j]);
         }
-        if (more) store_b(buf ^ 1);            // the other buffer was last read one barrier ago
+    };
+
+    int buf = 0;
+    if (advance()) {
+        load(true);
+        store_b(0);
         __syncthreads();
-        buf ^= 1;
+        bool nxt;
+        do {
+            // current chunk: A fragments move out of the prefetch registers, B fragments come from LDS
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ac[i][j] = an[i][j];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const float* row = &Bs[buf][((wn * WN + j) * 32 + l31) * BLD + kh * 16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bc[j][q] = *reinterpret_cast<const f32x4*>(row + 4 * q);
+            }
+            nxt = advance();
+            load(nxt);                  // next chunk's loads fly under this chunk's MFMAs; always issued (masked to
+                                        // out-of-range no-ops after the last chunk) so the vmcnt bookkeeping stays exact
+            __builtin_amdgcn_sched_barrier(0);      // keep the loads ABOVE the MFMA block (hipcc otherwise sinks them)
+            mfma_chunk();
+            __builtin_amdgcn_sched_barrier(0);
+            store_b(buf ^ 1);           // the other buffer was last read one barrier ago
+            __syncthreads();
+            buf ^= 1;
+        } while (nxt);
     }
 
     // ---- epilogue
@@ -299,6 +318,25 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
     p.M = (int)geom_pixels(a->g);
     p.splitk = pl.splitk;
     p.c_per_split = pl.c_per_split;
+    {
+        const long long npix = (long long)a->g.B * a->g.IH * a->g.IW;
+        const long long bytes = ((npix - 1) * a->in_ld + a->C) * 4;
+        if (bytes >= (1ll << 31)) return MTD_EINVAL;      // 32-bit buffer offsets (largest tensor of the step: 64 MiB)
+        p.in_bytes = (unsigned)bytes;
+    }
+    {
+        const mtd_geom& gg = a->g;
+        for (int t = 0; t < gg.TH * gg.TW; ++t) {
+            const int ty = t / gg.TW, tx = t % gg.TW;
+            p.tap_dy[t] = ty * gg.tap_dy;
+            p.tap_dx[t] = tx * gg.tap_dx;
+            p.tap_delta[t] = (int)((((long long)(ty * gg.tap_dy) * gg.IW + tx * gg.tap_dx) * a->in_ld) * 4);
+            p.tap_kidx[t] = (gg.ky0 + ty * gg.ky_step) * gg.KW + (gg.kx0 + tx * gg.kx_step);
+        }
+        // weight element offsets are formed in 32 bits
+        const long long wmax = (long long)(a->N - 1) * a->w_sn + (long long)(a->C - 1) * a->w_sc + 16;
+        if (wmax >= (1ll << 31)) return MTD_EINVAL;
+    }
     p.b_cfast = (a->w_sc < a->w_sn) ? 1 : 0;
     const mtd_geom& g = a->g;
     p.out_identity = (g.out_sy == 1 && g.out_sx == 1 && g.out_oy == 0 && g.out_ox == 0 && g.OHF == g.OH && g.OWF == g.OW);

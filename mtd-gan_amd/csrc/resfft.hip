@@ -76,10 +76,10 @@ constexpr int XLD = 65;   // LDS row stride (floats) of the [frequency][64 chann
 
 // ---------------------------------------------------------------------------------------------
 // rows forward: two image rows (h, h+1) of one channel per thread
-__global__ __launch_bounds__(256) void rfft_rows_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ R,
-                                                        int npairs, int col_weight) {
+__global__ __launch_bounds__(64) void rfft_rows_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ R,
+                                                       int npairs, int col_weight) {
     const int c = threadIdx.x & 31;
-    const int pair = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int pair = blockIdx.x * 2 + (threadIdx.x >> 5);
     if (pair >= npairs) return;
     const int b = pair >> 5, h = (pair & 31) * 2;
     float re[64], im[64];
@@ -109,13 +109,15 @@ __global__ __launch_bounds__(256) void rfft_rows_kernel(const float* __restrict_
     }
 }
 
-// rows backward (c2r): two rows per thread, fused epilogue
-__global__ __launch_bounds__(256) void irfft_rows_kernel(const float* __restrict__ T, float* __restrict__ out, int out_ld,
-                                                         const float* __restrict__ add1, int add1_ld,
-                                                         const float* __restrict__ add2, int add2_ld,
-                                                         const float* __restrict__ mask, int mask_ld, int npairs) {
+// rows backward (c2r): two rows per thread, fused epilogue (compile-time variants so that the optional
+// operand loads are branch-free and issued in batches of 8 pixels ahead of the stores)
+template <bool A1, bool A2, bool MK>
+__global__ __launch_bounds__(64) void irfft_rows_kernel(const float* __restrict__ T, float* __restrict__ out, int out_ld,
+                                                        const float* __restrict__ add1, int add1_ld,
+                                                        const float* __restrict__ add2, int add2_ld,
+                                                        const float* __restrict__ mask, int mask_ld, int npairs) {
     const int c = threadIdx.x & 31;
-    const int pair = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int pair = blockIdx.x * 2 + (threadIdx.x >> 5);
     if (pair >= npairs) return;
     const int b = pair >> 5, h = (pair & 31) * 2;
     float re[64], im[64];
@@ -137,17 +139,26 @@ __global__ __launch_bounds__(256) void irfft_rows_kernel(const float* __restrict
     fft64<+1>(re, im);
     const long long p0 = (long long)(b * 64 + h) * 64;
 #pragma unroll
-    for (int w = 0; w < 64; ++w) {
-        float va = re[brev6(w)] * 0.125f, vb = im[brev6(w)] * 0.125f;
-        const long long pa = p0 + w, pb = p0 + 64 + w;
-        if (add1) { va += add1[pa * add1_ld + c]; vb += add1[pb * add1_ld + c]; }
-        if (add2) { va += add2[pa * add2_ld + c]; vb += add2[pb * add2_ld + c]; }
-        if (mask) {
-            va = mask[pa * mask_ld + c] > 0.f ? va : 0.f;
-            vb = mask[pb * mask_ld + c] > 0.f ? vb : 0.f;
+    for (int w0 = 0; w0 < 64; w0 += 8) {
+        float x1a[8], x1b[8], x2a[8], x2b[8], mka[8], mkb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long long pa = p0 + w0 + j, pb = pa + 64;
+            if (A1) { x1a[j] = add1[pa * add1_ld + c]; x1b[j] = add1[pb * add1_ld + c]; }
+            if (A2) { x2a[j] = add2[pa * add2_ld + c]; x2b[j] = add2[pb * add2_ld + c]; }
+            if (MK) { mka[j] = mask[pa * mask_ld + c]; mkb[j] = mask[pb * mask_ld + c]; }
         }
-        out[pa * out_ld + c] = va;
-        out[pb * out_ld + c] = vb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int w = w0 + j;
+            float va = re[brev6(w)] * 0.125f, vb = im[brev6(w)] * 0.125f;
+            const long long pa = p0 + w, pb = pa + 64;
+            if (A1) { va += x1a[j]; vb += x1b[j]; }
+            if (A2) { va += x2a[j]; vb += x2b[j]; }
+            if (MK) { va = mka[j] > 0.f ? va : 0.f; vb = mkb[j] > 0.f ? vb : 0.f; }
+            out[pa * out_ld + c] = va;
+            out[pb * out_ld + c] = vb;
+        }
     }
 }
 
@@ -398,7 +409,8 @@ constexpr int MIX_GS = 32;
 extern "C" int mtd_rfft_rows(const float* x, int x_ld, float* R, int B, int col_weight, void* stream) {
     if (!x || !R || B <= 0 || x_ld < 32) return MTD_EINVAL;
     const int npairs = B * 32;
-    hipLaunchKernelGGL(rfft_rows_kernel, dim3((npairs + 7) / 8), dim3(256), 0, (hipStream_t)stream, x, x_ld, R, npairs, col_weight);
+    // one wave (two row pairs x 32 channels) per workgroup: 512 workgroups at B = 32 so that every CU is fed
+    hipLaunchKernelGGL(rfft_rows_kernel, dim3((npairs + 1) / 2), dim3(64), 0, (hipStream_t)stream, x, x_ld, R, npairs, col_weight);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }
@@ -408,8 +420,21 @@ extern "C" int mtd_irfft_rows(const float* T, float* out, int out_ld, const floa
     if (!T || !out || B <= 0 || out_ld < 32) return MTD_EINVAL;
     if ((add1 && add1_ld < 32) || (add2 && add2_ld < 32) || (mask && mask_ld < 32)) return MTD_EINVAL;
     const int npairs = B * 32;
-    hipLaunchKernelGGL(irfft_rows_kernel, dim3((npairs + 7) / 8), dim3(256), 0, (hipStream_t)stream, T, out, out_ld, add1, add1_ld,
-                       add2, add2_ld, mask, mask_ld, npairs);
+    const dim3 grid((npairs + 1) / 2), blk(64);
+    hipStream_t s = (hipStream_t)stream;
+#define MTD_IRFFT(A, B2, M) hipLaunchKernelGGL((irfft_rows_kernel<A, B2, M>), grid, blk, 0, s, T, out, out_ld, add1, add1_ld, add2, add2_ld, mask, mask_ld, npairs)
+    const int variant = (add1 ? 1 : 0) | (add2 ? 2 : 0) | (mask ? 4 : 0);
+    switch (variant) {
+        case 0: MTD_IRFFT(false, false, false); break;
+        case 1: MTD_IRFFT(true, false, false); break;
+        case 2: MTD_IRFFT(false, true, false); break;
+        case 3: MTD_IRFFT(true, true, false); break;
+        case 4: MTD_IRFFT(false, false, true); break;
+        case 5: MTD_IRFFT(true, false, true); break;
+        case 6: MTD_IRFFT(false, true, true); break;
+        default: MTD_IRFFT(true, true, true); break;
+    }
+#undef MTD_IRFFT
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }
