@@ -58,11 +58,13 @@ typedef struct {
  *                              + add1[pix,n] + add2[pix,n] ) )
  * Replaces F.conv2d / F.conv_transpose2d / F.linear call sites: arch/Ours/networks.py:18-19,32
  * (block convs), :97-162 (generator encoder/decoder), :385-472 (discriminator), and their autograd
- * data-gradients.  Requires C % 32 == 0, N % 32 == 0 (other shapes: mtd_conv_direct). */
+ * data-gradients.  Requires C % 32 == 0, N % 32 == 0 (other shapes: mtd_conv_direct) and a weight view that
+ * is contiguous along c (w_sc == 1, 16-byte aligned rows): 1x1 convs / Linear are that natively, other views
+ * are re-laid out once per optimizer step by mtd_pack_weights into [tap][n][c]. */
 typedef struct {
     mtd_geom g;
     const float* in;  int in_ld;  int C;
-    const float* w;   long long w_sn, w_sc;      /* W(n,c,kidx) = w[n*w_sn + c*w_sc + kidx] */
+    const float* w;   long long w_sn, w_sc, w_st; /* W(n,c,kidx) = w[n*w_sn + c*w_sc + kidx*w_st] */
     int N;
     float* out;       int out_ld;
     const float* scale;                          /* device scalar (1/sigma) or NULL        */
@@ -76,6 +78,11 @@ typedef struct {
 
 size_t mtd_conv_igemm_ws_bytes(const mtd_conv_args* a);
 int mtd_conv_igemm(const mtd_conv_args* a, void* stream);
+
+/* dst[(t*N + n)*C + c] = src[n*sn + c*sc + t]  for `count` weight tensors in one launch (table in device
+ * memory + the same table on the host for sizing). */
+typedef struct { const float* src; float* dst; int N, C, T; long long sn, sc; } mtd_pack_desc;
+int mtd_pack_weights(const mtd_pack_desc* table_dev, const mtd_pack_desc* table_host, int count, void* stream);
 
 /* Same contract on the vector ALU for degenerate channel counts (C==1, N==1, N or C not a multiple
  * of 32): generator encoder.0 / decoder.0 (networks.py:97,162), discriminator conv11, *_dconv61/62,

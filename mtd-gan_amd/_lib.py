@@ -20,7 +20,7 @@ class Geom(C.Structure):
 class ConvArgs(C.Structure):
     _fields_ = [("g", Geom),
                 ("inp", C.c_void_p), ("in_ld", C.c_int), ("C", C.c_int),
-                ("w", C.c_void_p), ("w_sn", C.c_longlong), ("w_sc", C.c_longlong),
+                ("w", C.c_void_p), ("w_sn", C.c_longlong), ("w_sc", C.c_longlong), ("w_st", C.c_longlong),
                 ("N", C.c_int),
                 ("out", C.c_void_p), ("out_ld", C.c_int),
                 ("scale", C.c_void_p), ("bias", C.c_void_p),
@@ -38,6 +38,11 @@ class WgradArgs(C.Structure):
                 ("dw", C.c_void_p), ("w_sn", C.c_longlong), ("w_sc", C.c_longlong),
                 ("db", C.c_void_p), ("accumulate", C.c_int),
                 ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("N", C.c_int), ("C", C.c_int), ("T", C.c_int),
+                ("sn", C.c_longlong), ("sc", C.c_longlong)]
 
 
 class SnLayer(C.Structure):
@@ -110,6 +115,7 @@ def lib():
     sig("mtd_pixel_shuffle2_fwd", ci, vp, ci, vp, ci, ci, ci, ci, ci, vp)
     sig("mtd_pixel_shuffle2_bwd", ci, vp, ci, vp, ci, ci, ci, ci, ci, vp)
     sig("mtd_mul", ci, vp, vp, vp, ll, vp)
+    sig("mtd_pack_weights", ci, vp, vp, ci, vp)
     sig("mtd_sn_ws_bytes", sz, vp, ci)
     sig("mtd_sn_power_iter", ci, vp, vp, ci, ci, vp, vp)
     sig("mtd_sn_grad_ws_bytes", sz, vp, ci)
@@ -133,7 +139,7 @@ EXPORTS = [
     "mtd_version", "mtd_conv_igemm_ws_bytes", "mtd_conv_igemm", "mtd_conv_direct", "mtd_conv_wgrad_ws_bytes",
     "mtd_conv_wgrad", "mtd_rfft_rows", "mtd_spec_mix_fwd", "mtd_spec_mix_bwd_ws_bytes", "mtd_spec_mix_bwd",
     "mtd_spec_mix_wgrad_reduce", "mtd_irfft_rows", "mtd_transpose64", "mtd_act_grad", "mtd_copy_channels",
-    "mtd_upsample2x_fwd", "mtd_upsample2x_bwd", "mtd_pixel_shuffle2_fwd", "mtd_pixel_shuffle2_bwd", "mtd_mul",
+    "mtd_upsample2x_fwd", "mtd_upsample2x_bwd", "mtd_pixel_shuffle2_fwd", "mtd_pixel_shuffle2_bwd", "mtd_mul", "mtd_pack_weights",
     "mtd_sn_ws_bytes", "mtd_sn_power_iter", "mtd_sn_grad_ws_bytes", "mtd_sn_grad", "mtd_pcgrad_ws_bytes",
     "mtd_pcgrad_gram", "mtd_pcgrad_combine", "mtd_adamw_multi", "mtd_loss_terms_ws_bytes", "mtd_loss_terms",
     "mtd_loss_term_grads", "mtd_clip01", "mtd_clip01_bwd", "mtd_edge_loss_ws_bytes", "mtd_edge_loss",

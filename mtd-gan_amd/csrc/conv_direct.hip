@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void direct_fwd_kernel(const mtd_conv_args a, 
                 if ((unsigned)ix >= (unsigned)g.IW) continue;
                 const int kidx = (g.ky0 + ty * g.ky_step) * g.KW + (g.kx0 + tx * g.kx_step);
                 const float* src = a.in + (((long long)b * g.IH + iy) * g.IW + ix) * a.in_ld;
-                const float* wp = a.w + (long long)n * a.w_sn + kidx;
+                const float* wp = a.w + (long long)n * a.w_sn + (long long)kidx * a.w_st;
                 if ((a.C & 3) == 0) {
                     for (int c = 0; c < a.C; c += 4) {
                         f32x4 v = *reinterpret_cast<const f32x4*>(src + c);

@@ -32,7 +32,6 @@ struct IgemmParams {
     int tap_dy[16], tap_dx[16];     // input displacement of tap t (validity test)
     int tap_delta[16];              // byte displacement of tap t in the NHWC input
     int tap_kidx[16];               // index of tap t in the kh*kw plane of the weights
-    int b_cfast;       // weight tile staging: c varies fastest across lanes (w_sc < w_sn)
     int out_identity;  // output pixel index == launch-grid pixel index
 };
 
@@ -58,7 +57,7 @@ __device__ __forceinline__ float epilogue_value(const mtd_conv_args& a, float ac
 template <int WM, int WN, int WGM, int WGN>
 __global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(const IgemmParams p) {
     constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN;
-    constexpr int PB = BN / 8;      // weight elements staged per thread and chunk
+    constexpr int PB = BN / 32;     // 16-byte weight vectors staged per thread and chunk (BN rows x 8 vectors)
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * BLD];
 
     const mtd_conv_args& a = p.a;
@@ -117,16 +116,15 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(cons
 
     // ---- K iterator (workgroup-uniform)
     int tap = -1, c0 = cend, kidx = 0;      // c0 = cend: the first advance() opens the first valid tap
-    // per-thread element offsets of the weight elements it stages (chunk / tap terms are uniform adds)
+    // per-thread element offsets of the weight vectors it stages (chunk / tap terms are uniform adds);
+    // the weight view is contiguous along c, so a row of the tile is 8 x 16 bytes
     int woff[PB], wlds[PB];
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
         const int e = tid + i * 256;
-        int n, c;
-        if (p.b_cfast) { c = e & (KC - 1); n = e / KC; }
-        else { n = e % BN; c = e / BN; }
-        woff[i] = (int)((long long)(n0 + n) * a.w_sn + (long long)c * a.w_sc);
-        wlds[i] = n * BLD + c;
+        const int n = e >> 3, q = e & 7;
+        woff[i] = (int)((long long)(n0 + n) * a.w_sn) + 4 * q;
+        wlds[i] = n * BLD + 4 * q;
     }
     unsigned tapdelta = 0;
     // moves to the next valid (tap, chunk); on exhaustion returns false and leaves the state on the last
@@ -143,7 +141,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(cons
         return true;
     };
     f32x4 an[WM][4];     // next chunk's A fragments (global -> registers)
-    float bn[PB];        // next chunk's weight elements
+    f32x4 bn[PB];        // next chunk's weight vectors
     auto load = [&](bool live) {
         const unsigned lm = 0u - (unsigned)live;        // all ones while chunks remain: keeps the loads branch-free
 #pragma unroll
@@ -153,13 +151,13 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(cons
             for (int j = 0; j < 4; ++j)
                 an[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 16 * j, 0));
         }
-        const int wchunk = (int)((long long)c0 * a.w_sc) + kidx;
+        const int wchunk = c0 + (int)((long long)kidx * a.w_st);
 #pragma unroll
-        for (int i = 0; i < PB; ++i) bn[i] = a.w[woff[i] + wchunk];
+        for (int i = 0; i < PB; ++i) bn[i] = *reinterpret_cast<const f32x4*>(a.w + (woff[i] + wchunk));
     };
     auto store_b = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < PB; ++i) Bs[buf][wlds[i]] = bn[i];
+        for (int i = 0; i < PB; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][wlds[i]]) = bn[i];
     };
 
     f32x4 ac[WM][4];
@@ -291,6 +289,8 @@ int check_args(const mtd_conv_args& a) {
     if (geom_pixels(g) > (1ll << 30)) return MTD_EINVAL;
     if (a.in_ld < a.C || a.out_ld < a.N || (a.in_ld % 4)) return MTD_EINVAL;
     if (!aligned16(a.in)) return MTD_EALIGN;
+    if (a.w_sc != 1 || a.w_st < 0) return MTD_EINVAL;                     // packed / natively c-contiguous weight view
+    if (!aligned16(a.w) || (a.w_sn % 4) || (a.g.TH * a.g.TW > 1 && (a.w_st % 4))) return MTD_EALIGN;
     if (a.add1 && a.add1_ld < a.N) return MTD_EINVAL;
     if (a.add2 && a.add2_ld < a.N) return MTD_EINVAL;
     if (a.mask && a.mask_ld < a.N) return MTD_EINVAL;
@@ -334,10 +334,9 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
             p.tap_kidx[t] = (gg.ky0 + ty * gg.ky_step) * gg.KW + (gg.kx0 + tx * gg.kx_step);
         }
         // weight element offsets are formed in 32 bits
-        const long long wmax = (long long)(a->N - 1) * a->w_sn + (long long)(a->C - 1) * a->w_sc + 16;
+        const long long wmax = (long long)(a->N - 1) * a->w_sn + (long long)(a->C - 1) + 16ll * a->w_st + 16;
         if (wmax >= (1ll << 31)) return MTD_EINVAL;
     }
-    p.b_cfast = (a->w_sc < a->w_sn) ? 1 : 0;
     const mtd_geom& g = a->g;
     p.out_identity = (g.out_sy == 1 && g.out_sx == 1 && g.out_oy == 0 && g.out_ox == 0 && g.OHF == g.OH && g.OWF == g.OW);
     if (pl.splitk > 1) {

@@ -145,6 +145,30 @@ __global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, c
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = a[i] * b[i];
 }
 
+constexpr int PACK_ELEMS = 4096;
+__global__ __launch_bounds__(256) void pack_weights_kernel(const mtd_pack_desc* __restrict__ D, int count) {
+    int acc = 0, di = -1, local = 0;
+    for (int t = 0; t < count; ++t) {
+        const int nb = (int)(((long long)D[t].N * D[t].C * D[t].T + PACK_ELEMS - 1) / PACK_ELEMS);
+        if ((int)blockIdx.x < acc + nb) { di = t; local = blockIdx.x - acc; break; }
+        acc += nb;
+    }
+    if (di < 0) return;
+    const mtd_pack_desc d = D[di];
+    const long long total = (long long)d.N * d.C * d.T;
+    const long long base = (long long)local * PACK_ELEMS;
+    for (int i = threadIdx.x; i < PACK_ELEMS; i += 256) {
+        const long long e = base + i;
+        if (e < total) {
+            const int c = (int)(e % d.C);
+            const long long r = e / d.C;
+            const int n = (int)(r % d.N);
+            const int t = (int)(r / d.N);
+            d.dst[e] = d.src[(long long)n * d.sn + (long long)c * d.sc + t];
+        }
+    }
+}
+
 inline unsigned grid_for(long long n) {
     long long b = (n + 255) / 256;
     if (b > 4096) b = 4096;
@@ -172,6 +196,18 @@ extern "C" int mtd_act_grad(const float* g, int g_ld, const float* y, int y_ld, 
 extern "C" int mtd_mul(const float* a, const float* b, float* out, long long n, void* stream) {
     if (!a || !b || !out || n <= 0) return MTD_EINVAL;
     hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_pack_weights(const mtd_pack_desc* table_dev, const mtd_pack_desc* table_host, int count, void* stream) {
+    if (!table_dev || !table_host || count <= 0) return MTD_EINVAL;
+    long long blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!table_host[i].src || !table_host[i].dst || table_host[i].N <= 0 || table_host[i].C <= 0 || table_host[i].T <= 0) return MTD_EINVAL;
+        blocks += ((long long)table_host[i].N * table_host[i].C * table_host[i].T + PACK_ELEMS - 1) / PACK_ELEMS;
+    }
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, table_dev, count);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }

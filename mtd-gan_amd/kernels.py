@@ -10,6 +10,33 @@ from . import _lib
 from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ConvArgs, Geom, WgradArgs, check  # noqa: F401
 
 _ws = {}
+_pack_cache = {}
+_pack_epoch = 0
+
+
+def weights_changed():
+    """Called by the optimizers after they update parameters through raw pointers (the tensors' version
+    counters do not move): drops every packed weight view."""
+    global _pack_epoch
+    _pack_epoch += 1
+    _pack_cache.clear()
+
+
+def packed_weight_view(w, N, Cc, w_sn, w_sc):
+    """[tap][n][c] copy of the weight view W(n,c,tap) = w[n*w_sn + c*w_sc + tap] (c contiguous, which is what
+    the implicit-GEMM kernel stages with 16-byte loads).  Cached until the weights change."""
+    T = w.numel() // (N * Cc)
+    key = (w.data_ptr(), w._version, _pack_epoch, N, Cc, w_sn, w_sc)
+    hit = _pack_cache.get(key)
+    if hit is None:
+        dst = torch.empty((T, N, Cc), dtype=torch.float32, device=w.device)
+        d = _lib.PackDesc()
+        d.src, d.dst, d.N, d.C, d.T, d.sn, d.sc = w.data_ptr(), dst.data_ptr(), N, Cc, T, w_sn, w_sc
+        tab, host = device_table([d], w.device)
+        check(_lib.lib().mtd_pack_weights(tab.data_ptr(), C.cast(host, C.c_void_p), 1, stream_ptr()), "mtd_pack_weights")
+        hit = (dst, w)          # keep the source alive so its data_ptr cannot be recycled under the same key
+        _pack_cache[key] = hit
+    return hit[0], Cc, 1, N * Cc
 PROFILE = None      # bench.py sets this to a list to collect (tag, start_event, end_event) per conv launch
 
 
@@ -85,7 +112,10 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, scale=None, bias=None, add1=None, a
     a = ConvArgs()
     a.g = geom
     a.inp, a.in_ld, a.C = x.data_ptr(), ld_of(x), Cc
-    a.w, a.w_sn, a.w_sc, a.N = w.data_ptr(), w_sn, w_sc, N
+    w_st = 1
+    if (Cc % 32 == 0) and (N % 32 == 0) and (w_sc != 1 or w.data_ptr() % 16 or w_sn % 4):
+        w, w_sn, w_sc, w_st = packed_weight_view(w, N, Cc, w_sn, w_sc)
+    a.w, a.w_sn, a.w_sc, a.w_st, a.N = w.data_ptr(), w_sn, w_sc, w_st, N
     a.out, a.out_ld = out.data_ptr(), ld_of(out)
     a.scale, a.bias = _ptr(scale), _ptr(bias)
     a.add1, a.add1_ld = _ptr(add1), (ld_of(add1) if add1 is not None else 0)

@@ -32,6 +32,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 b1, b2 = group["betas"]
                 K.adamw_multi([i[0] for i in items], [i[1] for i in items], [i[2] for i in items], [i[3] for i in items],
                               step, group["lr"], b1, b2, group["eps"], group["weight_decay"])
+        K.weights_changed()          # parameters were updated through raw pointers: packed weight views are stale
 
 
 def get_optimizer(name, model, lr):
