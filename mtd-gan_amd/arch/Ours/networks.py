@@ -43,6 +43,7 @@ class _BlockFn(torch.autograd.Function):
         grads = {"dw_img": torch.empty_like(w_img), "db_img": torch.empty(w_img.shape[0], device=g.device),
                  "dw_fft": torch.empty_like(w_fft), "db_fft": torch.empty(w_fft.shape[0], device=g.device)}
         gx = GP.block_backward(g.contiguous(), ctx.saved, w_img, w_fft, grads, False)
+        K.side_stream(g.device).join()
         return gx, grads["dw_img"], grads["db_img"], grads["dw_fft"], grads["db_fft"]
 
 
@@ -222,6 +223,7 @@ class _DiscFn(torch.autograd.Function):
         f = lambda g, shape: g.contiguous().reshape(shape) if g is not None else None
         gin = DP.disc_backward(ctx.module._rt, P, ctx.tape, f(g_enc, (B, 1, 1, 1)), f(g_dec, (B, 64, 64, 1)), f(g_rec, (B, 64, 64, 1)),
                                DP.GradSink(sink_t) if sink_t else None, ctx.needs_input_grad[0])
+        K.side_stream(P[names[0]].device).join()
         gx = gin.reshape(B, 1, 64, 64) if gin is not None else None
         return (gx, None, None, None, None) + tuple(sink_t.get(n) for n in names)
 

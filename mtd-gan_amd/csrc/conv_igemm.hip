@@ -18,6 +18,24 @@
 // Roofline: fp32 MFMA, 64 FLOP/clk/SIMD (157.3 TFLOP/s chip).  Algorithmic flops = 2*M*N*K.
 #include "common.h"
 
+// In-kernel phase stamps for the diagnostic build only (tools/igemm_stamp.hip defines MTD_STAMPS and includes this
+// file); in the library build MTD_STAMP expands to nothing.
+#ifdef MTD_STAMPS
+__device__ unsigned long long* mtd_stamp_buf;
+#define MTD_STAMP(i)                                                                                        \
+    do {                                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < 64 && blockIdx.y == 0 && blockIdx.z == 0) {                    \
+            __builtin_amdgcn_sched_barrier(0);                                                              \
+            unsigned long long t__;                                                                         \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                      \
+            mtd_stamp_buf[blockIdx.x * 64 + (i)] = t__;                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                              \
+        }                                                                                                   \
+    } while (0)
+#else
+#define MTD_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int KC = 32;      // channels per K chunk
@@ -70,6 +88,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(cons
     const int cend = min(a.C, cbeg + p.c_per_split);
     const int T = g.TH * g.TW;
 
+    MTD_STAMP(0);
     // ---- per-lane pixels (one per M tile): byte offset of tap (0,0) (mod 2^32; a valid tap always lands
     //      inside [0, in_bytes)), and the set of taps inside the image.  A is read with buffer loads:
     //      32-bit offsets, and an out-of-range offset returns 0, which gives the zero padding for free.
@@ -104,6 +123,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(cons
     if (lane == 0) atomicOr(&vmask_s, anymask);
     __syncthreads();
     const unsigned vmask = vmask_s;
+    MTD_STAMP(1);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)p.in_bytes, 0x00020000);
 
     f32x16 acc[WM][WN];
@@ -142,18 +162,26 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(cons
     };
     f32x4 an[WM][4];     // next chunk's A fragments (global -> registers)
     f32x4 bn[PB];        // next chunk's weight vectors
-    auto load = [&](bool live) {
-        const unsigned lm = 0u - (unsigned)live;        // all ones while chunks remain: keeps the loads branch-free
+    // The prefetch is issued in pieces BETWEEN groups of MFMAs (an in-order wave stalls at a VMEM instruction
+    // while the texture-address unit is busy; with 2-4 MFMAs queued ahead of each load the matrix pipe keeps
+    // running through those stalls).  Every piece is unconditional (masked out-of-range after the last chunk).
+    unsigned lm = 0;
+    auto load_a = [&](int i) {
+        const unsigned voff = ((okmask[i] >> tap) & lm & 1u) ? (boff[i] + tapdelta + (unsigned)c0 * 4u) : 0x80000000u;
 #pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            const unsigned voff = ((okmask[i] >> tap) & lm & 1u) ? (boff[i] + tapdelta + (unsigned)c0 * 4u) : 0x80000000u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                an[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 16 * j, 0));
-        }
+        for (int j = 0; j < 4; ++j)
+            an[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 16 * j, 0));
+    };
+    auto load_b = [&]() {
         const int wchunk = c0 + (int)((long long)kidx * a.w_st);
 #pragma unroll
         for (int i = 0; i < PB; ++i) bn[i] = *reinterpret_cast<const f32x4*>(a.w + (woff[i] + wchunk));
+    };
+    auto load = [&](bool live) {
+        lm = 0u - (unsigned)live;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) load_a(i);
+        load_b();
     };
     auto store_b = [&](int buf) {
 #pragma unroll
@@ -162,9 +190,9 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(cons
 
     f32x4 ac[WM][4];
     f32x4 bc[WN][4];
-    auto mfma_chunk = [&]() {
+    auto mfma_steps = [&](int k0, int k1) {
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
+        for (int kk = k0; kk < k1; ++kk) {
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -173,12 +201,16 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(cons
     };
 
     int buf = 0;
+    int it__ = 0;
     if (advance()) {
         load(true);
+        MTD_STAMP(2);
         store_b(0);
         __syncthreads();
+        MTD_STAMP(3);
         bool nxt;
         do {
+            if (it__ < 12) MTD_STAMP(4 + 4 * it__);
             // current chunk: A fragments move out of the prefetch registers, B fragments come from LDS
 #pragma unroll
             for (int i = 0; i < WM; ++i)
@@ -191,16 +223,33 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(cons
                 for (int q = 0; q < 4; ++q) bc[j][q] = *reinterpret_cast<const f32x4*>(row + 4 * q);
             }
             nxt = advance();
-            load(nxt);                  // next chunk's loads fly under this chunk's MFMAs; always issued (masked to
-                                        // out-of-range no-ops after the last chunk) so the vmcnt bookkeeping stays exact
-            __builtin_amdgcn_sched_barrier(0);      // keep the loads ABOVE the MFMA block (hipcc otherwise sinks them)
-            mfma_chunk();
+            lm = 0u - (unsigned)nxt;
+            // next chunk's loads interleaved with this chunk's MFMAs: [2 steps][A tile 0][..][A tile 1][..][B][rest]
             __builtin_amdgcn_sched_barrier(0);
+            if (it__ < 12) MTD_STAMP(5 + 4 * it__);
+            mfma_steps(0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_steps(2, 6);
+            __builtin_amdgcn_sched_barrier(0);
+            if (WM > 1) load_a(WM - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_steps(6, 10);
+            __builtin_amdgcn_sched_barrier(0);
+            load_b();
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_steps(10, 16);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it__ < 12) MTD_STAMP(6 + 4 * it__);
             store_b(buf ^ 1);           // the other buffer was last read one barrier ago
             __syncthreads();
+            if (it__ < 12) MTD_STAMP(7 + 4 * it__);
+            ++it__;
             buf ^= 1;
         } while (nxt);
     }
+    MTD_STAMP(60);
 
     // ---- epilogue
     if (p.splitk > 1) {
@@ -234,6 +283,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(cons
                 }
             }
         }
+    MTD_STAMP(61);
 }
 
 // sum the split-K slabs in order, then the same epilogue

@@ -24,6 +24,8 @@ struct WgradParams {
     int T;          // taps
     int nslab;
     long long slab_stride;   // floats per slab = T*N*C + N
+    unsigned p_bytes, q_bytes;          // extents for the buffer-load range checks
+    int tap_dy[16], tap_dx[16], tap_delta[16];   // per-tap input displacement (pixels / bytes)
 };
 
 template <int WN, int WC, int TG>
@@ -45,6 +47,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     float* Qs = Ps + 32 * PLD;
     const int mwave0 = (blockIdx.x * 4 + wave) * p.ppw;
     const bool do_bias = (a.db != nullptr) && ctile == 0 && blockIdx.z == 0;
+    // Both operands are read with buffer loads: 32-bit byte offsets, an out-of-range offset returns 0 (zero
+    // padding and the pixel tail without branches, so the compiler's vmcnt bookkeeping stays exact).
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p), (short)0, (int)p.p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.q), (short)0, (int)p.q_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
 
     f32x16 acc[TG][WN][WC];
 #pragma unroll
@@ -59,86 +66,101 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
     for (int j = 0; j < WN; ++j) bsum[j] = 0.f;
 
-    for (int mc = 0; mc < p.ppw; mc += 32) {
-        const int mbase = mwave0 + mc;
-        // ---- P tile (rows = pixels mbase..mbase+31, identity pixel mapping)
-        f32x4 pv[UP];
-#pragma unroll
-        for (int i = 0; i < UP; ++i) {
-            int u = lane + 64 * i;
-            int row = u / (8 * WN), quad = u % (8 * WN);
-            int m = mbase + row;
-            if (m < p.M) pv[i] = *reinterpret_cast<const f32x4*>(a.p + (long long)m * a.p_ld + n0 + 4 * quad);
-            else pv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        // ---- launch-grid coordinates of the Q rows this lane stages
-        int qb[UQ], qy[UQ], qx[UQ];
+    f32x4 pv[UP], qv[UQ];
+    unsigned qoff[UQ], qok[UQ];
+    // per chunk: byte offsets of the rows this lane stages (P: identity pixel mapping; Q: tap (0,0) position)
+    auto chunk_setup = [&](int mbase) {
 #pragma unroll
         for (int i = 0; i < UQ; ++i) {
-            int u = lane + 64 * i;
-            int row = u / (8 * WC);
-            int m = mbase + row;
+            const int u = lane + 64 * i;
+            const int row = u / (8 * WC), quad = u % (8 * WC);
+            const int m = mbase + row;
+            qoff[i] = 0;
+            qok[i] = 0;
             if (m < p.M) {
-                int ox = m % g.OW;
-                int t2 = m / g.OW;
-                int oy = t2 % g.OH;
-                qb[i] = t2 / g.OH;
-                qy[i] = oy * g.in_sy + g.off_y;
-                qx[i] = ox * g.in_sx + g.off_x;
-            } else {
-                qb[i] = 0;
-                qy[i] = -(1 << 28);
-                qx[i] = -(1 << 28);
+                const int ox = m % g.OW;
+                const int t2 = m / g.OW;
+                const int oy = t2 % g.OH;
+                const int b = t2 / g.OH;
+                const int py = oy * g.in_sy + g.off_y, px = ox * g.in_sx + g.off_x;
+                qoff[i] = (unsigned)(((((long long)b * g.IH + py) * g.IW + px) * a.q_ld + c0 + 4 * quad) * 4);
+                for (int t = 0; t < ntap; ++t) {
+                    const int iy = py + p.tap_dy[tap0 + t], ix = px + p.tap_dx[tap0 + t];
+                    if (((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW)) qok[i] |= 1u << t;
+                }
             }
         }
-        auto loadq = [&](int tap, f32x4 (&qv)[UQ]) {
-            int ty = tap / g.TW, tx = tap % g.TW;
-#pragma unroll
-            for (int i = 0; i < UQ; ++i) {
-                int u = lane + 64 * i;
-                int quad = u % (8 * WC);
-                int iy = qy[i] + ty * g.tap_dy, ix = qx[i] + tx * g.tap_dx;
-                bool ok = ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
-                if (ok) qv[i] = *reinterpret_cast<const f32x4*>(a.q + (((long long)qb[i] * g.IH + iy) * g.IW + ix) * a.q_ld + c0 + 4 * quad);
-                else qv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        };
-        f32x4 qv[UQ];
-        loadq(tap0, qv);
-        __syncthreads();   // previous chunk's MFMA reads are done
+    };
+    auto loadp = [&](int mbase) {
 #pragma unroll
         for (int i = 0; i < UP; ++i) {
-            int u = lane + 64 * i;
-            *reinterpret_cast<f32x4*>(Ps + 4 * u) = pv[i];   // row*(32*WN) + 4*quad == 4*u
+            const int u = lane + 64 * i;
+            const int row = u / (8 * WN), quad = u % (8 * WN);
+            const int m = mbase + row;
+            const unsigned off = (m < p.M) ? (unsigned)((((long long)m * a.p_ld) + n0 + 4 * quad) * 4) : OOB;
+            pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, off, 0, 0));
         }
+    };
+    auto loadq = [&](int t) {
+        const unsigned delta = (unsigned)p.tap_delta[tap0 + t];
+#pragma unroll
+        for (int i = 0; i < UQ; ++i) {
+            const unsigned off = ((qok[i] >> t) & 1u) ? (qoff[i] + delta) : OOB;
+            qv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qrs, off, 0, 0));
+        }
+    };
+
+    // No workgroup barrier in the main loop: each wave stages and reads ONLY its own LDS region, and the LDS
+    // executes one wave's DS instructions in issue order (a later ds_read sees an earlier ds_write; a later
+    // ds_write cannot overtake an earlier ds_read).  wave_barrier() only pins the compiler's ordering.
+    chunk_setup(mwave0);
+    loadp(mwave0);
+    loadq(0);
+    for (int mc = 0; mc < p.ppw; mc += 32) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < UP; ++i) *reinterpret_cast<f32x4*>(Ps + 4 * (lane + 64 * i)) = pv[i];   // row*(32*WN) + 4*quad == 4*u
+        const bool more_chunks = (mc + 32 < p.ppw);
 #pragma unroll
         for (int t = 0; t < TG; ++t) {
             if (t < ntap) {
 #pragma unroll
-                for (int i = 0; i < UQ; ++i) {
-                    int u = lane + 64 * i;
-                    *reinterpret_cast<f32x4*>(Qs + 4 * u) = qv[i];
+                for (int i = 0; i < UQ; ++i) *reinterpret_cast<f32x4*>(Qs + 4 * (lane + 64 * i)) = qv[i];
+                __builtin_amdgcn_wave_barrier();
+                // prefetch: next tap of this chunk, or P + first tap of the next chunk (always issued; masked OOB at the end)
+                if (t + 1 < ntap) {
+                    loadq(t + 1);
+                } else {
+                    const int mnext = more_chunks ? (mwave0 + mc + 32) : p.M;     // p.M => every offset out of range
+                    chunk_setup(mnext);
+                    loadp(mnext);
+                    loadq(0);
                 }
-                __syncthreads();
-                if (t + 1 < ntap) loadq(tap0 + t + 1, qv);
+                // operands for the 16 k-steps of this tap, read in one batch, then 16 back-to-back MFMA groups
+                float af[16][WN], bf[16][WC];
 #pragma unroll
                 for (int kk = 0; kk < 16; ++kk) {
                     const int k = 2 * kk + kh;
-                    float af[WN], bf[WC];
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) af[j] = Ps[k * PLD + j * 32 + l31];
+                    for (int j = 0; j < WN; ++j) af[kk][j] = Ps[k * PLD + j * 32 + l31];
 #pragma unroll
-                    for (int c = 0; c < WC; ++c) bf[c] = Qs[k * QLD + c * 32 + l31];
-                    if (t == 0) {
+                    for (int c = 0; c < WC; ++c) bf[kk][c] = Qs[k * QLD + c * 32 + l31];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (t == 0) {
 #pragma unroll
-                        for (int j = 0; j < WN; ++j) bsum[j] += af[j];
-                    }
+                    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) bsum[j] += af[kk][j];
+                }
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk)
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
 #pragma unroll
-                        for (int c = 0; c < WC; ++c) acc[t][j][c] = mfma32(af[j], bf[c], acc[t][j][c]);
-                }
-                __syncthreads();   // Q tile free for the next tap
+                        for (int c = 0; c < WC; ++c) acc[t][j][c] = mfma32(af[kk][j], bf[kk][c], acc[t][j][c]);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_wave_barrier();   // Q tile is rewritten for the next tap after these reads (same wave: in order)
             }
         }
     }
@@ -313,6 +335,20 @@ extern "C" int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream) {
     p.T = a->g.TH * a->g.TW;
     p.nslab = nsplit;
     p.slab_stride = (long long)p.T * a->N * a->C + a->N;
+    {
+        const mtd_geom& gg = a->g;
+        for (int t = 0; t < gg.TH * gg.TW; ++t) {
+            const int ty = t / gg.TW, tx = t % gg.TW;
+            p.tap_dy[t] = ty * gg.tap_dy;
+            p.tap_dx[t] = tx * gg.tap_dx;
+            p.tap_delta[t] = (int)((((long long)(ty * gg.tap_dy) * gg.IW + tx * gg.tap_dx) * a->q_ld) * 4);
+        }
+        const long long pb = (((long long)p.M - 1) * a->p_ld + a->N) * 4;
+        const long long qb = (((long long)gg.B * gg.IH * gg.IW - 1) * a->q_ld + a->C) * 4;
+        if (pb >= (1ll << 31) || qb >= (1ll << 31)) return MTD_EINVAL;
+        p.p_bytes = (unsigned)pb;
+        p.q_bytes = (unsigned)qb;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (direct) {
         p.ppw = 0;

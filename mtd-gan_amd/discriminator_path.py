@@ -56,6 +56,35 @@ for _n, _rows, _cols in SN_SPECS:
 SN_W_TOTAL = _o
 
 
+def conv_views(P, backward):
+    """Every implicit-GEMM weight view a discriminator pass (and its replay) will ask kernels.conv() for, so
+    that they can be packed in one launch per optimizer step instead of one per layer."""
+    v = []
+
+    def add(name, N, Cc, k, suffix=".weight_orig"):
+        w = P[name + suffix]
+        v.append((w, N, Cc, Cc * k * k, k * k))               # forward view (OIHW)
+        if backward:
+            v.append((w, Cc, N, k * k, Cc * k * k))           # data-gradient view (transposed)
+
+    cin = 1
+    for l, co in enumerate(CH, start=1):
+        add(f"conv{l}1", co, cin, 3)
+        add(f"conv{l}2", co, co, 3)
+        add(f"down{l}", co, co, 4)
+        cin = co
+    add("bconv1", 512, 512, 1)
+    add("bconv2", 512, 512, 1)
+    add("c_fc", 512, 512, 1)
+    for pre in ("s", "r"):
+        for l, (ci, co) in enumerate(DEC, start=1):
+            add(f"{pre}_dconv{l}1", co, ci, 3)
+            add(f"{pre}_dconv{l}2", co, co, 3)
+    for l, (ci, cu) in enumerate(RUP, start=1):
+        add(f"r_up{l}.upsample.0", 4 * cu, ci, 1, ".weight")
+    return v
+
+
 class DiscRuntime:
     """Per-module scratch: the raw weight-gradient temp (one flat buffer shared by all SN layers)."""
 
@@ -114,6 +143,7 @@ def disc_forward(P, x, train, drop_mask, need_rec, save):
     B = x.shape[0]
     dev = x.device
     tp = Tape()
+    K.prepack(conv_views(P, save))
     tp.sig, tp.u_save, tp.v_save = _sn_forward(P, train, dev)
     tp.x_in, tp.B, tp.drop_mask, tp.need_rec = x, B, drop_mask, need_rec
     tp.tin, tp.a, tp.xs = {}, {}, {}
@@ -207,6 +237,7 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad):
     x = tp.x_in
     dev = x.device
     sn_touched = []
+    side = K.side_stream(dev)          # weight gradients run beside the data-gradient chain
 
     def want(name):
         return sink is not None and sink.get(name) is not None
@@ -214,8 +245,8 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad):
     def wgrad_sn(name, p, q, geom, N, Cc, k):
         wn, bn = name + ".weight_orig", name + ".bias"
         if want(wn):
-            K.wgrad(p, q, geom, N, Cc, rt.gtemp(name, dev), Cc * k * k, k * k, db=sink.get(bn), accumulate=False,
-                    accumulate_bias=True)
+            side.run(lambda: K.wgrad(p, q, geom, N, Cc, rt.gtemp(name, dev), Cc * k * k, k * k, db=sink.get(bn), accumulate=False,
+                                     accumulate_bias=True), p, q)
             sn_touched.append(name)
         elif want(bn):
             raise NotImplementedError("bias-only gradient request")
@@ -234,7 +265,7 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad):
         """shared by the SEG ('s') and REC ('r') decoders; returns the gradient of x_bot"""
         t6 = o2s[6]
         if want(head + ".weight"):
-            K.wgrad(g_out, t6, g64, 1, 1, sink.get(head + ".weight"), 1, 1, db=sink.get(head + ".bias"), accumulate=True)
+            side.run(lambda: K.wgrad(g_out, t6, g64, 1, 1, sink.get(head + ".weight"), 1, 1, db=sink.get(head + ".bias"), accumulate=True), g_out, t6)
         g = K.empty_nhwc(B, 64, 64, 1, x)
         K.conv(g_out, P[head + ".weight"], g64, 1, 1, 1, 1, g)
         for lvl in range(6, 0, -1):
@@ -261,7 +292,8 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad):
                 gq = K.geom_fwd(B, r // 2, r // 2, 1, 1, 0)
                 wn = f"r_up{lvl}.upsample.0.weight"
                 if want(wn):
-                    K.wgrad(gr, tin, gq, 4 * cup, cin_up, sink.get(wn), cin_up, 1, db=sink.get(f"r_up{lvl}.upsample.0.bias"), accumulate=True)
+                    side.run(lambda gr=gr, tin=tin, gq=gq, wn=wn, cup=cup, cin_up=cin_up, lvl=lvl: K.wgrad(
+                        gr, tin, gq, 4 * cup, cin_up, sink.get(wn), cin_up, 1, db=sink.get(f"r_up{lvl}.upsample.0.bias"), accumulate=True), gr, tin)
                 g = K.empty_nhwc(B, r // 2, r // 2, cin_up, x)
                 K.conv(gr, P[wn], gq, cin_up, 4 * cup, 1, cin_up, g)
         return g
@@ -272,15 +304,15 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad):
         g_bot_parts.append(decoder_backward("s", g_dec, tp.s_cat, tp.s_o1, tp.s_o2, tp.s_in, "dec_out"))
     if g_enc is not None:
         if want("enc_out.weight"):
-            K.wgrad(g_enc, tp.cm, g1, 1, 512, sink.get("enc_out.weight"), 512, 1, db=sink.get("enc_out.bias"), accumulate=True)
+            side.run(lambda: K.wgrad(g_enc, tp.cm, g1, 1, 512, sink.get("enc_out.weight"), 512, 1, db=sink.get("enc_out.bias"), accumulate=True), g_enc)
         gcm = K.empty_nhwc(B, 1, 1, 512, x)
         K.conv(g_enc, P["enc_out.weight"], g1, 512, 1, 1, 512, gcm)
         gc = K.mul(gcm, tp.drop_mask.reshape(B, 1, 1, 512)) if tp.drop_mask is not None else gcm
         gpre = K.act_grad(gc, tp.c, 0.2)
         wn = "c_fc.weight_orig"
         if want(wn):
-            K.wgrad(gpre, tp.bot, g1, 512, 512, rt.gtemp("c_fc", dev), 512, 1, db=sink.get("c_fc.bias"), accumulate=False,
-                    accumulate_bias=True)
+            side.run(lambda: K.wgrad(gpre, tp.bot, g1, 512, 512, rt.gtemp("c_fc", dev), 512, 1, db=sink.get("c_fc.bias"), accumulate=False,
+                                     accumulate_bias=True), gpre)
             sn_touched.append("c_fc")
         gb = K.empty_nhwc(B, 1, 1, 512, x)
         K.conv(gpre, P[wn], g1, 512, 512, 1, 512, gb, scale=_inv_sigma(tp, "c_fc"))
@@ -344,6 +376,9 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad):
             structs.append(s)
         dev_tab, host_arr = K.device_table(structs, dev)
         need = L.mtd_sn_grad_ws_bytes(C.cast(host_arr, C.c_void_p), len(structs))
-        ws = K.workspace(need, dev)
-        K.check(L.mtd_sn_grad(dev_tab.data_ptr(), C.cast(host_arr, C.c_void_p), len(structs), ws.data_ptr(), K.stream_ptr()), "mtd_sn_grad")
+
+        def fix():
+            ws = K.workspace(need, dev)
+            K.check(L.mtd_sn_grad(dev_tab.data_ptr(), C.cast(host_arr, C.c_void_p), len(structs), ws.data_ptr(), K.stream_ptr()), "mtd_sn_grad")
+        side.run(fix)        # same stream as the weight gradients it corrects; callers join() before reading the sink
     return g_in

@@ -34,8 +34,9 @@ def block_backward(g, saved, w_img, w_fft, grads, premask):
     so the result is the gradient w.r.t. the producer's pre-activation."""
     x, img, S, Z = saved
     B, H, W, _ = x.shape
+    side = K.side_stream(x.device)
     gm = K.act_grad(g, img, 0.0)                                                    # g * (img > 0)
-    K.wgrad(gm, x, K.geom_fwd(B, H, W, 3, 1, 1), CH, CH, grads["dw_img"], CH * 9, 9, db=grads["db_img"])
+    side.run(lambda: K.wgrad(gm, x, K.geom_fwd(B, H, W, 3, 1, 1), CH, CH, grads["dw_img"], CH * 9, 9, db=grads["db_img"]), gm, g)
     gR = K.rfft_rows(g, 1)                                                          # irfft2 backward
     gT = K.spec_mix_bwd(gR, w_fft, S, Z, grads["dw_fft"], grads["db_fft"])
     d1 = K.empty_nhwc(B, H, W, CH, x)
@@ -57,6 +58,18 @@ def generator_forward(x, P, save):
     """x: (B,64,64,1) NHWC.  Returns (out (B,64,64,1), tape)."""
     B, H, W, _ = x.shape
     L = len(P.enc_w) - 1                                   # 10
+    views = []
+    for i in range(1, L + 1):
+        views.append((P.enc_w[i], CH, CH, CH * 9, 9))
+        views.append((P.dec_w[i], CH, CH, 9, CH * 9))
+        if save:
+            views.append((P.enc_w[i], CH, CH, 9, CH * 9))
+            views.append((P.dec_w[i], CH, CH, CH * 9, 9))
+    for (w_img, _b, _w2, _b2) in P.blk:
+        views.append((w_img, CH, CH, CH * 9, 9))
+        if save:
+            views.append((w_img, CH, CH, 9, CH * 9))
+    K.prepack(views)                                       # one launch for all [tap][n][c] weight views
     gf = K.geom_fwd(B, H, W, 3, 1, 1)
     gt = K.geom_dgrad_s1(B, H, W, 3, 1)                    # ConvTranspose2d(k3,s1,p1) gathers like a stride-1 dgrad
     tape = {"t": [], "e": [], "blk": [], "d": [], "u": []}
@@ -103,10 +116,11 @@ def generator_backward(g_out, tape, P, G):
     gf = K.geom_fwd(B, H, W, 3, 1, 1)
     gt = K.geom_dgrad_s1(B, H, W, 3, 1)
     # output ReLU
+    side = K.side_stream(x.device)
     gpre = K.act_grad(g_out, tape["out"], 0.0)
     # decoder[0]: ConvTranspose 32 -> 1
     u0 = tape["u"][L]
-    K.wgrad(gpre, u0, gt, 1, CH, G.dec_w[0], 9, 9, db=G.dec_b[0])
+    side.run(lambda: K.wgrad(gpre, u0, gt, 1, CH, G.dec_w[0], 9, 9, db=G.dec_b[0]), gpre)
     gu = K.empty_nhwc(B, H, W, CH, x)
     K.conv(gpre, P.dec_w[0], gf, CH, 1, 9, 9, gu)          # d/du0: plain conv with W_t read as OIHW [32][1][3][3]
     skip = [None] * (L + 1)
@@ -116,7 +130,7 @@ def generator_backward(g_out, tape, P, G):
         gpre_d = block_backward(gu, tape["blk"][L + 1 + k], *_blk_w(P, 2 * L + 1 - j), G.blk[2 * L + 1 - j], True)
         skip[j] = gpre_d                                    # flows unchanged into e_j
         uj = tape["u"][k]                                   # input of decoder[j]
-        K.wgrad(gpre_d, uj, gt, CH, CH, G.dec_w[j], 9, CH * 9, db=G.dec_b[j])
+        side.run(lambda: K.wgrad(gpre_d, uj, gt, CH, CH, G.dec_w[j], 9, CH * 9, db=G.dec_b[j]), gpre_d)
         gu = K.empty_nhwc(B, H, W, CH, x)
         K.conv(gpre_d, P.dec_w[j], gf, CH, CH, CH * 9, 9, gu)
     # gu is now the gradient of x_b (output of block 10)
@@ -125,11 +139,12 @@ def generator_backward(g_out, tape, P, G):
         gpre_t = block_backward(g_e, tape["blk"][i], *_blk_w(P, i), G.blk[i], True)
         if i > 0:
             e_prev = tape["e"][i - 1]
-            K.wgrad(gpre_t, e_prev, gf, CH, CH, G.enc_w[i], CH * 9, 9, db=G.enc_b[i])
+            side.run(lambda: K.wgrad(gpre_t, e_prev, gf, CH, CH, G.enc_w[i], CH * 9, 9, db=G.enc_b[i]), gpre_t)
             g_e = K.empty_nhwc(B, H, W, CH, x)
             K.conv(gpre_t, P.enc_w[i], K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, g_e, add1=skip[i])
         else:
-            K.wgrad(gpre_t, x, gf, CH, 1, G.enc_w[0], 9, 9, db=G.enc_b[0])
+            side.run(lambda: K.wgrad(gpre_t, x, gf, CH, 1, G.enc_w[0], 9, 9, db=G.enc_b[0]), gpre_t)
+    side.join()
 
 
 def _blk_w(P, i):

@@ -22,6 +22,27 @@ def weights_changed():
     _pack_cache.clear()
 
 
+def prepack(views):
+    """Pack many weight views in ONE launch.  views: iterable of (w, N, C, w_sn, w_sc) exactly as conv() will
+    ask for them; already cached / natively c-contiguous views are skipped."""
+    todo = []
+    for (w, N, Cc, w_sn, w_sc) in views:
+        if (Cc % 32) or (N % 32) or not (w_sc != 1 or w.data_ptr() % 16 or w_sn % 4):
+            continue
+        key = (w.data_ptr(), w._version, _pack_epoch, N, Cc, w_sn, w_sc)
+        if key in _pack_cache:
+            continue
+        T = w.numel() // (N * Cc)
+        dst = torch.empty((T, N, Cc), dtype=torch.float32, device=w.device)
+        d = _lib.PackDesc()
+        d.src, d.dst, d.N, d.C, d.T, d.sn, d.sc = w.data_ptr(), dst.data_ptr(), N, Cc, T, w_sn, w_sc
+        todo.append(d)
+        _pack_cache[key] = (dst, w)
+    if todo:
+        tab, host = device_table(todo, todo and views[0][0].device)
+        check(_lib.lib().mtd_pack_weights(tab.data_ptr(), C.cast(host, C.c_void_p), len(todo), stream_ptr()), "mtd_pack_weights")
+
+
 def packed_weight_view(w, N, Cc, w_sn, w_sc):
     """[tap][n][c] copy of the weight view W(n,c,tap) = w[n*w_sn + c*w_sc + tap] (c contiguous, which is what
     the implicit-GEMM kernel stages with 16-byte loads).  Cached until the weights change."""
@@ -268,7 +289,7 @@ def device_table(structs, device):
     key = (device.index, raw)
     hit = _desc_cache.get(key)
     if hit is None:
-        if len(_desc_cache) > 512:
+        if len(_desc_cache) > 16384:
             _desc_cache.clear()
         host = torch.frombuffer(bytearray(raw), dtype=torch.uint8).pin_memory()
         dev = host.to(device, non_blocking=True)
@@ -359,3 +380,51 @@ def adamw_multi(params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps,
     tab, host = device_table(structs, params[0].device)
     check(L.mtd_adamw_multi(tab.data_ptr(), C.cast(host, C.c_void_p), len(structs), float(lr), float(beta1), float(beta2), float(eps),
                             float(wd), int(step), stream_ptr()), "mtd_adamw_multi")
+
+
+# ---------------------------------------------------------------------------------------------- side stream
+class SideStream:
+    """A second HIP stream for work that is off the critical path of a backward pass (weight gradients, their
+    slab reductions, the spectral-norm correction): it runs beside the data-gradient chain on the main stream
+    so the matrix cores see two independent kernels.  fork() orders the side stream after everything enqueued
+    on the main stream so far; join() makes the main stream wait for the side work.  Tensors handed to keep()
+    stay referenced until join(), i.e. until the side kernels that read them are ordered before any reuse."""
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self._keep = []
+        self.enabled = True
+
+    def fork(self):
+        if self.enabled:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.stream.wait_event(ev)
+
+    def run(self, fn, *keep):
+        if not self.enabled:
+            fn()
+            return
+        self.fork()
+        with torch.cuda.stream(self.stream):
+            fn()
+        self._keep.extend(keep)
+
+    def join(self):
+        if self.enabled:
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            torch.cuda.current_stream().wait_event(ev)
+        self._keep.clear()
+
+
+_side = {}
+
+
+def side_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    s = _side.get(key)
+    if s is None:
+        s = SideStream(device)
+        _side[key] = s
+    return s

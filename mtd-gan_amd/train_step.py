@@ -89,6 +89,7 @@ class DStepTape:
             dp.all_reduce_avg_list([TSbuf[nme] for nme in ts_names])
         if dp is not None:
             dp.wait()
+        K.side_stream(dev).join()          # weight gradients / spectral-norm corrections ran on the side stream
         # ---- PCGrad: Gram of the original task gradients, replay of the projections, combine
         orders = shuffle_orders(3)
         orders_dev = torch.tensor([j for o in orders for j in o], dtype=torch.int32).to(dev, non_blocking=True)
@@ -110,6 +111,7 @@ class DStepTape:
     @staticmethod
     def _sync_task(dp, S, i):
         if dp is not None:
+            K.side_stream(S.device).join()     # the task vector is complete once the side-stream weight gradients are
             dp.all_reduce_avg(S[i])            # overlaps with the next task's backward (separate stream)
 
 
