@@ -6,10 +6,11 @@
 One process per GPU (launched by torch.distributed.run for N > 1, backend nccl == RCCL).  A "step" is
 one pass of the hot path over one batch of synthetic LDCT-shaped 64x64 patches (32 per GPU, weak
 scaling).  Prints ONE JSON line on rank 0.  `value` = patches/s over all ranks, inputs resident in HBM.
-Extra objects: `roofline` for the dominant kernel (fp32-MFMA implicit-GEMM 3x3 conv, 32->32 ch,
-M = 32*64*64 pixels: 2.416 GFLOP per launch) timed with HIP events on the launch stream in a second,
-event-instrumented pass of the same K steps (so the events do not perturb `value`), and `cpu_baseline`
-(the CPU oracle, kind "port", timed on rank 0 at N == 1 on a bounded sample).
+Extra objects: `roofline` for the dominant kernel -- the fp32-MFMA implicit-GEMM instantiation with the
+largest share of the step's GPU time -- timed by the library's own launch profiler (HIP events recorded
+on the launch stream directly around that kernel, include/mtdgan_hip.h mtd_prof_*) in a second pass of
+the same K steps, so the events do not perturb `value`; and `cpu_baseline` (the CPU oracle, kind "port",
+timed on rank 0 at N == 1 on a bounded sample).
 """
 import argparse
 import json
@@ -22,7 +23,6 @@ sys.path.insert(0, ROOT)
 
 PER_GPU_BATCH = 32
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA peak (dense)
-CONV_FLOPS = 2.0 * PER_GPU_BATCH * 64 * 64 * 32 * 288   # one 3x3 32->32 conv launch at B=32
 
 
 def parse():
@@ -60,7 +60,22 @@ def cpu_baseline(wl):
         dt = time.perf_counter() - t0
         return {"value": round(nb * iters / dt, 3), "unit": "img/s", "cores": cores, "kind": "port",
                 "sample": f"oracle generator fwd+bwd, {iters} x {nb} patches (1 warm-up), torch CPU {torch.__version__}, {cores} threads"}
-    return wl.cpu_baseline_run(orc, cores)
+    # full training iteration: oracle.train_step (engine.py:33-55 restated) on a small batch
+    nb, iters = 4, 2
+    x, y = orc.synthetic_ldct(nb, seed=1234)
+    state = {"Generator." + k: v for k, v in orc.seeded_fill(orc.g_param_shapes(), seed=7).items()}
+    state.update({"Discriminator." + k: v for k, v in orc.seeded_fill(orc.d_state_shapes(), seed=8).items()})
+    g = torch.Generator().manual_seed(3)
+    masks = [(torch.rand(nb, 512, generator=g) >= 0.3).float() / 0.7 for _ in range(5)]
+    opt = {}
+    orders = [[1, 2], [0, 2], [0, 1]]
+    orc.train_step(state, opt, x, y, masks, orders)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        orc.train_step(state, opt, x, y, masks, orders)
+    dt = time.perf_counter() - t0
+    return {"value": round(nb * iters / dt, 3), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": f"oracle full G+D+PCGrad+AdamW step, {iters} x {nb} patches (1 warm-up), torch CPU {torch.__version__}, {cores} threads"}
 
 
 def main():
@@ -111,19 +126,37 @@ def main():
     roofline = None
     if not args.no_roofline:
         from mtd_gan_amd import kernels as K
-        K.PROFILE = []
+        cap = 8192 * max(1, args.steps)
+        K.prof_enable(cap)
+        step = getattr(wl, "step_eager", wl.step)          # events cannot be recorded inside a graph replay
         for _ in range(args.steps):
-            wl.step()
+            step()
         torch.cuda.synchronize()
-        evs = [(tag, a.elapsed_time(b)) for tag, a, b in K.PROFILE if tag == "igemm_3x3_c32_n32"]
-        K.PROFILE = None
-        if evs:
-            avg_ms = sum(e for _, e in evs) / len(evs)
-            ach = CONV_FLOPS / (avg_ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "igemm_kernel<2,1,4,1> (3x3 conv 32->32, M=131072)", "achieved": round(ach, 2),
-                        "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                        "traffic": None, "launches_timed": len(evs), "avg_launch_us": round(avg_ms * 1e3, 2),
-                        "flops_per_launch": CONV_FLOPS}
+        recs = K.prof_collect(cap)
+        K.prof_enable(0)
+        by = {}
+        for r in recs:
+            if r["kernel"].startswith("igemm"):
+                d = by.setdefault(r["kernel"], {"ms": 0.0, "flops": 0.0, "n": 0, "shapes": {}})
+                d["ms"] += r["ms"]
+                d["flops"] += r["flops"]
+                d["n"] += 1
+                key = f"M{r['M']}_N{r['N']}_C{r['C']}_T{r['taps']}_S{r['splitk']}"
+                sh = d["shapes"].setdefault(key, [0.0, 0.0, 0])
+                sh[0] += r["ms"]; sh[1] += r["flops"]; sh[2] += 1
+        if by:
+            name, d = max(by.items(), key=lambda kv: kv[1]["ms"])
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            top = sorted(d["shapes"].items(), key=lambda kv: -kv[1][0])[:4]
+            roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "launches_timed": d["n"], "avg_launch_us": round(1e3 * d["ms"] / d["n"], 2),
+                        "flops_per_launch": round(d["flops"] / d["n"]),
+                        "share_of_step_gpu_ms": round(d["ms"] / args.steps, 3),
+                        "top_shapes": {k: {"us": round(1e3 * v[0] / v[2], 2), "tflops": round(v[1] / v[0] / 1e9, 2), "launches_per_step": v[2] // args.steps}
+                                       for k, v in top},
+                        "other_igemm": {k: {"tflops": round(v["flops"] / v["ms"] / 1e9, 2), "ms_per_step": round(v["ms"] / args.steps, 3)}
+                                        for k, v in by.items() if k != name}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -186,6 +186,10 @@ int mtd_pcgrad_combine(const float* g0, const float* g1, const float* g2, const 
 typedef struct { float* p; const float* g; float* m; float* v; long long n; } mtd_adamw_tensor;
 int mtd_adamw_multi(const mtd_adamw_tensor* tensors_dev, const mtd_adamw_tensor* tensors_host, int count,
                     float lr, float beta1, float beta2, float eps, float wd, int step, void* stream);
+/* same, with (1 - lr*wd, lr/bias_correction1, 1/sqrt(bias_correction2)) read from dyn[0..2] (device memory):
+ * lets a captured hipGraph be replayed with a new step count */
+int mtd_adamw_multi_dyn(const mtd_adamw_tensor* tensors_dev, const mtd_adamw_tensor* tensors_host, int count,
+                        float beta1, float beta2, float eps, const float* dyn, void* stream);
 
 /* ---- loss terms (losses.py:10-15,99-138; networks.py:1962-1977,1998-2002), batched by descriptor table --
  * kind 0: m*(a-t)^2 with t = b[i] or tconst, m = (mx[i]-my[i] != 0) or 1   (ls_gan / NDS_Loss / F.mse_loss)
@@ -209,6 +213,26 @@ int mtd_clip01_bwd(const float* g, const float* x, float* out, long long n, void
 size_t mtd_edge_loss_ws_bytes(int B);
 int mtd_edge_loss(const float* a, const float* b, int B, float scale, float eps, float* out, float* grad_out,
                   float coef, int accumulate, void* ws, void* stream);
+
+/* ---- launch profiler (bench.py's roofline leg) ---------------------------------------------------------------
+ * When enabled, mtd_conv_igemm / mtd_conv_wgrad bracket their MAIN kernel (not the split-K / slab reductions that
+ * follow it) with a pair of HIP events on the stream they were given.  mtd_prof_collect synchronises those events
+ * and returns one record per launch.  kernel: 0 = igemm_kernel, 1 = wgrad_kernel; cfg = tile configuration index
+ * (the template instantiation); flops = 2*M*N*C*taps (dense algorithmic count).
+ * Not for use while a hipGraph is being captured. */
+/* Tuning hook (tools/tune_igemm.py): force the tile configuration (0..5, -1 = automatic) and the split-K factor of
+ * every following mtd_conv_igemm call in this process. */
+int mtd_conv_igemm_override(int cfg, int splitk);
+
+typedef struct mtd_prof_record {
+    int kernel, cfg, splitk, N, C, taps;
+    long long M;
+    double flops;
+    float ms;
+    int _pad;
+} mtd_prof_record;
+int mtd_prof_enable(int capacity);                       /* capacity <= 0 switches profiling off and frees events */
+int mtd_prof_collect(mtd_prof_record* out, int max_records);   /* returns the number of completed records */
 
 const char* mtd_version(void);
 

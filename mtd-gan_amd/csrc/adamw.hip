@@ -8,7 +8,13 @@ namespace {
 constexpr int AW_ELEMS = 2048;   // elements per block
 
 __global__ __launch_bounds__(256) void adamw_kernel(const mtd_adamw_tensor* __restrict__ T, int count, float decay, float beta1,
-                                                    float beta2, float step_size, float inv_sqrt_bc2, float eps) {
+                                                    float beta2, float step_size, float inv_sqrt_bc2, float eps,
+                                                    const float* __restrict__ dyn) {
+    if (dyn) {      // step-dependent scalars from device memory (hipGraph replay: kernel arguments are frozen)
+        decay = dyn[0];
+        step_size = dyn[1];
+        inv_sqrt_bc2 = dyn[2];
+    }
     int acc = 0, ti = -1, local = 0;
     for (int t = 0; t < count; ++t) {
         int nb = (int)((T[t].n + AW_ELEMS - 1) / AW_ELEMS);
@@ -50,7 +56,23 @@ extern "C" int mtd_adamw_multi(const mtd_adamw_tensor* tensors_dev, const mtd_ad
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     const float decay = 1.f - lr * wd;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tensors_dev, count, decay, beta1, beta2,
-                       step_size, inv_sqrt_bc2, eps);
+                       step_size, inv_sqrt_bc2, eps, (const float*)nullptr);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+// Same update with (decay, step_size, 1/sqrt(bias_correction2)) read from dyn[0..2] in device memory, so that a
+// captured hipGraph can be replayed with a new step count: the host refreshes the three floats before each replay.
+extern "C" int mtd_adamw_multi_dyn(const mtd_adamw_tensor* tensors_dev, const mtd_adamw_tensor* tensors_host, int count, float beta1,
+                                   float beta2, float eps, const float* dyn, void* stream) {
+    if (!tensors_dev || !tensors_host || count <= 0 || !dyn) return MTD_EINVAL;
+    long long blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!tensors_host[i].p || !tensors_host[i].g || !tensors_host[i].m || !tensors_host[i].v || tensors_host[i].n <= 0) return MTD_EINVAL;
+        blocks += (tensors_host[i].n + AW_ELEMS - 1) / AW_ELEMS;
+    }
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tensors_dev, count, 0.f, beta1, beta2, 0.f,
+                       0.f, eps, dyn);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }

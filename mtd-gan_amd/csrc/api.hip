@@ -1,3 +1,62 @@
-// Library identification.
+// Library identification and the optional launch profiler (HIP events around the dominant kernels).
 #include "common.h"
+#include <mutex>
+#include <vector>
+
 extern "C" const char* mtd_version(void) { return "mtdgan_hip 0.1.0 (gfx950)"; }
+
+namespace {
+struct ProfSlot {
+    mtd_prof_record rec;
+    hipEvent_t e0, e1;
+};
+std::mutex g_prof_mu;
+std::vector<ProfSlot> g_prof;
+int g_prof_cap = 0;
+}  // namespace
+
+// Internal hooks (common.h).  begin returns a slot index or -1 when profiling is off / full.
+int mtd_prof_begin(int kernel, int cfg, int splitk, long long M, int N, int C, int taps, hipStream_t s) {
+    if (g_prof_cap <= 0) return -1;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if ((int)g_prof.size() >= g_prof_cap) return -1;
+    ProfSlot sl;
+    sl.rec.kernel = kernel; sl.rec.cfg = cfg; sl.rec.splitk = splitk;
+    sl.rec.M = M; sl.rec.N = N; sl.rec.C = C; sl.rec.taps = taps;
+    sl.rec.flops = 2.0 * (double)M * N * C * taps;
+    sl.rec.ms = 0.f;
+    if (hipEventCreate(&sl.e0) != hipSuccess) return -1;
+    if (hipEventCreate(&sl.e1) != hipSuccess) { (void)hipEventDestroy(sl.e0); return -1; }
+    (void)hipEventRecord(sl.e0, s);
+    g_prof.push_back(sl);
+    return (int)g_prof.size() - 1;
+}
+
+void mtd_prof_end(int slot, hipStream_t s) {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (slot < (int)g_prof.size()) (void)hipEventRecord(g_prof[slot].e1, s);
+}
+
+extern "C" int mtd_prof_enable(int capacity) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& sl : g_prof) { (void)hipEventDestroy(sl.e0); (void)hipEventDestroy(sl.e1); }
+    g_prof.clear();
+    g_prof_cap = capacity > 0 ? capacity : 0;
+    if (g_prof_cap) g_prof.reserve(g_prof_cap);
+    return MTD_OK;
+}
+
+extern "C" int mtd_prof_collect(mtd_prof_record* out, int max_records) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int n = 0;
+    for (auto& sl : g_prof) {
+        if (hipEventSynchronize(sl.e1) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, sl.e0, sl.e1) != hipSuccess) continue;
+        sl.rec.ms = ms;
+        if (out && n < max_records) out[n] = sl.rec;
+        ++n;
+    }
+    return n;
+}

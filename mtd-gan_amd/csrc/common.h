@@ -29,3 +29,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static inline long long geom_pixels(const mtd_geom& g) { return (long long)g.B * g.OH * g.OW; }
+// launch profiler hooks (api.hip)
+int mtd_prof_begin(int kernel, int cfg, int splitk, long long M, int N, int C, int taps, hipStream_t s);
+void mtd_prof_end(int slot, hipStream_t s);
+

@@ -2,6 +2,14 @@
 // 1 -> 1, Linear 512 -> 1).  These layers carry < 0.5 % of the step's FLOPs and are bound by HBM/L2
 // traffic of the wide side, so they stay off the matrix cores.  Same argument contract and epilogue
 // as mtd_conv_igemm.  The weight-gradient variant handles min(N, C) == 1.
+//
+// Roofline: HBM.  Algorithmic bytes per launch = 4 * (wide tensor elements + narrow tensor elements): the wide
+// tensor (M x V floats) must cross HBM once.  The fast paths are organised around that:
+//   fwd_c1   (1 -> N):  a thread owns 4 output channels with their taps in registers; one 16-byte store per 9 loads.
+//   fwd_n1   (C -> 1):  C/4 lanes share a pixel (16-byte loads of the NHWC row), taps re-read through L1/L2 with
+//                       an XCD-contiguous block order, DPP/shuffle reduction, one store per pixel.
+//   wgrad_wide (N==1 or C==1): loops over the pixels of the WIDE tensor so each of its rows is loaded exactly once
+//                       (16 bytes per lane); the narrow tensor is gathered at the tap offsets (L1-resident scalars).
 #include "common.h"
 
 namespace {
@@ -152,6 +160,280 @@ __global__ __launch_bounds__(256) void direct_wgrad_kernel(const DWParams p) {
     }
 }
 
+
+// ---- fast forward paths ------------------------------------------------------------------------
+struct FwdParams {
+    mtd_conv_args a;
+    int M, T, identity, vec_store;
+    int G;              // lanes (fwd_n1) or threads (fwd_c1) that share one pixel
+    int ppb;            // pixels per workgroup
+    int tap_dy[16], tap_dx[16], tap_kidx[16];
+};
+
+__device__ __forceinline__ int xcd_contiguous_block(int b, int nblk) {
+    // consecutive workgroup ids round-robin over the 8 XCDs; give every XCD one contiguous run of tiles so
+    // that neighbouring image rows (re-read by the vertical taps) meet in the same L2
+    const int q = nblk >> 3, r = nblk & 7;
+    const int x = b & 7, i = b >> 3;
+    return x * q + (x < r ? x : r) + i;
+}
+
+__device__ __forceinline__ void store_epilogue4(const mtd_conv_args& a, const float acc[4], float sc, const float bias[4],
+                                                long long pix, int n, int vec_store) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float x = acc[j] * sc + bias[j];
+        if (a.add1) x += a.add1[pix * a.add1_ld + n + j];
+        if (a.add2) x += a.add2[pix * a.add2_ld + n + j];
+        x = apply_act(x, a.act);
+        if (a.mask) x *= (a.mask[pix * a.mask_ld + n + j] > 0.f) ? 1.f : a.mask_slope;
+        v[j] = x;
+    }
+    float* o = a.out + pix * a.out_ld + n;
+    if (vec_store) {
+        f32x4 q = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(o) = q;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = v[j];
+    }
+}
+
+// C == 1: thread = (pixel lane, 4 output channels)
+__global__ __launch_bounds__(256) void fwd_c1_kernel(const FwdParams p) {
+    const mtd_conv_args& a = p.a;
+    const mtd_geom& g = a.g;
+    const int NQ = p.G, PL = 256 / NQ;
+    const int nq = threadIdx.x % NQ, pl = threadIdx.x / NQ;
+    const int n = nq * 4;
+    float w[4][16];
+    float bias[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bias[j] = a.bias ? a.bias[n + j] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) w[j][t] = (t < p.T) ? a.w[(long long)(n + j) * a.w_sn + (long long)p.tap_kidx[t] * a.w_st] : 0.f;
+    }
+    const float sc = a.scale ? *a.scale : 1.f;
+    const int mb = blockIdx.x * p.ppb;
+    const int me = min(p.M, mb + p.ppb);
+    for (int m = mb + pl; m < me; m += PL) {
+        int b, oy, ox;
+        decompose(g, m, b, oy, ox);
+        const int py = oy * g.in_sy + g.off_y, px = ox * g.in_sx + g.off_x;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            if (t < p.T) {
+                const int iy = py + p.tap_dy[t], ix = px + p.tap_dx[t];
+                if (((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW)) {
+                    const float v = a.in[(((long long)b * g.IH + iy) * g.IW + ix) * a.in_ld];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = fmaf(v, w[j][t], acc[j]);
+                }
+            }
+        }
+        long long pix = m;
+        if (!p.identity) pix = ((long long)b * g.OHF + (oy * g.out_sy + g.out_oy)) * g.OWF + (ox * g.out_sx + g.out_ox);
+        store_epilogue4(a, acc, sc, bias, pix, n, p.vec_store);
+    }
+}
+
+// N == 1: G = C/4 lanes per pixel, 64/G pixels per wave iteration
+__global__ __launch_bounds__(256) void fwd_n1_kernel(const FwdParams p, int nblk) {
+    const mtd_conv_args& a = p.a;
+    const mtd_geom& g = a.g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int CL = p.G, PPW = 64 / CL;
+    const int cl = lane % CL, pg = lane / CL;
+    f32x4 w[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            w[t][j] = (t < p.T) ? a.w[(long long)(4 * cl + j) * a.w_sc + (long long)p.tap_kidx[t] * a.w_st] : 0.f;
+    }
+    const float sc = a.scale ? *a.scale : 1.f;
+    const float bias = a.bias ? a.bias[0] : 0.f;
+    const int blk = xcd_contiguous_block(blockIdx.x, nblk);
+    const int mb = blk * p.ppb;
+    const int me = min(p.M, mb + p.ppb);
+    for (int base = mb + wave * PPW; base < me; base += 4 * PPW) {
+        const int m = base + pg;
+        const bool live = m < me;
+        int b = 0, oy = 0, ox = 0;
+        if (live) decompose(g, m, b, oy, ox);
+        const int py = oy * g.in_sy + g.off_y, px = ox * g.in_sx + g.off_x;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            if (t < p.T) {
+                const int iy = py + p.tap_dy[t], ix = px + p.tap_dx[t];
+                if (live & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW)) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(a.in + (((long long)b * g.IH + iy) * g.IW + ix) * a.in_ld + 4 * cl);
+                    acc = fmaf(v[0], w[t][0], acc);
+                    acc = fmaf(v[1], w[t][1], acc);
+                    acc = fmaf(v[2], w[t][2], acc);
+                    acc = fmaf(v[3], w[t][3], acc);
+                }
+            }
+        }
+        for (int off = CL >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (live && cl == 0) {
+            long long pix = m;
+            if (!p.identity) pix = ((long long)b * g.OHF + (oy * g.out_sy + g.out_oy)) * g.OWF + (ox * g.out_sx + g.out_ox);
+            float v = acc * sc + bias;
+            if (a.add1) v += a.add1[pix * a.add1_ld];
+            if (a.add2) v += a.add2[pix * a.add2_ld];
+            v = apply_act(v, a.act);
+            if (a.mask) v *= (a.mask[pix * a.mask_ld] > 0.f) ? 1.f : a.mask_slope;
+            a.out[pix * a.out_ld] = v;
+        }
+    }
+}
+
+// ---- fast weight gradient: min(N, C) == 1, loop over the pixels of the wide tensor ---------------
+struct WideParams {
+    mtd_wgrad_args a;
+    int Mw;             // pixels of the wide tensor's grid
+    int T, V, CL, ppb, n_is_one;
+    long long slab_stride;
+    int tap_dy[16], tap_dx[16];
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void wgrad_wide_kernel(const WideParams p) {
+    const mtd_wgrad_args& a = p.a;
+    const mtd_geom& g = a.g;
+    extern __shared__ float red[];                  // [4 waves][T * V + V]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int CL = p.CL, PPW = 64 / CL;
+    const int cl = lane % CL, pg = lane / CL;
+    const bool n1 = p.n_is_one != 0;
+    const float* wide = n1 ? a.q : a.p;
+    const int wide_ld = n1 ? a.q_ld : a.p_ld;
+    const float* nar = n1 ? a.p : a.q;
+    const int nar_ld = n1 ? a.p_ld : a.q_ld;
+    const int GH = n1 ? g.IH : g.OH, GW = n1 ? g.IW : g.OW;      // grid of the wide tensor
+    const int NH = n1 ? g.OH : g.IH, NW = n1 ? g.OW : g.IW;      // grid of the narrow tensor
+    float acc[VEC][16];
+    float bacc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        bacc[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[j][t] = 0.f;
+    }
+    const int mb = blockIdx.x * p.ppb;
+    const int me = min(p.Mw, mb + p.ppb);
+    for (int m = mb + wave * PPW + pg; m < me; m += 4 * PPW) {
+        const int x = m % GW;
+        const int t2 = m / GW;
+        const int y = t2 % GH;
+        const int b = t2 / GH;
+        float wv[VEC];
+        if (VEC == 4) {
+            const f32x4 q4 = *reinterpret_cast<const f32x4*>(wide + (long long)m * wide_ld + 4 * cl);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) wv[j] = q4[j];
+        } else {
+            wv[0] = wide[(long long)m * wide_ld + cl];
+        }
+        if (!n1) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) bacc[j] += wv[j];
+        } else if (cl == 0) {
+            bacc[0] += nar[(long long)m * nar_ld];             // same-size grids (checked on the host)
+        }
+        const int by = n1 ? (y - g.off_y) : (y * g.in_sy + g.off_y);
+        const int bx = n1 ? (x - g.off_x) : (x * g.in_sx + g.off_x);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            if (t < p.T) {
+                const int ny = n1 ? by - p.tap_dy[t] : by + p.tap_dy[t];
+                const int nx = n1 ? bx - p.tap_dx[t] : bx + p.tap_dx[t];
+                if (((unsigned)ny < (unsigned)NH) & ((unsigned)nx < (unsigned)NW)) {
+                    const float s = nar[(((long long)b * NH + ny) * NW + nx) * nar_ld];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) acc[j][t] = fmaf(s, wv[j], acc[j][t]);
+                }
+            }
+        }
+    }
+    // pixel groups inside the wave, then the four waves through LDS (fixed order => deterministic)
+    for (int off = CL; off < 64; off <<= 1) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            bacc[j] += __shfl_xor(bacc[j], off, 64);
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                if (t < p.T) acc[j][t] += __shfl_xor(acc[j][t], off, 64);
+        }
+    }
+    const int per = p.T * p.V + p.V;
+    if (pg == 0) {
+        float* r = red + wave * per;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int ch = VEC * cl + j;
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                if (t < p.T) r[t * p.V + ch] = acc[j][t];
+            r[p.T * p.V + ch] = bacc[j];
+        }
+    }
+    __syncthreads();
+    float* slab = a.ws + (long long)blockIdx.x * p.slab_stride;
+    const long long nw = (long long)p.T * p.V;
+    for (int i = threadIdx.x; i < per; i += 256) {
+        const float s = (red[i] + red[per + i]) + (red[2 * per + i] + red[3 * per + i]);
+        if (i < nw) slab[i] = s;
+        else if (a.db) {
+            const int ch = i - (int)nw;
+            if (n1) { if (ch == 0) slab[nw] = s; }
+            else slab[nw + ch] = s;
+        }
+    }
+}
+
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// fast weight-gradient path applicable?  fills the launch shape
+bool wide_plan(const mtd_wgrad_args& a, WideParams& p) {
+    const mtd_geom& g = a.g;
+    p.a = a;
+    p.T = g.TH * g.TW;
+    p.n_is_one = (a.N == 1);
+    p.V = a.N > a.C ? a.N : a.C;
+    if (p.T > 16) return false;
+    if (p.n_is_one) {
+        if (g.in_sy != 1 || g.in_sx != 1 || g.OH != g.IH || g.OW != g.IW) return false;
+        p.Mw = g.B * g.IH * g.IW;
+    } else {
+        p.Mw = g.B * g.OH * g.OW;
+    }
+    if (p.V == 1) p.CL = 1;
+    else {
+        if (p.V % 4) return false;
+        p.CL = p.V / 4;
+        if (!is_pow2(p.CL) || p.CL > 64) return false;
+        const int ld = p.n_is_one ? a.q_ld : a.p_ld;
+        const float* wide = p.n_is_one ? a.q : a.p;
+        if ((ld % 4) || !aligned16(wide)) return false;
+    }
+    if ((long long)(p.T * p.V + p.V) * 4 * 4 > 48 * 1024) return false;
+    long long ppb = (p.Mw + 511) / 512;
+    const long long min_ppb = 4ll * (64 / p.CL) * 4;
+    if (ppb < min_ppb) ppb = min_ppb;
+    p.ppb = (int)ppb;
+    for (int t = 0; t < p.T; ++t) {
+        p.tap_dy[t] = (t / g.TW) * g.tap_dy;
+        p.tap_dx[t] = (t % g.TW) * g.tap_dx;
+    }
+    return true;
+}
+
 }  // namespace
 
 extern "C" int mtd_conv_direct(const mtd_conv_args* a, void* stream) {
@@ -163,6 +445,44 @@ extern "C" int mtd_conv_direct(const mtd_conv_args* a, void* stream) {
     if ((g.OH - 1) * g.out_sy + g.out_oy >= g.OHF || (g.OW - 1) * g.out_sx + g.out_ox >= g.OWF) return MTD_EINVAL;
     long long total = geom_pixels(g) * a->N;
     int identity = (g.out_sy == 1 && g.out_sx == 1 && g.out_oy == 0 && g.out_ox == 0 && g.OHF == g.OH && g.OWF == g.OW);
+    const long long Mpix = geom_pixels(g);
+    const int T = g.TH * g.TW;
+    const bool fast_c1 = (a->C == 1 && (a->N % 4) == 0 && is_pow2(a->N / 4) && a->N / 4 <= 256 && T <= 16 && Mpix < (1ll << 31));
+    const bool fast_n1 = (a->N == 1 && (a->C % 4) == 0 && is_pow2(a->C / 4) && a->C / 4 <= 64 && T <= 16 && Mpix < (1ll << 31) &&
+                          (a->in_ld % 4) == 0 && aligned16(a->in));
+    if (fast_c1 || fast_n1) {
+        FwdParams p;
+        p.a = *a;
+        p.M = (int)Mpix;
+        p.T = T;
+        p.identity = identity;
+        p.vec_store = ((a->out_ld % 4) == 0 && aligned16(a->out)) ? 1 : 0;
+        for (int t = 0; t < T; ++t) {
+            const int ty = t / g.TW, tx = t % g.TW;
+            p.tap_dy[t] = ty * g.tap_dy;
+            p.tap_dx[t] = tx * g.tap_dx;
+            p.tap_kidx[t] = (g.ky0 + ty * g.ky_step) * g.KW + (g.kx0 + tx * g.kx_step);
+        }
+        if (fast_c1) {
+            p.G = a->N / 4;
+            const int PL = 256 / p.G;
+            long long ppb = (Mpix + 2047) / 2048;
+            if (ppb < PL) ppb = PL;
+            p.ppb = (int)ppb;
+            const int nblk = (int)((Mpix + ppb - 1) / ppb);
+            hipLaunchKernelGGL(fwd_c1_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
+        } else {
+            p.G = a->C / 4;
+            const int PPW = 64 / p.G;
+            long long ppb = (Mpix + 2047) / 2048;
+            if (ppb < 4 * PPW) ppb = 4 * PPW;
+            p.ppb = (int)ppb;
+            const int nblk = (int)((Mpix + ppb - 1) / ppb);
+            hipLaunchKernelGGL(fwd_n1_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p, nblk);
+        }
+        MTD_LAUNCH_CHECK();
+        return MTD_OK;
+    }
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(direct_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a, total, identity);
@@ -172,6 +492,19 @@ extern "C" int mtd_conv_direct(const mtd_conv_args* a, void* stream) {
 
 // called from mtd_conv_wgrad when min(N,C)==1; returns the number of slabs written (or <0)
 int mtd_direct_wgrad_launch(const mtd_wgrad_args* a, int* nslab_out, long long slab_stride, void* stream) {
+    {
+        WideParams wp;
+        if (wide_plan(*a, wp)) {
+            wp.slab_stride = slab_stride;
+            const int nblk = (wp.Mw + wp.ppb - 1) / wp.ppb;
+            *nslab_out = nblk;
+            const size_t lds = (size_t)4 * (wp.T * wp.V + wp.V) * sizeof(float);
+            if (wp.V == 1) hipLaunchKernelGGL((wgrad_wide_kernel<1>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, wp);
+            else hipLaunchKernelGGL((wgrad_wide_kernel<4>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, wp);
+            MTD_LAUNCH_CHECK();
+            return MTD_OK;
+        }
+    }
     DWParams p;
     p.a = *a;
     p.M = (int)geom_pixels(a->g);
@@ -200,6 +533,10 @@ int mtd_direct_wgrad_launch(const mtd_wgrad_args* a, int* nslab_out, long long s
 }
 
 int mtd_direct_wgrad_nslab(const mtd_wgrad_args* a) {
+    {
+        WideParams wp;
+        if (wide_plan(*a, wp)) return (wp.Mw + wp.ppb - 1) / wp.ppb;
+    }
     long long M = geom_pixels(a->g);
     int V = a->N > a->C ? a->N : a->C;
     int VL = 1;

@@ -304,25 +304,37 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IgemmParams 
 
 struct Plan { int cfg, BM, BN, splitk, c_per_split; };
 
+int g_force_cfg = -1, g_force_split = -1;      // tuning hook (mtd_conv_igemm_override)
+const int kCfgBM[6] = {256, 128, 256, 64, 128, 32};
+const int kCfgBN[6] = {32, 32, 64, 64, 128, 128};
+
 Plan make_plan(const mtd_conv_args& a) {
     const long long M = geom_pixels(a.g);
     Plan pl{};
-    if (a.N % 128 == 0) {
-        if (M > 64) { pl.cfg = 4; pl.BM = 128; pl.BN = 128; }
-        else { pl.cfg = 5; pl.BM = 32; pl.BN = 128; }
-    } else if (a.N % 64 == 0) {
-        if (M >= 1024) { pl.cfg = 2; pl.BM = 256; pl.BN = 64; }
-        else { pl.cfg = 3; pl.BM = 64; pl.BN = 64; }
-    } else {
-        if (M >= 1024) { pl.cfg = 0; pl.BM = 256; pl.BN = 32; }
-        else { pl.cfg = 1; pl.BM = 128; pl.BN = 32; }
+    if (g_force_cfg >= 0 && g_force_cfg < 6 && a.N % kCfgBN[g_force_cfg] == 0) {
+        pl.cfg = g_force_cfg; pl.BM = kCfgBM[pl.cfg]; pl.BN = kCfgBN[pl.cfg];
+        int chunks = a.C / KC;
+        int sk = g_force_split > 0 ? g_force_split : 1;
+        if (sk > chunks) sk = chunks;
+        int cps = (chunks + sk - 1) / sk;
+        pl.splitk = (chunks + cps - 1) / cps;
+        pl.c_per_split = cps * KC;
+        return pl;
     }
+    // Derived from the standalone sweep of all 109 conv shapes of the training step (tools/tune_igemm.py, profiles/):
+    // fp32 MFMA is slow enough (64 clk per 32x32x2) that one 32x32 accumulator tile per wave at high occupancy beats the
+    // register-blocked tiles almost everywhere; the wide tiles only pay for the huge-M, thin-K first-stage layers.
+    pl.cfg = 1;
+    if ((M >= 131072 && a.N >= 64) || (M >= 32768 && a.N >= 256 && a.C <= 64)) pl.cfg = 0;
+    else if (M >= 32768 && a.N == 64 && a.C >= 128) pl.cfg = 3;
+    pl.BM = kCfgBM[pl.cfg];
+    pl.BN = kCfgBN[pl.cfg];
     long long blocks = ((M + pl.BM - 1) / pl.BM) * (a.N / pl.BN);
     int chunks = a.C / KC;
-    int want = (int)((768 + blocks - 1) / blocks);
-    int sk = want < 1 ? 1 : want;
+    int sk = blocks <= 256 ? (int)(512 / blocks) : 1;      // fill ~2 workgroups per CU; never split a grid that already does
     if (sk > chunks) sk = chunks;
     if (sk > 32) sk = 32;
+    if (sk < 1) sk = 1;
     int cps = ((chunks + sk - 1) / sk);
     sk = (chunks + cps - 1) / cps;
     pl.splitk = sk;
@@ -350,6 +362,12 @@ int check_args(const mtd_conv_args& a) {
 }
 
 }  // namespace
+
+extern "C" int mtd_conv_igemm_override(int cfg, int splitk) {
+    g_force_cfg = cfg;
+    g_force_split = splitk;
+    return MTD_OK;
+}
 
 extern "C" size_t mtd_conv_igemm_ws_bytes(const mtd_conv_args* a) {
     if (!a || check_args(*a) != MTD_OK) return 0;
@@ -395,6 +413,7 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
     }
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((p.M + pl.BM - 1) / pl.BM, a->N / pl.BN, pl.splitk);
+    const int prof = mtd_prof_begin(0, pl.cfg, pl.splitk, p.M, a->N, a->C, a->g.TH * a->g.TW, s);
     switch (pl.cfg) {
         case 0: hipLaunchKernelGGL((igemm_kernel<2, 1, 4, 1>), grid, dim3(256), 0, s, p); break;
         case 1: hipLaunchKernelGGL((igemm_kernel<1, 1, 4, 1>), grid, dim3(256), 0, s, p); break;
@@ -403,6 +422,7 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
         case 4: hipLaunchKernelGGL((igemm_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p); break;
         default: hipLaunchKernelGGL((igemm_kernel<1, 1, 1, 4>), grid, dim3(256), 0, s, p); break;
     }
+    mtd_prof_end(prof, s);
     MTD_LAUNCH_CHECK();
     if (pl.splitk > 1) {
         long long total = (long long)p.M * a->N;

@@ -361,12 +361,14 @@ extern "C" int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream) {
         p.ppw = pl.ppw;
         p.nCt = a->C / (32 * pl.WC);
         dim3 grid(pl.nsplit, (a->N / (32 * pl.WN)) * p.nCt, pl.ntg);
+        const int prof = mtd_prof_begin(1, pl.cfg, pl.nsplit, geom_pixels(a->g), a->N, a->C, a->g.TH * a->g.TW, s);
         switch (pl.cfg) {
             case 0: hipLaunchKernelGGL((wgrad_kernel<1, 1, 9>), grid, dim3(256), 0, s, p); break;
             case 1: hipLaunchKernelGGL((wgrad_kernel<1, 1, 4>), grid, dim3(256), 0, s, p); break;
             case 2: hipLaunchKernelGGL((wgrad_kernel<2, 2, 1>), grid, dim3(256), 0, s, p); break;
             default: hipLaunchKernelGGL((wgrad_kernel<1, 1, 8>), grid, dim3(256), 0, s, p); break;
         }
+        mtd_prof_end(prof, s);
         MTD_LAUNCH_CHECK();
     }
     // staged, order-fixed reduction of the slabs

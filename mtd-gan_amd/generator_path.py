@@ -19,11 +19,14 @@ def block_forward(x, w_img, b_img, w_fft, b_fft, save):
     B, H, W, _ = x.shape
     g = K.geom_fwd(B, H, W, 3, 1, 1)
     img = K.empty_nhwc(B, H, W, CH, x)
-    K.conv(x, w_img, g, CH, CH, CH * 9, 9, img, bias=b_img, act=ACT_RELU)          # relu(conv3x3(x)+b)
+    # the spatial branch (fp32-MFMA conv) runs on a side stream beside the spectral branch (FFT rows / columns)
+    side = K.side_stream(x.device, 1)
+    side.run(lambda: K.conv(x, w_img, g, CH, CH, CH * 9, 9, img, bias=b_img, act=ACT_RELU), x)   # relu(conv3x3(x)+b)
     R = K.rfft_rows(x, 0)
     w2t = K.transpose64(w_fft)
     T, S, Z = K.spec_mix_fwd(R, w2t, b_fft, save)
     out = K.empty_nhwc(B, H, W, CH, x)
+    side.join()
     K.irfft_rows(T, out, add1=x, add2=img)                                          # x + img + irfft2(...)
     return out, ((x, img, S, Z) if save else None)
 
@@ -37,11 +40,20 @@ def block_backward(g, saved, w_img, w_fft, grads, premask):
     side = K.side_stream(x.device)
     gm = K.act_grad(g, img, 0.0)                                                    # g * (img > 0)
     side.run(lambda: K.wgrad(gm, x, K.geom_fwd(B, H, W, 3, 1, 1), CH, CH, grads["dw_img"], CH * 9, 9, db=grads["db_img"]), gm, g)
-    gR = K.rfft_rows(g, 1)                                                          # irfft2 backward
-    gT = K.spec_mix_bwd(gR, w_fft, S, Z, grads["dw_fft"], grads["db_fft"])
+    # spectral branch backward on a second side stream, beside the spatial data gradient on the main stream
+    side1 = K.side_stream(x.device, 1)
+    box = []
+
+    def spectral():
+        gR = K.rfft_rows(g, 1)                                                      # irfft2 backward
+        box.append(K.spec_mix_bwd(gR, w_fft, S, Z, grads["dw_fft"], grads["db_fft"]))
+    side1.run(spectral, g)
     d1 = K.empty_nhwc(B, H, W, CH, x)
     K.conv(gm, w_img, K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, d1, add1=g)  # dgrad(img branch) + residual
     gx = K.empty_nhwc(B, H, W, CH, x)
+    side1.join()
+    gT = box[0]
+    K.crosses_streams(gT)
     K.irfft_rows(gT, gx, add1=d1, mask=x if premask else None)
     return gx
 

@@ -58,16 +58,44 @@ def packed_weight_view(w, N, Cc, w_sn, w_sc):
         hit = (dst, w)          # keep the source alive so its data_ptr cannot be recycled under the same key
         _pack_cache[key] = hit
     return hit[0], Cc, 1, N * Cc
-PROFILE = None      # bench.py sets this to a list to collect (tag, start_event, end_event) per conv launch
+CALL_LOG = None     # tools/tune_igemm.py: a list collects ("igemm" | "wgrad", bytes(argument struct)) per call
+PROFILE = None      # legacy hook: a list collects (tag, start_event, end_event) per un-split igemm launch
+
+IGEMM_CONFIGS = ["igemm_kernel<2, 1, 4, 1>", "igemm_kernel<1, 1, 4, 1>", "igemm_kernel<2, 2, 4, 1>",
+                 "igemm_kernel<1, 1, 2, 2>", "igemm_kernel<2, 2, 2, 2>", "igemm_kernel<1, 1, 1, 4>"]
+WGRAD_CONFIGS = ["wgrad_kernel<1, 1, 9>", "wgrad_kernel<1, 1, 4>", "wgrad_kernel<2, 2, 1>", "wgrad_kernel<1, 1, 8>"]
+
+
+def prof_enable(capacity):
+    """Switch the library's launch profiler on (HIP events around every igemm / wgrad main kernel) or off (0)."""
+    L = _lib.lib()
+    L.mtd_prof_enable.argtypes = [C.c_int]
+    check(L.mtd_prof_enable(int(capacity)), "mtd_prof_enable")
+
+
+def prof_collect(capacity):
+    L = _lib.lib()
+    buf = (_lib.ProfRecord * capacity)()
+    L.mtd_prof_collect.argtypes = [C.c_void_p, C.c_int]
+    n = L.mtd_prof_collect(C.cast(buf, C.c_void_p), capacity)
+    out = []
+    for r in buf[:min(n, capacity)]:
+        names = IGEMM_CONFIGS if r.kernel == 0 else WGRAD_CONFIGS
+        out.append({"kernel": names[r.cfg] if 0 <= r.cfg < len(names) else "?", "splitk": r.splitk, "M": r.M, "N": r.N,
+                    "C": r.C, "taps": r.taps, "flops": r.flops, "ms": r.ms})
+    return out
 
 
 def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+CAPTURE_TAG = 0     # bumped while a hipGraph is captured so that graph-pool scratch never mixes with eager scratch
+
+
 def workspace(nbytes, device):
     """Grow-only scratch buffer per (device, stream).  Stream order makes reuse safe."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, CAPTURE_TAG)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -149,6 +177,8 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, scale=None, bias=None, add1=None, a
         if need:
             ws = workspace(need, x.device)
             a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+        if CALL_LOG is not None:
+            CALL_LOG.append(("igemm", bytes(a)))
         prof = PROFILE is not None and not need
         if prof:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -158,6 +188,8 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, scale=None, bias=None, add1=None, a
             e1.record()
             PROFILE.append((f"igemm_{geom.TH}x{geom.TW}_c{Cc}_n{N}", e0, e1))
     else:
+        if CALL_LOG is not None:
+            CALL_LOG.append(("direct", bytes(a)))
         check(L.mtd_conv_direct(C.byref(a), stream_ptr()), "mtd_conv_direct")
     return out
 
@@ -179,6 +211,8 @@ def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumula
         raise RuntimeError(f"mtd_conv_wgrad: unsupported arguments N={N} C={Cc}")
     ws = workspace(need, p.device)
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+    if CALL_LOG is not None:
+        CALL_LOG.append(("wgrad", bytes(a)))
     check(L.mtd_conv_wgrad(C.byref(a), stream_ptr()), "mtd_conv_wgrad")
 
 
@@ -280,6 +314,37 @@ def mul(a, b, out=None):
 _desc_cache = {}
 
 
+class _Arena:
+    """Pinned-host + device arenas for descriptor tables and small host->device scalars.  Pre-allocated so that
+    nothing is allocated while a hipGraph is being captured; the H2D copies are ordinary stream-ordered copies
+    (captured as memcpy nodes: a replay re-copies the current pinned contents)."""
+
+    def __init__(self, device, nbytes=16 << 20):
+        self.host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        self.dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.ofs = 0
+
+    def take(self, nbytes):
+        n = (nbytes + 255) & ~255
+        if self.ofs + n > self.host.numel():
+            raise RuntimeError("descriptor arena exhausted")
+        o = self.ofs
+        self.ofs += n
+        return self.host[o:o + nbytes], self.dev[o:o + nbytes]
+
+
+_arenas = {}
+
+
+def arena(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    a = _arenas.get(key)
+    if a is None:
+        a = _Arena(device)
+        _arenas[key] = a
+    return a
+
+
 def device_table(structs, device):
     """Upload an array of ctypes structs once per distinct content (pointers included); returns
     (device tensor, host ctypes array).  Keeps the host array alive for the C call."""
@@ -289,13 +354,64 @@ def device_table(structs, device):
     key = (device.index, raw)
     hit = _desc_cache.get(key)
     if hit is None:
-        if len(_desc_cache) > 16384:
+        ar = arena(device)
+        if ar.ofs + len(raw) + 256 > ar.host.numel():       # full: start over (old entries are dropped with it)
             _desc_cache.clear()
-        host = torch.frombuffer(bytearray(raw), dtype=torch.uint8).pin_memory()
-        dev = host.to(device, non_blocking=True)
+            ar.ofs = 0
+        host, dev = ar.take(len(raw))
+        host.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+        dev.copy_(host, non_blocking=True)
         hit = (dev, arr, host)
         _desc_cache[key] = hit
     return hit[0], hit[1]
+
+
+class HostScalars:
+    """A few 4-byte values that the host rewrites before every step (AdamW bias-correction terms, the PCGrad
+    shuffle order) and kernels read from device memory.  The upload is an asynchronous copy from pinned memory,
+    so the pinned source must not be rewritten before that copy has executed: eager steps rotate through a small
+    ring of slots (each guarded by an event), a captured hipGraph is pinned to ONE slot and its owner
+    (train_step.GraphedTrainStep) waits for the previous replay before calling set_inplace()."""
+
+    RING = 4
+
+    def __init__(self, device, count, dtype):
+        self.slots = []
+        for _ in range(self.RING):
+            h, d = arena(device).take(4 * count)
+            self.slots.append((h.view(dtype), d.view(dtype)))
+        self.events = [None] * self.RING
+        self.cur = 0
+
+    def set(self, values):
+        if not torch.cuda.is_current_stream_capturing():
+            self.cur = (self.cur + 1) % self.RING
+            ev = self.events[self.cur]
+            if ev is not None:
+                ev.synchronize()
+        self.set_inplace(values)
+
+    def set_inplace(self, values):
+        host = self.slots[self.cur][0]
+        for i, v in enumerate(values):
+            host[i] = v
+
+    def upload(self):
+        host, dev = self.slots[self.cur]
+        dev.copy_(host, non_blocking=True)
+        if not torch.cuda.is_current_stream_capturing():
+            ev = torch.cuda.Event()
+            ev.record()
+            self.events[self.cur] = ev
+        return dev
+
+    @property
+    def host(self):
+        return self.slots[self.cur][0]
+
+    @property
+    def dev(self):
+        return self.slots[self.cur][1]
 
 
 # ---------------------------------------------------------------------------------------------- losses
@@ -370,6 +486,18 @@ def pcgrad_combine(vecs, gram, orders_dev, merged):
     return coeff
 
 
+def adamw_multi_dyn(params, grads, exp_avg, exp_avg_sq, beta1, beta2, eps, dyn):
+    L = _lib.lib()
+    structs = []
+    for p, g, m, v in zip(params, grads, exp_avg, exp_avg_sq):
+        t = _lib.AdamwTensor()
+        t.p, t.g, t.m, t.v, t.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+        structs.append(t)
+    tab, host = device_table(structs, params[0].device)
+    check(L.mtd_adamw_multi_dyn(tab.data_ptr(), C.cast(host, C.c_void_p), len(structs), float(beta1), float(beta2), float(eps),
+                                dyn.data_ptr(), stream_ptr()), "mtd_adamw_multi_dyn")
+
+
 def adamw_multi(params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, wd):
     L = _lib.lib()
     structs = []
@@ -421,10 +549,19 @@ class SideStream:
 _side = {}
 
 
-def side_stream(device):
-    key = device.index if device.index is not None else torch.cuda.current_device()
+def side_stream(device, idx=0):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), idx)
     s = _side.get(key)
     if s is None:
         s = SideStream(device)
         _side[key] = s
     return s
+
+
+def crosses_streams(*tensors):
+    """Tensors allocated while a side stream was current and then consumed on the main stream: tell the caching
+    allocator so their memory is not recycled before the main-stream consumers have run."""
+    cur = torch.cuda.current_stream()
+    for t in tensors:
+        if t is not None:
+            t.record_stream(cur)

@@ -2,6 +2,8 @@
 (train.py:122-126, optimizers.py:8-9: lr, betas (0.9, 0.999), eps 1e-8, weight_decay 5e-4, no amsgrad).
 One HIP launch per step() over every parameter that has a gradient; parameters whose .grad is None are
 skipped exactly like torch.optim (this is what keeps the reference's `c_fc` frozen)."""
+import math
+
 import torch
 
 from . import kernels as K
@@ -10,10 +12,32 @@ from . import kernels as K
 class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._dyn = {}            # (group index, launch index) -> HostScalars with (decay, step_size, 1/sqrt(bc2))
+        self._captured = []       # launches of the last step(): (HostScalars, group index, parameters)
+
+    @staticmethod
+    def _scalars(group, step):
+        b1, b2 = group["betas"]
+        bc1 = 1.0 - b1 ** step
+        bc2 = 1.0 - b2 ** step
+        return (1.0 - group["lr"] * group["weight_decay"], group["lr"] / bc1, 1.0 / math.sqrt(bc2))
+
+    def advance_for_replay(self):
+        """Host-side bookkeeping of one replayed (hipGraph) step: bump the step counters of the parameters the
+        captured step updated and refresh the scalars its kernels read from device memory."""
+        for (slot, gi, members) in self._captured:
+            group = self.param_groups[gi]
+            step = 0
+            for p in members:
+                st = self.state[p]
+                st["step"] += 1
+                step = st["step"]
+            slot.set_inplace(self._scalars(group, step))
 
     @torch.no_grad()
     def step(self, closure=None):
-        for group in self.param_groups:
+        self._captured = []
+        for gi, group in enumerate(self.param_groups):
             by_step = {}
             for p in group["params"]:
                 if p.grad is None:
@@ -30,8 +54,14 @@ class FusedAdamW(torch.optim.Optimizer):
                 by_step.setdefault(st["step"], []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
             for step, items in by_step.items():
                 b1, b2 = group["betas"]
-                K.adamw_multi([i[0] for i in items], [i[1] for i in items], [i[2] for i in items], [i[3] for i in items],
-                              step, group["lr"], b1, b2, group["eps"], group["weight_decay"])
+                slot = self._dyn.get((gi, len(self._captured)))
+                if slot is None:
+                    slot = K.HostScalars(items[0][0].device, 3, torch.float32)
+                    self._dyn[(gi, len(self._captured))] = slot
+                slot.set(self._scalars(group, step))
+                self._captured.append((slot, gi, [it[0] for it in items]))
+                K.adamw_multi_dyn([i[0] for i in items], [i[1] for i in items], [i[2] for i in items], [i[3] for i in items],
+                                  b1, b2, group["eps"], slot.upload())
         K.weights_changed()          # parameters were updated through raw pointers: packed weight views are stale
 
 

@@ -91,8 +91,10 @@ class DStepTape:
             dp.wait()
         K.side_stream(dev).join()          # weight gradients / spectral-norm corrections ran on the side stream
         # ---- PCGrad: Gram of the original task gradients, replay of the projections, combine
-        orders = shuffle_orders(3)
-        orders_dev = torch.tensor([j for o in orders for j in o], dtype=torch.int32).to(dev, non_blocking=True)
+        orders = next_orders(3)
+        slot = orders_slot(dev)
+        slot.set([j for o in orders for j in o])
+        orders_dev = slot.upload()           # stream-ordered copy from a pinned slot (re-read on a hipGraph replay)
         vecs = [S[0], S[1], S[2]]
         gram = K.pcgrad_gram(vecs)
         coeff = K.pcgrad_combine(vecs, gram, orders_dev, S[3])
@@ -113,6 +115,27 @@ class DStepTape:
         if dp is not None:
             K.side_stream(S.device).join()     # the task vector is complete once the side-stream weight gradients are
             dp.all_reduce_avg(S[i])            # overlaps with the next task's backward (separate stream)
+
+
+_orders_slots = {}
+_pending_orders = []
+
+
+def orders_slot(dev):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    s = _orders_slots.get(key)
+    if s is None:
+        s = K.HostScalars(dev, 16, torch.int32)
+        _orders_slots[key] = s
+    return s
+
+
+def next_orders(T):
+    """The shuffle order of this step: drawn from Python's `random` like the reference.  A hipGraph replay
+    (GraphedTrainStep) pre-draws the order and refreshes the pinned slot itself."""
+    if _pending_orders:
+        return _pending_orders.pop(0)
+    return shuffle_orders(T)
 
 
 def shuffle_orders(T):
@@ -210,6 +233,60 @@ def g_loss(method, x, y):
     return total, details
 
 
+# ================================================================================================ hipGraph replay
+class GraphedTrainStep:
+    """One full training iteration captured into a hipGraph (torch.cuda.CUDAGraph) and replayed: the ~3700
+    kernel launches of a step cost one graph launch on the host.  Static shapes only (fixed batch); the inputs are
+    copied into static buffers.  Host-side per-step state is refreshed before every replay: the PCGrad shuffle
+    order (Python `random`, as the reference) and AdamW's step-dependent scalars; dropout masks come from the
+    graph-safe Philox state.  Falls back to eager execution if capture is not possible (e.g. N > 1 with RCCL)."""
+
+    def __init__(self, model, optimizer_G, optimizer_D, method_D, x, y, warmup=3):
+        from . import engine
+        self.model, self.oG, self.oD, self.wm = model, optimizer_G, optimizer_D, method_D
+        self.x, self.y = x.clone(), y.clone()
+        self.graph = None
+        dev = x.device
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self.names, self.vals = engine.train_iteration(model, self.x, self.y, optimizer_G, optimizer_D, method_D, None)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        K.CAPTURE_TAG += 1
+        g = torch.cuda.CUDAGraph()
+        rs = random.getstate()
+        _pending_orders.append(shuffle_orders(3))        # placeholder order for the capture (capture executes nothing)
+        random.setstate(rs)
+        with torch.cuda.graph(g):
+            self.names, self.vals = engine.train_iteration(model, self.x, self.y, optimizer_G, optimizer_D, method_D, None)
+        # capture ran the host-side bookkeeping of a step that was not executed: take it back
+        for opt in (optimizer_D, optimizer_G):
+            for (_slot, _gi, members) in opt._captured:
+                for p in members:
+                    opt.state[p]["step"] -= 1
+        self.graph = g
+        self.slot = orders_slot(dev)
+        self._done = None
+
+    def step(self, x=None, y=None):
+        # the graph's H2D copies read fixed pinned slots: do not rewrite them before the previous replay has run
+        if self._done is not None:
+            self._done.synchronize()
+        if x is not None:
+            self.x.copy_(x)
+            self.y.copy_(y)
+        orders = shuffle_orders(3)
+        self.slot.set_inplace([j for o in orders for j in o])
+        self.oD.advance_for_replay()
+        self.oG.advance_for_replay()
+        self.graph.replay()
+        self._done = torch.cuda.Event()
+        self._done.record()
+        return self.names, self.vals
+
+
 # ================================================================================================ bench workload
 class FullStepWorkload:
     """BASELINE config 3: full G + D + PCGrad training iteration (engine.train_MTD_GAN_Ours body) on
@@ -239,8 +316,26 @@ class FullStepWorkload:
         if self.dp is not None:
             self.dp.broadcast_module(self.model)
             self.wm.method.dp = self.dp
+        self.graphed = None
+        self.graph_error = None
+        import os
+        # hipGraph replay is opt-in: measured 84.6 ms/step replayed vs 73.9 ms/step launched eagerly over three
+        # streams (ROCm 7.2 serialises the captured multi-stream sections), see DESIGN.md
+        if world == 1 and os.environ.get("MTD_GRAPH", "0") == "1":
+            try:
+                self.graphed = GraphedTrainStep(self.model, self.oG, self.oD, self.wm, self.x, self.y)
+            except Exception as e:                      # capture is an optimisation: report and run eagerly
+                self.graph_error = repr(e)
+                self.graphed = None
+                torch.cuda.synchronize()
 
     def step(self):
+        if self.graphed is not None:
+            self.graphed.step()
+        else:
+            self.step_eager()
+
+    def step_eager(self):
         from . import engine
         engine.train_iteration(self.model, self.x, self.y, self.oG, self.oD, self.wm, self.dp)
 
@@ -249,4 +344,6 @@ class FullStepWorkload:
                 "global_batch": self.batch * world, "patch": "1x64x64", "parallelism": f"dp{world}"}
 
     def extra(self):
-        return {"algorithmic_gflop_per_patch": self.gflop_per_patch}
+        return {"algorithmic_gflop_per_patch": self.gflop_per_patch,
+                "launch_mode": "hipGraph replay" if getattr(self, "graphed", None) is not None else "eager launches",
+                "graph_error": getattr(self, "graph_error", None)}

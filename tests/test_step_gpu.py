@@ -212,3 +212,38 @@ def test_full_batch_step_runs_and_is_finite(hip_lib):
         assert torch.isfinite(v).all(), k
         if k.endswith("weight_u") or k.endswith("weight_v"):
             assert abs(v.norm().item() - 1.0) < 1e-4, k
+
+
+def test_graph_replay_equals_eager(hip_lib):
+    """hipGraph capture/replay of the whole iteration (GraphedTrainStep) must reproduce eager execution:
+    same kernels in the same order, host-side state (PCGrad order, AdamW step scalars) refreshed per replay."""
+    from mtd_gan_amd import engine
+    from mtd_gan_amd.arch.Ours.networks import MTD_GAN_Method
+    from mtd_gan_amd.module.weight_methods import WeightMethods
+    from mtd_gan_amd.optimizers import FusedAdamW
+    from mtd_gan_amd.train_step import GraphedTrainStep
+    x, y = orc.synthetic_ldct(4, seed=77)
+    x, y = x.cuda(), y.cuda()
+    results = []
+    for mode in ("eager", "graph"):
+        torch.manual_seed(5)
+        m = MTD_GAN_Method().cuda().train()
+        m.Discriminator.c_drop.p = 0.0                  # no dropout: the two runs draw no random numbers on the device
+        wm = WeightMethods("pcgrad", n_tasks=3, device=torch.device("cuda"))
+        oD = FusedAdamW(m.Discriminator.parameters(), lr=1e-4, weight_decay=5e-4)
+        oG = FusedAdamW(m.Generator.parameters(), lr=1e-4, weight_decay=5e-4)
+        random.seed(123)
+        if mode == "eager":
+            for _ in range(5):
+                names, vals = engine.train_iteration(m, x, y, oG, oD, wm, None)
+        else:
+            gs = GraphedTrainStep(m, oG, oD, wm, x, y, warmup=3)       # 3 eager steps, then capture
+            for _ in range(2):
+                names, vals = gs.step()
+        torch.cuda.synchronize()
+        results.append(({k: v.clone() for k, v in m.state_dict().items()}, vals.clone(), oD.state[m.Discriminator.enc_out.weight]["step"]))
+    (sd_e, v_e, st_e), (sd_g, v_g, st_g) = results
+    assert st_e == st_g == 5
+    assert rel(v_g, v_e) < 1e-5
+    for k in sd_e:
+        assert rel(sd_g[k], sd_e[k]) < 1e-5, k
