@@ -140,6 +140,10 @@ int mtd_act_grad(const float* g, int g_ld, const float* y, int y_ld, float* out,
                  long long npix, int C, float slope, void* stream);
 /* out[i] = a[i] * b[i]  (Dropout mask at networks.py:417 and its gradient), n contiguous floats */
 int mtd_mul(const float* a, const float* b, float* out, long long n, void* stream);
+/* dst[0..bytes) = src_pinned[0..bytes): src is page-locked host memory mapped into the device address space
+ * (hipHostMalloc / torch pin_memory), read by a kernel on `stream`; bytes % 16 == 0, both 16-byte aligned.
+ * Used for the descriptor tables (mtd_*_layer / mtd_loss_term / mtd_adamw_tensor arrays). */
+int mtd_upload(const void* src_pinned, void* dst, size_t bytes, void* stream);
 /* out[p, 0..C) = a[p, 0..C)  (strided copy: concat / slice), optional accumulate */
 int mtd_copy_channels(const float* a, int a_ld, float* out, int out_ld, long long npix, int C,
                       int accumulate, void* stream);
@@ -188,6 +192,8 @@ int mtd_adamw_multi(const mtd_adamw_tensor* tensors_dev, const mtd_adamw_tensor*
                     float lr, float beta1, float beta2, float eps, float wd, int step, void* stream);
 /* same, with (1 - lr*wd, lr/bias_correction1, 1/sqrt(bias_correction2)) read from dyn[0..2] (device memory):
  * lets a captured hipGraph be replayed with a new step count */
+int mtd_adamw_multi_pre(const mtd_adamw_tensor* tensors_dev, const mtd_adamw_tensor* tensors_host, int count, float beta1,
+                        float beta2, float eps, float decay, float step_size, float inv_sqrt_bc2, void* stream);
 int mtd_adamw_multi_dyn(const mtd_adamw_tensor* tensors_dev, const mtd_adamw_tensor* tensors_host, int count,
                         float beta1, float beta2, float eps, const float* dyn, void* stream);
 
@@ -223,6 +229,7 @@ int mtd_edge_loss(const float* a, const float* b, int B, float scale, float eps,
 /* Tuning hook (tools/tune_igemm.py): force the tile configuration (0..5, -1 = automatic) and the split-K factor of
  * every following mtd_conv_igemm call in this process. */
 int mtd_conv_igemm_override(int cfg, int splitk);
+int mtd_conv_wgrad_override(int cfg, int nsplit);      /* same for mtd_conv_wgrad: tile/tap-group config 0..6, pixel splits */
 
 typedef struct mtd_prof_record {
     int kernel, cfg, splitk, N, C, taps;

@@ -116,6 +116,7 @@ def lib():
     sig("mtd_pixel_shuffle2_bwd", ci, vp, ci, vp, ci, ci, ci, ci, ci, vp)
     sig("mtd_mul", ci, vp, vp, vp, ll, vp)
     sig("mtd_pack_weights", ci, vp, vp, ci, vp)
+    sig("mtd_upload", ci, vp, vp, sz, vp)
     sig("mtd_sn_ws_bytes", sz, vp, ci)
     sig("mtd_sn_power_iter", ci, vp, vp, ci, ci, vp, vp)
     sig("mtd_sn_grad_ws_bytes", sz, vp, ci)
@@ -125,6 +126,7 @@ def lib():
     sig("mtd_pcgrad_combine", ci, vp, vp, vp, vp, ci, ll, vp, vp, vp, vp, vp)
     sig("mtd_adamw_multi", ci, vp, vp, ci, cf, cf, cf, cf, cf, ci, vp)
     sig("mtd_adamw_multi_dyn", ci, vp, vp, ci, cf, cf, cf, vp, vp)
+    sig("mtd_adamw_multi_pre", ci, vp, vp, ci, cf, cf, cf, cf, cf, cf, vp)
     sig("mtd_loss_terms_ws_bytes", sz, ci)
     sig("mtd_loss_terms", ci, vp, ci, vp, vp, vp)
     sig("mtd_loss_term_grads", ci, vp, ci, vp)
@@ -142,9 +144,9 @@ EXPORTS = [
     "mtd_spec_mix_wgrad_reduce", "mtd_irfft_rows", "mtd_transpose64", "mtd_act_grad", "mtd_copy_channels",
     "mtd_upsample2x_fwd", "mtd_upsample2x_bwd", "mtd_pixel_shuffle2_fwd", "mtd_pixel_shuffle2_bwd", "mtd_mul", "mtd_pack_weights",
     "mtd_sn_ws_bytes", "mtd_sn_power_iter", "mtd_sn_grad_ws_bytes", "mtd_sn_grad", "mtd_pcgrad_ws_bytes",
-    "mtd_pcgrad_gram", "mtd_pcgrad_combine", "mtd_adamw_multi", "mtd_adamw_multi_dyn", "mtd_loss_terms_ws_bytes", "mtd_loss_terms",
+    "mtd_pcgrad_gram", "mtd_pcgrad_combine", "mtd_adamw_multi", "mtd_adamw_multi_dyn", "mtd_adamw_multi_pre", "mtd_loss_terms_ws_bytes", "mtd_loss_terms",
     "mtd_loss_term_grads", "mtd_clip01", "mtd_clip01_bwd", "mtd_edge_loss_ws_bytes", "mtd_edge_loss",
-    "mtd_prof_enable", "mtd_prof_collect", "mtd_conv_igemm_override",
+    "mtd_prof_enable", "mtd_prof_collect", "mtd_conv_igemm_override", "mtd_conv_wgrad_override", "mtd_upload",
 ]
 
 

@@ -61,6 +61,22 @@ extern "C" int mtd_adamw_multi(const mtd_adamw_tensor* tensors_dev, const mtd_ad
     return MTD_OK;
 }
 
+// Same update with the three step-dependent scalars precomputed by the caller (FusedAdamW computes them once in
+// double precision for both its eager and its captured path, so the two produce identical parameters).
+extern "C" int mtd_adamw_multi_pre(const mtd_adamw_tensor* tensors_dev, const mtd_adamw_tensor* tensors_host, int count, float beta1,
+                                   float beta2, float eps, float decay, float step_size, float inv_sqrt_bc2, void* stream) {
+    if (!tensors_dev || !tensors_host || count <= 0) return MTD_EINVAL;
+    long long blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!tensors_host[i].p || !tensors_host[i].g || !tensors_host[i].m || !tensors_host[i].v || tensors_host[i].n <= 0) return MTD_EINVAL;
+        blocks += (tensors_host[i].n + AW_ELEMS - 1) / AW_ELEMS;
+    }
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tensors_dev, count, decay, beta1, beta2,
+                       step_size, inv_sqrt_bc2, eps, (const float*)nullptr);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
 // Same update with (decay, step_size, 1/sqrt(bias_correction2)) read from dyn[0..2] in device memory, so that a
 // captured hipGraph can be replayed with a new step count: the host refreshes the three floats before each replay.
 extern "C" int mtd_adamw_multi_dyn(const mtd_adamw_tensor* tensors_dev, const mtd_adamw_tensor* tensors_host, int count, float beta1,

@@ -249,18 +249,30 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const WgradParams p, 
 
 struct WPlan { int cfg, WN, WC, TG, ppw, nsplit, ntg; };
 
+int g_wforce_cfg = -1, g_wforce_split = -1;     // tuning hook (mtd_conv_wgrad_override)
+constexpr int NWCFG = 7;
+const int kWcfgWN[NWCFG] = {1, 1, 2, 1, 1, 1, 2};
+const int kWcfgWC[NWCFG] = {1, 1, 2, 1, 1, 1, 2};
+const int kWcfgTG[NWCFG] = {9, 4, 1, 8, 3, 1, 3};
+
 WPlan make_wplan(const mtd_wgrad_args& a) {
     WPlan pl{};
     const int T = a.g.TH * a.g.TW;
     const long long M = geom_pixels(a.g);
-    if (T == 1 && a.N % 64 == 0 && a.C % 64 == 0) { pl.cfg = 2; pl.WN = 2; pl.WC = 2; pl.TG = 1; }
-    else if (T <= 4) { pl.cfg = 1; pl.WN = 1; pl.WC = 1; pl.TG = 4; }
-    else if (T <= 9) { pl.cfg = 0; pl.WN = 1; pl.WC = 1; pl.TG = 9; }
-    else { pl.cfg = 3; pl.WN = 1; pl.WC = 1; pl.TG = 8; }
+    if (T == 1 && a.N % 64 == 0 && a.C % 64 == 0) pl.cfg = 2;
+    else if (T <= 4) pl.cfg = 1;
+    else if (T <= 9) pl.cfg = 0;
+    else pl.cfg = 3;
+    if (g_wforce_cfg >= 0 && g_wforce_cfg < NWCFG && a.N % (32 * kWcfgWN[g_wforce_cfg]) == 0 && a.C % (32 * kWcfgWC[g_wforce_cfg]) == 0)
+        pl.cfg = g_wforce_cfg;
+    pl.WN = kWcfgWN[pl.cfg];
+    pl.WC = kWcfgWC[pl.cfg];
+    pl.TG = kWcfgTG[pl.cfg];
     pl.ntg = (T + pl.TG - 1) / pl.TG;
     long long tiles = (long long)(a.N / (32 * pl.WN)) * (a.C / (32 * pl.WC)) * pl.ntg;
     // aim for >= 512 workgroups; every wave gets a multiple of 32 pixels
     long long want_splits = (512 + tiles - 1) / tiles;
+    if (g_wforce_split > 0) want_splits = g_wforce_split;
     long long max_splits = (M + 127) / 128;             // at least 32 px per wave
     long long ns = want_splits < 1 ? 1 : want_splits;
     if (ns > max_splits) ns = max_splits;
@@ -311,6 +323,12 @@ size_t wgrad_ws_floats(const mtd_wgrad_args& a, int nsplit) {
 
 int mtd_direct_wgrad_launch(const mtd_wgrad_args* a, int* nslab_out, long long slab_stride, void* stream);
 int mtd_direct_wgrad_nslab(const mtd_wgrad_args* a);
+
+extern "C" int mtd_conv_wgrad_override(int cfg, int nsplit) {
+    g_wforce_cfg = cfg;
+    g_wforce_split = nsplit;
+    return MTD_OK;
+}
 
 extern "C" size_t mtd_conv_wgrad_ws_bytes(const mtd_wgrad_args* a) {
     if (!a || check_wargs(*a) != MTD_OK) return 0;
@@ -366,7 +384,10 @@ extern "C" int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream) {
             case 0: hipLaunchKernelGGL((wgrad_kernel<1, 1, 9>), grid, dim3(256), 0, s, p); break;
             case 1: hipLaunchKernelGGL((wgrad_kernel<1, 1, 4>), grid, dim3(256), 0, s, p); break;
             case 2: hipLaunchKernelGGL((wgrad_kernel<2, 2, 1>), grid, dim3(256), 0, s, p); break;
-            default: hipLaunchKernelGGL((wgrad_kernel<1, 1, 8>), grid, dim3(256), 0, s, p); break;
+            case 3: hipLaunchKernelGGL((wgrad_kernel<1, 1, 8>), grid, dim3(256), 0, s, p); break;
+            case 4: hipLaunchKernelGGL((wgrad_kernel<1, 1, 3>), grid, dim3(256), 0, s, p); break;
+            case 5: hipLaunchKernelGGL((wgrad_kernel<1, 1, 1>), grid, dim3(256), 0, s, p); break;
+            default: hipLaunchKernelGGL((wgrad_kernel<2, 2, 3>), grid, dim3(256), 0, s, p); break;
         }
         mtd_prof_end(prof, s);
         MTD_LAUNCH_CHECK();

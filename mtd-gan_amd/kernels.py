@@ -3,6 +3,7 @@ the current HIP stream; every arithmetic op below runs in libmtdgan_hip.so.  NHW
 tensors of shape (B, H, W, C) whose last-dim stride is 1 and whose pixel stride (`ld`) may exceed C
 (channel slices of a concat buffer)."""
 import ctypes as C
+import os
 
 import torch
 
@@ -58,12 +59,15 @@ def packed_weight_view(w, N, Cc, w_sn, w_sc):
         hit = (dst, w)          # keep the source alive so its data_ptr cannot be recycled under the same key
         _pack_cache[key] = hit
     return hit[0], Cc, 1, N * Cc
+STATS = {"table_hit": 0, "table_miss": 0, "zero_copy_reads": 0}
+_igemm_ws_cache = {}
 CALL_LOG = None     # tools/tune_igemm.py: a list collects ("igemm" | "wgrad", bytes(argument struct)) per call
 PROFILE = None      # legacy hook: a list collects (tag, start_event, end_event) per un-split igemm launch
 
 IGEMM_CONFIGS = ["igemm_kernel<2, 1, 4, 1>", "igemm_kernel<1, 1, 4, 1>", "igemm_kernel<2, 2, 4, 1>",
                  "igemm_kernel<1, 1, 2, 2>", "igemm_kernel<2, 2, 2, 2>", "igemm_kernel<1, 1, 1, 4>"]
-WGRAD_CONFIGS = ["wgrad_kernel<1, 1, 9>", "wgrad_kernel<1, 1, 4>", "wgrad_kernel<2, 2, 1>", "wgrad_kernel<1, 1, 8>"]
+WGRAD_CONFIGS = ["wgrad_kernel<1, 1, 9>", "wgrad_kernel<1, 1, 4>", "wgrad_kernel<2, 2, 1>", "wgrad_kernel<1, 1, 8>",
+                 "wgrad_kernel<1, 1, 3>", "wgrad_kernel<1, 1, 1>", "wgrad_kernel<2, 2, 3>"]
 
 
 def prof_enable(capacity):
@@ -86,8 +90,12 @@ def prof_collect(capacity):
     return out
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream       # (device index) -> hipStream_t as int; no Python Stream objects
+_cur_device = torch._C._cuda_getDevice
+
+
 def stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_raw_stream(_cur_device()))
 
 
 CAPTURE_TAG = 0     # bumped while a hipGraph is captured so that graph-pool scratch never mixes with eager scratch
@@ -95,7 +103,8 @@ CAPTURE_TAG = 0     # bumped while a hipGraph is captured so that graph-pool scr
 
 def workspace(nbytes, device):
     """Grow-only scratch buffer per (device, stream).  Stream order makes reuse safe."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, CAPTURE_TAG)
+    idx = device.index if device.index is not None else _cur_device()
+    key = (idx, _raw_stream(idx), CAPTURE_TAG)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -173,7 +182,11 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, scale=None, bias=None, add1=None, a
     a.mask, a.mask_ld, a.mask_slope = _ptr(mask), (ld_of(mask) if mask is not None else 0), mask_slope
     a.ws, a.ws_bytes = None, 0
     if (Cc % 32 == 0) and (N % 32 == 0):
-        need = L.mtd_conv_igemm_ws_bytes(C.byref(a))
+        wkey = (bytes(geom), N, Cc)
+        need = _igemm_ws_cache.get(wkey)
+        if need is None:
+            need = L.mtd_conv_igemm_ws_bytes(C.byref(a))
+            _igemm_ws_cache[wkey] = need
         if need:
             ws = workspace(need, x.device)
             a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
@@ -315,71 +328,82 @@ _desc_cache = {}
 
 
 class _Arena:
-    """Pinned-host + device arenas for descriptor tables and small host->device scalars.  Pre-allocated so that
-    nothing is allocated while a hipGraph is being captured; the H2D copies are ordinary stream-ordered copies
-    (captured as memcpy nodes: a replay re-copies the current pinned contents)."""
+    """Pinned-host staging + device storage for descriptor tables.  A table is written into the pinned half and
+    moved to the device half by mtd_upload (a kernel that reads the mapped pinned memory), so there is no
+    hipMemcpyAsync in the step.  Bump allocation; the eager arena recycles from the start after a device
+    synchronisation (every few hundred steps), the capture arena (tables referenced by a hipGraph) never does."""
 
-    def __init__(self, device, nbytes=16 << 20):
+    def __init__(self, device, nbytes, recycle):
         self.host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
         self.dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self.ofs = 0
+        self.recycle = recycle
 
     def take(self, nbytes):
         n = (nbytes + 255) & ~255
         if self.ofs + n > self.host.numel():
-            raise RuntimeError("descriptor arena exhausted")
+            if not self.recycle:
+                raise RuntimeError("descriptor arena of the captured graph exhausted")
+            torch.cuda.synchronize()                 # every kernel that reads an old table has finished
+            _desc_cache.clear()
+            self.ofs = 0
         o = self.ofs
         self.ofs += n
-        return self.host[o:o + nbytes], self.dev[o:o + nbytes]
+        return self.host[o:o + n], self.dev[o:o + n]
 
 
 _arenas = {}
 
 
 def arena(device):
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (device.index if device.index is not None else torch.cuda.current_device(), capturing)
     a = _arenas.get(key)
     if a is None:
-        a = _Arena(device)
+        if capturing:
+            raise RuntimeError("the capture arena must exist before a hipGraph capture starts (call kernels.prepare_capture)")
+        a = _Arena(device, 16 << 20, True)
         _arenas[key] = a
     return a
 
 
+def prepare_capture(device):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), True)
+    if key not in _arenas:
+        _arenas[key] = _Arena(device, 8 << 20, False)
+
+
 def device_table(structs, device):
-    """Upload an array of ctypes structs once per distinct content (pointers included); returns
+    """Array of ctypes structs -> device memory, once per distinct content (pointers included); returns
     (device tensor, host ctypes array).  Keeps the host array alive for the C call."""
     n = len(structs)
     arr = (type(structs[0]) * n)(*structs)
     raw = bytes(arr)
-    key = (device.index, raw)
+    key = (device.index, torch.cuda.is_current_stream_capturing(), raw)
     hit = _desc_cache.get(key)
+    STATS["table_hit" if hit is not None else "table_miss"] += 1
     if hit is None:
-        ar = arena(device)
-        if ar.ofs + len(raw) + 256 > ar.host.numel():       # full: start over (old entries are dropped with it)
-            _desc_cache.clear()
-            ar.ofs = 0
-        host, dev = ar.take(len(raw))
-        host.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
-        dev.copy_(host, non_blocking=True)
+        host, dev = arena(device).take(len(raw))
+        host[:len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+        check(_lib.lib().mtd_upload(host.data_ptr(), dev.data_ptr(), host.numel(), stream_ptr()), "mtd_upload")
         hit = (dev, arr, host)
         _desc_cache[key] = hit
     return hit[0], hit[1]
 
 
 class HostScalars:
-    """A few 4-byte values that the host rewrites before every step (AdamW bias-correction terms, the PCGrad
-    shuffle order) and kernels read from device memory.  The upload is an asynchronous copy from pinned memory,
-    so the pinned source must not be rewritten before that copy has executed: eager steps rotate through a small
-    ring of slots (each guarded by an event), a captured hipGraph is pinned to ONE slot and its owner
-    (train_step.GraphedTrainStep) waits for the previous replay before calling set_inplace()."""
+    """A few 4-byte values that the host rewrites before every step (the PCGrad shuffle order; the AdamW
+    bias-correction terms of a captured step) and a kernel reads at execution time.  They live in pinned host
+    memory, which the GPU addresses directly (zero-copy over PCIe: a handful of bytes read by one or a few
+    workgroups) -- no H2D copy, which on ROCm costs a ~0.3 ms bubble in the stream per copy.  The pinned source
+    must not be rewritten before the reading kernel has run: eager steps rotate through a small ring of slots
+    (each guarded by an event recorded after the consumer was enqueued), a captured hipGraph is pinned to ONE
+    slot and its owner (train_step.GraphedTrainStep) waits for the previous replay before set_inplace()."""
 
     RING = 4
 
     def __init__(self, device, count, dtype):
-        self.slots = []
-        for _ in range(self.RING):
-            h, d = arena(device).take(4 * count)
-            self.slots.append((h.view(dtype), d.view(dtype)))
+        self.slots = [torch.zeros(count, dtype=dtype).pin_memory() for _ in range(self.RING)]
         self.events = [None] * self.RING
         self.cur = 0
 
@@ -392,26 +416,25 @@ class HostScalars:
         self.set_inplace(values)
 
     def set_inplace(self, values):
-        host = self.slots[self.cur][0]
+        host = self.slots[self.cur]
         for i, v in enumerate(values):
             host[i] = v
 
-    def upload(self):
-        host, dev = self.slots[self.cur]
-        dev.copy_(host, non_blocking=True)
+    def device_ptr(self):
+        """Pointer a kernel may dereference (pinned memory is mapped into the device address space)."""
+        STATS["zero_copy_reads"] += 1
+        return self.slots[self.cur].data_ptr()
+
+    def consumed(self):
+        """Call after the kernel that reads the slot has been enqueued on the current stream."""
         if not torch.cuda.is_current_stream_capturing():
             ev = torch.cuda.Event()
             ev.record()
             self.events[self.cur] = ev
-        return dev
 
     @property
     def host(self):
-        return self.slots[self.cur][0]
-
-    @property
-    def dev(self):
-        return self.slots[self.cur][1]
+        return self.slots[self.cur]
 
 
 # ---------------------------------------------------------------------------------------------- losses
@@ -477,16 +500,18 @@ def pcgrad_gram(vecs):
 
 
 def pcgrad_combine(vecs, gram, orders_dev, merged):
+    """orders_dev: int32 device tensor, or an integer pointer the GPU can dereference (HostScalars.device_ptr())."""
     L = _lib.lib()
+    optr = orders_dev if isinstance(orders_dev, int) else orders_dev.data_ptr()
     T, n = len(vecs), vecs[0].numel()
     coeff = torch.empty(4, dtype=torch.float32, device=vecs[0].device)
     ptrs = [v.data_ptr() for v in vecs] + [None] * (4 - T)
-    check(L.mtd_pcgrad_combine(ptrs[0], ptrs[1], ptrs[2], ptrs[3], T, n, gram.data_ptr(), orders_dev.data_ptr(), merged.data_ptr(),
+    check(L.mtd_pcgrad_combine(ptrs[0], ptrs[1], ptrs[2], ptrs[3], T, n, gram.data_ptr(), optr, merged.data_ptr(),
                                coeff.data_ptr(), stream_ptr()), "mtd_pcgrad_combine")
     return coeff
 
 
-def adamw_multi_dyn(params, grads, exp_avg, exp_avg_sq, beta1, beta2, eps, dyn):
+def adamw_multi_dyn(params, grads, exp_avg, exp_avg_sq, beta1, beta2, eps, dyn_ptr):
     L = _lib.lib()
     structs = []
     for p, g, m, v in zip(params, grads, exp_avg, exp_avg_sq):
@@ -495,7 +520,20 @@ def adamw_multi_dyn(params, grads, exp_avg, exp_avg_sq, beta1, beta2, eps, dyn):
         structs.append(t)
     tab, host = device_table(structs, params[0].device)
     check(L.mtd_adamw_multi_dyn(tab.data_ptr(), C.cast(host, C.c_void_p), len(structs), float(beta1), float(beta2), float(eps),
-                                dyn.data_ptr(), stream_ptr()), "mtd_adamw_multi_dyn")
+                                C.c_void_p(dyn_ptr), stream_ptr()), "mtd_adamw_multi_dyn")
+
+
+def adamw_multi_pre(params, grads, exp_avg, exp_avg_sq, beta1, beta2, eps, scalars):
+    """scalars = (1 - lr*wd, lr / bias_correction1, 1 / sqrt(bias_correction2)) as kernel arguments."""
+    L = _lib.lib()
+    structs = []
+    for p, g, m, v in zip(params, grads, exp_avg, exp_avg_sq):
+        t = _lib.AdamwTensor()
+        t.p, t.g, t.m, t.v, t.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+        structs.append(t)
+    tab, host = device_table(structs, params[0].device)
+    check(L.mtd_adamw_multi_pre(tab.data_ptr(), C.cast(host, C.c_void_p), len(structs), float(beta1), float(beta2), float(eps),
+                                float(scalars[0]), float(scalars[1]), float(scalars[2]), stream_ptr()), "mtd_adamw_multi_pre")
 
 
 def adamw_multi(params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, wd):
@@ -521,7 +559,7 @@ class SideStream:
     def __init__(self, device):
         self.stream = torch.cuda.Stream(device=device)
         self._keep = []
-        self.enabled = True
+        self.enabled = os.environ.get("MTD_NO_SIDE_STREAMS", "0") != "1"      # diagnostic switch: everything on one stream
 
     def fork(self):
         if self.enabled:

@@ -12,6 +12,7 @@ from . import kernels as K
 class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.graph_mode = False   # True: step-dependent scalars are read from pinned slots (hipGraph capture / replay)
         self._dyn = {}            # (group index, launch index) -> HostScalars with (decay, step_size, 1/sqrt(bc2))
         self._captured = []       # launches of the last step(): (HostScalars, group index, parameters)
 
@@ -54,6 +55,12 @@ class FusedAdamW(torch.optim.Optimizer):
                 by_step.setdefault(st["step"], []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
             for step, items in by_step.items():
                 b1, b2 = group["betas"]
+                if not self.graph_mode:
+                    # eager launch: the step-dependent scalars travel as kernel arguments
+                    K.adamw_multi_pre([i[0] for i in items], [i[1] for i in items], [i[2] for i in items], [i[3] for i in items],
+                                      b1, b2, group["eps"], self._scalars(group, step))
+                    continue
+                # hipGraph capture: kernel arguments are frozen, the scalars are read from a pinned slot instead
                 slot = self._dyn.get((gi, len(self._captured)))
                 if slot is None:
                     slot = K.HostScalars(items[0][0].device, 3, torch.float32)
@@ -61,7 +68,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 slot.set(self._scalars(group, step))
                 self._captured.append((slot, gi, [it[0] for it in items]))
                 K.adamw_multi_dyn([i[0] for i in items], [i[1] for i in items], [i[2] for i in items], [i[3] for i in items],
-                                  b1, b2, group["eps"], slot.upload())
+                                  b1, b2, group["eps"], slot.device_ptr())
+                slot.consumed()
         K.weights_changed()          # parameters were updated through raw pointers: packed weight views are stale
 
 

@@ -94,10 +94,10 @@ class DStepTape:
         orders = next_orders(3)
         slot = orders_slot(dev)
         slot.set([j for o in orders for j in o])
-        orders_dev = slot.upload()           # stream-ordered copy from a pinned slot (re-read on a hipGraph replay)
         vecs = [S[0], S[1], S[2]]
         gram = K.pcgrad_gram(vecs)
-        coeff = K.pcgrad_combine(vecs, gram, orders_dev, S[3])
+        coeff = K.pcgrad_combine(vecs, gram, slot.device_ptr(), S[3])     # the order is read from the pinned slot at run time
+        slot.consumed()
         merged = S[3]
         if reduction == "mean":
             merged = merged / 3.0
@@ -247,6 +247,8 @@ class GraphedTrainStep:
         self.x, self.y = x.clone(), y.clone()
         self.graph = None
         dev = x.device
+        optimizer_G.graph_mode = optimizer_D.graph_mode = True     # step scalars through pinned slots (created in warm-up)
+        K.prepare_capture(dev)
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -346,4 +348,4 @@ class FullStepWorkload:
     def extra(self):
         return {"algorithmic_gflop_per_patch": self.gflop_per_patch,
                 "launch_mode": "hipGraph replay" if getattr(self, "graphed", None) is not None else "eager launches",
-                "graph_error": getattr(self, "graph_error", None)}
+                "graph_error": getattr(self, "graph_error", None), "table_stats": dict(K.STATS)}

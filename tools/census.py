@@ -30,6 +30,7 @@ def timed(fn, iters=10):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--sweep-wgrad", action="store_true", help="sweep (tile/tap-group config, pixel splits) per MFMA wgrad shape")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     wl = FullStepWorkload(dev, 0, 1, args.batch)
@@ -54,6 +55,7 @@ def main():
             key = (bytes(a.g), a.N, a.C, a.in_ld, a.out_ld, a.w_sn, a.w_sc, a.w_st, bool(a.add1), bool(a.mask), bool(a.bias), a.act)
             dr.setdefault(key, [0, raw])[0] += 1
     rows = []
+    tbest = [0.0]
     for key, (count, raw) in wg.items():
         a = _lib.WgradArgs.from_buffer_copy(raw)
         g = a.g
@@ -69,7 +71,37 @@ def main():
         a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
         t = timed(lambda: _lib.check(L.mtd_conv_wgrad(C.byref(a), s), "wgrad"))
         fl = 2.0 * M * a.N * a.C * T
-        rows.append((count * t, f"wgrad  x{count:3d} M={M:6d} N={a.N:4d} C={a.C:4d} T={T:2d} s{g.in_sy} d{g.tap_dy}  {t:7.1f} us {fl / t / 1e6:6.1f} TF  tot {count * t / 1e3:6.2f} ms"))
+        extra = ""
+        if args.sweep_wgrad and a.N % 32 == 0 and a.C % 32 == 0:
+            L.mtd_conv_wgrad_override.argtypes = [C.c_int, C.c_int]
+            WN = [1, 1, 2, 1, 1, 1, 2]
+            TG = [9, 4, 1, 8, 3, 1, 3]
+            res = []
+            for cfg in range(7):
+                if a.N % (32 * WN[cfg]) or a.C % (32 * WN[cfg]):
+                    continue
+                if T > 1 and TG[cfg] == 1 and WN[cfg] == 1 and a.N * a.C >= 128 * 128:
+                    continue
+                ntg = (T + TG[cfg] - 1) // TG[cfg]
+                tiles = (a.N // (32 * WN[cfg])) * (a.C // (32 * WN[cfg])) * ntg
+                for target in (128, 256, 512, 1024, 2048):
+                    ns = max(1, (target + tiles - 1) // tiles)
+                    if ns > (M + 127) // 128:
+                        ns = (M + 127) // 128
+                    L.mtd_conv_wgrad_override(cfg, ns)
+                    need = L.mtd_conv_wgrad_ws_bytes(C.byref(a))
+                    if need == 0 or need > ws.numel():
+                        continue
+                    tt = timed(lambda: L.mtd_conv_wgrad(C.byref(a), s), iters=5)
+                    res.append((round(tt, 1), cfg, ns))
+            L.mtd_conv_wgrad_override(-1, -1)
+            res = sorted(set(res))
+            if res:
+                extra = f"  best {res[0]}  next {res[1:4]}"
+                tbest[0] += count * min(res[0][0], t)
+        elif args.sweep_wgrad:
+            tbest[0] += count * t
+        rows.append((count * t, f"wgrad  x{count:3d} M={M:6d} N={a.N:4d} C={a.C:4d} T={T:2d} s{g.in_sy} d{g.tap_dy}  {t:7.1f} us {fl / t / 1e6:6.1f} TF  tot {count * t / 1e3:6.2f} ms" + extra))
     for key, (count, raw) in dr.items():
         a = _lib.ConvArgs.from_buffer_copy(raw)
         g = a.g
@@ -96,6 +128,8 @@ def main():
         rows.append((count * t, f"direct x{count:3d} M={M:6d} N={a.N:4d} C={a.C:4d} T={T:2d} s{g.in_sy} in_ld={a.in_ld} out_ld={a.out_ld}  {t:7.1f} us {byts / t / 1e3:7.1f} GB/s  tot {count * t / 1e3:6.2f} ms"))
     rows.sort(key=lambda r: -r[0])
     print(f"wgrad total {sum(r[0] for r in rows if r[1].startswith('wgrad')) / 1e3:.2f} ms/step, direct total {sum(r[0] for r in rows if r[1].startswith('direct')) / 1e3:.2f} ms/step")
+    if args.sweep_wgrad:
+        print(f"wgrad with the best swept plan per shape: {tbest[0] / 1e3:.2f} ms/step")
     for r in rows:
         print(r[1])
 
