@@ -210,6 +210,153 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }
 }
 
+
+// ---- row-window variant --------------------------------------------------------------------------
+// Stride-1 convolutions whose output rows are a multiple of 16 pixels wide (all 64/32/16-pixel feature maps: two
+// thirds of the step's weight-gradient flops).  No LDS in the main loop: with k-step kk of a 32-pixel chunk defined
+// as pixels (kk, 16 + kk), lane (l31, kh) needs P[pixel kh*16 + kk][n0 + l31] and Q[that pixel + tap][c0 + l31] --
+// one dword per k-step, 128 contiguous bytes per 32 lanes -- so both MFMA operands are loaded straight into
+// registers (buffer loads, out-of-image reads return 0).  A lane's 16 pixels lie in one image row, so the TW taps of
+// a filter row read the same 16 + TW - 1 input pixels shifted by one: each row of the window is loaded once and
+// serves TW taps (54 instead of 144 Q loads per chunk for 3x3).  The next window row (or the next chunk's P and
+// first row) is in flight under the current row's 16 * TW MFMAs.
+template <int TH, int TW, int DX>
+__global__ __launch_bounds__(256, 2) void wgrad_row_kernel(const WgradParams p) {
+    constexpr int T = TH * TW, WIN = 16 + TW - 1;
+    __shared__ __attribute__((aligned(16))) float Ls[3 * 1024 + 256];
+    const mtd_wgrad_args& a = p.a;
+    const mtd_geom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int ntile = blockIdx.y / p.nCt, ctile = blockIdx.y % p.nCt;
+    const int n0 = ntile * 32, c0 = ctile * 32;
+    const int mwave0 = (blockIdx.x * 4 + wave) * p.ppw;
+    const bool do_bias = (a.db != nullptr) && ctile == 0;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p), (short)0, (int)p.p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.q), (short)0, (int)p.q_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int smin = (DX > 0) ? 0 : -(TW - 1);          // smallest horizontal tap displacement
+    const int pstep = a.p_ld * 4, qstep = a.q_ld * 4;
+
+    f32x16 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    float bsum = 0.f;
+
+    float af[16], an[16], w0[WIN], w1[WIN];
+    unsigned pbase = OOB, rowoff[TH];
+    int xbase = 0;
+    auto setup = [&](int mc) {
+        const int m = mwave0 + mc + kh * 16;
+        pbase = OOB;
+        xbase = 0;
+#pragma unroll
+        for (int ty = 0; ty < TH; ++ty) rowoff[ty] = OOB;
+        if (mc < p.ppw && m < p.M) {
+            const int ox = m % g.OW;
+            const int t2 = m / g.OW;
+            const int oy = t2 % g.OH;
+            const int b = t2 / g.OH;
+            pbase = (unsigned)(((long long)m * a.p_ld + n0 + l31) * 4);
+            xbase = ox + g.off_x + smin;
+#pragma unroll
+            for (int ty = 0; ty < TH; ++ty) {
+                const int iy = oy + g.off_y + ty * g.tap_dy;
+                if ((unsigned)iy < (unsigned)g.IH)
+                    rowoff[ty] = (unsigned)(((((long long)b * g.IH + iy) * g.IW + xbase) * a.q_ld + c0 + l31) * 4);
+            }
+        }
+    };
+    auto load_p = [&](float* dst) {
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+            dst[kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, pbase, kk * pstep, 0));
+    };
+    auto load_row = [&](int ty, float* dst) {
+#pragma unroll
+        for (int j = 0; j < WIN; ++j) {
+            // the whole offset goes through the VGPR: the range check looks at it alone, and rowoff may be "negative"
+            // (x = -1 of the first row) until j is added
+            const unsigned off = (((unsigned)(xbase + j) < (unsigned)g.IW) & (rowoff[ty] != OOB)) ? rowoff[ty] + (unsigned)(j * qstep) : OOB;
+            dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(qrs, off, 0, 0));
+        }
+    };
+    auto mfma_row = [&](int ty, const float* wv) {
+#pragma unroll
+        for (int tx = 0; tx < TW; ++tx) {
+            const int sh = (DX > 0) ? tx : (TW - 1 - tx);
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) acc[ty * TW + tx] = mfma32(af[kk], wv[kk + sh], acc[ty * TW + tx]);
+        }
+    };
+
+    setup(0);
+    load_p(af);
+    load_row(0, w0);
+    for (int mc = 0; mc < p.ppw; mc += 32) {
+#pragma unroll
+        for (int ty = 0; ty < TH; ++ty) {
+            float* cur = (ty & 1) ? w1 : w0;
+            float* nxt = (ty & 1) ? w0 : w1;
+            __builtin_amdgcn_sched_barrier(0);
+            if (ty + 1 < TH) {
+                load_row(ty + 1, nxt);
+            } else {
+                setup(mc + 32);                 // past the wave's range: every offset out of range, loads return 0
+                load_p(an);
+                load_row(0, nxt);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ty == 0) {
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) bsum += af[kk];
+            }
+            mfma_row(ty, cur);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) af[kk] = an[kk];
+        if (TH & 1) {                           // an odd number of rows leaves the next chunk's first row in w1
+#pragma unroll
+            for (int j = 0; j < WIN; ++j) w0[j] = w1[j];
+        }
+    }
+
+    // ---- sum the four waves through LDS (tile by tile), wave 0 writes the workgroup's slab
+    float* slab = a.ws + (long long)blockIdx.x * p.slab_stride;
+    float* red = Ls;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        __syncthreads();
+        if (wave > 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[(wave - 1) * 1024 + e * 64 + lane] = acc[t][e];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float v = acc[t][e] + red[e * 64 + lane] + red[1024 + e * 64 + lane] + red[2048 + e * 64 + lane];
+                const int n = n0 + mfma32_row(e, lane);
+                const int cc = c0 + l31;
+                slab[((long long)t * a.N + n) * a.C + cc] = v;
+            }
+        }
+    }
+    if (do_bias) {
+        __syncthreads();
+        red[3072 + wave * 64 + lane] = bsum;
+        __syncthreads();
+        if (wave == 0 && lane < 32) {
+            float s2 = 0.f;
+            for (int wv = 0; wv < 4; ++wv) s2 += red[3072 + wv * 64 + lane] + red[3072 + wv * 64 + lane + 32];
+            slab[(long long)p.T * a.N * a.C + n0 + lane] = s2;
+        }
+    }
+}
+
 // out[g][idx] = sum_{s in group g} in[s][idx]     (group size gs), fixed order
 __global__ __launch_bounds__(256) void slab_group_sum_kernel(const float* in, float* out, int nslab, int gs, long long count,
                                                              long long stride_in, long long stride_out) {
@@ -255,14 +402,39 @@ const int kWcfgWN[NWCFG] = {1, 1, 2, 1, 1, 1, 2};
 const int kWcfgWC[NWCFG] = {1, 1, 2, 1, 1, 1, 2};
 const int kWcfgTG[NWCFG] = {9, 4, 1, 8, 3, 1, 3};
 
+// row-window kernel: stride 1, rows of a multiple of 16 output pixels, 3x3 (unit tap spacing) or 1x1
+bool row_window_ok(const mtd_wgrad_args& a) {
+    const mtd_geom& g = a.g;
+    if (g.in_sy != 1 || g.in_sx != 1 || (g.OW % 16) != 0) return false;
+    if (g.TH == 1 && g.TW == 1) return true;
+    return g.TH == 3 && g.TW == 3 && (g.tap_dx == 1 || g.tap_dx == -1);
+}
+
 WPlan make_wplan(const mtd_wgrad_args& a) {
     WPlan pl{};
     const int T = a.g.TH * a.g.TW;
     const long long M = geom_pixels(a.g);
+    // LDS-staged kernels (strided convs and feature maps narrower than 16 pixels); choices from tools/census.py --sweep-wgrad
     if (T == 1 && a.N % 64 == 0 && a.C % 64 == 0) pl.cfg = 2;
     else if (T <= 4) pl.cfg = 1;
-    else if (T <= 9) pl.cfg = 0;
-    else pl.cfg = 3;
+    else if (T <= 9) pl.cfg = (M <= 2048) ? 4 : 0;              // few pixels, many tiles: 3 taps per wave, no pixel split
+    else pl.cfg = (M >= 2048 && a.N % 64 == 0 && a.C % 64 == 0) ? 2 : 4;
+    if (row_window_ok(a) && g_wforce_cfg != -2) {           // override cfg -2: keep the LDS-staged kernels (A/B comparison)
+        pl.cfg = (T == 1) ? 9 : (a.g.tap_dx > 0 ? 7 : 8);
+        pl.WN = 1; pl.WC = 1; pl.TG = T; pl.ntg = 1;
+        long long tiles = (long long)(a.N / 32) * (a.C / 32);
+        long long want_splits = (256 + tiles - 1) / tiles;      // sweep: ~one workgroup per CU, longer pixel runs per wave
+        if (g_wforce_split > 0) want_splits = g_wforce_split;
+        long long max_splits = (M + 127) / 128;
+        long long ns = want_splits < 1 ? 1 : want_splits;
+        if (ns > max_splits) ns = max_splits;
+        long long ppw = (M + ns * 4 - 1) / (ns * 4);
+        ppw = ((ppw + 31) / 32) * 32;
+        ns = (M + ppw * 4 - 1) / (ppw * 4);
+        pl.ppw = (int)ppw;
+        pl.nsplit = (int)ns;
+        return pl;
+    }
     if (g_wforce_cfg >= 0 && g_wforce_cfg < NWCFG && a.N % (32 * kWcfgWN[g_wforce_cfg]) == 0 && a.C % (32 * kWcfgWC[g_wforce_cfg]) == 0)
         pl.cfg = g_wforce_cfg;
     pl.WN = kWcfgWN[pl.cfg];
@@ -386,6 +558,9 @@ extern "C" int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream) {
             case 2: hipLaunchKernelGGL((wgrad_kernel<2, 2, 1>), grid, dim3(256), 0, s, p); break;
             case 3: hipLaunchKernelGGL((wgrad_kernel<1, 1, 8>), grid, dim3(256), 0, s, p); break;
             case 4: hipLaunchKernelGGL((wgrad_kernel<1, 1, 3>), grid, dim3(256), 0, s, p); break;
+            case 7: hipLaunchKernelGGL((wgrad_row_kernel<3, 3, 1>), grid, dim3(256), 0, s, p); break;
+            case 8: hipLaunchKernelGGL((wgrad_row_kernel<3, 3, -1>), grid, dim3(256), 0, s, p); break;
+            case 9: hipLaunchKernelGGL((wgrad_row_kernel<1, 1, 1>), grid, dim3(256), 0, s, p); break;
             case 5: hipLaunchKernelGGL((wgrad_kernel<1, 1, 1>), grid, dim3(256), 0, s, p); break;
             default: hipLaunchKernelGGL((wgrad_kernel<2, 2, 3>), grid, dim3(256), 0, s, p); break;
         }
