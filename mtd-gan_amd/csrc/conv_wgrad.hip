@@ -211,6 +211,61 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 }
 
 
+
+// Epilogue of the register-operand kernels: sum the four waves of the workgroup through LDS (fixed order), then wave 0
+// writes the tile -- into the workgroup's slab, or, when the launch has a single pixel split, straight into the strided
+// parameter-gradient view (no reduce kernels at all).
+template <int T>
+__device__ __forceinline__ void reg_kernel_epilogue(const WgradParams& p, f32x16 (&acc)[T], float bsum, float* Ls, int n0, int c0,
+                                                    bool do_bias) {
+    const mtd_wgrad_args& a = p.a;
+    const mtd_geom& g = a.g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31;
+    const bool direct = (p.nslab == 1);
+    float* slab = a.ws + (long long)blockIdx.x * p.slab_stride;
+    float* red = Ls;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        __syncthreads();
+        if (wave > 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[(wave - 1) * 1024 + e * 64 + lane] = acc[t][e];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int ty = t / g.TW, tx = t % g.TW;
+            const int kidx = (g.ky0 + ty * g.ky_step) * g.KW + (g.kx0 + tx * g.kx_step);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float v = acc[t][e] + red[e * 64 + lane] + red[1024 + e * 64 + lane] + red[2048 + e * 64 + lane];
+                const int n = n0 + mfma32_row(e, lane);
+                const int cc = c0 + l31;
+                if (direct) {
+                    float* dst = a.dw + (long long)n * a.w_sn + (long long)cc * a.w_sc + kidx;
+                    *dst = (a.accumulate & 1) ? (*dst + v) : v;
+                } else {
+                    slab[((long long)t * a.N + n) * a.C + cc] = v;
+                }
+            }
+        }
+    }
+    if (do_bias) {
+        __syncthreads();
+        red[3072 + wave * 64 + lane] = bsum;
+        __syncthreads();
+        if (wave == 0 && lane < 32) {
+            float s2 = 0.f;
+            for (int wv = 0; wv < 4; ++wv) s2 += red[3072 + wv * 64 + lane] + red[3072 + wv * 64 + lane + 32];
+            if (direct) {
+                float* dst = a.db + n0 + lane;
+                *dst = (a.accumulate & 2) ? (*dst + s2) : s2;
+            } else {
+                slab[(long long)p.T * a.N * a.C + n0 + lane] = s2;
+            }
+        }
+    }
+}
+
 // ---- row-window variant --------------------------------------------------------------------------
 // Stride-1 convolutions whose output rows are a multiple of 16 pixels wide (all 64/32/16-pixel feature maps: two
 // thirds of the step's weight-gradient flops).  No LDS in the main loop: with k-step kk of a 32-pixel chunk defined
@@ -324,37 +379,119 @@ __global__ __launch_bounds__(256, 2) void wgrad_row_kernel(const WgradParams p) 
         }
     }
 
-    // ---- sum the four waves through LDS (tile by tile), wave 0 writes the workgroup's slab
-    float* slab = a.ws + (long long)blockIdx.x * p.slab_stride;
-    float* red = Ls;
+    reg_kernel_epilogue<T>(p, acc, bsum, Ls, n0, c0, do_bias);
+}
+
+
+// ---- block-window variant -------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolutions on the 8x8, 4x4 and 2x2 feature maps of the discriminator trunk (the layers
+// with 512 x 512 ... 256 x 1024 channels).  A lane's 16 pixels (k-steps) are two rows of an 8x8 image, a whole 4x4
+// image or four 2x2 images, so every tap of every pixel is a compile-time shift inside a small register window of the
+// input: 32 (8x8: two rows + one halo row either side) or 16 loads per 32-pixel chunk instead of 144, no LDS, no
+// per-tap address arithmetic -- and k-steps whose tap falls into the zero padding for every lane are not issued at all
+// (8 % / 31 % / 56 % of the MFMAs for 8x8 / 4x4 / 2x2).
+template <int W>
+__global__ __launch_bounds__(256, (W == 8) ? 1 : 2) void wgrad_blk_kernel(const WgradParams p) {
+    constexpr int T = 9;
+    constexpr int HALO = (W == 8) ? 8 : 0;
+    constexpr int NQ = 16 + 2 * HALO;
+    __shared__ __attribute__((aligned(16))) float Ls[3 * 1024 + 256];
+    const mtd_wgrad_args& a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int ntile = blockIdx.y / p.nCt, ctile = blockIdx.y % p.nCt;
+    const int n0 = ntile * 32, c0 = ctile * 32;
+    const int mwave0 = (blockIdx.x * 4 + wave) * p.ppw;
+    const bool do_bias = (a.db != nullptr) && ctile == 0;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p), (short)0, (int)p.p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.q), (short)0, (int)p.q_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int pstep = a.p_ld * 4, qstep = a.q_ld * 4;
+
+    f32x16 acc[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-        __syncthreads();
-        if (wave > 0) {
+    for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) red[(wave - 1) * 1024 + e * 64 + lane] = acc[t][e];
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    float bsum = 0.f;
+
+    float af[16], an[16], qf[NQ];
+    float qn[(W == 8) ? 1 : NQ];          // 4x4 / 2x2: plain double buffer; 8x8 recycles window rows in place
+    unsigned pbase = OOB, qbase = OOB;
+    bool up_ok = false, dn_ok = false;
+    auto setup = [&](int mc) {
+        const int m = mwave0 + mc + kh * 16;
+        const bool valid = (mc < p.ppw) && (m < p.M);
+        pbase = valid ? (unsigned)(((long long)m * a.p_ld + n0 + l31) * 4) : OOB;
+        qbase = valid ? (unsigned)(((long long)m * a.q_ld + c0 + l31) * 4) : OOB;
+        if (W == 8) {
+            const int y0 = (m & 63) >> 3;
+            up_ok = valid && y0 > 0;
+            dn_ok = valid && y0 < 6;
         }
-        __syncthreads();
-        if (wave == 0) {
+    };
+    auto load_p = [&](float* dst) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float v = acc[t][e] + red[e * 64 + lane] + red[1024 + e * 64 + lane] + red[2048 + e * 64 + lane];
-                const int n = n0 + mfma32_row(e, lane);
-                const int cc = c0 + l31;
-                slab[((long long)t * a.N + n) * a.C + cc] = v;
+        for (int kk = 0; kk < 16; ++kk)
+            dst[kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, pbase, kk * pstep, 0));
+    };
+    // window entries [j0, j1) of the chunk described by the current setup()
+    auto load_q = [&](float* dst, int j0, int j1) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            if (j < j0 || j >= j1) continue;
+            const int jj = j - HALO;
+            const bool ok = (qbase != OOB) && (jj < 0 ? up_ok : (jj >= 16 ? dn_ok : true));
+            const unsigned off = ok ? qbase + (unsigned)(jj * qstep) : OOB;
+            dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(qrs, off, 0, 0));
+        }
+    };
+    auto mfma_taprow = [&](int ty) {
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int x = kk % W, xx = x + tx - 1;
+                if (xx < 0 || xx >= W) continue;
+                if (W <= 4) {
+                    const int y = (kk / W) % W, yy = y + ty - 1;
+                    if (yy < 0 || yy >= W) continue;
+                }
+                acc[ty * 3 + tx] = mfma32(af[kk], qf[kk + (ty - 1) * W + (tx - 1) + HALO], acc[ty * 3 + tx]);
             }
         }
-    }
-    if (do_bias) {
-        __syncthreads();
-        red[3072 + wave * 64 + lane] = bsum;
-        __syncthreads();
-        if (wave == 0 && lane < 32) {
-            float s2 = 0.f;
-            for (int wv = 0; wv < 4; ++wv) s2 += red[3072 + wv * 64 + lane] + red[3072 + wv * 64 + lane + 32];
-            slab[(long long)p.T * a.N * a.C + n0 + lane] = s2;
+    };
+
+    setup(0);
+    load_p(af);
+    load_q(qf, 0, NQ);
+    for (int mc = 0; mc < p.ppw; mc += 32) {
+        __builtin_amdgcn_sched_barrier(0);
+        setup(mc + 32);
+        load_p(an);
+        if (W != 8) load_q(qn, 0, NQ);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) bsum += af[kk];
+        mfma_taprow(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (W == 8) load_q(qf, 0, 8);            // window row 0 is dead after filter row 0
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_taprow(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (W == 8) load_q(qf, 8, 16);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_taprow(2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (W == 8) load_q(qf, 16, 32);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) af[kk] = an[kk];
+        if (W != 8) {
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) qf[j] = qn[j];
         }
     }
+    reg_kernel_epilogue<T>(p, acc, bsum, Ls, n0, c0, do_bias);
 }
 
 // out[g][idx] = sum_{s in group g} in[s][idx]     (group size gs), fixed order
@@ -410,6 +547,14 @@ bool row_window_ok(const mtd_wgrad_args& a) {
     return g.TH == 3 && g.TW == 3 && (g.tap_dx == 1 || g.tap_dx == -1);
 }
 
+// block-window kernel: 3x3 / stride 1 / pad 1 on square 8x8, 4x4 or 2x2 maps (forward tap order)
+int block_window_w(const mtd_wgrad_args& a) {
+    const mtd_geom& g = a.g;
+    if (g.in_sy != 1 || g.in_sx != 1 || g.TH != 3 || g.TW != 3 || g.tap_dy != 1 || g.tap_dx != 1) return 0;
+    if (g.off_y != -1 || g.off_x != -1 || g.IH != g.OH || g.IW != g.OW || g.OH != g.OW) return 0;
+    return (g.OW == 8 || g.OW == 4 || g.OW == 2) ? g.OW : 0;
+}
+
 WPlan make_wplan(const mtd_wgrad_args& a) {
     WPlan pl{};
     const int T = a.g.TH * a.g.TW;
@@ -419,8 +564,9 @@ WPlan make_wplan(const mtd_wgrad_args& a) {
     else if (T <= 4) pl.cfg = 1;
     else if (T <= 9) pl.cfg = (M <= 2048) ? 4 : 0;              // few pixels, many tiles: 3 taps per wave, no pixel split
     else pl.cfg = (M >= 2048 && a.N % 64 == 0 && a.C % 64 == 0) ? 2 : 4;
-    if (row_window_ok(a) && g_wforce_cfg != -2) {           // override cfg -2: keep the LDS-staged kernels (A/B comparison)
-        pl.cfg = (T == 1) ? 9 : (a.g.tap_dx > 0 ? 7 : 8);
+    const int bw = block_window_w(a);
+    if ((row_window_ok(a) || bw) && g_wforce_cfg != -2) {   // override cfg -2: keep the LDS-staged kernels (A/B comparison)
+        pl.cfg = bw ? (bw == 8 ? 10 : (bw == 4 ? 11 : 12)) : ((T == 1) ? 9 : (a.g.tap_dx > 0 ? 7 : 8));
         pl.WN = 1; pl.WC = 1; pl.TG = T; pl.ntg = 1;
         long long tiles = (long long)(a.N / 32) * (a.C / 32);
         long long want_splits = (256 + tiles - 1) / tiles;      // sweep: ~one workgroup per CU, longer pixel runs per wave
@@ -561,12 +707,16 @@ extern "C" int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream) {
             case 7: hipLaunchKernelGGL((wgrad_row_kernel<3, 3, 1>), grid, dim3(256), 0, s, p); break;
             case 8: hipLaunchKernelGGL((wgrad_row_kernel<3, 3, -1>), grid, dim3(256), 0, s, p); break;
             case 9: hipLaunchKernelGGL((wgrad_row_kernel<1, 1, 1>), grid, dim3(256), 0, s, p); break;
+            case 10: hipLaunchKernelGGL((wgrad_blk_kernel<8>), grid, dim3(256), 0, s, p); break;
+            case 11: hipLaunchKernelGGL((wgrad_blk_kernel<4>), grid, dim3(256), 0, s, p); break;
+            case 12: hipLaunchKernelGGL((wgrad_blk_kernel<2>), grid, dim3(256), 0, s, p); break;
             case 5: hipLaunchKernelGGL((wgrad_kernel<1, 1, 1>), grid, dim3(256), 0, s, p); break;
             default: hipLaunchKernelGGL((wgrad_kernel<2, 2, 3>), grid, dim3(256), 0, s, p); break;
         }
         mtd_prof_end(prof, s);
         MTD_LAUNCH_CHECK();
     }
+    if (!direct && pl.cfg >= 7 && nsplit == 1) return MTD_OK;      // single split: the kernel wrote dw / db itself
     // staged, order-fixed reduction of the slabs
     const float* cur = a->ws;
     int ns = nsplit;
