@@ -15,6 +15,8 @@ constexpr float SN_EPS = 1e-12f;
 constexpr int COLS_PER_BLOCK = 256;
 constexpr int MAX_CHUNKS = 64;         // cols <= 16384
 constexpr int ELEMS_PER_BLOCK = 4096;
+constexpr int ROWS_PER_BLOCK = 64;     // W^T u is split over row chunks as well, so the pass fills the chip
+constexpr int MAX_ROW_CHUNKS = 32;     // rows <= 2048
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
     const int tid = threadIdx.x;
@@ -41,7 +43,9 @@ __device__ __forceinline__ bool locate(int n_layers, int bid, F count_of, int& l
     return false;
 }
 
-struct SnWs { float* t; float* partial; float* wv; };
+__device__ __forceinline__ bool aligned16_dev(const void* p) { return (((unsigned long long)p) & 15ull) == 0; }
+
+struct SnWs { float* t; float* partial; float* wv; float* tp; };
 
 __device__ __forceinline__ long long col_offset(const mtd_sn_layer* L, int layer) {
     long long o = 0;
@@ -54,16 +58,51 @@ __device__ __forceinline__ long long row_offset(const mtd_sn_layer* L, int layer
     return o;
 }
 
+// partial column sums over one chunk of rows: tp[rc][k] = sum_{r in chunk rc} W[r][k] u[r]
 __global__ __launch_bounds__(256) void sn_wtu_kernel(const mtd_sn_layer* __restrict__ L, int n_layers, SnWs ws) {
+    int layer, local;
+    auto blocks_of = [&](int l) {
+        return ((L[l].cols + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK) * ((L[l].rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+    };
+    if (!locate(n_layers, blockIdx.x, blocks_of, layer, local)) return;
+    const mtd_sn_layer ly = L[layer];
+    const int nchunk = (ly.cols + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK;
+    const int chunk = local % nchunk, rc = local / nchunk;
+    const int k = chunk * COLS_PER_BLOCK + threadIdx.x;
+    if (k >= ly.cols) return;
+    const int r0 = rc * ROWS_PER_BLOCK, r1 = min(ly.rows, r0 + ROWS_PER_BLOCK);
+    const float* w = ly.w + k;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int r = r0;
+    for (; r + 8 <= r1; r += 8) {
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = w[(long long)(r + i) * ly.cols];
+        t0 = fmaf(x[0], ly.u[r], t0);
+        t1 = fmaf(x[1], ly.u[r + 1], t1);
+        t2 = fmaf(x[2], ly.u[r + 2], t2);
+        t3 = fmaf(x[3], ly.u[r + 3], t3);
+        t0 = fmaf(x[4], ly.u[r + 4], t0);
+        t1 = fmaf(x[5], ly.u[r + 5], t1);
+        t2 = fmaf(x[6], ly.u[r + 6], t2);
+        t3 = fmaf(x[7], ly.u[r + 7], t3);
+    }
+    for (; r < r1; ++r) t0 = fmaf(w[(long long)r * ly.cols], ly.u[r], t0);
+    ws.tp[col_offset(L, layer) * MAX_ROW_CHUNKS + (long long)rc * ly.cols + k] = (t0 + t1) + (t2 + t3);
+}
+
+// t[k] = sum of the row-chunk partials (fixed order), and the per-column-chunk partial of |t|^2
+__global__ __launch_bounds__(256) void sn_tsum_kernel(const mtd_sn_layer* __restrict__ L, int n_layers, SnWs ws) {
     __shared__ float red[256];
     int layer, chunk;
     if (!locate(n_layers, blockIdx.x, [&](int l) { return (L[l].cols + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK; }, layer, chunk)) return;
     const mtd_sn_layer ly = L[layer];
     const int k = chunk * COLS_PER_BLOCK + threadIdx.x;
+    const int nrc = (ly.rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     float t = 0.f;
     if (k < ly.cols) {
-        const float* w = ly.w + k;
-        for (int r = 0; r < ly.rows; ++r) t = fmaf(w[(long long)r * ly.cols], ly.u[r], t);
+        const float* src = ws.tp + col_offset(L, layer) * MAX_ROW_CHUNKS + k;
+        for (int rc = 0; rc < nrc; ++rc) t += src[(long long)rc * ly.cols];
         ws.t[col_offset(L, layer) + k] = t;
     }
     float s = block_sum(t * t, red);
@@ -104,7 +143,25 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(const mtd_sn_layer* __restri
     if (r >= ly.rows) return;
     const float* w = ly.w + (long long)r * ly.cols;
     float s = 0.f;
-    for (int k = lane; k < ly.cols; k += 64) s = fmaf(w[k], ly.v[k], s);
+    if ((ly.cols & 3) == 0 && aligned16_dev(ly.w) && aligned16_dev(ly.v)) {
+        float s1 = 0.f;
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
+        const f32x4* v4 = reinterpret_cast<const f32x4*>(ly.v);
+        const int n4 = ly.cols >> 2;
+        int k = lane;
+        for (; k + 64 < n4; k += 128) {
+            const f32x4 a = w4[k], b = v4[k], c = w4[k + 64], d = v4[k + 64];
+            s = fmaf(a[0], b[0], s); s = fmaf(a[1], b[1], s); s = fmaf(a[2], b[2], s); s = fmaf(a[3], b[3], s);
+            s1 = fmaf(c[0], d[0], s1); s1 = fmaf(c[1], d[1], s1); s1 = fmaf(c[2], d[2], s1); s1 = fmaf(c[3], d[3], s1);
+        }
+        for (; k < n4; k += 64) {
+            const f32x4 a = w4[k], b = v4[k];
+            s = fmaf(a[0], b[0], s); s = fmaf(a[1], b[1], s); s = fmaf(a[2], b[2], s); s = fmaf(a[3], b[3], s);
+        }
+        s += s1;
+    } else {
+        for (int k = lane; k < ly.cols; k += 64) s = fmaf(w[k], ly.v[k], s);
+    }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0) ws.wv[row_offset(L, layer) + r] = s;
 }
@@ -207,7 +264,7 @@ size_t sn_ws_floats(const mtd_sn_layer* h, int n, long long* cols_total, long lo
     for (int i = 0; i < n; ++i) { c += h[i].cols; r += h[i].rows; }
     if (cols_total) *cols_total = c;
     if (rows_total) *rows_total = r;
-    return (size_t)(c + (long long)n * MAX_CHUNKS + r);
+    return (size_t)(c + (long long)n * MAX_CHUNKS + r + c * MAX_ROW_CHUNKS);
 }
 
 }  // namespace
@@ -222,19 +279,24 @@ extern "C" int mtd_sn_power_iter(const mtd_sn_layer* layers_dev, const mtd_sn_la
     if (!layers_dev || !layers_host || n_layers <= 0 || !ws) return MTD_EINVAL;
     long long ctot = 0, rtot = 0;
     sn_ws_floats(layers_host, n_layers, &ctot, &rtot);
-    int col_blocks = 0, row_blocks = 0;
+    int col_blocks = 0, row_blocks = 0, wtu_blocks = 0;
     for (int i = 0; i < n_layers; ++i) {
         if (layers_host[i].cols > COLS_PER_BLOCK * MAX_CHUNKS || layers_host[i].rows <= 0 || layers_host[i].cols <= 0) return MTD_EINVAL;
+        if (layers_host[i].rows > ROWS_PER_BLOCK * MAX_ROW_CHUNKS) return MTD_EINVAL;
         col_blocks += (layers_host[i].cols + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK;
+        wtu_blocks += ((layers_host[i].cols + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK) * ((layers_host[i].rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
         row_blocks += (layers_host[i].rows + 3) / 4;
     }
     SnWs w;
     w.t = ws;
     w.partial = ws + ctot;
     w.wv = w.partial + (long long)n_layers * MAX_CHUNKS;
+    w.tp = w.wv + rtot;
     hipStream_t s = (hipStream_t)stream;
     if (train) {
-        hipLaunchKernelGGL(sn_wtu_kernel, dim3(col_blocks), dim3(256), 0, s, layers_dev, n_layers, w);
+        hipLaunchKernelGGL(sn_wtu_kernel, dim3(wtu_blocks), dim3(256), 0, s, layers_dev, n_layers, w);
+        MTD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(sn_tsum_kernel, dim3(col_blocks), dim3(256), 0, s, layers_dev, n_layers, w);
         MTD_LAUNCH_CHECK();
         hipLaunchKernelGGL(sn_norm_v_kernel, dim3(col_blocks), dim3(256), 0, s, layers_dev, n_layers, w);
         MTD_LAUNCH_CHECK();
