@@ -232,3 +232,42 @@ def test_spectral_path_kernels(hip_lib):
     assert relerr(nchw(gx), x.grad) < 1e-4
     assert relerr(dw2.cpu(), w2.grad.reshape(64, 64)) < 1e-4
     assert relerr(db2.cpu(), b2.grad) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", list(range(8)))
+def test_igemm_every_tile_config(hip_lib, cfg):
+    """Each implicit-GEMM instantiation (forced through the tuning hook), with and without split-K, against F.conv2d:
+    forward 3x3 / 1x1 / strided 4x4-parity data gradient, on maps with borders inside every tile."""
+    import ctypes as C
+    from mtd_gan_amd import _lib, kernels as K
+    L = _lib.lib()
+    L.mtd_conv_igemm_override.argtypes = [C.c_int, C.c_int]
+    cases = [(2, 64, 128, 16, 16, 3, 1, 1), (3, 128, 128, 4, 4, 3, 1, 1), (2, 32, 128, 64, 64, 3, 1, 1), (2, 256, 128, 1, 1, 3, 1, 1),
+             (2, 64, 128, 8, 8, 1, 1, 0)]
+    try:
+        for split in (1, 2):
+            for (B, Ci, Co, H, W, k, s, p) in cases:
+                x = rnd(B, Ci, H, W, seed=11)
+                w = rnd(Co, Ci, k, k, seed=12, scale=(Ci * k * k) ** -0.5)
+                ref = F.conv2d(x, w, None, stride=s, padding=p)
+                out = torch.empty(B, ref.shape[2], ref.shape[3], Co, device="cuda")
+                L.mtd_conv_igemm_override(cfg, split)
+                K._igemm_ws_cache.clear()
+                K.conv(nhwc(x), w.cuda(), K.geom_fwd(B, H, W, k, s, p), Co, Ci, Ci * k * k, k * k, out)
+                assert relerr(nchw(out), ref) < TOL, (cfg, split, B, Ci, Co, H, W, k)
+            # strided data gradient (2x2 taps per output parity)
+            B, Ci, Co, H, W = 2, 64, 128, 16, 16
+            x = rnd(B, Ci, H, W, seed=13).requires_grad_(True)
+            w = rnd(Co, Ci, 4, 4, seed=14, scale=0.03)
+            y = F.conv2d(x, w, None, stride=2, padding=1)
+            cot = rnd(*y.shape, seed=15)
+            (y * cot).sum().backward()
+            dx = torch.empty(B, H, W, Ci, device="cuda")
+            for py in range(2):
+                for px in range(2):
+                    K.conv(nhwc(cot), w.cuda(), K.geom_dgrad_s2(B, H, W, py, px), Ci, Co, 16, Ci * 16, dx)
+            assert relerr(nchw(dx), x.grad) < TOL, (cfg, split, "dgrad_s2")
+    finally:
+        L.mtd_conv_igemm_override(-1, -1)
+        K._igemm_ws_cache.clear()
