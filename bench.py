@@ -78,6 +78,27 @@ def cpu_baseline(wl):
             "sample": f"oracle full G+D+PCGrad+AdamW step, {iters} x {nb} patches (1 warm-up), torch CPU {torch.__version__}, {cores} threads"}
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summaries (profiles/r1_pmc_*.csv: one pass
+    with FETCH_SIZE, one with WRITE_SIZE, values in KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    bench.py cannot collect PMC counters itself; returns None when the summaries are absent."""
+    import csv
+    tot = 0.0
+    for fn, mult in (("r1_pmc_fetch_size.csv", 2.0), ("r1_pmc_write_size.csv", 1.0)):
+        path = os.path.join(ROOT, "profiles", fn)
+        if not os.path.exists(path):
+            return None
+        hit = None
+        for row in csv.DictReader(open(path)):
+            if kernel in row["Kernel_Name"]:
+                hit = float(row["AvgPerDispatch"]) * 1024.0 * mult
+                break
+        if hit is None:
+            return None
+        tot += hit
+    return round(tot)
+
+
 def main():
     args = parse()
     import torch
@@ -134,6 +155,15 @@ def main():
         torch.cuda.synchronize()
         recs = K.prof_collect(cap)
         K.prof_enable(0)
+        # an empty event pair on the same stream: what the bracketing itself adds to every sample
+        pairs = []
+        for _ in range(64):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e1.record()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        ev_over_ms = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
         by = {}
         for r in recs:
             if r["kernel"].startswith("igemm"):
@@ -146,11 +176,17 @@ def main():
                 sh[0] += r["ms"]; sh[1] += r["flops"]; sh[2] += 1
         if by:
             name, d = max(by.items(), key=lambda kv: kv[1]["ms"])
+            raw_ms = d["ms"]
+            for dd in by.values():                          # remove the event-pair overhead from every launch
+                dd["ms"] = max(dd["ms"] - ev_over_ms * dd["n"], 1e-6)
+                for sh in dd["shapes"].values():
+                    sh[0] = max(sh[0] - ev_over_ms * sh[2], 1e-6)
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             top = sorted(d["shapes"].items(), key=lambda kv: -kv[1][0])[:4]
             roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(name),
                         "launches_timed": d["n"], "avg_launch_us": round(1e3 * d["ms"] / d["n"], 2),
+                        "avg_launch_us_with_event_pair": round(1e3 * raw_ms / d["n"], 2), "event_pair_us": round(1e3 * ev_over_ms, 2),
                         "flops_per_launch": round(d["flops"] / d["n"]),
                         "share_of_step_gpu_ms": round(d["ms"] / args.steps, 3),
                         "top_shapes": {k: {"us": round(1e3 * v[0] / v[2], 2), "tflops": round(v[1] / v[0] / 1e9, 2), "launches_per_step": v[2] // args.steps}
