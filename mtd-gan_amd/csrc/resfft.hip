@@ -194,6 +194,13 @@ __global__ __launch_bounds__(64) void spec_mix_fwd_kernel(const float* __restric
         }
     }
     __syncthreads();
+    // the mix weights as MFMA B fragments: 64 registers, one batch of loads (re / im are dead from here to the inverse FFT)
+    float wf0[32], wf1[32];
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+        wf0[kk] = w2t[(2 * kk + kh2) * 64 + l31];
+        wf1[kk] = w2t[(2 * kk + kh2) * 64 + 32 + l31];
+    }
 #pragma unroll 1
     for (int k2 = 0; k2 < 2; ++k2) {
         const int kw2 = 2 * blockIdx.x + k2;
@@ -205,13 +212,13 @@ __global__ __launch_bounds__(64) void spec_mix_fwd_kernel(const float* __restric
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-#pragma unroll 4
+#pragma unroll
         for (int kk = 0; kk < 32; ++kk) {
             const int k = 2 * kk + kh2;
             const float a0 = Xs[(k2 * 64 + l31) * XLD + k];
             const float a1 = Xs[(k2 * 64 + 32 + l31) * XLD + k];
-            const float b0 = w2t[k * 64 + l31];
-            const float b1 = w2t[k * 64 + 32 + l31];
+            const float b0 = wf0[kk];
+            const float b1 = wf1[kk];
             acc[0][0] = mfma32(a0, b0, acc[0][0]);
             acc[0][1] = mfma32(a0, b1, acc[0][1]);
             acc[1][0] = mfma32(a1, b0, acc[1][0]);
@@ -253,18 +260,38 @@ __global__ __launch_bounds__(64) void spec_mix_fwd_kernel(const float* __restric
 
 constexpr int MIX_SLAB = 64 * 64 + 128;   // dW2 partial + two db2 partial rows per workgroup
 
-// columns + channel mix, backward
+// columns + channel mix, backward.  One wave per workgroup: every global read that is not the column data itself is
+// taken off the critical path -- the two saved pre-activation columns (only their signs are needed) and the saved
+// spectrum of the column being reduced stream into LDS with global_load_lds while the column FFT runs in registers,
+// and the 64x64 mix weights sit in 64 registers as ready MFMA fragments.
+typedef __attribute__((address_space(3))) float lds_float;
+
+__device__ __forceinline__ void glds_tile16k(const float* gsrc, float* lds_dst, int lane) {
+    // 16 KiB contiguous global -> 16 KiB contiguous LDS: 16 wave instructions of 64 lanes x 16 bytes
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        __builtin_amdgcn_global_load_lds(gsrc + i * 256 + lane * 4, (lds_float*)(lds_dst + i * 256), 16, 0, 0);
+}
+
 __global__ __launch_bounds__(64) void spec_mix_bwd_kernel(const float* __restrict__ gR, const float* __restrict__ w2,
                                                           const float* __restrict__ S_save, const float* __restrict__ Z_save,
                                                           float* __restrict__ gT, float* __restrict__ ws) {
-    __shared__ float Gs[2 * 64 * XLD];
+    __shared__ __attribute__((aligned(16))) float Gs[2 * 64 * XLD];
+    __shared__ __attribute__((aligned(16))) float Ss[64 * 64];
     const int lane = threadIdx.x, kwl = lane >> 5, c = lane & 31, l31 = lane & 31, kh2 = lane >> 5;
     const int b = blockIdx.y;
     const int kw = 2 * blockIdx.x + kwl;
     const bool valid = kw < NKW;
+    const bool two = (2 * blockIdx.x + 1) < NKW;            // workgroup-uniform: does the second column exist
     float* slab = ws + ((long long)b * gridDim.x + blockIdx.x) * MIX_SLAB;
     float re[64], im[64];
     const long long colbase = ((long long)(b * NKW + (valid ? kw : 0)) * 64) * 64;
+    const long long cb0 = ((long long)(b * NKW + 2 * blockIdx.x) * 64) * 64;
+    // async: Z of column 0 -> Gs[0 ..), Z of column 1 -> Gs[64*XLD ..) (the bases of the two G images written later, so
+    // that the in-place sweep below never overwrites a Z row it still has to read), S of column 0 -> Ss
+    glds_tile16k(Z_save + cb0, Gs, lane);
+    if (two) glds_tile16k(Z_save + cb0 + 4096, Gs + 64 * XLD, lane);
+    glds_tile16k(S_save + cb0, Ss, lane);
     {
         const float* src = gR + colbase + c;
 #pragma unroll
@@ -274,21 +301,33 @@ __global__ __launch_bounds__(64) void spec_mix_bwd_kernel(const float* __restric
         }
     }
     fft64<-1>(re, im);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float dbr = 0.f, dbi = 0.f;
+    const int zbase = kwl * 64 * XLD;
+    // descending kh: G row kh (stride 65) lands on or above Z row kh (stride 64) and never on a lower one
 #pragma unroll
-    for (int kh = 0; kh < 64; ++kh) {
+    for (int kh = 63; kh >= 0; --kh) {
         float gr = re[brev6(kh)] * 0.125f, gi = im[brev6(kh)] * 0.125f;
-        const float zr = valid ? Z_save[colbase + kh * 64 + c] : 0.f;
-        const float zi = valid ? Z_save[colbase + kh * 64 + 32 + c] : 0.f;
+        const float zr = valid ? Gs[zbase + kh * 64 + c] : 0.f;
+        const float zi = valid ? Gs[zbase + kh * 64 + 32 + c] : 0.f;
+        __builtin_amdgcn_wave_barrier();
         gr = zr > 0.f ? gr : 0.f;
         gi = zi > 0.f ? gi : 0.f;
         dbr += gr;
         dbi += gi;
         Gs[(kwl * 64 + kh) * XLD + c] = gr;
         Gs[(kwl * 64 + kh) * XLD + 32 + c] = gi;
+        __builtin_amdgcn_wave_barrier();
     }
     slab[64 * 64 + kwl * 64 + c] = dbr;
     slab[64 * 64 + kwl * 64 + 32 + c] = dbi;
+    // mix weights as MFMA B fragments for the data gradient (re / im are dead until the inverse FFT)
+    float wf0[32], wf1[32];
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+        wf0[kk] = w2[(2 * kk + kh2) * 64 + l31];
+        wf1[kk] = w2[(2 * kk + kh2) * 64 + 32 + l31];
+    }
     __syncthreads();
     f32x16 accw[2][2];
 #pragma unroll
@@ -301,7 +340,6 @@ __global__ __launch_bounds__(64) void spec_mix_bwd_kernel(const float* __restric
     for (int k2 = 0; k2 < 2; ++k2) {
         const int kw2 = 2 * blockIdx.x + k2;
         if (kw2 >= NKW) break;
-        const long long cb2 = ((long long)(b * NKW + kw2) * 64) * 64;
         f32x16 accd[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -310,32 +348,35 @@ __global__ __launch_bounds__(64) void spec_mix_bwd_kernel(const float* __restric
 #pragma unroll
                 for (int e = 0; e < 16; ++e) accd[i][j][e] = 0.f;
         // data gradient  gS[f][k] = sum_o gZ[f][o] W2[o][k]
-#pragma unroll 4
+#pragma unroll
         for (int kk = 0; kk < 32; ++kk) {
             const int o = 2 * kk + kh2;
             const float a0 = Gs[(k2 * 64 + l31) * XLD + o];
             const float a1 = Gs[(k2 * 64 + 32 + l31) * XLD + o];
-            const float b0 = w2[o * 64 + l31];
-            const float b1 = w2[o * 64 + 32 + l31];
-            accd[0][0] = mfma32(a0, b0, accd[0][0]);
-            accd[0][1] = mfma32(a0, b1, accd[0][1]);
-            accd[1][0] = mfma32(a1, b0, accd[1][0]);
-            accd[1][1] = mfma32(a1, b1, accd[1][1]);
+            accd[0][0] = mfma32(a0, wf0[kk], accd[0][0]);
+            accd[0][1] = mfma32(a0, wf1[kk], accd[0][1]);
+            accd[1][0] = mfma32(a1, wf0[kk], accd[1][0]);
+            accd[1][1] = mfma32(a1, wf1[kk], accd[1][1]);
         }
+        if (k2 == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // S of the second column has landed in Ss
         // weight gradient  dW2[o][k] += sum_f gZ[f][o] S[f][k]
-#pragma unroll 4
+#pragma unroll 8
         for (int kk = 0; kk < 32; ++kk) {
             const int f = 2 * kk + kh2;
             const float a0 = Gs[(k2 * 64 + f) * XLD + l31];
             const float a1 = Gs[(k2 * 64 + f) * XLD + 32 + l31];
-            const float b0 = S_save[cb2 + f * 64 + l31];
-            const float b1 = S_save[cb2 + f * 64 + 32 + l31];
+            const float b0 = Ss[f * 64 + l31];
+            const float b1 = Ss[f * 64 + 32 + l31];
             accw[0][0] = mfma32(a0, b0, accw[0][0]);
             accw[0][1] = mfma32(a0, b1, accw[0][1]);
             accw[1][0] = mfma32(a1, b0, accw[1][0]);
             accw[1][1] = mfma32(a1, b1, accw[1][1]);
         }
         __syncthreads();
+        if (k2 == 0 && two) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // every read of Ss has returned
+            glds_tile16k(S_save + cb0 + 4096, Ss, lane);                     // lands under the next column's data gradient
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
