@@ -47,6 +47,7 @@ struct IgemmParams {
     int splitk;
     int c_per_split;
     unsigned in_bytes; // extent of the input view in bytes (buffer-load range check)
+    unsigned w_bytes;  // extent of the weight view in bytes
     int tap_dy[16], tap_dx[16];     // input displacement of tap t (validity test)
     int tap_delta[16];              // byte displacement of tap t in the NHWC input
     int tap_kidx[16];               // index of tap t in the kh*kw plane of the weights
@@ -454,6 +455,257 @@ __global__ __launch_bounds__(256, 2) void igemm_tb_kernel(const IgemmParams p) {
     }
 }
 
+
+// ---- persistent variant for C == 32, 3x3 (the generator's 32->32 convolutions and their data gradients) -------------
+// All nine taps of the [32 n][32 c] weight block (41 KB with padding) are staged into LDS once per workgroup; after
+// that single barrier every wave is on its own: it walks 32-pixel tiles (tile, tile + #waves, ...), nine 16-MFMA steps
+// each, A fragments prefetched one tap ahead -- across the tile boundary too, so the next tile's first loads are in
+// flight while this tile's epilogue stores drain.  No barrier in the steady state, no per-tile weight traffic, and the
+// waves of a SIMD drift into different phases instead of running prologue / loop / epilogue in lockstep.
+__global__ __launch_bounds__(256, 2) void igemm_c32p_kernel(const IgemmParams p, int ntiles) {
+    constexpr int T = 9;
+    __shared__ __attribute__((aligned(16))) float Bs[T * 32 * BLD];
+    const mtd_conv_args& a = p.a;
+    const mtd_geom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int n0 = blockIdx.y * 32;
+    {
+        const int sn = tid >> 3, sq = tid & 7;
+        const int wbase = (int)((long long)(n0 + sn) * a.w_sn) + 4 * sq;
+        f32x4 bn[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) bn[t] = *reinterpret_cast<const f32x4*>(a.w + (wbase + (int)((long long)p.tap_kidx[t] * a.w_st)));
+#pragma unroll
+        for (int t = 0; t < T; ++t) *reinterpret_cast<f32x4*>(&Bs[t * 32 * BLD + sn * BLD + 4 * sq]) = bn[t];
+    }
+    __syncthreads();
+    const int wstride = gridDim.x * 4;
+    int tile = blockIdx.x * 4 + wave;
+    if (tile >= ntiles) return;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)p.in_bytes, 0x00020000);
+    const float sc = a.scale ? *a.scale : 1.f;
+    const float bias_n = a.bias ? a.bias[n0 + l31] : 0.f;
+
+    unsigned boff = 0, okmask = 0;
+    auto setup = [&](int tl, unsigned& bo, unsigned& ok) {
+        const int m = tl * 32 + l31;
+        bo = 0;
+        ok = 0;
+        if (tl < ntiles && m < p.M) {
+            const int ox = m % g.OW;
+            const int t2 = m / g.OW;
+            const int oy = t2 % g.OH;
+            const int b = t2 / g.OH;
+            const int py = oy * g.in_sy + g.off_y, px = ox * g.in_sx + g.off_x;
+            bo = (unsigned)(((((long long)b * g.IH + py) * g.IW + px) * a.in_ld + kh * 16) * 4);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int iy = py + p.tap_dy[t], ix = px + p.tap_dx[t];
+                if (((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW)) ok |= 1u << t;
+            }
+        }
+    };
+    // A fragments are requested PF taps ahead (a load under contention takes ~2 us; one 16-MFMA step of the two waves
+    // that share a SIMD covers 0.85 us), in a ring of PF register sets; the ring runs across the tile boundary.
+    constexpr int PF = 3;
+    f32x4 ring[PF][4], ac[4], bc[4];
+    auto load_a = [&](int slot, int t, unsigned bo, unsigned ok) {
+        const unsigned voff = ((ok >> t) & 1u) ? (bo + (unsigned)p.tap_delta[t]) : 0x80000000u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            ring[slot][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 16 * j, 0));
+    };
+    setup(tile, boff, okmask);
+#pragma unroll
+    for (int t = 0; t < PF; ++t) load_a(t, t, boff, okmask);
+    while (true) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        const int next = tile + wstride;
+        unsigned boff2 = 0, ok2 = 0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ac[j] = ring[t % PF][j];
+            const float* row = &Bs[t * 32 * BLD + l31 * BLD + kh * 16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bc[q] = *reinterpret_cast<const f32x4*>(row + 4 * q);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = mfma32(ac[kk >> 2][kk & 3], bc[kk >> 2][kk & 3], acc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + PF < T) {
+                load_a(t % PF, t + PF, boff, okmask);
+            } else {
+                if (t + PF == T) setup(next, boff2, ok2);   // past the last tile: masks are empty, the loads return zeros
+                load_a(t % PF, t + PF - T, boff2, ok2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 4; kk < 16; ++kk) acc = mfma32(ac[kk >> 2][kk & 3], bc[kk >> 2][kk & 3], acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // epilogue of this tile (the next tile's first fragments are already in flight)
+        const int n = n0 + l31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = tile * 32 + mfma32_row(e, lane);
+            if (m < p.M) {
+                const long long pix = out_pixel(g, m, p.out_identity);
+                a.out[pix * a.out_ld + n] = epilogue_value(a, acc[e], sc, bias_n, pix, n);
+            }
+        }
+        if (next >= ntiles) break;
+        tile = next;
+        boff = boff2;
+        okmask = ok2;
+    }
+}
+
+
+// ---- v2: 128 x 128 workgroup tile, both operands through LDS by LDS-DMA ---------------------------------------------
+// The 3x3 layers are bound by L2 bandwidth in the kernels above: every 32-wide n-tile re-reads its activation tile for
+// each of the nine taps (measured: the generator conv's loads alone take 20 us = 7.4 TB/s of L2 traffic).  Here one
+// workgroup owns 128 pixels x 128 output channels, so a (tap, 32-channel) step moves 16 KB of activations and 16 KB of
+// weights for 256 MFMAs -- 4x less L2 traffic per flop.  Both tiles go global -> LDS with buffer_load_dwordx4 ... lds
+// (no staging registers; out-of-image pixels are out-of-range offsets and arrive as zeros), double-buffered, one
+// workgroup barrier per step with the next step's DMA in flight under the current step's MFMAs.
+// LDS image of a tile: row r (pixel or output channel) = 128 bytes = 8 pieces of 16 bytes; piece q sits at position
+// q ^ (r & 7).  The DMA destination is lane-linear, so the permutation is applied on the source side (lane L of an
+// instruction covering rows 8i..8i+7 fetches piece (L & 7) ^ (L >> 3) of row 8i + (L >> 3)); fragment reads
+// (lane = row, 4 x ds_read_b128) are then conflict-free.  Wave tile 64 x 64 (2 x 2 accumulators).
+template <int DUMMY>
+__global__ __launch_bounds__(256, 2) void igemm_v2_kernel(const IgemmParams p) {
+    __shared__ __attribute__((aligned(1024))) float Ls[2][2][128 * 32];      // [buffer][A | B][row][32]
+    const mtd_conv_args& a = p.a;
+    const mtd_geom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+    const int cbeg = blockIdx.z * p.c_per_split;
+    const int cend = min(a.C, cbeg + p.c_per_split);
+    const int T = g.TH * g.TW;
+    const int nchunk = (cend - cbeg) / KC;
+    const int S = T * nchunk;
+
+    // rows this lane moves in every step: 8 * (wave * 4 + ii) + (lane >> 3), piece (lane & 7) ^ (lane >> 3)
+    const int rsub = lane >> 3;
+    const int piece = (lane & 7) ^ rsub;
+    unsigned aoff[4], okm[4], woff[4];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        const int r = 8 * (wave * 4 + ii) + rsub;
+        const int m = m0 + r;
+        aoff[ii] = 0;
+        okm[ii] = 0;
+        if (m < p.M) {
+            const int ox = m % g.OW;
+            const int t2 = m / g.OW;
+            const int oy = t2 % g.OH;
+            const int b = t2 / g.OH;
+            const int py = oy * g.in_sy + g.off_y, px = ox * g.in_sx + g.off_x;
+            aoff[ii] = (unsigned)(((((long long)b * g.IH + py) * g.IW + px) * a.in_ld + piece * 4) * 4);
+            for (int t = 0; t < T; ++t) {
+                const int iy = py + p.tap_dy[t], ix = px + p.tap_dx[t];
+                if (((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW)) okm[ii] |= 1u << t;
+            }
+        }
+        woff[ii] = (unsigned)(((long long)(n0 + r) * a.w_sn + piece * 4) * 4);
+    }
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), (short)0, (int)p.w_bytes, 0x00020000);
+
+    typedef __attribute__((address_space(3))) float lds_f;
+    auto stage = [&](int s, int buf) {
+        const int t = s / nchunk, c0 = cbeg + (s - t * nchunk) * KC;
+        const unsigned adelta = (unsigned)p.tap_delta[t] + (unsigned)c0 * 4u;
+        const unsigned wdelta = (unsigned)(((long long)p.tap_kidx[t] * a.w_st + c0) * 4);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const unsigned voff = ((okm[ii] >> t) & 1u) ? aoff[ii] + adelta : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_f*)&Ls[buf][0][(wave * 4 + ii) * 256], 16, voff, 0, 0, 0);
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_f*)&Ls[buf][1][(wave * 4 + ii) * 256], 16, woff[ii] + wdelta, 0, 0, 0);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment addresses (floats) inside a tile: row * 32 + ((kh * 4 + q) ^ (row & 7)) * 4
+    int afr[2], bfr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        afr[i] = (wm * 64 + i * 32 + l31) * 32;
+        bfr[i] = (wn * 64 + i * 32 + l31) * 32;
+    }
+    const int sw = l31 & 7;
+
+    if (S > 0) stage(0, 0);
+    for (int s = 0; s < S; ++s) {
+        const int buf = s & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA of step s has landed
+        __syncthreads();                                      // everyone's has; everyone is done reading the other buffer
+        if (s + 1 < S) stage(s + 1, buf ^ 1);
+        f32x4 af[2][4], bf[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                af[i][q] = *reinterpret_cast<const f32x4*>(&Ls[buf][0][afr[i] + (((kh * 4 + q) ^ sw) << 2)]);
+                bf[i][q] = *reinterpret_cast<const f32x4*>(&Ls[buf][1][bfr[i] + (((kh * 4 + q) ^ sw) << 2)]);
+            }
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[i][kk >> 2][kk & 3], bf[j][kk >> 2][kk & 3], acc[i][j]);
+    }
+
+    // ---- epilogue
+    if (p.splitk > 1) {
+        float* slab = a.ws + (long long)blockIdx.z * p.M * a.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm * 64 + i * 32 + mfma32_row(e, lane);
+                    if (m < p.M) slab[(long long)m * a.N + n] = acc[i][j][e];
+                }
+            }
+        return;
+    }
+    const float sc = a.scale ? *a.scale : 1.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + l31;
+            const float bias_n = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + mfma32_row(e, lane);
+                if (m < p.M) {
+                    const long long pix = out_pixel(g, m, p.out_identity);
+                    a.out[pix * a.out_ld + n] = epilogue_value(a, acc[i][j][e], sc, bias_n, pix, n);
+                }
+            }
+        }
+}
+
 // sum the split-K slabs in order, then the same epilogue
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IgemmParams p) {
     const mtd_conv_args& a = p.a;
@@ -473,14 +725,14 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IgemmParams 
 struct Plan { int cfg, BM, BN, splitk, c_per_split; };
 
 int g_force_cfg = -1, g_force_split = -1;      // tuning hook (mtd_conv_igemm_override)
-constexpr int NCFG = 8;
-const int kCfgBM[NCFG] = {256, 128, 256, 64, 128, 32, 128, 256};
-const int kCfgBN[NCFG] = {32, 32, 64, 64, 128, 128, 32, 32};
+constexpr int NCFG = 9;
+const int kCfgBM[NCFG] = {256, 128, 256, 64, 128, 32, 128, 256, 128};
+const int kCfgBN[NCFG] = {32, 32, 64, 64, 128, 128, 32, 32, 128};
 
 Plan make_plan(const mtd_conv_args& a) {
     const long long M = geom_pixels(a.g);
     Plan pl{};
-    if (g_force_cfg >= 0 && g_force_cfg < NCFG && a.N % kCfgBN[g_force_cfg] == 0 && (g_force_cfg < 6 || a.g.TH * a.g.TW <= TB_MAXT)) {
+    if (g_force_cfg >= 0 && g_force_cfg < NCFG && a.N % kCfgBN[g_force_cfg] == 0 && (g_force_cfg < 6 || g_force_cfg == 8 || a.g.TH * a.g.TW <= TB_MAXT)) {
         pl.cfg = g_force_cfg; pl.BM = kCfgBM[pl.cfg]; pl.BN = kCfgBN[pl.cfg];
         int chunks = a.C / KC;
         int sk = g_force_split > 0 ? g_force_split : 1;
@@ -575,6 +827,10 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
         // weight element offsets are formed in 32 bits
         const long long wmax = (long long)(a->N - 1) * a->w_sn + (long long)(a->C - 1) + 16ll * a->w_st + 16;
         if (wmax >= (1ll << 31)) return MTD_EINVAL;
+        int kmax = 0;
+        for (int t = 0; t < gg.TH * gg.TW; ++t) kmax = p.tap_kidx[t] > kmax ? p.tap_kidx[t] : kmax;
+        const long long wb = ((long long)(a->N - 1) * a->w_sn + (long long)kmax * a->w_st + a->C) * 4;
+        p.w_bytes = wb >= (1ll << 31) ? 0x7FFFFFFFu : (unsigned)wb;
     }
     const mtd_geom& g = a->g;
     p.out_identity = (g.out_sy == 1 && g.out_sx == 1 && g.out_oy == 0 && g.out_ox == 0 && g.OHF == g.OH && g.OWF == g.OW);
@@ -583,6 +839,17 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
         if (!a->ws || a->ws_bytes < need) return MTD_EWS;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (g_force_cfg == -1 && a->C == 32 && a->g.TH * a->g.TW == 9 && p.M >= 32768) {
+        // generator-shaped layers: persistent kernel, two 32-pixel tiles per wave at M = 131072
+        const int ntiles = (p.M + 31) / 32;
+        int wgs = (ntiles + 7) / 8;
+        if (wgs > 512) wgs = 512;
+        const int prof = mtd_prof_begin(0, 9, 1, p.M, a->N, a->C, 9, s);
+        hipLaunchKernelGGL(igemm_c32p_kernel, dim3(wgs, a->N / 32), dim3(256), 0, s, p, ntiles);
+        mtd_prof_end(prof, s);
+        MTD_LAUNCH_CHECK();
+        return MTD_OK;
+    }
     dim3 grid((p.M + pl.BM - 1) / pl.BM, a->N / pl.BN, pl.splitk);
     const int prof = mtd_prof_begin(0, pl.cfg, pl.splitk, p.M, a->N, a->C, a->g.TH * a->g.TW, s);
     switch (pl.cfg) {
@@ -593,6 +860,7 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
         case 4: hipLaunchKernelGGL((igemm_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p); break;
         case 6: hipLaunchKernelGGL((igemm_tb_kernel<1>), grid, dim3(256), 0, s, p); break;
         case 7: hipLaunchKernelGGL((igemm_tb_kernel<2>), grid, dim3(256), 0, s, p); break;
+        case 8: hipLaunchKernelGGL((igemm_v2_kernel<0>), grid, dim3(256), 0, s, p); break;
         default: hipLaunchKernelGGL((igemm_kernel<1, 1, 1, 4>), grid, dim3(256), 0, s, p); break;
     }
     mtd_prof_end(prof, s);

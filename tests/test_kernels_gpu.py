@@ -235,7 +235,7 @@ def test_spectral_path_kernels(hip_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", list(range(8)))
+@pytest.mark.parametrize("cfg", list(range(9)))
 def test_igemm_every_tile_config(hip_lib, cfg):
     """Each implicit-GEMM instantiation (forced through the tuning hook), with and without split-K, against F.conv2d:
     forward 3x3 / 1x1 / strided 4x4-parity data gradient, on maps with borders inside every tile."""

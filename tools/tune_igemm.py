@@ -18,8 +18,8 @@ import mtd_gan_amd  # noqa: F401
 from mtd_gan_amd import _lib, kernels as K
 from mtd_gan_amd.train_step import FullStepWorkload
 
-CFG_BM = [256, 128, 256, 64, 128, 32, 128, 256]
-CFG_BN = [32, 32, 64, 64, 128, 128, 32, 32]
+CFG_BM = [256, 128, 256, 64, 128, 32, 128, 256, 128]
+CFG_BN = [32, 32, 64, 64, 128, 128, 32, 32, 128]
 
 
 def time_call(L, a, iters=20):
@@ -92,8 +92,8 @@ def main():
         table = []
         if args.sweep:
             chunks = a.C // 32
-            for cfg in range(8):
-                if a.N % CFG_BN[cfg] or (cfg >= 6 and T > 9):
+            for cfg in range(9):
+                if a.N % CFG_BN[cfg] or (cfg in (6, 7) and T > 9):
                     continue
                 blocks = ((M + CFG_BM[cfg] - 1) // CFG_BM[cfg]) * (a.N // CFG_BN[cfg])
                 if blocks > 4096 and CFG_BM[cfg] < 128:
