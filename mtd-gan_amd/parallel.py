@@ -14,6 +14,9 @@ class DataParallelSync:
         if not dist.is_initialized():
             raise RuntimeError("DataParallelSync needs an initialised torch.distributed process group")
         self.world = dist.get_world_size()
+        # MTD_FORCE_DP=1: run every collective even in a one-rank group (single-GPU smoke test of the N > 1 code path)
+        import os
+        self.force = os.environ.get("MTD_FORCE_DP", "0") == "1"
         self.device = device
         self.cuda = device is not None and torch.device(device).type == "cuda"
         self.side = torch.cuda.Stream(device=device) if self.cuda else None
@@ -26,7 +29,7 @@ class DataParallelSync:
     def all_reduce_avg(self, flat):
         """Average `flat` (a contiguous tensor) across ranks.  On GPUs the collective runs on a side stream
         ordered after the kernels already enqueued on the current stream; wait() joins it back."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if self.cuda:
             ev = torch.cuda.Event()
@@ -55,7 +58,7 @@ class DataParallelSync:
 
     def all_reduce_avg_list(self, tensors):
         """Bucket a list of tensors into one flat buffer, average, scatter back."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         self.wait()
         flat = torch.cat([t.reshape(-1) for t in tensors])

@@ -314,7 +314,9 @@ class FullStepWorkload:
         self.wm = WeightMethods("pcgrad", n_tasks=3, device=dev)
         self.oD = FusedAdamW(self.model.Discriminator.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
         self.oG = FusedAdamW(self.model.Generator.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
-        self.dp = parallel.DataParallelSync(dev) if world > 1 else None
+        import os
+        force_dp = os.environ.get("MTD_FORCE_DP", "0") == "1"
+        self.dp = parallel.DataParallelSync(dev) if (world > 1 or force_dp) else None
         if self.dp is not None:
             self.dp.broadcast_module(self.model)
             self.wm.method.dp = self.dp
