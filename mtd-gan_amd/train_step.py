@@ -45,7 +45,13 @@ class DStepTape:
         sizes = [D.get_parameter(nme).numel() for nme in sh_names]
         total = sum(sizes)
         S = torch.zeros((4, total), dtype=torch.float32, device=dev)       # 3 task vectors + merged
-        TSbuf = {nme: torch.zeros_like(D.get_parameter(nme)) for nme in ts_names}
+        # task-specific gradients: views of one flat buffer, so that N > 1 averages them with a single collective
+        ts_sizes = [D.get_parameter(nme).numel() for nme in ts_names]
+        TSflat = torch.zeros(max(sum(ts_sizes), 1), dtype=torch.float32, device=dev)
+        TSbuf, tofs = {}, 0
+        for nme, sz in zip(ts_names, ts_sizes):
+            TSbuf[nme] = TSflat[tofs:tofs + sz].view_as(D.get_parameter(nme))
+            tofs += sz
         sinks = []
         for i in range(3):
             t, ofs = dict(TSbuf), 0
@@ -85,11 +91,11 @@ class DStepTape:
         gin4 = DP.disc_backward(rt, P, t4, g["c_rfe"], g["c_rfd"], None, sinks[2], True)
         DP.disc_backward(rt, P, t2, g["c_fe"], g["c_fd"], K.clip01_bwd(gin4, fr), sinks[2], False)
         self._sync_task(dp, S, 2)
-        if dp is not None and ts_names:
-            dp.all_reduce_avg_list([TSbuf[nme] for nme in ts_names])
         if dp is not None:
-            dp.wait()
+            dp.wait()                      # the three averaged task vectors are needed by the Gram kernel
         K.side_stream(dev).join()          # weight gradients / spectral-norm corrections ran on the side stream
+        if dp is not None and ts_names:
+            dp.all_reduce_avg(TSflat)      # 158 MB, in flight under the Gram / combine kernels; joined below
         # ---- PCGrad: Gram of the original task gradients, replay of the projections, combine
         orders = next_orders(3)
         slot = orders_slot(dev)
@@ -107,6 +113,8 @@ class DStepTape:
             ofs += sz
         for p, nme in zip(task_specific_params or [], ts_names):
             p.grad = TSbuf[nme]
+        if dp is not None:
+            dp.wait()
         self.gram, self.coeff, self.orders, self.task_vectors = gram, coeff, orders, S
         self.consumed = True
 
