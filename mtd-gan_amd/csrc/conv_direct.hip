@@ -423,7 +423,7 @@ bool wide_plan(const mtd_wgrad_args& a, WideParams& p) {
         if ((ld % 4) || !aligned16(wide)) return false;
     }
     if ((long long)(p.T * p.V + p.V) * 4 * 4 > 48 * 1024) return false;
-    long long ppb = (p.Mw + 511) / 512;
+    long long ppb = (p.Mw + 2047) / 2048;      // many short workgroups: 8 per CU hide the latency of the one wide load per pixel
     const long long min_ppb = 4ll * (64 / p.CL) * 4;
     if (ppb < min_ppb) ppb = min_ppb;
     p.ppb = (int)ppb;
