@@ -131,6 +131,14 @@ int mtd_spec_mix_wgrad_reduce(const float* ws, int B, float* dw2, float* db2, in
 int mtd_irfft_rows(const float* T, float* out, int out_ld, const float* add1, int add1_ld,
                    const float* add2, int add2_ld, const float* mask, int mask_ld, int B, void* stream);
 
+/* The same three steps for square maps of side S = 128, 256 or 512 (whole-slice inference, reference engine.py:89,129:
+ * the generator runs on 512 x 512 images and rfft2 becomes a 512-point transform).  Forward only; spectra are
+ * [B][kw 0..S/2][h 0..S-1][Re 32 | Im 32], ortho scaling 1/sqrt(S) per dimension. */
+int mtd_rfft_rows_any(const float* x, int x_ld, float* R, int B, int S, void* stream);
+int mtd_spec_mix_any(const float* R, const float* w2t, const float* b2, float* T, int B, int S, void* stream);
+int mtd_irfft_rows_any(const float* T, float* out, int out_ld, const float* add1, int add1_ld, const float* add2,
+                       int add2_ld, int B, int S, void* stream);
+
 /* 64x64 transpose of the 1x1 spectral conv weight (W2[o][k] -> W2T[k][o]). */
 int mtd_transpose64(const float* src, float* dst, void* stream);
 

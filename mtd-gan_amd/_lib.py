@@ -108,6 +108,9 @@ def lib():
     sig("mtd_spec_mix_wgrad_reduce", ci, vp, ci, vp, vp, ci, vp)
     sig("mtd_irfft_rows", ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, ci, vp)
     sig("mtd_transpose64", ci, vp, vp, vp)
+    sig("mtd_rfft_rows_any", ci, vp, ci, vp, ci, ci, vp)
+    sig("mtd_spec_mix_any", ci, vp, vp, vp, vp, ci, ci, vp)
+    sig("mtd_irfft_rows_any", ci, vp, vp, ci, vp, ci, vp, ci, ci, ci, vp)
     sig("mtd_act_grad", ci, vp, ci, vp, ci, vp, ci, ll, ci, cf, vp)
     sig("mtd_copy_channels", ci, vp, ci, vp, ci, ll, ci, ci, vp)
     sig("mtd_upsample2x_fwd", ci, vp, ci, vp, ci, ci, ci, ci, ci, vp)
@@ -146,7 +149,7 @@ EXPORTS = [
     "mtd_sn_ws_bytes", "mtd_sn_power_iter", "mtd_sn_grad_ws_bytes", "mtd_sn_grad", "mtd_pcgrad_ws_bytes",
     "mtd_pcgrad_gram", "mtd_pcgrad_combine", "mtd_adamw_multi", "mtd_adamw_multi_dyn", "mtd_adamw_multi_pre", "mtd_loss_terms_ws_bytes", "mtd_loss_terms",
     "mtd_loss_term_grads", "mtd_clip01", "mtd_clip01_bwd", "mtd_edge_loss_ws_bytes", "mtd_edge_loss",
-    "mtd_prof_enable", "mtd_prof_collect", "mtd_conv_igemm_override", "mtd_conv_wgrad_override", "mtd_upload",
+    "mtd_prof_enable", "mtd_prof_collect", "mtd_conv_igemm_override", "mtd_conv_wgrad_override", "mtd_upload", "mtd_rfft_rows_any", "mtd_spec_mix_any", "mtd_irfft_rows_any",
 ]
 
 

@@ -167,8 +167,15 @@ class ResFFT_Generator(nn.Module):
         _require_cuda(x, "ResFFT_Generator")
         if self._cfg != (1, 32, 10, 3, 1):
             raise NotImplementedError("ResFFT_Generator HIP path is built for MTD_GAN_Method's (1,32,10,3,1) configuration")
-        if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] != 64 or x.shape[3] != 64:
-            raise NotImplementedError(f"ResFFT_Generator HIP path expects (B,1,64,64) patches, got {tuple(x.shape)}")
+        if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] != x.shape[3] or x.shape[2] not in (64, 128, 256, 512):
+            raise NotImplementedError(f"ResFFT_Generator HIP path expects (B,1,S,S) with S in 64/128/256/512, got {tuple(x.shape)}")
+        if x.shape[2] != 64 and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("ResFFT_Generator HIP path: maps larger than 64 x 64 are inference-only (use torch.no_grad())")
+        if not torch.is_grad_enabled():
+            xc = x.contiguous().float()
+            P = _unflatten_gen(self._flat_params(), self._cfg[2])
+            out, _ = GP.generator_forward(xc.reshape(xc.shape[0], xc.shape[2], xc.shape[3], 1), P, False)
+            return out.reshape(xc.shape)
         return _GeneratorFn.apply(x.contiguous().float(), self._cfg[2], *self._flat_params())
 
 

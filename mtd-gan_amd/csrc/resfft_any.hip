@@ -1,0 +1,205 @@
+// Res-FFT-Conv spectral path for square maps of any power-of-two size 128 .. 512 (inference on whole slices:
+// reference engine.py:89,129 runs the generator on 512 x 512 images, where rfft2 is a 512-point transform).
+// The 64 x 64 training path keeps its register-resident kernels (resfft.hip); here one workgroup owns one image line
+// (a row, or a frequency column) for all 32 channels and transforms it in LDS: [S points][32 channels] re + im = S * 256
+// bytes (128 KB at S = 512, 160 KB per CU), radix-2, one barrier per stage, lane = channel so every LDS access is
+// stride-1 across lanes.  Forward transforms are decimation-in-frequency (natural in, bit-reversed out), inverse ones
+// decimation-in-time (bit-reversed in, natural out): the 1x1 spectral conv between them is per frequency, so the
+// column kernel never reorders anything.  Spectra: [B][kw 0..S/2][h 0..S-1][Re 32 | Im 32], ortho scaling 1/sqrt(S)
+// per dimension.  HBM-bound in principle (two passes over 3 x the activation size per block); these kernels are the
+// simple, exact version -- the work of a slice is dominated by the 3x3 convolutions.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int brev_n(int k, int logS) { return (int)(__brev((unsigned)k) >> (32 - logS)); }
+
+// in-place radix-2 FFT of re/im[S][32]; every thread of the workgroup takes part
+template <int SIGN, bool DIF>
+__device__ __forceinline__ void lds_fft(float* re, float* im, int S, int logS) {
+    const int nbf = (S >> 1) * 32;                    // butterflies per stage (pair index x channel)
+    for (int st = 0; st < logS; ++st) {
+        const int half = DIF ? (S >> (st + 1)) : (1 << st);
+        const float inv_half = 1.f / (float)half;
+        for (int e = threadIdx.x; e < nbf; e += blockDim.x) {
+            const int c = e & 31, pidx = e >> 5;
+            const int grp = pidx / half, j = pidx - grp * half;
+            const int i0 = (grp * 2 * half + j) * 32 + c, i1 = i0 + half * 32;
+            float sn, cs;
+            sincospif((float)(SIGN * j) * inv_half, &sn, &cs);      // exp(SIGN * i * pi * j / half)
+            const float ur = re[i0], ui = im[i0], vr = re[i1], vi = im[i1];
+            if (DIF) {
+                const float dr = ur - vr, di = ui - vi;
+                re[i0] = ur + vr;
+                im[i0] = ui + vi;
+                re[i1] = dr * cs - di * sn;
+                im[i1] = dr * sn + di * cs;
+            } else {
+                const float wr = vr * cs - vi * sn, wi = vr * sn + vi * cs;
+                re[i0] = ur + wr;
+                im[i0] = ui + wi;
+                re[i1] = ur - wr;
+                im[i1] = ui - wi;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// rows forward: one workgroup per image row (b, h)
+__global__ __launch_bounds__(256) void rfft_rows_any_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ R, int S, int logS) {
+    extern __shared__ float lds[];
+    float* re = lds;
+    float* im = lds + S * 32;
+    const int b = blockIdx.x / S, h = blockIdx.x % S;
+    const int nkw = S / 2 + 1;
+    const float* src = x + ((long long)(b * S + h) * S) * x_ld;
+    for (int e = threadIdx.x; e < S * 32; e += 256) {
+        const int c = e & 31, w = e >> 5;
+        re[e] = src[(long long)w * x_ld + c];
+        im[e] = 0.f;
+    }
+    __syncthreads();
+    lds_fft<-1, true>(re, im, S, logS);
+    const float sc = rsqrtf((float)S);
+    for (int e = threadIdx.x; e < nkw * 32; e += 256) {
+        const int c = e & 31, kw = e >> 5;
+        const int pos = brev_n(kw, logS) * 32 + c;
+        float* o = R + (((long long)(b * nkw + kw) * S + h) * 64) + c;
+        o[0] = re[pos] * sc;
+        o[32] = im[pos] * sc;
+    }
+}
+
+// columns + channel mix + columns back: one workgroup per (b, kw)
+__global__ __launch_bounds__(256) void spec_mix_any_kernel(const float* __restrict__ R, const float* __restrict__ w2t,
+                                                           const float* __restrict__ b2, float* __restrict__ T, int S, int logS) {
+    extern __shared__ float lds[];
+    float* re = lds;
+    float* im = lds + S * 32;
+    const long long colbase = (long long)blockIdx.x * S * 64;
+    for (int e = threadIdx.x; e < S * 32; e += 256) {
+        const int c = e & 31, h = e >> 5;
+        re[e] = R[colbase + (long long)h * 64 + c];
+        im[e] = R[colbase + (long long)h * 64 + 32 + c];
+    }
+    __syncthreads();
+    lds_fft<-1, true>(re, im, S, logS);
+    // channel mix at every frequency (order of the frequencies is irrelevant): lane = output channel o, its 64 weights in
+    // registers; a wave owns whole rows, reads all 64 inputs of a row (broadcast reads) before it writes the 64 outputs
+    {
+        const int o = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        float wreg[64];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) wreg[k] = w2t[k * 64 + o];
+        const float bo = b2[o];
+        const float sc = rsqrtf((float)S);
+        for (int n = wv; n < S; n += 4) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) acc = fmaf(re[n * 32 + k], wreg[k], acc);
+#pragma unroll
+            for (int k = 0; k < 32; ++k) acc = fmaf(im[n * 32 + k], wreg[32 + k], acc);
+            const float z = fmaxf(acc * sc + bo, 0.f);
+            __builtin_amdgcn_wave_barrier();
+            if (o < 32) re[n * 32 + o] = z;
+            else im[n * 32 + o - 32] = z;
+        }
+    }
+    __syncthreads();
+    lds_fft<+1, false>(re, im, S, logS);
+    const float sc = rsqrtf((float)S);
+    for (int e = threadIdx.x; e < S * 32; e += 256) {
+        const int c = e & 31, h = e >> 5;
+        T[colbase + (long long)h * 64 + c] = re[e] * sc;
+        T[colbase + (long long)h * 64 + 32 + c] = im[e] * sc;
+    }
+}
+
+// rows back (c2r): one workgroup per image row; out = y + add1 + add2
+__global__ __launch_bounds__(256) void irfft_rows_any_kernel(const float* __restrict__ T, float* __restrict__ out, int out_ld,
+                                                             const float* __restrict__ add1, int add1_ld,
+                                                             const float* __restrict__ add2, int add2_ld, int S, int logS) {
+    extern __shared__ float lds[];
+    float* re = lds;
+    float* im = lds + S * 32;
+    const int b = blockIdx.x / S, h = blockIdx.x % S;
+    const int nkw = S / 2 + 1;
+    // Hermitian extension of the half spectrum; the imaginary parts of columns 0 and S/2 are ignored (as torch's c2r does)
+    for (int e = threadIdx.x; e < nkw * 32; e += 256) {
+        const int c = e & 31, kw = e >> 5;
+        const float* t = T + (((long long)(b * nkw + kw) * S + h) * 64) + c;
+        const float xr = t[0];
+        const float xi = (kw == 0 || kw == S / 2) ? 0.f : t[32];
+        const int p0 = brev_n(kw, logS) * 32 + c;
+        re[p0] = xr;
+        im[p0] = xi;
+        if (kw != 0 && kw != S / 2) {
+            const int p1 = brev_n(S - kw, logS) * 32 + c;
+            re[p1] = xr;
+            im[p1] = -xi;
+        }
+    }
+    __syncthreads();
+    lds_fft<+1, false>(re, im, S, logS);
+    const float sc = rsqrtf((float)S);
+    const long long rowpix = (long long)(b * S + h) * S;
+    for (int e = threadIdx.x; e < S * 32; e += 256) {
+        const int c = e & 31, w = e >> 5;
+        float v = re[e] * sc;
+        if (add1) v += add1[(rowpix + w) * add1_ld + c];
+        if (add2) v += add2[(rowpix + w) * add2_ld + c];
+        out[(rowpix + w) * out_ld + c] = v;
+    }
+}
+
+int log2_exact(int S) {
+    int l = 0;
+    while ((1 << l) < S) ++l;
+    return ((1 << l) == S) ? l : -1;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return MTD_OK;
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return e == hipSuccess ? MTD_OK : (int)e;
+}
+
+}  // namespace
+
+extern "C" int mtd_rfft_rows_any(const float* x, int x_ld, float* R, int B, int S, void* stream) {
+    const int logS = log2_exact(S);
+    if (!x || !R || B <= 0 || logS < 6 || S > 512 || x_ld < 32) return MTD_EINVAL;
+    const size_t lds = (size_t)S * 256;
+    int rc = set_lds(rfft_rows_any_kernel, lds);
+    if (rc != MTD_OK) return rc;
+    hipLaunchKernelGGL(rfft_rows_any_kernel, dim3(B * S), dim3(256), lds, (hipStream_t)stream, x, x_ld, R, S, logS);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_spec_mix_any(const float* R, const float* w2t, const float* b2, float* T, int B, int S, void* stream) {
+    const int logS = log2_exact(S);
+    if (!R || !w2t || !b2 || !T || B <= 0 || logS < 6 || S > 512) return MTD_EINVAL;
+    const size_t lds = (size_t)S * 256;
+    int rc = set_lds(spec_mix_any_kernel, lds);
+    if (rc != MTD_OK) return rc;
+    hipLaunchKernelGGL(spec_mix_any_kernel, dim3(B * (S / 2 + 1)), dim3(256), lds, (hipStream_t)stream, R, w2t, b2, T, S, logS);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_irfft_rows_any(const float* T, float* out, int out_ld, const float* add1, int add1_ld, const float* add2,
+                                  int add2_ld, int B, int S, void* stream) {
+    const int logS = log2_exact(S);
+    if (!T || !out || B <= 0 || logS < 6 || S > 512 || out_ld < 32) return MTD_EINVAL;
+    if ((add1 && add1_ld < 32) || (add2 && add2_ld < 32)) return MTD_EINVAL;
+    const size_t lds = (size_t)S * 256;
+    int rc = set_lds(irfft_rows_any_kernel, lds);
+    if (rc != MTD_OK) return rc;
+    hipLaunchKernelGGL(irfft_rows_any_kernel, dim3(B * S), dim3(256), lds, (hipStream_t)stream, T, out, out_ld, add1, add1_ld, add2,
+                       add2_ld, S, logS);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}

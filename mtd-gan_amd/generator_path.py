@@ -19,6 +19,16 @@ def block_forward(x, w_img, b_img, w_fft, b_fft, save):
     B, H, W, _ = x.shape
     g = K.geom_fwd(B, H, W, 3, 1, 1)
     img = K.empty_nhwc(B, H, W, CH, x)
+    if H != 64 or W != 64:
+        # whole-slice inference (reference engine.py:89,129): LDS-resident transforms of side 128 / 256 / 512, forward only
+        if save:
+            raise RuntimeError("FFT_ConvBlock: training is implemented for 64 x 64 patches; larger maps are inference-only")
+        if H != W or H not in (128, 256, 512):
+            raise RuntimeError(f"FFT_ConvBlock: unsupported map size {H} x {W} (64, 128, 256 or 512 square)")
+        K.conv(x, w_img, g, CH, CH, CH * 9, 9, img, bias=b_img, act=ACT_RELU)
+        out = K.empty_nhwc(B, H, W, CH, x)
+        K.spectral_branch_any(x, K.transpose64(w_fft), b_fft, out, add1=x, add2=img)
+        return out, None
     # the spatial branch (fp32-MFMA conv) runs on a side stream beside the spectral branch (FFT rows / columns)
     side = K.side_stream(x.device, 1)
     side.run(lambda: K.conv(x, w_img, g, CH, CH, CH * 9, 9, img, bias=b_img, act=ACT_RELU), x)   # relu(conv3x3(x)+b)

@@ -270,6 +270,19 @@ def irfft_rows(T, out, add1=None, add2=None, mask=None):
     return out
 
 
+def spectral_branch_any(x, w2t, b2, out, add1=None, add2=None):
+    """out = add1 + add2 + irfft2(relu(W2 . rfft2(x) + b2)) for a square NHWC map of side 128 / 256 / 512 (forward only)."""
+    L = _lib.lib()
+    B, S = x.shape[0], x.shape[1]
+    R = torch.empty((B, S // 2 + 1, S, 64), dtype=torch.float32, device=x.device)
+    T = torch.empty_like(R)
+    check(L.mtd_rfft_rows_any(x.data_ptr(), ld_of(x), R.data_ptr(), B, S, stream_ptr()), "mtd_rfft_rows_any")
+    check(L.mtd_spec_mix_any(R.data_ptr(), w2t.data_ptr(), b2.data_ptr(), T.data_ptr(), B, S, stream_ptr()), "mtd_spec_mix_any")
+    check(L.mtd_irfft_rows_any(T.data_ptr(), out.data_ptr(), ld_of(out), _ptr(add1), ld_of(add1) if add1 is not None else 0,
+                               _ptr(add2), ld_of(add2) if add2 is not None else 0, B, S, stream_ptr()), "mtd_irfft_rows_any")
+    return out
+
+
 def transpose64(src):
     dst = torch.empty((64, 64), dtype=torch.float32, device=src.device)
     check(_lib.lib().mtd_transpose64(src.data_ptr(), dst.data_ptr(), stream_ptr()), "mtd_transpose64")
