@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- MTD-GAN hot-path throughput on MI355X (contract: see the task statement / DESIGN.md).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload full_step|generator]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload full_step|generator|inference512]
 
 One process per GPU (launched by torch.distributed.run for N > 1, backend nccl == RCCL).  A "step" is
 one pass of the hot path over one batch of synthetic LDCT-shaped 64x64 patches (32 per GPU, weak
@@ -60,6 +60,16 @@ def cpu_baseline(wl):
         dt = time.perf_counter() - t0
         return {"value": round(nb * iters / dt, 3), "unit": "img/s", "cores": cores, "kind": "port",
                 "sample": f"oracle generator fwd+bwd, {iters} x {nb} patches (1 warm-up), torch CPU {torch.__version__}, {cores} threads"}
+    if wl.name == "inference512":
+        g = orc.seeded_fill(orc.g_param_shapes(), seed=7)
+        x, y = orc.synthetic_ldct(1, seed=1234, size=512)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            out = orc.generator_forward(g, x)
+            orc.psnr(out.clip(0, 1), y), orc.ssim(out.clip(0, 1), y), orc.rmse(out.clip(0, 1), y)
+        dt = time.perf_counter() - t0
+        return {"value": round(1.0 / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
+                "sample": f"oracle generator forward + pixel metrics on one 512x512 slice, torch CPU {torch.__version__}, {cores} threads"}
     # full training iteration: oracle.train_step (engine.py:33-55 restated) on a small batch
     nb, iters = 4, 2
     x, y = orc.synthetic_ldct(nb, seed=1234)
@@ -124,6 +134,7 @@ def main():
             dist.barrier()
     from mtd_gan_amd import bench_workloads as BW
     wl = BW.make(args.workload, dev, rank, world, PER_GPU_BATCH)
+    per_gpu_units = getattr(wl, "slices", PER_GPU_BATCH)
 
     def barrier():
         if world > 1:
@@ -143,7 +154,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms = 1e3 * dt / args.steps
-    value = PER_GPU_BATCH * world * args.steps / dt
+    value = per_gpu_units * world * args.steps / dt
 
     roofline = None
     if not args.no_roofline:

@@ -228,6 +228,13 @@ size_t mtd_edge_loss_ws_bytes(int B);
 int mtd_edge_loss(const float* a, const float* b, int B, float scale, float eps, float* out, float* grad_out,
                   float coef, int accumulate, void* ws, void* stream);
 
+/* ---- pixel metrics of the evaluation loops (metrics.py:172-244; engine.py:78-183) -------------------------------
+ * For a batch of B single-channel H x W images a, b (contiguous): out2[0] = sum (a' - b)^2, out2[1] = sum of the SSIM map
+ * of (a', b) (11x11 Gaussian window, sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2), a' = clip(a, 0, 1) if clip_a.
+ * RMSE = sqrt(out2[0] / n), PSNR = 10 log10(1 / (out2[0] / n + 1e-10)), SSIM = out2[1] / n with n = B*H*W. */
+size_t mtd_image_metrics_ws_bytes(int B, int H, int W);
+int mtd_image_metrics(const float* a, const float* b, int B, int H, int W, int clip_a, double* out2, void* ws, void* stream);
+
 /* ---- launch profiler (bench.py's roofline leg) ---------------------------------------------------------------
  * When enabled, mtd_conv_igemm / mtd_conv_wgrad bracket their MAIN kernel (not the split-K / slab reductions that
  * follow it) with a pair of HIP events on the stream they were given.  mtd_prof_collect synchronises those events

@@ -136,6 +136,8 @@ def lib():
     sig("mtd_clip01", ci, vp, vp, ll, vp)
     sig("mtd_clip01_bwd", ci, vp, vp, vp, ll, vp)
     sig("mtd_edge_loss_ws_bytes", sz, ci)
+    sig("mtd_image_metrics_ws_bytes", sz, ci, ci, ci)
+    sig("mtd_image_metrics", ci, vp, vp, ci, ci, ci, ci, vp, vp, vp)
     sig("mtd_edge_loss", ci, vp, vp, ci, cf, cf, vp, vp, cf, ci, vp, vp)
     _lib = L
     return L
@@ -149,7 +151,7 @@ EXPORTS = [
     "mtd_sn_ws_bytes", "mtd_sn_power_iter", "mtd_sn_grad_ws_bytes", "mtd_sn_grad", "mtd_pcgrad_ws_bytes",
     "mtd_pcgrad_gram", "mtd_pcgrad_combine", "mtd_adamw_multi", "mtd_adamw_multi_dyn", "mtd_adamw_multi_pre", "mtd_loss_terms_ws_bytes", "mtd_loss_terms",
     "mtd_loss_term_grads", "mtd_clip01", "mtd_clip01_bwd", "mtd_edge_loss_ws_bytes", "mtd_edge_loss",
-    "mtd_prof_enable", "mtd_prof_collect", "mtd_conv_igemm_override", "mtd_conv_wgrad_override", "mtd_upload", "mtd_rfft_rows_any", "mtd_spec_mix_any", "mtd_irfft_rows_any",
+    "mtd_prof_enable", "mtd_prof_collect", "mtd_conv_igemm_override", "mtd_conv_wgrad_override", "mtd_upload", "mtd_image_metrics_ws_bytes", "mtd_image_metrics", "mtd_rfft_rows_any", "mtd_spec_mix_any", "mtd_irfft_rows_any",
 ]
 
 

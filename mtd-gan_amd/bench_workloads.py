@@ -73,7 +73,43 @@ class GeneratorWorkload:
                 "launch_mode": "hipGraph replay" if self.graph is not None else "eager launches", "graph_error": self.graph_error}
 
 
+class InferenceWorkload:
+    """BASELINE configs[4]: whole-slice generator inference on (8,1,512,512) per GPU, torch.no_grad (what the reference's
+    valid_/test_MTD_GAN_Ours do, engine.py:89,129), followed by the pixel metrics of the test loop.  Work: 64 x 3.63 =
+    232 GFLOP per slice.  A "step" is one batch of 8 slices."""
+
+    name = "inference512"
+    gflop_per_patch = 232.0
+    slices = 8
+
+    def __init__(self, dev, rank, world, batch):
+        from .arch.Ours.networks import ResFFT_Generator
+        torch.manual_seed(2024)
+        self.G = ResFFT_Generator(1, 32, 10, 3, 1).to(dev).eval()
+        x, y = synthetic_ldct(self.slices, seed=1234 + rank, size=512)
+        self.x, self.y = x.to(dev), y.to(dev)
+        self.world = world
+        self.last = None
+
+    def step(self):
+        from . import kernels as K
+        from . import metrics as M
+        with torch.no_grad():
+            pred = self.G(self.x)
+            self.last = M.pixel_metrics(self.x, self.y, K.clip01(pred))
+
+    def config(self, world):
+        return {"workload": "Whole-slice generator inference + pixel metrics (BASELINE configs[4])", "per_gpu_batch": self.slices,
+                "global_batch": self.slices * world, "patch": "1x512x512", "parallelism": f"dp{world}"}
+
+    def extra(self):
+        return {"algorithmic_gflop_per_patch": self.gflop_per_patch, "unit_note": "img = one 512x512 slice",
+                "pixel_metrics_last_batch": self.last}
+
+
 def make(name, dev, rank, world, batch):
+    if name in ("inference", "inference512"):
+        return InferenceWorkload(dev, rank, world, batch)
     if name in ("auto", "generator", "generator_fwd_bwd"):
         try:
             if name == "auto":

@@ -65,3 +65,79 @@ def train_MTD_GAN_Ours(model, data_loader, optimizer_G, optimizer_D, device, epo
             print(f"Train: [epoch:{epoch}] [{it}/{n_it}] " + "  ".join(f"{k}: {m.global_avg:.4f}" for k, m in meters.items()), flush=True)
     order = ["lr"] + [k for k in meters if k != "lr"]
     return {k: round(meters[k].global_avg, 7) for k in order}
+
+
+# ================================================================================================ evaluation loops
+def _l1(loss, pred, target):
+    """The reference passes nn.L1Loss; its mean runs as one loss-term launch.  Any other callable is applied as given."""
+    from . import kernels as K
+    if isinstance(loss, torch.nn.L1Loss) and loss.reduction == "mean":
+        p, t = pred.contiguous(), target.contiguous()
+        return K.loss_terms([K.make_term(1, p, t, scale=1.0 / p.numel())], p.device)[0]
+    return loss(pred, target)
+
+
+def _save_png(path, img):
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+    except ImportError:                      # PNG dumps are cosmetic; the metrics do not depend on them
+        return
+    plt.imsave(path, img.squeeze().cpu().numpy(), cmap="gray")
+
+
+@torch.no_grad()
+def valid_MTD_GAN_Ours(model, loss, data_loader, device, epoch, save_dir, print_freq):
+    """Mirror of engine.py:78-106: whole-slice generator inference + L1 loss; returns {'L1_loss': global average}.
+    Slices may be 64, 128, 256 or 512 pixels square (the reference validates on 512 x 512)."""
+    model.Generator.eval()
+    model.Discriminator.eval()
+    m = _Meter()
+    n_it = len(data_loader)
+    last = None
+    for it, batch_data in enumerate(data_loader):
+        x = batch_data["n_20"].to(device).float()
+        y = batch_data["n_100"].to(device).float()
+        pred = model.Generator(x)
+        m.update(float(_l1(loss, pred, y)), 1)
+        last = (x, y, pred)
+        if print_freq and (it % print_freq == 0 or it == n_it - 1):
+            print(f"Valid: [epoch:{epoch}] [{it}/{n_it}] L1_loss: {m.global_avg:.6f}", flush=True)
+    if save_dir and last is not None:
+        import os
+        os.makedirs(save_dir, exist_ok=True)
+        for tag, t in zip(("input_n_20", "gt_n_100", "pred_n_100"), last):
+            _save_png(os.path.join(save_dir, f"epoch_{epoch}_{tag}.png"), t[0])
+    return {"L1_loss": round(m.global_avg, 7)}
+
+
+@torch.no_grad()
+def test_MTD_GAN_Ours(model, loss, data_loader, device, save_dir):
+    """Mirror of engine.py:108-183 for the pixel metrics: whole-slice inference, L1, RMSE / PSNR / SSIM of (input, gt,
+    clipped prediction) per slice, pred_results.csv.  The perceptual metrics of the reference (PL, TML, FID: torchvision
+    VGG16 / InceptionV3 weights) are outside this package; their columns are absent from the result."""
+    from . import metrics as M
+    model.Generator.eval()
+    meters = {}
+    rows = []
+    for batch_data in data_loader:
+        x = batch_data["n_20"].to(device).float()
+        y = batch_data["n_100"].to(device).float()
+        pred = model.Generator(x)
+        meters.setdefault("L1_loss", _Meter()).update(float(_l1(loss, pred, y)), 1)
+        from . import kernels as K
+        pm = M.pixel_metrics(x, y, K.clip01(pred.contiguous()))
+        for name, triple in pm.items():
+            for who, v in zip(("input", "gt", "pred"), triple):
+                meters.setdefault(f"{who}_{name}", _Meter()).update(v, 1)
+        path = batch_data.get("path_n_20", [f"slice_{len(rows)}"])[0] if isinstance(batch_data, dict) else f"slice_{len(rows)}"
+        rows.append((path, pm["rmse"][2], pm["psnr"][2], pm["ssim"][2]))
+    if save_dir:
+        import os
+        os.makedirs(save_dir, exist_ok=True)
+        with open(os.path.join(save_dir, "pred_results.csv"), "w") as f:
+            f.write(",PATH,RMSE,PSNR,SSIM\n")
+            for i, r in enumerate(rows):
+                f.write(f"{i},{r[0]},{r[1]},{r[2]},{r[3]}\n")
+    return {k: round(mm.global_avg, 7) for k, mm in meters.items()}

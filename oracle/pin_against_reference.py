@@ -151,6 +151,21 @@ def main():
     x32, _ = orc.synthetic_ldct(32, seed=1234)
     close(x32[0, 0, 0, :4], torch.tensor([0.243470, 0.229047, 0.101727, 0.305131]), 1e-5, "synthetic_ldct anchor (SURVEY 8d)")
 
+    # ------------------------------------------------------------------ 2b. whole-slice inference (engine.py:89,129), 128 x 128
+    print("generator, whole-slice inference (1 x 1 x 128 x 128, no_grad)")
+    x3, y3 = orc.synthetic_ldct(1, seed=77, size=128)
+    with torch.no_grad():
+        out_r3 = G(x3)
+        out_o3 = orc.generator_forward(gstate, x3)
+    close(out_o3, out_r3, 2e-6, "G fwd 128")
+    m_r = [metrics.compute_PSNR(x3, y3, out_r3.clip(0, 1)), metrics.compute_SSIM(x3, y3, out_r3.clip(0, 1)), metrics.compute_RMSE(x3, y3, out_r3.clip(0, 1))]
+    close(orc.psnr(x3, y3), m_r[0][0], 1e-6, "PSNR input")
+    close(orc.ssim(x3, y3), m_r[1][0], 1e-5, "SSIM input")
+    close(orc.ssim(y3, y3), m_r[1][1], 1e-6, "SSIM gt")
+    close(orc.ssim(out_o3.clip(0, 1), y3), m_r[1][2], 1e-5, "SSIM pred")
+    np.savez_compressed(os.path.join(GOLD, "generator128.npz"), x_head=x3[0, 0, 0, :4].numpy(), out=out_r3.numpy(),
+                        psnr=np.array(m_r[0], dtype=np.float64), ssim=np.array(m_r[1], dtype=np.float64), rmse=np.array(m_r[2], dtype=np.float64))
+
     # ------------------------------------------------------------------ 3. Discriminator fwd (eval, train) + bwd
     print("discriminator")
     dstate = orc.seeded_fill(dshapes, seed=9)

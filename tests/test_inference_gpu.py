@@ -1,0 +1,98 @@
+"""Whole-slice generator inference (reference engine.py:78-183) and the pixel metrics (metrics.py:172-244) on the HIP
+path against the CPU oracle and the golden vectors generated from the reference."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import mtdgan_oracle as orc  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+pytestmark = pytest.mark.gpu
+
+
+def _generator():
+    from mtd_gan_amd.arch.Ours.networks import ResFFT_Generator
+    g = orc.seeded_fill(orc.g_param_shapes(), seed=7)
+    G = ResFFT_Generator(1, 32, 10, 3, 1)
+    G.load_state_dict(g)
+    return G.cuda().eval(), g
+
+
+def test_whole_slice_128_matches_reference_golden(hip_lib):
+    from mtd_gan_amd import metrics as M
+    z = np.load(os.path.join(GOLD, "generator128.npz"))
+    G, _ = _generator()
+    x, y = orc.synthetic_ldct(1, seed=77, size=128)
+    assert np.allclose(x[0, 0, 0, :4].numpy(), z["x_head"])
+    with torch.no_grad():
+        out = G(x.cuda())
+    ref = torch.from_numpy(z["out"])
+    assert (out.cpu() - ref).abs().max().item() / ref.abs().max().item() < 1e-3           # north_star: 1e-3 rel fp32
+    pred = out.clip(0, 1)
+    psnr = M.compute_PSNR(x.cuda(), y.cuda(), pred)
+    ssim = M.compute_SSIM(x.cuda(), y.cuda(), pred)
+    rmse = M.compute_RMSE(x.cuda(), y.cuda(), pred)
+    for got, want in zip(psnr, z["psnr"]):
+        assert abs(got - want) < 0.01, (psnr, z["psnr"])                                   # PSNR within 0.01 dB
+    assert np.allclose(ssim, z["ssim"], atol=2e-5), (ssim, z["ssim"])
+    assert np.allclose(rmse, z["rmse"], rtol=1e-4, atol=1e-7), (rmse, z["rmse"])
+
+
+@pytest.mark.parametrize("S,B", [(256, 2), (512, 1)])
+def test_whole_slice_matches_oracle(hip_lib, S, B):
+    G, g = _generator()
+    x, y = orc.synthetic_ldct(B, seed=5, size=S)
+    ref = orc.generator_forward(g, x)
+    with torch.no_grad():
+        out = G(x.cuda())
+    assert tuple(out.shape) == (B, 1, S, S)
+    assert (out.cpu() - ref).abs().max().item() / ref.abs().max().item() < 1e-3
+    assert abs(orc.psnr(out.cpu().clip(0, 1), y).item() - orc.psnr(ref.clip(0, 1), y).item()) < 0.01
+
+
+def test_large_maps_are_inference_only(hip_lib):
+    G, _ = _generator()
+    x, _ = orc.synthetic_ldct(1, seed=5, size=128)
+    with pytest.raises(NotImplementedError):
+        G(x.cuda())                               # grad mode on, parameters require grad
+    with pytest.raises(NotImplementedError), torch.no_grad():
+        G(torch.zeros(1, 1, 96, 96, device="cuda"))
+
+
+@pytest.mark.parametrize("shape", [(3, 1, 64, 64), (2, 1, 100, 77), (1, 1, 512, 512)])
+def test_pixel_metrics_match_oracle(hip_lib, shape):
+    from mtd_gan_amd import metrics as M
+    g = torch.Generator().manual_seed(11)
+    y = torch.rand(shape, generator=g)
+    x = (y + 0.1 * torch.randn(shape, generator=g)).clip(0, 1)
+    p = y + 0.03 * torch.randn(shape, generator=g)            # un-clipped prediction
+    pm = M.pixel_metrics(x.cuda(), y.cuda(), p.clip(0, 1).cuda())
+    for i, a in enumerate((x, y, p.clip(0, 1))):
+        assert abs(pm["psnr"][i] - orc.psnr(a, y).item()) < 0.01
+        assert abs(pm["ssim"][i] - orc.ssim(a, y).item()) < 2e-5
+        assert abs(pm["rmse"][i] - orc.rmse(a, y).item()) < 1e-6
+    assert pm["ssim"][1] == pytest.approx(1.0, abs=1e-6) and pm["rmse"][1] == 0.0
+
+
+def test_eval_loops_mirror_reference_surface(hip_lib, tmp_path):
+    from mtd_gan_amd import engine
+    from mtd_gan_amd.arch.Ours.networks import MTD_GAN_Method
+    torch.manual_seed(3)
+    m = MTD_GAN_Method().cuda()
+    g = orc.seeded_fill(orc.g_param_shapes(), seed=7)
+    m.Generator.load_state_dict(g)
+    x, y = orc.synthetic_ldct(1, seed=9, size=128)
+    loader = [dict(n_20=x, n_100=y, path_n_20=["L000_0001.dcm"], path_n_100=["L000_0001.dcm"])]
+    v = engine.valid_MTD_GAN_Ours(m, torch.nn.L1Loss(), loader, torch.device("cuda"), 0, None, 1)
+    ref = orc.generator_forward(g, x)
+    assert abs(v["L1_loss"] - (ref - y).abs().mean().item()) < 1e-5
+    t = engine.test_MTD_GAN_Ours(m, torch.nn.L1Loss(), loader, torch.device("cuda"), str(tmp_path))
+    assert abs(t["pred_psnr"] - orc.psnr(ref.clip(0, 1), y).item()) < 0.01
+    assert abs(t["pred_ssim"] - orc.ssim(ref.clip(0, 1), y).item()) < 2e-5
+    assert abs(t["input_rmse"] - orc.rmse(x, y).item()) < 1e-6
+    assert os.path.exists(os.path.join(str(tmp_path), "pred_results.csv"))

@@ -110,3 +110,19 @@ def test_full_step_matches_reference_vectors():
             assert abs(t[idx].item() - s) <= 1e-5 * abs(s) + 1e-8, (k, i)
     assert torch.equal(full["Discriminator.c_fc.weight_orig"],
                        orc.seeded_fill(orc.d_state_shapes(), seed=z["dfill"])["c_fc.weight_orig"])   # frozen (quirk 1)
+
+
+def test_whole_slice_generator_and_pixel_metrics_golden():
+    """Whole-slice inference (engine.py:89,129) and metrics.py:172-244 of the oracle against the vectors generated from the reference."""
+    z = np.load(os.path.join(GOLD, "generator128.npz"))
+    g = orc.seeded_fill(orc.g_param_shapes(), seed=7)
+    x, y = orc.synthetic_ldct(1, seed=77, size=128)
+    assert np.allclose(x[0, 0, 0, :4].numpy(), z["x_head"])
+    with torch.no_grad():
+        out = orc.generator_forward(g, x)
+    assert np.abs(out.numpy() - z["out"]).max() < 2e-6
+    pred = out.clip(0, 1)
+    for i, a in enumerate((x, y, pred)):
+        assert abs(orc.psnr(a, y).item() - z["psnr"][i]) < 1e-4
+        assert abs(orc.ssim(a, y).item() - z["ssim"][i]) < 1e-5
+        assert abs(orc.rmse(a, y).item() - z["rmse"][i]) < 1e-6
