@@ -14,19 +14,33 @@ namespace {
 
 __device__ __forceinline__ int brev_n(int k, int logS) { return (int)(__brev((unsigned)k) >> (32 - logS)); }
 
-// in-place radix-2 FFT of re/im[S][32]; every thread of the workgroup takes part
+// twiddle table exp(-i * pi * k / (S/2)), k = 0 .. S/2-1, written once per workgroup (cos | sin)
+__device__ __forceinline__ void fill_twiddles(float* tw, int S) {
+    const int half = S >> 1;
+    const float inv = 1.f / (float)half;
+    for (int k = threadIdx.x; k < half; k += blockDim.x) {
+        float sn, cs;
+        sincospif((float)k * inv, &sn, &cs);
+        tw[k] = cs;
+        tw[half + k] = sn;
+    }
+}
+
+// in-place radix-2 FFT of re/im[S][32]; every thread of the workgroup takes part.  SIGN -1: forward, +1: inverse.
 template <int SIGN, bool DIF>
-__device__ __forceinline__ void lds_fft(float* re, float* im, int S, int logS) {
+__device__ __forceinline__ void lds_fft(float* re, float* im, const float* tw, int S, int logS) {
     const int nbf = (S >> 1) * 32;                    // butterflies per stage (pair index x channel)
+    const int hS = S >> 1;
     for (int st = 0; st < logS; ++st) {
-        const int half = DIF ? (S >> (st + 1)) : (1 << st);
-        const float inv_half = 1.f / (float)half;
+        const int lh = DIF ? (logS - 1 - st) : st;    // log2 of the half-span of this stage
+        const int half = 1 << lh;
+        const int tshift = logS - 1 - lh;             // twiddle index = j * S / (2 * half)
         for (int e = threadIdx.x; e < nbf; e += blockDim.x) {
             const int c = e & 31, pidx = e >> 5;
-            const int grp = pidx / half, j = pidx - grp * half;
-            const int i0 = (grp * 2 * half + j) * 32 + c, i1 = i0 + half * 32;
-            float sn, cs;
-            sincospif((float)(SIGN * j) * inv_half, &sn, &cs);      // exp(SIGN * i * pi * j / half)
+            const int grp = pidx >> lh, j = pidx & (half - 1);
+            const int i0 = (((grp << 1) << lh) + j) * 32 + c, i1 = i0 + half * 32;
+            const float cs = tw[j << tshift];
+            const float sn = (SIGN < 0) ? -tw[hS + (j << tshift)] : tw[hS + (j << tshift)];
             const float ur = re[i0], ui = im[i0], vr = re[i1], vi = im[i1];
             if (DIF) {
                 const float dr = ur - vr, di = ui - vi;
@@ -47,22 +61,24 @@ __device__ __forceinline__ void lds_fft(float* re, float* im, int S, int logS) {
 }
 
 // rows forward: one workgroup per image row (b, h)
-__global__ __launch_bounds__(256) void rfft_rows_any_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ R, int S, int logS) {
+__global__ __launch_bounds__(1024) void rfft_rows_any_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ R, int S, int logS) {
     extern __shared__ float lds[];
     float* re = lds;
     float* im = lds + S * 32;
+    float* tw = lds + S * 64;
+    fill_twiddles(tw, S);
     const int b = blockIdx.x / S, h = blockIdx.x % S;
     const int nkw = S / 2 + 1;
     const float* src = x + ((long long)(b * S + h) * S) * x_ld;
-    for (int e = threadIdx.x; e < S * 32; e += 256) {
+    for (int e = threadIdx.x; e < S * 32; e += blockDim.x) {
         const int c = e & 31, w = e >> 5;
         re[e] = src[(long long)w * x_ld + c];
         im[e] = 0.f;
     }
     __syncthreads();
-    lds_fft<-1, true>(re, im, S, logS);
+    lds_fft<-1, true>(re, im, tw, S, logS);
     const float sc = rsqrtf((float)S);
-    for (int e = threadIdx.x; e < nkw * 32; e += 256) {
+    for (int e = threadIdx.x; e < nkw * 32; e += blockDim.x) {
         const int c = e & 31, kw = e >> 5;
         const int pos = brev_n(kw, logS) * 32 + c;
         float* o = R + (((long long)(b * nkw + kw) * S + h) * 64) + c;
@@ -72,29 +88,31 @@ __global__ __launch_bounds__(256) void rfft_rows_any_kernel(const float* __restr
 }
 
 // columns + channel mix + columns back: one workgroup per (b, kw)
-__global__ __launch_bounds__(256) void spec_mix_any_kernel(const float* __restrict__ R, const float* __restrict__ w2t,
+__global__ __launch_bounds__(1024) void spec_mix_any_kernel(const float* __restrict__ R, const float* __restrict__ w2t,
                                                            const float* __restrict__ b2, float* __restrict__ T, int S, int logS) {
     extern __shared__ float lds[];
     float* re = lds;
     float* im = lds + S * 32;
+    float* tw = lds + S * 64;
+    fill_twiddles(tw, S);
     const long long colbase = (long long)blockIdx.x * S * 64;
-    for (int e = threadIdx.x; e < S * 32; e += 256) {
+    for (int e = threadIdx.x; e < S * 32; e += blockDim.x) {
         const int c = e & 31, h = e >> 5;
         re[e] = R[colbase + (long long)h * 64 + c];
         im[e] = R[colbase + (long long)h * 64 + 32 + c];
     }
     __syncthreads();
-    lds_fft<-1, true>(re, im, S, logS);
+    lds_fft<-1, true>(re, im, tw, S, logS);
     // channel mix at every frequency (order of the frequencies is irrelevant): lane = output channel o, its 64 weights in
     // registers; a wave owns whole rows, reads all 64 inputs of a row (broadcast reads) before it writes the 64 outputs
     {
-        const int o = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int o = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
         float wreg[64];
 #pragma unroll
         for (int k = 0; k < 64; ++k) wreg[k] = w2t[k * 64 + o];
         const float bo = b2[o];
         const float sc = rsqrtf((float)S);
-        for (int n = wv; n < S; n += 4) {
+        for (int n = wv; n < S; n += nwv) {
             float acc = 0.f;
 #pragma unroll
             for (int k = 0; k < 32; ++k) acc = fmaf(re[n * 32 + k], wreg[k], acc);
@@ -107,9 +125,9 @@ __global__ __launch_bounds__(256) void spec_mix_any_kernel(const float* __restri
         }
     }
     __syncthreads();
-    lds_fft<+1, false>(re, im, S, logS);
+    lds_fft<+1, false>(re, im, tw, S, logS);
     const float sc = rsqrtf((float)S);
-    for (int e = threadIdx.x; e < S * 32; e += 256) {
+    for (int e = threadIdx.x; e < S * 32; e += blockDim.x) {
         const int c = e & 31, h = e >> 5;
         T[colbase + (long long)h * 64 + c] = re[e] * sc;
         T[colbase + (long long)h * 64 + 32 + c] = im[e] * sc;
@@ -117,16 +135,18 @@ __global__ __launch_bounds__(256) void spec_mix_any_kernel(const float* __restri
 }
 
 // rows back (c2r): one workgroup per image row; out = y + add1 + add2
-__global__ __launch_bounds__(256) void irfft_rows_any_kernel(const float* __restrict__ T, float* __restrict__ out, int out_ld,
+__global__ __launch_bounds__(1024) void irfft_rows_any_kernel(const float* __restrict__ T, float* __restrict__ out, int out_ld,
                                                              const float* __restrict__ add1, int add1_ld,
                                                              const float* __restrict__ add2, int add2_ld, int S, int logS) {
     extern __shared__ float lds[];
     float* re = lds;
     float* im = lds + S * 32;
+    float* tw = lds + S * 64;
+    fill_twiddles(tw, S);
     const int b = blockIdx.x / S, h = blockIdx.x % S;
     const int nkw = S / 2 + 1;
     // Hermitian extension of the half spectrum; the imaginary parts of columns 0 and S/2 are ignored (as torch's c2r does)
-    for (int e = threadIdx.x; e < nkw * 32; e += 256) {
+    for (int e = threadIdx.x; e < nkw * 32; e += blockDim.x) {
         const int c = e & 31, kw = e >> 5;
         const float* t = T + (((long long)(b * nkw + kw) * S + h) * 64) + c;
         const float xr = t[0];
@@ -141,10 +161,10 @@ __global__ __launch_bounds__(256) void irfft_rows_any_kernel(const float* __rest
         }
     }
     __syncthreads();
-    lds_fft<+1, false>(re, im, S, logS);
+    lds_fft<+1, false>(re, im, tw, S, logS);
     const float sc = rsqrtf((float)S);
     const long long rowpix = (long long)(b * S + h) * S;
-    for (int e = threadIdx.x; e < S * 32; e += 256) {
+    for (int e = threadIdx.x; e < S * 32; e += blockDim.x) {
         const int c = e & 31, w = e >> 5;
         float v = re[e] * sc;
         if (add1) v += add1[(rowpix + w) * add1_ld + c];
@@ -171,10 +191,10 @@ int set_lds(K kernel, size_t bytes) {
 extern "C" int mtd_rfft_rows_any(const float* x, int x_ld, float* R, int B, int S, void* stream) {
     const int logS = log2_exact(S);
     if (!x || !R || B <= 0 || logS < 6 || S > 512 || x_ld < 32) return MTD_EINVAL;
-    const size_t lds = (size_t)S * 256;
+    const size_t lds = (size_t)S * 256 + (size_t)S * 4;
     int rc = set_lds(rfft_rows_any_kernel, lds);
     if (rc != MTD_OK) return rc;
-    hipLaunchKernelGGL(rfft_rows_any_kernel, dim3(B * S), dim3(256), lds, (hipStream_t)stream, x, x_ld, R, S, logS);
+    hipLaunchKernelGGL(rfft_rows_any_kernel, dim3(B * S), dim3(1024), lds, (hipStream_t)stream, x, x_ld, R, S, logS);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }
@@ -182,10 +202,10 @@ extern "C" int mtd_rfft_rows_any(const float* x, int x_ld, float* R, int B, int 
 extern "C" int mtd_spec_mix_any(const float* R, const float* w2t, const float* b2, float* T, int B, int S, void* stream) {
     const int logS = log2_exact(S);
     if (!R || !w2t || !b2 || !T || B <= 0 || logS < 6 || S > 512) return MTD_EINVAL;
-    const size_t lds = (size_t)S * 256;
+    const size_t lds = (size_t)S * 256 + (size_t)S * 4;
     int rc = set_lds(spec_mix_any_kernel, lds);
     if (rc != MTD_OK) return rc;
-    hipLaunchKernelGGL(spec_mix_any_kernel, dim3(B * (S / 2 + 1)), dim3(256), lds, (hipStream_t)stream, R, w2t, b2, T, S, logS);
+    hipLaunchKernelGGL(spec_mix_any_kernel, dim3(B * (S / 2 + 1)), dim3(1024), lds, (hipStream_t)stream, R, w2t, b2, T, S, logS);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }
@@ -195,10 +215,10 @@ extern "C" int mtd_irfft_rows_any(const float* T, float* out, int out_ld, const 
     const int logS = log2_exact(S);
     if (!T || !out || B <= 0 || logS < 6 || S > 512 || out_ld < 32) return MTD_EINVAL;
     if ((add1 && add1_ld < 32) || (add2 && add2_ld < 32)) return MTD_EINVAL;
-    const size_t lds = (size_t)S * 256;
+    const size_t lds = (size_t)S * 256 + (size_t)S * 4;
     int rc = set_lds(irfft_rows_any_kernel, lds);
     if (rc != MTD_OK) return rc;
-    hipLaunchKernelGGL(irfft_rows_any_kernel, dim3(B * S), dim3(256), lds, (hipStream_t)stream, T, out, out_ld, add1, add1_ld, add2,
+    hipLaunchKernelGGL(irfft_rows_any_kernel, dim3(B * S), dim3(1024), lds, (hipStream_t)stream, T, out, out_ld, add1, add1_ld, add2,
                        add2_ld, S, logS);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
