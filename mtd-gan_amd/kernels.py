@@ -15,12 +15,21 @@ _pack_cache = {}
 _pack_epoch = 0
 
 
-def weights_changed():
-    """Called by the optimizers after they update parameters through raw pointers (the tensors' version
-    counters do not move): drops every packed weight view."""
+def weights_changed(params=None):
+    """Called by the optimizers after they update parameters through raw pointers (the tensors' version counters do
+    not move): drops the packed views of those parameters (of every parameter when params is None) and bumps the
+    `_mtd_epoch` stamp that caches of derived quantities (train_step: the generator tape) compare."""
     global _pack_epoch
-    _pack_epoch += 1
-    _pack_cache.clear()
+    if params is None:
+        _pack_epoch += 1
+        _pack_cache.clear()
+        return
+    stor = set()
+    for p in params:
+        stor.add(p.untyped_storage().data_ptr())
+        p._mtd_epoch = getattr(p, "_mtd_epoch", 0) + 1
+    for key in [k for k, (_dst, w) in _pack_cache.items() if w.untyped_storage().data_ptr() in stor]:
+        del _pack_cache[key]
 
 
 def prepack(views):

@@ -70,7 +70,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 K.adamw_multi_dyn([i[0] for i in items], [i[1] for i in items], [i[2] for i in items], [i[3] for i in items],
                                   b1, b2, group["eps"], slot.device_ptr())
                 slot.consumed()
-        K.weights_changed()          # parameters were updated through raw pointers: packed weight views are stale
+        # parameters were updated through raw pointers: their packed weight views (and only theirs) are stale
+        K.weights_changed([p for group in self.param_groups for p in group["params"] if p.grad is not None])
 
 
 def get_optimizer(name, model, lr):

@@ -162,9 +162,16 @@ def d_loss(method, x, y):
     if not x.is_cuda:
         raise RuntimeError("MTD_GAN_Method.d_loss: HIP path needs CUDA tensors")
     B, dev = x.shape[0], x.device
-    with torch.no_grad():
-        fake = G(x)                                       # networks.py:1958 (.detach())
-    xn, yn, fn = _nhwc1(x.float()), _nhwc1(y.float()), _nhwc1(fake)
+    from .arch.Ours import networks as N
+    xn, yn = _nhwc1(x.float()), _nhwc1(y.float())
+    # networks.py:1958 (.detach()).  The generator step that follows runs G on the same x with the same weights
+    # (engine.py:38-55 updates G only after it), so this forward also records the tape that step needs: G runs once
+    # per iteration (the "sufficient work" count of SURVEY 8d), bit-identical to recomputing it.
+    gflat = G._flat_params()
+    GPm = N._unflatten_gen(gflat, G._cfg[2])
+    keep = torch.is_grad_enabled() and any(p.requires_grad for p in gflat)
+    fn, gtape = GP.generator_forward(xn, GPm, keep)
+    method._gcache = (_gkey(x, gflat), fn, gtape, GPm) if keep else None
     P = D._param_dict()
     train = D.training
     (re, rd, rr), t1 = DP.disc_forward(P, yn, train, D._next_mask(B, dev), True, True)
@@ -186,6 +193,13 @@ def d_loss(method, x, y):
     return losses, details
 
 
+def _gkey(x, gparams):
+    """Identity of a generator forward: the input tensor (storage, shape, version) and every parameter's storage and
+    modification stamps (autograd version for in-place torch updates, _mtd_epoch for FusedAdamW's raw-pointer updates)."""
+    return (x.data_ptr(), tuple(x.shape), x._version,
+            tuple((p.data_ptr(), p._version, getattr(p, "_mtd_epoch", 0)) for p in gparams))
+
+
 # ================================================================================================ G step
 class _GStepFn(torch.autograd.Function):
     @staticmethod
@@ -196,7 +210,11 @@ class _GStepFn(torch.autograd.Function):
         xn, yn = _nhwc1(x.float()), _nhwc1(y.float())
         GPm = N._unflatten_gen(gparams, nlayers)
         need = any(ctx.needs_input_grad)
-        fake, gtape = GP.generator_forward(xn, GPm, need)
+        cache, method._gcache = getattr(method, "_gcache", None), None
+        if need and cache is not None and cache[0] == _gkey(x, gparams):
+            _, fake, gtape, GPm = cache                      # same input, same weights: the D step's forward and its tape
+        else:
+            fake, gtape = GP.generator_forward(xn, GPm, need)
         P = D._param_dict()
         (ge, gd, _), dtape = DP.disc_forward(P, fake, D.training, D._next_mask(B, dev), False, need)
         n = B * NPIX
@@ -265,6 +283,8 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         K.CAPTURE_TAG += 1
+        K.weights_changed(None)      # packed weight views made by eager steps must not be baked into the graph: the captured step packs its own
+        model._gcache = None
         g = torch.cuda.CUDAGraph()
         rs = random.getstate()
         _pending_orders.append(shuffle_orders(3))        # placeholder order for the capture (capture executes nothing)
