@@ -60,30 +60,35 @@ __device__ __forceinline__ void lds_fft(float* re, float* im, const float* tw, i
     }
 }
 
-// rows forward: one workgroup per image row (b, h)
+// rows forward: one workgroup per PAIR of image rows (b, h), (b, h + 1): the two real rows are the real and imaginary
+// part of one complex transform Z; X_h[k] = (Z[k] + conj Z[-k]) / 2, X_{h+1}[k] = (Z[k] - conj Z[-k]) / 2i
 __global__ __launch_bounds__(1024) void rfft_rows_any_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ R, int S, int logS) {
     extern __shared__ float lds[];
     float* re = lds;
     float* im = lds + S * 32;
     float* tw = lds + S * 64;
     fill_twiddles(tw, S);
-    const int b = blockIdx.x / S, h = blockIdx.x % S;
+    const int hp = S >> 1;
+    const int b = blockIdx.x / hp, h = (blockIdx.x % hp) * 2;
     const int nkw = S / 2 + 1;
     const float* src = x + ((long long)(b * S + h) * S) * x_ld;
     for (int e = threadIdx.x; e < S * 32; e += blockDim.x) {
         const int c = e & 31, w = e >> 5;
         re[e] = src[(long long)w * x_ld + c];
-        im[e] = 0.f;
+        im[e] = src[(long long)(S + w) * x_ld + c];
     }
     __syncthreads();
     lds_fft<-1, true>(re, im, tw, S, logS);
-    const float sc = rsqrtf((float)S);
+    const float sc = 0.5f * rsqrtf((float)S);
     for (int e = threadIdx.x; e < nkw * 32; e += blockDim.x) {
         const int c = e & 31, kw = e >> 5;
-        const int pos = brev_n(kw, logS) * 32 + c;
+        const int pk = brev_n(kw, logS) * 32 + c, pm = brev_n((S - kw) & (S - 1), logS) * 32 + c;
+        const float zkr = re[pk], zki = im[pk], zmr = re[pm], zmi = im[pm];
         float* o = R + (((long long)(b * nkw + kw) * S + h) * 64) + c;
-        o[0] = re[pos] * sc;
-        o[32] = im[pos] * sc;
+        o[0] = (zkr + zmr) * sc;
+        o[32] = (zki - zmi) * sc;
+        o[64] = (zki + zmi) * sc;
+        o[64 + 32] = (zmr - zkr) * sc;
     }
 }
 
@@ -134,30 +139,33 @@ __global__ __launch_bounds__(1024) void spec_mix_any_kernel(const float* __restr
     }
 }
 
-// rows back (c2r): one workgroup per image row; out = y + add1 + add2
+// rows back (c2r): one workgroup per pair of image rows; out = y + add1 + add2.  With A = X_h, B = X_{h+1} (Hermitian,
+// the imaginary parts of columns 0 and S/2 ignored as torch's c2r does) the complex spectrum Z = A + iB transforms
+// back to row h in the real part and row h + 1 in the imaginary part.
 __global__ __launch_bounds__(1024) void irfft_rows_any_kernel(const float* __restrict__ T, float* __restrict__ out, int out_ld,
-                                                             const float* __restrict__ add1, int add1_ld,
-                                                             const float* __restrict__ add2, int add2_ld, int S, int logS) {
+                                                              const float* __restrict__ add1, int add1_ld,
+                                                              const float* __restrict__ add2, int add2_ld, int S, int logS) {
     extern __shared__ float lds[];
     float* re = lds;
     float* im = lds + S * 32;
     float* tw = lds + S * 64;
     fill_twiddles(tw, S);
-    const int b = blockIdx.x / S, h = blockIdx.x % S;
+    const int hp = S >> 1;
+    const int b = blockIdx.x / hp, h = (blockIdx.x % hp) * 2;
     const int nkw = S / 2 + 1;
-    // Hermitian extension of the half spectrum; the imaginary parts of columns 0 and S/2 are ignored (as torch's c2r does)
     for (int e = threadIdx.x; e < nkw * 32; e += blockDim.x) {
         const int c = e & 31, kw = e >> 5;
         const float* t = T + (((long long)(b * nkw + kw) * S + h) * 64) + c;
-        const float xr = t[0];
-        const float xi = (kw == 0 || kw == S / 2) ? 0.f : t[32];
+        const bool edge = (kw == 0 || kw == S / 2);
+        const float ar = t[0], ai = edge ? 0.f : t[32];
+        const float br = t[64], bi = edge ? 0.f : t[64 + 32];
         const int p0 = brev_n(kw, logS) * 32 + c;
-        re[p0] = xr;
-        im[p0] = xi;
-        if (kw != 0 && kw != S / 2) {
-            const int p1 = brev_n(S - kw, logS) * 32 + c;
-            re[p1] = xr;
-            im[p1] = -xi;
+        re[p0] = ar - bi;
+        im[p0] = ai + br;
+        if (!edge) {
+            const int p1 = brev_n(S - kw, logS) * 32 + c;       // Z[S-k] = conj(A[k]) + i conj(B[k])
+            re[p1] = ar + bi;
+            im[p1] = br - ai;
         }
     }
     __syncthreads();
@@ -166,10 +174,11 @@ __global__ __launch_bounds__(1024) void irfft_rows_any_kernel(const float* __res
     const long long rowpix = (long long)(b * S + h) * S;
     for (int e = threadIdx.x; e < S * 32; e += blockDim.x) {
         const int c = e & 31, w = e >> 5;
-        float v = re[e] * sc;
-        if (add1) v += add1[(rowpix + w) * add1_ld + c];
-        if (add2) v += add2[(rowpix + w) * add2_ld + c];
-        out[(rowpix + w) * out_ld + c] = v;
+        float v0 = re[e] * sc, v1 = im[e] * sc;
+        if (add1) { v0 += add1[(rowpix + w) * add1_ld + c]; v1 += add1[(rowpix + S + w) * add1_ld + c]; }
+        if (add2) { v0 += add2[(rowpix + w) * add2_ld + c]; v1 += add2[(rowpix + S + w) * add2_ld + c]; }
+        out[(rowpix + w) * out_ld + c] = v0;
+        out[(rowpix + S + w) * out_ld + c] = v1;
     }
 }
 
@@ -194,7 +203,7 @@ extern "C" int mtd_rfft_rows_any(const float* x, int x_ld, float* R, int B, int 
     const size_t lds = (size_t)S * 256 + (size_t)S * 4;
     int rc = set_lds(rfft_rows_any_kernel, lds);
     if (rc != MTD_OK) return rc;
-    hipLaunchKernelGGL(rfft_rows_any_kernel, dim3(B * S), dim3(1024), lds, (hipStream_t)stream, x, x_ld, R, S, logS);
+    hipLaunchKernelGGL(rfft_rows_any_kernel, dim3(B * S / 2), dim3(1024), lds, (hipStream_t)stream, x, x_ld, R, S, logS);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }
@@ -218,7 +227,7 @@ extern "C" int mtd_irfft_rows_any(const float* T, float* out, int out_ld, const 
     const size_t lds = (size_t)S * 256 + (size_t)S * 4;
     int rc = set_lds(irfft_rows_any_kernel, lds);
     if (rc != MTD_OK) return rc;
-    hipLaunchKernelGGL(irfft_rows_any_kernel, dim3(B * S), dim3(1024), lds, (hipStream_t)stream, T, out, out_ld, add1, add1_ld, add2,
+    hipLaunchKernelGGL(irfft_rows_any_kernel, dim3(B * S / 2), dim3(1024), lds, (hipStream_t)stream, T, out, out_ld, add1, add1_ld, add2,
                        add2_ld, S, logS);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
