@@ -196,7 +196,8 @@ def main():
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             top = sorted(d["shapes"].items(), key=lambda kv: -kv[1][0])[:4]
             roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(name),
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                        "traffic": pmc_traffic(name) if wl.name == "full_step" else None,   # the committed PMC passes profile the default workload
                         "launches_timed": d["n"], "avg_launch_us": round(1e3 * d["ms"] / d["n"], 2),
                         "avg_launch_us_with_event_pair": round(1e3 * raw_ms / d["n"], 2), "event_pair_us": round(1e3 * ev_over_ms, 2),
                         "flops_per_launch": round(d["flops"] / d["n"]),
