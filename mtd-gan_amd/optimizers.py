@@ -16,6 +16,17 @@ class FusedAdamW(torch.optim.Optimizer):
         self._dyn = {}            # (group index, launch index) -> HostScalars with (decay, step_size, 1/sqrt(bc2))
         self._captured = []       # launches of the last step(): (HostScalars, group index, parameters)
 
+    def load_state_dict(self, state_dict):
+        """Accepts the optimizer section of a reference checkpoint (train.py:146-159 saves torch.optim.AdamW's state
+        dict; its `step` entries are 0-d tensors since torch 1.12): steps become Python ints, moments stay tensors."""
+        super().load_state_dict(state_dict)
+        for st in self.state.values():
+            if torch.is_tensor(st.get("step")):
+                st["step"] = int(st["step"].item())
+        for group in self.param_groups:                      # torch.optim.AdamW-only switches of a reference checkpoint
+            if group.get("amsgrad") or group.get("maximize"):
+                raise NotImplementedError("FusedAdamW implements the reference's configuration (no amsgrad, no maximize)")
+
     @staticmethod
     def _scalars(group, step):
         b1, b2 = group["betas"]

@@ -62,3 +62,23 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert "mtdgan_oracle" not in src and "import oracle" not in src, os.path.join(dp, f)
+
+
+def test_fused_adamw_loads_reference_optimizer_checkpoint():
+    """train.py:146-159 checkpoints torch.optim.AdamW state; FusedAdamW must resume from it (host-side conversion only)."""
+    import torch
+    from mtd_gan_amd.optimizers import FusedAdamW
+    w = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(5))]
+    ref = torch.optim.AdamW(w, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+    for p in w:
+        p.grad = torch.randn_like(p)
+    ref.step()
+    ref.step()
+    sd = ref.state_dict()
+    mine = FusedAdamW(w, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+    mine.load_state_dict(sd)
+    for p in w:
+        st = mine.state[p]
+        assert st["step"] == 2 and isinstance(st["step"], int)
+        assert torch.equal(st["exp_avg"], ref.state[p]["exp_avg"]) and torch.equal(st["exp_avg_sq"], ref.state[p]["exp_avg_sq"])
+    assert mine.param_groups[0]["lr"] == 1e-4 and mine.param_groups[0]["weight_decay"] == 5e-4
