@@ -27,6 +27,15 @@ class FusedAdamW(torch.optim.Optimizer):
             if group.get("amsgrad") or group.get("maximize"):
                 raise NotImplementedError("FusedAdamW implements the reference's configuration (no amsgrad, no maximize)")
 
+    def state_dict(self):
+        """Same layout as torch.optim.AdamW's (train.py:276-288 saves it): `step` leaves as a 0-d float tensor, so that a
+        checkpoint written with this optimizer resumes under the reference's torch.optim.AdamW as well."""
+        sd = super().state_dict()
+        for st in sd["state"].values():
+            if isinstance(st.get("step"), int):
+                st["step"] = torch.tensor(float(st["step"]))
+        return sd
+
     @staticmethod
     def _scalars(group, step):
         b1, b2 = group["betas"]

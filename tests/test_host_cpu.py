@@ -82,3 +82,9 @@ def test_fused_adamw_loads_reference_optimizer_checkpoint():
         assert st["step"] == 2 and isinstance(st["step"], int)
         assert torch.equal(st["exp_avg"], ref.state[p]["exp_avg"]) and torch.equal(st["exp_avg_sq"], ref.state[p]["exp_avg_sq"])
     assert mine.param_groups[0]["lr"] == 1e-4 and mine.param_groups[0]["weight_decay"] == 5e-4
+    # and back: a checkpoint written by FusedAdamW resumes under torch.optim.AdamW (reference train.py:146-159)
+    back = torch.optim.AdamW(w, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+    back.load_state_dict(mine.state_dict())
+    back.step()
+    assert int(back.state[w[0]]["step"]) == 3
+    assert isinstance(mine.state[w[0]]["step"], int)          # exporting did not disturb the live state
