@@ -31,9 +31,13 @@ class FusedAdamW(torch.optim.Optimizer):
         """Same layout as torch.optim.AdamW's (train.py:276-288 saves it): `step` leaves as a 0-d float tensor, so that a
         checkpoint written with this optimizer resumes under the reference's torch.optim.AdamW as well."""
         sd = super().state_dict()
-        for st in sd["state"].values():
+        state = {}
+        for k, st in sd["state"].items():                     # the packed entries alias the live state: copy before editing
+            st = dict(st)
             if isinstance(st.get("step"), int):
                 st["step"] = torch.tensor(float(st["step"]))
+            state[k] = st
+        sd["state"] = state
         return sd
 
     @staticmethod
