@@ -26,34 +26,92 @@ __device__ __forceinline__ void fill_twiddles(float* tw, int S) {
     }
 }
 
-// in-place radix-2 FFT of re/im[S][32]; every thread of the workgroup takes part.  SIGN -1: forward, +1: inverse.
+// in-place FFT of re/im[S][32]; every thread of the workgroup takes part.  SIGN -1: forward, +1: inverse.
+// Two radix-2 stages are fused per pass over LDS (four points in registers: half the LDS traffic and half the barriers
+// of a stage-by-stage radix-2); an odd log2(S) leaves one single stage.
+template <int SIGN>
+__device__ __forceinline__ void twiddle(const float* tw, int hS, int idx, float& cs, float& sn) {
+    cs = tw[idx];
+    sn = (SIGN < 0) ? -tw[hS + idx] : tw[hS + idx];
+}
+
 template <int SIGN, bool DIF>
 __device__ __forceinline__ void lds_fft(float* re, float* im, const float* tw, int S, int logS) {
-    const int nbf = (S >> 1) * 32;                    // butterflies per stage (pair index x channel)
     const int hS = S >> 1;
-    for (int st = 0; st < logS; ++st) {
-        const int lh = DIF ? (logS - 1 - st) : st;    // log2 of the half-span of this stage
-        const int half = 1 << lh;
-        const int tshift = logS - 1 - lh;             // twiddle index = j * S / (2 * half)
-        for (int e = threadIdx.x; e < nbf; e += blockDim.x) {
+    int st = 0;
+    // single radix-2 stage when log2(S) is odd: the first stage for DIF (half = S/2), the first for DIT (half = 1)
+    if (logS & 1) {
+        const int lh = DIF ? (logS - 1) : 0;
+        const int half = 1 << lh, tshift = logS - 1 - lh;
+        for (int e = threadIdx.x; e < hS * 32; e += blockDim.x) {
             const int c = e & 31, pidx = e >> 5;
             const int grp = pidx >> lh, j = pidx & (half - 1);
             const int i0 = (((grp << 1) << lh) + j) * 32 + c, i1 = i0 + half * 32;
-            const float cs = tw[j << tshift];
-            const float sn = (SIGN < 0) ? -tw[hS + (j << tshift)] : tw[hS + (j << tshift)];
+            float cs, sn;
+            twiddle<SIGN>(tw, hS, j << tshift, cs, sn);
             const float ur = re[i0], ui = im[i0], vr = re[i1], vi = im[i1];
             if (DIF) {
                 const float dr = ur - vr, di = ui - vi;
-                re[i0] = ur + vr;
-                im[i0] = ui + vi;
-                re[i1] = dr * cs - di * sn;
-                im[i1] = dr * sn + di * cs;
+                re[i0] = ur + vr; im[i0] = ui + vi;
+                re[i1] = dr * cs - di * sn; im[i1] = dr * sn + di * cs;
             } else {
                 const float wr = vr * cs - vi * sn, wi = vr * sn + vi * cs;
-                re[i0] = ur + wr;
-                im[i0] = ui + wi;
-                re[i1] = ur - wr;
-                im[i1] = ui - wi;
+                re[i0] = ur + wr; im[i0] = ui + wi;
+                re[i1] = ur - wr; im[i1] = ui - wi;
+            }
+        }
+        __syncthreads();
+        st = 1;
+    }
+    const int nq = (S >> 2) * 32;                     // 4-point groups per fused pass (x channel)
+    for (; st < logS; st += 2) {
+        if (DIF) {
+            // stages with half = H and H/2;  points a, b = a + H/2, c = a + H, d = a + 3H/2 of a block of 2H
+            const int lH = logS - 1 - st;             // log2(H)
+            const int H = 1 << lH, Q = H >> 1;
+            const int ts1 = logS - 1 - lH, ts2 = ts1 + 1;
+            for (int e = threadIdx.x; e < nq; e += blockDim.x) {
+                const int c = e & 31, q = e >> 5;
+                const int blk = q >> (lH - 1), j = q & (Q - 1);
+                const int ia = ((blk << (lH + 1)) + j) * 32 + c, ib = ia + Q * 32, ic = ia + H * 32, id = ic + Q * 32;
+                float c1, s1, c2, s2, c3, s3;
+                twiddle<SIGN>(tw, hS, j << ts1, c1, s1);
+                twiddle<SIGN>(tw, hS, (j + Q) << ts1, c2, s2);
+                twiddle<SIGN>(tw, hS, j << ts2, c3, s3);
+                const float ar = re[ia], ai = im[ia], br = re[ib], bi = im[ib], cr = re[ic], ci = im[ic], dr = re[id], di = im[id];
+                const float a1r = ar + cr, a1i = ai + ci, tr = ar - cr, ti = ai - ci;
+                const float c1r = tr * c1 - ti * s1, c1i = tr * s1 + ti * c1;
+                const float b1r = br + dr, b1i = bi + di, ur = br - dr, ui = bi - di;
+                const float d1r = ur * c2 - ui * s2, d1i = ur * s2 + ui * c2;
+                re[ia] = a1r + b1r; im[ia] = a1i + b1i;
+                { const float xr = a1r - b1r, xi = a1i - b1i; re[ib] = xr * c3 - xi * s3; im[ib] = xr * s3 + xi * c3; }
+                re[ic] = c1r + d1r; im[ic] = c1i + d1i;
+                { const float xr = c1r - d1r, xi = c1i - d1i; re[id] = xr * c3 - xi * s3; im[id] = xr * s3 + xi * c3; }
+            }
+        } else {
+            // stages with half = h and 2h;  points a, b = a + h, c = a + 2h, d = a + 3h of a block of 4h
+            const int lh = st;
+            const int h = 1 << lh;
+            const int ts1 = logS - 1 - lh, ts2 = ts1 - 1;
+            for (int e = threadIdx.x; e < nq; e += blockDim.x) {
+                const int c = e & 31, q = e >> 5;
+                const int blk = q >> lh, j = q & (h - 1);
+                const int ia = ((blk << (lh + 2)) + j) * 32 + c, ib = ia + h * 32, ic = ib + h * 32, id = ic + h * 32;
+                float c1, s1, c2, s2, c3, s3;
+                twiddle<SIGN>(tw, hS, j << ts1, c1, s1);
+                twiddle<SIGN>(tw, hS, j << ts2, c2, s2);
+                twiddle<SIGN>(tw, hS, (j + h) << ts2, c3, s3);
+                const float ar = re[ia], ai = im[ia], br = re[ib], bi = im[ib], cr = re[ic], ci = im[ic], dr = re[id], di = im[id];
+                const float bwr = br * c1 - bi * s1, bwi = br * s1 + bi * c1;
+                const float dwr = dr * c1 - di * s1, dwi = dr * s1 + di * c1;
+                const float a1r = ar + bwr, a1i = ai + bwi, b1r = ar - bwr, b1i = ai - bwi;
+                const float c1r = cr + dwr, c1i = ci + dwi, d1r = cr - dwr, d1i = ci - dwi;
+                const float cwr = c1r * c2 - c1i * s2, cwi = c1r * s2 + c1i * c2;
+                const float ewr = d1r * c3 - d1i * s3, ewi = d1r * s3 + d1i * c3;
+                re[ia] = a1r + cwr; im[ia] = a1i + cwi;
+                re[ic] = a1r - cwr; im[ic] = a1i - cwi;
+                re[ib] = b1r + ewr; im[ib] = b1i + ewi;
+                re[id] = b1r - ewr; im[id] = b1i - ewi;
             }
         }
         __syncthreads();
