@@ -74,6 +74,9 @@ typedef struct {
     int act;
     const float* mask; int mask_ld; float mask_slope;  /* v *= (mask>0 ? 1 : mask_slope)  */
     float* ws; size_t ws_bytes;                  /* split-K slabs (see mtd_conv_igemm_ws_bytes) */
+    const float* scale2; int scale_split;        /* optional second scale: launch-grid pixels >= scale_split use *scale2.  Two
+                                                    discriminator passes with their own spectral-norm sigma share one launch
+                                                    (batch halves); 0 / NULL = one scale for all pixels */
 } mtd_conv_args;
 
 size_t mtd_conv_igemm_ws_bytes(const mtd_conv_args* a);

@@ -28,7 +28,8 @@ class ConvArgs(C.Structure):
                 ("add2", C.c_void_p), ("add2_ld", C.c_int),
                 ("act", C.c_int),
                 ("mask", C.c_void_p), ("mask_ld", C.c_int), ("mask_slope", C.c_float),
-                ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
+                ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+                ("scale2", C.c_void_p), ("scale_split", C.c_int)]
 
 
 class WgradArgs(C.Structure):

@@ -29,6 +29,18 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static inline long long geom_pixels(const mtd_geom& g) { return (long long)g.B * g.OH * g.OW; }
+// accumulator scale of a conv launch: one value, or two for the two batch halves of a paired discriminator pass
+struct ScalePair { float s0, s1; int split; };
+__device__ __forceinline__ ScalePair load_scale(const mtd_conv_args& a) {
+    ScalePair r;
+    r.s0 = a.scale ? *a.scale : 1.f;
+    const bool two = a.scale2 != nullptr && a.scale_split > 0;
+    r.s1 = two ? *a.scale2 : r.s0;
+    r.split = two ? a.scale_split : 0x7fffffff;
+    return r;
+}
+__device__ __forceinline__ float pick_scale(const ScalePair& s, int m) { return m < s.split ? s.s0 : s.s1; }
+
 // launch profiler hooks (api.hip)
 int mtd_prof_begin(int kernel, int cfg, int splitk, long long M, int N, int C, int taps, hipStream_t s);
 void mtd_prof_end(int slot, hipStream_t s);

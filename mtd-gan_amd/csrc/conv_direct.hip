@@ -24,7 +24,7 @@ __device__ __forceinline__ void decompose(const mtd_geom& g, int m, int& b, int&
 // one thread per (pixel, n)
 __global__ __launch_bounds__(256) void direct_fwd_kernel(const mtd_conv_args a, long long total, int identity) {
     const mtd_geom& g = a.g;
-    const float sc = a.scale ? *a.scale : 1.f;
+    const ScalePair sp = load_scale(a);
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int n = (int)(idx % a.N);
         const int m = (int)(idx / a.N);
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void direct_fwd_kernel(const mtd_conv_args a, 
         }
         long long pix = m;
         if (!identity) pix = ((long long)b * g.OHF + (oy * g.out_sy + g.out_oy)) * g.OWF + (ox * g.out_sx + g.out_ox);
-        float v = acc * sc + (a.bias ? a.bias[n] : 0.f);
+        float v = acc * pick_scale(sp, m) + (a.bias ? a.bias[n] : 0.f);
         if (a.add1) v += a.add1[pix * a.add1_ld + n];
         if (a.add2) v += a.add2[pix * a.add2_ld + n];
         v = apply_act(v, a.act);
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void fwd_c1_kernel(const FwdParams p) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) w[j][t] = (t < p.T) ? a.w[(long long)(n + j) * a.w_sn + (long long)p.tap_kidx[t] * a.w_st] : 0.f;
     }
-    const float sc = a.scale ? *a.scale : 1.f;
+    const ScalePair sp = load_scale(a);
     const int mb = blockIdx.x * p.ppb;
     const int me = min(p.M, mb + p.ppb);
     for (int m = mb + pl; m < me; m += PL) {
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void fwd_c1_kernel(const FwdParams p) {
         }
         long long pix = m;
         if (!p.identity) pix = ((long long)b * g.OHF + (oy * g.out_sy + g.out_oy)) * g.OWF + (ox * g.out_sx + g.out_ox);
-        store_epilogue4(a, acc, sc, bias, pix, n, p.vec_store);
+        store_epilogue4(a, acc, pick_scale(sp, m), bias, pix, n, p.vec_store);
     }
 }
 
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void fwd_n1_kernel(const FwdParams p, int nblk
         for (int j = 0; j < 4; ++j)
             w[t][j] = (t < p.T) ? a.w[(long long)(4 * cl + j) * a.w_sc + (long long)p.tap_kidx[t] * a.w_st] : 0.f;
     }
-    const float sc = a.scale ? *a.scale : 1.f;
+    const ScalePair sp = load_scale(a);
     const float bias = a.bias ? a.bias[0] : 0.f;
     const int blk = xcd_contiguous_block(blockIdx.x, nblk);
     const int mb = blk * p.ppb;
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void fwd_n1_kernel(const FwdParams p, int nblk
         if (live && cl == 0) {
             long long pix = m;
             if (!p.identity) pix = ((long long)b * g.OHF + (oy * g.out_sy + g.out_oy)) * g.OWF + (ox * g.out_sx + g.out_ox);
-            float v = acc * sc + bias;
+            float v = acc * pick_scale(sp, m) + bias;
             if (a.add1) v += a.add1[pix * a.add1_ld];
             if (a.add2) v += a.add2[pix * a.add2_ld];
             v = apply_act(v, a.act);

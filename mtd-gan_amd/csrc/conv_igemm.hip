@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(cons
             }
         return;
     }
-    const float sc = a.scale ? *a.scale : 1.f;
+    const ScalePair sp = load_scale(a);
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(cons
                 const int m = m0 + (wm * WM + i) * 32 + mfma32_row(e, lane);
                 if (m < p.M) {
                     const long long pix = out_pixel(g, m, p.out_identity);
-                    a.out[pix * a.out_ld + n] = epilogue_value(a, acc[i][j][e], sc, bias_n, pix, n);
+                    a.out[pix * a.out_ld + n] = epilogue_value(a, acc[i][j][e], pick_scale(sp, m), bias_n, pix, n);
                 }
             }
         }
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tb_kernel(const IgemmParams p) {
         }
         return;
     }
-    const float sc = a.scale ? *a.scale : 1.f;
+    const ScalePair sp = load_scale(a);
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int n = n0 + l31;
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tb_kernel(const IgemmParams p) {
             const int m = m0 + (wave * WM + i) * 32 + mfma32_row(e, lane);
             if (m < p.M) {
                 const long long pix = out_pixel(g, m, p.out_identity);
-                a.out[pix * a.out_ld + n] = epilogue_value(a, acc[i][e], sc, bias_n, pix, n);
+                a.out[pix * a.out_ld + n] = epilogue_value(a, acc[i][e], pick_scale(sp, m), bias_n, pix, n);
             }
         }
     }
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void igemm_c32p_kernel(const IgemmParams p,
     int tile = blockIdx.x * 4 + wave;
     if (tile >= ntiles) return;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)p.in_bytes, 0x00020000);
-    const float sc = a.scale ? *a.scale : 1.f;
+    const ScalePair sp = load_scale(a);
     const float bias_n = a.bias ? a.bias[n0 + l31] : 0.f;
 
     unsigned boff = 0, okmask = 0;
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void igemm_c32p_kernel(const IgemmParams p,
             const int m = tile * 32 + mfma32_row(e, lane);
             if (m < p.M) {
                 const long long pix = out_pixel(g, m, p.out_identity);
-                a.out[pix * a.out_ld + n] = epilogue_value(a, acc[e], sc, bias_n, pix, n);
+                a.out[pix * a.out_ld + n] = epilogue_value(a, acc[e], pick_scale(sp, m), bias_n, pix, n);
             }
         }
         if (next >= ntiles) break;
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256, 2) void igemm_v2_kernel(const IgemmParams p) {
             }
         return;
     }
-    const float sc = a.scale ? *a.scale : 1.f;
+    const ScalePair sp = load_scale(a);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(256, 2) void igemm_v2_kernel(const IgemmParams p) {
                 const int m = m0 + wm * 64 + i * 32 + mfma32_row(e, lane);
                 if (m < p.M) {
                     const long long pix = out_pixel(g, m, p.out_identity);
-                    a.out[pix * a.out_ld + n] = epilogue_value(a, acc[i][j][e], sc, bias_n, pix, n);
+                    a.out[pix * a.out_ld + n] = epilogue_value(a, acc[i][j][e], pick_scale(sp, m), bias_n, pix, n);
                 }
             }
         }
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256, 2) void igemm_v2_kernel(const IgemmParams p) {
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IgemmParams p) {
     const mtd_conv_args& a = p.a;
     const long long total = (long long)p.M * a.N;
-    const float sc = a.scale ? *a.scale : 1.f;
+    const ScalePair sp = load_scale(a);
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int n = (int)(idx % a.N);
         const int m = (int)(idx / a.N);
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IgemmParams 
         for (int z = 0; z < p.splitk; ++z) s += a.ws[(long long)z * total + idx];
         const long long pix = out_pixel(a.g, m, p.out_identity);
         const float bias_n = a.bias ? a.bias[n] : 0.f;
-        a.out[pix * a.out_ld + n] = epilogue_value(a, s, sc, bias_n, pix, n);
+        a.out[pix * a.out_ld + n] = epilogue_value(a, s, pick_scale(sp, m), bias_n, pix, n);
     }
 }
 

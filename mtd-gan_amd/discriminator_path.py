@@ -89,13 +89,14 @@ class DiscRuntime:
     """Per-module scratch: the raw weight-gradient temp (one flat buffer shared by all SN layers)."""
 
     def __init__(self):
-        self._gtemp = None
+        self._gtemp = [None, None]
 
-    def gtemp(self, name, device):
-        if self._gtemp is None or self._gtemp.device != device:
-            self._gtemp = torch.empty(SN_W_TOTAL, dtype=torch.float32, device=device)
+    def gtemp(self, name, device, which=0):
+        """which: 0 / 1 = first / second pass of a paired tape (each pass has its own sigma, u, v)."""
+        if self._gtemp[which] is None or self._gtemp[which].device != device:
+            self._gtemp[which] = torch.empty(SN_W_TOTAL, dtype=torch.float32, device=device)
         i = SN_INDEX[name]
-        return self._gtemp[SN_W_OFF[i]:SN_W_OFF[i] + SN_SPECS[i][1] * SN_SPECS[i][2]]
+        return self._gtemp[which][SN_W_OFF[i]:SN_W_OFF[i] + SN_SPECS[i][1] * SN_SPECS[i][2]]
 
 
 class Tape:
@@ -132,19 +133,38 @@ def _inv_sigma(tape, name):
     return tape.sig[i, 1:2]
 
 
+def _scales(tape, name, geom):
+    """Accumulator scale(s) 1/sigma of an SN layer for a launch with geometry `geom`: a paired tape (two passes stacked along
+    the batch, each with its own power-iteration state) switches to the second pass's 1/sigma at its first pixel."""
+    i = SN_INDEX[name]
+    kw = {"scale": tape.sig[i, 1:2]}
+    if getattr(tape, "pair", 0):
+        kw["scale2"] = tape.sig2[i, 1:2]
+        kw["scale_split"] = tape.pair * geom.OH * geom.OW
+    return kw
+
+
 def _sn_conv(P, tape, name, x, out, geom, N, Cc, k, act):
-    return K.conv(x, P[name + ".weight_orig"], geom, N, Cc, Cc * k * k, k * k, out, scale=_inv_sigma(tape, name),
-                  bias=P[name + ".bias"], act=act)
+    return K.conv(x, P[name + ".weight_orig"], geom, N, Cc, Cc * k * k, k * k, out, bias=P[name + ".bias"], act=act,
+                  **_scales(tape, name, geom))
 
 
-def disc_forward(P, x, train, drop_mask, need_rec, save):
+def disc_forward(P, x, train, drop_mask, need_rec, save, sn=None, sn2=None, pair=0):
     """x: (B,64,64,1) NHWC.  P: dict name -> tensor (reference state_dict names).  drop_mask: (B,512)
-    multiplier or None.  Returns ((enc (B,1,1,1), dec (B,64,64,1), rec or None), tape)."""
+    multiplier or None.  Returns ((enc (B,1,1,1), dec (B,64,64,1), rec or None), tape).
+    Paired mode (train_step.d_loss): x stacks TWO passes of the reference along the batch, the first `pair` images being
+    the earlier pass; sn / sn2 are their power-iteration results (sigma table, u, v), run ahead of time in the reference's
+    order.  Every conv then serves both passes in one launch with the 1/sigma of each half (scale2 / scale_split)."""
     B = x.shape[0]
     dev = x.device
     tp = Tape()
     K.prepack(conv_views(P, save))
-    tp.sig, tp.u_save, tp.v_save = _sn_forward(P, train, dev)
+    tp.sig, tp.u_save, tp.v_save = sn if sn is not None else _sn_forward(P, train, dev)
+    tp.pair = int(pair)
+    if tp.pair:
+        if sn is None or sn2 is None or not (0 < tp.pair < B):
+            raise ValueError("paired discriminator pass needs both power-iteration states and 0 < pair < batch")
+        tp.sig2, tp.u_save2, tp.v_save2 = sn2
     tp.x_in, tp.B, tp.drop_mask, tp.need_rec = x, B, drop_mask, need_rec
     tp.tin, tp.a, tp.xs = {}, {}, {}
     t, h, cin = x, 64, 1
@@ -242,19 +262,36 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad):
     def want(name):
         return sink is not None and sink.get(name) is not None
 
-    def wgrad_sn(name, p, q, geom, N, Cc, k):
+    Bh = getattr(tp, "pair", 0)
+
+    def wgrad_sn(name, p, q, gspec, N, Cc, k):
+        """Raw weight gradient of an SN layer into the pass's temp (corrected and accumulated by mtd_sn_grad below).
+        gspec = (h, k, stride, pad) of the forward conv.  A paired tape needs the two passes' gradients separately (each
+        has its own sigma, u, v), so its batch halves go through two launches."""
         wn, bn = name + ".weight_orig", name + ".bias"
         if want(wn):
-            side.run(lambda: K.wgrad(p, q, geom, N, Cc, rt.gtemp(name, dev), Cc * k * k, k * k, db=sink.get(bn), accumulate=False,
-                                     accumulate_bias=True), p, q)
+            hh, kk, ss, pp = gspec
+            if Bh:
+                pa, qa, pb, qb = p[:Bh], q[:Bh], p[Bh:], q[Bh:]
+                ga, gb_ = K.geom_fwd(Bh, hh, hh, kk, ss, pp), K.geom_fwd(B - Bh, hh, hh, kk, ss, pp)
+
+                def both():
+                    K.wgrad(pa, qa, ga, N, Cc, rt.gtemp(name, dev, 0), Cc * k * k, k * k, db=sink.get(bn), accumulate=False, accumulate_bias=True)
+                    K.wgrad(pb, qb, gb_, N, Cc, rt.gtemp(name, dev, 1), Cc * k * k, k * k, db=sink.get(bn), accumulate=False, accumulate_bias=True)
+                side.run(both, p, q)
+            else:
+                geom = K.geom_fwd(B, hh, hh, kk, ss, pp)
+                side.run(lambda: K.wgrad(p, q, geom, N, Cc, rt.gtemp(name, dev), Cc * k * k, k * k, db=sink.get(bn), accumulate=False,
+                                         accumulate_bias=True), p, q)
             sn_touched.append(name)
         elif want(bn):
             raise NotImplementedError("bias-only gradient request")
 
     def dgrad_s1(name, gpre, r, N, Cc, out, k=3, mask=None, add1=None):
         # data gradient of a stride-1 SN conv with N input channels (outputs of this launch), Cc output channels
-        return K.conv(gpre, P[name + ".weight_orig"], K.geom_dgrad_s1(B, r, r, k, (k - 1) // 2), N, Cc, k * k, N * k * k, out,
-                      scale=_inv_sigma(tp, name), add1=add1, mask=mask, mask_slope=0.2)
+        gd = K.geom_dgrad_s1(B, r, r, k, (k - 1) // 2)
+        return K.conv(gpre, P[name + ".weight_orig"], gd, N, Cc, k * k, N * k * k, out, add1=add1, mask=mask, mask_slope=0.2,
+                      **_scales(tp, name, gd))
 
     g_bot_parts = []
     g_skip = {l: [] for l in range(1, 7)}
@@ -274,10 +311,10 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad):
             o2, o1, cat, tin = o2s[lvl], o1s[lvl], cats[lvl], ins[lvl]
             g3 = K.geom_fwd(B, r, r, 3, 1, 1)
             gpre2 = K.act_grad(g, o2, 0.2)
-            wgrad_sn(f"{pre}_dconv{lvl}2", gpre2, o1, g3, co, co, 3)
+            wgrad_sn(f"{pre}_dconv{lvl}2", gpre2, o1, (r, 3, 1, 1), co, co, 3)
             gpre1 = K.empty_nhwc(B, r, r, co, x)
             dgrad_s1(f"{pre}_dconv{lvl}2", gpre2, r, co, co, gpre1, mask=o1)
-            wgrad_sn(f"{pre}_dconv{lvl}1", gpre1, cat, g3, co, ccat, 3)
+            wgrad_sn(f"{pre}_dconv{lvl}1", gpre1, cat, (r, 3, 1, 1), co, ccat, 3)
             gcat = K.empty_nhwc(B, r, r, ccat, x)
             dgrad_s1(f"{pre}_dconv{lvl}1", gpre1, r, ccat, co, gcat)
             cprev = tin.shape[3] if pre == "s" else RUP[lvl - 1][1]
@@ -311,11 +348,9 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad):
         gpre = K.act_grad(gc, tp.c, 0.2)
         wn = "c_fc.weight_orig"
         if want(wn):
-            side.run(lambda: K.wgrad(gpre, tp.bot, g1, 512, 512, rt.gtemp("c_fc", dev), 512, 1, db=sink.get("c_fc.bias"), accumulate=False,
-                                     accumulate_bias=True), gpre)
-            sn_touched.append("c_fc")
+            wgrad_sn("c_fc", gpre, tp.bot, (1, 1, 1, 0), 512, 512, 1)
         gb = K.empty_nhwc(B, 1, 1, 512, x)
-        K.conv(gpre, P[wn], g1, 512, 512, 1, 512, gb, scale=_inv_sigma(tp, "c_fc"))
+        K.conv(gpre, P[wn], g1, 512, 512, 1, 512, gb, **_scales(tp, "c_fc", g1))
         g_bot_parts.append(gb)
 
     # ---- bottleneck
@@ -323,12 +358,12 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad):
     for extra in g_bot_parts[1:]:
         K.copy_channels(extra, gbot, accumulate=True)
     gpre = K.act_grad(gbot, tp.bot, 0.2)
-    wgrad_sn("bconv2", gpre, tp.b1, g1, 512, 512, 1)
+    wgrad_sn("bconv2", gpre, tp.b1, (1, 1, 1, 0), 512, 512, 1)
     gpre1 = K.empty_nhwc(B, 1, 1, 512, x)
-    K.conv(gpre, P["bconv2.weight_orig"], g1, 512, 512, 1, 512, gpre1, scale=_inv_sigma(tp, "bconv2"), mask=tp.b1, mask_slope=0.2)
-    wgrad_sn("bconv1", gpre1, tp.d6, g1, 512, 512, 1)
+    K.conv(gpre, P["bconv2.weight_orig"], g1, 512, 512, 1, 512, gpre1, mask=tp.b1, mask_slope=0.2, **_scales(tp, "bconv2", g1))
+    wgrad_sn("bconv1", gpre1, tp.d6, (1, 1, 1, 0), 512, 512, 1)
     g = K.empty_nhwc(B, 1, 1, 512, x)
-    K.conv(gpre1, P["bconv1.weight_orig"], g1, 512, 512, 1, 512, g, scale=_inv_sigma(tp, "bconv1"))
+    K.conv(gpre1, P["bconv1.weight_orig"], g1, 512, 512, 1, 512, g, **_scales(tp, "bconv1", g1))
 
     # ---- trunk, levels 6..1
     g_in = None
@@ -337,7 +372,7 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad):
         co = CH[l - 1]
         ci = 1 if l == 1 else CH[l - 2]
         xl, a, tin = tp.xs[l], tp.a[l], tp.tin[l]
-        wgrad_sn(f"down{l}", g, xl, K.geom_fwd(B, h, h, 4, 2, 1), co, co, 4)
+        wgrad_sn(f"down{l}", g, xl, (h, 4, 2, 1), co, co, 4)
         gpre2 = K.empty_nhwc(B, h, h, co, x)
         adds = g_skip[l]
         add1 = adds[0] if len(adds) > 0 else None
@@ -345,13 +380,14 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad):
         wd = P[f"down{l}.weight_orig"]
         for py in range(2):
             for px in range(2):
-                K.conv(g, wd, K.geom_dgrad_s2(B, h, h, py, px), co, co, 16, co * 16, gpre2, scale=_inv_sigma(tp, f"down{l}"),
-                       add1=add1, add2=add2, mask=xl, mask_slope=0.2)
+                gp = K.geom_dgrad_s2(B, h, h, py, px)
+                K.conv(g, wd, gp, co, co, 16, co * 16, gpre2, add1=add1, add2=add2, mask=xl, mask_slope=0.2,
+                       **_scales(tp, f"down{l}", gp))
         g3 = K.geom_fwd(B, h, h, 3, 1, 1)
-        wgrad_sn(f"conv{l}2", gpre2, a, g3, co, co, 3)
+        wgrad_sn(f"conv{l}2", gpre2, a, (h, 3, 1, 1), co, co, 3)
         gpre1 = K.empty_nhwc(B, h, h, co, x)
         dgrad_s1(f"conv{l}2", gpre2, h, co, co, gpre1, mask=a)
-        wgrad_sn(f"conv{l}1", gpre1, tin, g3, co, ci, 3)
+        wgrad_sn(f"conv{l}1", gpre1, tin, (h, 3, 1, 1), co, ci, 3)
         if l > 1:
             g = K.empty_nhwc(B, h, h, ci, x)
             dgrad_s1(f"conv{l}1", gpre1, h, ci, co, g)
@@ -363,17 +399,19 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad):
     if sn_touched:
         L = _lib.lib()
         structs = []
-        for name in sn_touched:
-            i = SN_INDEX[name]
-            s = _lib.SnGradLayer()
-            s.G = rt.gtemp(name, dev).data_ptr()
-            s.w = P[name + ".weight_orig"].data_ptr()
-            s.u = tp.u_save.data_ptr() + 4 * SN_ROW_OFF[i]
-            s.v = tp.v_save.data_ptr() + 4 * SN_COL_OFF[i]
-            s.sigma = tp.sig.data_ptr() + 8 * i
-            s.g_out = sink.get(name + ".weight_orig").data_ptr()
-            s.rows, s.cols, s.accumulate = SN_SPECS[i][1], SN_SPECS[i][2], 1
-            structs.append(s)
+        states = [(0, tp.u_save, tp.v_save, tp.sig)] + ([(1, tp.u_save2, tp.v_save2, tp.sig2)] if Bh else [])
+        for which, u_save, v_save, sig in states:
+            for name in sn_touched:
+                i = SN_INDEX[name]
+                s = _lib.SnGradLayer()
+                s.G = rt.gtemp(name, dev, which).data_ptr()
+                s.w = P[name + ".weight_orig"].data_ptr()
+                s.u = u_save.data_ptr() + 4 * SN_ROW_OFF[i]
+                s.v = v_save.data_ptr() + 4 * SN_COL_OFF[i]
+                s.sigma = sig.data_ptr() + 8 * i
+                s.g_out = sink.get(name + ".weight_orig").data_ptr()
+                s.rows, s.cols, s.accumulate = SN_SPECS[i][1], SN_SPECS[i][2], 1
+                structs.append(s)
         dev_tab, host_arr = K.device_table(structs, dev)
         need = L.mtd_sn_grad_ws_bytes(C.cast(host_arr, C.c_void_p), len(structs))
 

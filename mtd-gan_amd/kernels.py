@@ -176,7 +176,7 @@ def _ptr(t):
 
 # ---------------------------------------------------------------------------------------------- conv
 def conv(x, w, geom, N, Cc, w_sn, w_sc, out, scale=None, bias=None, add1=None, add2=None, act=ACT_NONE,
-         mask=None, mask_slope=0.0):
+         mask=None, mask_slope=0.0, scale2=None, scale_split=0):
     """out = epilogue(conv(x, W-view)).  `out` is an NHWC tensor (B, OHF, OWF, >=N view)."""
     L = _lib.lib()
     a = ConvArgs()
@@ -188,6 +188,7 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, scale=None, bias=None, add1=None, a
     a.w, a.w_sn, a.w_sc, a.w_st, a.N = w.data_ptr(), w_sn, w_sc, w_st, N
     a.out, a.out_ld = out.data_ptr(), ld_of(out)
     a.scale, a.bias = _ptr(scale), _ptr(bias)
+    a.scale2, a.scale_split = _ptr(scale2), int(scale_split) if scale2 is not None else 0
     a.add1, a.add1_ld = _ptr(add1), (ld_of(add1) if add1 is not None else 0)
     a.add2, a.add2_ld = _ptr(add2), (ld_of(add2) if add2 is not None else 0)
     a.act = act

@@ -59,15 +59,20 @@ class DStepTape:
                 t[nme] = S[i, ofs:ofs + sz]
                 ofs += sz
             sinks.append(DP.GradSink(t))
-        (re, rd, rr), (fe, fd, fr), (rre, rrd), (rfe, rfd) = self.outs
-        t1, t2, t3, t4 = self.passes
+        (re, rd, rr), (fe, fd, fr), (rre, rrd), (rfe, rfd), r12 = self.outs
+        t12, t34 = self.passes
         rt, P = D._rt, self.P
-        e = lambda: torch.empty((B, 1, 1, 1), dtype=torch.float32, device=dev)
-        m = lambda: torch.empty((B, 64, 64, 1), dtype=torch.float32, device=dev)
         x, y, fake = self.x, self.y, self.fake
-        # ---- all output cotangents of the three tasks in one launch
-        g = {k: (e() if k.endswith("e") else m()) for k in
-             ("d_re", "d_fe", "c_re", "c_fe", "c_rre", "c_rfe", "d_rd", "d_fd", "r_rr", "r_fr", "c_rd", "c_fd", "c_rrd", "c_rfd")}
+        # ---- all output cotangents of the three tasks in one launch.  Each is allocated for the pair of passes it belongs
+        # to (2B images); the real / fake halves are views, so one backward serves both passes.
+        E = lambda: torch.empty((2 * B, 1, 1, 1), dtype=torch.float32, device=dev)
+        Mp = lambda: torch.empty((2 * B, 64, 64, 1), dtype=torch.float32, device=dev)
+        G2 = {k: (E() if k.endswith("e") else Mp()) for k in ("d_e", "c_e", "c3_e", "d_d", "r_r", "c_d", "c3_d")}
+        h0 = lambda k: G2[k][:B]
+        h1 = lambda k: G2[k][B:]
+        g = {"d_re": h0("d_e"), "d_fe": h1("d_e"), "c_re": h0("c_e"), "c_fe": h1("c_e"), "c_rre": h0("c3_e"), "c_rfe": h1("c3_e"),
+             "d_rd": h0("d_d"), "d_fd": h1("d_d"), "r_rr": h0("r_r"), "r_fr": h1("r_r"), "c_rd": h0("c_d"), "c_fd": h1("c_d"),
+             "c_rrd": h0("c3_d"), "c_rfd": h1("c3_d")}
         T = K.make_term
         K.loss_term_grads([
             T(0, re, tconst=1.0, grad_out=g["d_re"], coef=1.0 / B), T(0, fe, tconst=0.0, grad_out=g["d_fe"], coef=1.0 / B),
@@ -77,19 +82,15 @@ class DStepTape:
             T(0, rd, rrd, grad_out=g["c_rd"], coef=1.0 / n), T(0, rrd, rd, grad_out=g["c_rrd"], coef=1.0 / n),
             T(0, fe, rfe, grad_out=g["c_fe"], coef=1.0 / B), T(0, rfe, fe, grad_out=g["c_rfe"], coef=1.0 / B),
             T(0, fd, rfd, grad_out=g["c_fd"], coef=1.0 / n), T(0, rfd, fd, grad_out=g["c_rfd"], coef=1.0 / n)], dev)
-        # ---- task 0: adversarial (image-level + pixel-level)
-        DP.disc_backward(rt, P, t1, g["d_re"], g["d_rd"], None, sinks[0], False)
-        DP.disc_backward(rt, P, t2, g["d_fe"], g["d_fd"], None, sinks[0], False)
+        # ---- task 0: adversarial (image-level + pixel-level), passes 1 and 2 together
+        DP.disc_backward(rt, P, t12, G2["d_e"], G2["d_d"], None, sinks[0], False)
         self._sync_task(dp, S, 0)
         # ---- task 1: restoration
-        DP.disc_backward(rt, P, t1, None, None, g["r_rr"], sinks[1], False)
-        DP.disc_backward(rt, P, t2, None, None, g["r_fr"], sinks[1], False)
+        DP.disc_backward(rt, P, t12, None, None, G2["r_r"], sinks[1], False)
         self._sync_task(dp, S, 1)
-        # ---- task 2: consistency (through D(real_rec.clip) back into the restoration decoder of pass 1)
-        gin3 = DP.disc_backward(rt, P, t3, g["c_rre"], g["c_rrd"], None, sinks[2], True)
-        DP.disc_backward(rt, P, t1, g["c_re"], g["c_rd"], K.clip01_bwd(gin3, rr), sinks[2], False)
-        gin4 = DP.disc_backward(rt, P, t4, g["c_rfe"], g["c_rfd"], None, sinks[2], True)
-        DP.disc_backward(rt, P, t2, g["c_fe"], g["c_fd"], K.clip01_bwd(gin4, fr), sinks[2], False)
+        # ---- task 2: consistency (through D(rec.clip), passes 3 and 4, back into the restoration decoder of passes 1 and 2)
+        gin34 = DP.disc_backward(rt, P, t34, G2["c3_e"], G2["c3_d"], None, sinks[2], True)
+        DP.disc_backward(rt, P, t12, G2["c_e"], G2["c_d"], K.clip01_bwd(gin34, r12), sinks[2], False)
         self._sync_task(dp, S, 2)
         if dp is not None:
             dp.wait()                      # the three averaged task vectors are needed by the Gram kernel
@@ -174,10 +175,20 @@ def d_loss(method, x, y):
     method._gcache = (_gkey(x, gflat), fn, gtape, GPm) if keep else None
     P = D._param_dict()
     train = D.training
-    (re, rd, rr), t1 = DP.disc_forward(P, yn, train, D._next_mask(B, dev), True, True)
-    (fe, fd, fr), t2 = DP.disc_forward(P, fn, train, D._next_mask(B, dev), True, True)
-    (rre, rrd, _), t3 = DP.disc_forward(P, K.clip01(rr), train, D._next_mask(B, dev), False, True)
-    (rfe, rfd, _), t4 = DP.disc_forward(P, K.clip01(fr), train, D._next_mask(B, dev), False, True)
+    # The four discriminator passes of the reference run as TWO launches sequences of batch 2B: (D(y), D(fake)) and
+    # (D(clip(real_rec)), D(clip(fake_rec))).  Each pass keeps its own spectral-norm state: the four power iterations run
+    # first, in the reference's order, and every conv applies the 1/sigma of the half it is computing (scale2 /
+    # scale_split).  Same arithmetic per image; half the launches, twice the pixels per launch on the deep 4x4 .. 1x1 layers.
+    K.prepack(DP.conv_views(P, True))
+    sn = [DP._sn_forward(P, train, dev) for _ in range(4)]
+    masks = [D._next_mask(B, dev) for _ in range(4)]
+    cat_mask = lambda a, b: None if a is None else torch.cat([a, b], 0)
+    (e12, d12, r12), t12 = DP.disc_forward(P, torch.cat([yn, fn], 0), train, cat_mask(masks[0], masks[1]), True, True,
+                                           sn=sn[0], sn2=sn[1], pair=B)
+    (e34, d34, _), t34 = DP.disc_forward(P, K.clip01(r12), train, cat_mask(masks[2], masks[3]), False, True,
+                                         sn=sn[2], sn2=sn[3], pair=B)
+    re, fe, rd, fd, rr, fr = e12[:B], e12[B:], d12[:B], d12[B:], r12[:B], r12[B:]
+    rre, rfe, rrd, rfd = e34[:B], e34[B:], d34[:B], d34[B:]
     n = B * NPIX
     T = K.make_term
     v = K.loss_terms([
@@ -189,7 +200,7 @@ def d_loss(method, x, y):
     keys = ["D/real_enc", "D/fake_enc", "D/real_dec", "D/fake_dec", "D/rec_loss_real", "D/rec_loss_fake",
             "D/consist_loss_real_enc", "D/consist_loss_real_dec", "D/consist_loss_fake_enc", "D/consist_loss_fake_dec"]
     details = {k: v[i] for i, k in enumerate(keys)}
-    losses._mtd_tape = DStepTape(method, P, (t1, t2, t3, t4), ((re, rd, rr), (fe, fd, fr), (rre, rrd), (rfe, rfd)), xn, yn, fn)
+    losses._mtd_tape = DStepTape(method, P, (t12, t34), ((re, rd, rr), (fe, fd, fr), (rre, rrd), (rfe, rfd), r12), xn, yn, fn)
     return losses, details
 
 
