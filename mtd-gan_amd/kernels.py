@@ -71,7 +71,6 @@ def packed_weight_view(w, N, Cc, w_sn, w_sc):
 STATS = {"table_hit": 0, "table_miss": 0, "zero_copy_reads": 0}
 _igemm_ws_cache = {}
 CALL_LOG = None     # tools/tune_igemm.py: a list collects ("igemm" | "wgrad", bytes(argument struct)) per call
-PROFILE = None      # legacy hook: a list collects (tag, start_event, end_event) per un-split igemm launch
 
 IGEMM_CONFIGS = ["igemm_kernel<2, 1, 4, 1>", "igemm_kernel<1, 1, 4, 1>", "igemm_kernel<2, 2, 4, 1>",
                  "igemm_kernel<1, 1, 2, 2>", "igemm_kernel<2, 2, 2, 2>", "igemm_kernel<1, 1, 1, 4>",
@@ -205,14 +204,7 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, scale=None, bias=None, add1=None, a
             a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
         if CALL_LOG is not None:
             CALL_LOG.append(("igemm", bytes(a)))
-        prof = PROFILE is not None and not need
-        if prof:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
         check(L.mtd_conv_igemm(C.byref(a), stream_ptr()), "mtd_conv_igemm")
-        if prof:
-            e1.record()
-            PROFILE.append((f"igemm_{geom.TH}x{geom.TW}_c{Cc}_n{N}", e0, e1))
     else:
         if CALL_LOG is not None:
             CALL_LOG.append(("direct", bytes(a)))
