@@ -746,10 +746,16 @@ Plan make_plan(const mtd_conv_args& a) {
     // fp32 MFMA is slow enough (64 clk per 32x32x2) that one 32x32 accumulator tile per wave at high occupancy beats the
     // register-blocked tiles almost everywhere; the wide tiles only pay for the huge-M, thin-K first-stage layers.
     pl.cfg = 1;
-    if ((M >= 131072 && a.N >= 64) || (M >= 32768 && a.N >= 256 && a.C <= 64)) pl.cfg = 0;
+    if ((M >= 131072 && a.N >= 64) || (M >= 32768 && a.N >= 256 && a.C <= 64) || (M >= 65536 && a.N >= 128) ||
+        (M >= 16384 && a.N >= 512 && a.C <= 128)) pl.cfg = 0;
     else if (M >= 32768 && a.N == 64 && a.C >= 128) pl.cfg = 3;
-    // (The tap-block kernels, configs 6 / 7, are 5-13 % faster on a few mid-size shapes and slower on others; within run-to-run
-    //  noise in the sum over the step, so they stay selectable through mtd_conv_igemm_override only.)
+    // tap-block kernel (all taps of a channel chunk per barrier; 41 KB of LDS = 3 workgroups per CU): 5-9 % faster on the
+    // paired-pass shapes (profiles/r1_igemm_tile_sweep.txt) when several chunks stream and the grid fits one round of residency
+    if (pl.cfg == 1 && a.C >= 128 && M >= 4096 && a.g.TH * a.g.TW <= TB_MAXT) {
+        const long long b6 = ((M + 127) / 128) * (a.N / 32);
+        const long long sk6 = b6 <= 256 ? 512 / b6 : 1;
+        if (b6 * sk6 <= 768) pl.cfg = 6;
+    }
     pl.BM = kCfgBM[pl.cfg];
     pl.BN = kCfgBN[pl.cfg];
     long long blocks = ((M + pl.BM - 1) / pl.BM) * (a.N / pl.BN);
