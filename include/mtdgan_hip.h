@@ -182,6 +182,9 @@ int mtd_sn_power_iter(const mtd_sn_layer* layers_dev, const mtd_sn_layer* layers
 typedef struct {
     const float* G; const float* w; const float* u; const float* v; const float* sigma;
     float* g_out; int rows, cols; int accumulate;
+    /* optional second pass over the same weight (a batch-paired discriminator pass has one sigma, u, v per half):
+     * g_out (+)= corr(G, u, v, sigma) and then += corr(G2, u2, v2, sigma2), in that order; G2 == NULL: single pass */
+    const float* G2; const float* u2; const float* v2; const float* sigma2;
 } mtd_sn_grad_layer;
 size_t mtd_sn_grad_ws_bytes(const mtd_sn_grad_layer* layers_host, int n_layers);
 int mtd_sn_grad(const mtd_sn_grad_layer* layers_dev, const mtd_sn_grad_layer* layers_host, int n_layers,

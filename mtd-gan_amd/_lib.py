@@ -53,7 +53,8 @@ class SnLayer(C.Structure):
 
 class SnGradLayer(C.Structure):
     _fields_ = [("G", C.c_void_p), ("w", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("sigma", C.c_void_p),
-                ("g_out", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("accumulate", C.c_int)]
+                ("g_out", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("accumulate", C.c_int),
+                ("G2", C.c_void_p), ("u2", C.c_void_p), ("v2", C.c_void_p), ("sigma2", C.c_void_p)]
 
 
 class LossTerm(C.Structure):

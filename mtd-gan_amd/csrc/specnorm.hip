@@ -202,59 +202,126 @@ __global__ __launch_bounds__(256) void sn_finish_kernel(const mtd_sn_layer* __re
 }
 
 // ---- backward -----------------------------------------------------------------------------------
+// HBM-bound: <G, W> reads 2 floats per weight, the correction reads 2 and writes 1.  16 Ki weights per block keep the
+// (layer, block) lookup off the critical path; 16-byte accesses whenever the layer's pointers and row length allow.
 struct SnGradWs { float* partial; float* dot; };
+constexpr int GRAD_ELEMS_PER_BLOCK = 16384;
 
 __device__ __forceinline__ int grad_blocks(const mtd_sn_grad_layer& l) {
-    return (int)(((long long)l.rows * l.cols + ELEMS_PER_BLOCK - 1) / ELEMS_PER_BLOCK);
+    return (int)(((long long)l.rows * l.cols + GRAD_ELEMS_PER_BLOCK - 1) / GRAD_ELEMS_PER_BLOCK);
 }
-__device__ __forceinline__ long long grad_block_offset(const mtd_sn_grad_layer* L, int layer) {
-    long long o = 0;
-    for (int l = 0; l < layer; ++l) o += grad_blocks(L[l]);
-    return o;
+__device__ __forceinline__ bool grad_vec_ok(const mtd_sn_grad_layer& l) {
+    return (l.cols & 3) == 0 && aligned16_dev(l.G) && aligned16_dev(l.w) && aligned16_dev(l.g_out) && aligned16_dev(l.G2);
+}
+__device__ __forceinline__ float dot4(const float4& g, const float4& w, float p) {
+    p = fmaf(g.x, w.x, p); p = fmaf(g.y, w.y, p); p = fmaf(g.z, w.z, p); return fmaf(g.w, w.w, p);
 }
 
+// partial[2 * block + s] = this block's share of <G_s, W>  (s = 1 only for a paired layer)
 __global__ __launch_bounds__(256) void sn_grad_dot_kernel(const mtd_sn_grad_layer* __restrict__ L, int n_layers, SnGradWs ws) {
     __shared__ float red[256];
     int layer, local;
     if (!locate(n_layers, blockIdx.x, [&](int l) { return grad_blocks(L[l]); }, layer, local)) return;
     const mtd_sn_grad_layer ly = L[layer];
-    const long long total = (long long)ly.rows * ly.cols;
-    const long long base = (long long)local * ELEMS_PER_BLOCK;
-    float p = 0.f;
-    for (int i = threadIdx.x; i < ELEMS_PER_BLOCK; i += 256) {
-        long long e = base + i;
-        if (e < total) p = fmaf(ly.G[e], ly.w[e], p);
+    const unsigned total = (unsigned)ly.rows * (unsigned)ly.cols;
+    const unsigned base = (unsigned)local * GRAD_ELEMS_PER_BLOCK;
+    const bool two = ly.G2 != nullptr;
+    float p = 0.f, p2 = 0.f;
+    if (grad_vec_ok(ly)) {
+        // fixed association: lane-local sums over its float4s in index order, then the block tree
+#pragma unroll 4
+        for (int i = threadIdx.x * 4; i < GRAD_ELEMS_PER_BLOCK; i += 1024) {
+            const unsigned e = base + i;
+            if (e < total) {
+                const float4 w = *reinterpret_cast<const float4*>(ly.w + e);
+                p = dot4(*reinterpret_cast<const float4*>(ly.G + e), w, p);
+                if (two) p2 = dot4(*reinterpret_cast<const float4*>(ly.G2 + e), w, p2);
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < GRAD_ELEMS_PER_BLOCK; i += 256) {
+            const unsigned e = base + i;
+            if (e < total) {
+                const float w = ly.w[e];
+                p = fmaf(ly.G[e], w, p);
+                if (two) p2 = fmaf(ly.G2[e], w, p2);
+            }
+        }
     }
     const float s = block_sum(p, red);
-    if (threadIdx.x == 0) ws.partial[grad_block_offset(L, layer) + local] = s;
+    if (threadIdx.x == 0) ws.partial[2 * (long long)blockIdx.x] = s;      // blockIdx.x - local = first block of this layer
+    if (two) {
+        const float s2 = block_sum(p2, red);
+        if (threadIdx.x == 0) ws.partial[2 * (long long)blockIdx.x + 1] = s2;
+    }
 }
 
+// dot[2 * layer + s] = sum of the layer's partials, one block per (layer, s)
 __global__ __launch_bounds__(256) void sn_grad_sum_kernel(const mtd_sn_grad_layer* __restrict__ L, int n_layers, SnGradWs ws) {
     __shared__ float red[256];
-    const int layer = blockIdx.x;
-    if (layer >= n_layers) return;
+    const int layer = blockIdx.x >> 1, s = blockIdx.x & 1;
+    if (layer >= n_layers || (s && !L[layer].G2)) return;
     const int nb = grad_blocks(L[layer]);
-    const float* part = ws.partial + grad_block_offset(L, layer);
+    long long first = 0;
+    for (int l = 0; l < layer; ++l) first += grad_blocks(L[l]);
+    const float* part = ws.partial + 2 * first + s;
     float p = 0.f;
-    for (int i = threadIdx.x; i < nb; i += 256) p += part[i];
-    const float s = block_sum(p, red);
-    if (threadIdx.x == 0) ws.dot[layer] = s;
+    for (int i = threadIdx.x; i < nb; i += 256) p += part[2 * i];
+    const float t = block_sum(p, red);
+    if (threadIdx.x == 0) ws.dot[2 * layer + s] = t;
 }
 
 __global__ __launch_bounds__(256) void sn_grad_apply_kernel(const mtd_sn_grad_layer* __restrict__ L, int n_layers, SnGradWs ws) {
     int layer, local;
     if (!locate(n_layers, blockIdx.x, [&](int l) { return grad_blocks(L[l]); }, layer, local)) return;
     const mtd_sn_grad_layer ly = L[layer];
-    const long long total = (long long)ly.rows * ly.cols;
-    const long long base = (long long)local * ELEMS_PER_BLOCK;
+    const unsigned total = (unsigned)ly.rows * (unsigned)ly.cols;
+    const unsigned base = (unsigned)local * GRAD_ELEMS_PER_BLOCK;
+    const unsigned cols = (unsigned)ly.cols;
+    const bool two = ly.G2 != nullptr;
     const float inv = ly.sigma[1];
-    const float coef = ws.dot[layer] * inv * inv;
-    for (int i = threadIdx.x; i < ELEMS_PER_BLOCK; i += 256) {
-        long long e = base + i;
-        if (e < total) {
-            const int r = (int)(e / ly.cols), k = (int)(e % ly.cols);
-            const float g = ly.G[e] * inv - coef * ly.u[r] * ly.v[k];
-            ly.g_out[e] = ly.accumulate ? ly.g_out[e] + g : g;
+    const float coef = ws.dot[2 * layer] * inv * inv;
+    const float inv2 = two ? ly.sigma2[1] : 0.f;
+    const float coef2 = two ? ws.dot[2 * layer + 1] * inv2 * inv2 : 0.f;
+    if (grad_vec_ok(ly)) {
+#pragma unroll 4
+        for (int i = threadIdx.x * 4; i < GRAD_ELEMS_PER_BLOCK; i += 1024) {
+            const unsigned e = base + i;
+            if (e < total) {
+                const unsigned r = e / cols, k = e - r * cols;          // cols % 4 == 0: the four weights share a row
+                const float cu = coef * ly.u[r];
+                const float4 G = *reinterpret_cast<const float4*>(ly.G + e);
+                float4 o;
+                o.x = G.x * inv - cu * ly.v[k];
+                o.y = G.y * inv - cu * ly.v[k + 1];
+                o.z = G.z * inv - cu * ly.v[k + 2];
+                o.w = G.w * inv - cu * ly.v[k + 3];
+                float4* dst = reinterpret_cast<float4*>(ly.g_out + e);
+                if (ly.accumulate) {
+                    const float4 a = *dst;
+                    o.x = a.x + o.x; o.y = a.y + o.y; o.z = a.z + o.z; o.w = a.w + o.w;
+                }
+                if (two) {                                               // second pass added after the first, as two launches would
+                    const float cu2 = coef2 * ly.u2[r];
+                    const float4 H = *reinterpret_cast<const float4*>(ly.G2 + e);
+                    o.x += H.x * inv2 - cu2 * ly.v2[k];
+                    o.y += H.y * inv2 - cu2 * ly.v2[k + 1];
+                    o.z += H.z * inv2 - cu2 * ly.v2[k + 2];
+                    o.w += H.w * inv2 - cu2 * ly.v2[k + 3];
+                }
+                *dst = o;
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < GRAD_ELEMS_PER_BLOCK; i += 256) {
+            const unsigned e = base + i;
+            if (e < total) {
+                const unsigned r = e / cols, k = e - r * cols;
+                float g = ly.G[e] * inv - coef * ly.u[r] * ly.v[k];
+                if (ly.accumulate) g = ly.g_out[e] + g;
+                if (two) g += ly.G2[e] * inv2 - coef2 * ly.u2[r] * ly.v2[k];
+                ly.g_out[e] = g;
+            }
         }
     }
 }
@@ -313,13 +380,13 @@ extern "C" int mtd_sn_power_iter(const mtd_sn_layer* layers_dev, const mtd_sn_la
 
 static long long sn_grad_blocks_host(const mtd_sn_grad_layer* h, int n) {
     long long b = 0;
-    for (int i = 0; i < n; ++i) b += ((long long)h[i].rows * h[i].cols + ELEMS_PER_BLOCK - 1) / ELEMS_PER_BLOCK;
+    for (int i = 0; i < n; ++i) b += ((long long)h[i].rows * h[i].cols + GRAD_ELEMS_PER_BLOCK - 1) / GRAD_ELEMS_PER_BLOCK;
     return b;
 }
 
 extern "C" size_t mtd_sn_grad_ws_bytes(const mtd_sn_grad_layer* layers_host, int n_layers) {
     if (!layers_host || n_layers <= 0) return 0;
-    return (size_t)(sn_grad_blocks_host(layers_host, n_layers) + n_layers) * sizeof(float);
+    return (size_t)(2 * (sn_grad_blocks_host(layers_host, n_layers) + n_layers)) * sizeof(float);
 }
 
 extern "C" int mtd_sn_grad(const mtd_sn_grad_layer* layers_dev, const mtd_sn_grad_layer* layers_host, int n_layers, float* ws,
@@ -328,11 +395,11 @@ extern "C" int mtd_sn_grad(const mtd_sn_grad_layer* layers_dev, const mtd_sn_gra
     const long long nb = sn_grad_blocks_host(layers_host, n_layers);
     SnGradWs w;
     w.partial = ws;
-    w.dot = ws + nb;
+    w.dot = ws + 2 * nb;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(sn_grad_dot_kernel, dim3((unsigned)nb), dim3(256), 0, s, layers_dev, n_layers, w);
     MTD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sn_grad_sum_kernel, dim3(n_layers), dim3(256), 0, s, layers_dev, n_layers, w);
+    hipLaunchKernelGGL(sn_grad_sum_kernel, dim3(2 * n_layers), dim3(256), 0, s, layers_dev, n_layers, w);
     MTD_LAUNCH_CHECK();
     hipLaunchKernelGGL(sn_grad_apply_kernel, dim3((unsigned)nb), dim3(256), 0, s, layers_dev, n_layers, w);
     MTD_LAUNCH_CHECK();

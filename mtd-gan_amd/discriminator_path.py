@@ -399,19 +399,22 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad):
     if sn_touched:
         L = _lib.lib()
         structs = []
-        states = [(0, tp.u_save, tp.v_save, tp.sig)] + ([(1, tp.u_save2, tp.v_save2, tp.sig2)] if Bh else [])
-        for which, u_save, v_save, sig in states:
-            for name in sn_touched:
-                i = SN_INDEX[name]
-                s = _lib.SnGradLayer()
-                s.G = rt.gtemp(name, dev, which).data_ptr()
-                s.w = P[name + ".weight_orig"].data_ptr()
-                s.u = u_save.data_ptr() + 4 * SN_ROW_OFF[i]
-                s.v = v_save.data_ptr() + 4 * SN_COL_OFF[i]
-                s.sigma = sig.data_ptr() + 8 * i
-                s.g_out = sink.get(name + ".weight_orig").data_ptr()
-                s.rows, s.cols, s.accumulate = SN_SPECS[i][1], SN_SPECS[i][2], 1
-                structs.append(s)
+        for name in sn_touched:
+            i = SN_INDEX[name]
+            s = _lib.SnGradLayer()
+            s.G = rt.gtemp(name, dev, 0).data_ptr()
+            s.w = P[name + ".weight_orig"].data_ptr()
+            s.u = tp.u_save.data_ptr() + 4 * SN_ROW_OFF[i]
+            s.v = tp.v_save.data_ptr() + 4 * SN_COL_OFF[i]
+            s.sigma = tp.sig.data_ptr() + 8 * i
+            s.g_out = sink.get(name + ".weight_orig").data_ptr()
+            s.rows, s.cols, s.accumulate = SN_SPECS[i][1], SN_SPECS[i][2], 1
+            if Bh:      # the second half's own sigma, u, v: corrected and added in the same launch, after the first
+                s.G2 = rt.gtemp(name, dev, 1).data_ptr()
+                s.u2 = tp.u_save2.data_ptr() + 4 * SN_ROW_OFF[i]
+                s.v2 = tp.v_save2.data_ptr() + 4 * SN_COL_OFF[i]
+                s.sigma2 = tp.sig2.data_ptr() + 8 * i
+            structs.append(s)
         dev_tab, host_arr = K.device_table(structs, dev)
         need = L.mtd_sn_grad_ws_bytes(C.cast(host_arr, C.c_void_p), len(structs))
 

@@ -47,11 +47,12 @@ class DStepTape:
         S = torch.zeros((4, total), dtype=torch.float32, device=dev)       # 3 task vectors + merged
         # task-specific gradients: views of one flat buffer, so that N > 1 averages them with a single collective
         ts_sizes = [D.get_parameter(nme).numel() for nme in ts_names]
-        TSflat = torch.zeros(max(sum(ts_sizes), 1), dtype=torch.float32, device=dev)
+        # (each view starts on a 16-byte boundary: the spectral-norm correction then moves float4s)
+        TSflat = torch.zeros(max(sum((sz + 3) // 4 * 4 for sz in ts_sizes), 4), dtype=torch.float32, device=dev)
         TSbuf, tofs = {}, 0
         for nme, sz in zip(ts_names, ts_sizes):
             TSbuf[nme] = TSflat[tofs:tofs + sz].view_as(D.get_parameter(nme))
-            tofs += sz
+            tofs += (sz + 3) // 4 * 4
         sinks = []
         for i in range(3):
             t, ofs = dict(TSbuf), 0

@@ -115,3 +115,47 @@ def test_spectral_norm_kernels_vs_torch(hip_lib):
         assert abs(sig[i, 0].item() - sigma.item()) < 1e-4 * abs(sigma.item()), n
         assert abs(sig[i, 1].item() * sigma.item() - 1.0) < 1e-4, n
         assert rel(us[DP.SN_ROW_OFF[i]:DP.SN_ROW_OFF[i] + rows], u) < 1e-4
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_sn_grad_kernel_vs_formula(hip_lib, paired):
+    """mtd_sn_grad alone: g_out += G/sigma - <G, W>/sigma^2 u v^T (torch.nn.utils.spectral_norm's backward with u, v
+    detached), for one and for two passes over the same weight, float4 and unaligned layers, 1..many blocks."""
+    import ctypes as C
+    from mtd_gan_amd import _lib, kernels as K
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(77 + paired)
+    shapes = [(64, 9), (64, 576), (130, 37), (512, 8192), (96, 1028)]
+    structs, keep, want = [], [], []
+    for (rows, cols) in shapes:
+        def rnd(*s):
+            return torch.randn(*s, generator=g)
+        W, G1, G2 = rnd(rows, cols), rnd(rows, cols), rnd(rows, cols)
+        u1, v1, u2, v2 = rnd(rows), rnd(cols), rnd(rows), rnd(cols)
+        s1, s2 = 1.7, 0.6
+        out0 = rnd(rows, cols)
+
+        def corr(Gm, u, v, s):
+            Gd, Wd = Gm.double(), W.double()
+            return Gd / s - (Gd * Wd).sum() / (s * s) * torch.outer(u.double(), v.double())
+        ref = out0.double() + corr(G1, u1, v1, s1) + (corr(G2, u2, v2, s2) if paired else 0.0)
+        t = {k: x.to(dev).contiguous() for k, x in dict(W=W, G1=G1, G2=G2, u1=u1, v1=v1, u2=u2, v2=v2, out=out0).items()}
+        t["s1"] = torch.tensor([s1, 1.0 / s1], device=dev)
+        t["s2"] = torch.tensor([s2, 1.0 / s2], device=dev)
+        keep.append(t)
+        want.append(ref)
+        s = _lib.SnGradLayer()
+        s.G, s.w, s.u, s.v, s.sigma = (t[k].data_ptr() for k in ("G1", "W", "u1", "v1", "s1"))
+        s.g_out, s.rows, s.cols, s.accumulate = t["out"].data_ptr(), rows, cols, 1
+        if paired:
+            s.G2, s.u2, s.v2, s.sigma2 = (t[k].data_ptr() for k in ("G2", "u2", "v2", "s2"))
+        structs.append(s)
+    L = _lib.lib()
+    tab, host = K.device_table(structs, dev)
+    need = L.mtd_sn_grad_ws_bytes(C.cast(host, C.c_void_p), len(structs))
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    K.check(L.mtd_sn_grad(tab.data_ptr(), C.cast(host, C.c_void_p), len(structs), ws.data_ptr(), K.stream_ptr()), "mtd_sn_grad")
+    torch.cuda.synchronize()
+    for t, ref, shp in zip(keep, want, shapes):
+        err = rel(t["out"], ref)       # fp32 rounding of <G, W> over up to 4 Mi products, relative to the largest entry
+        assert err < 2e-5, (shp, err)
