@@ -12,7 +12,7 @@ constexpr int MAXT = 4;
 constexpr int NPAIR = MAXT * (MAXT + 1) / 2;
 struct Vecs { const float* g[MAXT]; };
 
-__global__ __launch_bounds__(256) void gram_partial_kernel(Vecs v, int T, long long n, double* __restrict__ partial) {
+__global__ __launch_bounds__(256) void gram_partial_kernel(Vecs v, int T, long long n, int vec, double* __restrict__ partial) {
     __shared__ double red[256];
     float acc[NPAIR];
 #pragma unroll
@@ -22,7 +22,28 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(Vecs v, int T, long l
 #pragma unroll
     for (int i = 0; i < NPAIR; ++i) dacc[i] = 0.0;
     int cnt = 0;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
+    // 16-byte loads when every vector allows them (vec = 1), the last n % 4 entries and unaligned vectors one by one
+    const long long n4 = vec ? n / 4 : 0;
+    for (long long i4 = (long long)blockIdx.x * 256 + threadIdx.x; i4 < n4; i4 += (long long)gridDim.x * 256) {
+        f32x4 x[MAXT];
+#pragma unroll
+        for (int a = 0; a < MAXT; ++a) x[a] = (a < T) ? *reinterpret_cast<const f32x4*>(v.g[a] + 4 * i4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        int pi = 0;
+#pragma unroll
+        for (int a = 0; a < MAXT; ++a)
+#pragma unroll
+            for (int b = a; b < MAXT; ++b) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[pi] = fmaf(x[a][j], x[b][j], acc[pi]);
+                ++pi;
+            }
+        if (++cnt == 16) {
+#pragma unroll
+            for (int i = 0; i < NPAIR; ++i) { dacc[i] += (double)acc[i]; acc[i] = 0.f; }
+            cnt = 0;
+        }
+    }
+    for (long long idx = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
         float x[MAXT];
 #pragma unroll
         for (int a = 0; a < MAXT; ++a) x[a] = (a < T) ? v.g[a][idx] : 0.f;
@@ -51,11 +72,20 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(Vecs v, int T, long l
     }
 }
 
-__global__ void gram_finish_kernel(const double* __restrict__ partial, int nblocks, int T, double* __restrict__ gram) {
-    const int i = threadIdx.x;
-    if (i >= NPAIR) return;
+// one block per pair: strided sums in a fixed order, then a tree (doubles, bit-reproducible)
+__global__ __launch_bounds__(256) void gram_finish_kernel(const double* __restrict__ partial, int nblocks, int T, double* __restrict__ gram) {
+    __shared__ double red[256];
+    const int i = blockIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(long long)b * NPAIR + i];
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[(long long)b * NPAIR + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    s = red[0];
     int pi = 0;
     for (int a = 0; a < MAXT; ++a)
         for (int b = a; b < MAXT; ++b) {
@@ -125,9 +155,15 @@ extern "C" int mtd_pcgrad_gram(const float* g0, const float* g1, const float* g2
     hipStream_t s = (hipStream_t)stream;
     long long want = (n + 255) / 256;
     int blocks = (int)(want < GRAM_BLOCKS ? want : GRAM_BLOCKS);
-    hipLaunchKernelGGL(gram_partial_kernel, dim3(blocks), dim3(256), 0, s, v, T, n, (double*)ws);
+    int vec = 1;
+    for (int a = 0; a < T; ++a) vec &= (v.g[a] && aligned16(v.g[a])) ? 1 : 0;
+    if (vec) {
+        want = (n / 4 + 255) / 256;
+        blocks = (int)(want < GRAM_BLOCKS ? (want < 1 ? 1 : want) : GRAM_BLOCKS);
+    }
+    hipLaunchKernelGGL(gram_partial_kernel, dim3(blocks), dim3(256), 0, s, v, T, n, vec, (double*)ws);
     MTD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gram_finish_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, blocks, T, gram);
+    hipLaunchKernelGGL(gram_finish_kernel, dim3(NPAIR), dim3(256), 0, s, (const double*)ws, blocks, T, gram);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }
