@@ -247,8 +247,9 @@ int mtd_image_metrics(const float* a, const float* b, int B, int H, int W, int c
  * and returns one record per launch.  kernel: 0 = igemm_kernel, 1 = wgrad_kernel; cfg = tile configuration index
  * (the template instantiation); flops = 2*M*N*C*taps (dense algorithmic count).
  * Not for use while a hipGraph is being captured. */
-/* Tuning hook (tools/tune_igemm.py): force the tile configuration (0..5, -1 = automatic) and the split-K factor of
- * every following mtd_conv_igemm call in this process. */
+/* Tuning hook (tools/tune_igemm.py): force the tile configuration (0..8, -1 = automatic) and the split-K factor of
+ * every following mtd_conv_igemm call in this process.  9 / 10 leave the plan automatic and pick the persistent / the
+ * halo-tile kernel for the generator-shaped layers (C == 32, 3x3, M >= 32768). */
 int mtd_conv_igemm_override(int cfg, int splitk);
 int mtd_conv_wgrad_override(int cfg, int nsplit);      /* same for mtd_conv_wgrad: tile/tap-group config 0..6, pixel splits */
 

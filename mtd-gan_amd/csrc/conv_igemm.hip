@@ -52,6 +52,7 @@ struct IgemmParams {
     int tap_delta[16];              // byte displacement of tap t in the NHWC input
     int tap_kidx[16];               // index of tap t in the kh*kw plane of the weights
     int out_identity;  // output pixel index == launch-grid pixel index
+    int out_linear;    // 32 consecutive launch-grid pixels (from a multiple of 32) map to output pixels pix0 + r * out_sx
 };
 
 __device__ __forceinline__ long long out_pixel(const mtd_geom& g, int m, int identity) {
@@ -71,6 +72,125 @@ __device__ __forceinline__ float epilogue_value(const mtd_conv_args& a, float ac
     v = apply_act(v, a.act);
     if (a.mask) v *= (a.mask[pix * a.mask_ld + n] > 0.f) ? 1.f : a.mask_slope;
     return v;
+}
+
+// ---- epilogue of one 32 x 32 accumulator block ---------------------------------------------------------------------
+// A lane holds 16 values: rows mfma32_row(e, lane) of the block, column n.  Everything that is uniform per launch (the
+// output mapping, which operands exist, the activation) is decided ONCE around groups of NE values, and the operand loads
+// of a group are issued back to back; the per-element form (branches and an address division chain inside the loop,
+// each load followed by its use) cost ~100 instructions and a memory round trip per value.  With the identity output
+// mapping a value's address is (wave-uniform row base) + (one 32-bit lane offset), so a group needs no address registers.
+// The arithmetic per value and its order are those of epilogue_value().  Absent operands are the neutral elements -0.0f
+// (x + -0.0f == x for every x, signed zeros included) and a mask of 1.  Groups of 8 keep the generic kernels at their
+// main-loop register count; the halo-tile kernel loads all 16 before its MFMA loop.
+template <int NE> struct EpiOps { float e1[NE], e2[NE], em[NE]; };
+
+// Addresses of values E0 .. E0+NE-1 of a block whose 32 rows map to output pixels pix0 + r * step ("linear": the identity
+// mapping, or a strided one on rows of >= 32 pixels -- p.out_linear).
+template <bool FULL, int E0, int NE>
+struct EpiAddr {
+    int mu, lane, lane_row, n, step;
+    long long pix0;
+    __device__ __forceinline__ void init(const IgemmParams& p, int mrow0, int lane_, int n_) {
+        mu = __builtin_amdgcn_readfirstlane(mrow0);
+        lane = lane_;
+        n = n_;
+        step = p.out_identity ? 1 : p.a.g.out_sx;
+        lane_row = 4 * (lane_ >> 5) * step;
+        pix0 = p.out_identity ? (long long)mu : out_pixel(p.a.g, mu, 0);
+    }
+    __device__ __forceinline__ bool ok(const IgemmParams& p, int i) const { return FULL || mu + mfma32_row(E0 + i, lane) < p.M; }
+    template <typename Tp>
+    __device__ __forceinline__ Tp* at(Tp* base, int ld, int i) const {
+        return base + (pix0 + (((E0 + i) & 3) + 8 * ((E0 + i) >> 2)) * step) * ld + (lane_row * ld + n);
+    }
+};
+
+template <bool FULL, int E0, int NE>
+__device__ __forceinline__ void epi_load(const IgemmParams& p, const EpiAddr<FULL, E0, NE>& ad, EpiOps<NE>& o) {
+    const mtd_conv_args& a = p.a;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) { o.e1[i] = -0.0f; o.e2[i] = -0.0f; o.em[i] = 1.f; }
+    if (a.add1) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+            if (ad.ok(p, i)) o.e1[i] = *ad.at(a.add1, a.add1_ld, i);
+    }
+    if (a.add2) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+            if (ad.ok(p, i)) o.e2[i] = *ad.at(a.add2, a.add2_ld, i);
+    }
+    if (a.mask) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+            if (ad.ok(p, i)) o.em[i] = *ad.at(a.mask, a.mask_ld, i);
+    }
+}
+
+template <bool FULL, int E0, int NE>
+__device__ __forceinline__ void epi_store(const IgemmParams& p, const f32x16& acc, const EpiAddr<FULL, E0, NE>& ad, const ScalePair& sp,
+                                          float bias_n, const EpiOps<NE>& o) {
+    const mtd_conv_args& a = p.a;
+    float v[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        v[i] = acc[E0 + i] * pick_scale(sp, ad.mu + mfma32_row(E0 + i, ad.lane)) + bias_n;
+        v[i] += o.e1[i];
+        v[i] += o.e2[i];
+    }
+    if (a.act == MTD_ACT_RELU) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+    } else if (a.act == MTD_ACT_LRELU) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) v[i] = v[i] > 0.f ? v[i] : 0.2f * v[i];
+    }
+    if (a.mask) {
+        const float slope = a.mask_slope;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) v[i] *= (o.em[i] > 0.f) ? 1.f : slope;
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i)
+        if (ad.ok(p, i)) *ad.at(a.out, a.out_ld, i) = v[i];
+}
+
+template <bool FULL, int E0>
+__device__ __forceinline__ void epi_group8(const IgemmParams& p, const f32x16& acc, int mrow0, int lane, int n, const ScalePair& sp,
+                                           float bias_n) {
+    EpiAddr<FULL, E0, 8> ad;
+    EpiOps<8> o;
+    ad.init(p, mrow0, lane, n);
+    epi_load(p, ad, o);
+    epi_store(p, acc, ad, sp, bias_n, o);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// rows mrow0 .. mrow0 + 31 of the launch (mrow0 is wave-uniform and a multiple of 32), column n of this lane
+__device__ __forceinline__ void epilogue16(const IgemmParams& p, const f32x16& acc, int mrow0, int lane, int n, const ScalePair& sp) {
+    if (mrow0 >= p.M) return;
+    const mtd_conv_args& a = p.a;
+    const float bias_n = a.bias ? a.bias[n] : 0.f;
+    if (p.out_linear) {
+        if (mrow0 + 32 <= p.M) {
+            epi_group8<true, 0>(p, acc, mrow0, lane, n, sp, bias_n);
+            epi_group8<true, 8>(p, acc, mrow0, lane, n, sp, bias_n);
+        } else {
+            epi_group8<false, 0>(p, acc, mrow0, lane, n, sp, bias_n);
+            epi_group8<false, 8>(p, acc, mrow0, lane, n, sp, bias_n);
+        }
+        return;
+    }
+    // small maps with a strided output (rows shorter than a block): value by value
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = mrow0 + mfma32_row(e, lane);
+        if (m < p.M) {
+            const long long pix = out_pixel(a.g, m, 0);
+            a.out[pix * a.out_ld + n] = epilogue_value(a, acc[e], pick_scale(sp, m), bias_n, pix, n);
+        }
+    }
 }
 
 template <int WM, int WN, int WGM, int WGN>
@@ -274,15 +394,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(cons
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             const int n = n0 + (wn * WN + j) * 32 + l31;
-            const float bias_n = a.bias ? a.bias[n] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + (wm * WM + i) * 32 + mfma32_row(e, lane);
-                if (m < p.M) {
-                    const long long pix = out_pixel(g, m, p.out_identity);
-                    a.out[pix * a.out_ld + n] = epilogue_value(a, acc[i][j][e], pick_scale(sp, m), bias_n, pix, n);
-                }
-            }
+            epilogue16(p, acc[i][j], m0 + (wm * WM + i) * 32, lane, n, sp);
         }
     MTD_STAMP(61);
 }
@@ -442,16 +554,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tb_kernel(const IgemmParams p) {
     const ScalePair sp = load_scale(a);
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
-        const int n = n0 + l31;
-        const float bias_n = a.bias ? a.bias[n] : 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = m0 + (wave * WM + i) * 32 + mfma32_row(e, lane);
-            if (m < p.M) {
-                const long long pix = out_pixel(g, m, p.out_identity);
-                a.out[pix * a.out_ld + n] = epilogue_value(a, acc[i][e], pick_scale(sp, m), bias_n, pix, n);
-            }
-        }
+        epilogue16(p, acc[i], m0 + (wave * WM + i) * 32, lane, n0 + l31, sp);
     }
 }
 
@@ -485,7 +588,6 @@ __global__ __launch_bounds__(256, 2) void igemm_c32p_kernel(const IgemmParams p,
     if (tile >= ntiles) return;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)p.in_bytes, 0x00020000);
     const ScalePair sp = load_scale(a);
-    const float bias_n = a.bias ? a.bias[n0 + l31] : 0.f;
 
     unsigned boff = 0, okmask = 0;
     auto setup = [&](int tl, unsigned& bo, unsigned& ok) {
@@ -548,20 +650,132 @@ __global__ __launch_bounds__(256, 2) void igemm_c32p_kernel(const IgemmParams p,
             __builtin_amdgcn_sched_barrier(0);
         }
         // epilogue of this tile (the next tile's first fragments are already in flight)
-        const int n = n0 + l31;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = tile * 32 + mfma32_row(e, lane);
-            if (m < p.M) {
-                const long long pix = out_pixel(g, m, p.out_identity);
-                a.out[pix * a.out_ld + n] = epilogue_value(a, acc[e], pick_scale(sp, m), bias_n, pix, n);
-            }
-        }
+        epilogue16(p, acc, tile * 32, lane, n0 + l31, sp);
         if (next >= ntiles) break;
         tile = next;
         boff = boff2;
         okmask = ok2;
     }
+}
+
+
+// ---- halo-tile variant of the same layers (C == 32, 3x3, stride 1, "same" padding, 64-pixel image rows) ----------------
+// The persistent kernel above re-reads its 32 pixels x 128 bytes for every tap (9 x 16.8 MB of L2 traffic per launch at
+// M = 131072).  Here a workgroup of eight waves owns four image rows (256 pixels) at a time: the 6 x 66-pixel halo tile
+// goes global -> LDS ONCE by LDS-DMA (out-of-image pixels are out-of-range offsets and arrive as zeros, which is the
+// padding), and the nine taps read their A fragments from it -- conflict-free b128 reads through the piece ^ (pixel & 7)
+// permutation, applied on the DMA's source side.  The nine [32 n][32 c] weight blocks are DMA'd once per workgroup, same
+// layout.  One workgroup per CU walks tiles blockIdx.x, + gridDim.x, ...; the next tile's DMA and this tile's epilogue
+// operands are requested before the MFMA loop and waited for after it, and the output stores drain under the next
+// tile's MFMAs, so memory phases and MFMA phases of a CU overlap instead of alternating chip-wide.
+// LDS: 2 x 50 KB tiles + 36 KB weights.
+constexpr int C32T_W = 64, C32T_R = 4, C32T_HW = C32T_W + 2, C32T_HP = (C32T_R + 2) * C32T_HW, C32T_NI = (C32T_HP + 7) / 8;
+
+__global__ __launch_bounds__(512, 1) void igemm_c32t_kernel(const IgemmParams p, int ntiles) {
+    constexpr int T = 9;
+    __shared__ __attribute__((aligned(1024))) float Hs[2][C32T_NI * 8 * 32];
+    __shared__ __attribute__((aligned(1024))) float Bs[T * 32 * 32];
+    const mtd_conv_args& a = p.a;
+    const mtd_geom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int n0 = blockIdx.y * 32;
+    const int tiles_per_image = g.OH / C32T_R;
+    typedef __attribute__((address_space(3))) float lds_f;
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)p.in_bytes, 0x00020000);
+    const int rsub = lane >> 3, piece = (lane & 7) ^ rsub;
+
+    // DMA instruction i of a tile moves halo pixels 8i .. 8i+7: lane L -> pixel 8i + (L >> 3), LDS piece L & 7
+    auto stage_tile = [&](int tile, int buf) {
+        const int b = tile / tiles_per_image;
+        const int oy0 = (tile - b * tiles_per_image) * C32T_R;
+        for (int i = wave; i < C32T_NI; i += 8) {
+            const int hp = 8 * i + rsub;
+            const int hr = hp / C32T_HW, hc = hp - hr * C32T_HW;
+            const int iy = oy0 - 1 + hr, ix = hc - 1;
+            const bool ok = (hp < C32T_HP) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
+            const unsigned voff = ok ? (unsigned)(((((long long)b * g.IH + iy) * g.IW + ix) * a.in_ld + piece * 4) * 4) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_f*)&Hs[buf][i * 256], 16, voff, 0, 0, 0);
+        }
+    };
+    MTD_STAMP(0);
+    int tile = blockIdx.x;
+    stage_tile(tile, 0);
+    {   // weights: row r = tap * 32 + n of a [288][32 c] matrix, same piece permutation
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), (short)0, (int)p.w_bytes, 0x00020000);
+        for (int i = wave; i < T * 4; i += 8) {
+            const int t = i >> 2, nn = 8 * (i & 3) + rsub;
+            const unsigned voff = (unsigned)(((long long)(n0 + nn) * a.w_sn + (long long)p.tap_kidx[t] * a.w_st + piece * 4) * 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_f*)&Bs[i * 256], 16, voff, 0, 0, 0);
+        }
+    }
+    MTD_STAMP(1);
+    const ScalePair sp = load_scale(a);
+    const int n = n0 + l31;
+    const float bias_n = a.bias ? a.bias[n] : 0.f;
+    const int bsw = l31 & 7;
+    // this wave's 32 pixels of a tile: tile row wave >> 1, columns 32 * (wave & 1) + l31; halo index of the pixel itself:
+    const int hp0 = ((wave >> 1) + 1) * C32T_HW + (wave & 1) * 32 + l31 + 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    MTD_STAMP(2);
+    int cur = 0;
+    while (true) {
+        const int next = tile + gridDim.x;
+        if (next < ntiles) stage_tile(next, cur ^ 1);      // every wave is past its MFMAs on that buffer (barrier below)
+        const int mbase = tile * (C32T_R * C32T_W) + wave * 32;
+        EpiAddr<true, 0, 16> ead;
+        EpiOps<16> eo;
+        ead.init(p, mbase, lane, n);
+        epi_load(p, ead, eo);
+        __builtin_amdgcn_sched_barrier(0);
+        const float* H = Hs[cur];
+        auto frag = [&](int t, f32x4* af, f32x4* bf) {
+            const int hp = hp0 + (g.off_y + p.tap_dy[t]) * C32T_HW + (g.off_x + p.tap_dx[t]);
+            const float* px = &H[hp * 32];
+            const int sw = hp & 7;
+            const float* row = &Bs[(t * 32 + l31) * 32];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                af[q] = *reinterpret_cast<const f32x4*>(px + (((kh * 4 + q) ^ sw) << 2));
+                bf[q] = *reinterpret_cast<const f32x4*>(row + (((kh * 4 + q) ^ bsw) << 2));
+            }
+        };
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        f32x4 af[2][4], bf[2][4];
+        frag(0, af[0], bf[0]);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (t + 1 < T) frag(t + 1, af[(t + 1) & 1], bf[(t + 1) & 1]);
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) acc = mfma32(af[t & 1][kk >> 2][kk & 3], bf[t & 1][kk >> 2][kk & 3], acc);
+        }
+        MTD_STAMP(3 + 3 * (cur));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile and this tile's epilogue operands have landed
+        MTD_STAMP(4 + 3 * (cur));
+        epi_store(p, acc, ead, sp, bias_n, eo);                // stores drain under the next tile's MFMAs
+        MTD_STAMP(5 + 3 * (cur));
+        if (next >= ntiles) break;
+        __syncthreads();
+        tile = next;
+        cur ^= 1;
+    }
+}
+
+// the halo-tile kernel's geometry: 3x3, stride 1, every tap within one pixel of the output position, 64-pixel rows
+bool c32t_eligible(const mtd_conv_args& a) {
+    const mtd_geom& g = a.g;
+    if (a.C != 32 || g.TH != 3 || g.TW != 3 || g.in_sy != 1 || g.in_sx != 1) return false;
+    if (g.OW != C32T_W || g.IW != C32T_W || g.IH != g.OH || (g.OH % C32T_R)) return false;
+    if (!(g.out_sy == 1 && g.out_sx == 1 && g.out_oy == 0 && g.out_ox == 0 && g.OHF == g.OH && g.OWF == g.OW)) return false;
+    for (int i = 0; i < 3; ++i) {
+        const int dy = g.off_y + i * g.tap_dy, dx = g.off_x + i * g.tap_dx;
+        if (dy < -1 || dy > 1 || dx < -1 || dx > 1) return false;
+    }
+    return true;
 }
 
 
@@ -693,16 +907,7 @@ __global__ __launch_bounds__(256, 2) void igemm_v2_kernel(const IgemmParams p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + l31;
-            const float bias_n = a.bias ? a.bias[n] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + i * 32 + mfma32_row(e, lane);
-                if (m < p.M) {
-                    const long long pix = out_pixel(g, m, p.out_identity);
-                    a.out[pix * a.out_ld + n] = epilogue_value(a, acc[i][j][e], pick_scale(sp, m), bias_n, pix, n);
-                }
-            }
+            epilogue16(p, acc[i][j], m0 + wm * 64 + i * 32, lane, n0 + wn * 64 + j * 32 + l31, sp);
         }
 }
 
@@ -840,12 +1045,23 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
     }
     const mtd_geom& g = a->g;
     p.out_identity = (g.out_sy == 1 && g.out_sx == 1 && g.out_oy == 0 && g.out_ox == 0 && g.OHF == g.OH && g.OWF == g.OW);
+    p.out_linear = p.out_identity || (g.OW % 32 == 0);
     if (pl.splitk > 1) {
         size_t need = (size_t)pl.splitk * (size_t)p.M * a->N * sizeof(float);
         if (!a->ws || a->ws_bytes < need) return MTD_EWS;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (g_force_cfg == -1 && a->C == 32 && a->g.TH * a->g.TW == 9 && p.M >= 32768) {
+    const bool gen_shape = a->C == 32 && a->g.TH * a->g.TW == 9 && p.M >= 32768;
+    if ((g_force_cfg == -1 || g_force_cfg == 10) && gen_shape && c32t_eligible(*a)) {
+        // generator-shaped layers on 64-pixel rows: halo tiles of four image rows, one persistent workgroup per CU
+        const int prof = mtd_prof_begin(0, 10, 1, p.M, a->N, a->C, 9, s);
+        const int ntiles = p.M / (C32T_R * C32T_W);
+        hipLaunchKernelGGL(igemm_c32t_kernel, dim3(ntiles < 256 ? ntiles : 256, a->N / 32), dim3(512), 0, s, p, ntiles);
+        mtd_prof_end(prof, s);
+        MTD_LAUNCH_CHECK();
+        return MTD_OK;
+    }
+    if ((g_force_cfg == -1 || g_force_cfg == 9) && gen_shape) {
         // generator-shaped layers: persistent kernel, two 32-pixel tiles per wave at M = 131072
         const int ntiles = (p.M + 31) / 32;
         int wgs = (ntiles + 7) / 8;

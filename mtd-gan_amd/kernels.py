@@ -74,7 +74,7 @@ CALL_LOG = None     # tools/tune_igemm.py: a list collects ("igemm" | "wgrad", b
 
 IGEMM_CONFIGS = ["igemm_kernel<2, 1, 4, 1>", "igemm_kernel<1, 1, 4, 1>", "igemm_kernel<2, 2, 4, 1>",
                  "igemm_kernel<1, 1, 2, 2>", "igemm_kernel<2, 2, 2, 2>", "igemm_kernel<1, 1, 1, 4>",
-                 "igemm_tb_kernel<1>", "igemm_tb_kernel<2>", "igemm_v2_kernel<0>", "igemm_c32p_kernel"]
+                 "igemm_tb_kernel<1>", "igemm_tb_kernel<2>", "igemm_v2_kernel<0>", "igemm_c32p_kernel", "igemm_c32t_kernel"]
 WGRAD_CONFIGS = ["wgrad_kernel<1, 1, 9>", "wgrad_kernel<1, 1, 4>", "wgrad_kernel<2, 2, 1>", "wgrad_kernel<1, 1, 8>",
                  "wgrad_kernel<1, 1, 3>", "wgrad_kernel<1, 1, 1>", "wgrad_kernel<2, 2, 3>",
                  "wgrad_row_kernel<3, 3, 1>", "wgrad_row_kernel<3, 3, -1>", "wgrad_row_kernel<1, 1, 1>",
@@ -100,6 +100,17 @@ def prof_collect(capacity):
                     "C": r.C, "taps": r.taps, "flops": r.flops, "ms": r.ms})
     return out
 
+
+def igemm_override(cfg, splitk=1):
+    """Tuning / diagnostic hook (mtd_conv_igemm_override): force an implicit-GEMM instantiation; (-1, -1) restores the plan."""
+    L = _lib.lib()
+    L.mtd_conv_igemm_override.argtypes = [C.c_int, C.c_int]
+    L.mtd_conv_igemm_override(cfg, splitk)
+    _igemm_ws_cache.clear()
+
+
+if os.environ.get("MTD_IGEMM_CFG"):        # diagnostic switch, e.g. MTD_IGEMM_CFG=9: persistent kernel for the 32-channel 3x3 layers
+    igemm_override(int(os.environ["MTD_IGEMM_CFG"]), 1)
 
 _raw_stream = torch._C._cuda_getCurrentRawStream       # (device index) -> hipStream_t as int; no Python Stream objects
 _cur_device = torch._C._cuda_getDevice

@@ -271,3 +271,42 @@ def test_igemm_every_tile_config(hip_lib, cfg):
     finally:
         L.mtd_conv_igemm_override(-1, -1)
         K._igemm_ws_cache.clear()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [-1, 9, 10])
+def test_igemm_generator_shaped_kernels(hip_lib, cfg):
+    """The two kernels for the generator's 32-channel 3x3 layers on 64 x 64 maps (9 = persistent, 10 = halo tile, -1 = the
+    library's choice): forward with the full epilogue, 64 output channels, and the stride-1 data gradient, against F.conv2d."""
+    import ctypes as C
+    from mtd_gan_amd import _lib, kernels as K
+    L = _lib.lib()
+    L.mtd_conv_igemm_override.argtypes = [C.c_int, C.c_int]
+    B, H = 20, 64            # 320 four-row tiles: the halo-tile kernel's workgroups take one or two each
+    try:
+        L.mtd_conv_igemm_override(cfg, 1)
+        K._igemm_ws_cache.clear()
+        for Co in (32, 64):
+            x = rnd(B, 32, H, H, seed=21)
+            w = rnd(Co, 32, 3, 3, seed=22, scale=0.06)
+            bias = rnd(Co, seed=23)
+            res = rnd(B, Co, H, H, seed=24)
+            ref = F.leaky_relu(F.conv2d(x, w, bias, padding=1) + res, 0.2)
+            out = torch.empty(B, H, H, Co, device="cuda")
+            K.conv(nhwc(x), w.cuda(), K.geom_fwd(B, H, H, 3, 1, 1), Co, 32, 32 * 9, 9, out, bias=bias.cuda(), add1=nhwc(res),
+                   act=_lib.ACT_LRELU)
+            assert relerr(nchw(out), ref) < TOL, (cfg, Co)
+        # data gradient of a 32 -> 32 layer (flipped taps), input a 32-channel slice of a wider tensor
+        x = rnd(B, 32, H, H, seed=25).requires_grad_(True)
+        w = rnd(32, 32, 3, 3, seed=26, scale=0.06)
+        y = F.conv2d(x, w, None, padding=1)
+        cot = rnd(*y.shape, seed=27)
+        (y * cot).sum().backward()
+        wide = torch.zeros(B, H, H, 48, device="cuda")
+        wide[..., 8:40] = nhwc(cot)
+        dx = torch.empty(B, H, H, 32, device="cuda")
+        K.conv(wide[..., 8:40], w.cuda(), K.geom_dgrad_s1(B, H, H, 3, 1), 32, 32, 9, 32 * 9, dx)
+        assert relerr(nchw(dx), x.grad) < TOL, (cfg, "dgrad")
+    finally:
+        L.mtd_conv_igemm_override(-1, -1)
+        K._igemm_ws_cache.clear()
