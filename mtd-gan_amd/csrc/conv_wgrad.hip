@@ -215,47 +215,52 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 // Epilogue of the register-operand kernels: sum the four waves of the workgroup through LDS (fixed order), then wave 0
 // writes the tile -- into the workgroup's slab, or, when the launch has a single pixel split, straight into the strided
 // parameter-gradient view (no reduce kernels at all).
-template <int T>
+template <int T, int NW>
 __device__ __forceinline__ void reg_kernel_epilogue(const WgradParams& p, f32x16 (&acc)[T], float bsum, float* Ls, int n0, int c0,
                                                     bool do_bias) {
     const mtd_wgrad_args& a = p.a;
     const mtd_geom& g = a.g;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31;
     const bool direct = (p.nslab == 1);
+    constexpr int EPW = 16 / NW;        // values per lane that each wave finishes (sum over waves 0, 1, ... in that order)
     float* slab = a.ws + (long long)blockIdx.x * p.slab_stride;
-    float* red = Ls;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         __syncthreads();
-        if (wave > 0) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) red[(wave - 1) * 1024 + e * 64 + lane] = acc[t][e];
-        }
+        for (int e = 0; e < 16; ++e) Ls[wave * 1024 + e * 64 + lane] = acc[t][e];
         __syncthreads();
-        if (wave == 0) {
-            const int ty = t / g.TW, tx = t % g.TW;
-            const int kidx = (g.ky0 + ty * g.ky_step) * g.KW + (g.kx0 + tx * g.kx_step);
+        const int ty = t / g.TW, tx = t % g.TW;
+        const int kidx = (g.ky0 + ty * g.ky_step) * g.KW + (g.kx0 + tx * g.kx_step);
+        float v[EPW];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float v = acc[t][e] + red[e * 64 + lane] + red[1024 + e * 64 + lane] + red[2048 + e * 64 + lane];
-                const int n = n0 + mfma32_row(e, lane);
-                const int cc = c0 + l31;
-                if (direct) {
-                    float* dst = a.dw + (long long)n * a.w_sn + (long long)cc * a.w_sc + kidx;
-                    *dst = (a.accumulate & 1) ? (*dst + v) : v;
-                } else {
-                    slab[((long long)t * a.N + n) * a.C + cc] = v;
-                }
+        for (int i = 0; i < EPW; ++i) {
+            const int e = wave * EPW + i;
+            v[i] = Ls[e * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) v[i] += Ls[w * 1024 + e * 64 + lane];
+        }
+#pragma unroll
+        for (int i = 0; i < EPW; ++i) {
+            const int e = wave * EPW + i;
+            const int n = n0 + mfma32_row(e, lane);
+            const int cc = c0 + l31;
+            if (direct) {
+                float* dst = a.dw + (long long)n * a.w_sn + (long long)cc * a.w_sc + kidx;
+                *dst = (a.accumulate & 1) ? (*dst + v[i]) : v[i];
+            } else {
+                slab[((long long)t * a.N + n) * a.C + cc] = v[i];
             }
         }
     }
     if (do_bias) {
+        float* red = Ls + NW * 1024;
         __syncthreads();
-        red[3072 + wave * 64 + lane] = bsum;
+        red[wave * 64 + lane] = bsum;
         __syncthreads();
         if (wave == 0 && lane < 32) {
             float s2 = 0.f;
-            for (int wv = 0; wv < 4; ++wv) s2 += red[3072 + wv * 64 + lane] + red[3072 + wv * 64 + lane + 32];
+            for (int wv = 0; wv < NW; ++wv) s2 += red[wv * 64 + lane] + red[wv * 64 + lane + 32];
             if (direct) {
                 float* dst = a.db + n0 + lane;
                 *dst = (a.accumulate & 2) ? (*dst + s2) : s2;
@@ -275,17 +280,17 @@ __device__ __forceinline__ void reg_kernel_epilogue(const WgradParams& p, f32x16
 // a filter row read the same 16 + TW - 1 input pixels shifted by one: each row of the window is loaded once and
 // serves TW taps (54 instead of 144 Q loads per chunk for 3x3).  The next window row (or the next chunk's P and
 // first row) is in flight under the current row's 16 * TW MFMAs.
-template <int TH, int TW, int DX>
-__global__ __launch_bounds__(256, 2) void wgrad_row_kernel(const WgradParams p) {
+template <int TH, int TW, int DX, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 4) ? 2 : 1) void wgrad_row_kernel(const WgradParams p) {
     constexpr int T = TH * TW, WIN = 16 + TW - 1;
-    __shared__ __attribute__((aligned(16))) float Ls[3 * 1024 + 256];
+    __shared__ __attribute__((aligned(16))) float Ls[NW * 1024 + NW * 64];
     const mtd_wgrad_args& a = p.a;
     const mtd_geom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
     const int ntile = blockIdx.y / p.nCt, ctile = blockIdx.y % p.nCt;
     const int n0 = ntile * 32, c0 = ctile * 32;
-    const int mwave0 = (blockIdx.x * 4 + wave) * p.ppw;
+    const int mwave0 = (blockIdx.x * NW + wave) * p.ppw;
     const bool do_bias = (a.db != nullptr) && ctile == 0;
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p), (short)0, (int)p.p_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.q), (short)0, (int)p.q_bytes, 0x00020000);
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_row_kernel(const WgradParams p) 
         }
     }
 
-    reg_kernel_epilogue<T>(p, acc, bsum, Ls, n0, c0, do_bias);
+    reg_kernel_epilogue<T, NW>(p, acc, bsum, Ls, n0, c0, do_bias);
 }
 
 
@@ -390,18 +395,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_row_kernel(const WgradParams p) 
 // input: 32 (8x8: two rows + one halo row either side) or 16 loads per 32-pixel chunk instead of 144, no LDS, no
 // per-tap address arithmetic -- and k-steps whose tap falls into the zero padding for every lane are not issued at all
 // (8 % / 31 % / 56 % of the MFMAs for 8x8 / 4x4 / 2x2).
-template <int W>
-__global__ __launch_bounds__(256, (W == 8) ? 1 : 2) void wgrad_blk_kernel(const WgradParams p) {
+template <int W, int NW>
+__global__ __launch_bounds__(NW * 64, (W == 8 || NW == 8) ? 1 : 2) void wgrad_blk_kernel(const WgradParams p) {
     constexpr int T = 9;
     constexpr int HALO = (W == 8) ? 8 : 0;
     constexpr int NQ = 16 + 2 * HALO;
-    __shared__ __attribute__((aligned(16))) float Ls[3 * 1024 + 256];
+    __shared__ __attribute__((aligned(16))) float Ls[NW * 1024 + NW * 64];
     const mtd_wgrad_args& a = p.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
     const int ntile = blockIdx.y / p.nCt, ctile = blockIdx.y % p.nCt;
     const int n0 = ntile * 32, c0 = ctile * 32;
-    const int mwave0 = (blockIdx.x * 4 + wave) * p.ppw;
+    const int mwave0 = (blockIdx.x * NW + wave) * p.ppw;
     const bool do_bias = (a.db != nullptr) && ctile == 0;
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p), (short)0, (int)p.p_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.q), (short)0, (int)p.q_bytes, 0x00020000);
@@ -491,7 +496,7 @@ __global__ __launch_bounds__(256, (W == 8) ? 1 : 2) void wgrad_blk_kernel(const 
             for (int j = 0; j < NQ; ++j) qf[j] = qn[j];
         }
     }
-    reg_kernel_epilogue<T>(p, acc, bsum, Ls, n0, c0, do_bias);
+    reg_kernel_epilogue<T, NW>(p, acc, bsum, Ls, n0, c0, do_bias);
 }
 
 // out[g][idx] = sum_{s in group g} in[s][idx]     (group size gs), fixed order
@@ -531,9 +536,10 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const WgradParams p, 
     }
 }
 
-struct WPlan { int cfg, WN, WC, TG, ppw, nsplit, ntg; };
+struct WPlan { int cfg, WN, WC, TG, ppw, nsplit, ntg, nw; };
 
 int g_wforce_cfg = -1, g_wforce_split = -1;     // tuning hook (mtd_conv_wgrad_override)
+int g_wforce_nw = 0;                            // waves per workgroup of the register-operand kernels (env MTD_WGRAD_NW, lab only)
 constexpr int NWCFG = 7;
 const int kWcfgWN[NWCFG] = {1, 1, 2, 1, 1, 1, 2};
 const int kWcfgWC[NWCFG] = {1, 1, 2, 1, 1, 1, 2};
@@ -574,9 +580,12 @@ WPlan make_wplan(const mtd_wgrad_args& a) {
         long long max_splits = (M + 127) / 128;
         long long ns = want_splits < 1 ? 1 : want_splits;
         if (ns > max_splits) ns = max_splits;
-        long long ppw = (M + ns * 4 - 1) / (ns * 4);
+        // four waves per workgroup; eight (two per SIMD, same workgroup count and slab traffic) measured 1 % faster
+        // standalone and no different inside the step, so it stays a lab switch (MTD_WGRAD_NW=8)
+        pl.nw = (g_wforce_nw == 8 && bw != 8) ? 8 : 4;    // (the 8x8 window kernel needs more than 256 registers)
+        long long ppw = (M + ns * pl.nw - 1) / (ns * pl.nw);
         ppw = ((ppw + 31) / 32) * 32;
-        ns = (M + ppw * 4 - 1) / (ppw * 4);
+        ns = (M + ppw * pl.nw - 1) / (ppw * pl.nw);
         pl.ppw = (int)ppw;
         pl.nsplit = (int)ns;
         return pl;
@@ -587,6 +596,7 @@ WPlan make_wplan(const mtd_wgrad_args& a) {
     pl.WC = kWcfgWC[pl.cfg];
     pl.TG = kWcfgTG[pl.cfg];
     pl.ntg = (T + pl.TG - 1) / pl.TG;
+    pl.nw = 4;
     long long tiles = (long long)(a.N / (32 * pl.WN)) * (a.C / (32 * pl.WC)) * pl.ntg;
     // aim for >= 512 workgroups; every wave gets a multiple of 32 pixels
     long long want_splits = (512 + tiles - 1) / tiles;
@@ -657,6 +667,8 @@ extern "C" size_t mtd_conv_wgrad_ws_bytes(const mtd_wgrad_args* a) {
 
 extern "C" int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream) {
     if (!a) return MTD_EINVAL;
+    static const int env_nw = [] { const char* e = getenv("MTD_WGRAD_NW"); return e ? atoi(e) : 0; }();
+    if (env_nw == 4 || env_nw == 8) g_wforce_nw = env_nw;
     int rc = check_wargs(*a);
     if (rc != MTD_OK) return rc;
     const bool direct = is_direct(*a);
@@ -704,12 +716,22 @@ extern "C" int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream) {
             case 2: hipLaunchKernelGGL((wgrad_kernel<2, 2, 1>), grid, dim3(256), 0, s, p); break;
             case 3: hipLaunchKernelGGL((wgrad_kernel<1, 1, 8>), grid, dim3(256), 0, s, p); break;
             case 4: hipLaunchKernelGGL((wgrad_kernel<1, 1, 3>), grid, dim3(256), 0, s, p); break;
-            case 7: hipLaunchKernelGGL((wgrad_row_kernel<3, 3, 1>), grid, dim3(256), 0, s, p); break;
-            case 8: hipLaunchKernelGGL((wgrad_row_kernel<3, 3, -1>), grid, dim3(256), 0, s, p); break;
-            case 9: hipLaunchKernelGGL((wgrad_row_kernel<1, 1, 1>), grid, dim3(256), 0, s, p); break;
-            case 10: hipLaunchKernelGGL((wgrad_blk_kernel<8>), grid, dim3(256), 0, s, p); break;
-            case 11: hipLaunchKernelGGL((wgrad_blk_kernel<4>), grid, dim3(256), 0, s, p); break;
-            case 12: hipLaunchKernelGGL((wgrad_blk_kernel<2>), grid, dim3(256), 0, s, p); break;
+            case 7: if (pl.nw == 8) hipLaunchKernelGGL((wgrad_row_kernel<3, 3, 1, 8>), grid, dim3(512), 0, s, p);
+                    else hipLaunchKernelGGL((wgrad_row_kernel<3, 3, 1, 4>), grid, dim3(256), 0, s, p);
+                    break;
+            case 8: if (pl.nw == 8) hipLaunchKernelGGL((wgrad_row_kernel<3, 3, -1, 8>), grid, dim3(512), 0, s, p);
+                    else hipLaunchKernelGGL((wgrad_row_kernel<3, 3, -1, 4>), grid, dim3(256), 0, s, p);
+                    break;
+            case 9: if (pl.nw == 8) hipLaunchKernelGGL((wgrad_row_kernel<1, 1, 1, 8>), grid, dim3(512), 0, s, p);
+                    else hipLaunchKernelGGL((wgrad_row_kernel<1, 1, 1, 4>), grid, dim3(256), 0, s, p);
+                    break;
+            case 10: hipLaunchKernelGGL((wgrad_blk_kernel<8, 4>), grid, dim3(256), 0, s, p); break;
+            case 11: if (pl.nw == 8) hipLaunchKernelGGL((wgrad_blk_kernel<4, 8>), grid, dim3(512), 0, s, p);
+                     else hipLaunchKernelGGL((wgrad_blk_kernel<4, 4>), grid, dim3(256), 0, s, p);
+                     break;
+            case 12: if (pl.nw == 8) hipLaunchKernelGGL((wgrad_blk_kernel<2, 8>), grid, dim3(512), 0, s, p);
+                     else hipLaunchKernelGGL((wgrad_blk_kernel<2, 4>), grid, dim3(256), 0, s, p);
+                     break;
             case 5: hipLaunchKernelGGL((wgrad_kernel<1, 1, 1>), grid, dim3(256), 0, s, p); break;
             default: hipLaunchKernelGGL((wgrad_kernel<2, 2, 3>), grid, dim3(256), 0, s, p); break;
         }

@@ -12,15 +12,20 @@ static mtd_geom geom_fwd(int B, int H, int W, int k, int s, int p) {
     mtd_geom g = {B, H, W, OH, OW, s, s, -p, -p, 1, 1, k, k, k, 0, 0, 1, 1, OH, OW, 1, 1, 0, 0};
     return g;
 }
-int main() {
-    const int B = 32, H = 64, W = 64, C = 32, N = 32;
+int mtd_prof_begin(int, int, int, long long, int, int, int, hipStream_t) { return -1; }
+void mtd_prof_end(int, hipStream_t) {}
+int main(int argc, char** argv) {
+    // igemm_stamp [B H C N cfg]   (default: the generator's 32 -> 32 layer at batch 32 under config 1)
+    const int B = argc > 1 ? atoi(argv[1]) : 32, H = argc > 2 ? atoi(argv[2]) : 64, W = H;
+    const int C = argc > 3 ? atoi(argv[3]) : 32, N = argc > 4 ? atoi(argv[4]) : 32;
+    mtd_conv_igemm_override(argc > 5 ? atoi(argv[5]) : 1, 1);
     float *in, *w, *out, *bias;
     (void)hipMalloc(&in, (size_t)B * H * W * C * 4);
     (void)hipMalloc(&out, (size_t)B * H * W * N * 4);
-    (void)hipMalloc(&w, 9 * N * C * 4);
+    (void)hipMalloc(&w, (size_t)9 * N * C * 4);
     (void)hipMalloc(&bias, N * 4);
     (void)hipMemset(in, 0, (size_t)B * H * W * C * 4);
-    (void)hipMemset(w, 0, 9 * N * C * 4);
+    (void)hipMemset(w, 0, (size_t)9 * N * C * 4);
     (void)hipMemset(bias, 0, N * 4);
     unsigned long long* sb;
     (void)hipMalloc(&sb, 64 * 64 * 8);
