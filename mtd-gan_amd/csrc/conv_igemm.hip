@@ -911,8 +911,8 @@ __global__ __launch_bounds__(256, 2) void igemm_v2_kernel(const IgemmParams p) {
         }
 }
 
-// sum the split-K slabs in order, then the same epilogue
-__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IgemmParams p) {
+// sum the split-K slabs in order, then the same epilogue (value by value: any alignment)
+__global__ __launch_bounds__(256) void splitk_epilogue_scalar_kernel(const IgemmParams p) {
     const mtd_conv_args& a = p.a;
     const long long total = (long long)p.M * a.N;
     const ScalePair sp = load_scale(a);
@@ -925,6 +925,67 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IgemmParams 
         const float bias_n = a.bias ? a.bias[n] : 0.f;
         a.out[pix * a.out_ld + n] = epilogue_value(a, s, pick_scale(sp, m), bias_n, pix, n);
     }
+}
+
+// Four consecutive output channels of one pixel per thread: 16-byte slab reads with up to eight splits in flight (the
+// scalar loop above serialises one memory round trip per split), 16-byte operand reads and stores.  Needs every row
+// stride a multiple of 4 floats and 16-byte aligned bases (splitk_vec_ok); total < 2^31.
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IgemmParams p) {
+    const mtd_conv_args& a = p.a;
+    const unsigned total4 = (unsigned)(((long long)p.M * a.N) >> 2);
+    const long long total = (long long)p.M * a.N;
+    const unsigned n4n = (unsigned)a.N >> 2;
+    const ScalePair sp = load_scale(a);
+    for (unsigned i4 = blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += gridDim.x * 256) {
+        const unsigned m = i4 / n4n;
+        const unsigned n = (i4 - m * n4n) << 2;
+        const float* base = a.ws + 4ll * i4;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int z = 0;
+        for (; z + 8 <= p.splitk; z += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(base + (long long)(z + j) * total);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        if (z + 4 <= p.splitk) {
+            f32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(base + (long long)(z + j) * total);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += v[j];
+            z += 4;
+        }
+        for (; z < p.splitk; ++z) s += *reinterpret_cast<const f32x4*>(base + (long long)z * total);
+        const long long pix = out_pixel(a.g, (int)m, p.out_identity);
+        const float sc = pick_scale(sp, (int)m);
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f}, e1 = {-0.0f, -0.0f, -0.0f, -0.0f}, e2 = e1, em = {1.f, 1.f, 1.f, 1.f};
+        if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + n);
+        if (a.add1) e1 = *reinterpret_cast<const f32x4*>(a.add1 + pix * a.add1_ld + n);
+        if (a.add2) e2 = *reinterpret_cast<const f32x4*>(a.add2 + pix * a.add2_ld + n);
+        if (a.mask) em = *reinterpret_cast<const f32x4*>(a.mask + pix * a.mask_ld + n);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = s[j] * sc + bias[j];      // the order of epilogue_value(); absent operands are neutral elements
+            v += e1[j];
+            v += e2[j];
+            v = apply_act(v, a.act);
+            if (a.mask) v *= (em[j] > 0.f) ? 1.f : a.mask_slope;
+            o[j] = v;
+        }
+        *reinterpret_cast<f32x4*>(a.out + pix * a.out_ld + n) = o;
+    }
+}
+
+bool splitk_vec_ok(const mtd_conv_args& a, long long M) {
+    if (M * a.N >= (1ll << 31) || !aligned16(a.ws) || !aligned16(a.out) || (a.out_ld % 4)) return false;
+    if (a.bias && !aligned16(a.bias)) return false;
+    if (a.add1 && (!aligned16(a.add1) || (a.add1_ld % 4))) return false;
+    if (a.add2 && (!aligned16(a.add2) || (a.add2_ld % 4))) return false;
+    if (a.mask && (!aligned16(a.mask) || (a.mask_ld % 4))) return false;
+    return true;
 }
 
 struct Plan { int cfg, BM, BN, splitk, c_per_split; };
@@ -1088,10 +1149,12 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
     mtd_prof_end(prof, s);
     MTD_LAUNCH_CHECK();
     if (pl.splitk > 1) {
-        long long total = (long long)p.M * a->N;
-        int blocks = (int)((total + 255) / 256);
+        const long long total = (long long)p.M * a->N;
+        const bool vec = splitk_vec_ok(*a, p.M);
+        int blocks = (int)(((vec ? total / 4 : total) + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, p);
+        if (vec) hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(splitk_epilogue_scalar_kernel, dim3(blocks), dim3(256), 0, s, p);
         MTD_LAUNCH_CHECK();
     }
     return MTD_OK;

@@ -500,8 +500,9 @@ __global__ __launch_bounds__(NW * 64, (W == 8 || NW == 8) ? 1 : 2) void wgrad_bl
 }
 
 // out[g][idx] = sum_{s in group g} in[s][idx]     (group size gs), fixed order
-__global__ __launch_bounds__(256) void slab_group_sum_kernel(const float* in, float* out, int nslab, int gs, long long count,
-                                                             long long stride_in, long long stride_out) {
+// scalar forms of the two kernels below, for the thin layers (N == 1 or C == 1: slab strides are not multiples of 4)
+__global__ __launch_bounds__(256) void slab_group_sum_scalar_kernel(const float* in, float* out, int nslab, int gs, long long count,
+                                                                    long long stride_in, long long stride_out) {
     const int grp = blockIdx.y;
     const int s0 = grp * gs, s1 = min(nslab, s0 + gs);
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < count; idx += (long long)gridDim.x * 256) {
@@ -511,8 +512,7 @@ __global__ __launch_bounds__(256) void slab_group_sum_kernel(const float* in, fl
     }
 }
 
-// final: sum <= gs slabs and scatter into the strided weight-gradient view (+ bias gradient)
-__global__ __launch_bounds__(256) void wgrad_finish_kernel(const WgradParams p, const float* in, int nslab, long long stride_in) {
+__global__ __launch_bounds__(256) void wgrad_finish_scalar_kernel(const WgradParams p, const float* in, int nslab, long long stride_in) {
     const mtd_wgrad_args& a = p.a;
     const mtd_geom& g = a.g;
     const long long nw = (long long)p.T * a.N * a.C;
@@ -532,6 +532,78 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const WgradParams p, 
         } else {
             float* dst = a.db + (idx - nw);
             *dst = (a.accumulate & 2) ? (*dst + s) : s;
+        }
+    }
+}
+
+// sum of slabs k0 .. k1-1 at float4 index i4, in slab order; the loads of eight slabs are in flight together (a plain
+// `for k: s += in[k]` loop of unknown length serialises one memory round trip per slab)
+__device__ __forceinline__ f32x4 slab_sum4(const float* __restrict__ in, long long stride_in, int k0, int k1, long long i4) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const float* base = in + 4 * i4;
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(base + (long long)(k + j) * stride_in);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    if (k + 4 <= k1) {
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(base + (long long)(k + j) * stride_in);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += v[j];
+        k += 4;
+    }
+    for (; k < k1; ++k) s += *reinterpret_cast<const f32x4*>(base + (long long)k * stride_in);
+    return s;
+}
+
+// out[g][idx] = sum_{s in group g} in[s][idx]     (group size gs), fixed order.  count and both strides are multiples of 4
+// (N % 32 == 0) and the workspace is 16-byte aligned (checked by the caller).
+__global__ __launch_bounds__(256) void slab_group_sum_kernel(const float* __restrict__ in, float* __restrict__ out, int nslab, int gs,
+                                                             long long count, long long stride_in, long long stride_out) {
+    const int grp = blockIdx.y;
+    const int s0 = grp * gs, s1 = min(nslab, s0 + gs);
+    const long long count4 = count >> 2;
+    for (long long i4 = (long long)blockIdx.x * 256 + threadIdx.x; i4 < count4; i4 += (long long)gridDim.x * 256)
+        *reinterpret_cast<f32x4*>(out + (long long)grp * stride_out + 4 * i4) = slab_sum4(in, stride_in, s0, s1, i4);
+}
+
+// final: sum <= gs slabs and scatter into the strided weight-gradient view (+ bias gradient).  A thread owns four
+// consecutive c of one (tap, n); index arithmetic in 32 bits (T * N * C < 2^31, checked by the caller).
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const WgradParams p, const float* __restrict__ in, int nslab, long long stride_in) {
+    const mtd_wgrad_args& a = p.a;
+    const mtd_geom& g = a.g;
+    const unsigned nw4 = (unsigned)(p.T * a.N * a.C) >> 2;
+    const unsigned count4 = nw4 + (a.db ? ((unsigned)a.N >> 2) : 0u);
+    const unsigned c4n = (unsigned)a.C >> 2;
+    for (unsigned i4 = blockIdx.x * 256 + threadIdx.x; i4 < count4; i4 += gridDim.x * 256) {
+        const f32x4 s = slab_sum4(in, stride_in, 0, nslab, i4);
+        if (i4 < nw4) {
+            const unsigned t2 = i4 / c4n;
+            const unsigned c = (i4 - t2 * c4n) << 2;
+            const unsigned tap = t2 / (unsigned)a.N;
+            const unsigned n = t2 - tap * (unsigned)a.N;
+            const int ty = (int)tap / g.TW, tx = (int)tap % g.TW;
+            const int kidx = (g.ky0 + ty * g.ky_step) * g.KW + (g.kx0 + tx * g.kx_step);
+            float* dst = a.dw + (long long)n * a.w_sn + (long long)c * a.w_sc + kidx;
+            if (a.accumulate & 1) {
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = dst[(long long)j * a.w_sc];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[(long long)j * a.w_sc] = o[j] + s[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[(long long)j * a.w_sc] = s[j];
+            }
+        } else {
+            float* dst = a.db + ((i4 - nw4) << 2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[j] = (a.accumulate & 2) ? (dst[j] + s[j]) : s[j];
         }
     }
 }
@@ -744,20 +816,25 @@ extern "C" int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream) {
     int ns = nsplit;
     float* next = a->ws + (long long)ns * p.slab_stride;
     const long long count = p.slab_stride;
+    const bool vec = !direct;      // MFMA layers: N, C multiples of 32, so every slab offset is a multiple of 4 floats
+    if (vec && (!aligned16(a->ws) || (long long)p.T * a->N * a->C >= (1ll << 31))) return MTD_EINVAL;   // float4 reads, 32-bit indices
+    const long long units = vec ? count / 4 : count;
     while (ns > GS) {
         int ng = (ns + GS - 1) / GS;
-        int bx = (int)((count + 255) / 256);
+        int bx = (int)((units + 255) / 256);
         if (bx > 1024) bx = 1024;
-        hipLaunchKernelGGL(slab_group_sum_kernel, dim3(bx, ng), dim3(256), 0, s, cur, next, ns, GS, count, p.slab_stride, p.slab_stride);
+        if (vec) hipLaunchKernelGGL(slab_group_sum_kernel, dim3(bx, ng), dim3(256), 0, s, cur, next, ns, GS, count, p.slab_stride, p.slab_stride);
+        else hipLaunchKernelGGL(slab_group_sum_scalar_kernel, dim3(bx, ng), dim3(256), 0, s, cur, next, ns, GS, count, p.slab_stride, p.slab_stride);
         MTD_LAUNCH_CHECK();
         cur = next;
         next = next + (long long)ng * p.slab_stride;
         ns = ng;
     }
     {
-        int bx = (int)((count + 255) / 256);
+        int bx = (int)((units + 255) / 256);
         if (bx > 2048) bx = 2048;
-        hipLaunchKernelGGL(wgrad_finish_kernel, dim3(bx), dim3(256), 0, s, p, cur, ns, p.slab_stride);
+        if (vec) hipLaunchKernelGGL(wgrad_finish_kernel, dim3(bx), dim3(256), 0, s, p, cur, ns, p.slab_stride);
+        else hipLaunchKernelGGL(wgrad_finish_scalar_kernel, dim3(bx), dim3(256), 0, s, p, cur, ns, p.slab_stride);
         MTD_LAUNCH_CHECK();
     }
     return MTD_OK;
