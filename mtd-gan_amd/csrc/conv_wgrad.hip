@@ -165,9 +165,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         }
     }
 
-    // ---- sum the four waves through LDS (tile by tile), wave 0 writes the workgroup's slab
+    // ---- sum the four waves through LDS (tile by tile, waves 0..3 in that order); every wave finishes a quarter of the
+    //      tile (4 values per lane) and writes it into the workgroup's slab
     float* slab = a.ws + (long long)blockIdx.x * p.slab_stride;
-    float* red = Ls;   // 3 * 1024 floats
+    float* red = Ls;   // 4 * 1024 floats
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
         if (t < ntap) {
@@ -176,20 +177,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
                 for (int c = 0; c < WC; ++c) {
                     __syncthreads();
-                    if (wave > 0) {
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) red[(wave - 1) * 1024 + e * 64 + lane] = acc[t][j][c][e];
-                    }
+                    for (int e = 0; e < 16; ++e) red[wave * 1024 + e * 64 + lane] = acc[t][j][c][e];
                     __syncthreads();
-                    if (wave == 0) {
-                        const int tap = tap0 + t;
+                    const int tap = tap0 + t;
+                    float v[4];
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            float v = acc[t][j][c][e] + red[e * 64 + lane] + red[1024 + e * 64 + lane] + red[2048 + e * 64 + lane];
-                            int n = n0 + j * 32 + mfma32_row(e, lane);
-                            int cc = c0 + c * 32 + l31;
-                            slab[((long long)tap * a.N + n) * a.C + cc] = v;
-                        }
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = wave * 4 + i;
+                        v[i] = red[e * 64 + lane] + red[1024 + e * 64 + lane] + red[2048 + e * 64 + lane] + red[3072 + e * 64 + lane];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = wave * 4 + i;
+                        const int n = n0 + j * 32 + mfma32_row(e, lane);
+                        const int cc = c0 + c * 32 + l31;
+                        slab[((long long)tap * a.N + n) * a.C + cc] = v[i];
                     }
                 }
         }
@@ -705,7 +708,7 @@ int check_wargs(const mtd_wgrad_args& a) {
     return MTD_OK;
 }
 
-constexpr int GS = 32;   // slabs summed per reduce stage
+constexpr int GS = 64;   // slabs summed per reduce stage (eight loads in flight per thread: 64 slabs cost less than a second launch)
 
 size_t wgrad_ws_floats(const mtd_wgrad_args& a, int nsplit) {
     const long long T = a.g.TH * a.g.TW;
