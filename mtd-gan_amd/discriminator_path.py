@@ -89,14 +89,17 @@ class DiscRuntime:
     """Per-module scratch: the raw weight-gradient temp (one flat buffer shared by all SN layers)."""
 
     def __init__(self):
-        self._gtemp = [None, None]
+        self._gtemp = {}
 
-    def gtemp(self, name, device, which=0):
-        """which: 0 / 1 = first / second pass of a paired tape (each pass has its own sigma, u, v)."""
-        if self._gtemp[which] is None or self._gtemp[which].device != device:
-            self._gtemp[which] = torch.empty(SN_W_TOTAL, dtype=torch.float32, device=device)
+    def gtemp(self, name, device, which=0, chain=0):
+        """which: 0 / 1 = first / second pass of a paired tape (each pass has its own sigma, u, v); chain: backward passes
+        that run concurrently on different streams (train_step.DStepTape.run_pcgrad) each own a set."""
+        buf = self._gtemp.get((which, chain))
+        if buf is None or buf.device != device:
+            buf = torch.empty(SN_W_TOTAL, dtype=torch.float32, device=device)
+            self._gtemp[(which, chain)] = buf
         i = SN_INDEX[name]
-        return self._gtemp[which][SN_W_OFF[i]:SN_W_OFF[i] + SN_SPECS[i][1] * SN_SPECS[i][2]]
+        return buf[SN_W_OFF[i]:SN_W_OFF[i] + SN_SPECS[i][1] * SN_SPECS[i][2]]
 
 
 class Tape:
@@ -250,14 +253,14 @@ class GradSink:
         return self.t.get(name)
 
 
-def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad):
+def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0):
     """Replay one recorded pass.  g_enc (B,1,1,1) / g_dec (B,64,64,1) / g_rec (B,64,64,1): output
     cotangents (any may be None).  sink: GradSink or None.  All parameter gradients are ACCUMULATED."""
     B = tp.B
     x = tp.x_in
     dev = x.device
     sn_touched = []
-    side = K.side_stream(dev)          # weight gradients run beside the data-gradient chain
+    side = K.side_stream(dev, 10 + chain if chain else 0)   # weight gradients run beside the data-gradient chain (one side stream per chain)
 
     def want(name):
         return sink is not None and sink.get(name) is not None
@@ -276,12 +279,12 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad):
                 ga, gb_ = K.geom_fwd(Bh, hh, hh, kk, ss, pp), K.geom_fwd(B - Bh, hh, hh, kk, ss, pp)
 
                 def both():
-                    K.wgrad(pa, qa, ga, N, Cc, rt.gtemp(name, dev, 0), Cc * k * k, k * k, db=sink.get(bn), accumulate=False, accumulate_bias=True)
-                    K.wgrad(pb, qb, gb_, N, Cc, rt.gtemp(name, dev, 1), Cc * k * k, k * k, db=sink.get(bn), accumulate=False, accumulate_bias=True)
+                    K.wgrad(pa, qa, ga, N, Cc, rt.gtemp(name, dev, 0, chain), Cc * k * k, k * k, db=sink.get(bn), accumulate=False, accumulate_bias=True)
+                    K.wgrad(pb, qb, gb_, N, Cc, rt.gtemp(name, dev, 1, chain), Cc * k * k, k * k, db=sink.get(bn), accumulate=False, accumulate_bias=True)
                 side.run(both, p, q)
             else:
                 geom = K.geom_fwd(B, hh, hh, kk, ss, pp)
-                side.run(lambda: K.wgrad(p, q, geom, N, Cc, rt.gtemp(name, dev), Cc * k * k, k * k, db=sink.get(bn), accumulate=False,
+                side.run(lambda: K.wgrad(p, q, geom, N, Cc, rt.gtemp(name, dev, 0, chain), Cc * k * k, k * k, db=sink.get(bn), accumulate=False,
                                          accumulate_bias=True), p, q)
             sn_touched.append(name)
         elif want(bn):
@@ -402,7 +405,7 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad):
         for name in sn_touched:
             i = SN_INDEX[name]
             s = _lib.SnGradLayer()
-            s.G = rt.gtemp(name, dev, 0).data_ptr()
+            s.G = rt.gtemp(name, dev, 0, chain).data_ptr()
             s.w = P[name + ".weight_orig"].data_ptr()
             s.u = tp.u_save.data_ptr() + 4 * SN_ROW_OFF[i]
             s.v = tp.v_save.data_ptr() + 4 * SN_COL_OFF[i]
@@ -410,7 +413,7 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad):
             s.g_out = sink.get(name + ".weight_orig").data_ptr()
             s.rows, s.cols, s.accumulate = SN_SPECS[i][1], SN_SPECS[i][2], 1
             if Bh:      # the second half's own sigma, u, v: corrected and added in the same launch, after the first
-                s.G2 = rt.gtemp(name, dev, 1).data_ptr()
+                s.G2 = rt.gtemp(name, dev, 1, chain).data_ptr()
                 s.u2 = tp.u_save2.data_ptr() + 4 * SN_ROW_OFF[i]
                 s.v2 = tp.v_save2.data_ptr() + 4 * SN_COL_OFF[i]
                 s.sigma2 = tp.sig2.data_ptr() + 8 * i

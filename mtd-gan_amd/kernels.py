@@ -408,7 +408,9 @@ def device_table(structs, device):
     n = len(structs)
     arr = (type(structs[0]) * n)(*structs)
     raw = bytes(arr)
-    key = (device.index, torch.cuda.is_current_stream_capturing(), raw)
+    # (the stream is part of the key: a table uploaded on one stream must not be read by a kernel on another stream that
+    # is not ordered after the upload)
+    key = (device.index, torch.cuda.is_current_stream_capturing(), _raw_stream(device.index if device.index is not None else _cur_device()), raw)
     hit = _desc_cache.get(key)
     STATS["table_hit" if hit is not None else "table_miss"] += 1
     if hit is None:
@@ -623,6 +625,23 @@ def side_stream(device, idx=0):
         s = SideStream(device)
         _side[key] = s
     return s
+
+
+_chain = {}
+
+
+def chain_stream(device, idx):
+    """Extra streams for independent kernel chains of one step (the three PCGrad task backward passes): each kernel
+    boundary in a stream drains the chip, so chains that do not depend on each other run side by side."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), idx)
+    s = _chain.get(key)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _chain[key] = s
+    return s
+
+
+CHAINS = os.environ.get("MTD_NO_CHAINS", "0") != "1" and os.environ.get("MTD_NO_SIDE_STREAMS", "0") != "1"
 
 
 def crosses_streams(*tensors):

@@ -83,19 +83,60 @@ class DStepTape:
             T(0, rd, rrd, grad_out=g["c_rd"], coef=1.0 / n), T(0, rrd, rd, grad_out=g["c_rrd"], coef=1.0 / n),
             T(0, fe, rfe, grad_out=g["c_fe"], coef=1.0 / B), T(0, rfe, fe, grad_out=g["c_rfe"], coef=1.0 / B),
             T(0, fd, rfd, grad_out=g["c_fd"], coef=1.0 / n), T(0, rfd, fd, grad_out=g["c_rfd"], coef=1.0 / n)], dev)
-        # ---- task 0: adversarial (image-level + pixel-level), passes 1 and 2 together
-        DP.disc_backward(rt, P, t12, G2["d_e"], G2["d_d"], None, sinks[0], False)
-        self._sync_task(dp, S, 0)
-        # ---- task 1: restoration
-        DP.disc_backward(rt, P, t12, None, None, G2["r_r"], sinks[1], False)
-        self._sync_task(dp, S, 1)
-        # ---- task 2: consistency (through D(rec.clip), passes 3 and 4, back into the restoration decoder of passes 1 and 2)
-        gin34 = DP.disc_backward(rt, P, t34, G2["c3_e"], G2["c3_d"], None, sinks[2], True)
-        DP.disc_backward(rt, P, t12, G2["c_e"], G2["c_d"], K.clip01_bwd(gin34, r12), sinks[2], False)
-        self._sync_task(dp, S, 2)
+        # The consistency task touches the decoders of both other tasks, so its task-specific gradients go to a buffer of
+        # their own, added at the end (tasks 0 and 1 own disjoint decoders): the three task backward passes then share only
+        # read-only tapes and can run as concurrent chains.
+        TSc = torch.zeros_like(TSflat)
+        t2, tofs = dict(sinks[2].t), 0
+        for nme, sz in zip(ts_names, ts_sizes):
+            t2[nme] = TSc[tofs:tofs + sz].view_as(D.get_parameter(nme))
+            tofs += (sz + 3) // 4 * 4
+        sink_c = DP.GradSink(t2)
+
+        def consistency(chain):
+            # through D(rec.clip), passes 3 and 4, back into the restoration decoder of passes 1 and 2
+            gin34 = DP.disc_backward(rt, P, t34, G2["c3_e"], G2["c3_d"], None, sink_c, True, chain=chain)
+            DP.disc_backward(rt, P, t12, G2["c_e"], G2["c_d"], K.clip01_bwd(gin34, r12), sink_c, False, chain=chain)
+
+        if K.CHAINS and not torch.cuda.is_current_stream_capturing():
+            # main stream + two chain streams, each with its own side stream for weight gradients: every kernel boundary in
+            # a stream drains the chip, three independent chains fill each other's ramps and tails.  Longest chain first.
+            main = torch.cuda.current_stream()
+            start = torch.cuda.Event()
+            start.record(main)
+            done = []
+
+            def chain(idx, body, task):
+                st = K.chain_stream(dev, idx)
+                st.wait_event(start)
+                with torch.cuda.stream(st):
+                    body()
+                    K.side_stream(dev, 10 + idx).join()
+                    if dp is not None:
+                        dp.all_reduce_avg(S[task])
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                done.append(ev)
+
+            chain(2, lambda: consistency(2), 2)
+            chain(1, lambda: DP.disc_backward(rt, P, t12, None, None, G2["r_r"], sinks[1], False, chain=1), 1)
+            DP.disc_backward(rt, P, t12, G2["d_e"], G2["d_d"], None, sinks[0], False)       # adversarial (image + pixel level)
+            K.side_stream(dev).join()
+            if dp is not None:
+                dp.all_reduce_avg(S[0])
+            for ev in done:
+                main.wait_event(ev)
+        else:
+            DP.disc_backward(rt, P, t12, G2["d_e"], G2["d_d"], None, sinks[0], False)       # task 0: adversarial
+            self._sync_task(dp, S, 0)
+            DP.disc_backward(rt, P, t12, None, None, G2["r_r"], sinks[1], False)            # task 1: restoration
+            self._sync_task(dp, S, 1)
+            consistency(0)                                                                   # task 2: consistency
+            self._sync_task(dp, S, 2)
+            K.side_stream(dev).join()          # weight gradients / spectral-norm corrections ran on the side stream
         if dp is not None:
-            dp.wait()                      # the three averaged task vectors are needed by the Gram kernel
-        K.side_stream(dev).join()          # weight gradients / spectral-norm corrections ran on the side stream
+            dp.wait()                          # the three averaged task vectors are needed by the Gram kernel
+        TSflat.add_(TSc)
         if dp is not None and ts_names:
             dp.all_reduce_avg(TSflat)      # 158 MB, in flight under the Gram / combine kernels; joined below
         # ---- PCGrad: Gram of the original task gradients, replay of the projections, combine
