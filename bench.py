@@ -9,7 +9,8 @@ scaling).  Prints ONE JSON line on rank 0.  `value` = patches/s over all ranks, 
 Extra objects: `roofline` for the dominant kernel -- the fp32-MFMA implicit-GEMM instantiation with the
 largest share of the step's GPU time -- timed by the library's own launch profiler (HIP events recorded
 on the launch stream directly around that kernel, include/mtdgan_hip.h mtd_prof_*) in a second pass of
-the same K steps, so the events do not perturb `value`; and `cpu_baseline` (the CPU oracle, kind "port",
+the same K steps with every kernel in one stream, so the events do not perturb `value` and a launch's duration is
+the kernel's own rather than its share of a chip it runs on beside other streams' kernels; and `cpu_baseline` (the CPU oracle, kind "port",
 timed on rank 0 at N == 1 on a bounded sample).
 """
 import argparse
@@ -160,13 +161,19 @@ def main():
     if not args.no_roofline:
         from mtd_gan_amd import kernels as K
         cap = 8192 * max(1, args.steps)
-        K.prof_enable(cap)
         step = getattr(wl, "step_eager", wl.step)          # events cannot be recorded inside a graph replay
+        # This pass runs every kernel in ONE stream: with the side streams and task chains of the timed region a launch's
+        # event-to-event time includes the share of the chip it cedes to concurrent kernels, which says nothing about the
+        # kernel.  (profiles/*_kernel_stats_single_stream.csv is the rocprofv3 trace of the same mode.)
+        K.set_concurrency(False)
+        step()
+        K.prof_enable(cap)
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
         recs = K.prof_collect(cap)
         K.prof_enable(0)
+        K.set_concurrency(True)
         # an empty event pair on the same stream: what the bracketing itself adds to every sample
         pairs = []
         for _ in range(64):
@@ -200,7 +207,7 @@ def main():
                         "traffic": pmc_traffic(name) if wl.name == "full_step" else None,   # the committed PMC passes profile the default workload
                         "launches_timed": d["n"], "avg_launch_us": round(1e3 * d["ms"] / d["n"], 2),
                         "avg_launch_us_with_event_pair": round(1e3 * raw_ms / d["n"], 2), "event_pair_us": round(1e3 * ev_over_ms, 2),
-                        "flops_per_launch": round(d["flops"] / d["n"]),
+                        "flops_per_launch": round(d["flops"] / d["n"]), "measured": "second pass of the same steps, all kernels in one stream",
                         "share_of_step_gpu_ms": round(d["ms"] / args.steps, 3),
                         "top_shapes": {k: {"us": round(1e3 * v[0] / v[2], 2), "tflops": round(v[1] / v[0] / 1e9, 2), "launches_per_step": v[2] // args.steps}
                                        for k, v in top},
@@ -217,6 +224,10 @@ def main():
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": wl.config(world), "roofline": roofline, "cpu_baseline": cpu}
         line.update(wl.extra())
+        if "algorithmic_gflop_per_patch" in line:          # whole-step rate against the same peak, from the timed region
+            tf = line["algorithmic_gflop_per_patch"] * per_gpu_units * world / (ms * 1e-3) / 1e3 / world
+            line["step_tflops_per_gpu"] = round(tf, 2)
+            line["step_frac_of_fp32_mfma_peak"] = round(tf / PEAK_F32_MFMA_TFLOPS, 4)
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -580,6 +580,21 @@ def adamw_multi(params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps,
 
 
 # ---------------------------------------------------------------------------------------------- side stream
+SIDE_STREAMS = os.environ.get("MTD_NO_SIDE_STREAMS", "0") != "1"
+
+
+def set_concurrency(on):
+    """Side streams and task chains on / off at run time (bench.py times single kernels with everything in one stream:
+    under concurrency a launch's duration includes the time it shares the chip with other kernels).  Synchronises."""
+    global SIDE_STREAMS, CHAINS
+    torch.cuda.synchronize()
+    on = bool(on) and os.environ.get("MTD_NO_SIDE_STREAMS", "0") != "1"
+    SIDE_STREAMS = on
+    CHAINS = on and os.environ.get("MTD_NO_CHAINS", "0") != "1"
+    for s in _side.values():
+        s.enabled = on
+
+
 class SideStream:
     """A second HIP stream for work that is off the critical path of a backward pass (weight gradients, their
     slab reductions, the spectral-norm correction): it runs beside the data-gradient chain on the main stream
@@ -590,7 +605,7 @@ class SideStream:
     def __init__(self, device):
         self.stream = torch.cuda.Stream(device=device)
         self._keep = []
-        self.enabled = os.environ.get("MTD_NO_SIDE_STREAMS", "0") != "1"      # diagnostic switch: everything on one stream
+        self.enabled = SIDE_STREAMS      # MTD_NO_SIDE_STREAMS=1 / set_concurrency(False): everything on one stream
 
     def fork(self):
         if self.enabled:
