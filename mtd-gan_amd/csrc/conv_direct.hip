@@ -300,13 +300,15 @@ struct WideParams {
     int T, V, CL, ppb, n_is_one;
     long long slab_stride;
     int tap_dy[16], tap_dx[16];
+    int tile_rows;              // > 0: the workgroup's pixels are tile_rows whole image rows and every tap lies within one
+    int ddy[16], ddx[16];       //      pixel of the wide tensor's pixel: narrow-tensor taps come from an LDS tile
 };
 
 template <int VEC>
 __global__ __launch_bounds__(256) void wgrad_wide_kernel(const WideParams p) {
     const mtd_wgrad_args& a = p.a;
     const mtd_geom& g = a.g;
-    extern __shared__ float red[];                  // [4 waves][T * V + V]
+    extern __shared__ float red[];                  // [4 waves][T * V + V], then the narrow-tensor tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int CL = p.CL, PPW = 64 / CL;
     const int cl = lane % CL, pg = lane / CL;
@@ -327,6 +329,52 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(const WideParams p) {
     }
     const int mb = blockIdx.x * p.ppb;
     const int me = min(p.Mw, mb + p.ppb);
+    if (p.tile_rows > 0) {
+        // Whole image rows per workgroup, 3x3-neighbourhood taps: the narrow tensor's rows y0-1 .. y0+R (zero halo) are staged
+        // in LDS once, so a pixel costs one 16-byte load of the wide tensor and T broadcast LDS reads instead of T global
+        // loads with their bounds tests and 64-bit address arithmetic (the loop below: ~200 instructions per pixel group,
+        // VALU-bound at 56 us per launch).  Same pixel order per lane as that loop => the same sums.
+        float* tile = red + 4 * (p.T * p.V + p.V);
+        const int R = p.tile_rows, TW2 = GW + 2;
+        const int row0 = mb / GW;                       // first image row (over all images) of this workgroup
+        const int b = row0 / GH, y0 = row0 - b * GH;
+        for (int i = threadIdx.x; i < (R + 2) * TW2; i += 256) {
+            const int ry = i / TW2, rx = i - ry * TW2;
+            const int ny = y0 - 1 + ry, nx = rx - 1;
+            float v = 0.f;
+            if (((unsigned)ny < (unsigned)NH) & ((unsigned)nx < (unsigned)NW))
+                v = nar[(((long long)b * NH + ny) * NW + nx) * nar_ld];
+            tile[i] = v;
+        }
+        __syncthreads();
+        const float* wrow = wide + (long long)mb * wide_ld + VEC * cl;
+        for (int i = wave * PPW + pg; i < me - mb; i += 4 * PPW) {
+            const int ry = i / GW, rx = i - ry * GW;
+            float wv[VEC];
+            if (VEC == 4) {
+                const f32x4 q4 = *reinterpret_cast<const f32x4*>(wrow + (long long)i * wide_ld);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) wv[j] = q4[j];
+            } else {
+                wv[0] = wrow[(long long)i * wide_ld];
+            }
+            const float* tc = tile + (ry + 1) * TW2 + rx + 1;
+            if (!n1) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) bacc[j] += wv[j];
+            } else if (cl == 0) {
+                bacc[0] += tc[0];
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                if (t < p.T) {
+                    const float s = tc[p.ddy[t] * TW2 + p.ddx[t]];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) acc[j][t] = fmaf(s, wv[j], acc[j][t]);
+                }
+            }
+        }
+    } else
     for (int m = mb + wave * PPW + pg; m < me; m += 4 * PPW) {
         const int x = m % GW;
         const int t2 = m / GW;
@@ -427,10 +475,21 @@ bool wide_plan(const mtd_wgrad_args& a, WideParams& p) {
     const long long min_ppb = 4ll * (64 / p.CL) * 4;
     if (ppb < min_ppb) ppb = min_ppb;
     p.ppb = (int)ppb;
+    bool near = true;
     for (int t = 0; t < p.T; ++t) {
         p.tap_dy[t] = (t / g.TW) * g.tap_dy;
         p.tap_dx[t] = (t % g.TW) * g.tap_dx;
+        // displacement of tap t's narrow-tensor pixel from the wide tensor's pixel (see the kernel's address formulas)
+        p.ddy[t] = p.n_is_one ? -(g.off_y + p.tap_dy[t]) : (g.off_y + p.tap_dy[t]);
+        p.ddx[t] = p.n_is_one ? -(g.off_x + p.tap_dx[t]) : (g.off_x + p.tap_dx[t]);
+        near = near && p.ddy[t] >= -1 && p.ddy[t] <= 1 && p.ddx[t] >= -1 && p.ddx[t] <= 1;
     }
+    // LDS-tile path: same-size stride-1 grids, the workgroup's pixel range = whole rows of one image
+    const int GW = p.n_is_one ? g.IW : g.OW, GH = p.n_is_one ? g.IH : g.OH;
+    p.tile_rows = 0;
+    if (near && g.in_sy == 1 && g.in_sx == 1 && g.OH == g.IH && g.OW == g.IW && GW > 0 && p.ppb % GW == 0 && GH % (p.ppb / GW) == 0 &&
+        (long long)(p.ppb / GW + 2) * (GW + 2) * 4 <= 16 * 1024)
+        p.tile_rows = p.ppb / GW;
     return true;
 }
 
@@ -498,7 +557,8 @@ int mtd_direct_wgrad_launch(const mtd_wgrad_args* a, int* nslab_out, long long s
             wp.slab_stride = slab_stride;
             const int nblk = (wp.Mw + wp.ppb - 1) / wp.ppb;
             *nslab_out = nblk;
-            const size_t lds = (size_t)4 * (wp.T * wp.V + wp.V) * sizeof(float);
+            const int tgw = wp.n_is_one ? a->g.IW : a->g.OW;
+            const size_t lds = ((size_t)4 * (wp.T * wp.V + wp.V) + (wp.tile_rows > 0 ? (size_t)(wp.tile_rows + 2) * (tgw + 2) : 0)) * sizeof(float);
             if (wp.V == 1) hipLaunchKernelGGL((wgrad_wide_kernel<1>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, wp);
             else hipLaunchKernelGGL((wgrad_wide_kernel<4>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, wp);
             MTD_LAUNCH_CHECK();

@@ -504,25 +504,37 @@ __global__ __launch_bounds__(NW * 64, (W == 8 || NW == 8) ? 1 : 2) void wgrad_bl
 
 // out[g][idx] = sum_{s in group g} in[s][idx]     (group size gs), fixed order
 // scalar forms of the two kernels below, for the thin layers (N == 1 or C == 1: slab strides are not multiples of 4)
-__global__ __launch_bounds__(256) void slab_group_sum_scalar_kernel(const float* in, float* out, int nslab, int gs, long long count,
-                                                                    long long stride_in, long long stride_out) {
-    const int grp = blockIdx.y;
-    const int s0 = grp * gs, s1 = min(nslab, s0 + gs);
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < count; idx += (long long)gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = s0; k < s1; ++k) s += in[(long long)k * stride_in + idx];
-        out[(long long)grp * stride_out + idx] = s;
+// sum of slabs k0 .. k1-1 at element idx, in slab order, eight loads in flight
+__device__ __forceinline__ float slab_sum1(const float* __restrict__ in, long long stride_in, int k0, int k1, long long idx) {
+    float s = 0.f;
+    const float* base = in + idx;
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = base[(long long)(k + j) * stride_in];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
     }
+    for (; k < k1; ++k) s += base[(long long)k * stride_in];
+    return s;
 }
 
-__global__ __launch_bounds__(256) void wgrad_finish_scalar_kernel(const WgradParams p, const float* in, int nslab, long long stride_in) {
+__global__ __launch_bounds__(256) void slab_group_sum_scalar_kernel(const float* __restrict__ in, float* __restrict__ out, int nslab, int gs,
+                                                                    long long count, long long stride_in, long long stride_out) {
+    const int grp = blockIdx.y;
+    const int s0 = grp * gs, s1 = min(nslab, s0 + gs);
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < count; idx += (long long)gridDim.x * 256)
+        out[(long long)grp * stride_out + idx] = slab_sum1(in, stride_in, s0, s1, idx);
+}
+
+__global__ __launch_bounds__(256) void wgrad_finish_scalar_kernel(const WgradParams p, const float* __restrict__ in, int nslab, long long stride_in) {
     const mtd_wgrad_args& a = p.a;
     const mtd_geom& g = a.g;
     const long long nw = (long long)p.T * a.N * a.C;
     const long long count = nw + (a.db ? a.N : 0);
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < count; idx += (long long)gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < nslab; ++k) s += in[(long long)k * stride_in + idx];
+        const float s = slab_sum1(in, stride_in, 0, nslab, idx);
         if (idx < nw) {
             int c = (int)(idx % a.C);
             long long t2 = idx / a.C;
