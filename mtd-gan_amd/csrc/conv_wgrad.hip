@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     //      tile (4 values per lane) and writes it into the workgroup's slab
     float* slab = a.ws + (long long)blockIdx.x * p.slab_stride;
     float* red = Ls;   // 4 * 1024 floats
+    const bool direct = (p.nslab == 1);
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
         if (t < ntap) {
@@ -187,12 +188,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
                         const int e = wave * 4 + i;
                         v[i] = red[e * 64 + lane] + red[1024 + e * 64 + lane] + red[2048 + e * 64 + lane] + red[3072 + e * 64 + lane];
                     }
+                    const int kidx = (g.ky0 + (tap / g.TW) * g.ky_step) * g.KW + (g.kx0 + (tap % g.TW) * g.kx_step);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int e = wave * 4 + i;
                         const int n = n0 + j * 32 + mfma32_row(e, lane);
                         const int cc = c0 + c * 32 + l31;
-                        slab[((long long)tap * a.N + n) * a.C + cc] = v[i];
+                        if (direct) {       // a single pixel split: straight into the strided parameter-gradient view
+                            float* dst = a.dw + (long long)n * a.w_sn + (long long)cc * a.w_sc + kidx;
+                            *dst = (a.accumulate & 1) ? (*dst + v[i]) : v[i];
+                        } else {
+                            slab[((long long)tap * a.N + n) * a.C + cc] = v[i];
+                        }
                     }
                 }
         }
@@ -207,7 +214,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
             for (int j = 0; j < WN; ++j) {
                 float s = 0.f;
                 for (int w = 0; w < 4; ++w) s += red[(w * WN + j) * 64 + lane] + red[(w * WN + j) * 64 + lane + 32];
-                slab[(long long)p.T * a.N * a.C + n0 + j * 32 + lane] = s;
+                if (direct) {
+                    float* dst = a.db + n0 + j * 32 + lane;
+                    *dst = (a.accumulate & 2) ? (*dst + s) : s;
+                } else {
+                    slab[(long long)p.T * a.N * a.C + n0 + j * 32 + lane] = s;
+                }
             }
         }
     }
@@ -825,7 +837,7 @@ extern "C" int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream) {
         mtd_prof_end(prof, s);
         MTD_LAUNCH_CHECK();
     }
-    if (!direct && pl.cfg >= 7 && nsplit == 1) return MTD_OK;      // single split: the kernel wrote dw / db itself
+    if (!direct && nsplit == 1) return MTD_OK;      // single split: the kernel wrote dw / db itself
     // staged, order-fixed reduction of the slabs
     const float* cur = a->ws;
     int ns = nsplit;
