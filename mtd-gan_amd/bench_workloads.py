@@ -25,11 +25,14 @@ class GeneratorWorkload:
         self.graph = None
         self.graph_error = None
         import os
-        if world == 1 and os.environ.get("MTD_GRAPH", "0") == "1":
-            # hipGraph replay of the forward + backward (static shapes, no host-side state): removes the ~7 ms of
-            # Python enqueue per step, which is as long as the GPU work
+        if world == 1 and os.environ.get("MTD_GRAPH", "1") == "1":
+            # hipGraph replay of the forward + backward (static shapes, no host-side state): the Python enqueue of the 432
+            # launches takes 7.3 ms per step, as long as the GPU work.  Captured with every kernel in ONE stream: replay of a
+            # single-stream graph runs at the kernels' own pace (7.1 ms), a captured multi-stream section does not (7.9 ms,
+            # ROCm 7.2), and eager launches are host-bound (7.8 ms).  MTD_GRAPH=0 keeps the eager launches.
+            from . import kernels as K
             try:
-                from . import kernels as K
+                K.set_concurrency(False)
                 K.prepare_capture(dev)
                 s = torch.cuda.Stream(device=dev)
                 s.wait_stream(torch.cuda.current_stream())
@@ -47,6 +50,8 @@ class GeneratorWorkload:
                 self.graph_error = repr(e)
                 self.graph = None
                 torch.cuda.synchronize()
+            finally:
+                K.set_concurrency(True)
 
     def step(self):
         if self.graph is not None:

@@ -125,3 +125,19 @@ def test_cpu_tensor_is_rejected(hip_lib):
     G = ResFFT_Generator(1, 32, 10, 3, 1)
     with pytest.raises(RuntimeError):
         G(torch.zeros(1, 1, 64, 64))
+
+
+def test_generator_workload_graph_replay_equals_eager(hip_lib):
+    """bench.py's generator workload replays a captured single-stream hipGraph by default: same gradients as eager launches."""
+    from mtd_gan_amd import bench_workloads as BW
+    dev = torch.device("cuda", 0)
+    wl = BW.GeneratorWorkload(dev, 0, 1, 4)
+    assert wl.graph is not None, wl.graph_error
+    wl.step()
+    wl.step()
+    torch.cuda.synchronize()
+    replayed = [p.grad.clone() for p in wl.params]
+    wl.step_eager()
+    torch.cuda.synchronize()
+    for a, b in zip(replayed, wl.params):
+        assert torch.equal(a, b.grad)
