@@ -1017,7 +1017,7 @@ Plan make_plan(const mtd_conv_args& a) {
     else if (M >= 32768 && a.N == 64 && a.C >= 128) pl.cfg = 3;
     // tap-block kernel (all taps of a channel chunk per barrier; 41 KB of LDS = 3 workgroups per CU): 5-9 % faster on the
     // paired-pass shapes (profiles/r1_igemm_tile_sweep.txt) when several chunks stream and the grid fits one round of residency
-    if (pl.cfg == 1 && a.C >= 128 && M >= 4096 && a.g.TH * a.g.TW <= TB_MAXT) {
+    if (pl.cfg == 1 && a.C >= 128 && M >= 4096 && a.g.TH * a.g.TW == TB_MAXT) {        // (1x1 layers: 30-40 % slower there)
         const long long b6 = ((M + 127) / 128) * (a.N / 32);
         const long long sk6 = b6 <= 256 ? 512 / b6 : 1;
         if (b6 * sk6 <= 768) pl.cfg = 6;
@@ -1027,6 +1027,7 @@ Plan make_plan(const mtd_conv_args& a) {
     long long blocks = ((M + pl.BM - 1) / pl.BM) * (a.N / pl.BN);
     int chunks = a.C / KC;
     int sk = blocks <= 256 ? (int)(512 / blocks) : 1;      // fill ~2 workgroups per CU; never split a grid that already does
+    if (blocks > 256 && blocks <= 512 && chunks * a.g.TH * a.g.TW <= 32) sk = 2;      // ... unless its workgroups are short (2x2-tap data gradients: -22 %)
     if (sk > chunks) sk = chunks;
     if (sk > 32) sk = 32;
     if (sk < 1) sk = 1;
