@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- MTD-GAN hot-path throughput on MI355X (contract: see the task statement / DESIGN.md).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload full_step|generator|inference512]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload full_step|generator|inference512|patch_sampler]
 
 One process per GPU (launched by torch.distributed.run for N > 1, backend nccl == RCCL).  A "step" is
 one pass of the hot path over one batch of synthetic LDCT-shaped 64x64 patches (32 per GPU, weak
@@ -61,6 +61,19 @@ def cpu_baseline(wl):
         dt = time.perf_counter() - t0
         return {"value": round(nb * iters / dt, 3), "unit": "img/s", "cores": cores, "kind": "port",
                 "sample": f"oracle generator fwd+bwd, {iters} x {nb} patches (1 warm-up), torch CPU {torch.__version__}, {cores} threads"}
+    if wl.name == "patch_sampler":
+        import numpy as np
+        import data_oracle as DO
+        from mtd_gan_amd.create_datasets import Mayo
+        lo, hi = wl.lo.cpu().numpy(), wl.hi.cpu().numpy()
+        rng = np.random.RandomState(5)
+        iters = 20
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            DO.window_patches(lo, hi, Mayo.draw_descriptors(rng, wl.n_slices))
+        dt = time.perf_counter() - t0
+        return {"value": round(32 * iters / dt, 1), "unit": "img/s", "cores": 1, "kind": "port",
+                "sample": f"oracle/data_oracle.py (numpy restatement of the monai pipeline), {iters} batches of 32 patch pairs, 1 thread"}
     if wl.name == "inference512":
         g = orc.seeded_fill(orc.g_param_shapes(), seed=7)
         x, y = orc.synthetic_ldct(1, seed=1234, size=512)
@@ -214,6 +227,12 @@ def main():
                         "other_igemm": {k: {"tflops": round(v["flops"] / v["ms"] / 1e9, 2), "ms_per_step": round(v["ms"] / args.steps, 3)}
                                         for k, v in by.items() if k != name}}
 
+    if roofline is None and not args.no_roofline and hasattr(wl, "roofline_bytes_per_step"):
+        # byte-moving workloads: algorithmic bytes of a step over the step time (the kernels are launch-latency bound
+        # at this size; the figure says how far from the HBM roof a whole batch is, not a single kernel)
+        gbs = wl.roofline_bytes_per_step / (ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "bbox_kernel + sample_kernel (whole step)", "achieved": round(gbs, 2), "peak": 8000.0,
+                    "unit": "GB/s", "frac": round(gbs / 8000.0, 5), "traffic": None, "bytes_per_step": wl.roofline_bytes_per_step}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(wl)
@@ -221,7 +240,7 @@ def main():
     if rank == 0:
         line = {"metric": "GAN train-step imgs/sec (G+D fwd+bwd) @ 64x64 patch", "value": round(value, 2), "unit": "img/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": getattr(wl, "dtype", "f32"), "data": "synthetic",
                 "config": wl.config(world), "roofline": roofline, "cpu_baseline": cpu}
         line.update(wl.extra())
         if "algorithmic_gflop_per_patch" in line:          # whole-step rate against the same peak, from the timed region

@@ -241,6 +241,24 @@ int mtd_edge_loss(const float* a, const float* b, int B, float scale, float eps,
 size_t mtd_image_metrics_ws_bytes(int B, int H, int W);
 int mtd_image_metrics(const float* a, const float* b, int B, int H, int W, int clip_a, double* out2, void* ws, void* stream);
 
+/* ---- training-patch front end (create_datasets/Mayo.py:117-136, the "window_patch" pipeline, on the device) ----------
+ * Input: the two dose levels of one or more CT slices in Hounsfield units as the reference's get_pixels_hu produces them
+ * (int16, Mayo.py:19-43), resident in HBM.  mtd_foreground_bbox = CropForegroundd(source_key = full dose, select x > 0
+ * after windowing, i.e. HU > a_min): per slice [y0, y1, x0, x1), the whole slice when nothing is foreground.
+ * mtd_window_patches = ScaleIntensityRanged(a_min, a_max -> 0..1, clip) + crop to the box + SpatialPadd(roi) (symmetric,
+ * zeros) + one roi x roi sample per descriptor (RandSpatialCropSamplesd: origin = floor(u * (size - roi + 1))) followed by
+ * RandRotate90d (rot_k quarter turns, np.rot90 on axes (H, W)), RandFlipd over both axes (flip != 0) and RandRotated
+ * (angle radians about the patch centre, bilinear, border padding, align_corners = False; 0 = not applied), as ONE gather
+ * per output pixel.  The random draws are the caller's (the reference's come from monai's RandomState): uy, ux in [0, 1).
+ * Outputs: (n, 1, roi, roi) float32 for each dose level. */
+typedef struct { int slice; float uy, ux; int rot_k; int flip; float angle; } mtd_patch_desc;
+int mtd_foreground_bbox(const short* hu_full, int n_slices, int H, int W, float a_min, int* bbox, void* stream);
+int mtd_window_patches(const short* hu_low, const short* hu_full, int n_slices, int H, int W, const int* bbox,
+                       const mtd_patch_desc* descs, int n, float a_min, float a_max, int roi, float* out_low, float* out_full,
+                       void* stream);
+/* whole slices (valid / test pipelines, Mayo.py:150-157): out[i] = clip((hu[i] - a_min) / (a_max - a_min), 0, 1) */
+int mtd_hu_window(const short* hu, long long n, float a_min, float a_max, float* out, void* stream);
+
 /* ---- launch profiler (bench.py's roofline leg) ---------------------------------------------------------------
  * When enabled, mtd_conv_igemm / mtd_conv_wgrad bracket their MAIN kernel (not the split-K / slab reductions that
  * follow it) with a pair of HIP events on the stream they were given.  mtd_prof_collect synchronises those events

@@ -63,6 +63,10 @@ class LossTerm(C.Structure):
                 ("grad_out", C.c_void_p), ("coef", C.c_float), ("accumulate", C.c_int)]
 
 
+class PatchDesc(C.Structure):
+    _fields_ = [("slice", C.c_int), ("uy", C.c_float), ("ux", C.c_float), ("rot_k", C.c_int), ("flip", C.c_int), ("angle", C.c_float)]
+
+
 class AdamwTensor(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_longlong)]
 
@@ -141,6 +145,9 @@ def lib():
     sig("mtd_image_metrics_ws_bytes", sz, ci, ci, ci)
     sig("mtd_image_metrics", ci, vp, vp, ci, ci, ci, ci, vp, vp, vp)
     sig("mtd_edge_loss", ci, vp, vp, ci, cf, cf, vp, vp, cf, ci, vp, vp)
+    sig("mtd_foreground_bbox", ci, vp, ci, ci, ci, cf, vp, vp)
+    sig("mtd_window_patches", ci, vp, vp, ci, ci, ci, vp, vp, ci, cf, cf, ci, vp, vp, vp)
+    sig("mtd_hu_window", ci, vp, ll, cf, cf, vp, vp)
     _lib = L
     return L
 
@@ -154,6 +161,7 @@ EXPORTS = [
     "mtd_pcgrad_gram", "mtd_pcgrad_combine", "mtd_adamw_multi", "mtd_adamw_multi_dyn", "mtd_adamw_multi_pre", "mtd_loss_terms_ws_bytes", "mtd_loss_terms",
     "mtd_loss_term_grads", "mtd_clip01", "mtd_clip01_bwd", "mtd_edge_loss_ws_bytes", "mtd_edge_loss",
     "mtd_prof_enable", "mtd_prof_collect", "mtd_conv_igemm_override", "mtd_conv_wgrad_override", "mtd_upload", "mtd_image_metrics_ws_bytes", "mtd_image_metrics", "mtd_rfft_rows_any", "mtd_spec_mix_any", "mtd_irfft_rows_any",
+    "mtd_foreground_bbox", "mtd_window_patches", "mtd_hu_window",
 ]
 
 

@@ -112,7 +112,43 @@ class InferenceWorkload:
                 "pixel_metrics_last_batch": self.last}
 
 
+class PatchSamplerWorkload:
+    """the training-patch front end (create_datasets/Mayo.py:117-136) on the device.  A "step" produces one
+    training batch: 32 patch pairs (8 samples from each of 4 resident 512 x 512 HU slice pairs), fresh random choices every
+    step (drawn on the host, uploaded as a descriptor table)."""
+
+    name = "patch_sampler"
+    n_slices = 4
+    dtype = "i16 -> f32"
+
+    def __init__(self, dev, rank, world, batch):
+        import numpy as np
+        from .create_datasets import Mayo
+        self.Mayo = Mayo
+        lo, hi = Mayo.synthetic_hu_slices(self.n_slices, size=512, seed=77 + rank)
+        self.lo, self.hi = lo.to(dev), hi.to(dev)
+        self.rng = np.random.RandomState(5 + rank)
+        self.world, self.batch = world, batch
+        self.last = None
+        # bytes a step has to move: the box pass reads the full-dose slices, the gather reads 2 bytes and writes 4 per pixel and dose
+        self.roofline_bytes_per_step = self.n_slices * 512 * 512 * 2 + 2 * 32 * 64 * 64 * (2 + 4)
+
+    def step(self):
+        d = self.Mayo.draw_descriptors(self.rng, self.n_slices)
+        self.last = self.Mayo.window_patches(self.lo, self.hi, d)
+
+    def config(self, world):
+        return {"workload": "Training-patch front end: HU window + foreground crop + 8 x 64x64 samples per slice + rot90 / flip / "
+                            "rotate (Mayo.py window_patch), 4 slices per step", "per_gpu_batch": 32, "global_batch": 32 * world,
+                "patch": "1x64x64 from 512x512 int16 HU", "parallelism": f"dp{world}"}
+
+    def extra(self):
+        return {"unit_note": "img = one (quarter dose, full dose) patch pair"}
+
+
 def make(name, dev, rank, world, batch):
+    if name in ("patch_sampler", "sampler"):
+        return PatchSamplerWorkload(dev, rank, world, batch)
     if name in ("inference", "inference512"):
         return InferenceWorkload(dev, rank, world, batch)
     if name in ("auto", "generator", "generator_fwd_bwd"):

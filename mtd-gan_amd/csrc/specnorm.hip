@@ -14,7 +14,6 @@ namespace {
 constexpr float SN_EPS = 1e-12f;
 constexpr int COLS_PER_BLOCK = 256;
 constexpr int MAX_CHUNKS = 64;         // cols <= 16384
-constexpr int ELEMS_PER_BLOCK = 4096;
 constexpr int ROWS_PER_BLOCK = 64;     // W^T u is split over row chunks as well, so the pass fills the chip
 constexpr int MAX_ROW_CHUNKS = 32;     // rows <= 2048
 
