@@ -247,3 +247,62 @@ def test_graph_replay_equals_eager(hip_lib):
     assert rel(v_g, v_e) < 1e-5
     for k in sd_e:
         assert rel(sd_g[k], sd_e[k]) < 1e-5, k
+
+
+def test_checkpoint_resume_like_train_py(hip_lib, tmp_path):
+    """train.py:276-288 saves {model_state_dict, optimizer_D, scheduler_D, optimizer_G, scheduler_G, epoch}; train.py:146-159
+    loads it on the CPU map and resumes.  A run that is saved and resumed that way continues exactly like the run that
+    was never interrupted (same dropout masks and PCGrad orders injected)."""
+    import random
+    from mtd_gan_amd import engine
+    from mtd_gan_amd.arch.Ours.networks import MTD_GAN_Method
+    from mtd_gan_amd.module.weight_methods import WeightMethods
+    from mtd_gan_amd.optimizers import FusedAdamW
+    dev = torch.device("cuda")
+    x, y = orc.synthetic_ldct(4, seed=77)
+    batch = [dict(n_20=x, n_100=y)]
+
+    def build(seed):
+        torch.manual_seed(seed)
+        m = MTD_GAN_Method().cuda().train()
+        oD = FusedAdamW(m.Discriminator.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+        oG = FusedAdamW(m.Generator.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+        sD = torch.optim.lr_scheduler.LambdaLR(oD, lr_lambda=lambda e: 0.9 ** e)
+        sG = torch.optim.lr_scheduler.LambdaLR(oG, lr_lambda=lambda e: 0.9 ** e)
+        return m, oD, oG, sD, sG, WeightMethods("pcgrad", n_tasks=3, device=dev)
+
+    def epoch(m, oD, oG, sD, sG, wm, e):
+        torch.manual_seed(1000 + e)           # dropout masks of the epoch
+        random.seed(2000 + e)                 # PCGrad shuffle orders of the epoch
+        engine.train_MTD_GAN_Ours(m, batch, oG, oD, dev, e, 0, 4, wm)
+        sD.step()
+        sG.step()
+
+    a = build(1)
+    epoch(*a, 0)
+    ck = {"model_state_dict": a[0].state_dict(), "optimizer_D": a[1].state_dict(), "scheduler_D": a[3].state_dict(),
+          "optimizer_G": a[2].state_dict(), "scheduler_G": a[4].state_dict(), "epoch": 0}
+    path = str(tmp_path / "epoch_0_checkpoint.pth")
+    torch.save(ck, path)
+    epoch(*a, 1)                              # the uninterrupted run
+
+    b = build(2)                              # different initial weights: everything must come from the file
+    ck2 = torch.load(path, map_location="cpu")
+    ck2["model_state_dict"] = {k.replace(".module", ""): v for k, v in ck2["model_state_dict"].items()}
+    b[0].load_state_dict(ck2["model_state_dict"])
+    b[1].load_state_dict(ck2["optimizer_D"])
+    b[3].load_state_dict(ck2["scheduler_D"])
+    b[2].load_state_dict(ck2["optimizer_G"])
+    b[4].load_state_dict(ck2["scheduler_G"])
+    assert ck2["epoch"] + 1 == 1
+    epoch(*b, 1)
+    sa, sb = a[0].state_dict(), b[0].state_dict()
+    assert sa.keys() == sb.keys()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    for oa, ob in ((a[1], b[1]), (a[2], b[2])):
+        da, db = oa.state_dict(), ob.state_dict()
+        assert da["param_groups"] == db["param_groups"]
+        for i in da["state"]:
+            for f in ("step", "exp_avg", "exp_avg_sq"):
+                assert torch.equal(torch.as_tensor(da["state"][i][f]).cpu(), torch.as_tensor(db["state"][i][f]).cpu()), (i, f)
