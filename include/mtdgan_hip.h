@@ -151,6 +151,7 @@ int mtd_act_grad(const float* g, int g_ld, const float* y, int y_ld, float* out,
                  long long npix, int C, float slope, void* stream);
 /* out[i] = a[i] * b[i]  (Dropout mask at networks.py:417 and its gradient), n contiguous floats */
 int mtd_mul(const float* a, const float* b, float* out, long long n, void* stream);
+int mtd_add(const float* a, const float* b, float* out, long long n, void* stream);      /* out = a + b (sum of two tasks' cotangents before a shared weight gradient) */
 /* dst[0..bytes) = src_pinned[0..bytes): src is page-locked host memory mapped into the device address space
  * (hipHostMalloc / torch pin_memory), read by a kernel on `stream`; bytes % 16 == 0, both 16-byte aligned.
  * Used for the descriptor tables (mtd_*_layer / mtd_loss_term / mtd_adamw_tensor arrays). */

@@ -145,6 +145,13 @@ __global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, c
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = a[i] * b[i];
 }
 
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = a[i] + b[i];
+}
+__global__ __launch_bounds__(256) void add4_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x4* __restrict__ out, long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) out[i] = a[i] + b[i];
+}
+
 constexpr int PACK_ELEMS = 4096;
 __global__ __launch_bounds__(256) void pack_weights_kernel(const mtd_pack_desc* __restrict__ D, int count) {
     int acc = 0, di = -1, local = 0;
@@ -196,6 +203,16 @@ extern "C" int mtd_act_grad(const float* g, int g_ld, const float* y, int y_ld, 
 extern "C" int mtd_mul(const float* a, const float* b, float* out, long long n, void* stream) {
     if (!a || !b || !out || n <= 0) return MTD_EINVAL;
     hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_add(const float* a, const float* b, float* out, long long n, void* stream) {
+    if (!a || !b || !out || n <= 0) return MTD_EINVAL;
+    if ((n % 4) == 0 && aligned16(a) && aligned16(b) && aligned16(out))
+        hipLaunchKernelGGL(add4_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)a, (const f32x4*)b, (f32x4*)out, n / 4);
+    else
+        hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }

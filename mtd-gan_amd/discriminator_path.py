@@ -253,9 +253,13 @@ class GradSink:
         return self.t.get(name)
 
 
-def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0):
+def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0, dec_export=None, dec_import=None):
     """Replay one recorded pass.  g_enc (B,1,1,1) / g_dec (B,64,64,1) / g_rec (B,64,64,1): output
-    cotangents (any may be None).  sink: GradSink or None.  All parameter gradients are ACCUMULATED."""
+    cotangents (any may be None).  sink: GradSink or None.  All parameter gradients are ACCUMULATED.
+    The decoders are task-specific: their parameter gradient is the SUM over the tasks that reach them through this tape,
+    and a weight gradient is linear in the cotangent -- so a pass may hand its decoder cotangents over instead of computing
+    the decoder weight gradients (dec_export: dict to fill, layer -> cotangent tensor) and the last pass over the tape
+    computes them once from the sums (dec_import: the dicts of the earlier passes merged)."""
     B = tp.B
     x = tp.x_in
     dev = x.device
@@ -266,6 +270,20 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0
         return sink is not None and sink.get(name) is not None
 
     Bh = getattr(tp, "pair", 0)
+    in_decoder = [False]
+
+    def cot(key, p):
+        """The cotangent a decoder weight gradient is taken from: None if it is handed over to a later pass, the sum with
+        the earlier passes' cotangents if this pass computes it for them, p otherwise (trunk and heads of the encoder)."""
+        if not in_decoder[0]:
+            return lambda: p
+        if dec_export is not None:
+            dec_export[key] = p
+            return None
+        if dec_import is not None and key in dec_import:
+            other = dec_import[key]
+            return lambda: K.add(p, other)          # evaluated on the side stream, right before the weight gradient
+        return lambda: p
 
     def wgrad_sn(name, p, q, gspec, N, Cc, k):
         """Raw weight gradient of an SN layer into the pass's temp (corrected and accumulated by mtd_sn_grad below).
@@ -273,18 +291,22 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0
         has its own sigma, u, v), so its batch halves go through two launches."""
         wn, bn = name + ".weight_orig", name + ".bias"
         if want(wn):
+            src = cot(name, p)
+            if src is None:
+                return
             hh, kk, ss, pp = gspec
             if Bh:
-                pa, qa, pb, qb = p[:Bh], q[:Bh], p[Bh:], q[Bh:]
+                qa, qb = q[:Bh], q[Bh:]
                 ga, gb_ = K.geom_fwd(Bh, hh, hh, kk, ss, pp), K.geom_fwd(B - Bh, hh, hh, kk, ss, pp)
 
                 def both():
-                    K.wgrad(pa, qa, ga, N, Cc, rt.gtemp(name, dev, 0, chain), Cc * k * k, k * k, db=sink.get(bn), accumulate=False, accumulate_bias=True)
-                    K.wgrad(pb, qb, gb_, N, Cc, rt.gtemp(name, dev, 1, chain), Cc * k * k, k * k, db=sink.get(bn), accumulate=False, accumulate_bias=True)
+                    pe = src()
+                    K.wgrad(pe[:Bh], qa, ga, N, Cc, rt.gtemp(name, dev, 0, chain), Cc * k * k, k * k, db=sink.get(bn), accumulate=False, accumulate_bias=True)
+                    K.wgrad(pe[Bh:], qb, gb_, N, Cc, rt.gtemp(name, dev, 1, chain), Cc * k * k, k * k, db=sink.get(bn), accumulate=False, accumulate_bias=True)
                 side.run(both, p, q)
             else:
                 geom = K.geom_fwd(B, hh, hh, kk, ss, pp)
-                side.run(lambda: K.wgrad(p, q, geom, N, Cc, rt.gtemp(name, dev, 0, chain), Cc * k * k, k * k, db=sink.get(bn), accumulate=False,
+                side.run(lambda: K.wgrad(src(), q, geom, N, Cc, rt.gtemp(name, dev, 0, chain), Cc * k * k, k * k, db=sink.get(bn), accumulate=False,
                                          accumulate_bias=True), p, q)
             sn_touched.append(name)
         elif want(bn):
@@ -304,8 +326,11 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0
     def decoder_backward(pre, g_out, cats, o1s, o2s, ins, head):
         """shared by the SEG ('s') and REC ('r') decoders; returns the gradient of x_bot"""
         t6 = o2s[6]
+        in_decoder[0] = True
         if want(head + ".weight"):
-            side.run(lambda: K.wgrad(g_out, t6, g64, 1, 1, sink.get(head + ".weight"), 1, 1, db=sink.get(head + ".bias"), accumulate=True), g_out, t6)
+            src_h = cot(head, g_out)
+            if src_h is not None:
+                side.run(lambda: K.wgrad(src_h(), t6, g64, 1, 1, sink.get(head + ".weight"), 1, 1, db=sink.get(head + ".bias"), accumulate=True), g_out, t6)
         g = K.empty_nhwc(B, 64, 64, 1, x)
         K.conv(g_out, P[head + ".weight"], g64, 1, 1, 1, 1, g)
         for lvl in range(6, 0, -1):
@@ -332,10 +357,13 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0
                 gq = K.geom_fwd(B, r // 2, r // 2, 1, 1, 0)
                 wn = f"r_up{lvl}.upsample.0.weight"
                 if want(wn):
-                    side.run(lambda gr=gr, tin=tin, gq=gq, wn=wn, cup=cup, cin_up=cin_up, lvl=lvl: K.wgrad(
-                        gr, tin, gq, 4 * cup, cin_up, sink.get(wn), cin_up, 1, db=sink.get(f"r_up{lvl}.upsample.0.bias"), accumulate=True), gr, tin)
+                    src_u = cot(f"r_up{lvl}", gr)
+                    if src_u is not None:
+                        side.run(lambda src_u=src_u, tin=tin, gq=gq, wn=wn, cup=cup, cin_up=cin_up, lvl=lvl: K.wgrad(
+                            src_u(), tin, gq, 4 * cup, cin_up, sink.get(wn), cin_up, 1, db=sink.get(f"r_up{lvl}.upsample.0.bias"), accumulate=True), gr, tin)
                 g = K.empty_nhwc(B, r // 2, r // 2, cin_up, x)
                 K.conv(gr, P[wn], gq, cin_up, 4 * cup, 1, cin_up, g)
+        in_decoder[0] = False
         return g
 
     if g_rec is not None:

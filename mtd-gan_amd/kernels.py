@@ -352,6 +352,15 @@ def mul(a, b, out=None):
     return out
 
 
+def add(a, b):
+    """a + b for two contiguous tensors of the same shape (new tensor)."""
+    if a.shape != b.shape or not (a.is_contiguous() and b.is_contiguous()):
+        raise ValueError("add: expected two contiguous tensors of the same shape")
+    out = torch.empty_like(a)
+    check(_lib.lib().mtd_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), stream_ptr()), "mtd_add")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- descriptor tables
 _desc_cache = {}
 

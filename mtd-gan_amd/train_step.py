@@ -93,10 +93,24 @@ class DStepTape:
             tofs += (sz + 3) // 4 * 4
         sink_c = DP.GradSink(t2)
 
-        def consistency(chain):
-            # through D(rec.clip), passes 3 and 4, back into the restoration decoder of passes 1 and 2
-            gin34 = DP.disc_backward(rt, P, t34, G2["c3_e"], G2["c3_d"], None, sink_c, True, chain=chain)
-            DP.disc_backward(rt, P, t12, G2["c_e"], G2["c_d"], K.clip01_bwd(gin34, r12), sink_c, False, chain=chain)
+        # The decoders' gradients are sums over the tasks that reach them through passes 1+2 (SEG decoder: adversarial +
+        # consistency, REC decoder: restoration + consistency) and a weight gradient is linear in its cotangent: the
+        # adversarial and the restoration pass hand their decoder cotangents over and the consistency pass, the last one over
+        # that tape, computes every decoder weight gradient once from the sums -- two decoder weight-gradient sweeps less.
+        exp_s, exp_r = {}, {}
+
+        def adversarial(chain):         # image-level + pixel-level heads on passes 1 and 2
+            DP.disc_backward(rt, P, t12, G2["d_e"], G2["d_d"], None, sinks[0], False, chain=chain, dec_export=exp_s)
+
+        def restoration(chain):
+            DP.disc_backward(rt, P, t12, None, None, G2["r_r"], sinks[1], False, chain=chain, dec_export=exp_r)
+
+        def consistency34(chain):       # through D(rec.clip), passes 3 and 4 ...
+            return DP.disc_backward(rt, P, t34, G2["c3_e"], G2["c3_d"], None, sink_c, True, chain=chain)
+
+        def consistency12(chain, gin34):  # ... and back into the restoration decoder of passes 1 and 2
+            DP.disc_backward(rt, P, t12, G2["c_e"], G2["c_d"], K.clip01_bwd(gin34, r12), sink_c, False, chain=chain,
+                             dec_import={**exp_s, **exp_r})
 
         if K.CHAINS and not torch.cuda.is_current_stream_capturing():
             # main stream + two chain streams, each with its own side stream for weight gradients: every kernel boundary in
@@ -104,34 +118,43 @@ class DStepTape:
             main = torch.cuda.current_stream()
             start = torch.cuda.Event()
             start.record(main)
-            done = []
-
-            def chain(idx, body, task):
-                st = K.chain_stream(dev, idx)
-                st.wait_event(start)
-                with torch.cuda.stream(st):
-                    body()
-                    K.side_stream(dev, 10 + idx).join()
-                    if dp is not None:
-                        dp.all_reduce_avg(S[task])
-                    ev = torch.cuda.Event()
-                    ev.record(st)
-                done.append(ev)
-
-            chain(2, lambda: consistency(2), 2)
-            chain(1, lambda: DP.disc_backward(rt, P, t12, None, None, G2["r_r"], sinks[1], False, chain=1), 1)
-            DP.disc_backward(rt, P, t12, G2["d_e"], G2["d_d"], None, sinks[0], False)       # adversarial (image + pixel level)
+            st_c, st_r = K.chain_stream(dev, 2), K.chain_stream(dev, 1)
+            st_c.wait_event(start)
+            with torch.cuda.stream(st_c):
+                gin34 = consistency34(2)
+            st_r.wait_event(start)
+            with torch.cuda.stream(st_r):
+                restoration(1)
+                ev_r_cot = torch.cuda.Event()
+                ev_r_cot.record(st_r)                    # its decoder cotangents exist (data-gradient chain)
+                K.side_stream(dev, 11).join()
+                if dp is not None:
+                    dp.all_reduce_avg(S[1])
+                ev_r = torch.cuda.Event()
+                ev_r.record(st_r)
+            adversarial(0)
+            ev_d_cot = torch.cuda.Event()
+            ev_d_cot.record(main)
             K.side_stream(dev).join()
             if dp is not None:
                 dp.all_reduce_avg(S[0])
-            for ev in done:
-                main.wait_event(ev)
+            with torch.cuda.stream(st_c):
+                st_c.wait_event(ev_r_cot)
+                st_c.wait_event(ev_d_cot)
+                consistency12(2, gin34)
+                K.side_stream(dev, 12).join()
+                if dp is not None:
+                    dp.all_reduce_avg(S[2])
+                ev_c = torch.cuda.Event()
+                ev_c.record(st_c)
+            main.wait_event(ev_r)
+            main.wait_event(ev_c)
         else:
-            DP.disc_backward(rt, P, t12, G2["d_e"], G2["d_d"], None, sinks[0], False)       # task 0: adversarial
+            adversarial(0)                                                                   # task 0
             self._sync_task(dp, S, 0)
-            DP.disc_backward(rt, P, t12, None, None, G2["r_r"], sinks[1], False)            # task 1: restoration
+            restoration(0)                                                                   # task 1
             self._sync_task(dp, S, 1)
-            consistency(0)                                                                   # task 2: consistency
+            consistency12(0, consistency34(0))                                               # task 2
             self._sync_task(dp, S, 2)
             K.side_stream(dev).join()          # weight gradients / spectral-norm corrections ran on the side stream
         if dp is not None:
