@@ -41,6 +41,14 @@ __device__ __forceinline__ ScalePair load_scale(const mtd_conv_args& a) {
 }
 __device__ __forceinline__ float pick_scale(const ScalePair& s, int m) { return m < s.split ? s.s0 : s.s1; }
 
+// Consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2).  Position of workgroup b in an order
+// that gives every XCD one contiguous run of the nblk tiles: tiles that share operands then meet in the same L2.
+__device__ __forceinline__ int xcd_contiguous_block(int b, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int x = b & 7, i = b >> 3;
+    return x * q + (x < r ? x : r) + i;
+}
+
 // launch profiler hooks (api.hip)
 int mtd_prof_begin(int kernel, int cfg, int splitk, long long M, int N, int C, int taps, hipStream_t s);
 void mtd_prof_end(int slot, hipStream_t s);

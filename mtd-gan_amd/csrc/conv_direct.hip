@@ -170,14 +170,6 @@ struct FwdParams {
     int tap_dy[16], tap_dx[16], tap_kidx[16];
 };
 
-__device__ __forceinline__ int xcd_contiguous_block(int b, int nblk) {
-    // consecutive workgroup ids round-robin over the 8 XCDs; give every XCD one contiguous run of tiles so
-    // that neighbouring image rows (re-read by the vertical taps) meet in the same L2
-    const int q = nblk >> 3, r = nblk & 7;
-    const int x = b & 7, i = b >> 3;
-    return x * q + (x < r ? x : r) + i;
-}
-
 __device__ __forceinline__ void store_epilogue4(const mtd_conv_args& a, const float acc[4], float sc, const float bias[4],
                                                 long long pix, int n, int vec_store) {
     float v[4];

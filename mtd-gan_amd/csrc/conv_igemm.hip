@@ -53,7 +53,20 @@ struct IgemmParams {
     int tap_kidx[16];               // index of tap t in the kh*kw plane of the weights
     int out_identity;  // output pixel index == launch-grid pixel index
     int out_linear;    // 32 consecutive launch-grid pixels (from a multiple of 32) map to output pixels pix0 + r * out_sx
+    int xcd_map;       // tiles in XCD-contiguous, n-fastest order (tile_of below)
 };
+
+// (m tile, n tile) of this workgroup.  Dispatch order is blockIdx.x fastest and consecutive workgroups land on different
+// XCDs, so with the plain mapping the N/BN workgroups that read the same activation tile are spread over all eight L2s
+// and over time.  With xcd_map every XCD walks its own contiguous run of tiles, n fastest: an activation tile is fetched
+// into one L2 once and reused by all its n tiles while the (small) weight block stays resident.
+__device__ __forceinline__ void tile_of(const IgemmParams& p, int& tm, int& tn) {
+    if (!p.xcd_map) { tm = blockIdx.x; tn = blockIdx.y; return; }
+    const int MT = gridDim.x, NT = gridDim.y;
+    const int t = xcd_contiguous_block(blockIdx.y * MT + blockIdx.x, MT * NT);
+    tm = t / NT;
+    tn = t - tm * NT;
+}
 
 __device__ __forceinline__ long long out_pixel(const mtd_geom& g, int m, int identity) {
     if (identity) return m;
@@ -204,7 +217,9 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
     const int wm = wave / WGN, wn = wave % WGN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int tile_m, tile_n;
+    tile_of(p, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int cbeg = blockIdx.z * p.c_per_split;
     const int cend = min(a.C, cbeg + p.c_per_split);
     const int T = g.TH * g.TW;
@@ -417,7 +432,9 @@ __global__ __launch_bounds__(256, 2) void igemm_tb_kernel(const IgemmParams p) {
     const mtd_geom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * 32;
+    int tile_m, tile_n;
+    tile_of(p, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * 32;
     const int cbeg = blockIdx.z * p.c_per_split;
     const int cend = min(a.C, cbeg + p.c_per_split);
     const int T = g.TH * g.TW;
@@ -1108,6 +1125,8 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
     const mtd_geom& g = a->g;
     p.out_identity = (g.out_sy == 1 && g.out_sx == 1 && g.out_oy == 0 && g.out_ox == 0 && g.OHF == g.OH && g.OWF == g.OW);
     p.out_linear = p.out_identity || (g.OW % 32 == 0);
+    static const int env_xcd = [] { const char* e = getenv("MTD_IGEMM_XCD"); return e ? atoi(e) : 1; }();
+    p.xcd_map = env_xcd;
     if (pl.splitk > 1) {
         size_t need = (size_t)pl.splitk * (size_t)p.M * a->N * sizeof(float);
         if (!a->ws || a->ws_bytes < need) return MTD_EWS;
