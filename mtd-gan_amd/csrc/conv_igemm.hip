@@ -169,29 +169,46 @@ __device__ __forceinline__ void epi_store(const IgemmParams& p, const f32x16& ac
         if (ad.ok(p, i)) *ad.at(a.out, a.out_ld, i) = v[i];
 }
 
-template <bool FULL, int E0>
-__device__ __forceinline__ void epi_group8(const IgemmParams& p, const f32x16& acc, int mrow0, int lane, int n, const ScalePair& sp,
-                                           float bias_n) {
-    EpiAddr<FULL, E0, 8> ad;
-    EpiOps<8> o;
+template <bool FULL, int E0, int NE>
+__device__ __forceinline__ void epi_group(const IgemmParams& p, const f32x16& acc, int mrow0, int lane, int n, const ScalePair& sp,
+                                          float bias_n) {
+    EpiAddr<FULL, E0, NE> ad;
+    EpiOps<NE> o;
     ad.init(p, mrow0, lane, n);
     epi_load(p, ad, o);
     epi_store(p, acc, ad, sp, bias_n, o);
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// rows mrow0 .. mrow0 + 31 of the launch (mrow0 is wave-uniform and a multiple of 32), column n of this lane
+// rows mrow0 .. mrow0 + 31 of the launch (mrow0 is wave-uniform and a multiple of 32), column n of this lane.  NE = values
+// per group: 8 for one accumulator per wave, 4 for register-blocked tiles (keeps their register count -- and with it the
+// resident waves per SIMD -- at the main loop's).
+template <int NE>
 __device__ __forceinline__ void epilogue16(const IgemmParams& p, const f32x16& acc, int mrow0, int lane, int n, const ScalePair& sp) {
     if (mrow0 >= p.M) return;
     const mtd_conv_args& a = p.a;
     const float bias_n = a.bias ? a.bias[n] : 0.f;
     if (p.out_linear) {
         if (mrow0 + 32 <= p.M) {
-            epi_group8<true, 0>(p, acc, mrow0, lane, n, sp, bias_n);
-            epi_group8<true, 8>(p, acc, mrow0, lane, n, sp, bias_n);
+            if (NE == 8) {
+                epi_group<true, 0, 8>(p, acc, mrow0, lane, n, sp, bias_n);
+                epi_group<true, 8, 8>(p, acc, mrow0, lane, n, sp, bias_n);
+            } else {
+                epi_group<true, 0, 4>(p, acc, mrow0, lane, n, sp, bias_n);
+                epi_group<true, 4, 4>(p, acc, mrow0, lane, n, sp, bias_n);
+                epi_group<true, 8, 4>(p, acc, mrow0, lane, n, sp, bias_n);
+                epi_group<true, 12, 4>(p, acc, mrow0, lane, n, sp, bias_n);
+            }
         } else {
-            epi_group8<false, 0>(p, acc, mrow0, lane, n, sp, bias_n);
-            epi_group8<false, 8>(p, acc, mrow0, lane, n, sp, bias_n);
+            if (NE == 8) {
+                epi_group<false, 0, 8>(p, acc, mrow0, lane, n, sp, bias_n);
+                epi_group<false, 8, 8>(p, acc, mrow0, lane, n, sp, bias_n);
+            } else {
+                epi_group<false, 0, 4>(p, acc, mrow0, lane, n, sp, bias_n);
+                epi_group<false, 4, 4>(p, acc, mrow0, lane, n, sp, bias_n);
+                epi_group<false, 8, 4>(p, acc, mrow0, lane, n, sp, bias_n);
+                epi_group<false, 12, 4>(p, acc, mrow0, lane, n, sp, bias_n);
+            }
         }
         return;
     }
@@ -409,7 +426,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(cons
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             const int n = n0 + (wn * WN + j) * 32 + l31;
-            epilogue16(p, acc[i][j], m0 + (wm * WM + i) * 32, lane, n, sp);
+            epilogue16<4>(p, acc[i][j], m0 + (wm * WM + i) * 32, lane, n, sp);
         }
     MTD_STAMP(61);
 }
@@ -571,7 +588,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tb_kernel(const IgemmParams p) {
     const ScalePair sp = load_scale(a);
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
-        epilogue16(p, acc[i], m0 + (wave * WM + i) * 32, lane, n0 + l31, sp);
+        epilogue16<(WM > 1) ? 4 : 8>(p, acc[i], m0 + (wave * WM + i) * 32, lane, n0 + l31, sp);
     }
 }
 
@@ -667,7 +684,7 @@ __global__ __launch_bounds__(256, 2) void igemm_c32p_kernel(const IgemmParams p,
             __builtin_amdgcn_sched_barrier(0);
         }
         // epilogue of this tile (the next tile's first fragments are already in flight)
-        epilogue16(p, acc, tile * 32, lane, n0 + l31, sp);
+        epilogue16<8>(p, acc, tile * 32, lane, n0 + l31, sp);
         if (next >= ntiles) break;
         tile = next;
         boff = boff2;
@@ -924,7 +941,7 @@ __global__ __launch_bounds__(256, 2) void igemm_v2_kernel(const IgemmParams p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            epilogue16(p, acc[i][j], m0 + wm * 64 + i * 32, lane, n0 + wn * 64 + j * 32 + l31, sp);
+            epilogue16<4>(p, acc[i][j], m0 + wm * 64 + i * 32, lane, n0 + wn * 64 + j * 32 + l31, sp);
         }
 }
 
