@@ -144,6 +144,8 @@ int mtd_irfft_rows_any(const float* T, float* out, int out_ld, const float* add1
 
 /* 64x64 transpose of the 1x1 spectral conv weight (W2[o][k] -> W2T[k][o]). */
 int mtd_transpose64(const float* src, float* dst, void* stream);
+/* n transposes in one launch; ptrs_dev (device): [src_0, dst_0, src_1, dst_1, ...] (the 21 blocks' mix weights, once per step) */
+int mtd_transpose64_multi(const float* const* ptrs_dev, int n, void* stream);
 
 /* ---- element-wise helpers -------------------------------------------------------------------- */
 /* out[p,c] = g[p,c] * (y[p,c] > 0 ? 1 : slope)  over npix x C, each tensor with its own ld. */

@@ -63,6 +63,10 @@ class LossTerm(C.Structure):
                 ("grad_out", C.c_void_p), ("coef", C.c_float), ("accumulate", C.c_int)]
 
 
+class PtrPair(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p)]
+
+
 class PatchDesc(C.Structure):
     _fields_ = [("slice", C.c_int), ("uy", C.c_float), ("ux", C.c_float), ("rot_k", C.c_int), ("flip", C.c_int), ("angle", C.c_float)]
 
@@ -114,6 +118,7 @@ def lib():
     sig("mtd_spec_mix_wgrad_reduce", ci, vp, ci, vp, vp, ci, vp)
     sig("mtd_irfft_rows", ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, ci, vp)
     sig("mtd_transpose64", ci, vp, vp, vp)
+    sig("mtd_transpose64_multi", ci, vp, ci, vp)
     sig("mtd_rfft_rows_any", ci, vp, ci, vp, ci, ci, vp)
     sig("mtd_spec_mix_any", ci, vp, vp, vp, vp, ci, ci, vp)
     sig("mtd_irfft_rows_any", ci, vp, vp, ci, vp, ci, vp, ci, ci, ci, vp)
@@ -162,7 +167,7 @@ EXPORTS = [
     "mtd_pcgrad_gram", "mtd_pcgrad_combine", "mtd_adamw_multi", "mtd_adamw_multi_dyn", "mtd_adamw_multi_pre", "mtd_loss_terms_ws_bytes", "mtd_loss_terms",
     "mtd_loss_term_grads", "mtd_clip01", "mtd_clip01_bwd", "mtd_edge_loss_ws_bytes", "mtd_edge_loss",
     "mtd_prof_enable", "mtd_prof_collect", "mtd_conv_igemm_override", "mtd_conv_wgrad_override", "mtd_upload", "mtd_image_metrics_ws_bytes", "mtd_image_metrics", "mtd_rfft_rows_any", "mtd_spec_mix_any", "mtd_irfft_rows_any",
-    "mtd_foreground_bbox", "mtd_window_patches", "mtd_hu_window", "mtd_add",
+    "mtd_foreground_bbox", "mtd_window_patches", "mtd_hu_window", "mtd_add", "mtd_transpose64_multi",
 ]
 
 

@@ -443,6 +443,16 @@ __global__ __launch_bounds__(256) void transpose64_kernel(const float* __restric
     for (int i = threadIdx.x; i < 4096; i += 256) dst[i] = t[(i & 63) * 65 + (i >> 6)];
 }
 
+// all blocks' mix weights in one launch: ptrs = [src_0, dst_0, src_1, dst_1, ...]
+__global__ __launch_bounds__(256) void transpose64_multi_kernel(const float* const* __restrict__ ptrs) {
+    __shared__ float t[64 * 65];
+    const float* src = ptrs[2 * blockIdx.x];
+    float* dst = const_cast<float*>(ptrs[2 * blockIdx.x + 1]);
+    for (int i = threadIdx.x; i < 4096; i += 256) t[(i >> 6) * 65 + (i & 63)] = src[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += 256) dst[i] = t[(i & 63) * 65 + (i >> 6)];
+}
+
 constexpr int MIX_GS = 32;
 
 }  // namespace
@@ -523,6 +533,13 @@ extern "C" int mtd_spec_mix_wgrad_reduce(const float* ws, int B, float* dw2, flo
         ns = ng;
     }
     hipLaunchKernelGGL(mix_finish_kernel, dim3((4096 + 64 + 255) / 256), dim3(256), 0, s, cur, ns, dw2, db2, accumulate);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_transpose64_multi(const float* const* ptrs_dev, int n, void* stream) {
+    if (!ptrs_dev || n <= 0) return MTD_EINVAL;
+    hipLaunchKernelGGL(transpose64_multi_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, ptrs_dev);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }

@@ -14,7 +14,7 @@ CH = 32
 
 
 # ------------------------------------------------------------------------------------------------ block
-def block_forward(x, w_img, b_img, w_fft, b_fft, save):
+def block_forward(x, w_img, b_img, w_fft, b_fft, save, w2t=None):
     """x: (B,64,64,32).  Returns (out, saved) with saved = (x, img, S, Z) when save."""
     B, H, W, _ = x.shape
     g = K.geom_fwd(B, H, W, 3, 1, 1)
@@ -33,7 +33,8 @@ def block_forward(x, w_img, b_img, w_fft, b_fft, save):
     side = K.side_stream(x.device, 1)
     side.run(lambda: K.conv(x, w_img, g, CH, CH, CH * 9, 9, img, bias=b_img, act=ACT_RELU), x)   # relu(conv3x3(x)+b)
     R = K.rfft_rows(x, 0)
-    w2t = K.transpose64(w_fft)
+    if w2t is None:
+        w2t = K.transpose64(w_fft)
     T, S, Z = K.spec_mix_fwd(R, w2t, b_fft, save)
     out = K.empty_nhwc(B, H, W, CH, x)
     side.join()
@@ -92,6 +93,7 @@ def generator_forward(x, P, save):
         if save:
             views.append((w_img, CH, CH, 9, CH * 9))
     K.prepack(views)                                       # one launch for all [tap][n][c] weight views
+    w2ts = K.transpose64_all([blk[2] for blk in P.blk]) if (H == 64 and W == 64) else {}      # ... and one for the mix weights
     gf = K.geom_fwd(B, H, W, 3, 1, 1)
     gt = K.geom_dgrad_s1(B, H, W, 3, 1)                    # ConvTranspose2d(k3,s1,p1) gathers like a stride-1 dgrad
     tape = {"t": [], "e": [], "blk": [], "d": [], "u": []}
@@ -99,7 +101,7 @@ def generator_forward(x, P, save):
     K.conv(x, P.enc_w[0], gf, CH, 1, 9, 9, t, bias=P.enc_b[0], act=ACT_RELU)
     e = None
     for i in range(L + 1):
-        e, sv = block_forward(t, *P.blk[i], save)
+        e, sv = block_forward(t, *P.blk[i], save, w2t=w2ts.get(id(P.blk[i][2])))
         if save:
             tape["t"].append(t)
             tape["blk"].append(sv)
@@ -114,7 +116,7 @@ def generator_forward(x, P, save):
     for j in range(L, 0, -1):                              # decoder[j], j = 10..1
         d = K.empty_nhwc(B, H, W, CH, x)
         K.conv(cur, P.dec_w[j], gt, CH, CH, 9, CH * 9, d, bias=P.dec_b[j], add1=tape["e"][j - 1], act=ACT_RELU)
-        u, sv = block_forward(d, *P.blk[2 * L + 1 - j], save)   # enforce[11] after decoder[-1] ... enforce[20] after decoder[-10]
+        u, sv = block_forward(d, *P.blk[2 * L + 1 - j], save, w2t=w2ts.get(id(P.blk[2 * L + 1 - j][2])))   # enforce[11] after decoder[-1] ... enforce[20] after decoder[-10]
         if save:
             tape["u"].append(cur)                          # input of decoder[j]
             tape["d"].append(d)

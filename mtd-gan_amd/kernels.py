@@ -12,6 +12,7 @@ from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ConvArgs, Geom, WgradArgs, chec
 
 _ws = {}
 _pack_cache = {}
+_t64_cache = {}     # transposed 64 x 64 mix weights of the Res-FFT blocks
 _pack_epoch = 0
 
 
@@ -23,13 +24,15 @@ def weights_changed(params=None):
     if params is None:
         _pack_epoch += 1
         _pack_cache.clear()
+        _t64_cache.clear()
         return
     stor = set()
     for p in params:
         stor.add(p.untyped_storage().data_ptr())
         p._mtd_epoch = getattr(p, "_mtd_epoch", 0) + 1
-    for key in [k for k, (_dst, w) in _pack_cache.items() if w.untyped_storage().data_ptr() in stor]:
-        del _pack_cache[key]
+    for cache in (_pack_cache, _t64_cache):
+        for key in [k for k, (_dst, w) in cache.items() if w.untyped_storage().data_ptr() in stor]:
+            del cache[key]
 
 
 def prepack(views):
@@ -293,6 +296,27 @@ def spectral_branch_any(x, w2t, b2, out, add1=None, add2=None):
     check(L.mtd_spec_mix_any(R.data_ptr(), w2t.data_ptr(), b2.data_ptr(), T.data_ptr(), B, S, stream_ptr()), "mtd_spec_mix_any")
     check(L.mtd_irfft_rows_any(T.data_ptr(), out.data_ptr(), ld_of(out), _ptr(add1), ld_of(add1) if add1 is not None else 0,
                                _ptr(add2), ld_of(add2) if add2 is not None else 0, B, S, stream_ptr()), "mtd_irfft_rows_any")
+    return out
+
+
+def transpose64_all(weights):
+    """Transposes of many 64 x 64 matrices in ONE launch (the mix weights of all Res-FFT blocks of a forward pass), cached
+    until the weights change (dropped by weights_changed() like the packed conv weights).  Returns {id(w): transposed}."""
+    out, todo = {}, []
+    for w in weights:
+        key = (w.data_ptr(), w._version, _pack_epoch)
+        hit = _t64_cache.get(key)
+        if hit is None:
+            dst = torch.empty((64, 64), dtype=torch.float32, device=w.device)
+            d = _lib.PtrPair()
+            d.src, d.dst = w.data_ptr(), dst.data_ptr()
+            todo.append(d)
+            hit = (dst, w)
+            _t64_cache[key] = hit
+        out[id(w)] = hit[0]
+    if todo:
+        tab, _host = device_table(todo, weights[0].device)
+        check(_lib.lib().mtd_transpose64_multi(tab.data_ptr(), len(todo), stream_ptr()), "mtd_transpose64_multi")
     return out
 
 
