@@ -123,6 +123,19 @@ def pmc_traffic(kernel):
     return round(tot)
 
 
+def pmc_mfma_util(kernel):
+    """MFMA-pipe utilisation of `kernel` from the committed PMC pass (profiles/r1_pmc_mfma_util.csv: SQ_VALU_MFMA_BUSY_CYCLES /
+    (32 x SQ_BUSY_CYCLES), calibrated at 1.000 on a register-only MFMA loop, tools/pmc_mfma_util.py); None when absent."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r1_pmc_mfma_util.csv")
+    if not os.path.exists(path):
+        return None
+    for row in csv.DictReader(open(path)):
+        if kernel in row["Kernel_Name"]:
+            return float(row["MfmaUtil"])
+    return None
+
+
 def main():
     args = parse()
     import torch
@@ -218,6 +231,7 @@ def main():
             roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                         "traffic": pmc_traffic(name) if wl.name == "full_step" else None,   # the committed PMC passes profile the default workload
+                        "mfma_util_pmc": pmc_mfma_util(name) if wl.name == "full_step" else None,
                         "launches_timed": d["n"], "avg_launch_us": round(1e3 * d["ms"] / d["n"], 2),
                         "avg_launch_us_with_event_pair": round(1e3 * raw_ms / d["n"], 2), "event_pair_us": round(1e3 * ev_over_ms, 2),
                         "flops_per_launch": round(d["flops"] / d["n"]), "measured": "second pass of the same steps, all kernels in one stream",
