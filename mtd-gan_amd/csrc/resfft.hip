@@ -19,6 +19,23 @@
 // the column/mix kernel is fp32-MFMA-bound (2*64*64 flops per frequency) with VALU FFTs beside it.
 #include "common.h"
 
+// In-kernel phase stamps for the diagnostic build only (tools/specmix_stamp.hip defines MTD_STAMPS and includes this file).
+#ifdef MTD_STAMPS
+__device__ unsigned long long* rf_stamp_buf;
+#define RF_STAMP(i)                                                                                         \
+    do {                                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < 8 && blockIdx.y < 8) {                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                              \
+            unsigned long long t__;                                                                         \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                      \
+            rf_stamp_buf[(blockIdx.y * 8 + blockIdx.x) * 16 + (i)] = t__;                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                              \
+        }                                                                                                   \
+    } while (0)
+#else
+#define RF_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 __device__ __constant__ const float COS64[32] = {
@@ -172,6 +189,7 @@ __global__ __launch_bounds__(64) void spec_mix_fwd_kernel(const float* __restric
     const int b = blockIdx.y;
     const int kw = 2 * blockIdx.x + kwl;
     const bool valid = kw < NKW;
+    RF_STAMP(0);
     float re[64], im[64];
     const long long colbase = ((long long)(b * NKW + (valid ? kw : 0)) * 64) * 64;
     {
@@ -182,7 +200,9 @@ __global__ __launch_bounds__(64) void spec_mix_fwd_kernel(const float* __restric
             im[h] = valid ? src[h * 64 + 32] : 0.f;
         }
     }
+    RF_STAMP(1);
     fft64<-1>(re, im);
+    RF_STAMP(2);
 #pragma unroll
     for (int kh = 0; kh < 64; ++kh) {
         const float sr = re[brev6(kh)] * 0.125f, si = im[brev6(kh)] * 0.125f;
@@ -194,6 +214,7 @@ __global__ __launch_bounds__(64) void spec_mix_fwd_kernel(const float* __restric
         }
     }
     __syncthreads();
+    RF_STAMP(3);
     // the mix weights as MFMA B fragments: 64 registers, one batch of loads (re / im are dead from here to the inverse FFT)
     float wf0[32], wf1[32];
 #pragma unroll
@@ -201,6 +222,7 @@ __global__ __launch_bounds__(64) void spec_mix_fwd_kernel(const float* __restric
         wf0[kk] = w2t[(2 * kk + kh2) * 64 + l31];
         wf1[kk] = w2t[(2 * kk + kh2) * 64 + 32 + l31];
     }
+    RF_STAMP(4);
 #pragma unroll 1
     for (int k2 = 0; k2 < 2; ++k2) {
         const int kw2 = 2 * blockIdx.x + k2;
@@ -242,12 +264,15 @@ __global__ __launch_bounds__(64) void spec_mix_fwd_kernel(const float* __restric
         }
     }
     __syncthreads();
+    RF_STAMP(5);
 #pragma unroll
     for (int kh = 0; kh < 64; ++kh) {
         re[kh] = Xs[(kwl * 64 + kh) * XLD + c];
         im[kh] = Xs[(kwl * 64 + kh) * XLD + 32 + c];
     }
+    RF_STAMP(6);
     fft64<+1>(re, im);
+    RF_STAMP(7);
     if (valid) {
         float* dst = T + colbase + c;
 #pragma unroll
@@ -256,6 +281,7 @@ __global__ __launch_bounds__(64) void spec_mix_fwd_kernel(const float* __restric
             dst[h * 64 + 32] = im[brev6(h)] * 0.125f;
         }
     }
+    RF_STAMP(8);
 }
 
 constexpr int MIX_SLAB = 64 * 64 + 128;   // dW2 partial + two db2 partial rows per workgroup
