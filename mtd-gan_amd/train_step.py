@@ -44,7 +44,8 @@ class DStepTape:
         ts_names = [by_id[id(p)] for p in (task_specific_params or [])]
         sizes = [D.get_parameter(nme).numel() for nme in sh_names]
         total = sum(sizes)
-        S = torch.zeros((4, total), dtype=torch.float32, device=dev)       # 3 task vectors + merged
+        S = torch.empty((4, total), dtype=torch.float32, device=dev)       # 3 task vectors (accumulated into: zeroed) + merged (written whole)
+        S[:3].zero_()
         # task-specific gradients: views of one flat buffer, so that N > 1 averages them with a single collective
         ts_sizes = [D.get_parameter(nme).numel() for nme in ts_names]
         # (each view starts on a 16-byte boundary: the spectral-norm correction then moves float4s)
