@@ -13,7 +13,18 @@ from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ConvArgs, Geom, WgradArgs, chec
 _ws = {}
 _pack_cache = {}
 _t64_cache = {}     # transposed 64 x 64 mix weights of the Res-FFT blocks
+_latest = {}        # (cache id, identity of a derived view without its version) -> current key: one generation per view
 _pack_epoch = 0
+
+
+def _remember(cache, ident, key, value):
+    """cache[key] = value, dropping the entry of an older version of the same view (an optimizer that updates in place,
+    e.g. torch.optim.AdamW, bumps the version counter on every step; without this the old generations would pile up)."""
+    old = _latest.get((id(cache), ident))
+    if old is not None and old != key:
+        cache.pop(old, None)
+    _latest[(id(cache), ident)] = key
+    cache[key] = value
 
 
 def weights_changed(params=None):
@@ -25,6 +36,7 @@ def weights_changed(params=None):
         _pack_epoch += 1
         _pack_cache.clear()
         _t64_cache.clear()
+        _latest.clear()
         return
     stor = set()
     for p in params:
@@ -50,7 +62,7 @@ def prepack(views):
         d = _lib.PackDesc()
         d.src, d.dst, d.N, d.C, d.T, d.sn, d.sc = w.data_ptr(), dst.data_ptr(), N, Cc, T, w_sn, w_sc
         todo.append(d)
-        _pack_cache[key] = (dst, w)
+        _remember(_pack_cache, (w.data_ptr(), N, Cc, w_sn, w_sc), key, (dst, w))
     if todo:
         tab, host = device_table(todo, todo and views[0][0].device)
         check(_lib.lib().mtd_pack_weights(tab.data_ptr(), C.cast(host, C.c_void_p), len(todo), stream_ptr()), "mtd_pack_weights")
@@ -69,7 +81,7 @@ def packed_weight_view(w, N, Cc, w_sn, w_sc):
         tab, host = device_table([d], w.device)
         check(_lib.lib().mtd_pack_weights(tab.data_ptr(), C.cast(host, C.c_void_p), 1, stream_ptr()), "mtd_pack_weights")
         hit = (dst, w)          # keep the source alive so its data_ptr cannot be recycled under the same key
-        _pack_cache[key] = hit
+        _remember(_pack_cache, (w.data_ptr(), N, Cc, w_sn, w_sc), key, hit)
     return hit[0], Cc, 1, N * Cc
 STATS = {"table_hit": 0, "table_miss": 0, "zero_copy_reads": 0}
 _igemm_ws_cache = {}
@@ -312,7 +324,7 @@ def transpose64_all(weights):
             d.src, d.dst = w.data_ptr(), dst.data_ptr()
             todo.append(d)
             hit = (dst, w)
-            _t64_cache[key] = hit
+            _remember(_t64_cache, w.data_ptr(), key, hit)
         out[id(w)] = hit[0]
     if todo:
         tab, _host = device_table(todo, weights[0].device)

@@ -88,3 +88,15 @@ def test_fused_adamw_loads_reference_optimizer_checkpoint():
     back.step()
     assert int(back.state[w[0]]["step"]) == 3
     assert isinstance(mine.state[w[0]]["step"], int)          # exporting did not disturb the live state
+
+
+def test_derived_view_cache_keeps_one_generation():
+    """kernels._remember: a new version of the same weight view replaces the cached one (torch optimizers bump the version
+    counter every step; FusedAdamW drops entries itself through weights_changed)."""
+    import importlib
+    K = importlib.import_module("mtd_gan_amd.kernels")
+    cache = {}
+    for version in range(5):
+        K._remember(cache, ("ptr", 32, 32, 288, 9), ("ptr", version, 0, 32, 32, 288, 9), ("packed", version))
+        K._remember(cache, ("other", 32, 32, 9, 288), ("other", version, 0, 32, 32, 9, 288), ("packed2", version))
+    assert len(cache) == 2 and cache[("ptr", 4, 0, 32, 32, 288, 9)] == ("packed", 4)
