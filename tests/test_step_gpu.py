@@ -306,3 +306,40 @@ def test_checkpoint_resume_like_train_py(hip_lib, tmp_path):
         for i in da["state"]:
             for f in ("step", "exp_avg", "exp_avg_sq"):
                 assert torch.equal(torch.as_tensor(da["state"][i][f]).cpu(), torch.as_tensor(db["state"][i][f]).cpu()), (i, f)
+
+
+def test_torch_adamw_drives_the_same_step(hip_lib):
+    """The reference's own optimizer (torch.optim.AdamW, train.py:122-126) instead of FusedAdamW: gradients are ordinary
+    .grad tensors and the caches of derived weight views (packed conv weights, transposed mix weights, the generator tape)
+    follow the tensors' version counters.  (a) one iteration lands where FusedAdamW lands (same gradients, the update's
+    fp32 rounding aside); (b) two iterations are bit-identical to two iterations with every cache dropped in between."""
+    import random
+    from mtd_gan_amd import engine, kernels as K
+    from mtd_gan_amd.arch.Ours.networks import MTD_GAN_Method
+    from mtd_gan_amd.module.weight_methods import WeightMethods
+    from mtd_gan_amd.optimizers import FusedAdamW
+    dev = torch.device("cuda")
+    x, y = orc.synthetic_ldct(4, seed=5)
+
+    def run(kind, iters, drop_caches=False):
+        torch.manual_seed(3)
+        m = MTD_GAN_Method().cuda().train()
+        mk = (lambda ps: FusedAdamW(ps, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)) if kind == "fused" else \
+             (lambda ps: torch.optim.AdamW(ps, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4))
+        oD, oG = mk(m.Discriminator.parameters()), mk(m.Generator.parameters())
+        wm = WeightMethods("pcgrad", n_tasks=3, device=dev)
+        for it in range(iters):
+            torch.manual_seed(100 + it)
+            random.seed(200 + it)
+            engine.train_MTD_GAN_Ours(m, [dict(n_20=x, n_100=y)], oG, oD, dev, it, 0, 4, wm)
+            if drop_caches:
+                K.weights_changed(None)
+                m._gcache = None
+        return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    f1, t1 = run("fused", 1), run("torch", 1)
+    for k in f1:                                  # a first AdamW step moves every weight by ~lr = 1e-4
+        assert (f1[k].double() - t1[k].double()).abs().max().item() <= 2e-7, k
+    t2, t2_fresh = run("torch", 2), run("torch", 2, drop_caches=True)
+    for k in t2:
+        assert torch.equal(t2[k], t2_fresh[k]), k
