@@ -14,12 +14,18 @@ from mtd_gan_amd.train_step import FullStepWorkload
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=400)
+ap.add_argument("--fresh-inputs", action="store_true", help="new input tensors every step (new descriptor tables: exercises the arena recycling)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 wl = FullStepWorkload(dev, 0, 1, 32)
 t0 = time.perf_counter()
+keep = []
 for i in range(a.steps):
+    if a.fresh_inputs:
+        keep.append((wl.x, wl.y))                 # hold a few old batches so that the allocator hands out new addresses
+        keep = keep[-7:]
+        wl.x, wl.y = wl.x.clone(), wl.y.clone()
     wl.step()
     if i % 50 == 0 or i == a.steps - 1:
         torch.cuda.synchronize()
