@@ -164,6 +164,10 @@ int mtd_copy_channels(const float* a, int a_ld, float* out, int out_ld, long lon
 /* bilinear x2, align_corners=False (nn.Upsample at networks.py:230-260) and its adjoint */
 int mtd_upsample2x_fwd(const float* in, int in_ld, float* out, int out_ld, int B, int H, int W, int C, void* stream);
 int mtd_upsample2x_bwd(const float* gout, int gout_ld, float* gin, int gin_ld, int B, int H, int W, int C, void* stream);
+/* same with four channels per thread and the LeakyReLU-gradient mask of the consumer fused in: gin = U^T(gout) * (y > 0 ? 1 : slope)
+ * (y == NULL: no mask).  Needs C and the strides to be multiples of 4 and 16-byte aligned bases (MTD_EALIGN otherwise). */
+int mtd_upsample2x_bwd_masked(const float* gout, int gout_ld, float* gin, int gin_ld, const float* y, int y_ld, float slope,
+                              int B, int H, int W, int C, void* stream);
 /* PixelShuffle(2) (networks.py:166-175): in [B,H,W,4C] -> out [B,2H,2W,C] and adjoint */
 int mtd_pixel_shuffle2_fwd(const float* in, int in_ld, float* out, int out_ld, int B, int H, int W, int C, void* stream);
 int mtd_pixel_shuffle2_bwd(const float* gout, int gout_ld, float* gin, int gin_ld, int B, int H, int W, int C, void* stream);

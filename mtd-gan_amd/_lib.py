@@ -126,6 +126,7 @@ def lib():
     sig("mtd_copy_channels", ci, vp, ci, vp, ci, ll, ci, ci, vp)
     sig("mtd_upsample2x_fwd", ci, vp, ci, vp, ci, ci, ci, ci, ci, vp)
     sig("mtd_upsample2x_bwd", ci, vp, ci, vp, ci, ci, ci, ci, ci, vp)
+    sig("mtd_upsample2x_bwd_masked", ci, vp, ci, vp, ci, vp, ci, cf, ci, ci, ci, ci, vp)
     sig("mtd_pixel_shuffle2_fwd", ci, vp, ci, vp, ci, ci, ci, ci, ci, vp)
     sig("mtd_pixel_shuffle2_bwd", ci, vp, ci, vp, ci, ci, ci, ci, ci, vp)
     sig("mtd_mul", ci, vp, vp, vp, ll, vp)
@@ -167,7 +168,7 @@ EXPORTS = [
     "mtd_pcgrad_gram", "mtd_pcgrad_combine", "mtd_adamw_multi", "mtd_adamw_multi_dyn", "mtd_adamw_multi_pre", "mtd_loss_terms_ws_bytes", "mtd_loss_terms",
     "mtd_loss_term_grads", "mtd_clip01", "mtd_clip01_bwd", "mtd_edge_loss_ws_bytes", "mtd_edge_loss",
     "mtd_prof_enable", "mtd_prof_collect", "mtd_conv_igemm_override", "mtd_conv_wgrad_override", "mtd_upload", "mtd_image_metrics_ws_bytes", "mtd_image_metrics", "mtd_rfft_rows_any", "mtd_spec_mix_any", "mtd_irfft_rows_any",
-    "mtd_foreground_bbox", "mtd_window_patches", "mtd_hu_window", "mtd_add", "mtd_transpose64_multi",
+    "mtd_foreground_bbox", "mtd_window_patches", "mtd_hu_window", "mtd_add", "mtd_transpose64_multi", "mtd_upsample2x_bwd_masked",
 ]
 
 

@@ -122,6 +122,37 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
     }
 }
 
+// four channels per thread, optional LeakyReLU-gradient mask of the consumer fused in (gin = upsampled^T(gout) * (y > 0 ? 1 : slope))
+__global__ __launch_bounds__(256) void upsample2x_bwd4_kernel(const float* __restrict__ gout, int gout_ld, float* __restrict__ gin, int gin_ld,
+                                                              const float* __restrict__ y, int y_ld, float slope, int B, int H, int W, int C4) {
+    const unsigned total = (unsigned)B * H * W * C4;
+    for (unsigned idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const unsigned c = (idx % (unsigned)C4) * 4;
+        unsigned t = idx / (unsigned)C4;
+        const int x = (int)(t % (unsigned)W);
+        t /= (unsigned)W;
+        const int yy = (int)(t % (unsigned)H);
+        const int b = (int)(t / (unsigned)H);
+        int oy[4], ox[4];
+        float wy[4], wx[4];
+        const int ny = up_adj(yy, H, oy, wy), nx = up_adj(x, W, ox, wx);
+        const float* base = gout + (long long)b * 4 * H * W * gout_ld + c;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < ny; ++i) {
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < nx; ++j) r += wx[j] * *reinterpret_cast<const f32x4*>(base + ((long long)oy[i] * 2 * W + ox[j]) * gout_ld);
+            s += wy[i] * r;
+        }
+        const long long pix = ((long long)b * H + yy) * W + x;
+        if (y) {
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(y + pix * y_ld + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] = yv[e] > 0.f ? s[e] : s[e] * slope;
+        }
+        *reinterpret_cast<f32x4*>(gin + pix * gin_ld + c) = s;
+    }
+}
+
 // PixelShuffle(2): out[b, 2h+i, 2w+j, c] = in[b, h, w, 4c + 2i + j]
 __global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const float* __restrict__ src, int src_ld, float* __restrict__ dst, int dst_ld,
                                                              int B, int H, int W, int C, int inverse) {
@@ -272,6 +303,18 @@ extern "C" int mtd_upsample2x_bwd(const float* gout, int gout_ld, float* gin, in
     if (!gout || !gin || B <= 0 || H <= 0 || W <= 0 || C <= 0 || gout_ld < C || gin_ld < C) return MTD_EINVAL;
     hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((long long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, gout, gout_ld,
                        gin, gin_ld, B, H, W, C);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_upsample2x_bwd_masked(const float* gout, int gout_ld, float* gin, int gin_ld, const float* y, int y_ld, float slope,
+                                         int B, int H, int W, int C, void* stream) {
+    if (!gout || !gin || B <= 0 || H <= 0 || W <= 0 || C <= 0 || gout_ld < C || gin_ld < C || (y && y_ld < C)) return MTD_EINVAL;
+    if ((C % 4) || (gout_ld % 4) || (gin_ld % 4) || (y && (y_ld % 4)) || !aligned16(gout) || !aligned16(gin) || (y && !aligned16(y)) ||
+        (long long)B * H * W * C >= (1ll << 32))
+        return MTD_EALIGN;
+    hipLaunchKernelGGL(upsample2x_bwd4_kernel, dim3(grid_for((long long)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, gout,
+                       gout_ld, gin, gin_ld, y, y_ld, slope, B, H, W, C / 4);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }

@@ -331,14 +331,17 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0
             src_h = cot(head, g_out)
             if src_h is not None:
                 side.run(lambda: K.wgrad(src_h(), t6, g64, 1, 1, sink.get(head + ".weight"), 1, 1, db=sink.get(head + ".bias"), accumulate=True), g_out, t6)
+        # every cotangent that reaches a level's second conv is multiplied by that conv's LeakyReLU gradient; the producer of the
+        # cotangent (head conv, upsampling adjoint, 1x1 up-conv data gradient) applies it in its epilogue instead of a pass of its own
         g = K.empty_nhwc(B, 64, 64, 1, x)
-        K.conv(g_out, P[head + ".weight"], g64, 1, 1, 1, 1, g)
+        K.conv(g_out, P[head + ".weight"], g64, 1, 1, 1, 1, g, mask=o2s[6], mask_slope=0.2)
         for lvl in range(6, 0, -1):
             r = 2 ** lvl
             ccat, co = DEC[lvl - 1]
             o2, o1, cat, tin = o2s[lvl], o1s[lvl], cats[lvl], ins[lvl]
             g3 = K.geom_fwd(B, r, r, 3, 1, 1)
-            gpre2 = K.act_grad(g, o2, 0.2)
+            gpre2 = g                                      # already times (o2 > 0 ? 1 : 0.2)
+            below = o2s[lvl - 1] if lvl > 1 else None      # output of the level below (None: the bottleneck, masked by the caller)
             wgrad_sn(f"{pre}_dconv{lvl}2", gpre2, o1, (r, 3, 1, 1), co, co, 3)
             gpre1 = K.empty_nhwc(B, r, r, co, x)
             dgrad_s1(f"{pre}_dconv{lvl}2", gpre2, r, co, co, gpre1, mask=o1)
@@ -349,7 +352,7 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0
             g_skip[7 - lvl].append(gcat[..., cprev:])
             if pre == "s":
                 g = K.empty_nhwc(B, r // 2, r // 2, cprev, x)
-                K.upsample2x_bwd(gcat[..., :cprev], g)
+                K.upsample2x_bwd(gcat[..., :cprev], g, mask=below, slope=0.2)
             else:
                 cin_up, cup = RUP[lvl - 1]
                 gr = K.empty_nhwc(B, r // 2, r // 2, 4 * cup, x)
@@ -362,7 +365,7 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0
                         side.run(lambda src_u=src_u, tin=tin, gq=gq, wn=wn, cup=cup, cin_up=cin_up, lvl=lvl: K.wgrad(
                             src_u(), tin, gq, 4 * cup, cin_up, sink.get(wn), cin_up, 1, db=sink.get(f"r_up{lvl}.upsample.0.bias"), accumulate=True), gr, tin)
                 g = K.empty_nhwc(B, r // 2, r // 2, cin_up, x)
-                K.conv(gr, P[wn], gq, cin_up, 4 * cup, 1, cin_up, g)
+                K.conv(gr, P[wn], gq, cin_up, 4 * cup, 1, cin_up, g, mask=below, mask_slope=0.2)
         in_decoder[0] = False
         return g
 

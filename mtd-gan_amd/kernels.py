@@ -361,10 +361,19 @@ def upsample2x_fwd(x, out):
     return out
 
 
-def upsample2x_bwd(gout, gin):
+def upsample2x_bwd(gout, gin, mask=None, slope=0.0):
+    """gin = adjoint of the bilinear x2 upsampling applied to gout; with mask: times the LeakyReLU gradient (mask > 0 ? 1 : slope)
+    of the layer that produced the upsampled tensor (one launch instead of two when the tensors allow 16-byte accesses)."""
     B, H, W, Cc = gin.shape
-    check(_lib.lib().mtd_upsample2x_bwd(gout.data_ptr(), ld_of(gout), gin.data_ptr(), ld_of(gin), B, H, W, Cc, stream_ptr()), "mtd_upsample2x_bwd")
-    return gin
+    L = _lib.lib()
+    rc = L.mtd_upsample2x_bwd_masked(gout.data_ptr(), ld_of(gout), gin.data_ptr(), ld_of(gin), _ptr(mask), ld_of(mask) if mask is not None else 0,
+                                     float(slope), B, H, W, Cc, stream_ptr())
+    if rc == 0:
+        return gin
+    if rc != -2:                                         # anything but MTD_EALIGN is an error
+        check(rc, "mtd_upsample2x_bwd_masked")
+    check(L.mtd_upsample2x_bwd(gout.data_ptr(), ld_of(gout), gin.data_ptr(), ld_of(gin), B, H, W, Cc, stream_ptr()), "mtd_upsample2x_bwd")
+    return act_grad(gin, mask, slope) if mask is not None else gin
 
 
 def pixel_shuffle2_fwd(x, out):
