@@ -49,6 +49,57 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nblk) {
     return x * q + (x < r ? x : r) + i;
 }
 
+// One-launch, order-fixed sum of `ns` partial-result slabs (slab k at in + k * stride, float4 index i4) by a workgroup of
+// 16 * SQ * SQ threads: thread (tx = tid & 15, ty = tid >> 4) adds the contiguous run of slabs ty * per .. of float4
+// i4 = 16 * blockIdx.x + tx with eight loads in flight, the SQ * SQ run sums meet in LDS and are added in two levels of SQ
+// (always the same association, so the result does not depend on timing).  Returns the total in the threads with
+// ty == 0 (others get a partial); `red` needs 16 * SQ * (SQ + 1) float4.  i4 >= count4 contributes zeros.
+template <int SQ>
+__device__ __forceinline__ f32x4 block_slab_sum(const float* __restrict__ in, long long stride, int ns, long long i4, bool valid,
+                                                f32x4* red) {
+    constexpr int G = SQ * SQ;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int per = (ns + G - 1) / G;
+    const int k0 = min(ns, ty * per), k1 = min(ns, k0 + per);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+        const float* base = in + 4 * i4;
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(base + (long long)(k + j) * stride);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        if (k + 4 <= k1) {
+            f32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(base + (long long)(k + j) * stride);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += v[j];
+            k += 4;
+        }
+        for (; k < k1; ++k) s += *reinterpret_cast<const f32x4*>(base + (long long)k * stride);
+    }
+    red[ty * 16 + tx] = s;
+    __syncthreads();
+    f32x4* red2 = red + G * 16;
+    if (ty < SQ) {
+        f32x4 t = red[(ty * SQ) * 16 + tx];
+#pragma unroll
+        for (int j = 1; j < SQ; ++j) t += red[(ty * SQ + j) * 16 + tx];
+        red2[ty * 16 + tx] = t;
+    }
+    __syncthreads();
+    if (ty == 0) {
+        s = red2[tx];
+#pragma unroll
+        for (int j = 1; j < SQ; ++j) s += red2[j * 16 + tx];
+    }
+    return s;
+}
+
 // launch profiler hooks (api.hip)
 int mtd_prof_begin(int kernel, int cfg, int splitk, long long M, int N, int C, int taps, hipStream_t s);
 void mtd_prof_end(int slot, hipStream_t s);

@@ -635,6 +635,45 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const WgradParams p, 
     }
 }
 
+// the two reduce stages and the scatter in one launch (workgroup of 16 float4 columns x SQ * SQ slab runs, common.h
+// block_slab_sum): the 256-slab sums of the 32-channel 3x3 layers cost one 5 us launch instead of two
+template <int SQ>
+__global__ __launch_bounds__(16 * SQ * SQ) void wgrad_reduce_finish_kernel(const WgradParams p, const float* __restrict__ in, int nslab,
+                                                                           long long stride_in) {
+    __shared__ f32x4 red[16 * SQ * (SQ + 1)];
+    const mtd_wgrad_args& a = p.a;
+    const mtd_geom& g = a.g;
+    const unsigned nw4 = (unsigned)(p.T * a.N * a.C) >> 2;
+    const unsigned count4 = nw4 + (a.db ? ((unsigned)a.N >> 2) : 0u);
+    const unsigned c4n = (unsigned)a.C >> 2;
+    const unsigned i4 = blockIdx.x * 16 + (threadIdx.x & 15);
+    const f32x4 s = block_slab_sum<SQ>(in, stride_in, nslab, i4, i4 < count4, red);
+    if ((threadIdx.x >> 4) != 0 || i4 >= count4) return;
+    if (i4 < nw4) {
+        const unsigned t2 = i4 / c4n;
+        const unsigned c = (i4 - t2 * c4n) << 2;
+        const unsigned tap = t2 / (unsigned)a.N;
+        const unsigned n = t2 - tap * (unsigned)a.N;
+        const int ty = (int)tap / g.TW, tx = (int)tap % g.TW;
+        const int kidx = (g.ky0 + ty * g.ky_step) * g.KW + (g.kx0 + tx * g.kx_step);
+        float* dst = a.dw + (long long)n * a.w_sn + (long long)c * a.w_sc + kidx;
+        if (a.accumulate & 1) {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = dst[(long long)j * a.w_sc];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[(long long)j * a.w_sc] = o[j] + s[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[(long long)j * a.w_sc] = s[j];
+        }
+    } else {
+        float* dst = a.db + ((i4 - nw4) << 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = (a.accumulate & 2) ? (dst[j] + s[j]) : s[j];
+    }
+}
+
 struct WPlan { int cfg, WN, WC, TG, ppw, nsplit, ntg, nw; };
 
 int g_wforce_cfg = -1, g_wforce_split = -1;     // tuning hook (mtd_conv_wgrad_override)
@@ -846,6 +885,16 @@ extern "C" int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream) {
     const bool vec = !direct;      // MFMA layers: N, C multiples of 32, so every slab offset is a multiple of 4 floats
     if (vec && (!aligned16(a->ws) || (long long)p.T * a->N * a->C >= (1ll << 31))) return MTD_EINVAL;   // float4 reads, 32-bit indices
     const long long units = vec ? count / 4 : count;
+    // 16 < ns <= 1024 slabs of a layer small enough that 16-column workgroups still fill the chip's launch slots quickly:
+    // one fused launch.  (Large layers have few slabs and keep the one-thread-per-float4 finish kernel.)
+    static const int env_fused = [] { const char* e = getenv("MTD_WGRAD_FUSED_REDUCE"); return e ? atoi(e) : 1; }();
+    if (vec && env_fused && ns > 16 && ns <= 1024 && units <= 16 * 4096) {
+        const int bx = (int)((units + 15) / 16);
+        if (ns > 128) hipLaunchKernelGGL((wgrad_reduce_finish_kernel<8>), dim3(bx), dim3(1024), 0, s, p, cur, ns, p.slab_stride);
+        else hipLaunchKernelGGL((wgrad_reduce_finish_kernel<4>), dim3(bx), dim3(256), 0, s, p, cur, ns, p.slab_stride);
+        MTD_LAUNCH_CHECK();
+        return MTD_OK;
+    }
     while (ns > GS) {
         int ng = (ns + GS - 1) / GS;
         int bx = (int)((units + 255) / 256);

@@ -462,6 +462,31 @@ __global__ __launch_bounds__(256) void mix_finish_kernel(const float* __restrict
     }
 }
 
+// both reduce stages and the accumulate in one launch: workgroups 0..63 own 16 float4 of dW2 each, workgroup 64 the bias
+// gradient (the sum of the slab's two db2 rows); 1024 threads = 16 columns x 64 slab runs (common.h block_slab_sum)
+__global__ __launch_bounds__(1024) void mix_reduce_finish_kernel(const float* __restrict__ in, int nslab, float* __restrict__ dw2,
+                                                                 float* __restrict__ db2, int accumulate) {
+    __shared__ f32x4 red[16 * 8 * 9];
+    const int tx = threadIdx.x & 15;
+    const bool lead = (threadIdx.x >> 4) == 0;
+    if (blockIdx.x < 64) {
+        const int i4 = blockIdx.x * 16 + tx;
+        const f32x4 s = block_slab_sum<8>(in, MIX_SLAB, nslab, i4, true, red);
+        if (lead) {
+            f32x4* dst = reinterpret_cast<f32x4*>(dw2) + i4;
+            *dst = accumulate ? (*dst + s) : s;
+        }
+    } else {
+        const f32x4 s1 = block_slab_sum<8>(in + 4096, MIX_SLAB, nslab, tx, true, red);
+        const f32x4 s2 = block_slab_sum<8>(in + 4096 + 64, MIX_SLAB, nslab, tx, true, red);
+        if (lead) {
+            const f32x4 s = s1 + s2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) db2[4 * tx + j] = accumulate ? (db2[4 * tx + j] + s[j]) : s[j];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void transpose64_kernel(const float* __restrict__ src, float* __restrict__ dst) {
     __shared__ float t[64 * 65];
     for (int i = threadIdx.x; i < 4096; i += 256) t[(i >> 6) * 65 + (i & 63)] = src[i];
@@ -549,6 +574,12 @@ extern "C" int mtd_spec_mix_wgrad_reduce(const float* ws, int B, float* dw2, flo
     hipStream_t s = (hipStream_t)stream;
     int ns = B * 17;
     const float* cur = ws;
+    static const int env_fused = [] { const char* e = getenv("MTD_MIX_FUSED_REDUCE"); return e ? atoi(e) : 1; }();
+    if (env_fused && ns <= 4096 && aligned16(ws) && aligned16(dw2)) {
+        hipLaunchKernelGGL(mix_reduce_finish_kernel, dim3(65), dim3(1024), 0, s, cur, ns, dw2, db2, accumulate);
+        MTD_LAUNCH_CHECK();
+        return MTD_OK;
+    }
     float* next = const_cast<float*>(ws) + (long long)ns * MIX_SLAB;
     while (ns > MIX_GS) {
         int ng = (ns + MIX_GS - 1) / MIX_GS;

@@ -30,6 +30,7 @@ CONV_CASES = [
     # B, Cin, Cout, H, W, k, s, p
     (2, 32, 32, 64, 64, 3, 1, 1),     # generator conv, cfg 256x32
     (1, 32, 32, 8, 8, 3, 1, 1),       # small-M 128x32, split-K
+    (32, 32, 32, 64, 64, 3, 1, 1),    # full batch: 256 weight-gradient slabs, 1024-thread fused reduce
     (2, 64, 64, 32, 32, 3, 1, 1),     # 256x64
     (2, 64, 64, 16, 16, 4, 2, 1),     # strided 4x4, 64x64 tile
     (2, 64, 128, 16, 16, 3, 1, 1),    # 128x128
