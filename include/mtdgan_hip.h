@@ -108,6 +108,23 @@ typedef struct {
 size_t mtd_conv_wgrad_ws_bytes(const mtd_wgrad_args* a);
 int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream);
 
+/* Deferred form for a backward pass with many small layers (the generator: 41 conv layers of 32 channels, each with
+ * 256 partial-sum slabs).  mtd_conv_wgrad_slabs runs only the slab-producing kernel into a->ws, which must stay
+ * untouched until the reduce; *nslab == 0 means the kernel wrote dw / db itself and nothing is left to do.
+ * mtd_conv_wgrad_reduce_multi then sums the slabs of `count` layers and scatters into their dw / db in ONE launch
+ * (same fixed two-level order as mtd_conv_wgrad's own reduce).  N and C must be multiples of 32. */
+typedef struct {
+    mtd_wgrad_args a;          /* as passed to mtd_conv_wgrad_slabs (a.ws = the slabs) */
+    int T;                     /* taps */
+    int nslab;
+    long long slab_stride;     /* floats */
+    int first_block;           /* filled by the caller: prefix sum of blocks (mtd_conv_wgrad_reduce_blocks) */
+    int pad_;
+} mtd_wgrad_reduce_desc;
+int mtd_conv_wgrad_slabs(const mtd_wgrad_args* a, int* nslab, long long* slab_stride, void* stream);
+int mtd_conv_wgrad_reduce_blocks(const mtd_wgrad_reduce_desc* d);
+int mtd_conv_wgrad_reduce_multi(const mtd_wgrad_reduce_desc* table_dev, const mtd_wgrad_reduce_desc* table_host, int count, void* stream);
+
 /* ---- Res-FFT-Conv block spectral path (arch/Ours/networks.py:21-30), H = W = 64, C = 32 ------
  * Spectra are stored as [B][kw 0..32][h or kh 0..63][2 (re,im)][32 channels].                  */
 
@@ -128,6 +145,9 @@ size_t mtd_spec_mix_bwd_ws_bytes(int B);
 int mtd_spec_mix_bwd(const float* gR, const float* w2, const float* S_save, const float* Z_save,
                      float* gT, float* ws, int B, void* stream);
 int mtd_spec_mix_wgrad_reduce(const float* ws, int B, float* dw2, float* db2, int accumulate, void* stream);
+/* the same reduce for `count` blocks' slab sets in one launch (dw2 and ws 16-byte aligned) */
+typedef struct { const float* ws; float* dw2; float* db2; int nslab; int accumulate; } mtd_mix_reduce_desc;
+int mtd_spec_mix_wgrad_reduce_multi(const mtd_mix_reduce_desc* table_dev, const mtd_mix_reduce_desc* table_host, int count, void* stream);
 
 /* rows back: c2r along W (uses only Re of columns 0 and 32), ortho 1/8, fused epilogue
  *   out = (y + add1 + add2) * (mask > 0 ? 1 : 0)     (add1/add2/mask optional, NHWC with own ld) */

@@ -57,6 +57,15 @@ class SnGradLayer(C.Structure):
                 ("G2", C.c_void_p), ("u2", C.c_void_p), ("v2", C.c_void_p), ("sigma2", C.c_void_p)]
 
 
+class WgradReduceDesc(C.Structure):
+    _fields_ = [("a", WgradArgs), ("T", C.c_int), ("nslab", C.c_int), ("slab_stride", C.c_longlong),
+                ("first_block", C.c_int), ("pad_", C.c_int)]
+
+
+class MixReduceDesc(C.Structure):
+    _fields_ = [("ws", C.c_void_p), ("dw2", C.c_void_p), ("db2", C.c_void_p), ("nslab", C.c_int), ("accumulate", C.c_int)]
+
+
 class LossTerm(C.Structure):
     _fields_ = [("kind", C.c_int), ("a", C.c_void_p), ("b", C.c_void_p), ("tconst", C.c_float),
                 ("mx", C.c_void_p), ("my", C.c_void_p), ("n", C.c_longlong), ("scale", C.c_float), ("eps", C.c_float),
@@ -111,6 +120,10 @@ def lib():
     sig("mtd_conv_direct", ci, C.POINTER(ConvArgs), vp)
     sig("mtd_conv_wgrad_ws_bytes", sz, C.POINTER(WgradArgs))
     sig("mtd_conv_wgrad", ci, C.POINTER(WgradArgs), vp)
+    sig("mtd_conv_wgrad_slabs", ci, C.POINTER(WgradArgs), C.POINTER(C.c_int), C.POINTER(C.c_longlong), vp)
+    sig("mtd_conv_wgrad_reduce_blocks", ci, C.POINTER(WgradReduceDesc))
+    sig("mtd_conv_wgrad_reduce_multi", ci, vp, vp, ci, vp)
+    sig("mtd_spec_mix_wgrad_reduce_multi", ci, vp, vp, ci, vp)
     sig("mtd_rfft_rows", ci, vp, ci, vp, ci, ci, vp)
     sig("mtd_spec_mix_fwd", ci, vp, vp, vp, vp, vp, vp, ci, vp)
     sig("mtd_spec_mix_bwd_ws_bytes", sz, ci)
@@ -168,6 +181,7 @@ EXPORTS = [
     "mtd_pcgrad_gram", "mtd_pcgrad_combine", "mtd_adamw_multi", "mtd_adamw_multi_dyn", "mtd_adamw_multi_pre", "mtd_loss_terms_ws_bytes", "mtd_loss_terms",
     "mtd_loss_term_grads", "mtd_clip01", "mtd_clip01_bwd", "mtd_edge_loss_ws_bytes", "mtd_edge_loss",
     "mtd_prof_enable", "mtd_prof_collect", "mtd_conv_igemm_override", "mtd_conv_wgrad_override", "mtd_upload", "mtd_image_metrics_ws_bytes", "mtd_image_metrics", "mtd_rfft_rows_any", "mtd_spec_mix_any", "mtd_irfft_rows_any",
+    "mtd_conv_wgrad_slabs", "mtd_conv_wgrad_reduce_blocks", "mtd_conv_wgrad_reduce_multi", "mtd_spec_mix_wgrad_reduce_multi",
     "mtd_foreground_bbox", "mtd_window_patches", "mtd_hu_window", "mtd_add", "mtd_transpose64_multi", "mtd_upsample2x_bwd_masked",
 ]
 

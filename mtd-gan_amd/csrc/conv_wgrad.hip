@@ -637,18 +637,11 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const WgradParams p, 
 
 // the two reduce stages and the scatter in one launch (workgroup of 16 float4 columns x SQ * SQ slab runs, common.h
 // block_slab_sum): the 256-slab sums of the 32-channel 3x3 layers cost one 5 us launch instead of two
-template <int SQ>
-__global__ __launch_bounds__(16 * SQ * SQ) void wgrad_reduce_finish_kernel(const WgradParams p, const float* __restrict__ in, int nslab,
-                                                                           long long stride_in) {
-    __shared__ f32x4 red[16 * SQ * (SQ + 1)];
-    const mtd_wgrad_args& a = p.a;
+// scatter one summed float4 (four consecutive c of one (tap, n), or four bias entries) into the strided gradient views
+__device__ __forceinline__ void finish_scatter4(const mtd_wgrad_args& a, int T, unsigned i4, const f32x4 s) {
     const mtd_geom& g = a.g;
-    const unsigned nw4 = (unsigned)(p.T * a.N * a.C) >> 2;
-    const unsigned count4 = nw4 + (a.db ? ((unsigned)a.N >> 2) : 0u);
+    const unsigned nw4 = (unsigned)(T * a.N * a.C) >> 2;
     const unsigned c4n = (unsigned)a.C >> 2;
-    const unsigned i4 = blockIdx.x * 16 + (threadIdx.x & 15);
-    const f32x4 s = block_slab_sum<SQ>(in, stride_in, nslab, i4, i4 < count4, red);
-    if ((threadIdx.x >> 4) != 0 || i4 >= count4) return;
     if (i4 < nw4) {
         const unsigned t2 = i4 / c4n;
         const unsigned c = (i4 - t2 * c4n) << 2;
@@ -672,6 +665,32 @@ __global__ __launch_bounds__(16 * SQ * SQ) void wgrad_reduce_finish_kernel(const
 #pragma unroll
         for (int j = 0; j < 4; ++j) dst[j] = (a.accumulate & 2) ? (dst[j] + s[j]) : s[j];
     }
+}
+
+template <int SQ>
+__global__ __launch_bounds__(16 * SQ * SQ) void wgrad_reduce_finish_kernel(const WgradParams p, const float* __restrict__ in, int nslab,
+                                                                           long long stride_in) {
+    __shared__ f32x4 red[16 * SQ * (SQ + 1)];
+    const mtd_wgrad_args& a = p.a;
+    const unsigned count4 = ((unsigned)(p.T * a.N * a.C) >> 2) + (a.db ? ((unsigned)a.N >> 2) : 0u);
+    const unsigned i4 = blockIdx.x * 16 + (threadIdx.x & 15);
+    const f32x4 s = block_slab_sum<SQ>(in, stride_in, nslab, i4, i4 < count4, red);
+    if ((threadIdx.x >> 4) != 0 || i4 >= count4) return;
+    finish_scatter4(a, p.T, i4, s);
+}
+
+// the same for many layers in one launch: workgroup -> (layer, 16-column chunk) through the table's block prefix sums
+__global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(const mtd_wgrad_reduce_desc* __restrict__ table, int count) {
+    __shared__ f32x4 red[16 * 8 * 9];
+    int li = 0;
+    while (li + 1 < count && (int)blockIdx.x >= table[li + 1].first_block) ++li;     // count <= a few dozen, uniform scalar loads
+    const mtd_wgrad_reduce_desc& d = table[li];
+    const mtd_wgrad_args& a = d.a;
+    const unsigned count4 = ((unsigned)(d.T * a.N * a.C) >> 2) + (a.db ? ((unsigned)a.N >> 2) : 0u);
+    const unsigned i4 = (blockIdx.x - d.first_block) * 16 + (threadIdx.x & 15);
+    const f32x4 s = block_slab_sum<8>(a.ws, d.slab_stride, d.nslab, i4, i4 < count4, red);
+    if ((threadIdx.x >> 4) != 0 || i4 >= count4) return;
+    finish_scatter4(a, d.T, i4, s);
 }
 
 struct WPlan { int cfg, WN, WC, TG, ppw, nsplit, ntg, nw; };
@@ -803,19 +822,19 @@ extern "C" size_t mtd_conv_wgrad_ws_bytes(const mtd_wgrad_args* a) {
     return wgrad_ws_floats(*a, pl.nsplit) * sizeof(float);
 }
 
-extern "C" int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream) {
+// the slab-producing kernel of one layer; fills p, nsplit, direct
+static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, int& nsplit, bool& direct_out) {
     if (!a) return MTD_EINVAL;
     static const int env_nw = [] { const char* e = getenv("MTD_WGRAD_NW"); return e ? atoi(e) : 0; }();
     if (env_nw == 4 || env_nw == 8) g_wforce_nw = env_nw;
     int rc = check_wargs(*a);
     if (rc != MTD_OK) return rc;
     const bool direct = is_direct(*a);
+    direct_out = direct;
     WPlan pl{};
-    int nsplit;
     if (direct) nsplit = mtd_direct_wgrad_nslab(a);
     else { pl = make_wplan(*a); nsplit = pl.nsplit; }
     if (!a->ws || a->ws_bytes < wgrad_ws_floats(*a, nsplit) * sizeof(float)) return MTD_EWS;
-    WgradParams p;
     p.a = *a;
     p.M = (int)geom_pixels(a->g);
     p.T = a->g.TH * a->g.TW;
@@ -876,6 +895,58 @@ extern "C" int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream) {
         mtd_prof_end(prof, s);
         MTD_LAUNCH_CHECK();
     }
+    return MTD_OK;
+}
+
+extern "C" int mtd_conv_wgrad_slabs(const mtd_wgrad_args* a, int* nslab, long long* slab_stride, void* stream) {
+    if (!a || !nslab || !slab_stride) return MTD_EINVAL;
+    if (is_direct(*a)) return MTD_EINVAL;           // vector-ALU layers reduce immediately (mtd_conv_wgrad)
+    WgradParams p;
+    int nsplit = 0;
+    bool direct = false;
+    int rc = wgrad_partial(a, stream, p, nsplit, direct);
+    if (rc != MTD_OK) return rc;
+    *nslab = nsplit == 1 ? 0 : nsplit;              // single split: the kernel wrote dw / db itself
+    *slab_stride = p.slab_stride;
+    return MTD_OK;
+}
+
+static int reduce_desc_ok(const mtd_wgrad_reduce_desc& d) {
+    const mtd_wgrad_args& a = d.a;
+    if (!a.ws || !a.dw || !aligned16(a.ws) || (a.N % 32) || (a.C % 32) || a.N <= 0 || a.C <= 0) return 0;
+    if (d.T <= 0 || d.nslab < 2 || d.nslab > 4096 || (d.slab_stride % 4) || (long long)d.T * a.N * a.C >= (1ll << 31)) return 0;
+    if (d.slab_stride < (long long)d.T * a.N * a.C + (a.db ? a.N : 0)) return 0;
+    return 1;
+}
+
+extern "C" int mtd_conv_wgrad_reduce_blocks(const mtd_wgrad_reduce_desc* d) {
+    if (!d || !reduce_desc_ok(*d)) return 0;
+    const long long units = ((long long)d->T * d->a.N * d->a.C + (d->a.db ? d->a.N : 0)) / 4;
+    return (int)((units + 15) / 16);
+}
+
+extern "C" int mtd_conv_wgrad_reduce_multi(const mtd_wgrad_reduce_desc* table_dev, const mtd_wgrad_reduce_desc* table_host, int count,
+                                           void* stream) {
+    if (!table_dev || !table_host || count <= 0 || count > 4096) return MTD_EINVAL;
+    long long blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        const int nb = mtd_conv_wgrad_reduce_blocks(&table_host[i]);
+        if (nb <= 0 || table_host[i].first_block != (int)blocks) return MTD_EINVAL;
+        blocks += nb;
+    }
+    if (blocks > (1ll << 30)) return MTD_EINVAL;
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, table_dev, count);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream) {
+    WgradParams p;
+    int nsplit = 0;
+    bool direct = false;
+    int rc = wgrad_partial(a, stream, p, nsplit, direct);
+    if (rc != MTD_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
     if (!direct && nsplit == 1) return MTD_OK;      // single split: the kernel wrote dw / db itself
     // staged, order-fixed reduction of the slabs
     const float* cur = a->ws;

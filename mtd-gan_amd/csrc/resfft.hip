@@ -464,13 +464,12 @@ __global__ __launch_bounds__(256) void mix_finish_kernel(const float* __restrict
 
 // both reduce stages and the accumulate in one launch: workgroups 0..63 own 16 float4 of dW2 each, workgroup 64 the bias
 // gradient (the sum of the slab's two db2 rows); 1024 threads = 16 columns x 64 slab runs (common.h block_slab_sum)
-__global__ __launch_bounds__(1024) void mix_reduce_finish_kernel(const float* __restrict__ in, int nslab, float* __restrict__ dw2,
-                                                                 float* __restrict__ db2, int accumulate) {
-    __shared__ f32x4 red[16 * 8 * 9];
+__device__ __forceinline__ void mix_reduce_block(const float* __restrict__ in, int nslab, float* __restrict__ dw2,
+                                                 float* __restrict__ db2, int accumulate, int blk, f32x4* red) {
     const int tx = threadIdx.x & 15;
     const bool lead = (threadIdx.x >> 4) == 0;
-    if (blockIdx.x < 64) {
-        const int i4 = blockIdx.x * 16 + tx;
+    if (blk < 64) {
+        const int i4 = blk * 16 + tx;
         const f32x4 s = block_slab_sum<8>(in, MIX_SLAB, nslab, i4, true, red);
         if (lead) {
             f32x4* dst = reinterpret_cast<f32x4*>(dw2) + i4;
@@ -485,6 +484,19 @@ __global__ __launch_bounds__(1024) void mix_reduce_finish_kernel(const float* __
             for (int j = 0; j < 4; ++j) db2[4 * tx + j] = accumulate ? (db2[4 * tx + j] + s[j]) : s[j];
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void mix_reduce_finish_kernel(const float* __restrict__ in, int nslab, float* __restrict__ dw2,
+                                                                 float* __restrict__ db2, int accumulate) {
+    __shared__ f32x4 red[16 * 8 * 9];
+    mix_reduce_block(in, nslab, dw2, db2, accumulate, blockIdx.x, red);
+}
+
+// the slab sets of many Res-FFT blocks in one launch: blockIdx.y = block of the network
+__global__ __launch_bounds__(1024) void mix_reduce_multi_kernel(const mtd_mix_reduce_desc* __restrict__ table) {
+    __shared__ f32x4 red[16 * 8 * 9];
+    const mtd_mix_reduce_desc& d = table[blockIdx.y];
+    mix_reduce_block(d.ws, d.nslab, d.dw2, d.db2, d.accumulate, blockIdx.x, red);
 }
 
 __global__ __launch_bounds__(256) void transpose64_kernel(const float* __restrict__ src, float* __restrict__ dst) {
@@ -590,6 +602,19 @@ extern "C" int mtd_spec_mix_wgrad_reduce(const float* ws, int B, float* dw2, flo
         ns = ng;
     }
     hipLaunchKernelGGL(mix_finish_kernel, dim3((4096 + 64 + 255) / 256), dim3(256), 0, s, cur, ns, dw2, db2, accumulate);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_spec_mix_wgrad_reduce_multi(const mtd_mix_reduce_desc* table_dev, const mtd_mix_reduce_desc* table_host, int count,
+                                               void* stream) {
+    if (!table_dev || !table_host || count <= 0 || count > 65535) return MTD_EINVAL;
+    for (int i = 0; i < count; ++i) {
+        const mtd_mix_reduce_desc& d = table_host[i];
+        if (!d.ws || !d.dw2 || !d.db2 || d.nslab <= 0 || d.nslab > 4096) return MTD_EINVAL;
+        if (!aligned16(d.ws) || !aligned16(d.dw2)) return MTD_EALIGN;
+    }
+    hipLaunchKernelGGL(mix_reduce_multi_kernel, dim3(65, count), dim3(1024), 0, (hipStream_t)stream, table_dev);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }

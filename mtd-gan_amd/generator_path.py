@@ -42,7 +42,7 @@ def block_forward(x, w_img, b_img, w_fft, b_fft, save, w2t=None):
     return out, ((x, img, S, Z) if save else None)
 
 
-def block_backward(g, saved, w_img, w_fft, grads, premask):
+def block_backward(g, saved, w_img, w_fft, grads, premask, defer=None):
     """g: grad of the block output.  grads: dict with tensors dw_img, db_img, dw_fft, db_fft (written).
     premask: multiply the input gradient by (x > 0) -- x is always a ReLU output inside the generator,
     so the result is the gradient w.r.t. the producer's pre-activation."""
@@ -50,14 +50,14 @@ def block_backward(g, saved, w_img, w_fft, grads, premask):
     B, H, W, _ = x.shape
     side = K.side_stream(x.device)
     gm = K.act_grad(g, img, 0.0)                                                    # g * (img > 0)
-    side.run(lambda: K.wgrad(gm, x, K.geom_fwd(B, H, W, 3, 1, 1), CH, CH, grads["dw_img"], CH * 9, 9, db=grads["db_img"]), gm, g)
+    side.run(lambda: K.wgrad(gm, x, K.geom_fwd(B, H, W, 3, 1, 1), CH, CH, grads["dw_img"], CH * 9, 9, db=grads["db_img"], defer=defer), gm, g)
     # spectral branch backward on a second side stream, beside the spatial data gradient on the main stream
     side1 = K.side_stream(x.device, 1)
     box = []
 
     def spectral():
         gR = K.rfft_rows(g, 1)                                                      # irfft2 backward
-        box.append(K.spec_mix_bwd(gR, w_fft, S, Z, grads["dw_fft"], grads["db_fft"]))
+        box.append(K.spec_mix_bwd(gR, w_fft, S, Z, grads["dw_fft"], grads["db_fft"], defer=defer))
     side1.run(spectral, g)
     d1 = K.empty_nhwc(B, H, W, CH, x)
     K.conv(gm, w_img, K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, d1, add1=g)  # dgrad(img branch) + residual
@@ -141,6 +141,7 @@ def generator_backward(g_out, tape, P, G):
     gt = K.geom_dgrad_s1(B, H, W, 3, 1)
     # output ReLU
     side = K.side_stream(x.device)
+    defer = K.DeferredWgrads()      # the 62 slab sums of this pass (41 conv, 21 mix layers) are taken in two launches at the end
     gpre = K.act_grad(g_out, tape["out"], 0.0)
     # decoder[0]: ConvTranspose 32 -> 1
     u0 = tape["u"][L]
@@ -151,24 +152,26 @@ def generator_backward(g_out, tape, P, G):
     # blocks 20..11 and decoders 1..10 (tape order: d/u/blk appended for j = 10..1)
     for j in range(1, L + 1):
         k = L - j                                           # position in the tape lists for decoder[j]
-        gpre_d = block_backward(gu, tape["blk"][L + 1 + k], *_blk_w(P, 2 * L + 1 - j), G.blk[2 * L + 1 - j], True)
+        gpre_d = block_backward(gu, tape["blk"][L + 1 + k], *_blk_w(P, 2 * L + 1 - j), G.blk[2 * L + 1 - j], True, defer)
         skip[j] = gpre_d                                    # flows unchanged into e_j
         uj = tape["u"][k]                                   # input of decoder[j]
-        side.run(lambda: K.wgrad(gpre_d, uj, gt, CH, CH, G.dec_w[j], 9, CH * 9, db=G.dec_b[j]), gpre_d)
+        side.run(lambda: K.wgrad(gpre_d, uj, gt, CH, CH, G.dec_w[j], 9, CH * 9, db=G.dec_b[j], defer=defer), gpre_d)
         gu = K.empty_nhwc(B, H, W, CH, x)
         K.conv(gpre_d, P.dec_w[j], gf, CH, CH, CH * 9, 9, gu)
     # gu is now the gradient of x_b (output of block 10)
     g_e = gu
     for i in range(L, -1, -1):                              # blocks 10..0, encoders 10..0
-        gpre_t = block_backward(g_e, tape["blk"][i], *_blk_w(P, i), G.blk[i], True)
+        gpre_t = block_backward(g_e, tape["blk"][i], *_blk_w(P, i), G.blk[i], True, defer)
         if i > 0:
             e_prev = tape["e"][i - 1]
-            side.run(lambda: K.wgrad(gpre_t, e_prev, gf, CH, CH, G.enc_w[i], CH * 9, 9, db=G.enc_b[i]), gpre_t)
+            side.run(lambda: K.wgrad(gpre_t, e_prev, gf, CH, CH, G.enc_w[i], CH * 9, 9, db=G.enc_b[i], defer=defer), gpre_t)
             g_e = K.empty_nhwc(B, H, W, CH, x)
             K.conv(gpre_t, P.enc_w[i], K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, g_e, add1=skip[i])
         else:
             side.run(lambda: K.wgrad(gpre_t, x, gf, CH, 1, G.enc_w[0], 9, 9, db=G.enc_b[0]), gpre_t)
     side.join()
+    K.side_stream(x.device, 1).join()
+    K.flush_wgrads(defer)
 
 
 def _blk_w(P, i):

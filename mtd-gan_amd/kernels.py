@@ -135,6 +135,7 @@ def stream_ptr():
     return C.c_void_p(_raw_stream(_cur_device()))
 
 
+DEFER_WGRADS = os.environ.get("MTD_NO_DEFERRED_WGRAD", "0") != "1"     # generator backward: slab sums of all layers in two launches
 CAPTURE_TAG = 0     # bumped while a hipGraph is captured so that graph-pool scratch never mixes with eager scratch
 
 
@@ -238,7 +239,55 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, scale=None, bias=None, add1=None, a
     return out
 
 
-def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumulate_bias=None):
+class DeferredWgrads:
+    """Weight-gradient slab sets of one backward pass whose sums are taken together at the end: two launches
+    (conv layers, spectral-mix layers) instead of one per layer.  Each layer gets a slab buffer of its own, kept for
+    the life of the process under the gradient tensor's address (a generator pass holds 41 x 9.5 MB + 21 x 9.2 MB)."""
+
+    def __init__(self):
+        self.conv, self.mix, self.bufs, self.slot = [], [], [], 0
+
+
+_deferred_ws = {}
+
+
+def _layer_ws(nbytes, defer, device):
+    # keyed by the layer's position in the pass (the schedules are fixed), so the set of buffers is bounded whatever
+    # gradient tensors the caller hands in; reuse from pass to pass is ordered by the streams like workspace()'s
+    key = (defer.slot, device.index if device.index is not None else _cur_device(), CAPTURE_TAG)
+    defer.slot += 1
+    buf = _deferred_ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _deferred_ws[key] = buf
+    return buf
+
+
+def flush_wgrads(defer):
+    """Sum every deferred slab set into its gradient tensors (on the current stream, which must be ordered after
+    the kernels that wrote the slabs)."""
+    L = _lib.lib()
+    if defer.bufs:
+        crosses_streams(*defer.bufs)
+    if defer.conv:
+        blocks = 0
+        for d in defer.conv:
+            d.first_block = blocks
+            nb = L.mtd_conv_wgrad_reduce_blocks(C.byref(d))
+            if nb <= 0:
+                raise RuntimeError("mtd_conv_wgrad_reduce_blocks: invalid deferred weight-gradient descriptor")
+            blocks += nb
+        tab, host = device_table(defer.conv, defer.bufs[0].device)
+        check(L.mtd_conv_wgrad_reduce_multi(tab.data_ptr(), C.cast(host, C.c_void_p), len(defer.conv), stream_ptr()),
+              "mtd_conv_wgrad_reduce_multi")
+    if defer.mix:
+        tab, host = device_table(defer.mix, defer.bufs[0].device)
+        check(L.mtd_spec_mix_wgrad_reduce_multi(tab.data_ptr(), C.cast(host, C.c_void_p), len(defer.mix), stream_ptr()),
+              "mtd_spec_mix_wgrad_reduce_multi")
+    defer.conv, defer.mix, defer.bufs, defer.slot = [], [], [], 0
+
+
+def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumulate_bias=None, defer=None):
     L = _lib.lib()
     a = WgradArgs()
     a.g = geom
@@ -253,6 +302,18 @@ def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumula
     need = L.mtd_conv_wgrad_ws_bytes(C.byref(a))
     if need == 0:
         raise RuntimeError(f"mtd_conv_wgrad: unsupported arguments N={N} C={Cc}")
+    if defer is not None and DEFER_WGRADS and N % 32 == 0 and Cc % 32 == 0:
+        ws = _layer_ws(need, defer, p.device)
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+        nslab, stride = C.c_int(0), C.c_longlong(0)
+        check(L.mtd_conv_wgrad_slabs(C.byref(a), C.byref(nslab), C.byref(stride), stream_ptr()), "mtd_conv_wgrad_slabs")
+        if nslab.value > 0:
+            d = _lib.WgradReduceDesc()
+            d.a, d.T, d.nslab, d.slab_stride = a, geom.TH * geom.TW, nslab.value, stride.value
+            d.a.p, d.a.q = None, None          # not read by the reduce; keeps the table's bytes (its cache key) the same from step to step
+            defer.conv.append(d)
+            defer.bufs.append(ws)
+        return
     ws = workspace(need, p.device)
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     if CALL_LOG is not None:
@@ -278,13 +339,21 @@ def spec_mix_fwd(R, w2t, b2, save):
     return T, S, Z
 
 
-def spec_mix_bwd(gR, w2, S, Z, dw2, db2, accumulate=False):
+def spec_mix_bwd(gR, w2, S, Z, dw2, db2, accumulate=False, defer=None):
     L = _lib.lib()
     B = gR.shape[0]
     gT = torch.empty_like(gR)
-    ws = workspace(L.mtd_spec_mix_bwd_ws_bytes(B), gR.device)
+    deferred = defer is not None and DEFER_WGRADS and dw2.data_ptr() % 16 == 0 and B * 17 <= 4096
+    need = L.mtd_spec_mix_bwd_ws_bytes(B)
+    ws = _layer_ws(need, defer, gR.device) if deferred else workspace(need, gR.device)
     check(L.mtd_spec_mix_bwd(gR.data_ptr(), w2.data_ptr(), S.data_ptr(), Z.data_ptr(), gT.data_ptr(), ws.data_ptr(), B, stream_ptr()),
           "mtd_spec_mix_bwd")
+    if deferred:
+        d = _lib.MixReduceDesc()
+        d.ws, d.dw2, d.db2, d.nslab, d.accumulate = ws.data_ptr(), dw2.data_ptr(), db2.data_ptr(), B * 17, 1 if accumulate else 0
+        defer.mix.append(d)
+        defer.bufs.append(ws)
+        return gT
     check(L.mtd_spec_mix_wgrad_reduce(ws.data_ptr(), B, dw2.data_ptr(), db2.data_ptr(), 1 if accumulate else 0, stream_ptr()),
           "mtd_spec_mix_wgrad_reduce")
     return gT

@@ -141,3 +141,25 @@ def test_generator_workload_graph_replay_equals_eager(hip_lib):
     torch.cuda.synchronize()
     for a, b in zip(replayed, wl.params):
         assert torch.equal(a, b.grad)
+
+
+def test_deferred_weight_gradient_sums_equal_immediate(hip_lib):
+    """generator_backward takes the slab sums of its 62 layers in two launches at the end of the pass
+    (mtd_conv_wgrad_reduce_multi / mtd_spec_mix_wgrad_reduce_multi): same association as the per-layer reduce,
+    so the gradients are bit-identical; 32 patches = 256 conv slabs and 544 mix slabs per layer."""
+    from mtd_gan_amd import kernels as K
+    G, _ = _gen()
+    x, _ = orc.synthetic_ldct(32, seed=77)
+    xd = x.cuda()
+    got = {}
+    for mode in (True, False):
+        K.DEFER_WGRADS = mode
+        try:
+            G.zero_grad()
+            G(xd).sum().backward()
+            torch.cuda.synchronize()
+            got[mode] = {n: p.grad.clone() for n, p in G.named_parameters()}
+        finally:
+            K.DEFER_WGRADS = True
+    for n in got[True]:
+        assert torch.equal(got[True][n], got[False][n]), n
