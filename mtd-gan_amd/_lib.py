@@ -96,10 +96,46 @@ def _preload_torch_hip_runtime():
         C.CDLL(tl, mode=C.RTLD_GLOBAL)
 
 
+RECORDER = None      # kernels.LaunchList: while a step is being recorded, the list every launch is appended to
+_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "mtd_prof_enable", "mtd_prof_collect", "_override")
+
+
+class _RecordingLib:
+    """Stand-in for the CDLL while kernels.LaunchList records a step: every launch entry point is called as usual and
+    (function, arguments) is appended to the list.  Arguments are raw pointers, scalars and byref()s of argument structs
+    (which keep their structs alive), so the pair can be called again as it is."""
+
+    def __init__(self, L):
+        self._L = L
+        self._wrapped = {}
+
+    def __getattr__(self, name):
+        w = self._wrapped.get(name)
+        if w is None:
+            f = getattr(self._L, name)
+            if any(t in name for t in _NOT_LAUNCHES):
+                w = f
+            else:
+                def w(*args, _f=f):
+                    rc = _f(*args)
+                    if RECORDER is not None:
+                        RECORDER.append((_f, args))
+                    return rc
+            self._wrapped[name] = w
+        return w
+
+
+_recording_lib = None
+
+
 def lib():
     """Load the HIP library or fail loudly."""
-    global _lib
+    global _lib, _recording_lib
     if _lib is not None:
+        if RECORDER is not None:
+            if _recording_lib is None:
+                _recording_lib = _RecordingLib(_lib)
+            return _recording_lib
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(

@@ -24,8 +24,29 @@ class GeneratorWorkload:
         self.flat = None
         self.graph = None
         self.graph_error = None
+        self.launch_list = None
         import os
-        if world == 1 and os.environ.get("MTD_GRAPH", "1") == "1":
+        mode = os.environ.get("MTD_GRAPH", "1")
+        if world == 1 and mode == "list":
+            # recorded launch list (kernels.LaunchList): the step's C-ABI calls and stream-order operations re-issued
+            # without the Python around them, side streams kept.  Measured (tools/list_probe.py, 284 launches, host enqueue
+            # 1.1-3.0 ms per step, so GPU-bound in every mode): all side streams 7.14 ms, weight gradients only 6.74 ms, one
+            # stream 6.56 ms -- against 6.43 ms for the captured single-stream graph, which therefore stays the default.
+            # The kernels of a block cannot share a CU (the halo-tile conv holds 136 KB of LDS, one workgroup per CU), so
+            # a second stream only adds event waits between them.
+            from . import kernels as K
+            try:
+                for _ in range(2):
+                    self.step_eager()
+                ll = K.LaunchList()
+                ll.record(self.step_eager, dev)
+                self.launch_list = ll
+                self.list_grads = [p.grad for p in self.params]
+            except Exception as e:
+                self.graph_error = repr(e)
+                self.launch_list = None
+                torch.cuda.synchronize()
+        if world == 1 and mode == "1":
             # hipGraph replay of the forward + backward (static shapes, no host-side state): the Python enqueue of the 432
             # launches takes 7.3 ms per step, as long as the GPU work.  Captured with every kernel in ONE stream: replay of a
             # single-stream graph runs at the kernels' own pace (7.1 ms), a captured multi-stream section does not (7.9 ms,
@@ -54,7 +75,12 @@ class GeneratorWorkload:
                 K.set_concurrency(True)
 
     def step(self):
-        if self.graph is not None:
+        if self.launch_list is not None:
+            self.launch_list.replay()
+            if self.params[0].grad is not self.list_grads[0]:
+                for p, g in zip(self.params, self.list_grads):
+                    p.grad = g
+        elif self.graph is not None:
             self.graph.replay()
         else:
             self.step_eager()
@@ -75,7 +101,8 @@ class GeneratorWorkload:
 
     def extra(self):
         return {"algorithmic_gflop_per_patch": self.gflop_per_patch,
-                "launch_mode": "hipGraph replay" if self.graph is not None else "eager launches", "graph_error": self.graph_error}
+                "launch_mode": ("launch-list replay, side streams" if self.launch_list is not None else
+                                "hipGraph replay" if self.graph is not None else "eager launches"), "graph_error": self.graph_error}
 
 
 class InferenceWorkload:

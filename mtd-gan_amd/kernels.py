@@ -136,6 +136,7 @@ def stream_ptr():
 
 
 DEFER_WGRADS = os.environ.get("MTD_NO_DEFERRED_WGRAD", "0") != "1"     # generator backward: slab sums of all layers in two launches
+RECORDING = None    # the LaunchList being recorded, if any
 CAPTURE_TAG = 0     # bumped while a hipGraph is captured so that graph-pool scratch never mixes with eager scratch
 
 
@@ -507,8 +508,13 @@ class _Arena:
 _arenas = {}
 
 
+def _static_tables():
+    """Tables made now must outlive the step: a hipGraph capture or a LaunchList recording is in progress."""
+    return RECORDING is not None or torch.cuda.is_current_stream_capturing()
+
+
 def arena(device):
-    capturing = torch.cuda.is_current_stream_capturing()
+    capturing = _static_tables()
     key = (device.index if device.index is not None else torch.cuda.current_device(), capturing)
     a = _arenas.get(key)
     if a is None:
@@ -533,7 +539,7 @@ def device_table(structs, device):
     raw = bytes(arr)
     # (the stream is part of the key: a table uploaded on one stream must not be read by a kernel on another stream that
     # is not ordered after the upload)
-    key = (device.index, torch.cuda.is_current_stream_capturing(), _raw_stream(device.index if device.index is not None else _cur_device()), raw)
+    key = (device.index, _static_tables(), CAPTURE_TAG, _raw_stream(device.index if device.index is not None else _cur_device()), raw)
     hit = _desc_cache.get(key)
     STATS["table_hit" if hit is not None else "table_miss"] += 1
     if hit is None:
@@ -542,6 +548,8 @@ def device_table(structs, device):
         check(_lib.lib().mtd_upload(host.data_ptr(), dev.data_ptr(), host.numel(), stream_ptr()), "mtd_upload")
         hit = (dev, arr, host)
         _desc_cache[key] = hit
+        if RECORDING is not None:
+            RECORDING.keep.append(hit)        # the host array is an argument of the recorded call
     return hit[0], hit[1]
 
 
@@ -718,6 +726,70 @@ def set_concurrency(on):
         s.enabled = on
 
 
+def _order(later, earlier):
+    """Everything enqueued on `later` from now on runs after everything enqueued on `earlier` so far."""
+    ev = torch.cuda.Event()
+    ev.record(earlier)
+    later.wait_event(ev)
+    if RECORDING is not None:
+        RECORDING.ops.append((ev.record, (earlier,)))
+        RECORDING.ops.append((later.wait_event, (ev,)))
+
+
+class LaunchList:
+    """One step of a static-shape schedule as a flat list of (C entry point, arguments) and stream-order operations,
+    recorded while the step runs eagerly and re-issued by replay() with none of the Python around the calls (tensor
+    allocation, geometry and plan look-ups: 17 us per launch, which makes eager generator steps host-bound).  Unlike a
+    captured hipGraph -- whose multi-stream sections ROCm 7.2 serialises -- the replay keeps the side streams, so the
+    spectral branch, the weight gradients and the data-gradient chain of a Res-FFT block overlap on the chip.
+    Every tensor allocated while recording is kept (no address is reused inside the step, so the stream-order
+    operations of the recording are the only ordering the replay needs); scratch and descriptor tables come from the
+    capture-side pools (CAPTURE_TAG, the non-recycling arena).  Inputs are the tensors the step read when it was
+    recorded: refresh them in place."""
+
+    def __init__(self):
+        self.ops, self.keep = [], []
+
+    def record(self, fn, device):
+        global RECORDING, CAPTURE_TAG
+        if RECORDING is not None or torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("LaunchList.record: a recording or a hipGraph capture is already in progress")
+        prepare_capture(device)
+        weights_changed()                 # packed / transposed weight views are produced inside the list
+        torch.cuda.synchronize()
+        real_empty, real_empty_like = torch.empty, torch.empty_like
+
+        # (the storages are kept, not the tensors: autograd takes a gradient tensor over as .grad without a copy only
+        # while nothing else refers to the tensor object)
+        def empty(*a, **k):
+            t = real_empty(*a, **k)
+            self.keep.append(t.untyped_storage())
+            return t
+
+        def empty_like(*a, **k):
+            t = real_empty_like(*a, **k)
+            self.keep.append(t.untyped_storage())
+            return t
+        CAPTURE_TAG += 1
+        RECORDING = self
+        _lib.RECORDER = self.ops
+        torch.empty, torch.empty_like = empty, empty_like
+        try:
+            out = fn()
+        finally:
+            torch.empty, torch.empty_like = real_empty, real_empty_like
+            _lib.RECORDER = None
+            RECORDING = None
+        torch.cuda.synchronize()
+        return out
+
+    def replay(self):
+        for f, args in self.ops:
+            rc = f(*args)
+            if rc:
+                raise RuntimeError(f"LaunchList.replay: {getattr(f, '__name__', f)} failed with code {rc}")
+
+
 class SideStream:
     """A second HIP stream for work that is off the critical path of a backward pass (weight gradients, their
     slab reductions, the spectral-norm correction): it runs beside the data-gradient chain on the main stream
@@ -732,9 +804,7 @@ class SideStream:
 
     def fork(self):
         if self.enabled:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self.stream.wait_event(ev)
+            _order(self.stream, torch.cuda.current_stream())
 
     def run(self, fn, *keep):
         if not self.enabled:
@@ -747,9 +817,7 @@ class SideStream:
 
     def join(self):
         if self.enabled:
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-            torch.cuda.current_stream().wait_event(ev)
+            _order(torch.cuda.current_stream(), self.stream)
         self._keep.clear()
 
 

@@ -127,9 +127,45 @@ def test_cpu_tensor_is_rejected(hip_lib):
         G(torch.zeros(1, 1, 64, 64))
 
 
-def test_generator_workload_graph_replay_equals_eager(hip_lib):
-    """bench.py's generator workload replays a captured single-stream hipGraph by default: same gradients as eager launches."""
+def test_generator_workload_launch_list_replay_equals_eager(hip_lib, monkeypatch):
+    """bench.py's generator workload replays a recorded launch list (kernels.LaunchList) with the side streams kept:
+    same gradients as eager launches, recomputed on every replay, and it follows its input tensors."""
     from mtd_gan_amd import bench_workloads as BW
+    monkeypatch.setenv("MTD_GRAPH", "list")
+    dev = torch.device("cuda", 0)
+    wl = BW.GeneratorWorkload(dev, 0, 1, 4)
+    assert wl.launch_list is not None, wl.graph_error
+    assert len(wl.launch_list.ops) > 300
+    wl.step()
+    wl.step()
+    torch.cuda.synchronize()
+    replayed = [p.grad.clone() for p in wl.params]
+    for p in wl.params:
+        p.grad.zero_()
+    wl.step()
+    torch.cuda.synchronize()
+    for a, p in zip(replayed, wl.params):
+        assert torch.equal(a, p.grad)
+    wl.step_eager()
+    torch.cuda.synchronize()
+    for a, p in zip(replayed, wl.params):
+        assert torch.equal(a, p.grad)
+    x2, _ = orc.synthetic_ldct(4, seed=99)
+    wl.x.copy_(x2.cuda())
+    wl.step()
+    torch.cuda.synchronize()
+    replayed = [p.grad.clone() for p in wl.params]
+    wl.step_eager()
+    torch.cuda.synchronize()
+    for a, p in zip(replayed, wl.params):
+        assert torch.equal(a, p.grad)
+        assert float(a.abs().max()) > 0
+
+
+def test_generator_workload_graph_replay_equals_eager(hip_lib, monkeypatch):
+    """MTD_GRAPH=1: the generator workload replays a captured single-stream hipGraph: same gradients as eager launches."""
+    from mtd_gan_amd import bench_workloads as BW
+    monkeypatch.setenv("MTD_GRAPH", "1")
     dev = torch.device("cuda", 0)
     wl = BW.GeneratorWorkload(dev, 0, 1, 4)
     assert wl.graph is not None, wl.graph_error
