@@ -77,6 +77,10 @@ typedef struct {
     const float* scale2; int scale_split;        /* optional second scale: launch-grid pixels >= scale_split use *scale2.  Two
                                                     discriminator passes with their own spectral-norm sigma share one launch
                                                     (batch halves); 0 / NULL = one scale for all pixels */
+    float* out2; int out2_ld;                    /* optional second output: the value BEFORE the mask factor (out gets it after).
+                                                    A data-gradient launch then also hands the next layer's activation-masked
+                                                    cotangent over.  Halo-tile kernel only (C == 32, 3x3, 64-pixel rows,
+                                                    >= 32768 pixels); MTD_EINVAL on every other path */
 } mtd_conv_args;
 
 size_t mtd_conv_igemm_ws_bytes(const mtd_conv_args* a);

@@ -29,7 +29,8 @@ class ConvArgs(C.Structure):
                 ("act", C.c_int),
                 ("mask", C.c_void_p), ("mask_ld", C.c_int), ("mask_slope", C.c_float),
                 ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
-                ("scale2", C.c_void_p), ("scale_split", C.c_int)]
+                ("scale2", C.c_void_p), ("scale_split", C.c_int),
+                ("out2", C.c_void_p), ("out2_ld", C.c_int)]
 
 
 class WgradArgs(C.Structure):

@@ -159,6 +159,11 @@ __device__ __forceinline__ void epi_store(const IgemmParams& p, const f32x16& ac
 #pragma unroll
         for (int i = 0; i < NE; ++i) v[i] = v[i] > 0.f ? v[i] : 0.2f * v[i];
     }
+    if (a.out2) {       // the unmasked value as well (halo-tile kernel; rejected by the dispatch elsewhere)
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+            if (ad.ok(p, i)) *ad.at(a.out2, a.out2_ld, i) = v[i];
+    }
     if (a.mask) {
         const float slope = a.mask_slope;
 #pragma unroll
@@ -1086,6 +1091,7 @@ int check_args(const mtd_conv_args& a) {
     if (a.add1 && a.add1_ld < a.N) return MTD_EINVAL;
     if (a.add2 && a.add2_ld < a.N) return MTD_EINVAL;
     if (a.mask && a.mask_ld < a.N) return MTD_EINVAL;
+    if (a.out2 && a.out2_ld < a.N) return MTD_EINVAL;
     // the furthest output pixel must stay inside the OHF x OWF image
     if ((g.OH - 1) * g.out_sy + g.out_oy >= g.OHF || (g.OW - 1) * g.out_sx + g.out_ox >= g.OWF) return MTD_EINVAL;
     return MTD_OK;
@@ -1159,6 +1165,7 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
         MTD_LAUNCH_CHECK();
         return MTD_OK;
     }
+    if (a->out2) return MTD_EINVAL;               // second output: halo-tile kernel only
     if ((g_force_cfg == -1 || g_force_cfg == 9) && gen_shape) {
         // generator-shaped layers: persistent kernel, two 32-pixel tiles per wave at M = 131072
         const int ntiles = (p.M + 31) / 32;

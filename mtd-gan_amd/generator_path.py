@@ -42,14 +42,16 @@ def block_forward(x, w_img, b_img, w_fft, b_fft, save, w2t=None):
     return out, ((x, img, S, Z) if save else None)
 
 
-def block_backward(g, saved, w_img, w_fft, grads, premask, defer=None):
+def block_backward(g, saved, w_img, w_fft, grads, premask, defer=None, gm=None):
     """g: grad of the block output.  grads: dict with tensors dw_img, db_img, dw_fft, db_fft (written).
     premask: multiply the input gradient by (x > 0) -- x is always a ReLU output inside the generator,
-    so the result is the gradient w.r.t. the producer's pre-activation."""
+    so the result is the gradient w.r.t. the producer's pre-activation.  gm: g * (img > 0) if the launch that
+    produced g has written it already (conv(out2=...))."""
     x, img, S, Z = saved
     B, H, W, _ = x.shape
     side = K.side_stream(x.device)
-    gm = K.act_grad(g, img, 0.0)                                                    # g * (img > 0)
+    if gm is None:
+        gm = K.act_grad(g, img, 0.0)                                                # g * (img > 0)
     side.run(lambda: K.wgrad(gm, x, K.geom_fwd(B, H, W, 3, 1, 1), CH, CH, grads["dw_img"], CH * 9, 9, db=grads["db_img"], defer=defer), gm, g)
     # spectral branch backward on a second side stream, beside the spatial data gradient on the main stream
     side1 = K.side_stream(x.device, 1)
@@ -149,24 +151,37 @@ def generator_backward(g_out, tape, P, G):
     gu = K.empty_nhwc(B, H, W, CH, x)
     K.conv(gpre, P.dec_w[0], gf, CH, 1, 9, 9, gu)          # d/du0: plain conv with W_t read as OIHW [32][1][3][3]
     skip = [None] * (L + 1)
+    # A data-gradient launch also writes its result times (img > 0) of the block that consumes it -- that block's
+    # masked cotangent, otherwise a pass of its own (21 x 10 us per step) -- where the halo-tile kernel runs it.
+    fuse = K.fuses_masked_cotangent(B, H, W, CH, CH)
+    gm = None
     # blocks 20..11 and decoders 1..10 (tape order: d/u/blk appended for j = 10..1)
     for j in range(1, L + 1):
         k = L - j                                           # position in the tape lists for decoder[j]
-        gpre_d = block_backward(gu, tape["blk"][L + 1 + k], *_blk_w(P, 2 * L + 1 - j), G.blk[2 * L + 1 - j], True, defer)
+        gpre_d = block_backward(gu, tape["blk"][L + 1 + k], *_blk_w(P, 2 * L + 1 - j), G.blk[2 * L + 1 - j], True, defer, gm)
         skip[j] = gpre_d                                    # flows unchanged into e_j
         uj = tape["u"][k]                                   # input of decoder[j]
         side.run(lambda: K.wgrad(gpre_d, uj, gt, CH, CH, G.dec_w[j], 9, CH * 9, db=G.dec_b[j], defer=defer), gpre_d)
         gu = K.empty_nhwc(B, H, W, CH, x)
-        K.conv(gpre_d, P.dec_w[j], gf, CH, CH, CH * 9, 9, gu)
+        if fuse:                                            # consumer: block 2L - j (tape position L + k), or block L after the loop
+            gm = K.empty_nhwc(B, H, W, CH, x)
+            K.conv(gpre_d, P.dec_w[j], gf, CH, CH, CH * 9, 9, gm, mask=tape["blk"][L + k][1], mask_slope=0.0, out2=gu)
+        else:
+            K.conv(gpre_d, P.dec_w[j], gf, CH, CH, CH * 9, 9, gu)
     # gu is now the gradient of x_b (output of block 10)
     g_e = gu
     for i in range(L, -1, -1):                              # blocks 10..0, encoders 10..0
-        gpre_t = block_backward(g_e, tape["blk"][i], *_blk_w(P, i), G.blk[i], True, defer)
+        gpre_t = block_backward(g_e, tape["blk"][i], *_blk_w(P, i), G.blk[i], True, defer, gm)
         if i > 0:
             e_prev = tape["e"][i - 1]
             side.run(lambda: K.wgrad(gpre_t, e_prev, gf, CH, CH, G.enc_w[i], CH * 9, 9, db=G.enc_b[i], defer=defer), gpre_t)
             g_e = K.empty_nhwc(B, H, W, CH, x)
-            K.conv(gpre_t, P.enc_w[i], K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, g_e, add1=skip[i])
+            if fuse:
+                gm = K.empty_nhwc(B, H, W, CH, x)
+                K.conv(gpre_t, P.enc_w[i], K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, gm, add1=skip[i],
+                       mask=tape["blk"][i - 1][1], mask_slope=0.0, out2=g_e)
+            else:
+                K.conv(gpre_t, P.enc_w[i], K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, g_e, add1=skip[i])
         else:
             side.run(lambda: K.wgrad(gpre_t, x, gf, CH, 1, G.enc_w[0], 9, 9, db=G.enc_b[0]), gpre_t)
     side.join()

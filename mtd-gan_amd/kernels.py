@@ -203,8 +203,9 @@ def _ptr(t):
 
 # ---------------------------------------------------------------------------------------------- conv
 def conv(x, w, geom, N, Cc, w_sn, w_sc, out, scale=None, bias=None, add1=None, add2=None, act=ACT_NONE,
-         mask=None, mask_slope=0.0, scale2=None, scale_split=0):
-    """out = epilogue(conv(x, W-view)).  `out` is an NHWC tensor (B, OHF, OWF, >=N view)."""
+         mask=None, mask_slope=0.0, scale2=None, scale_split=0, out2=None):
+    """out = epilogue(conv(x, W-view)).  `out` is an NHWC tensor (B, OHF, OWF, >=N view).  out2 (see
+    fuses_masked_cotangent): also store the value before the mask factor."""
     L = _lib.lib()
     a = ConvArgs()
     a.g = geom
@@ -220,6 +221,7 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, scale=None, bias=None, add1=None, a
     a.add2, a.add2_ld = _ptr(add2), (ld_of(add2) if add2 is not None else 0)
     a.act = act
     a.mask, a.mask_ld, a.mask_slope = _ptr(mask), (ld_of(mask) if mask is not None else 0), mask_slope
+    a.out2, a.out2_ld = _ptr(out2), (ld_of(out2) if out2 is not None else 0)
     a.ws, a.ws_bytes = None, 0
     if (Cc % 32 == 0) and (N % 32 == 0):
         wkey = (bytes(geom), N, Cc)
@@ -238,6 +240,15 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, scale=None, bias=None, add1=None, a
             CALL_LOG.append(("direct", bytes(a)))
         check(L.mtd_conv_direct(C.byref(a), stream_ptr()), "mtd_conv_direct")
     return out
+
+
+FUSE_ACT_GRAD = os.environ.get("MTD_NO_FUSED_ACT_GRAD", "0") != "1"
+
+
+def fuses_masked_cotangent(B, H, W, Cc, N):
+    """Can a 3x3 / stride-1 conv launch of this shape write both its result and result * (mask > 0) (conv(out2=...))?
+    That is the halo-tile kernel's domain (conv_igemm.hip c32t_eligible + the generator-shape test of the dispatch)."""
+    return FUSE_ACT_GRAD and Cc == 32 and N % 32 == 0 and H == 64 and W == 64 and B * H * W >= 32768
 
 
 class DeferredWgrads:

@@ -188,14 +188,17 @@ def test_deferred_weight_gradient_sums_equal_immediate(hip_lib):
     x, _ = orc.synthetic_ldct(32, seed=77)
     xd = x.cuda()
     got = {}
-    for mode in (True, False):
-        K.DEFER_WGRADS = mode
+    for mode in ((True, True), (False, True), (True, False)):
+        K.DEFER_WGRADS, K.FUSE_ACT_GRAD = mode
         try:
             G.zero_grad()
             G(xd).sum().backward()
             torch.cuda.synchronize()
             got[mode] = {n: p.grad.clone() for n, p in G.named_parameters()}
         finally:
-            K.DEFER_WGRADS = True
-    for n in got[True]:
-        assert torch.equal(got[True][n], got[False][n]), n
+            K.DEFER_WGRADS, K.FUSE_ACT_GRAD = True, True
+    # (second switch: the data-gradient launches of the halo-tile kernel also write the next block's activation-masked
+    # cotangent, conv(out2=...), instead of a separate act_grad pass -- the same values)
+    for n in got[(True, True)]:
+        assert torch.equal(got[(True, True)][n], got[(False, True)][n]), n
+        assert torch.equal(got[(True, True)][n], got[(True, False)][n]), n
