@@ -87,7 +87,7 @@ size_t mtd_conv_igemm_ws_bytes(const mtd_conv_args* a);
 int mtd_conv_igemm(const mtd_conv_args* a, void* stream);
 
 /* dst[(t*N + n)*C + c] = src[n*sn + c*sc + t]  for `count` weight tensors in one launch (table in device
- * memory + the same table on the host for sizing). */
+ * memory + the same table on the host for sizing).  N and C multiples of 32, T <= 16. */
 typedef struct { const float* src; float* dst; int N, C, T; long long sn, sc; } mtd_pack_desc;
 int mtd_pack_weights(const mtd_pack_desc* table_dev, const mtd_pack_desc* table_host, int count, void* stream);
 

@@ -183,27 +183,59 @@ __global__ __launch_bounds__(256) void add4_kernel(const f32x4* __restrict__ a, 
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) out[i] = a[i] + b[i];
 }
 
-constexpr int PACK_ELEMS = 4096;
+// [tap][n][c] re-layout of weight views W(n,c,t) = src[n*sn + c*sc + t].  A workgroup owns a 32 n x 32 c tile with all its
+// taps: it reads the tile in the source's own order (for OIHW storage the 32 c x T taps of one n are one contiguous run, for
+// a transposed-conv view the 32 n x T taps of one c), turns it in LDS and writes 128-byte rows of c.  (The first version
+// read one element per thread in destination order: every source line was fetched once per tap, 1 TB/s.)
+constexpr int PACK_MAXT = 16;
+constexpr int PACK_TS = 552;                   // LDS floats per tap: 16 rows of 33 (or 32 rows of 17) + pad, taps eight banks apart
+__device__ __forceinline__ int pack_div(int x, float inv) { return __float2int_rz(((float)x + 0.5f) * inv); }   // x < 2^14, exact
+// tile: 16 values of the source's slow index x 32 of its fast index x all taps (2144 B of LDS per tap: 4 workgroups per CU
+// with the 4x4 layers in the launch)
 __global__ __launch_bounds__(256) void pack_weights_kernel(const mtd_pack_desc* __restrict__ D, int count) {
+    extern __shared__ float tile[];               // [max T of the launch][PACK_TS]
     int acc = 0, di = -1, local = 0;
     for (int t = 0; t < count; ++t) {
-        const int nb = (int)(((long long)D[t].N * D[t].C * D[t].T + PACK_ELEMS - 1) / PACK_ELEMS);
+        const int nb = (D[t].N >> 5) * (D[t].C >> 5) * 2;
         if ((int)blockIdx.x < acc + nb) { di = t; local = blockIdx.x - acc; break; }
         acc += nb;
     }
     if (di < 0) return;
     const mtd_pack_desc d = D[di];
-    const long long total = (long long)d.N * d.C * d.T;
-    const long long base = (long long)local * PACK_ELEMS;
-    for (int i = threadIdx.x; i < PACK_ELEMS; i += 256) {
-        const long long e = base + i;
-        if (e < total) {
-            const int c = (int)(e % d.C);
-            const long long r = e / d.C;
-            const int n = (int)(r % d.N);
-            const int t = (int)(r / d.N);
-            d.dst[e] = d.src[(long long)n * d.sn + (long long)c * d.sc + t];
+    const bool c_inner = d.sc <= d.sn;            // which of n / c is the faster index in the source
+    const int ctiles = c_inner ? (d.C >> 5) : (d.C >> 4);
+    const int n0 = (local / ctiles) << (c_inner ? 4 : 5), c0 = (local % ctiles) << (c_inner ? 5 : 4);
+    const int T = d.T, per = 32 * T, total = 16 * per;
+    const float inv_per = 1.f / (float)per, inv_t = 1.f / (float)T;
+    const int nrow = c_inner ? 33 : 17;            // LDS row stride of an n
+    const float* src = d.src + (long long)n0 * d.sn + (long long)c0 * d.sc;
+    for (int base = 0; base < total; base += 8 * 256) {      // eight loads in flight per thread
+        float v[8];
+        int li[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * 256 + threadIdx.x;
+            li[u] = -1;
+            v[u] = 0.f;
+            if (i < total) {
+                const int outer = pack_div(i, inv_per), rem = i - outer * per;
+                const int inner = pack_div(rem, inv_t), t = rem - inner * T;
+                const int n = c_inner ? outer : inner, c = c_inner ? inner : outer;
+                v[u] = src[(long long)n * d.sn + (long long)c * d.sc + t];
+                li[u] = t * PACK_TS + n * nrow + c;
+            }
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (li[u] >= 0) tile[li[u]] = v[u];
+    }
+    __syncthreads();
+    float* dst = d.dst + (long long)n0 * d.C + c0;
+    const long long tstride = (long long)d.N * d.C;
+    const int cbits = c_inner ? 5 : 4, cmask = (1 << cbits) - 1, nmask = c_inner ? 15 : 31;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int c = i & cmask, n = (i >> cbits) & nmask, t = i >> 9;
+        dst[t * tstride + (long long)n * d.C + c] = tile[t * PACK_TS + n * nrow + c];
     }
 }
 
@@ -268,11 +300,15 @@ extern "C" int mtd_upload(const void* src_pinned, void* dst, size_t bytes, void*
 extern "C" int mtd_pack_weights(const mtd_pack_desc* table_dev, const mtd_pack_desc* table_host, int count, void* stream) {
     if (!table_dev || !table_host || count <= 0) return MTD_EINVAL;
     long long blocks = 0;
+    int maxT = 1;
     for (int i = 0; i < count; ++i) {
         if (!table_host[i].src || !table_host[i].dst || table_host[i].N <= 0 || table_host[i].C <= 0 || table_host[i].T <= 0) return MTD_EINVAL;
-        blocks += ((long long)table_host[i].N * table_host[i].C * table_host[i].T + PACK_ELEMS - 1) / PACK_ELEMS;
+        if ((table_host[i].N % 32) || (table_host[i].C % 32) || table_host[i].T > PACK_MAXT) return MTD_EINVAL;
+        blocks += (long long)(table_host[i].N / 32) * (table_host[i].C / 32) * 2;
+        if (table_host[i].T > maxT) maxT = table_host[i].T;
     }
-    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, table_dev, count);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)blocks), dim3(256), (size_t)maxT * PACK_TS * sizeof(float), (hipStream_t)stream,
+                       table_dev, count);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }
