@@ -102,13 +102,13 @@ def cpu_baseline(wl):
             "sample": f"oracle full G+D+PCGrad+AdamW step, {iters} x {nb} patches (1 warm-up), torch CPU {torch.__version__}, {cores} threads"}
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, tag=""):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summaries (profiles/r1_pmc_*.csv: one pass
     with FETCH_SIZE, one with WRITE_SIZE, values in KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
     bench.py cannot collect PMC counters itself; returns None when the summaries are absent."""
     import csv
     tot = 0.0
-    for fn, mult in (("r1_pmc_fetch_size.csv", 2.0), ("r1_pmc_write_size.csv", 1.0)):
+    for fn, mult in ((f"r1_pmc_{tag}fetch_size.csv", 2.0), (f"r1_pmc_{tag}write_size.csv", 1.0)):
         path = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(path):
             return None
@@ -123,11 +123,11 @@ def pmc_traffic(kernel):
     return round(tot)
 
 
-def pmc_mfma_util(kernel):
+def pmc_mfma_util(kernel, tag=""):
     """MFMA-pipe utilisation of `kernel` from the committed PMC pass (profiles/r1_pmc_mfma_util.csv: SQ_VALU_MFMA_BUSY_CYCLES /
     (32 x SQ_BUSY_CYCLES), calibrated at 1.000 on a register-only MFMA loop, tools/pmc_mfma_util.py); None when absent."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r1_pmc_mfma_util.csv")
+    path = os.path.join(ROOT, "profiles", f"r1_pmc_{tag}mfma_util.csv")
     if not os.path.exists(path):
         return None
     for row in csv.DictReader(open(path)):
@@ -226,12 +226,15 @@ def main():
                 dd["ms"] = max(dd["ms"] - ev_over_ms * dd["n"], 1e-6)
                 for sh in dd["shapes"].values():
                     sh[0] = max(sh[0] - ev_over_ms * sh[2], 1e-6)
+            pmc_tag = {"full_step": "", "generator_fwd_bwd": "generator_"}.get(wl.name)
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             top = sorted(d["shapes"].items(), key=lambda kv: -kv[1][0])[:4]
             roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                        "traffic": pmc_traffic(name) if wl.name == "full_step" else None,   # the committed PMC passes profile the default workload
-                        "mfma_util_pmc": pmc_mfma_util(name) if wl.name == "full_step" else None,
+                        # committed PMC passes: the default workload (profiles/r1_pmc_*.csv) and the generator workload
+                        # (profiles/r1_pmc_generator_*.csv, tools/pmc_generator.sh)
+                        "traffic": pmc_traffic(name, pmc_tag) if pmc_tag is not None else None,
+                        "mfma_util_pmc": pmc_mfma_util(name, pmc_tag) if pmc_tag is not None else None,
                         "launches_timed": d["n"], "avg_launch_us": round(1e3 * d["ms"] / d["n"], 2),
                         "avg_launch_us_with_event_pair": round(1e3 * raw_ms / d["n"], 2), "event_pair_us": round(1e3 * ev_over_ms, 2),
                         "flops_per_launch": round(d["flops"] / d["n"]), "measured": "second pass of the same steps, all kernels in one stream",
