@@ -682,8 +682,12 @@ __global__ __launch_bounds__(16 * SQ * SQ) void wgrad_reduce_finish_kernel(const
 // the same for many layers in one launch: workgroup -> (layer, 16-column chunk) through the table's block prefix sums
 __global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(const mtd_wgrad_reduce_desc* __restrict__ table, int count) {
     __shared__ f32x4 red[16 * 8 * 9];
-    int li = 0;
-    while (li + 1 < count && (int)blockIdx.x >= table[li + 1].first_block) ++li;     // count <= a few dozen, uniform scalar loads
+    int li = 0, hi = count - 1;                   // last layer whose first_block <= blockIdx.x (uniform scalar loads)
+    while (li < hi) {
+        const int mid = (li + hi + 1) >> 1;
+        if ((int)blockIdx.x >= table[mid].first_block) li = mid;
+        else hi = mid - 1;
+    }
     const mtd_wgrad_reduce_desc& d = table[li];
     const mtd_wgrad_args& a = d.a;
     const unsigned count4 = ((unsigned)(d.T * a.N * a.C) >> 2) + (a.db ? ((unsigned)a.N >> 2) : 0u);

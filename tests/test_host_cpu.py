@@ -100,3 +100,33 @@ def test_derived_view_cache_keeps_one_generation():
         K._remember(cache, ("ptr", 32, 32, 288, 9), ("ptr", version, 0, 32, 32, 288, 9), ("packed", version))
         K._remember(cache, ("other", 32, 32, 9, 288), ("other", version, 0, 32, 32, 9, 288), ("packed2", version))
     assert len(cache) == 2 and cache[("ptr", 4, 0, 32, 32, 288, 9)] == ("packed", 4)
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """The argument structs the Python host fills (mtd_gan_amd/_lib.py) have the size and field offsets the C header
+    declares (gcc, no GPU): conv / weight-gradient arguments and the descriptor tables of the deferred reductions."""
+    import subprocess
+    from mtd_gan_amd import _lib as L
+    checks = [("mtd_conv_args", L.ConvArgs, ["out", "mask", "ws", "scale2", "out2", "out2_ld"], {"inp": "in"}),
+              ("mtd_wgrad_args", L.WgradArgs, ["p", "q", "dw", "db", "accumulate", "ws"], {}),
+              ("mtd_wgrad_reduce_desc", L.WgradReduceDesc, ["a", "T", "nslab", "slab_stride", "first_block"], {}),
+              ("mtd_mix_reduce_desc", L.MixReduceDesc, ["ws", "dw2", "db2", "nslab", "accumulate"], {}),
+              ("mtd_pack_desc", L.PackDesc, ["src", "dst", "N", "T", "sn", "sc"], {})]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT}/include/mtdgan_hip.h"', "int main(void) {"]
+    for cname, _cls, fields, _ren in checks:
+        lines.append(f'  printf("%zu", sizeof({cname}));')
+        for f in fields:
+            lines.append(f'  printf(" %zu", offsetof({cname}, {f}));')
+        lines.append('  printf("\\n");')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    for (cname, cls, fields, ren), line in zip(checks, out):
+        vals = [int(v) for v in line.split()]
+        inv = {v: k for k, v in ren.items()}
+        assert vals[0] == ctypes.sizeof(cls), cname
+        for f, off in zip(fields, vals[1:]):
+            assert getattr(cls, inv.get(f, f)).offset == off, (cname, f)
