@@ -37,8 +37,7 @@ class DataParallelSync:
             self.side.wait_event(ev)
             flat.record_stream(self.side)
             with torch.cuda.stream(self.side):
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-                flat.mul_(1.0 / self.world)
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG)      # RCCL scales inside the collective: no extra pass over 114 MB
             done = torch.cuda.Event()
             done.record(self.side)
             self._pending.append(done)
@@ -63,10 +62,10 @@ class DataParallelSync:
         self.wait()
         flat = torch.cat([t.reshape(-1) for t in tensors])
         if self.cuda:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG)
         else:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.mul_(1.0 / self.world)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)          # gloo has no AVG
+            flat.mul_(1.0 / self.world)
         ofs = 0
         for t in tensors:
             n = t.numel()
