@@ -343,3 +343,51 @@ def test_torch_adamw_drives_the_same_step(hip_lib):
     t2, t2_fresh = run("torch", 2), run("torch", 2, drop_caches=True)
     for k in t2:
         assert torch.equal(t2[k], t2_fresh[k]), k
+
+
+def test_data_parallel_path_on_one_rank_equals_plain_step(hip_lib, monkeypatch):
+    """The N > 1 code path (parallel.DataParallelSync: per-task all-reduce on a side stream before the PCGrad
+    projection, task-specific and generator gradients bucketed) with every collective forced in a one-rank RCCL
+    group (MTD_FORCE_DP=1): the average over one rank is the identity, so three iterations must give the plain
+    step's parameters bit for bit -- the stream hand-offs around the collectives are what is being tested."""
+    import torch.distributed as dist
+    from mtd_gan_amd import engine, parallel
+    from mtd_gan_amd.arch.Ours.networks import MTD_GAN_Method
+    from mtd_gan_amd.module.weight_methods import WeightMethods
+    from mtd_gan_amd.optimizers import FusedAdamW
+    monkeypatch.setenv("MTD_FORCE_DP", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29533")
+    dev = torch.device("cuda", 0)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        x, y = orc.synthetic_ldct(4, seed=78)
+        x, y = x.cuda(), y.cuda()
+        results = []
+        for mode in ("plain", "dp"):
+            torch.manual_seed(6)
+            m = MTD_GAN_Method().cuda().train()
+            m.Discriminator.c_drop.p = 0.0
+            wm = WeightMethods("pcgrad", n_tasks=3, device=dev)
+            oD = FusedAdamW(m.Discriminator.parameters(), lr=1e-4, weight_decay=5e-4)
+            oG = FusedAdamW(m.Generator.parameters(), lr=1e-4, weight_decay=5e-4)
+            dp = None
+            if mode == "dp":
+                dp = parallel.DataParallelSync(dev)
+                assert dp.force and dp.world == 1
+                dp.broadcast_module(m)
+                wm.method.dp = dp
+            random.seed(321)
+            for _ in range(3):
+                names, vals = engine.train_iteration(m, x, y, oG, oD, wm, dp)
+            torch.cuda.synchronize()
+            results.append(({k: v.clone() for k, v in m.state_dict().items()}, vals.clone()))
+        (sd_p, v_p), (sd_d, v_d) = results
+        assert torch.equal(v_p, v_d)
+        for k in sd_p:
+            assert torch.equal(sd_p[k], sd_d[k]), k
+    finally:
+        if created:
+            dist.destroy_process_group()
