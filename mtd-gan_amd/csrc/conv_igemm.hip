@@ -54,6 +54,7 @@ struct IgemmParams {
     int out_identity;  // output pixel index == launch-grid pixel index
     int out_linear;    // 32 consecutive launch-grid pixels (from a multiple of 32) map to output pixels pix0 + r * out_sx
     int xcd_map;       // tiles in XCD-contiguous, n-fastest order (tile_of below)
+    int nt_store;      // lab switch MTD_IGEMM_NT=1: non-temporal output stores in the block epilogue
 };
 
 // (m tile, n tile) of this workgroup.  Dispatch order is blockIdx.x fastest and consecutive workgroups land on different
@@ -168,6 +169,12 @@ __device__ __forceinline__ void epi_store(const IgemmParams& p, const f32x16& ac
         const float slope = a.mask_slope;
 #pragma unroll
         for (int i = 0; i < NE; ++i) v[i] *= (o.em[i] > 0.f) ? 1.f : slope;
+    }
+    if (p.nt_store) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+            if (ad.ok(p, i)) __builtin_nontemporal_store(v[i], ad.at(a.out, a.out_ld, i));
+        return;
     }
 #pragma unroll
     for (int i = 0; i < NE; ++i)
@@ -708,11 +715,16 @@ __global__ __launch_bounds__(256, 2) void igemm_c32p_kernel(const IgemmParams p,
 // operands are requested before the MFMA loop and waited for after it, and the output stores drain under the next
 // tile's MFMAs, so memory phases and MFMA phases of a CU overlap instead of alternating chip-wide.
 // LDS: 2 x 50 KB tiles + 36 KB weights.
-constexpr int C32T_W = 64, C32T_R = 4, C32T_HW = C32T_W + 2, C32T_HP = (C32T_R + 2) * C32T_HW, C32T_NI = (C32T_HP + 7) / 8;
+constexpr int C32T_W = 64, C32T_R = 4, C32T_HW = C32T_W + 2;
 
-__global__ __launch_bounds__(512, 1) void igemm_c32t_kernel(const IgemmParams p, int ntiles) {
-    constexpr int T = 9;
-    __shared__ __attribute__((aligned(1024))) float Hs[2][C32T_NI * 8 * 32];
+// R image rows per tile, 2 R waves per workgroup.  DB: two halo buffers, one workgroup per CU, the next tile's DMA under this
+// tile's MFMAs (R = 4).  !DB (R = 2, lab variant MTD_C32T_VARIANT=1): one halo buffer of half the size, TWO workgroups per CU
+// that are meant to alternate -- one in its memory phase (epilogue stores, next tile's DMA) while the other has the MFMA
+// pipes -- with the second workgroup of a CU held back by `stagger` x 64 clocks at the start.
+template <int R, bool DB>
+__global__ __launch_bounds__(128 * R, DB ? 1 : 2) void igemm_c32t_kernel(const IgemmParams p, int ntiles, int stagger) {
+    constexpr int T = 9, NW = 2 * R, HP = (R + 2) * C32T_HW, NI = (HP + 7) / 8;
+    __shared__ __attribute__((aligned(1024))) float Hs[DB ? 2 : 1][NI * 8 * 32];
     __shared__ __attribute__((aligned(1024))) float Bs[T * 32 * 32];
     const mtd_conv_args& a = p.a;
     const mtd_geom& g = a.g;
@@ -720,7 +732,7 @@ __global__ __launch_bounds__(512, 1) void igemm_c32t_kernel(const IgemmParams p,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kh = lane >> 5;
     const int n0 = blockIdx.y * 32;
-    const int tiles_per_image = g.OH / C32T_R;
+    const int tiles_per_image = g.OH / R;
     typedef __attribute__((address_space(3))) float lds_f;
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)p.in_bytes, 0x00020000);
     const int rsub = lane >> 3, piece = (lane & 7) ^ rsub;
@@ -728,12 +740,12 @@ __global__ __launch_bounds__(512, 1) void igemm_c32t_kernel(const IgemmParams p,
     // DMA instruction i of a tile moves halo pixels 8i .. 8i+7: lane L -> pixel 8i + (L >> 3), LDS piece L & 7
     auto stage_tile = [&](int tile, int buf) {
         const int b = tile / tiles_per_image;
-        const int oy0 = (tile - b * tiles_per_image) * C32T_R;
-        for (int i = wave; i < C32T_NI; i += 8) {
+        const int oy0 = (tile - b * tiles_per_image) * R;
+        for (int i = wave; i < NI; i += NW) {
             const int hp = 8 * i + rsub;
             const int hr = hp / C32T_HW, hc = hp - hr * C32T_HW;
             const int iy = oy0 - 1 + hr, ix = hc - 1;
-            const bool ok = (hp < C32T_HP) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
+            const bool ok = (hp < HP) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
             const unsigned voff = ok ? (unsigned)(((((long long)b * g.IH + iy) * g.IW + ix) * a.in_ld + piece * 4) * 4) : 0x80000000u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_f*)&Hs[buf][i * 256], 16, voff, 0, 0, 0);
         }
@@ -743,7 +755,7 @@ __global__ __launch_bounds__(512, 1) void igemm_c32t_kernel(const IgemmParams p,
     stage_tile(tile, 0);
     {   // weights: row r = tap * 32 + n of a [288][32 c] matrix, same piece permutation
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), (short)0, (int)p.w_bytes, 0x00020000);
-        for (int i = wave; i < T * 4; i += 8) {
+        for (int i = wave; i < T * 4; i += NW) {
             const int t = i >> 2, nn = 8 * (i & 3) + rsub;
             const unsigned voff = (unsigned)(((long long)(n0 + nn) * a.w_sn + (long long)p.tap_kidx[t] * a.w_st + piece * 4) * 4);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_f*)&Bs[i * 256], 16, voff, 0, 0, 0);
@@ -756,20 +768,23 @@ __global__ __launch_bounds__(512, 1) void igemm_c32t_kernel(const IgemmParams p,
     const int bsw = l31 & 7;
     // this wave's 32 pixels of a tile: tile row wave >> 1, columns 32 * (wave & 1) + l31; halo index of the pixel itself:
     const int hp0 = ((wave >> 1) + 1) * C32T_HW + (wave & 1) * 32 + l31 + 1;
+    if (!DB && stagger > 0 && (int)blockIdx.x >= ((int)gridDim.x >> 1)) {
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);      // 64 clocks each
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     MTD_STAMP(2);
     int cur = 0;
     while (true) {
         const int next = tile + gridDim.x;
-        if (next < ntiles) stage_tile(next, cur ^ 1);      // every wave is past its MFMAs on that buffer (barrier below)
-        const int mbase = tile * (C32T_R * C32T_W) + wave * 32;
+        if (DB && next < ntiles) stage_tile(next, cur ^ 1);      // every wave is past its MFMAs on that buffer (barrier below)
+        const int mbase = tile * (R * C32T_W) + wave * 32;
         EpiAddr<true, 0, 16> ead;
         EpiOps<16> eo;
         ead.init(p, mbase, lane, n);
         epi_load(p, ead, eo);
         __builtin_amdgcn_sched_barrier(0);
-        const float* H = Hs[cur];
+        const float* H = Hs[DB ? cur : 0];
         auto frag = [&](int t, f32x4* af, f32x4* bf) {
             const int hp = hp0 + (g.off_y + p.tap_dy[t]) * C32T_HW + (g.off_x + p.tap_dx[t]);
             const float* px = &H[hp * 32];
@@ -793,14 +808,25 @@ __global__ __launch_bounds__(512, 1) void igemm_c32t_kernel(const IgemmParams p,
             for (int kk = 0; kk < 16; ++kk) acc = mfma32(af[t & 1][kk >> 2][kk & 3], bf[t & 1][kk >> 2][kk & 3], acc);
         }
         MTD_STAMP(3 + 3 * (cur));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile and this tile's epilogue operands have landed
-        MTD_STAMP(4 + 3 * (cur));
-        epi_store(p, acc, ead, sp, bias_n, eo);                // stores drain under the next tile's MFMAs
-        MTD_STAMP(5 + 3 * (cur));
-        if (next >= ntiles) break;
-        __syncthreads();
-        tile = next;
-        cur ^= 1;
+        if (DB) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile and this tile's epilogue operands have landed
+            MTD_STAMP(4 + 3 * (cur));
+            epi_store(p, acc, ead, sp, bias_n, eo);                // stores drain under the next tile's MFMAs
+            MTD_STAMP(5 + 3 * (cur));
+            if (next >= ntiles) break;
+            __syncthreads();
+            tile = next;
+            cur ^= 1;
+        } else {
+            __syncthreads();                                       // every wave is done reading the halo tile
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this tile's epilogue operands have landed
+            if (next < ntiles) stage_tile(next, 0);                // the next tile's DMA in flight under the stores ...
+            epi_store(p, acc, ead, sp, bias_n, eo);                // ... and under the other workgroup's MFMAs
+            if (next >= ntiles) break;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            tile = next;
+        }
     }
 }
 
@@ -1150,6 +1176,8 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
     p.out_linear = p.out_identity || (g.OW % 32 == 0);
     static const int env_xcd = [] { const char* e = getenv("MTD_IGEMM_XCD"); return e ? atoi(e) : 1; }();
     p.xcd_map = env_xcd;
+    static const int env_nt = [] { const char* e = getenv("MTD_IGEMM_NT"); return e ? atoi(e) : 0; }();
+    p.nt_store = env_nt;
     if (pl.splitk > 1) {
         size_t need = (size_t)pl.splitk * (size_t)p.M * a->N * sizeof(float);
         if (!a->ws || a->ws_bytes < need) return MTD_EWS;
@@ -1159,8 +1187,15 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
     if ((g_force_cfg == -1 || g_force_cfg == 10) && gen_shape && c32t_eligible(*a)) {
         // generator-shaped layers on 64-pixel rows: halo tiles of four image rows, one persistent workgroup per CU
         const int prof = mtd_prof_begin(0, 10, 1, p.M, a->N, a->C, 9, s);
-        const int ntiles = p.M / (C32T_R * C32T_W);
-        hipLaunchKernelGGL(igemm_c32t_kernel, dim3(ntiles < 256 ? ntiles : 256, a->N / 32), dim3(512), 0, s, p, ntiles);
+        static const int env_variant = [] { const char* e = getenv("MTD_C32T_VARIANT"); return e ? atoi(e) : 0; }();
+        static const int env_stagger = [] { const char* e = getenv("MTD_C32T_STAGGER"); return e ? atoi(e) : 0; }();
+        if (env_variant == 1) {
+            const int ntiles = p.M / (2 * C32T_W);
+            hipLaunchKernelGGL((igemm_c32t_kernel<2, false>), dim3(ntiles < 512 ? ntiles : 512, a->N / 32), dim3(256), 0, s, p, ntiles, env_stagger);
+        } else {
+            const int ntiles = p.M / (C32T_R * C32T_W);
+            hipLaunchKernelGGL((igemm_c32t_kernel<C32T_R, true>), dim3(ntiles < 256 ? ntiles : 256, a->N / 32), dim3(512), 0, s, p, ntiles, 0);
+        }
         mtd_prof_end(prof, s);
         MTD_LAUNCH_CHECK();
         return MTD_OK;
