@@ -9,7 +9,7 @@ import __graft_entry__  # noqa: F401
 from mtd_gan_amd import bench_workloads as BW, kernels as K
 
 dev = torch.device("cuda", 0)
-wl = BW.make(os.environ.get("WL", "full_step"), dev, 0, 1, 32)
+wl = BW.make(os.environ.get("WL", "full_step"), dev, 0, 1, int(os.environ.get("BATCH", "32")))
 for _ in range(3):
     wl.step()
 K.set_concurrency(False)
