@@ -126,6 +126,11 @@ typedef struct {
     int pad_;
 } mtd_wgrad_reduce_desc;
 int mtd_conv_wgrad_slabs(const mtd_wgrad_args* a, int* nslab, long long* slab_stride, void* stream);
+/* mtd_conv_wgrad_slabs plus mtd_rfft_rows(x, x_ld, R, B, col_weight) -- in one launch when the layer runs on the row-window
+ * kernel (3x3, stride 1, one 32 x 32 tile: the generator's blocks, whose weight gradient and spectral backward chain start from
+ * the same cotangent), otherwise as two launches. */
+int mtd_conv_wgrad_slabs_rfft(const mtd_wgrad_args* a, int* nslab, long long* slab_stride, const float* x, int x_ld, float* R,
+                              int B, int col_weight, void* stream);
 int mtd_conv_wgrad_reduce_blocks(const mtd_wgrad_reduce_desc* d);
 int mtd_conv_wgrad_reduce_multi(const mtd_wgrad_reduce_desc* table_dev, const mtd_wgrad_reduce_desc* table_host, int count, void* stream);
 

@@ -22,7 +22,7 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "mtdgan_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "fft64.h"), os.path.join(os.path.dirname(HERE), "include", "mtdgan_hip.h")]
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     objs = []
     procs = []

@@ -158,6 +158,7 @@ def lib():
     sig("mtd_conv_wgrad_ws_bytes", sz, C.POINTER(WgradArgs))
     sig("mtd_conv_wgrad", ci, C.POINTER(WgradArgs), vp)
     sig("mtd_conv_wgrad_slabs", ci, C.POINTER(WgradArgs), C.POINTER(C.c_int), C.POINTER(C.c_longlong), vp)
+    sig("mtd_conv_wgrad_slabs_rfft", ci, C.POINTER(WgradArgs), C.POINTER(C.c_int), C.POINTER(C.c_longlong), vp, ci, vp, ci, ci, vp)
     sig("mtd_conv_wgrad_reduce_blocks", ci, C.POINTER(WgradReduceDesc))
     sig("mtd_conv_wgrad_reduce_multi", ci, vp, vp, ci, vp)
     sig("mtd_spec_mix_wgrad_reduce_multi", ci, vp, vp, ci, vp)
@@ -218,7 +219,7 @@ EXPORTS = [
     "mtd_pcgrad_gram", "mtd_pcgrad_combine", "mtd_adamw_multi", "mtd_adamw_multi_dyn", "mtd_adamw_multi_pre", "mtd_loss_terms_ws_bytes", "mtd_loss_terms",
     "mtd_loss_term_grads", "mtd_clip01", "mtd_clip01_bwd", "mtd_edge_loss_ws_bytes", "mtd_edge_loss",
     "mtd_prof_enable", "mtd_prof_collect", "mtd_conv_igemm_override", "mtd_conv_wgrad_override", "mtd_upload", "mtd_image_metrics_ws_bytes", "mtd_image_metrics", "mtd_rfft_rows_any", "mtd_spec_mix_any", "mtd_irfft_rows_any",
-    "mtd_conv_wgrad_slabs", "mtd_conv_wgrad_reduce_blocks", "mtd_conv_wgrad_reduce_multi", "mtd_spec_mix_wgrad_reduce_multi",
+    "mtd_conv_wgrad_slabs", "mtd_conv_wgrad_slabs_rfft", "mtd_conv_wgrad_reduce_blocks", "mtd_conv_wgrad_reduce_multi", "mtd_spec_mix_wgrad_reduce_multi",
     "mtd_foreground_bbox", "mtd_window_patches", "mtd_hu_window", "mtd_add", "mtd_transpose64_multi", "mtd_upsample2x_bwd_masked",
 ]
 

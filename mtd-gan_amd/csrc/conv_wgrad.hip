@@ -13,6 +13,7 @@
 //
 // Roofline: fp32 MFMA.  Algorithmic flops = 2*M*N*C*taps.
 #include "common.h"
+#include "fft64.h"
 
 namespace {
 
@@ -232,13 +233,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 // parameter-gradient view (no reduce kernels at all).
 template <int T, int NW>
 __device__ __forceinline__ void reg_kernel_epilogue(const WgradParams& p, f32x16 (&acc)[T], float bsum, float* Ls, int n0, int c0,
-                                                    bool do_bias) {
+                                                    bool do_bias, int bx) {
     const mtd_wgrad_args& a = p.a;
     const mtd_geom& g = a.g;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31;
     const bool direct = (p.nslab == 1);
     constexpr int EPW = 16 / NW;        // values per lane that each wave finishes (sum over waves 0, 1, ... in that order)
-    float* slab = a.ws + (long long)blockIdx.x * p.slab_stride;
+    float* slab = a.ws + (long long)bx * p.slab_stride;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         __syncthreads();
@@ -296,16 +297,15 @@ __device__ __forceinline__ void reg_kernel_epilogue(const WgradParams& p, f32x16
 // serves TW taps (54 instead of 144 Q loads per chunk for 3x3).  The next window row (or the next chunk's P and
 // first row) is in flight under the current row's 16 * TW MFMAs.
 template <int TH, int TW, int DX, int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 4) ? 2 : 1) void wgrad_row_kernel(const WgradParams p) {
+__device__ __forceinline__ void wgrad_row_body(const WgradParams& p, const int bx, const int by, float* Ls) {
     constexpr int T = TH * TW, WIN = 16 + TW - 1;
-    __shared__ __attribute__((aligned(16))) float Ls[NW * 1024 + NW * 64];
     const mtd_wgrad_args& a = p.a;
     const mtd_geom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
-    const int ntile = blockIdx.y / p.nCt, ctile = blockIdx.y % p.nCt;
+    const int ntile = by / p.nCt, ctile = by % p.nCt;
     const int n0 = ntile * 32, c0 = ctile * 32;
-    const int mwave0 = (blockIdx.x * NW + wave) * p.ppw;
+    const int mwave0 = (bx * NW + wave) * p.ppw;
     const bool do_bias = (a.db != nullptr) && ctile == 0;
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p), (short)0, (int)p.p_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.q), (short)0, (int)p.q_bytes, 0x00020000);
@@ -399,7 +399,30 @@ __global__ __launch_bounds__(NW * 64, (NW == 4) ? 2 : 1) void wgrad_row_kernel(c
         }
     }
 
-    reg_kernel_epilogue<T, NW>(p, acc, bsum, Ls, n0, c0, do_bias);
+    reg_kernel_epilogue<T, NW>(p, acc, bsum, Ls, n0, c0, do_bias, bx);
+}
+
+template <int TH, int TW, int DX, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 4) ? 2 : 1) void wgrad_row_kernel(const WgradParams p) {
+    __shared__ __attribute__((aligned(16))) float Ls[NW * 1024 + NW * 64];
+    wgrad_row_body<TH, TW, DX, NW>(p, blockIdx.x, blockIdx.y, Ls);
+}
+
+// The row-window weight gradient of a generator block and the row transform of the same cotangent (the first kernel of the
+// block's spectral backward chain) in ONE launch: workgroups 0 .. nwg-1 are the weight gradient's (MFMA-bound, one wave per
+// SIMD), the rest take the 512 row-pair waves of mtd_rfft_rows four at a time (HBM-bound) -- 21 launches and their ramps
+// less per generator backward pass, and the transform runs in the issue slots the MFMA waves leave.
+struct RowsArgs { const float* x; int x_ld; float* R; int npairs; int col_weight; };
+template <int DX>
+__global__ __launch_bounds__(256, 2) void wgrad_row_rfft_kernel(const WgradParams p, const int nwg, const RowsArgs r) {
+    __shared__ __attribute__((aligned(16))) float Ls[4 * 1024 + 4 * 64];
+    if ((int)blockIdx.x < nwg) {
+        wgrad_row_body<3, 3, DX, 4>(p, blockIdx.x, 0, Ls);
+    } else {
+        const int vb = ((int)blockIdx.x - nwg) * 4 + (threadIdx.x >> 6);      // block index of the stand-alone rows kernel
+        const int lane = threadIdx.x & 63;
+        rfft_rows_body(r.x, r.x_ld, r.R, r.npairs, r.col_weight, vb * 2 + (lane >> 5), lane & 31);
+    }
 }
 
 
@@ -511,7 +534,7 @@ __global__ __launch_bounds__(NW * 64, (W == 8 || NW == 8) ? 1 : 2) void wgrad_bl
             for (int j = 0; j < NQ; ++j) qf[j] = qn[j];
         }
     }
-    reg_kernel_epilogue<T, NW>(p, acc, bsum, Ls, n0, c0, do_bias);
+    reg_kernel_epilogue<T, NW>(p, acc, bsum, Ls, n0, c0, do_bias, blockIdx.x);
 }
 
 // out[g][idx] = sum_{s in group g} in[s][idx]     (group size gs), fixed order
@@ -827,7 +850,10 @@ extern "C" size_t mtd_conv_wgrad_ws_bytes(const mtd_wgrad_args* a) {
 }
 
 // the slab-producing kernel of one layer; fills p, nsplit, direct
-static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, int& nsplit, bool& direct_out) {
+// (rows != nullptr: also run the forward row transform `rows` describes, inside the same launch if the plan is the row-window
+// kernel on one (n, c) tile -- *rows_done says whether it was)
+static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, int& nsplit, bool& direct_out,
+                         const RowsArgs* rows = nullptr, bool* rows_done = nullptr) {
     if (!a) return MTD_EINVAL;
     static const int env_nw = [] { const char* e = getenv("MTD_WGRAD_NW"); return e ? atoi(e) : 0; }();
     if (env_nw == 4 || env_nw == 8) g_wforce_nw = env_nw;
@@ -878,10 +904,18 @@ static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, 
             case 3: hipLaunchKernelGGL((wgrad_kernel<1, 1, 8>), grid, dim3(256), 0, s, p); break;
             case 4: hipLaunchKernelGGL((wgrad_kernel<1, 1, 3>), grid, dim3(256), 0, s, p); break;
             case 7: if (pl.nw == 8) hipLaunchKernelGGL((wgrad_row_kernel<3, 3, 1, 8>), grid, dim3(512), 0, s, p);
-                    else hipLaunchKernelGGL((wgrad_row_kernel<3, 3, 1, 4>), grid, dim3(256), 0, s, p);
+                    else if (rows && grid.y == 1 && grid.z == 1) {
+                        const dim3 fg(grid.x + (unsigned)((rows->npairs + 7) / 8));
+                        hipLaunchKernelGGL((wgrad_row_rfft_kernel<1>), fg, dim3(256), 0, s, p, (int)grid.x, *rows);
+                        *rows_done = true;
+                    } else hipLaunchKernelGGL((wgrad_row_kernel<3, 3, 1, 4>), grid, dim3(256), 0, s, p);
                     break;
             case 8: if (pl.nw == 8) hipLaunchKernelGGL((wgrad_row_kernel<3, 3, -1, 8>), grid, dim3(512), 0, s, p);
-                    else hipLaunchKernelGGL((wgrad_row_kernel<3, 3, -1, 4>), grid, dim3(256), 0, s, p);
+                    else if (rows && grid.y == 1 && grid.z == 1) {
+                        const dim3 fg(grid.x + (unsigned)((rows->npairs + 7) / 8));
+                        hipLaunchKernelGGL((wgrad_row_rfft_kernel<-1>), fg, dim3(256), 0, s, p, (int)grid.x, *rows);
+                        *rows_done = true;
+                    } else hipLaunchKernelGGL((wgrad_row_kernel<3, 3, -1, 4>), grid, dim3(256), 0, s, p);
                     break;
             case 9: if (pl.nw == 8) hipLaunchKernelGGL((wgrad_row_kernel<1, 1, 1, 8>), grid, dim3(512), 0, s, p);
                     else hipLaunchKernelGGL((wgrad_row_kernel<1, 1, 1, 4>), grid, dim3(256), 0, s, p);
@@ -912,6 +946,22 @@ extern "C" int mtd_conv_wgrad_slabs(const mtd_wgrad_args* a, int* nslab, long lo
     if (rc != MTD_OK) return rc;
     *nslab = nsplit == 1 ? 0 : nsplit;              // single split: the kernel wrote dw / db itself
     *slab_stride = p.slab_stride;
+    return MTD_OK;
+}
+
+extern "C" int mtd_conv_wgrad_slabs_rfft(const mtd_wgrad_args* a, int* nslab, long long* slab_stride, const float* x, int x_ld, float* R,
+                                         int B, int col_weight, void* stream) {
+    if (!a || !nslab || !slab_stride || !x || !R || B <= 0 || x_ld < 32) return MTD_EINVAL;
+    if (is_direct(*a)) return MTD_EINVAL;
+    WgradParams p;
+    int nsplit = 0;
+    bool direct = false, rows_done = false;
+    const RowsArgs rows{x, x_ld, R, B * 32, col_weight};
+    int rc = wgrad_partial(a, stream, p, nsplit, direct, &rows, &rows_done);
+    if (rc != MTD_OK) return rc;
+    *nslab = nsplit == 1 ? 0 : nsplit;
+    *slab_stride = p.slab_stride;
+    if (!rows_done) return mtd_rfft_rows(x, x_ld, R, B, col_weight, stream);       // another plan: two launches
     return MTD_OK;
 }
 

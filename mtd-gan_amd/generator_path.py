@@ -52,15 +52,24 @@ def block_backward(g, saved, w_img, w_fft, grads, premask, defer=None, gm=None):
     side = K.side_stream(x.device)
     if gm is None:
         gm = K.act_grad(g, img, 0.0)                                                # g * (img > 0)
-    side.run(lambda: K.wgrad(gm, x, K.geom_fwd(B, H, W, 3, 1, 1), CH, CH, grads["dw_img"], CH * 9, 9, db=grads["db_img"], defer=defer), gm, g)
+    # the block conv's weight gradient and the row transform that opens the spectral backward chain read the same
+    # cotangent: one launch when the slab sums are deferred (kernels.wgrad rows=...), at the head of the spectral stream
+    fused_rows = defer is not None and K.DEFER_WGRADS and K.FUSE_WGRAD_ROWS
+    if not fused_rows:
+        side.run(lambda: K.wgrad(gm, x, K.geom_fwd(B, H, W, 3, 1, 1), CH, CH, grads["dw_img"], CH * 9, 9, db=grads["db_img"],
+                                 defer=defer), gm, g)
     # spectral branch backward on a second side stream, beside the spatial data gradient on the main stream
     side1 = K.side_stream(x.device, 1)
     box = []
 
     def spectral():
-        gR = K.rfft_rows(g, 1)                                                      # irfft2 backward
+        if fused_rows:
+            gR = K.wgrad(gm, x, K.geom_fwd(B, H, W, 3, 1, 1), CH, CH, grads["dw_img"], CH * 9, 9, db=grads["db_img"], defer=defer,
+                         rows=(g, 1))
+        else:
+            gR = K.rfft_rows(g, 1)                                                  # irfft2 backward
         box.append(K.spec_mix_bwd(gR, w_fft, S, Z, grads["dw_fft"], grads["db_fft"], defer=defer))
-    side1.run(spectral, g)
+    side1.run(spectral, g, gm)
     d1 = K.empty_nhwc(B, H, W, CH, x)
     K.conv(gm, w_img, K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, d1, add1=g)  # dgrad(img branch) + residual
     gx = K.empty_nhwc(B, H, W, CH, x)

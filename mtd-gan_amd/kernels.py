@@ -299,7 +299,18 @@ def flush_wgrads(defer):
     defer.conv, defer.mix, defer.bufs, defer.slot = [], [], [], 0
 
 
-def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumulate_bias=None, defer=None):
+# Lab switch, off: the block conv's weight-gradient launch carries the row transform of the same cotangent (workgroups of
+# both kinds in one grid, mtd_conv_wgrad_slabs_rfft).  Correct (bit-identical, tested) but slower: the fused launch takes
+# 54 us against 29.3 + 8.7 us for the two -- the row-transform waves share SIMDs with the MFMA waves on half of the CUs.
+FUSE_WGRAD_ROWS = os.environ.get("MTD_FUSED_WGRAD_ROWS", "0") == "1"
+
+
+def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumulate_bias=None, defer=None, rows=None):
+    """rows = (x, col_weight): also return rfft_rows(x, col_weight) -- carried by the weight-gradient launch itself when
+    the slab sums are deferred (mtd_conv_wgrad_slabs_rfft), a launch of its own otherwise."""
+    if rows is not None and not (defer is not None and DEFER_WGRADS and FUSE_WGRAD_ROWS and N % 32 == 0 and Cc % 32 == 0):
+        wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=db, accumulate=accumulate, accumulate_bias=accumulate_bias, defer=defer)
+        return rfft_rows(rows[0], rows[1])
     L = _lib.lib()
     a = WgradArgs()
     a.g = geom
@@ -318,14 +329,21 @@ def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumula
         ws = _layer_ws(need, defer, p.device)
         a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
         nslab, stride = C.c_int(0), C.c_longlong(0)
-        check(L.mtd_conv_wgrad_slabs(C.byref(a), C.byref(nslab), C.byref(stride), stream_ptr()), "mtd_conv_wgrad_slabs")
+        R = None
+        if rows is not None:
+            xr = rows[0]
+            R = torch.empty((xr.shape[0], 33, 64, 64), dtype=torch.float32, device=xr.device)
+            check(L.mtd_conv_wgrad_slabs_rfft(C.byref(a), C.byref(nslab), C.byref(stride), xr.data_ptr(), ld_of(xr), R.data_ptr(),
+                                              xr.shape[0], int(rows[1]), stream_ptr()), "mtd_conv_wgrad_slabs_rfft")
+        else:
+            check(L.mtd_conv_wgrad_slabs(C.byref(a), C.byref(nslab), C.byref(stride), stream_ptr()), "mtd_conv_wgrad_slabs")
         if nslab.value > 0:
             d = _lib.WgradReduceDesc()
             d.a, d.T, d.nslab, d.slab_stride = a, geom.TH * geom.TW, nslab.value, stride.value
             d.a.p, d.a.q = None, None          # not read by the reduce; keeps the table's bytes (its cache key) the same from step to step
             defer.conv.append(d)
             defer.bufs.append(ws)
-        return
+        return R
     ws = workspace(need, p.device)
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     if CALL_LOG is not None:

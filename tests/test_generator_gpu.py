@@ -188,17 +188,21 @@ def test_deferred_weight_gradient_sums_equal_immediate(hip_lib):
     x, _ = orc.synthetic_ldct(32, seed=77)
     xd = x.cuda()
     got = {}
-    for mode in ((True, True), (False, True), (True, False)):
-        K.DEFER_WGRADS, K.FUSE_ACT_GRAD = mode
+    rows_default = K.FUSE_WGRAD_ROWS
+    for mode in ((True, True), (False, True), (True, False), (True, True, True)):
+        K.DEFER_WGRADS, K.FUSE_ACT_GRAD = mode[:2]
+        K.FUSE_WGRAD_ROWS = len(mode) == 3
         try:
             G.zero_grad()
             G(xd).sum().backward()
             torch.cuda.synchronize()
             got[mode] = {n: p.grad.clone() for n, p in G.named_parameters()}
         finally:
-            K.DEFER_WGRADS, K.FUSE_ACT_GRAD = True, True
+            K.DEFER_WGRADS, K.FUSE_ACT_GRAD, K.FUSE_WGRAD_ROWS = True, True, rows_default
     # (second switch: the data-gradient launches of the halo-tile kernel also write the next block's activation-masked
     # cotangent, conv(out2=...), instead of a separate act_grad pass -- the same values)
     for n in got[(True, True)]:
         assert torch.equal(got[(True, True)][n], got[(False, True)][n]), n
         assert torch.equal(got[(True, True)][n], got[(True, False)][n]), n
+        # (third switch, a lab variant: the block conv's weight-gradient launch carries the row transform of the same cotangent)
+        assert torch.equal(got[(True, True)][n], got[(True, True, True)][n]), n
