@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- MTD-GAN hot-path throughput on MI355X (contract: see the task statement / DESIGN.md).
+"""bench.py -- MTD-GAN hot-path throughput on MI355X (contract: see the task statement / DESIGN.md section 5).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload full_step|generator|inference512|patch_sampler]
 
-One process per GPU (launched by torch.distributed.run for N > 1, backend nccl == RCCL).  A "step" is
-one pass of the hot path over one batch of synthetic LDCT-shaped 64x64 patches (32 per GPU, weak
-scaling).  Prints ONE JSON line on rank 0.  `value` = patches/s over all ranks, inputs resident in HBM.
-Extra objects: `roofline` for the dominant kernel -- the fp32-MFMA implicit-GEMM instantiation with the
-largest share of the step's GPU time -- timed by the library's own launch profiler (HIP events recorded
-on the launch stream directly around that kernel, include/mtdgan_hip.h mtd_prof_*) in a second pass of
-the same K steps with every kernel in one stream, so the events do not perturb `value` and a launch's duration is
-the kernel's own rather than its share of a chip it runs on beside other streams' kernels; and `cpu_baseline` (the CPU oracle, kind "port",
-timed on rank 0 at N == 1 on a bounded sample).
+One process per GPU, backend nccl == RCCL.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment
+starts the N ranks itself (fresh child processes; the parent never touches the GPU); under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one of the ranks.  A "step" is one pass of
+the hot path over one batch of synthetic LDCT-shaped 64x64 patches (32 per GPU, weak scaling).  Prints ONE JSON line
+on rank 0.  `value` = patches/s over all ranks, inputs resident in HBM.  Extra objects:
+  roofline      the dominant kernel -- the fp32-MFMA implicit-GEMM instantiation with the largest share of the step's
+                GPU time -- timed by the library's launch profiler (include/mtdgan_hip.h mtd_prof_*: two HIP events that
+                ride on the kernel's own dispatch packet, i.e. the dispatch's begin / end timestamps, the duration a
+                rocprofv3 kernel trace reports) in a second pass of the same K steps with every kernel in one stream;
+  generator_fwd_bwd   BASELINE configs[1] (generator-only forward + backward, the north_star's 40 % target) timed in the
+                same process after the main workload, with its own dominant-kernel figures;
+  cpu_baseline  the CPU oracle (kind "port"), timed on rank 0 at N == 1 on a bounded sample.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,7 +32,7 @@ PER_GPU_BATCH = 32
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA peak (dense)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -34,9 +40,54 @@ def parse():
     ap.add_argument("--workload", default=os.environ.get("MTD_BENCH_WORKLOAD", "auto"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-generator", action="store_true", help="skip the configs[1] generator object of the default workload")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / collective plumbing only: gloo on the CPU, a trivial step (no GPU, no HIP library)")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # launcher test: this rank exits with 3
+    return ap.parse_args(argv)
 
 
+# ====================================================================================================== launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """Start --gpus fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment),
+    wait for all of them and return the first non-zero exit code.  Runs before anything in this process has touched the
+    GPU; nothing is exec'ed over a running process.  Rank 0's stdout (the JSON line) is this process's stdout."""
+    n = args.gpus
+    env0 = dict(os.environ)
+    env0.setdefault("MASTER_ADDR", "127.0.0.1")
+    env0["MASTER_PORT"] = env0.get("MASTER_PORT") or str(_free_port())
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:             # a rank died: the others would wait in a collective forever
+                    q.terminate()
+        if pending:
+            time.sleep(0.05)
+    return rc
+
+
+# ====================================================================================================== CPU baseline
 def cpu_baseline(wl):
     """The CPU oracle (oracle/mtdgan_oracle.py, kind "port": a restatement pinned bit-exact to the reference
     in the build container) timed on this box's host cores on a bounded sample of the same workload."""
@@ -48,7 +99,7 @@ def cpu_baseline(wl):
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     if wl.name == "generator_fwd_bwd":
-        nb, iters = 8, 2
+        nb, iters = 32, 2
         x, y = orc.synthetic_ldct(nb, seed=1234)
         gs = {k: v.clone().requires_grad_(True) for k, v in orc.seeded_fill(orc.g_param_shapes(), seed=7).items()}
         def run():
@@ -84,74 +135,221 @@ def cpu_baseline(wl):
         dt = time.perf_counter() - t0
         return {"value": round(1.0 / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
                 "sample": f"oracle generator forward + pixel metrics on one 512x512 slice, torch CPU {torch.__version__}, {cores} threads"}
-    # full training iteration: oracle.train_step (engine.py:33-55 restated) on a small batch
-    nb, iters = 4, 2
+    # full training iteration: oracle.train_step (engine.py:33-55 restated) on the workload's own batch of 32 patches,
+    # ONE iteration with no warm-up (about 20-30 s of CPU work)
+    nb, iters = PER_GPU_BATCH, 1
     x, y = orc.synthetic_ldct(nb, seed=1234)
     state = {"Generator." + k: v for k, v in orc.seeded_fill(orc.g_param_shapes(), seed=7).items()}
     state.update({"Discriminator." + k: v for k, v in orc.seeded_fill(orc.d_state_shapes(), seed=8).items()})
     g = torch.Generator().manual_seed(3)
     masks = [(torch.rand(nb, 512, generator=g) >= 0.3).float() / 0.7 for _ in range(5)]
     opt = {}
-    orders = [[1, 2], [0, 2], [0, 1]]
-    orc.train_step(state, opt, x, y, masks, orders)
+    orders = [[1, 2, 0], [0, 2, 1], [2, 0, 1]]
     t0 = time.perf_counter()
     for _ in range(iters):
         orc.train_step(state, opt, x, y, masks, orders)
     dt = time.perf_counter() - t0
     return {"value": round(nb * iters / dt, 3), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": f"oracle full G+D+PCGrad+AdamW step, {iters} x {nb} patches (1 warm-up), torch CPU {torch.__version__}, {cores} threads"}
+            "sample": f"oracle full G+D+PCGrad+AdamW step, {iters} x {nb} patches (the workload's batch, no warm-up), torch CPU {torch.__version__}, {cores} threads"}
 
 
-def pmc_traffic(kernel, tag=""):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summaries (profiles/r1_pmc_*.csv: one pass
-    with FETCH_SIZE, one with WRITE_SIZE, values in KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
-    bench.py cannot collect PMC counters itself; returns None when the summaries are absent."""
+# ====================================================================================================== PMC provenance
+def _kernel_source_hash():
+    """sha256 over the kernel sources: a committed PMC summary describes the kernels of ONE source state."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mtd-gan_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _kernel_base(name, keep_template):
+    """'void (anonymous namespace)::igemm_kernel<1, 1, 4, 1>((anonymous namespace)::IgemmParams)' -> 'igemm_kernel<1, 1, 4, 1>'
+    (without the template arguments when the name looked for carries none)."""
+    n = name.strip().replace("(anonymous namespace)::", "")
+    if n.startswith("void "):
+        n = n[5:]
+    depth, end = 0, len(n)
+    for i, ch in enumerate(n):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            end = i
+            break
+    n = n[:end].strip()
+    return n if keep_template else n.split("<")[0]
+
+
+def pmc_summary(kernel, tag):
+    """HBM-side bytes per launch and MFMA-pipe utilisation of `kernel` from the committed rocprofv3 PMC summaries
+    (separate passes: FETCH_SIZE, WRITE_SIZE in KiB with FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950;
+    SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES), tools/pmc_mfma_util.py).  bench.py cannot collect PMC counters
+    itself, so the figures carry their provenance (profiles/pmc_manifest.json: files, commit, kernel-source hash) and
+    are emitted ONLY when the kernel sources are the ones the passes were taken on; otherwise null + the reason."""
     import csv
-    tot = 0.0
-    for fn, mult in ((f"r1_pmc_{tag}fetch_size.csv", 2.0), (f"r1_pmc_{tag}write_size.csv", 1.0)):
+    mpath = os.path.join(ROOT, "profiles", "pmc_manifest.json")
+    if not os.path.exists(mpath):
+        return None, None, {"pmc": "no profiles/pmc_manifest.json"}
+    man = json.load(open(mpath)).get(tag)
+    if man is None:
+        return None, None, {"pmc": f"no PMC passes recorded for workload '{tag}'"}
+    prov = {"files": man["files"], "commit": man.get("commit"), "source_hash": man.get("source_hash")}
+    if man.get("source_hash") != _kernel_source_hash():
+        prov["stale"] = "kernel sources changed since the PMC passes were taken"
+        return None, None, prov
+
+    def lookup(fn, col):
         path = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(path):
             return None
-        hit = None
         for row in csv.DictReader(open(path)):
-            if kernel in row["Kernel_Name"]:
-                hit = float(row["AvgPerDispatch"]) * 1024.0 * mult
-                break
-        if hit is None:
-            return None
-        tot += hit
-    return round(tot)
-
-
-def pmc_mfma_util(kernel, tag=""):
-    """MFMA-pipe utilisation of `kernel` from the committed PMC pass (profiles/r1_pmc_mfma_util.csv: SQ_VALU_MFMA_BUSY_CYCLES /
-    (32 x SQ_BUSY_CYCLES), calibrated at 1.000 on a register-only MFMA loop, tools/pmc_mfma_util.py); None when absent."""
-    import csv
-    path = os.path.join(ROOT, "profiles", f"r1_pmc_{tag}mfma_util.csv")
-    if not os.path.exists(path):
+            if _kernel_base(row["Kernel_Name"], "<" in kernel) == kernel:          # exact name, not a substring hit
+                return float(row[col])
         return None
-    for row in csv.DictReader(open(path)):
-        if kernel in row["Kernel_Name"]:
-            return float(row["MfmaUtil"])
-    return None
+    f, w, u = lookup(man["files"]["fetch"], "AvgPerDispatch"), lookup(man["files"]["write"], "AvgPerDispatch"), lookup(man["files"]["mfma"], "MfmaUtil")
+    traffic = round(2.0 * f * 1024.0 + w * 1024.0) if (f is not None and w is not None) else None
+    return traffic, u, prov
 
 
-def main():
-    args = parse()
+# ====================================================================================================== roofline pass
+def roofline_pass(wl, steps, pmc_tag):
+    """Second pass of the same K steps, every kernel in one stream, the library's launch profiler on."""
+    import torch
+    from mtd_gan_amd import kernels as K
+    cap = 8192 * max(1, steps)
+    step = getattr(wl, "step_eager", wl.step)          # events cannot ride on launches inside a graph replay
+    # One stream: beside the side streams and task chains of the timed region a kernel shares the chip with others, and
+    # its duration then says nothing about the kernel.  (profiles/*_kernel_stats_single_stream.csv: rocprofv3, same mode.)
+    K.set_concurrency(False)
+    step()
+    attach = K.prof_mode(-1)
+    K.prof_enable(cap)
+    K.FLOP_COUNT = {}
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    counted, K.FLOP_COUNT = K.FLOP_COUNT, None
+    recs = K.prof_collect(cap)
+    K.prof_enable(0)
+    K.set_concurrency(True)
+    by = {}
+    for r in recs:
+        if r["kernel"].startswith("igemm"):
+            d = by.setdefault(r["kernel"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0, "shapes": {}})
+            d["ms"] += r["ms"]
+            d["flops"] += r["flops"]
+            d["bytes"] += r["bytes"]
+            d["n"] += 1
+            key = f"M{r['M']}_N{r['N']}_C{r['C']}_T{r['taps']}_S{r['splitk']}"
+            sh = d["shapes"].setdefault(key, [0.0, 0.0, 0])
+            sh[0] += r["ms"]; sh[1] += r["flops"]; sh[2] += 1
+    units = getattr(wl, "batch", None) or getattr(wl, "slices", PER_GPU_BATCH)
+    executed = {k: round(v / steps / 1e9 / units, 4) for k, v in counted.items() if k != "launches"}
+    executed_total = round(sum(executed.values()), 3)
+    extra = {"executed_gflop_per_patch": executed_total, "executed_gflop_per_patch_by_kind": executed,
+             "counted_launches_per_step": counted.get("launches", 0) // steps}
+    if not by:
+        return None, extra
+    name, d = max(by.items(), key=lambda kv: kv[1]["ms"])
+    ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    top = sorted(d["shapes"].items(), key=lambda kv: -kv[1][0])[:4]
+    traffic, util, prov = pmc_summary(name, pmc_tag) if pmc_tag is not None else (None, None, None)
+    roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": traffic, "algorithmic_bytes_per_launch": round(d["bytes"] / d["n"]),
+                "mfma_util_pmc": util, "pmc_provenance": prov,
+                "launches_timed": d["n"], "avg_launch_us": round(1e3 * d["ms"] / d["n"], 2),
+                "timing": ("HIP events on the kernel's dispatch packet (begin / end timestamps of the dispatch: no bracketing overhead, "
+                           "nothing subtracted)" if attach == 1 else "HIP events recorded before / after the launch (includes the marker packets; nothing subtracted)"),
+                "flops_per_launch": round(d["flops"] / d["n"]), "measured": "second pass of the same steps, all kernels in one stream",
+                "share_of_step_gpu_ms": round(d["ms"] / steps, 3),
+                "top_shapes": {k: {"us": round(1e3 * v[0] / v[2], 2), "tflops": round(v[1] / v[0] / 1e9, 2), "launches_per_step": v[2] // steps}
+                               for k, v in top},
+                "other_igemm": {k: {"tflops": round(v["flops"] / v["ms"] / 1e9, 2), "ms_per_step": round(v["ms"] / steps, 3)}
+                                for k, v in by.items() if k != name}}
+    return roofline, extra
+
+
+def timed(wl, steps, warmup, barrier):
+    for _ in range(warmup):
+        wl.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    barrier()
+    return time.perf_counter() - t0
+
+
+# ====================================================================================================== dry run
+def dry_run(args, rank, world):
+    """Launcher / rendezvous / max-over-ranks plumbing on the CPU (gloo): what tests/test_bench_launcher.py drives."""
     import torch
     import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if rank == args.dry_run_fail_rank:
+        return 3
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = dist.get_world_size() if world > 1 else 1
+    v = torch.ones(1024)
+
+    def step():
+        w = v * 2.0
+        if world > 1:
+            dist.all_reduce(w)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (launcher plumbing, gloo on the CPU)", "value": round(PER_GPU_BATCH * seen * args.steps / dt, 2),
+                          "unit": "img/s", "n_gpus": seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "dry-run"}, "roofline": None, "cpu_baseline": None}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+# ====================================================================================================== main
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, argv)              # nothing below has run in this process: no GPU call, no torch import
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} in the environment but --gpus {args.gpus}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    import torch
+    import torch.distributed as dist
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 or os.environ.get("MTD_FORCE_DP", "0") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ranks_seen = dist.get_world_size() if dist.is_initialized() else 1
 
     import __graft_entry__ as ge
     if not os.path.exists(os.path.join(ROOT, "mtd-gan_amd", "libmtdgan_hip.so")):
@@ -168,106 +366,72 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        wl.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = timed(wl, args.steps, args.warmup, barrier)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms = 1e3 * dt / args.steps
-    value = per_gpu_units * world * args.steps / dt
+    value = per_gpu_units * ranks_seen * args.steps / dt
 
-    roofline = None
-    if not args.no_roofline:
-        from mtd_gan_amd import kernels as K
-        cap = 8192 * max(1, args.steps)
-        step = getattr(wl, "step_eager", wl.step)          # events cannot be recorded inside a graph replay
-        # This pass runs every kernel in ONE stream: with the side streams and task chains of the timed region a launch's
-        # event-to-event time includes the share of the chip it cedes to concurrent kernels, which says nothing about the
-        # kernel.  (profiles/*_kernel_stats_single_stream.csv is the rocprofv3 trace of the same mode.)
-        K.set_concurrency(False)
-        step()
-        K.prof_enable(cap)
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        recs = K.prof_collect(cap)
-        K.prof_enable(0)
-        K.set_concurrency(True)
-        # an empty event pair on the same stream: what the bracketing itself adds to every sample
-        pairs = []
-        for _ in range(64):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            e1.record()
-            pairs.append((e0, e1))
-        torch.cuda.synchronize()
-        ev_over_ms = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
-        by = {}
-        for r in recs:
-            if r["kernel"].startswith("igemm"):
-                d = by.setdefault(r["kernel"], {"ms": 0.0, "flops": 0.0, "n": 0, "shapes": {}})
-                d["ms"] += r["ms"]
-                d["flops"] += r["flops"]
-                d["n"] += 1
-                key = f"M{r['M']}_N{r['N']}_C{r['C']}_T{r['taps']}_S{r['splitk']}"
-                sh = d["shapes"].setdefault(key, [0.0, 0.0, 0])
-                sh[0] += r["ms"]; sh[1] += r["flops"]; sh[2] += 1
-        if by:
-            name, d = max(by.items(), key=lambda kv: kv[1]["ms"])
-            raw_ms = d["ms"]
-            for dd in by.values():                          # remove the event-pair overhead from every launch
-                dd["ms"] = max(dd["ms"] - ev_over_ms * dd["n"], 1e-6)
-                for sh in dd["shapes"].values():
-                    sh[0] = max(sh[0] - ev_over_ms * sh[2], 1e-6)
-            pmc_tag = {"full_step": "", "generator_fwd_bwd": "generator_"}.get(wl.name)
-            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            top = sorted(d["shapes"].items(), key=lambda kv: -kv[1][0])[:4]
-            roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                        # committed PMC passes: the default workload (profiles/r1_pmc_*.csv) and the generator workload
-                        # (profiles/r1_pmc_generator_*.csv, tools/pmc_generator.sh)
-                        "traffic": pmc_traffic(name, pmc_tag) if pmc_tag is not None else None,
-                        "mfma_util_pmc": pmc_mfma_util(name, pmc_tag) if pmc_tag is not None else None,
-                        "launches_timed": d["n"], "avg_launch_us": round(1e3 * d["ms"] / d["n"], 2),
-                        "avg_launch_us_with_event_pair": round(1e3 * raw_ms / d["n"], 2), "event_pair_us": round(1e3 * ev_over_ms, 2),
-                        "flops_per_launch": round(d["flops"] / d["n"]), "measured": "second pass of the same steps, all kernels in one stream",
-                        "share_of_step_gpu_ms": round(d["ms"] / args.steps, 3),
-                        "top_shapes": {k: {"us": round(1e3 * v[0] / v[2], 2), "tflops": round(v[1] / v[0] / 1e9, 2), "launches_per_step": v[2] // args.steps}
-                                       for k, v in top},
-                        "other_igemm": {k: {"tflops": round(v["flops"] / v["ms"] / 1e9, 2), "ms_per_step": round(v["ms"] / args.steps, 3)}
-                                        for k, v in by.items() if k != name}}
-
+    roofline, extra = None, {}
+    pmc_tag = {"full_step": "full_step", "generator_fwd_bwd": "generator"}.get(wl.name)
+    if not args.no_roofline and wl.name in ("full_step", "generator_fwd_bwd", "inference512"):
+        roofline, extra = roofline_pass(wl, args.steps, pmc_tag)
     if roofline is None and not args.no_roofline and hasattr(wl, "roofline_bytes_per_step"):
         # byte-moving workloads: algorithmic bytes of a step over the step time (the kernels are launch-latency bound
         # at this size; the figure says how far from the HBM roof a whole batch is, not a single kernel)
         gbs = wl.roofline_bytes_per_step / (ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "bbox_kernel + sample_kernel (whole step)", "achieved": round(gbs, 2), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(gbs / 8000.0, 5), "traffic": None, "bytes_per_step": wl.roofline_bytes_per_step}
+
+    # ---- BASELINE configs[1] beside the headline workload: generator-only forward + backward on the same 32 patches
+    gen = None
+    if wl.name == "full_step" and not args.no_generator:
+        gw = BW.make("generator", dev, rank, world, PER_GPU_BATCH)
+        gdt = timed(gw, args.steps, args.warmup, barrier)
+        if world > 1:
+            t = torch.tensor([gdt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            gdt = float(t.item())
+        gms = 1e3 * gdt / args.steps
+        gtf = gw.gflop_per_patch * PER_GPU_BATCH / (gms * 1e-3) / 1e3
+        gen = {"config": gw.config(ranks_seen), "value": round(PER_GPU_BATCH * ranks_seen * args.steps / gdt, 2), "unit": "img/s",
+               "ms_per_step": round(gms, 3), "algorithmic_gflop_per_patch": gw.gflop_per_patch, "step_tflops_per_gpu": round(gtf, 2),
+               "step_frac_of_fp32_mfma_peak": round(gtf / PEAK_F32_MFMA_TFLOPS, 4), "target_frac": 0.40}
+        gen.update(gw.extra())
+        if not args.no_roofline:
+            groof, gextra = roofline_pass(gw, args.steps, "generator")
+            gen["roofline"] = groof
+            gen.update(gextra)
+        del gw
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(wl)
 
     if rank == 0:
         line = {"metric": "GAN train-step imgs/sec (G+D fwd+bwd) @ 64x64 patch", "value": round(value, 2), "unit": "img/s",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+                "n_gpus": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": getattr(wl, "dtype", "f32"), "data": "synthetic",
-                "config": wl.config(world), "roofline": roofline, "cpu_baseline": cpu}
+                "config": wl.config(ranks_seen), "roofline": roofline, "cpu_baseline": cpu}
         line.update(wl.extra())
+        line.update(extra)
         if "algorithmic_gflop_per_patch" in line:          # whole-step rate against the same peak, from the timed region
-            tf = line["algorithmic_gflop_per_patch"] * per_gpu_units * world / (ms * 1e-3) / 1e3 / world
+            tf = line["algorithmic_gflop_per_patch"] * per_gpu_units / (ms * 1e-3) / 1e3
             line["step_tflops_per_gpu"] = round(tf, 2)
             line["step_frac_of_fp32_mfma_peak"] = round(tf / PEAK_F32_MFMA_TFLOPS, 4)
+            if "executed_gflop_per_patch" in line:           # ... and the same for the flops the step actually executes
+                tfe = line["executed_gflop_per_patch"] * per_gpu_units / (ms * 1e-3) / 1e3
+                line["step_executed_tflops_per_gpu"] = round(tfe, 2)
+                line["step_executed_frac_of_fp32_mfma_peak"] = round(tfe / PEAK_F32_MFMA_TFLOPS, 4)
+        if gen is not None:
+            line["generator_fwd_bwd"] = gen
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -296,8 +296,8 @@ int mtd_window_patches(const short* hu_low, const short* hu_full, int n_slices, 
 int mtd_hu_window(const short* hu, long long n, float a_min, float a_max, float* out, void* stream);
 
 /* ---- launch profiler (bench.py's roofline leg) ---------------------------------------------------------------
- * When enabled, mtd_conv_igemm / mtd_conv_wgrad bracket their MAIN kernel (not the split-K / slab reductions that
- * follow it) with a pair of HIP events on the stream they were given.  mtd_prof_collect synchronises those events
+ * When enabled, mtd_conv_igemm / mtd_conv_wgrad time their MAIN kernel (not the split-K / slab reductions that
+ * follow it) with a pair of HIP events on the stream they were given (see mtd_prof_mode).  mtd_prof_collect synchronises those events
  * and returns one record per launch.  kernel: 0 = igemm_kernel, 1 = wgrad_kernel; cfg = tile configuration index
  * (the template instantiation); flops = 2*M*N*C*taps (dense algorithmic count).
  * Not for use while a hipGraph is being captured. */
@@ -313,9 +313,14 @@ typedef struct mtd_prof_record {
     double flops;
     float ms;
     int _pad;
+    double bytes;     /* algorithmic HBM bytes of the launch: every distinct operand element read once, every result written once */
 } mtd_prof_record;
 int mtd_prof_enable(int capacity);                       /* capacity <= 0 switches profiling off and frees events */
 int mtd_prof_collect(mtd_prof_record* out, int max_records);   /* returns the number of completed records */
+/* Timing mode of the profiler: 1 (default) = the events ride on the kernel's dispatch packet (duration = the dispatch's
+ * own begin / end timestamps, what a kernel trace reports); 0 = hipEventRecord before / after the launch.  attach < 0
+ * only queries.  Returns the mode in effect, MTD_EINVAL while records are pending. */
+int mtd_prof_mode(int attach);
 
 const char* mtd_version(void);
 

@@ -98,7 +98,7 @@ def _preload_torch_hip_runtime():
 
 
 RECORDER = None      # kernels.LaunchList: while a step is being recorded, the list every launch is appended to
-_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "mtd_prof_enable", "mtd_prof_collect", "_override")
+_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "mtd_prof_", "_override")
 
 
 class _RecordingLib:
@@ -206,6 +206,7 @@ def lib():
     sig("mtd_foreground_bbox", ci, vp, ci, ci, ci, cf, vp, vp)
     sig("mtd_window_patches", ci, vp, vp, ci, ci, ci, vp, vp, ci, cf, cf, ci, vp, vp, vp)
     sig("mtd_hu_window", ci, vp, ll, cf, cf, vp, vp)
+    sig("mtd_prof_mode", ci, ci)
     _lib = L
     return L
 
@@ -221,12 +222,14 @@ EXPORTS = [
     "mtd_prof_enable", "mtd_prof_collect", "mtd_conv_igemm_override", "mtd_conv_wgrad_override", "mtd_upload", "mtd_image_metrics_ws_bytes", "mtd_image_metrics", "mtd_rfft_rows_any", "mtd_spec_mix_any", "mtd_irfft_rows_any",
     "mtd_conv_wgrad_slabs", "mtd_conv_wgrad_slabs_rfft", "mtd_conv_wgrad_reduce_blocks", "mtd_conv_wgrad_reduce_multi", "mtd_spec_mix_wgrad_reduce_multi",
     "mtd_foreground_bbox", "mtd_window_patches", "mtd_hu_window", "mtd_add", "mtd_transpose64_multi", "mtd_upsample2x_bwd_masked",
+    "mtd_prof_mode",
 ]
 
 
 class ProfRecord(C.Structure):
     _fields_ = [("kernel", C.c_int), ("cfg", C.c_int), ("splitk", C.c_int), ("N", C.c_int), ("C", C.c_int),
-                ("taps", C.c_int), ("M", C.c_longlong), ("flops", C.c_double), ("ms", C.c_float), ("_pad", C.c_int)]
+                ("taps", C.c_int), ("M", C.c_longlong), ("flops", C.c_double), ("ms", C.c_float), ("_pad", C.c_int),
+                ("bytes", C.c_double)]
 
 
 def check(rc, what):

@@ -13,10 +13,25 @@ struct ProfSlot {
 std::mutex g_prof_mu;
 std::vector<ProfSlot> g_prof;
 int g_prof_cap = 0;
+// Timing mode.  1 (default): the two events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL start / stop
+// events), so their difference is the dispatch's begin / end timestamps -- the duration a kernel trace (rocprofv3
+// --kernel-trace) reports, with nothing of the bracketing in it.  0 (MTD_PROF_MODE=bracket): hipEventRecord before and
+// after the launch, which adds the marker packets' own processing (2.8 us on a 35 us kernel in round 1).
+int g_prof_attach = 1;
+thread_local int t_pending_slot = -1;
 }  // namespace
 
+MtdProfLaunch mtd_prof_launch_events() {
+    MtdProfLaunch r{nullptr, nullptr, false};
+    if (t_pending_slot < 0) return r;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (t_pending_slot < (int)g_prof.size()) { r.e0 = g_prof[t_pending_slot].e0; r.e1 = g_prof[t_pending_slot].e1; r.on = true; }
+    t_pending_slot = -1;
+    return r;
+}
+
 // Internal hooks (common.h).  begin returns a slot index or -1 when profiling is off / full.
-int mtd_prof_begin(int kernel, int cfg, int splitk, long long M, int N, int C, int taps, hipStream_t s) {
+int mtd_prof_begin(int kernel, int cfg, int splitk, long long M, int N, int C, int taps, hipStream_t s, double bytes) {
     if (g_prof_cap <= 0) return -1;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if ((int)g_prof.size() >= g_prof_cap) return -1;
@@ -25,17 +40,28 @@ int mtd_prof_begin(int kernel, int cfg, int splitk, long long M, int N, int C, i
     sl.rec.M = M; sl.rec.N = N; sl.rec.C = C; sl.rec.taps = taps;
     sl.rec.flops = 2.0 * (double)M * N * C * taps;
     sl.rec.ms = 0.f;
+    sl.rec.bytes = bytes;
     if (hipEventCreate(&sl.e0) != hipSuccess) return -1;
     if (hipEventCreate(&sl.e1) != hipSuccess) { (void)hipEventDestroy(sl.e0); return -1; }
-    (void)hipEventRecord(sl.e0, s);
+    if (!g_prof_attach) (void)hipEventRecord(sl.e0, s);
     g_prof.push_back(sl);
+    if (g_prof_attach) t_pending_slot = (int)g_prof.size() - 1;      // consumed by the MTD_LAUNCH that follows
     return (int)g_prof.size() - 1;
 }
 
 void mtd_prof_end(int slot, hipStream_t s) {
     if (slot < 0) return;
+    t_pending_slot = -1;
+    if (g_prof_attach) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (slot < (int)g_prof.size()) (void)hipEventRecord(g_prof[slot].e1, s);
+}
+
+extern "C" int mtd_prof_mode(int attach) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof.empty()) return MTD_EINVAL;              // not while records are pending
+    if (attach >= 0) g_prof_attach = attach ? 1 : 0;
+    return g_prof_attach;
 }
 
 extern "C" int mtd_prof_enable(int capacity) {
@@ -44,6 +70,8 @@ extern "C" int mtd_prof_enable(int capacity) {
     g_prof.clear();
     g_prof_cap = capacity > 0 ? capacity : 0;
     if (g_prof_cap) g_prof.reserve(g_prof_cap);
+    static const bool env_bracket = [] { const char* e = getenv("MTD_PROF_MODE"); return e && e[0] == 'b'; }();
+    if (env_bracket) g_prof_attach = 0;
     return MTD_OK;
 }
 

@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 kernels of libmtdgan_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include "../../include/mtdgan_hip.h"
 
@@ -100,7 +101,16 @@ __device__ __forceinline__ f32x4 block_slab_sum(const float* __restrict__ in, lo
     return s;
 }
 
-// launch profiler hooks (api.hip)
-int mtd_prof_begin(int kernel, int cfg, int splitk, long long M, int N, int C, int taps, hipStream_t s);
+// launch profiler hooks (api.hip).  Between mtd_prof_begin and mtd_prof_end the main kernel is launched with MTD_LAUNCH:
+// when the profiler is on (kernel-timestamp mode) the slot's two events travel on the kernel's dispatch packet.
+int mtd_prof_begin(int kernel, int cfg, int splitk, long long M, int N, int C, int taps, hipStream_t s, double bytes = 0.0);
 void mtd_prof_end(int slot, hipStream_t s);
+struct MtdProfLaunch { hipEvent_t e0, e1; bool on; };
+MtdProfLaunch mtd_prof_launch_events();
+#define MTD_LAUNCH(kernel, grid, block, shmem, s, ...)                                                         \
+    do {                                                                                                       \
+        MtdProfLaunch pe__ = mtd_prof_launch_events();                                                         \
+        if (pe__.on) hipExtLaunchKernelGGL(kernel, grid, block, shmem, s, pe__.e0, pe__.e1, 0, __VA_ARGS__);   \
+        else hipLaunchKernelGGL(kernel, grid, block, shmem, s, __VA_ARGS__);                                   \
+    } while (0)
 

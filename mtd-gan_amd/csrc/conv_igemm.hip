@@ -1183,18 +1183,21 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
         if (!a->ws || a->ws_bytes < need) return MTD_EWS;
     }
     hipStream_t s = (hipStream_t)stream;
+    // algorithmic bytes of the launch (profiler record): input image, weight taps, result, epilogue operands -- each once
+    const double alg_bytes = 4.0 * ((double)a->g.B * a->g.IH * a->g.IW * a->C + (double)a->g.TH * a->g.TW * a->N * a->C +
+                                    (double)p.M * a->N * (1 + (a->add1 != nullptr) + (a->add2 != nullptr) + (a->mask != nullptr) + (a->out2 != nullptr)));
     const bool gen_shape = a->C == 32 && a->g.TH * a->g.TW == 9 && p.M >= 32768;
     if ((g_force_cfg == -1 || g_force_cfg == 10) && gen_shape && c32t_eligible(*a)) {
         // generator-shaped layers on 64-pixel rows: halo tiles of four image rows, one persistent workgroup per CU
-        const int prof = mtd_prof_begin(0, 10, 1, p.M, a->N, a->C, 9, s);
+        const int prof = mtd_prof_begin(0, 10, 1, p.M, a->N, a->C, 9, s, alg_bytes);
         static const int env_variant = [] { const char* e = getenv("MTD_C32T_VARIANT"); return e ? atoi(e) : 0; }();
         static const int env_stagger = [] { const char* e = getenv("MTD_C32T_STAGGER"); return e ? atoi(e) : 0; }();
         if (env_variant == 1) {
             const int ntiles = p.M / (2 * C32T_W);
-            hipLaunchKernelGGL((igemm_c32t_kernel<2, false>), dim3(ntiles < 512 ? ntiles : 512, a->N / 32), dim3(256), 0, s, p, ntiles, env_stagger);
+            MTD_LAUNCH((igemm_c32t_kernel<2, false>), dim3(ntiles < 512 ? ntiles : 512, a->N / 32), dim3(256), 0, s, p, ntiles, env_stagger);
         } else {
             const int ntiles = p.M / (C32T_R * C32T_W);
-            hipLaunchKernelGGL((igemm_c32t_kernel<C32T_R, true>), dim3(ntiles < 256 ? ntiles : 256, a->N / 32), dim3(512), 0, s, p, ntiles, 0);
+            MTD_LAUNCH((igemm_c32t_kernel<C32T_R, true>), dim3(ntiles < 256 ? ntiles : 256, a->N / 32), dim3(512), 0, s, p, ntiles, 0);
         }
         mtd_prof_end(prof, s);
         MTD_LAUNCH_CHECK();
@@ -1206,24 +1209,24 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
         const int ntiles = (p.M + 31) / 32;
         int wgs = (ntiles + 7) / 8;
         if (wgs > 512) wgs = 512;
-        const int prof = mtd_prof_begin(0, 9, 1, p.M, a->N, a->C, 9, s);
-        hipLaunchKernelGGL(igemm_c32p_kernel, dim3(wgs, a->N / 32), dim3(256), 0, s, p, ntiles);
+        const int prof = mtd_prof_begin(0, 9, 1, p.M, a->N, a->C, 9, s, alg_bytes);
+        MTD_LAUNCH(igemm_c32p_kernel, dim3(wgs, a->N / 32), dim3(256), 0, s, p, ntiles);
         mtd_prof_end(prof, s);
         MTD_LAUNCH_CHECK();
         return MTD_OK;
     }
     dim3 grid((p.M + pl.BM - 1) / pl.BM, a->N / pl.BN, pl.splitk);
-    const int prof = mtd_prof_begin(0, pl.cfg, pl.splitk, p.M, a->N, a->C, a->g.TH * a->g.TW, s);
+    const int prof = mtd_prof_begin(0, pl.cfg, pl.splitk, p.M, a->N, a->C, a->g.TH * a->g.TW, s, alg_bytes);
     switch (pl.cfg) {
-        case 0: hipLaunchKernelGGL((igemm_kernel<2, 1, 4, 1>), grid, dim3(256), 0, s, p); break;
-        case 1: hipLaunchKernelGGL((igemm_kernel<1, 1, 4, 1>), grid, dim3(256), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((igemm_kernel<2, 2, 4, 1>), grid, dim3(256), 0, s, p); break;
-        case 3: hipLaunchKernelGGL((igemm_kernel<1, 1, 2, 2>), grid, dim3(256), 0, s, p); break;
-        case 4: hipLaunchKernelGGL((igemm_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p); break;
-        case 6: hipLaunchKernelGGL((igemm_tb_kernel<1>), grid, dim3(256), 0, s, p); break;
-        case 7: hipLaunchKernelGGL((igemm_tb_kernel<2>), grid, dim3(256), 0, s, p); break;
-        case 8: hipLaunchKernelGGL((igemm_v2_kernel<0>), grid, dim3(256), 0, s, p); break;
-        default: hipLaunchKernelGGL((igemm_kernel<1, 1, 1, 4>), grid, dim3(256), 0, s, p); break;
+        case 0: MTD_LAUNCH((igemm_kernel<2, 1, 4, 1>), grid, dim3(256), 0, s, p); break;
+        case 1: MTD_LAUNCH((igemm_kernel<1, 1, 4, 1>), grid, dim3(256), 0, s, p); break;
+        case 2: MTD_LAUNCH((igemm_kernel<2, 2, 4, 1>), grid, dim3(256), 0, s, p); break;
+        case 3: MTD_LAUNCH((igemm_kernel<1, 1, 2, 2>), grid, dim3(256), 0, s, p); break;
+        case 4: MTD_LAUNCH((igemm_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p); break;
+        case 6: MTD_LAUNCH((igemm_tb_kernel<1>), grid, dim3(256), 0, s, p); break;
+        case 7: MTD_LAUNCH((igemm_tb_kernel<2>), grid, dim3(256), 0, s, p); break;
+        case 8: MTD_LAUNCH((igemm_v2_kernel<0>), grid, dim3(256), 0, s, p); break;
+        default: MTD_LAUNCH((igemm_kernel<1, 1, 1, 4>), grid, dim3(256), 0, s, p); break;
     }
     mtd_prof_end(prof, s);
     MTD_LAUNCH_CHECK();

@@ -896,44 +896,45 @@ static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, 
         p.ppw = pl.ppw;
         p.nCt = a->C / (32 * pl.WC);
         dim3 grid(pl.nsplit, (a->N / (32 * pl.WN)) * p.nCt, pl.ntg);
-        const int prof = mtd_prof_begin(1, pl.cfg, pl.nsplit, geom_pixels(a->g), a->N, a->C, a->g.TH * a->g.TW, s);
+        const int prof = mtd_prof_begin(1, pl.cfg, pl.nsplit, geom_pixels(a->g), a->N, a->C, a->g.TH * a->g.TW, s,
+                                            4.0 * ((double)geom_pixels(a->g) * a->N + (double)a->g.B * a->g.IH * a->g.IW * a->C + (double)a->g.TH * a->g.TW * a->N * a->C));
         // Row-window kernel: 64 KB of dynamic LDS nobody uses caps it at ONE workgroup (one wave per SIMD) per CU.  Alone in
         // a stream that changes nothing (generator step: 31.7 us per launch either way); in the full step, where it runs on a
         // side stream beside the data-gradient chain, a second workgroup on a CU took the slots of the other stream's
         // kernel: 44.47 -> 44.03 ms per step (three A/B runs each, tools/wgrad_pad_full.sh).  MTD_WGRAD_LDS_PAD=0 is the old launch.
         static const unsigned lds_pad = [] { const char* e = getenv("MTD_WGRAD_LDS_PAD"); return e ? (unsigned)atoi(e) : 65536u; }();
         switch (pl.cfg) {
-            case 0: hipLaunchKernelGGL((wgrad_kernel<1, 1, 9>), grid, dim3(256), 0, s, p); break;
-            case 1: hipLaunchKernelGGL((wgrad_kernel<1, 1, 4>), grid, dim3(256), 0, s, p); break;
-            case 2: hipLaunchKernelGGL((wgrad_kernel<2, 2, 1>), grid, dim3(256), 0, s, p); break;
-            case 3: hipLaunchKernelGGL((wgrad_kernel<1, 1, 8>), grid, dim3(256), 0, s, p); break;
-            case 4: hipLaunchKernelGGL((wgrad_kernel<1, 1, 3>), grid, dim3(256), 0, s, p); break;
-            case 7: if (pl.nw == 8) hipLaunchKernelGGL((wgrad_row_kernel<3, 3, 1, 8>), grid, dim3(512), 0, s, p);
+            case 0: MTD_LAUNCH((wgrad_kernel<1, 1, 9>), grid, dim3(256), 0, s, p); break;
+            case 1: MTD_LAUNCH((wgrad_kernel<1, 1, 4>), grid, dim3(256), 0, s, p); break;
+            case 2: MTD_LAUNCH((wgrad_kernel<2, 2, 1>), grid, dim3(256), 0, s, p); break;
+            case 3: MTD_LAUNCH((wgrad_kernel<1, 1, 8>), grid, dim3(256), 0, s, p); break;
+            case 4: MTD_LAUNCH((wgrad_kernel<1, 1, 3>), grid, dim3(256), 0, s, p); break;
+            case 7: if (pl.nw == 8) MTD_LAUNCH((wgrad_row_kernel<3, 3, 1, 8>), grid, dim3(512), 0, s, p);
                     else if (rows && grid.y == 1 && grid.z == 1) {
                         const dim3 fg(grid.x + (unsigned)((rows->npairs + 7) / 8));
-                        hipLaunchKernelGGL((wgrad_row_rfft_kernel<1>), fg, dim3(256), 0, s, p, (int)grid.x, *rows);
+                        MTD_LAUNCH((wgrad_row_rfft_kernel<1>), fg, dim3(256), 0, s, p, (int)grid.x, *rows);
                         *rows_done = true;
-                    } else hipLaunchKernelGGL((wgrad_row_kernel<3, 3, 1, 4>), grid, dim3(256), lds_pad, s, p);
+                    } else MTD_LAUNCH((wgrad_row_kernel<3, 3, 1, 4>), grid, dim3(256), lds_pad, s, p);
                     break;
-            case 8: if (pl.nw == 8) hipLaunchKernelGGL((wgrad_row_kernel<3, 3, -1, 8>), grid, dim3(512), 0, s, p);
+            case 8: if (pl.nw == 8) MTD_LAUNCH((wgrad_row_kernel<3, 3, -1, 8>), grid, dim3(512), 0, s, p);
                     else if (rows && grid.y == 1 && grid.z == 1) {
                         const dim3 fg(grid.x + (unsigned)((rows->npairs + 7) / 8));
-                        hipLaunchKernelGGL((wgrad_row_rfft_kernel<-1>), fg, dim3(256), 0, s, p, (int)grid.x, *rows);
+                        MTD_LAUNCH((wgrad_row_rfft_kernel<-1>), fg, dim3(256), 0, s, p, (int)grid.x, *rows);
                         *rows_done = true;
-                    } else hipLaunchKernelGGL((wgrad_row_kernel<3, 3, -1, 4>), grid, dim3(256), lds_pad, s, p);
+                    } else MTD_LAUNCH((wgrad_row_kernel<3, 3, -1, 4>), grid, dim3(256), lds_pad, s, p);
                     break;
-            case 9: if (pl.nw == 8) hipLaunchKernelGGL((wgrad_row_kernel<1, 1, 1, 8>), grid, dim3(512), 0, s, p);
-                    else hipLaunchKernelGGL((wgrad_row_kernel<1, 1, 1, 4>), grid, dim3(256), 0, s, p);
+            case 9: if (pl.nw == 8) MTD_LAUNCH((wgrad_row_kernel<1, 1, 1, 8>), grid, dim3(512), 0, s, p);
+                    else MTD_LAUNCH((wgrad_row_kernel<1, 1, 1, 4>), grid, dim3(256), 0, s, p);
                     break;
-            case 10: hipLaunchKernelGGL((wgrad_blk_kernel<8, 4>), grid, dim3(256), 0, s, p); break;
-            case 11: if (pl.nw == 8) hipLaunchKernelGGL((wgrad_blk_kernel<4, 8>), grid, dim3(512), 0, s, p);
-                     else hipLaunchKernelGGL((wgrad_blk_kernel<4, 4>), grid, dim3(256), 0, s, p);
+            case 10: MTD_LAUNCH((wgrad_blk_kernel<8, 4>), grid, dim3(256), 0, s, p); break;
+            case 11: if (pl.nw == 8) MTD_LAUNCH((wgrad_blk_kernel<4, 8>), grid, dim3(512), 0, s, p);
+                     else MTD_LAUNCH((wgrad_blk_kernel<4, 4>), grid, dim3(256), 0, s, p);
                      break;
-            case 12: if (pl.nw == 8) hipLaunchKernelGGL((wgrad_blk_kernel<2, 8>), grid, dim3(512), 0, s, p);
-                     else hipLaunchKernelGGL((wgrad_blk_kernel<2, 4>), grid, dim3(256), 0, s, p);
+            case 12: if (pl.nw == 8) MTD_LAUNCH((wgrad_blk_kernel<2, 8>), grid, dim3(512), 0, s, p);
+                     else MTD_LAUNCH((wgrad_blk_kernel<2, 4>), grid, dim3(256), 0, s, p);
                      break;
-            case 5: hipLaunchKernelGGL((wgrad_kernel<1, 1, 1>), grid, dim3(256), 0, s, p); break;
-            default: hipLaunchKernelGGL((wgrad_kernel<2, 2, 3>), grid, dim3(256), 0, s, p); break;
+            case 5: MTD_LAUNCH((wgrad_kernel<1, 1, 1>), grid, dim3(256), 0, s, p); break;
+            default: MTD_LAUNCH((wgrad_kernel<2, 2, 3>), grid, dim3(256), 0, s, p); break;
         }
         mtd_prof_end(prof, s);
         MTD_LAUNCH_CHECK();

@@ -84,6 +84,18 @@ def packed_weight_view(w, N, Cc, w_sn, w_sc):
         _remember(_pack_cache, (w.data_ptr(), N, Cc, w_sn, w_sc), key, hit)
     return hit[0], Cc, 1, N * Cc
 STATS = {"table_hit": 0, "table_miss": 0, "zero_copy_reads": 0}
+# bench.py: while this is a dict, the helpers below add the dense algorithmic flop count of every launch they make
+# (2*M*N*C*taps for convolutions and weight gradients, 2*64*64 per frequency for the spectral mix, 2.5*N*log2(N) per
+# real 64 x 64 plane split evenly over the row and column passes) -- the work a step EXECUTES, as opposed to the
+# reference-derived "sufficient" count its throughput is quoted against.
+FLOP_COUNT = None
+_FFT_HALF_PLANE = 2.5 * 4096 * 12 / 2
+
+
+def _count(kind, flops):
+    if FLOP_COUNT is not None:
+        FLOP_COUNT[kind] = FLOP_COUNT.get(kind, 0.0) + float(flops)
+        FLOP_COUNT["launches"] = FLOP_COUNT.get("launches", 0) + 1
 _igemm_ws_cache = {}
 CALL_LOG = None     # tools/tune_igemm.py: a list collects ("igemm" | "wgrad", bytes(argument struct)) per call
 
@@ -101,6 +113,12 @@ def prof_enable(capacity):
     L = _lib.lib()
     L.mtd_prof_enable.argtypes = [C.c_int]
     check(L.mtd_prof_enable(int(capacity)), "mtd_prof_enable")
+
+
+def prof_mode(attach=-1):
+    """Timing mode of the launch profiler (mtd_prof_mode): 1 = the kernel dispatch's own begin / end timestamps, 0 = events
+    recorded before / after the launch; -1 queries."""
+    return _lib.lib().mtd_prof_mode(int(attach))
 
 
 def prof_collect(capacity):
@@ -223,6 +241,8 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, scale=None, bias=None, add1=None, a
     a.mask, a.mask_ld, a.mask_slope = _ptr(mask), (ld_of(mask) if mask is not None else 0), mask_slope
     a.out2, a.out2_ld = _ptr(out2), (ld_of(out2) if out2 is not None else 0)
     a.ws, a.ws_bytes = None, 0
+    if FLOP_COUNT is not None:
+        _count("conv_mfma" if (Cc % 32 == 0 and N % 32 == 0) else "conv_valu", 2.0 * geom.B * geom.OH * geom.OW * N * Cc * geom.TH * geom.TW)
     if (Cc % 32 == 0) and (N % 32 == 0):
         wkey = (bytes(geom), N, Cc)
         need = _igemm_ws_cache.get(wkey)
@@ -312,6 +332,8 @@ def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumula
         wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=db, accumulate=accumulate, accumulate_bias=accumulate_bias, defer=defer)
         return rfft_rows(rows[0], rows[1])
     L = _lib.lib()
+    if FLOP_COUNT is not None:
+        _count("wgrad_mfma" if (Cc % 32 == 0 and N % 32 == 0) else "wgrad_valu", 2.0 * geom.B * geom.OH * geom.OW * N * Cc * geom.TH * geom.TW)
     a = WgradArgs()
     a.g = geom
     a.p, a.p_ld, a.N = p.data_ptr(), ld_of(p), N
@@ -354,6 +376,7 @@ def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumula
 # ---------------------------------------------------------------------------------------------- spectral path
 def rfft_rows(x, col_weight):
     B = x.shape[0]
+    _count("fft", B * 32 * _FFT_HALF_PLANE)
     R = torch.empty((B, 33, 64, 64), dtype=torch.float32, device=x.device)
     check(_lib.lib().mtd_rfft_rows(x.data_ptr(), ld_of(x), R.data_ptr(), B, int(col_weight), stream_ptr()), "mtd_rfft_rows")
     return R
@@ -361,6 +384,8 @@ def rfft_rows(x, col_weight):
 
 def spec_mix_fwd(R, w2t, b2, save):
     B = R.shape[0]
+    _count("spec_mix_mfma", B * 2112 * 2.0 * 64 * 64)
+    _count("fft", 2 * B * 32 * _FFT_HALF_PLANE)
     T = torch.empty_like(R)
     S = torch.empty_like(R) if save else None
     Z = torch.empty_like(R) if save else None
@@ -372,6 +397,8 @@ def spec_mix_fwd(R, w2t, b2, save):
 def spec_mix_bwd(gR, w2, S, Z, dw2, db2, accumulate=False, defer=None):
     L = _lib.lib()
     B = gR.shape[0]
+    _count("spec_mix_mfma", 2 * B * 2112 * 2.0 * 64 * 64)
+    _count("fft", 2 * B * 32 * _FFT_HALF_PLANE)
     gT = torch.empty_like(gR)
     deferred = defer is not None and DEFER_WGRADS and dw2.data_ptr() % 16 == 0 and B * 17 <= 4096
     need = L.mtd_spec_mix_bwd_ws_bytes(B)
@@ -391,6 +418,7 @@ def spec_mix_bwd(gR, w2, S, Z, dw2, db2, accumulate=False, defer=None):
 
 def irfft_rows(T, out, add1=None, add2=None, mask=None):
     B = T.shape[0]
+    _count("fft", B * 32 * _FFT_HALF_PLANE)
     check(_lib.lib().mtd_irfft_rows(T.data_ptr(), out.data_ptr(), ld_of(out), _ptr(add1), ld_of(add1) if add1 is not None else 0,
                                     _ptr(add2), ld_of(add2) if add2 is not None else 0, _ptr(mask),
                                     ld_of(mask) if mask is not None else 0, B, stream_ptr()), "mtd_irfft_rows")

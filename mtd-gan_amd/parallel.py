@@ -23,8 +23,45 @@ class DataParallelSync:
         self._pending = []
 
     def broadcast_module(self, module):
-        for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src=0)
+        """Rank 0's parameters and buffers to every rank.  The weights change under every cache of derived quantities
+        (packed conv weights, transposed mix weights, the generator tape), so those are dropped and the parameters'
+        `_mtd_epoch` stamps bumped: a forward that ran before the broadcast must not leave stale views behind."""
+        from . import kernels as K
+        params = list(module.parameters())
+        with torch.no_grad():
+            for t in params + list(module.buffers()):
+                dist.broadcast(t.detach(), src=0)          # shares the version counter with t (unlike t.data)
+        K.weights_changed(params)
+        K.weights_changed(None)
+
+    def broadcast_orders(self, orders, device=None, upload=None):
+        """The PCGrad projection order of this step as ONE collective decision: rank 0's draw wins.  Every rank still
+        consumes its own `random` stream exactly like the reference (module/weight_methods.py:452), so a single process
+        behaves as before, but ranks whose `random` states differ (seed+rank conventions, data loaders consuming
+        `random`) can no longer apply different projections to the same averaged gradients.
+        orders: list of T index lists.  Returns an int32 tensor (T*T, padded to 16) on `device` holding rank 0's order;
+        on GPUs the broadcast runs on the collective side stream (no host synchronisation) and wait() joins it.
+        upload: optional callable(list_of_ints) -> int32 device tensor (train_step supplies a pinned-slot upload so that
+        the step has no hipMemcpy); the default builds the tensor with torch."""
+        flat = [j for o in orders for j in o]
+        flat = flat + [0] * (16 - len(flat))
+        if self.cuda:
+            t = upload(flat) if upload is not None else torch.tensor(flat, dtype=torch.int32).to(device or self.device)
+            if self.world > 1 or self.force:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self.side.wait_event(ev)
+                t.record_stream(self.side)
+                with torch.cuda.stream(self.side):
+                    dist.broadcast(t, src=0)
+                done = torch.cuda.Event()
+                done.record(self.side)
+                self._pending.append(done)
+            return t
+        t = torch.tensor(flat, dtype=torch.int32)
+        if self.world > 1:
+            dist.broadcast(t, src=0)
+        return t
 
     def all_reduce_avg(self, flat):
         """Average `flat` (a contiguous tensor) across ranks.  On GPUs the collective runs on a side stream

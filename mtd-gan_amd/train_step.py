@@ -61,6 +61,15 @@ class DStepTape:
                 t[nme] = S[i, ofs:ofs + sz]
                 ofs += sz
             sinks.append(DP.GradSink(t))
+        # ---- the projection order of this step: Python's `random`, as the reference draws it.  Under data parallelism
+        # it is a collective decision (rank 0's draw, broadcast on the RCCL stream under the backward passes): ranks with
+        # different `random` states would otherwise project the same averaged gradients differently and drift apart.
+        orders = next_orders(3)
+        slot = orders_slot(dev)
+        slot.set([j for o in orders for j in o] + [0] * 7)
+        orders_dev = None
+        if dp is not None:
+            orders_dev = dp.broadcast_orders(orders, dev, upload=lambda flat: _upload_slot(slot, dev))
         (re, rd, rr), (fe, fd, fr), (rre, rrd), (rfe, rfd), r12 = self.outs
         t12, t34 = self.passes
         rt, P = D._rt, self.P
@@ -164,13 +173,13 @@ class DStepTape:
         if dp is not None and ts_names:
             dp.all_reduce_avg(TSflat)      # 158 MB, in flight under the Gram / combine kernels; joined below
         # ---- PCGrad: Gram of the original task gradients, replay of the projections, combine
-        orders = next_orders(3)
-        slot = orders_slot(dev)
-        slot.set([j for o in orders for j in o])
         vecs = [S[0], S[1], S[2]]
         gram = K.pcgrad_gram(vecs)
-        coeff = K.pcgrad_combine(vecs, gram, slot.device_ptr(), S[3])     # the order is read from the pinned slot at run time
-        slot.consumed()
+        if orders_dev is not None:
+            coeff = K.pcgrad_combine(vecs, gram, orders_dev, S[3])        # rank 0's order, broadcast at the top of the pass
+        else:
+            coeff = K.pcgrad_combine(vecs, gram, slot.device_ptr(), S[3])     # the order is read from the pinned slot at run time
+            slot.consumed()
         merged = S[3]
         if reduction == "mean":
             merged = merged / 3.0
@@ -182,7 +191,8 @@ class DStepTape:
             p.grad = TSbuf[nme]
         if dp is not None:
             dp.wait()
-        self.gram, self.coeff, self.orders, self.task_vectors = gram, coeff, orders, S
+        # (under data parallelism `orders` is this rank's own draw; the order applied is rank 0's, in orders_dev)
+        self.gram, self.coeff, self.orders, self.orders_dev, self.task_vectors = gram, coeff, orders, orders_dev, S
         self.consumed = True
 
     @staticmethod
@@ -194,6 +204,16 @@ class DStepTape:
 
 _orders_slots = {}
 _pending_orders = []
+
+
+def _upload_slot(slot, dev):
+    """The 16 int32s of a pinned HostScalars slot as a device tensor, moved by mtd_upload (a kernel reading the mapped
+    pinned memory: no hipMemcpy in the step)."""
+    from . import _lib
+    t = torch.empty(16, dtype=torch.int32, device=dev)
+    K.check(_lib.lib().mtd_upload(slot.device_ptr(), t.data_ptr(), 64, K.stream_ptr()), "mtd_upload")
+    slot.consumed()
+    return t
 
 
 def orders_slot(dev):
@@ -238,7 +258,8 @@ def d_loss(method, x, y):
     GPm = N._unflatten_gen(gflat, G._cfg[2])
     keep = torch.is_grad_enabled() and any(p.requires_grad for p in gflat)
     fn, gtape = GP.generator_forward(xn, GPm, keep)
-    method._gcache = (_gkey(x, gflat), fn, gtape, GPm) if keep else None
+    # (the entry holds x itself: a strong reference keeps its address from being recycled for another batch)
+    method._gcache = (x, _gkey(x, gflat), fn, gtape, GPm) if keep else None
     P = D._param_dict()
     train = D.training
     # The four discriminator passes of the reference run as TWO launches sequences of batch 2B: (D(y), D(fake)) and
@@ -287,9 +308,9 @@ class _GStepFn(torch.autograd.Function):
         xn, yn = _nhwc1(x.float()), _nhwc1(y.float())
         GPm = N._unflatten_gen(gparams, nlayers)
         need = any(ctx.needs_input_grad)
-        cache, method._gcache = getattr(method, "_gcache", None), None
-        if need and cache is not None and cache[0] == _gkey(x, gparams):
-            _, fake, gtape, GPm = cache                      # same input, same weights: the D step's forward and its tape
+        cache, method._gcache_hit = getattr(method, "_gcache_hit", None), None
+        if need and cache is not None:
+            _, _, fake, gtape, GPm = cache                   # same input object, same weights: the D step's forward and its tape
         else:
             fake, gtape = GP.generator_forward(xn, GPm, need)
         P = D._param_dict()
@@ -331,7 +352,14 @@ def g_loss(method, x, y):
     G = method.Generator
     if not x.is_cuda:
         raise RuntimeError("MTD_GAN_Method.g_loss: HIP path needs CUDA tensors")
-    total, v, edge = _GStepFn.apply(x, y, method, G._cfg[2], *G._flat_params())
+    # The D step's generator forward is reused only for the very tensor object it ran on (engine.train_iteration passes
+    # the same x to d_loss and g_loss) with unchanged contents and weights; anything else -- a new batch of the same shape
+    # at a recycled address, separate D and G batches, n_critic loops -- recomputes.
+    gparams = G._flat_params()
+    cache, method._gcache = getattr(method, "_gcache", None), None
+    method._gcache_hit = cache if (cache is not None and cache[0] is x and cache[1] == _gkey(x, gparams)) else None
+    total, v, edge = _GStepFn.apply(x, y, method, G._cfg[2], *gparams)
+    method._gcache_hit = None
     details = {"G/gen_enc": v[0], "G/gen_dec": v[1], "G/pix_loss": v[2], "G/edge_loss": edge[0]}
     return total, details
 

@@ -1,0 +1,49 @@
+"""CPU test of bench.py's own launcher: `python bench.py --gpus N` (no WORLD_SIZE in the environment) must start N rank
+processes itself, rendezvous them over 127.0.0.1, print ONE JSON line from rank 0 whose n_gpus is the number of ranks the
+process group saw, and hand a failing rank's exit code back.  --dry-run keeps it on the CPU (gloo, no HIP library)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "3", "--warmup", "1", *extra],
+                          env=env, capture_output=True, text=True, timeout=240)
+
+
+@pytest.mark.timeout(300)
+def test_gpus_2_launches_two_ranks_unwrapped():
+    r = _run("--gpus", "2")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # one line, from rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+    for key in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in line, key
+
+
+@pytest.mark.timeout(300)
+def test_a_failing_rank_fails_the_launch():
+    r = _run("--gpus", "2", "--dry-run-fail-rank", "1")
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_world_size_must_match_gpus():
+    r = _run("--gpus", "2", env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_single_rank_needs_no_launcher():
+    r = _run("--gpus", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 1

@@ -88,3 +88,44 @@ def test_two_shards_plus_allreduce_equal_large_batch():
     assert res["loss"] < 1e-5, res
     assert max(res["tasks"]) < 5e-3, res          # fp32 sums in a different order; consist gradients are tiny
     assert res["merged"] < 5e-3 and res["ts"] < 5e-3, res
+
+
+def _orders_worker(rank, world, port, out):
+    """Ranks whose global `random` states differ (the seed+rank convention) must still apply ONE projection order:
+    rank 0's draw, taken from its own `random` stream exactly as the reference consumes it."""
+    import random
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mtd_gan_amd import train_step as TS
+    from mtd_gan_amd.parallel import DataParallelSync
+    dp = DataParallelSync(device=None)
+    random.seed(100 + rank)
+    got = []
+    for _ in range(3):
+        mine = TS.next_orders(3)
+        got.append((mine, dp.broadcast_orders(mine).tolist()))
+    out.put((rank, got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_projection_order_is_a_collective_decision():
+    import random
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_orders_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get() for _ in procs)
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    random.seed(100)
+    expect = [[j for o in orc.shuffle_orders(3) for j in o] for _ in range(3)]
+    for step in range(3):
+        for rank in range(2):
+            assert res[rank][step][1][:9] == expect[step], (rank, step, res[rank][step])
+    assert any(res[1][s][0] != res[0][s][0] for s in range(3))        # the ranks' own draws did differ
