@@ -236,6 +236,14 @@ int mtd_pcgrad_gram(const float* g0, const float* g1, const float* g2, const flo
 int mtd_pcgrad_combine(const float* g0, const float* g1, const float* g2, const float* g3, int T, long long n,
                        const double* gram, const int* orders, float* merged, float* coeff_out, void* stream);
 
+/* The two halves of mtd_pcgrad_combine on their own, for module/pcgrad.py::PCGrad (the optimizer wrapper,
+ * pcgrad.py:50-69): the projections run on the flat gradient of ALL optimizer parameters, then parameters every
+ * objective reaches get the mean of the projected gradients and the others their sum -- one coefficient replay, one
+ * axpy (merged = scale * sum_k coeff[k] g_k over n elements) per run of parameters with the same reduction. */
+int mtd_pcgrad_coeff(const double* gram, const int* orders, int T, float* coeff_out, void* stream);
+int mtd_pcgrad_axpy(const float* g0, const float* g1, const float* g2, const float* g3, int T, long long n,
+                    const float* coeff, float scale, float* merged, void* stream);
+
 /* ---- fused multi-tensor AdamW (train.py:122-126; torch.optim.AdamW semantics) ---------------- */
 typedef struct { float* p; const float* g; float* m; float* v; long long n; } mtd_adamw_tensor;
 int mtd_adamw_multi(const mtd_adamw_tensor* tensors_dev, const mtd_adamw_tensor* tensors_host, int count,

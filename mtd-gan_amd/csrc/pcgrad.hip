@@ -113,10 +113,10 @@ __global__ void pcgrad_coeff_kernel(const double* __restrict__ gram, const int* 
 }
 
 __global__ __launch_bounds__(256) void combine_kernel(Vecs v, int T, long long n4, long long n, const float* __restrict__ coeff,
-                                                      float* __restrict__ merged) {
+                                                      float* __restrict__ merged, float scale = 1.f) {
     float w[MAXT];
 #pragma unroll
-    for (int a = 0; a < MAXT; ++a) w[a] = (a < T) ? coeff[a] : 0.f;
+    for (int a = 0; a < MAXT; ++a) w[a] = (a < T) ? scale * coeff[a] : 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -185,6 +185,33 @@ extern "C" int mtd_pcgrad_combine(const float* g0, const float* g1, const float*
     long long want = (n4 + 255) / 256;
     int blocks = (int)(want < 4096 ? (want < 1 ? 1 : want) : 4096);
     hipLaunchKernelGGL(combine_kernel, dim3(blocks), dim3(256), 0, s, v, T, n4, n, coeff_out, merged);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+/* ---- the two halves of mtd_pcgrad_combine on their own (module/pcgrad.py's optimizer wrapper: one coefficient replay
+ * over the whole flat vector, then one axpy per run of parameters with the same reduction) ---- */
+extern "C" int mtd_pcgrad_coeff(const double* gram, const int* orders, int T, float* coeff_out, void* stream) {
+    if (T <= 0 || T > MAXT || !gram || !orders || !coeff_out) return MTD_EINVAL;
+    hipLaunchKernelGGL(pcgrad_coeff_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gram, orders, T, coeff_out);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_pcgrad_axpy(const float* g0, const float* g1, const float* g2, const float* g3, int T, long long n,
+                               const float* coeff, float scale, float* merged, void* stream) {
+    if (T <= 0 || T > MAXT || n <= 0 || !coeff || !merged || !g0) return MTD_EINVAL;
+    Vecs v;
+    v.g[0] = g0; v.g[1] = g1; v.g[2] = g2; v.g[3] = g3;
+    for (int a = 0; a < T; ++a) {
+        if (!v.g[a]) return MTD_EINVAL;
+        if (!aligned16(v.g[a])) return MTD_EALIGN;
+    }
+    if (!aligned16(merged)) return MTD_EALIGN;
+    const long long n4 = n / 4;
+    const long long want = (n4 + 255) / 256;
+    const int blocks = (int)(want < 4096 ? (want < 1 ? 1 : want) : 4096);
+    hipLaunchKernelGGL(combine_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, T, n4, n, coeff, merged, scale);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }

@@ -730,6 +730,23 @@ def pcgrad_combine(vecs, gram, orders_dev, merged):
     return coeff
 
 
+def pcgrad_coeff(gram, orders_dev, T):
+    """Projection replay on the Gram matrix alone: T coefficients w with sum_i pc_i = sum_k w_k g_k (device tensor)."""
+    coeff = torch.empty(4, dtype=torch.float32, device=gram.device)
+    optr = orders_dev if isinstance(orders_dev, int) else orders_dev.data_ptr()
+    check(_lib.lib().mtd_pcgrad_coeff(gram.data_ptr(), optr, T, coeff.data_ptr(), stream_ptr()), "mtd_pcgrad_coeff")
+    return coeff
+
+
+def pcgrad_axpy(vecs, coeff, scale, merged):
+    """merged = scale * sum_k coeff[k] * vecs[k] (flat fp32 views of equal length, 16-byte aligned)."""
+    T, n = len(vecs), vecs[0].numel()
+    ptrs = [v.data_ptr() for v in vecs] + [None] * (4 - T)
+    check(_lib.lib().mtd_pcgrad_axpy(ptrs[0], ptrs[1], ptrs[2], ptrs[3], T, n, coeff.data_ptr(), float(scale), merged.data_ptr(), stream_ptr()),
+          "mtd_pcgrad_axpy")
+    return merged
+
+
 def adamw_multi_dyn(params, grads, exp_avg, exp_avg_sq, beta1, beta2, eps, dyn_ptr):
     L = _lib.lib()
     structs = []

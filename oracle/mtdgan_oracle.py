@@ -25,6 +25,7 @@ Reference anchors (file:line under /root/reference):
   charbonnier / edge_loss losses.py:99-138
   d_loss / g_loss         arch/Ours/networks.py:1957-2009
   pcgrad_*                module/weight_methods.py:429-468
+  pcgrad_wrapper_merge    module/pcgrad.py:50-69 (the optimizer wrapper's projection + mean / sum reduction)
   adamw_step              train.py:122-126, optimizers.py:8-9 (torch.optim.AdamW)
   train_step              engine.py:33-55
   psnr / ssim / rmse      metrics.py:172-244
@@ -455,6 +456,28 @@ def shuffle_orders(T, rng=random):
         rng.shuffle(idx)
         orders.append(list(idx))
     return orders
+
+
+def pcgrad_wrapper_merge(grads, has_grads, reduction="mean", rng=random):
+    """module/pcgrad.py:50-69 restated on flat vectors.  grads: T flat gradients over ALL optimizer parameters (zeros
+    where an objective does not reach a parameter), has_grads: T flat 0/1 masks.  The projection runs over the whole
+    vector with one cumulative in-place shuffle of the task list per i; elements every objective reaches get the mean
+    of the projected gradients (`if self._reduction:` is truthy for 'mean' and 'sum' alike), the others their sum."""
+    if not reduction:
+        raise ValueError("invalid reduction method")
+    shared = torch.stack(has_grads).prod(0).bool()
+    order = list(grads)
+    pc = [g.clone() for g in grads]
+    for gi in pc:
+        rng.shuffle(order)
+        for gj in order:
+            d = torch.dot(gi, gj)
+            if d < 0:
+                gi -= d * gj / (gj.norm() ** 2)
+    merged = torch.zeros_like(grads[0])
+    merged[shared] = torch.stack([g[shared] for g in pc]).mean(dim=0)
+    merged[~shared] = torch.stack([g[~shared] for g in pc]).sum(dim=0)
+    return merged
 
 
 # ----------------------------------------------------------------------------------------------

@@ -18,6 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
 import _refboot  # noqa: E402
+import rng_tape  # noqa: E402
 
 _refboot.boot()
 import mtdgan_oracle as orc  # noqa: E402
@@ -301,8 +302,12 @@ def main():
     torch.manual_seed(2024)
     np.random.seed(2024)
     random.seed(2024)
-    m = MTD_GAN_Method()
+    tape = []
+    with rng_tape.recording(tape) as draws:
+        m = MTD_GAN_Method()
     init_sd = {k: v.clone() for k, v in m.state_dict().items()}
+    derivation = rng_tape.derive(init_sd, draws)
+    del draws
     m.Discriminator.c_drop = RecDrop(0.3)
     wm = WeightMethods(method="pcgrad", n_tasks=3, device=torch.device("cpu"))
     oD = torch.optim.AdamW([dict(params=m.Discriminator.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4),
@@ -326,6 +331,109 @@ def main():
             close(v, stats[k], 1e-4, "anchor " + k, atol=1e-7)
     with open(os.path.join(GOLD, "config1_anchor.json"), "w") as f:
         json.dump(dict(stats=stats, known=known), f)
+    # ---- 6b. what a machine without the reference needs to REPLAY this run (tests/test_step_gpu.py): the construction's
+    # random draws as a tape (oracle/rng_tape.py), float64 checksums of the 326 initial tensors and of the two input
+    # batches, the five dropout masks the step drew (bit-packed keep flags), the PCGrad orders.
+    torch.manual_seed(2024)
+    re_sd = rng_tape.replay(tape, derivation)
+    for k, v in init_sd.items():
+        assert torch.equal(re_sd[k], v), "tape replay != reference construction: " + k
+    rx, ry = torch.rand(16, 1, 64, 64), torch.rand(16, 1, 64, 64)
+    assert torch.equal(rx, loader[0]["n_20"]) and torch.equal(ry, loader[0]["n_100"])
+    masks_rec = m.Discriminator.c_drop.rec
+    assert len(masks_rec) == 5 and all(tuple(k.shape) == (16, 512) for k in masks_rec)
+    keep = np.stack([(k > 0).numpy() for k in masks_rec])
+    assert all(torch.equal(k, torch.from_numpy(kp).float() / 0.7) for k, kp in zip(masks_rec, keep))
+    np.savez_compressed(os.path.join(GOLD, "config1_replay_masks.npz"), keep_bits=np.packbits(keep.reshape(-1)))
+    with open(os.path.join(GOLD, "config1_replay.json"), "w") as f:
+        json.dump(dict(seed=2024, tape=tape, derivation=derivation, checksums={k: rng_tape.checksum(v) for k, v in init_sd.items()},
+                       x_checksum=rng_tape.checksum(rx), y_checksum=rng_tape.checksum(ry), orders=orders, stats=stats,
+                       lr=1e-4, patches=16, batch_size_arg=2), f)
+
+    # ------------------------------------------------------------------ 7. module/pcgrad.py::PCGrad (the optimizer wrapper, a13b)
+    print("module/pcgrad.py PCGrad wrapper")
+    from module import pcgrad as ref_pcgrad
+    import torch.nn as nn
+    import torch.optim as optim
+    cases = []
+
+    def run_case(tag, net, objectives_fn, rseed, x, ys):
+        sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+        pc = ref_pcgrad.PCGrad(optim.Adam(net.parameters()))
+        pc.zero_grad()
+        random.seed(rseed)
+        pc.pc_backward(objectives_fn(net, x, ys))
+        ref_grads = [p.grad.clone() for p in net.parameters()]
+        # the oracle restatement on the same flat vectors (its own backward passes, same shuffle stream)
+        params = list(net.parameters())
+        flat, has = [], []
+        for obj in objectives_fn(net, x, ys):
+            gs = torch.autograd.grad(obj, params, retain_graph=True, allow_unused=True)
+            flat.append(torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(gs, params)]))
+            has.append(torch.cat([(torch.ones_like(p) if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(gs, params)]))
+        random.seed(rseed)
+        merged = orc.pcgrad_wrapper_merge(flat, has)
+        close(merged, torch.cat([g.reshape(-1) for g in ref_grads]), 1e-6, f"wrapper {tag}: oracle == reference")
+        cases.append(dict(tag=tag, rseed=rseed, state={k: v.tolist() for k, v in sd0.items()}, x=x.tolist(), ys=[y.tolist() for y in ys],
+                          grads={n: g.tolist() for (n, _), g in zip(net.named_parameters(), ref_grads)}))
+
+    # (a) + (b): the reference file's own self-test nets and losses (pcgrad.py:144-195), torch.manual_seed(4)
+    torch.manual_seed(4)
+    x, y = torch.randn(2, 3), torch.randn(2, 4)
+    run_case("TestNet", ref_pcgrad.TestNet(), lambda net, x, ys: [nn.L1Loss()(net(x), ys[0]), nn.MSELoss()(net(x), ys[0])], 1, x, [y])
+    torch.manual_seed(4)
+    x, y = torch.randn(2, 3), torch.randn(2, 4)
+    run_case("MultiHeadTestNet", ref_pcgrad.MultiHeadTestNet(),
+             lambda net, x, ys: [nn.MSELoss()(net(x)[0], ys[0]), nn.MSELoss()(net(x)[1], ys[0])], 2, x, [y])
+    # (c) three objectives, two of them in conflict on the shared trunk and on head 1, the third alone on head 2
+    torch.manual_seed(5)
+    x, y1, y2 = torch.randn(8, 3), torch.randn(8, 4), torch.randn(8, 4)
+    run_case("MultiHeadTestNet/3 objectives", ref_pcgrad.MultiHeadTestNet(),
+             lambda net, x, ys: [nn.MSELoss()(net(x)[0], ys[0]), nn.MSELoss()(net(x)[0], -ys[0] + 0.1), nn.L1Loss()(net(x)[1], ys[1])], 3, x, [y1, y2])
+    with open(os.path.join(GOLD, "pcgrad_wrapper.json"), "w") as f:
+        json.dump(cases, f)
+
+    # ------------------------------------------------------------------ 8. Full step with seeded fill at BASELINE size (B=32)
+    print("full step (seeded fill, B=32, lr 1e-4) + generator PSNR after the step")
+    gold32 = {}
+    for B in (2, 32):
+        x32, y32 = orc.synthetic_ldct(B, seed=1234)
+        model = MTD_GAN_Method()
+        model.load_state_dict(full)
+        masksB = mask_seq(5, B, seed=33)
+        model.Discriminator.c_drop = RecDrop(0.3, inject=masksB)
+        wmB = WeightMethods("pcgrad", n_tasks=3, device=torch.device("cpu"))
+        oD = torch.optim.AdamW([dict(params=model.Discriminator.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4),
+                                dict(params=wmB.parameters(), lr=0.025, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)])
+        oG = torch.optim.AdamW(model.Generator.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+        random.seed(77)
+        rstate = random.getstate()
+        statsB = engine.train_MTD_GAN_Ours(model, [dict(n_20=x32, n_100=y32)], oG, oD, torch.device("cpu"), 0, 1, B, wmB)
+        random.setstate(rstate)
+        ordersB = orc.shuffle_orders(3)
+        with torch.no_grad():
+            pred = model.Generator(x32)                      # the generator AFTER its update (SURVEY 8d config 3 acceptance)
+        post_metrics = dict(psnr=float(metrics.compute_PSNR(x32, y32, pred.clip(0, 1))[2]), ssim=float(metrics.compute_SSIM(x32, y32, pred.clip(0, 1))[2]),
+                            rmse=float(metrics.compute_RMSE(x32, y32, pred.clip(0, 1))[2]))
+        if B == 2:
+            gold32["b2_post_metrics"] = post_metrics
+            gold32["b2_post_pred_sample"] = pred[:, 0, ::8, ::8].tolist()
+            continue
+        ost = {k: v.clone() for k, v in full.items()}
+        res = orc.train_step(ost, {}, x32, y32, masksB, ordersB, lr=1e-4)
+        close(sum(res["d_losses"]), statsB["d_loss"], 1e-5, "B=32 step d_loss")
+        close(res["g_loss"], statsB["g_loss"], 1e-5, "B=32 step g_loss")
+        post = model.state_dict()
+        worst = max((ost[k] - post[k]).abs().max().item() / (post[k].abs().max().item() + 1e-30) for k in post)
+        print(f"  B=32 post-step state (326 tensors) oracle vs reference worst rel {worst:.3e}")
+        assert worst < 1e-5
+        close(orc.psnr(orc.generator_forward(ost, x32, "Generator.").clip(0, 1), y32), post_metrics["psnr"], 1e-6, "B=32 post-step PSNR (oracle)")
+        samp = {k: [post[k].reshape(-1)[i].item() for i in sample_idx(post[k].numel(), 4)] for k in sorted(post)}
+        gold32.update(stats=statsB, orders=ordersB, gram=res["gram"], pc_weights=res["pc_weights"], d_losses=res["d_losses"].tolist(),
+                      d_grad_norms=res["d_grad_norms"], g_grad_norms=res["g_grad_norms"], post_samples=samp, post_metrics=post_metrics,
+                      post_pred_sample=pred[:, 0, ::16, ::16].tolist(), lr=1e-4, mask_seed=33, gfill=7, dfill=9, batch=32, data_seed=1234)
+    with open(os.path.join(GOLD, "step_seeded_b32.json"), "w") as f:
+        json.dump(gold32, f)
     print(f"all pins OK in {time.time() - t0:.1f}s")
 
 

@@ -126,3 +126,64 @@ def test_whole_slice_generator_and_pixel_metrics_golden():
         assert abs(orc.psnr(a, y).item() - z["psnr"][i]) < 1e-4
         assert abs(orc.ssim(a, y).item() - z["ssim"][i]) < 1e-5
         assert abs(orc.rmse(a, y).item() - z["rmse"][i]) < 1e-6
+
+
+def test_pcgrad_optimizer_wrapper_matches_reference_vectors():
+    """module/pcgrad.py::PCGrad (a13b): the oracle's restatement on the reference's own self-test nets."""
+    import torch.nn as nn
+    cases = json.load(open(os.path.join(GOLD, "pcgrad_wrapper.json")))
+    assert [c["tag"] for c in cases] == ["TestNet", "MultiHeadTestNet", "MultiHeadTestNet/3 objectives"]
+    for c in cases:
+        st = {k: torch.tensor(v, requires_grad=True) for k, v in c["state"].items()}
+        x, ys = torch.tensor(c["x"]), [torch.tensor(y) for y in c["ys"]]
+        lin = lambda pre, t: torch.nn.functional.linear(t, st[pre + ".weight"], st[pre + ".bias"])
+        if c["tag"] == "TestNet":
+            objs = [nn.L1Loss()(lin("_linear", x), ys[0]), nn.MSELoss()(lin("_linear", x), ys[0])]
+        else:
+            feat = lin("_linear", x)
+            h1, h2 = lin("_head1", feat), lin("_head2", feat)
+            objs = [nn.MSELoss()(h1, ys[0]), nn.MSELoss()(h2, ys[0])] if len(ys) == 1 else \
+                   [nn.MSELoss()(h1, ys[0]), nn.MSELoss()(h1, -ys[0] + 0.1), nn.L1Loss()(h2, ys[1])]
+        params = list(st.values())
+        flat, has = [], []
+        for obj in objs:
+            gs = torch.autograd.grad(obj, params, retain_graph=True, allow_unused=True)
+            flat.append(torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(gs, params)]))
+            has.append(torch.cat([(torch.ones_like(p) if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(gs, params)]))
+        random.seed(c["rseed"])
+        merged = orc.pcgrad_wrapper_merge(flat, has)
+        ref = torch.cat([torch.tensor(c["grads"][k]).reshape(-1) for k in c["state"]])
+        assert rel(merged, ref) < 1e-6, c["tag"]
+
+
+def test_config1_replay_and_oracle_step():
+    """BASELINE configs[0]: the reference's default-init state rebuilt from the recorded draw tape (checked against the
+    reference's per-tensor checksums inside load()), then the oracle's step on it against the reference's 17 scalars."""
+    import replay_config1
+    z, state, x, y, masks = replay_config1.load()
+    random.seed(z["seed"])
+    orders = orc.shuffle_orders(3)
+    assert orders == z["orders"]
+    res = orc.train_step(state, {}, x, y, masks, orders, lr=z["lr"])
+    got = {"d_loss": float(sum(res["d_losses"])), "g_loss": res["g_loss"], **res["d_details"], **res["g_details"]}
+    for k, v in z["stats"].items():
+        if k != "lr":
+            assert abs(got[k] - v) <= 1e-5 * abs(v) + 2e-7, (k, got[k], v)
+
+
+def test_full_step_b32_matches_reference_vectors():
+    """BASELINE configs[2] size: the seeded-fill step at 32 patches and the generator's PSNR after the step."""
+    z = json.load(open(os.path.join(GOLD, "step_seeded_b32.json")))
+    full = {"Generator." + k: v for k, v in orc.seeded_fill(orc.g_param_shapes(), seed=z["gfill"]).items()}
+    full.update({"Discriminator." + k: v for k, v in orc.seeded_fill(orc.d_state_shapes(), seed=z["dfill"]).items()})
+    x, y = orc.synthetic_ldct(z["batch"], seed=z["data_seed"])
+    g = torch.Generator().manual_seed(z["mask_seed"])
+    masks = [(torch.rand(z["batch"], 512, generator=g) >= 0.3).float() / 0.7 for _ in range(5)]
+    res = orc.train_step(full, {}, x, y, masks, z["orders"], lr=z["lr"])
+    assert rel(res["d_losses"], z["d_losses"]) < 1e-5
+    for k, v in {**res["d_details"], **res["g_details"]}.items():
+        assert abs(v - z["stats"][k]) <= 2e-4 * abs(z["stats"][k]) + 2e-7, k
+    with torch.no_grad():
+        pred = orc.generator_forward(full, x, "Generator.")
+    assert abs(float(orc.psnr(pred.clip(0, 1), y)) - z["post_metrics"]["psnr"]) < 1e-4
+    assert rel(pred[:, 0, ::16, ::16], torch.tensor(z["post_pred_sample"])) < 1e-5

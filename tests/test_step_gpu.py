@@ -147,11 +147,160 @@ def test_full_step_vs_golden_and_oracle(hip_lib):
                 bad.append((k, i, t[idx].item(), s))
     assert len(bad) <= 0.01 * 4 * len(z["post_samples"]), bad[:10]      # sign flips of ~0 gradients are the only tolerated misses
     assert torch.equal(post["Discriminator.c_fc.weight_orig"].cpu(), full["Discriminator.c_fc.weight_orig"])   # frozen (quirk 1)
+    # ---- SURVEY 8d config-3 acceptance: PSNR of the generator AFTER its update against the reference's (metrics.py:184-197)
+    z32 = json.load(open(os.path.join(GOLD, "step_seeded_b32.json")))
+    _post_step_psnr(m, x, y, z32["b2_post_metrics"], z32["b2_post_pred_sample"], 8)
+
+
+def _post_step_psnr(m, x, y, want, pred_sample, stride):
+    from mtd_gan_amd import metrics as M
+    with torch.no_grad():
+        pred = m.Generator(x.cuda())
+    got = M.compute_PSNR(x.cuda(), y.cuda(), pred.clip(0, 1))[2]
+    assert abs(float(got) - want["psnr"]) <= 0.01, (float(got), want["psnr"])                  # north_star: within 0.01 dB
+    assert abs(float(M.compute_RMSE(x.cuda(), y.cuda(), pred.clip(0, 1))[2]) - want["rmse"]) <= TOL * want["rmse"]
+    assert rel(pred[:, 0, ::stride, ::stride], torch.tensor(pred_sample)) < TOL
+
+
+def test_full_step_b32_vs_golden(hip_lib):
+    """BASELINE configs[2] at its full size: one iteration on 32 patches from the seeded-fill state (O(1) activations, all
+    three task gradients non-degenerate) against the step the reference itself ran -- 17 logged scalars, sampled
+    post-step parameters and spectral-norm vectors, the Gram matrix of the task gradients, the generator's PSNR after
+    the step.  The D optimizer has the reference's two-group layout (train.py:122-124: second group empty, lr 0.025)."""
+    from mtd_gan_amd import engine
+    from mtd_gan_amd.module.weight_methods import WeightMethods
+    from mtd_gan_amd.optimizers import FusedAdamW
+    z = json.load(open(os.path.join(GOLD, "step_seeded_b32.json")))
+    m, full, masks, _ = _model(32)
+    m.Discriminator._inject_masks = [k.clone() for k in masks]
+    x, y = orc.synthetic_ldct(32, seed=z["data_seed"])
+    wm = WeightMethods("pcgrad", n_tasks=3, device=torch.device("cuda"))
+    kw = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+    oD = FusedAdamW([dict(params=m.Discriminator.parameters(), lr=z["lr"], **kw), dict(params=wm.parameters(), lr=0.025, **kw)])
+    oG = FusedAdamW(m.Generator.parameters(), lr=z["lr"], **kw)
+    assert len(oD.param_groups) == 2 and oD.param_groups[1]["params"] == []
+    random.seed(77)
+    captured = {}
+    real_d_loss = m.d_loss
+
+    def d_loss(a, b):
+        out = real_d_loss(a, b)
+        captured["tape"] = out[0]._mtd_tape
+        return out
+    m.d_loss = d_loss
+    stats = engine.train_MTD_GAN_Ours(m, [dict(n_20=x, n_100=y)], oG, oD, torch.device("cuda"), 0, 0, 32, wm)
+    for k, v in z["stats"].items():
+        assert abs(stats[k] - v) <= TOL * abs(v) + 2e-6, (k, stats[k], v)
+    tape = captured["tape"]
+    assert tape.orders == z["orders"]
+    gram_ref = torch.tensor(z["gram"], dtype=torch.float64)
+    scale = torch.sqrt(torch.outer(gram_ref.diag(), gram_ref.diag()))
+    assert ((tape.gram.reshape(3, 3).cpu() - gram_ref).abs() / scale).max().item() < TOL
+    assert rel(tape.coeff[:3], torch.tensor(z["pc_weights"])) < TOL
+    post = m.state_dict()
+    bad = []
+    for k, samples in z["post_samples"].items():
+        t, t0 = post[k].reshape(-1).cpu(), full[k].reshape(-1)
+        for i, sv in enumerate(samples):
+            idx = (i * 2654435761 + 12345) % t.numel()
+            if k.endswith(("weight_u", "weight_v")):
+                ok = abs(t[idx].item() - sv) <= TOL * max(abs(sv), 1e-3)
+            else:             # a first AdamW step moves a weight by lr * sign(gradient): compare the updates
+                ok = abs((t[idx].item() - t0[idx].item()) - (sv - t0[idx].item())) <= 0.05 * z["lr"] + 1e-9
+            if not ok:
+                bad.append((k, i, t[idx].item(), sv))
+    assert len(bad) <= 0.01 * 4 * len(z["post_samples"]), bad[:10]
+    assert torch.equal(post["Discriminator.c_fc.weight_orig"].cpu(), full["Discriminator.c_fc.weight_orig"])
+    _post_step_psnr(m, x, y, z["post_metrics"], z["post_pred_sample"], 16)
+
+
+def test_config1_anchor_on_the_hip_path(hip_lib):
+    """BASELINE configs[0] (`MTD_GAN_Method`, --batch-size 2 => 16 patches, 1 train step; a CPU run in the reference): the
+    same run on the HIP path.  The reference's default-init state (seeds 2024) is rebuilt from the recorded draw tape and
+    verified against per-tensor checksums, the inputs continue the same generator stream, the five dropout masks the
+    reference drew are injected, `random` is seeded as the reference seeded it; the 17 logged scalars must match the
+    reference's (tests/golden/config1_replay.json == config1_anchor.json == BASELINE.md section 3)."""
+    import replay_config1
+    from mtd_gan_amd import engine
+    from mtd_gan_amd.arch.Ours.networks import MTD_GAN_Method
+    from mtd_gan_amd.module.weight_methods import WeightMethods
+    from mtd_gan_amd.optimizers import FusedAdamW
+    z, state, x, y, masks = replay_config1.load()
+    anchor = json.load(open(os.path.join(GOLD, "config1_anchor.json")))
+    assert anchor["stats"] == z["stats"]
+    m = MTD_GAN_Method()
+    m.load_state_dict(state)
+    m.cuda().train()
+    m.Discriminator._inject_masks = [k.clone() for k in masks]
+    dev = torch.device("cuda")
+    wm = WeightMethods(method="pcgrad", n_tasks=3, device=dev)
+    kw = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+    oD = FusedAdamW([dict(params=m.Discriminator.parameters(), lr=z["lr"], **kw), dict(params=wm.parameters(), lr=0.025, **kw)])
+    oG = FusedAdamW(m.Generator.parameters(), lr=z["lr"], **kw)
+    random.seed(z["seed"])
+    stats = engine.train_MTD_GAN_Ours(m, [dict(n_20=x, n_100=y)], oG, oD, dev, 0, 0, z["batch_size_arg"], wm)
+    assert list(stats.keys()) == list(z["stats"].keys())                       # same 17 keys, same order
+    for k, v in z["stats"].items():
+        assert abs(stats[k] - v) <= TOL * abs(v) + 2e-6, (k, stats[k], v)
+    for k, v in anchor["known"].items():                                       # BASELINE.md's known answer
+        assert abs(stats[k] - v) <= TOL * abs(v), (k, stats[k], v)
+    assert D_frozen(m, state)
+
+
+def D_frozen(m, state):
+    post = m.state_dict()
+    return torch.equal(post["Discriminator.c_fc.weight_orig"].cpu(), state["Discriminator.c_fc.weight_orig"])
+
+
+def test_pcgrad_optimizer_wrapper_vs_reference(hip_lib):
+    """module/pcgrad.py::PCGrad (SURVEY a13b) on the HIP Gram / coefficient / axpy kernels against the gradients the
+    reference class produced on its own self-test nets (pcgrad.py:144-195) and on a three-objective conflict case."""
+    import torch.nn as nn
+    from mtd_gan_amd.module.pcgrad import PCGrad
+    from mtd_gan_amd.optimizers import FusedAdamW
+    cases = json.load(open(os.path.join(GOLD, "pcgrad_wrapper.json")))
+
+    class Net(nn.Module):
+        def __init__(self, heads):
+            super().__init__()
+            self._linear = nn.Linear(3, 2 if heads else 4)
+            if heads:
+                self._head1, self._head2 = nn.Linear(2, 4), nn.Linear(2, 4)
+
+        def forward(self, t):
+            f = self._linear(t)
+            return (self._head1(f), self._head2(f)) if hasattr(self, "_head1") else f
+    for c in cases:
+        net = Net(c["tag"] != "TestNet")
+        net.load_state_dict({k: torch.tensor(v) for k, v in c["state"].items()})
+        net.cuda()
+        x, ys = torch.tensor(c["x"]).cuda(), [torch.tensor(v).cuda() for v in c["ys"]]
+        pc = PCGrad(FusedAdamW(net.parameters(), lr=1e-3))
+        pc.zero_grad()
+        if c["tag"] == "TestNet":
+            objs = [nn.L1Loss()(net(x), ys[0]), nn.MSELoss()(net(x), ys[0])]
+        elif len(ys) == 1:
+            objs = [nn.MSELoss()(net(x)[0], ys[0]), nn.MSELoss()(net(x)[1], ys[0])]
+        else:
+            objs = [nn.MSELoss()(net(x)[0], ys[0]), nn.MSELoss()(net(x)[0], -ys[0] + 0.1), nn.L1Loss()(net(x)[1], ys[1])]
+        random.seed(c["rseed"])
+        pc.pc_backward(objs)
+        for n, p in net.named_parameters():
+            assert p.grad is not None and rel(p.grad, torch.tensor(c["grads"][n])) < 1e-4, (c["tag"], n)
+        before = [p.detach().clone() for p in net.parameters()]
+        pc.step()                                                       # the wrapped optimizer consumes the written gradients
+        assert all(not torch.equal(a, p.detach()) for a, p in zip(before, net.parameters()))
+        pc.zero_grad()
+        assert all(p.grad is None for p in net.parameters())
+    with pytest.raises(ValueError):
+        PCGrad(FusedAdamW(net.parameters(), lr=1e-3), reduction="").pc_backward([nn.MSELoss()(net(x)[0], ys[0])])
 
 
 def test_d_step_task_gradients_vs_oracle(hip_lib):
-    """The three per-task shared gradients (what PCGrad projects), their Gram matrix and the merged
-    gradient against the float64 oracle."""
+    """The three per-task shared gradients (what PCGrad projects), their Gram matrix, the merged gradient and the
+    task-specific gradients against the float64 oracle, PER TENSOR (40 shared tensors x 3 tasks, 66 task-specific ones):
+    error relative to that tensor's own max-abs, bound max(1e-3, 2 x the error of the reference's own fp32 CPU
+    arithmetic against float64 on the same tensor) -- the criterion of DESIGN.md section 4, applied where it is earned."""
     from mtd_gan_amd.module.weight_methods import WeightMethods
     m, full, masks, z = _model(2)
     m.Discriminator._inject_masks = [k.clone() for k in masks[:4]]
@@ -163,29 +312,55 @@ def test_d_step_task_gradients_vs_oracle(hip_lib):
     wm.backward(losses=losses, shared_parameters=list(D.shared_parameters()), task_specific_parameters=list(D.task_specific_parameters()),
                 last_shared_parameters=list(D.last_shared_parameters()))
     tape = losses._mtd_tape
-    # oracle, fp64
-    st = {k: v.double().clone() for k, v in full.items()}
     shared = ["Discriminator." + n for n in orc.d_shared_names()]
     tspec = ["Discriminator." + n for n in orc.d_task_specific_names()]
-    for n in shared + tspec:
-        st[n] = st[n].requires_grad_(True)
-    lo, _, _ = orc.d_loss(st, x.double(), y.double(), [k.double() for k in masks[:4]])
-    assert rel(losses, lo.detach()) < TOL
-    sp = [st[n] for n in shared]
-    flat = [torch.cat([g.reshape(-1) for g in torch.autograd.grad(lo[i], sp, retain_graph=True)]) for i in range(3)]
-    ts = torch.autograd.grad(lo.sum(), [st[n] for n in tspec])
+
+    def oracle(dtype):
+        st = {k: v.to(dtype).clone() for k, v in full.items()}
+        for n in shared + tspec:
+            st[n] = st[n].requires_grad_(True)
+        lo, _, _ = orc.d_loss(st, x.to(dtype), y.to(dtype), [k.to(dtype) for k in masks[:4]])
+        sp = [st[n] for n in shared]
+        per_task = [torch.autograd.grad(lo[i], sp, retain_graph=True) for i in range(3)]
+        ts = torch.autograd.grad(lo.sum(), [st[n] for n in tspec])
+        return lo.detach(), per_task, ts
+    lo, g64, ts64 = oracle(torch.float64)
+    _, g32, ts32 = oracle(torch.float32)
+    assert rel(losses, lo) < TOL
+    sizes = [g.numel() for g in g64[0]]
+    bad, worst = [], 0.0
+
+    def check(tag, hip, r64, r32):
+        nonlocal worst
+        den = r64.abs().max().item() + 1e-30
+        e_hip = (hip.double().cpu() - r64).abs().max().item() / den
+        e_cpu = (r32.double() - r64).abs().max().item() / den
+        worst = max(worst, e_hip)
+        if e_hip > max(TOL, 2 * e_cpu):
+            bad.append((tag, f"{e_hip:.2e}", f"cpu32 {e_cpu:.2e}"))
     for i in range(3):
-        assert rel(tape.task_vectors[i], flat[i]) < 5e-3, i
+        ofs = 0
+        for n, sz, r64, r32 in zip(shared, sizes, g64[i], g32[i]):
+            check(f"task{i} {n}", tape.task_vectors[i][ofs:ofs + sz].reshape(r64.shape), r64, r32)
+            ofs += sz
+    names = {id(p): n for n, p in D.named_parameters()}
+    for p, r64, r32 in zip(D.task_specific_parameters(), ts64, ts32):
+        check("task-specific " + names[id(p)], p.grad, r64, r32)
+    flat = [torch.cat([g.reshape(-1) for g in tg]) for tg in g64]
     gram_ref = torch.stack([torch.stack([torch.dot(a, b) for b in flat]) for a in flat])
     scale = torch.sqrt(torch.outer(gram_ref.diag(), gram_ref.diag()))
-    assert ((tape.gram.reshape(3, 3).cpu() - gram_ref).abs() / scale).max().item() < 5e-3        # relative to |g_a||g_b|
+    gram_err = ((tape.gram.reshape(3, 3).cpu() - gram_ref).abs() / scale).max().item()
     assert tape.orders == z["orders"]
     w = orc.pcgrad_coefficients(gram_ref.tolist(), tape.orders)
     merged_ref = sum(wk * f for wk, f in zip(w, flat))
-    assert rel(tape.task_vectors[3], merged_ref) < 5e-3
-    names = {id(p): n for n, p in D.named_parameters()}
-    for p, g in zip(D.task_specific_parameters(), ts):
-        assert rel(p.grad, g) < 5e-3, names[id(p)]
+    merged32 = sum(wk * torch.cat([g.reshape(-1) for g in tg]).double() for wk, tg in zip(w, g32))
+    ofs = 0
+    for n, sz in zip(shared, sizes):
+        check("merged " + n, tape.task_vectors[3][ofs:ofs + sz], merged_ref[ofs:ofs + sz], merged32[ofs:ofs + sz])
+        ofs += sz
+    print(f"per-tensor worst rel err vs fp64 oracle {worst:.2e}; Gram err relative to |g_a||g_b| {gram_err:.2e}; {len(bad)} over the bound")
+    assert not bad, bad[:12]
+    assert gram_err < TOL                                             # relative to |g_a||g_b|
     assert D.c_fc.weight_orig.grad is None
 
 
