@@ -130,7 +130,7 @@ def prof_collect(capacity):
     for r in buf[:min(n, capacity)]:
         names = IGEMM_CONFIGS if r.kernel == 0 else WGRAD_CONFIGS
         out.append({"kernel": names[r.cfg] if 0 <= r.cfg < len(names) else "?", "splitk": r.splitk, "M": r.M, "N": r.N,
-                    "C": r.C, "taps": r.taps, "flops": r.flops, "ms": r.ms})
+                    "C": r.C, "taps": r.taps, "flops": r.flops, "ms": r.ms, "bytes": r.bytes})
     return out
 
 
