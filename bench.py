@@ -226,8 +226,8 @@ def roofline_pass(wl, steps, pmc_tag):
     # its duration then says nothing about the kernel.  (profiles/*_kernel_stats_single_stream.csv: rocprofv3, same mode.)
     K.set_concurrency(False)
     step()
-    attach = K.prof_mode(-1)
     K.prof_enable(cap)
+    attach = K.prof_mode(-1)
     K.FLOP_COUNT = {}
     for _ in range(steps):
         step()
