@@ -85,6 +85,12 @@ typedef struct {
 
 size_t mtd_conv_igemm_ws_bytes(const mtd_conv_args* a);
 int mtd_conv_igemm(const mtd_conv_args* a, void* stream);
+/* Up to four launches of ONE shape (same pixels, N, C, taps) as one grid -- the four input-parity classes of a stride-2
+ * data gradient (arch/Ours/networks.py down{l}: Conv2d(k4, s2, p1) backward w.r.t. its input), each a 2x2-tap stride-1
+ * gather that writes every other pixel of the same output.  a[0..count) are complete argument sets; with split-K each
+ * needs its own workspace of mtd_conv_igemm_multi_ws_bytes(a, count) bytes.  No out2. */
+size_t mtd_conv_igemm_multi_ws_bytes(const mtd_conv_args* a, int count);
+int mtd_conv_igemm_multi(const mtd_conv_args* a, int count, void* stream);
 
 /* dst[(t*N + n)*C + c] = src[n*sn + c*sc + t]  for `count` weight tensors in one launch (table in device
  * memory + the same table on the host for sizing).  N and C multiples of 32, T <= 16. */

@@ -207,6 +207,8 @@ def lib():
     sig("mtd_window_patches", ci, vp, vp, ci, ci, ci, vp, vp, ci, cf, cf, ci, vp, vp, vp)
     sig("mtd_hu_window", ci, vp, ll, cf, cf, vp, vp)
     sig("mtd_prof_mode", ci, ci)
+    sig("mtd_conv_igemm_multi_ws_bytes", sz, C.POINTER(ConvArgs), ci)
+    sig("mtd_conv_igemm_multi", ci, C.POINTER(ConvArgs), ci, vp)
     sig("mtd_pcgrad_coeff", ci, vp, vp, ci, vp, vp)
     sig("mtd_pcgrad_axpy", ci, vp, vp, vp, vp, ci, ll, vp, cf, vp, vp)
     _lib = L
@@ -224,7 +226,7 @@ EXPORTS = [
     "mtd_prof_enable", "mtd_prof_collect", "mtd_conv_igemm_override", "mtd_conv_wgrad_override", "mtd_upload", "mtd_image_metrics_ws_bytes", "mtd_image_metrics", "mtd_rfft_rows_any", "mtd_spec_mix_any", "mtd_irfft_rows_any",
     "mtd_conv_wgrad_slabs", "mtd_conv_wgrad_slabs_rfft", "mtd_conv_wgrad_reduce_blocks", "mtd_conv_wgrad_reduce_multi", "mtd_spec_mix_wgrad_reduce_multi",
     "mtd_foreground_bbox", "mtd_window_patches", "mtd_hu_window", "mtd_add", "mtd_transpose64_multi", "mtd_upsample2x_bwd_masked",
-    "mtd_prof_mode", "mtd_pcgrad_coeff", "mtd_pcgrad_axpy",
+    "mtd_prof_mode", "mtd_pcgrad_coeff", "mtd_pcgrad_axpy", "mtd_conv_igemm_multi_ws_bytes", "mtd_conv_igemm_multi",
 ]
 
 

@@ -232,6 +232,72 @@ __global__ __launch_bounds__(256) void fwd_c1_kernel(const FwdParams p) {
     }
 }
 
+// C == 1 on whole image rows, every tap within one pixel of the output position (3x3 "same" layers: the discriminator's
+// conv11, the generator's encoder.0, the data gradient of decoder.0).  fwd_c1_kernel above pays, per pixel and thread,
+// an index decomposition (two integer divisions), nine bounds tests and nine 64-bit global addresses for 36 FMAs and one
+// 16-byte store: ~200 instructions per store, VALU-bound at 0.6-1.1 TB/s of output.  Here a workgroup owns R rows of
+// one image: the R + 2 input rows (zero halo) are staged in LDS once, a pixel costs nine LDS reads at immediate
+// offsets from three row pointers, the taps' weights sit in registers by NEIGHBOURHOOD position (zero where the
+// geometry has no tap), and the store addresses advance by constants.  Taps are summed in neighbourhood order (the
+// launch's tap order for a forward conv, its reverse for a data gradient).
+__global__ __launch_bounds__(256) void fwd_c1_tile_kernel(const FwdParams p, int R) {
+    extern __shared__ float c1tile[];
+    const mtd_conv_args& a = p.a;
+    const mtd_geom& g = a.g;
+    const int W = g.OW, TW2 = W + 2;
+    const int row0 = blockIdx.x * R;                       // first image row (over all images) of this workgroup
+    const int b = row0 / g.OH, y0 = row0 - b * g.OH;
+    for (int i = threadIdx.x; i < (R + 2) * TW2; i += 256) {
+        const int ry = i / TW2, rx = i - ry * TW2;
+        const int iy = y0 - 1 + ry, ix = rx - 1;
+        float v = 0.f;
+        if (((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW)) v = a.in[(((long long)b * g.IH + iy) * g.IW + ix) * a.in_ld];
+        c1tile[i] = v;
+    }
+    const int NQ = p.G, PL = 256 / NQ;
+    const int nq = threadIdx.x % NQ, pl = threadIdx.x / NQ;
+    const int n = nq * 4;
+    float w9[4][9], bias[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bias[j] = a.bias ? a.bias[n + j] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) w9[j][q] = 0.f;
+    }
+    for (int t = 0; t < p.T; ++t) {
+        const int q = (g.off_y + p.tap_dy[t] + 1) * 3 + (g.off_x + p.tap_dx[t] + 1);      // neighbourhood position of tap t
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float wv = a.w[(long long)(n + j) * a.w_sn + (long long)p.tap_kidx[t] * a.w_st];
+#pragma unroll
+            for (int qq = 0; qq < 9; ++qq)
+                if (qq == q) w9[j][qq] = wv;
+        }
+    }
+    const ScalePair sp = load_scale(a);
+    __syncthreads();
+    for (int ry = 0; ry < R; ++ry) {
+        const float* r0 = c1tile + ry * TW2 + pl;          // rows ry-1, ry, ry+1 of the tile, column rx - 1
+        const int m0 = (row0 + ry) * W;
+        const float sc = pick_scale(sp, m0);                // a paired pass switches scale at an image boundary
+        for (int rx = pl; rx < W; rx += PL, r0 += PL) {
+            const float v00 = r0[0], v01 = r0[1], v02 = r0[2];
+            const float v10 = r0[TW2], v11 = r0[TW2 + 1], v12 = r0[TW2 + 2];
+            const float v20 = r0[2 * TW2], v21 = r0[2 * TW2 + 1], v22 = r0[2 * TW2 + 2];
+            float acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s = 0.f;
+                s = fmaf(v00, w9[j][0], s); s = fmaf(v01, w9[j][1], s); s = fmaf(v02, w9[j][2], s);
+                s = fmaf(v10, w9[j][3], s); s = fmaf(v11, w9[j][4], s); s = fmaf(v12, w9[j][5], s);
+                s = fmaf(v20, w9[j][6], s); s = fmaf(v21, w9[j][7], s); s = fmaf(v22, w9[j][8], s);
+                acc[j] = s;
+            }
+            store_epilogue4(a, acc, sc, bias, (long long)m0 + rx, n, p.vec_store);
+        }
+    }
+}
+
 // N == 1: G = C/4 lanes per pixel, 64/G pixels per wave iteration
 __global__ __launch_bounds__(256) void fwd_n1_kernel(const FwdParams p, int nblk) {
     const mtd_conv_args& a = p.a;
@@ -521,6 +587,25 @@ extern "C" int mtd_conv_direct(const mtd_conv_args* a, void* stream) {
             if (ppb < PL) ppb = PL;
             p.ppb = (int)ppb;
             const int nblk = (int)((Mpix + ppb - 1) / ppb);
+            // whole-row tiles with the input rows in LDS where the geometry allows (see fwd_c1_tile_kernel)
+            bool near = g.in_sy == 1 && g.in_sx == 1 && g.OH == g.IH && g.OW == g.IW && identity && T <= 9;
+            bool seen[9] = {false, false, false, false, false, false, false, false, false};
+            for (int t = 0; t < T && near; ++t) {
+                const int dy = g.off_y + p.tap_dy[t], dx = g.off_x + p.tap_dx[t];
+                near = dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1 && !seen[(dy + 1) * 3 + dx + 1];
+                if (near) seen[(dy + 1) * 3 + dx + 1] = true;
+            }
+            static const int env_tile = [] { const char* e = getenv("MTD_C1_TILE"); return e ? atoi(e) : 1; }();
+            int R = 0;
+            if (near && env_tile && g.OW % PL == 0 && (a->scale2 == nullptr || a->scale_split % (g.OH * g.OW) == 0)) {
+                R = (int)(ppb / g.OW);
+                while (R > 1 && g.OH % R) --R;                                 // whole tiles per image
+                if (R < 1 || (long long)(R + 2) * (g.OW + 2) * 4 > 48 * 1024) R = 0;
+            }
+            if (R > 0) {
+                const size_t lds = (size_t)(R + 2) * (g.OW + 2) * sizeof(float);
+                hipLaunchKernelGGL(fwd_c1_tile_kernel, dim3((unsigned)((long long)g.B * g.OH / R)), dim3(256), lds, (hipStream_t)stream, p, R);
+            } else
             hipLaunchKernelGGL(fwd_c1_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
         } else {
             p.G = a->C / 4;

@@ -235,8 +235,9 @@ __device__ __forceinline__ void epilogue16(const IgemmParams& p, const f32x16& a
     }
 }
 
+// zk: this workgroup's split-K slice (blockIdx.z of a single launch; blockIdx.z % splitk of a multi launch, below)
 template <int WM, int WN, int WGM, int WGN>
-__global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(const IgemmParams p) {
+__device__ __forceinline__ void igemm_body(const IgemmParams& p, const int zk) {
     constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN;
     constexpr int PB = BN / 32;     // 16-byte weight vectors staged per thread and chunk (BN rows x 8 vectors)
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * BLD];
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(cons
     int tile_m, tile_n;
     tile_of(p, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int cbeg = blockIdx.z * p.c_per_split;
+    const int cbeg = zk * p.c_per_split;
     const int cend = min(a.C, cbeg + p.c_per_split);
     const int T = g.TH * g.TW;
 
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(cons
 
     // ---- epilogue
     if (p.splitk > 1) {
-        float* slab = a.ws + (long long)blockIdx.z * p.M * a.N;
+        float* slab = a.ws + (long long)zk * p.M * a.N;
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -441,6 +442,33 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(cons
             epilogue16<4>(p, acc[i][j], m0 + (wm * WM + i) * 32, lane, n, sp);
         }
     MTD_STAMP(61);
+}
+
+template <int WM, int WN, int WGM, int WGN>
+__global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_kernel(const IgemmParams p) {
+    igemm_body<WM, WN, WGM, WGN>(p, blockIdx.z);
+}
+
+// Several launches of ONE shape (same M, N, C, taps: the same plan) in one grid: blockIdx.z = set * splitk + split-K slice.
+// Each set has its own geometry offsets, operands and outputs -- the four input-parity classes of a stride-2 data
+// gradient (each a 2x2-tap stride-1 gather writing every other output pixel), which as four launches of 27-35 us ran at
+// 60-79 TFLOP/s, half of them split-K with an epilogue launch each.
+constexpr int MULTI_MAX = 4;
+struct IgemmMulti { IgemmParams p[MULTI_MAX]; };
+
+template <int WM, int WN, int WGM, int WGN>
+__global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_multi_kernel(const IgemmMulti mp) {
+    const int sk = mp.p[0].splitk;
+    const int set = __builtin_amdgcn_readfirstlane(blockIdx.z / sk);
+    const int zk = __builtin_amdgcn_readfirstlane(blockIdx.z - set * sk);
+    // (a switch, not an index: with a dynamic index into the kernel arguments the compiler moved the tap tables of the
+    // register-blocked tiles to scratch memory)
+    switch (set) {
+        case 0: igemm_body<WM, WN, WGM, WGN>(mp.p[0], zk); break;
+        case 1: igemm_body<WM, WN, WGM, WGN>(mp.p[1], zk); break;
+        case 2: igemm_body<WM, WN, WGM, WGN>(mp.p[2], zk); break;
+        default: igemm_body<WM, WN, WGM, WGN>(mp.p[3], zk); break;
+    }
 }
 
 
@@ -995,7 +1023,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_scalar_kernel(const Igemm
 // Four consecutive output channels of one pixel per thread: 16-byte slab reads with up to eight splits in flight (the
 // scalar loop above serialises one memory round trip per split), 16-byte operand reads and stores.  Needs every row
 // stride a multiple of 4 floats and 16-byte aligned bases (splitk_vec_ok); total < 2^31.
-__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IgemmParams p) {
+__device__ __forceinline__ void splitk_epilogue_body(const IgemmParams& p) {
     const mtd_conv_args& a = p.a;
     const unsigned total4 = (unsigned)(((long long)p.M * a.N) >> 2);
     const long long total = (long long)p.M * a.N;
@@ -1044,6 +1072,9 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IgemmParams 
     }
 }
 
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IgemmParams p) { splitk_epilogue_body(p); }
+__global__ __launch_bounds__(256) void splitk_epilogue_multi_kernel(const IgemmMulti mp) { splitk_epilogue_body(mp.p[blockIdx.y]); }
+
 bool splitk_vec_ok(const mtd_conv_args& a, long long M) {
     if (M * a.N >= (1ll << 31) || !aligned16(a.ws) || !aligned16(a.out) || (a.out_ld % 4)) return false;
     if (a.bias && !aligned16(a.bias)) return false;
@@ -1060,8 +1091,8 @@ constexpr int NCFG = 9;
 const int kCfgBM[NCFG] = {256, 128, 256, 64, 128, 32, 128, 256, 128};
 const int kCfgBN[NCFG] = {32, 32, 64, 64, 128, 128, 32, 32, 128};
 
-Plan make_plan(const mtd_conv_args& a) {
-    const long long M = geom_pixels(a.g);
+Plan make_plan(const mtd_conv_args& a, int sets = 1) {
+    const long long M = geom_pixels(a.g) * sets;        // tile choice by the pixels of the whole grid (all sets)
     Plan pl{};
     if (g_force_cfg >= 0 && g_force_cfg < NCFG && a.N % kCfgBN[g_force_cfg] == 0 && (g_force_cfg < 6 || g_force_cfg == 8 || a.g.TH * a.g.TW <= TB_MAXT)) {
         pl.cfg = g_force_cfg; pl.BM = kCfgBM[pl.cfg]; pl.BN = kCfgBN[pl.cfg];
@@ -1089,7 +1120,8 @@ Plan make_plan(const mtd_conv_args& a) {
     }
     pl.BM = kCfgBM[pl.cfg];
     pl.BN = kCfgBN[pl.cfg];
-    long long blocks = ((M + pl.BM - 1) / pl.BM) * (a.N / pl.BN);
+    const long long Mset = geom_pixels(a.g);
+    long long blocks = ((Mset + pl.BM - 1) / pl.BM) * (a.N / pl.BN) * sets;
     int chunks = a.C / KC;
     int sk = blocks <= 256 ? (int)(512 / blocks) : 1;      // fill ~2 workgroups per CU; never split a grid that already does
     if (blocks > 256 && blocks <= 512 && chunks * a.g.TH * a.g.TW <= 32) sk = 2;      // ... unless its workgroups are short (2x2-tap data gradients: -22 %)
@@ -1138,12 +1170,10 @@ extern "C" size_t mtd_conv_igemm_ws_bytes(const mtd_conv_args* a) {
     return (size_t)pl.splitk * (size_t)geom_pixels(a->g) * a->N * sizeof(float);
 }
 
-extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
-    if (!a) return MTD_EINVAL;
-    int rc = check_args(*a);
-    if (rc != MTD_OK) return rc;
-    Plan pl = make_plan(*a);
-    IgemmParams p;
+namespace {
+
+// everything of IgemmParams that follows from the arguments and the plan
+int fill_params(const mtd_conv_args* a, const Plan& pl, IgemmParams& p) {
     p.a = *a;
     p.M = (int)geom_pixels(a->g);
     p.splitk = pl.splitk;
@@ -1182,10 +1212,27 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
         size_t need = (size_t)pl.splitk * (size_t)p.M * a->N * sizeof(float);
         if (!a->ws || a->ws_bytes < need) return MTD_EWS;
     }
+    return MTD_OK;
+}
+
+double algorithmic_bytes(const mtd_conv_args* a) {
+    // input image, weight taps, result, epilogue operands -- each once
+    return 4.0 * ((double)a->g.B * a->g.IH * a->g.IW * a->C + (double)a->g.TH * a->g.TW * a->N * a->C +
+                  (double)geom_pixels(a->g) * a->N * (1 + (a->add1 != nullptr) + (a->add2 != nullptr) + (a->mask != nullptr) + (a->out2 != nullptr)));
+}
+
+}  // namespace
+
+extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
+    if (!a) return MTD_EINVAL;
+    int rc = check_args(*a);
+    if (rc != MTD_OK) return rc;
+    Plan pl = make_plan(*a);
+    IgemmParams p;
+    rc = fill_params(a, pl, p);
+    if (rc != MTD_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    // algorithmic bytes of the launch (profiler record): input image, weight taps, result, epilogue operands -- each once
-    const double alg_bytes = 4.0 * ((double)a->g.B * a->g.IH * a->g.IW * a->C + (double)a->g.TH * a->g.TW * a->N * a->C +
-                                    (double)p.M * a->N * (1 + (a->add1 != nullptr) + (a->add2 != nullptr) + (a->mask != nullptr) + (a->out2 != nullptr)));
+    const double alg_bytes = algorithmic_bytes(a);      // profiler record
     const bool gen_shape = a->C == 32 && a->g.TH * a->g.TW == 9 && p.M >= 32768;
     if ((g_force_cfg == -1 || g_force_cfg == 10) && gen_shape && c32t_eligible(*a)) {
         // generator-shaped layers on 64-pixel rows: halo tiles of four image rows, one persistent workgroup per CU
@@ -1238,6 +1285,79 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
         if (vec) hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, p);
         else hipLaunchKernelGGL(splitk_epilogue_scalar_kernel, dim3(blocks), dim3(256), 0, s, p);
         MTD_LAUNCH_CHECK();
+    }
+    return MTD_OK;
+}
+
+// Up to four launches of one shape as ONE grid (igemm_multi_kernel).  a[0..count): identical M, N, C, taps, weight view
+// strides and epilogue operand KINDS (each set brings its own pointers / geometry offsets); every set with split-K needs
+// its own workspace of mtd_conv_igemm_multi_ws_bytes(a, count) bytes.  Falls back to `count` single launches when the
+// plan picks a kernel without a multi form.
+extern "C" size_t mtd_conv_igemm_multi_ws_bytes(const mtd_conv_args* a, int count) {
+    if (!a || count < 1 || count > MULTI_MAX || check_args(a[0]) != MTD_OK) return 0;
+    Plan pl = make_plan(a[0], count);
+    if (pl.cfg > 5) pl = make_plan(a[0]);
+    if (pl.splitk <= 1) return 0;
+    return (size_t)pl.splitk * (size_t)geom_pixels(a[0].g) * a[0].N * sizeof(float);
+}
+
+extern "C" int mtd_conv_igemm_multi(const mtd_conv_args* a, int count, void* stream) {
+    if (!a || count < 1 || count > MULTI_MAX) return MTD_EINVAL;
+    for (int i = 0; i < count; ++i) {
+        int rc = check_args(a[i]);
+        if (rc != MTD_OK) return rc;
+        if (a[i].out2) return MTD_EINVAL;
+        if (geom_pixels(a[i].g) != geom_pixels(a[0].g) || a[i].N != a[0].N || a[i].C != a[0].C || a[i].g.TH != a[0].g.TH ||
+            a[i].g.TW != a[0].g.TW) return MTD_EINVAL;
+    }
+    Plan pl = make_plan(a[0], count);
+    const bool gen_shape = a[0].C == 32 && a[0].g.TH * a[0].g.TW == 9 && geom_pixels(a[0].g) >= 32768;
+    if (count == 1 || pl.cfg > 5 || g_force_cfg >= 6 || gen_shape) {
+        for (int i = 0; i < count; ++i) {
+            int rc = mtd_conv_igemm(&a[i], stream);
+            if (rc != MTD_OK) return rc;
+        }
+        return MTD_OK;
+    }
+    IgemmMulti mp;
+    for (int i = 0; i < MULTI_MAX; ++i) {
+        int rc = fill_params(&a[i < count ? i : 0], pl, mp.p[i]);
+        if (rc != MTD_OK) return rc;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int M = mp.p[0].M;
+    double bytes = 0.0;
+    for (int i = 0; i < count; ++i) bytes += algorithmic_bytes(&a[i]);
+    dim3 grid((M + pl.BM - 1) / pl.BM, a[0].N / pl.BN, pl.splitk * count);
+    const int prof = mtd_prof_begin(0, pl.cfg, pl.splitk, (long long)M * count, a[0].N, a[0].C, a[0].g.TH * a[0].g.TW, s, bytes);
+    switch (pl.cfg) {
+        case 0: MTD_LAUNCH((igemm_multi_kernel<2, 1, 4, 1>), grid, dim3(256), 0, s, mp); break;
+        case 1: MTD_LAUNCH((igemm_multi_kernel<1, 1, 4, 1>), grid, dim3(256), 0, s, mp); break;
+        case 2: MTD_LAUNCH((igemm_multi_kernel<2, 2, 4, 1>), grid, dim3(256), 0, s, mp); break;
+        case 3: MTD_LAUNCH((igemm_multi_kernel<1, 1, 2, 2>), grid, dim3(256), 0, s, mp); break;
+        case 4: MTD_LAUNCH((igemm_multi_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, mp); break;
+        default: MTD_LAUNCH((igemm_multi_kernel<1, 1, 1, 4>), grid, dim3(256), 0, s, mp); break;
+    }
+    mtd_prof_end(prof, s);
+    MTD_LAUNCH_CHECK();
+    if (pl.splitk > 1) {
+        bool vec = true;
+        for (int i = 0; i < count; ++i) vec = vec && splitk_vec_ok(a[i], M);
+        if (vec) {
+            const long long total = (long long)M * a[0].N;
+            int blocks = (int)((total / 4 + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(splitk_epilogue_multi_kernel, dim3(blocks, count), dim3(256), 0, s, mp);
+            MTD_LAUNCH_CHECK();
+        } else {
+            const long long total = (long long)M * a[0].N;
+            int blocks = (int)((total + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            for (int i = 0; i < count; ++i) {
+                hipLaunchKernelGGL(splitk_epilogue_scalar_kernel, dim3(blocks), dim3(256), 0, s, mp.p[i]);
+                MTD_LAUNCH_CHECK();
+            }
+        }
     }
     return MTD_OK;
 }

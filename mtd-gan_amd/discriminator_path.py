@@ -412,11 +412,14 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0
         add1 = adds[0] if len(adds) > 0 else None
         add2 = adds[1] if len(adds) > 1 else None
         wd = P[f"down{l}.weight_orig"]
+        # the four input-parity classes of the stride-2 data gradient: one grid (kernels.conv_multi)
+        calls = []
         for py in range(2):
             for px in range(2):
                 gp = K.geom_dgrad_s2(B, h, h, py, px)
-                K.conv(g, wd, gp, co, co, 16, co * 16, gpre2, add1=add1, add2=add2, mask=xl, mask_slope=0.2,
-                       **_scales(tp, f"down{l}", gp))
+                calls.append(((g, wd, gp, co, co, 16, co * 16, gpre2),
+                              dict(add1=add1, add2=add2, mask=xl, mask_slope=0.2, **_scales(tp, f"down{l}", gp))))
+        K.conv_multi(calls)
         g3 = K.geom_fwd(B, h, h, 3, 1, 1)
         wgrad_sn(f"conv{l}2", gpre2, a, (h, 3, 1, 1), co, co, 3)
         gpre1 = K.empty_nhwc(B, h, h, co, x)

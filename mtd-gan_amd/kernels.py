@@ -220,11 +220,8 @@ def _ptr(t):
 
 
 # ---------------------------------------------------------------------------------------------- conv
-def conv(x, w, geom, N, Cc, w_sn, w_sc, out, scale=None, bias=None, add1=None, add2=None, act=ACT_NONE,
-         mask=None, mask_slope=0.0, scale2=None, scale_split=0, out2=None):
-    """out = epilogue(conv(x, W-view)).  `out` is an NHWC tensor (B, OHF, OWF, >=N view).  out2 (see
-    fuses_masked_cotangent): also store the value before the mask factor."""
-    L = _lib.lib()
+def _conv_args(x, w, geom, N, Cc, w_sn, w_sc, out, scale=None, bias=None, add1=None, add2=None, act=ACT_NONE,
+               mask=None, mask_slope=0.0, scale2=None, scale_split=0, out2=None):
     a = ConvArgs()
     a.g = geom
     a.inp, a.in_ld, a.C = x.data_ptr(), ld_of(x), Cc
@@ -243,6 +240,15 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, scale=None, bias=None, add1=None, a
     a.ws, a.ws_bytes = None, 0
     if FLOP_COUNT is not None:
         _count("conv_mfma" if (Cc % 32 == 0 and N % 32 == 0) else "conv_valu", 2.0 * geom.B * geom.OH * geom.OW * N * Cc * geom.TH * geom.TW)
+    return a
+
+
+def conv(x, w, geom, N, Cc, w_sn, w_sc, out, **kw):
+    """out = epilogue(conv(x, W-view)).  `out` is an NHWC tensor (B, OHF, OWF, >=N view).  Keywords: scale, bias, add1,
+    add2, act, mask, mask_slope, scale2, scale_split, out2 (see fuses_masked_cotangent: also store the value before the
+    mask factor)."""
+    L = _lib.lib()
+    a = _conv_args(x, w, geom, N, Cc, w_sn, w_sc, out, **kw)
     if (Cc % 32 == 0) and (N % 32 == 0):
         wkey = (bytes(geom), N, Cc)
         need = _igemm_ws_cache.get(wkey)
@@ -260,6 +266,33 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, scale=None, bias=None, add1=None, a
             CALL_LOG.append(("direct", bytes(a)))
         check(L.mtd_conv_direct(C.byref(a), stream_ptr()), "mtd_conv_direct")
     return out
+
+
+MULTI_CONV = os.environ.get("MTD_NO_MULTI_CONV", "0") != "1"
+
+
+def conv_multi(calls):
+    """Up to four conv() calls of one shape (same pixels, N, C, taps; each with its own geometry offsets and operands) as
+    ONE grid (mtd_conv_igemm_multi): the four input-parity classes of a stride-2 data gradient.  calls: list of
+    (args tuple, keyword dict) exactly as conv() takes them."""
+    N, Cc = calls[0][0][3], calls[0][0][4]
+    if not MULTI_CONV or len(calls) == 1 or (Cc % 32) or (N % 32):
+        for args, kw in calls:
+            conv(*args, **kw)
+        return
+    L = _lib.lib()
+    arr = (ConvArgs * len(calls))(*[_conv_args(*args, **kw) for args, kw in calls])
+    key = ("multi", bytes(calls[0][0][2]), N, Cc, len(calls))
+    need = _igemm_ws_cache.get(key)
+    if need is None:
+        need = L.mtd_conv_igemm_multi_ws_bytes(arr, len(calls))
+        _igemm_ws_cache[key] = need
+    if need:
+        need = (need + 255) & ~255
+        ws = workspace(need * len(calls), calls[0][0][0].device)
+        for i in range(len(calls)):
+            arr[i].ws, arr[i].ws_bytes = ws.data_ptr() + i * need, need
+    check(L.mtd_conv_igemm_multi(arr, len(calls), stream_ptr()), "mtd_conv_igemm_multi")
 
 
 FUSE_ACT_GRAD = os.environ.get("MTD_NO_FUSED_ACT_GRAD", "0") != "1"

@@ -269,6 +269,22 @@ def test_igemm_every_tile_config(hip_lib, cfg):
                 for px in range(2):
                     K.conv(nhwc(cot), w.cuda(), K.geom_dgrad_s2(B, H, W, py, px), Ci, Co, 16, Ci * 16, dx)
             assert relerr(nchw(dx), x.grad) < TOL, (cfg, split, "dgrad_s2")
+            # the same four parity classes as ONE grid (mtd_conv_igemm_multi), full epilogue: adds, LeakyReLU mask, 1/sigma pair
+            if cfg <= 5:
+                a1, a2, mk = rnd(B, Ci, H, W, seed=16), rnd(B, Ci, H, W, seed=17), rnd(B, Ci, H, W, seed=18)
+                sc = torch.tensor([0.7, 1.3], device="cuda")
+                dx2 = torch.empty(B, H, W, Ci, device="cuda")
+                calls = []
+                for py in range(2):
+                    for px in range(2):
+                        gp = K.geom_dgrad_s2(B, H, W, py, px)
+                        calls.append(((nhwc(cot), w.cuda(), gp, Ci, Co, 16, Ci * 16, dx2),
+                                      dict(add1=nhwc(a1), add2=nhwc(a2), mask=nhwc(mk), mask_slope=0.2, scale=sc[0:1], scale2=sc[1:2],
+                                           scale_split=(B // 2) * gp.OH * gp.OW)))
+                K.conv_multi(calls)
+                half = torch.cat([torch.full((B // 2, 1, 1, 1), 0.7), torch.full((B - B // 2, 1, 1, 1), 1.3)])
+                want = (x.grad * half + a1 + a2) * torch.where(mk > 0, 1.0, 0.2)
+                assert relerr(nchw(dx2), want) < TOL, (cfg, split, "dgrad_s2 multi")
     finally:
         L.mtd_conv_igemm_override(-1, -1)
         K._igemm_ws_cache.clear()
