@@ -309,6 +309,16 @@ int mtd_window_patches(const short* hu_low, const short* hu_full, int n_slices, 
 /* whole slices (valid / test pipelines, Mayo.py:150-157): out[i] = clip((hu[i] - a_min) / (a_max - a_min), 0, 1) */
 int mtd_hu_window(const short* hu, long long n, float a_min, float a_max, float* out, void* stream);
 
+/* ---- backward of one 32 -> 32 channel 3x3 generator layer in ONE launch (csrc/conv_c32_bwd.hip) ----------------------
+ * d: the data gradient exactly as mtd_conv_igemm would take it (it must be a launch of the halo-tile kernel: C == N == 32,
+ * 3x3, stride 1, 64-pixel rows, whole four-row tiles); w: the weight + bias gradient of the same layer exactly as
+ * mtd_conv_wgrad_slabs would take it (reference: the backward of arch/Ours/networks.py:21-36 img_conv and :95-164
+ * encoder / decoder layers, which autograd runs as two ATen kernels).  Slabs go to w->ws (mtd_conv_c32_bwd_ws_bytes),
+ * to be summed by mtd_conv_wgrad_reduce_multi.  mtd_conv_c32_bwd_ok: 1 if the pair is eligible. */
+int mtd_conv_c32_bwd_ok(const mtd_conv_args* d, const mtd_wgrad_args* w);
+size_t mtd_conv_c32_bwd_ws_bytes(const mtd_conv_args* d, const mtd_wgrad_args* w);
+int mtd_conv_c32_bwd(const mtd_conv_args* d, const mtd_wgrad_args* w, int* nslab, long long* slab_stride, void* stream);
+
 /* ---- launch profiler (bench.py's roofline leg) ---------------------------------------------------------------
  * When enabled, mtd_conv_igemm / mtd_conv_wgrad time their MAIN kernel (not the split-K / slab reductions that
  * follow it) with a pair of HIP events on the stream they were given (see mtd_prof_mode).  mtd_prof_collect synchronises those events

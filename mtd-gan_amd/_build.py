@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmtdgan_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "conv_direct.hip", "resfft.hip", "resfft_any.hip", "elementwise.hip",
+SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "conv_c32_bwd.hip", "conv_direct.hip", "resfft.hip", "resfft_any.hip", "elementwise.hip",
            "specnorm.hip", "losses.hip", "metrics.hip", "sampler.hip", "pcgrad.hip", "adamw.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
@@ -22,7 +22,8 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "fft64.h"), os.path.join(os.path.dirname(HERE), "include", "mtdgan_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "fft64.h"), os.path.join(os.path.dirname(HERE), "include", "mtdgan_hip.h"),
+               os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_wgrad.hip")]      # (conv_c32_bwd.hip includes the two kernel files)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     objs = []
     procs = []

@@ -207,6 +207,9 @@ def lib():
     sig("mtd_window_patches", ci, vp, vp, ci, ci, ci, vp, vp, ci, cf, cf, ci, vp, vp, vp)
     sig("mtd_hu_window", ci, vp, ll, cf, cf, vp, vp)
     sig("mtd_prof_mode", ci, ci)
+    sig("mtd_conv_c32_bwd_ok", ci, C.POINTER(ConvArgs), C.POINTER(WgradArgs))
+    sig("mtd_conv_c32_bwd_ws_bytes", sz, C.POINTER(ConvArgs), C.POINTER(WgradArgs))
+    sig("mtd_conv_c32_bwd", ci, C.POINTER(ConvArgs), C.POINTER(WgradArgs), C.POINTER(C.c_int), C.POINTER(C.c_longlong), vp)
     sig("mtd_conv_igemm_multi_ws_bytes", sz, C.POINTER(ConvArgs), ci)
     sig("mtd_conv_igemm_multi", ci, C.POINTER(ConvArgs), ci, vp)
     sig("mtd_pcgrad_coeff", ci, vp, vp, ci, vp, vp)
@@ -227,6 +230,7 @@ EXPORTS = [
     "mtd_conv_wgrad_slabs", "mtd_conv_wgrad_slabs_rfft", "mtd_conv_wgrad_reduce_blocks", "mtd_conv_wgrad_reduce_multi", "mtd_spec_mix_wgrad_reduce_multi",
     "mtd_foreground_bbox", "mtd_window_patches", "mtd_hu_window", "mtd_add", "mtd_transpose64_multi", "mtd_upsample2x_bwd_masked",
     "mtd_prof_mode", "mtd_pcgrad_coeff", "mtd_pcgrad_axpy", "mtd_conv_igemm_multi_ws_bytes", "mtd_conv_igemm_multi",
+    "mtd_conv_c32_bwd_ok", "mtd_conv_c32_bwd_ws_bytes", "mtd_conv_c32_bwd",
 ]
 
 

@@ -1,0 +1,340 @@
+// Backward of one 32 -> 32 channel 3x3 layer of the generator (64-pixel rows) in ONE launch: the data gradient
+// (halo-tile implicit GEMM, conv_igemm.hip igemm_c32t_kernel) and the weight + bias gradient (row-window kernel,
+// conv_wgrad.hip wgrad_row_body) of arch/Ours/networks.py:21-36 / :95-164's Conv2d / ConvTranspose2d(32, 32, 3, 1, 1).
+//
+// Why one launch.  At 32 patches a layer is 2.4 GFLOP per kernel = 15.4 us of MFMA time, and each of the two launches
+// spends as long again outside its MFMA loop (prologue DMA, the store burst of the last tile, ramp and drain of a 256
+// workgroup grid): 31.3 + 29.7 us per layer, 41 layers per backward pass.  The two kernels cannot share a CU as two
+// launches (2 x 172 + 227 registers per SIMD lane, 136 KB + 64 KB of LDS), so streams do not overlap them.  Here a
+// 512-thread workgroup per CU splits its eight waves by ROLE: waves 0-3 walk the workgroup's halo tiles exactly like the
+// halo-tile kernel (two 32-pixel blocks per wave and tile instead of one), waves 4-7 take the workgroup's share of the
+// pixels through the row-window weight-gradient loop (operands straight from global memory, all nine taps of the 32 x 32 block in 144
+// accumulator registers across the workgroup's whole pixel range).  A SIMD hosts one wave of each role: while one waits
+// for its fragments, its epilogue operands or its stores, the other has the matrix pipe -- the pipe sees 2 x 288 MFMAs
+// per tile back to back, and prologue, tail and launch cost are paid once per layer.
+// The workgroup barrier is shared by the roles: both execute one per tile (the halo buffers' hand-over), and the data-
+// gradient waves join the barriers of the weight-gradient waves' final cross-wave sum.
+//
+// Results: the data gradient's arithmetic (tap order, accumulation order, epilogue) is the halo-tile kernel's; the weight
+// gradient waves take the pixel runs the stand-alone row-window launch would give them, so at 256 workgroups (32 patches)
+// the slabs are that launch's bit for bit; at other sizes the split differs and with it the rounding, not the value.
+// Roofline: fp32 MFMA, 2 x 2 * M * 32 * 32 * 9 flop per launch.
+#define MTD_NO_API 1
+#include "conv_igemm.hip"
+#include "conv_wgrad.hip"
+
+namespace {
+
+struct C32BwdParams {
+    IgemmParams d;       // the data gradient as mtd_conv_igemm would run it (halo-tile eligible)
+    WgradParams w;       // the weight gradient as mtd_conv_wgrad_slabs would run it (row window, one (n, c) tile)
+    int ntiles, iters;   // halo tiles of the launch; tiles per workgroup (same for every workgroup: barrier counts)
+};
+
+template <int DX>
+__global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) {
+    constexpr int T = 9, R = C32T_R, HP = (R + 2) * C32T_HW, NI = (HP + 7) / 8, ND = 4;      // ND: data-gradient waves
+    __shared__ __attribute__((aligned(1024))) float Hs[2][NI * 8 * 32];
+    __shared__ __attribute__((aligned(1024))) float Bs[T * 32 * 32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int ntiles = fp.ntiles, iters = fp.iters;
+
+    if (wave < ND) {
+        // ================================================================ data gradient: halo tiles (igemm_c32t_kernel)
+        const IgemmParams& p = fp.d;
+        const mtd_conv_args& a = p.a;
+        const mtd_geom& g = a.g;
+        const int tiles_per_image = g.OH / R;
+        typedef __attribute__((address_space(3))) float lds_f;
+        const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)p.in_bytes, 0x00020000);
+        const int rsub = lane >> 3, piece = (lane & 7) ^ rsub;
+        auto stage_tile = [&](int tile, int buf) {
+            const int b = tile / tiles_per_image;
+            const int oy0 = (tile - b * tiles_per_image) * R;
+            for (int i = wave; i < NI; i += ND) {
+                const int hp = 8 * i + rsub;
+                const int hr = hp / C32T_HW, hc = hp - hr * C32T_HW;
+                const int iy = oy0 - 1 + hr, ix = hc - 1;
+                const bool ok = (hp < HP) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
+                const unsigned voff = ok ? (unsigned)(((((long long)b * g.IH + iy) * g.IW + ix) * a.in_ld + piece * 4) * 4) : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_f*)&Hs[buf][i * 256], 16, voff, 0, 0, 0);
+            }
+        };
+        int tile = blockIdx.x;
+        if (tile < ntiles) stage_tile(tile, 0);
+        {
+            const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), (short)0, (int)p.w_bytes, 0x00020000);
+            for (int i = wave; i < T * 4; i += ND) {
+                const int t = i >> 2, nn = 8 * (i & 3) + rsub;
+                const unsigned voff = (unsigned)(((long long)nn * a.w_sn + (long long)p.tap_kidx[t] * a.w_st + piece * 4) * 4);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_f*)&Bs[i * 256], 16, voff, 0, 0, 0);
+            }
+        }
+        const ScalePair sp = load_scale(a);
+        const int n = l31;
+        const float bias_n = a.bias ? a.bias[n] : 0.f;
+        const int bsw = l31 & 7;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                                                   // barrier 0
+        int cur = 0;
+        for (int it = 0; it < iters; ++it) {
+            const int next = tile + gridDim.x;
+            const bool live = tile < ntiles;
+            if (live && next < ntiles) stage_tile(next, cur ^ 1);
+            if (live) {
+                const float* H = Hs[cur];
+#pragma unroll 1
+                for (int half = 0; half < 2; ++half) {
+                    const int vw = wave + ND * half;                  // the block an eight-wave halo-tile workgroup gives wave vw
+                    const int hp0 = ((vw >> 1) + 1) * C32T_HW + (vw & 1) * 32 + l31 + 1;
+                    const int mbase = tile * (R * C32T_W) + vw * 32;
+                    EpiAddr<true, 0, 16> ead;
+                    EpiOps<16> eo;
+                    ead.init(p, mbase, lane, n);
+                    epi_load(p, ead, eo);
+                    __builtin_amdgcn_sched_barrier(0);
+                    auto frag = [&](int t, f32x4* af, f32x4* bf) {
+                        const int hp = hp0 + (g.off_y + p.tap_dy[t]) * C32T_HW + (g.off_x + p.tap_dx[t]);
+                        const float* px = &H[hp * 32];
+                        const int sw = hp & 7;
+                        const float* row = &Bs[(t * 32 + l31) * 32];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            af[q] = *reinterpret_cast<const f32x4*>(px + (((kh * 4 + q) ^ sw) << 2));
+                            bf[q] = *reinterpret_cast<const f32x4*>(row + (((kh * 4 + q) ^ bsw) << 2));
+                        }
+                    };
+                    f32x16 acc;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                    f32x4 af[2][4], bf[2][4];
+                    frag(0, af[0], bf[0]);
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        if (t + 1 < T) frag(t + 1, af[(t + 1) & 1], bf[(t + 1) & 1]);
+#pragma unroll
+                        for (int kk = 0; kk < 16; ++kk) acc = mfma32(af[t & 1][kk >> 2][kk & 3], bf[t & 1][kk >> 2][kk & 3], acc);
+                    }
+                    epi_store(p, acc, ead, sp, bias_n, eo);          // stores drain under the next block's / tile's MFMAs
+                }
+            }
+            if (it + 1 < iters) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile has landed (also when this one was not live)
+                __syncthreads();                                                           // barrier it + 1
+            }
+            tile = next;
+            cur ^= 1;
+        }
+        // the weight-gradient waves' cross-wave sum: 2 barriers per tap, 2 for the bias row
+        const bool do_bias = fp.w.a.db != nullptr;
+        for (int t = 0; t < T; ++t) { __syncthreads(); __syncthreads(); }
+        if (do_bias) { __syncthreads(); __syncthreads(); }
+        return;
+    }
+
+    // ==================================================================== weight gradient: row window (wgrad_row_body)
+    {
+        constexpr int TH = 3, TW = 3, WIN = 16 + TW - 1, NWG = 4;
+        const WgradParams& p = fp.w;
+        const mtd_wgrad_args& a = p.a;
+        const mtd_geom& g = a.g;
+        const int wv = wave - ND;                                  // 0 .. 3
+        const bool do_bias = a.db != nullptr;
+        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p), (short)0, (int)p.p_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.q), (short)0, (int)p.q_bytes, 0x00020000);
+        constexpr unsigned OOB = 0x80000000u;
+        const int smin = (DX > 0) ? 0 : -(TW - 1);
+        const int pstep = a.p_ld * 4, qstep = a.q_ld * 4;
+        f32x16 acc[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        float bsum = 0.f;
+        float af[16], an[16], w0[WIN], w1[WIN];
+        unsigned pbase = OOB, rowoff[TH];
+        int xbase = 0;
+        // chunk q of this wave: 32 pixels from (4 blockIdx.x + wv) * 64 iters + 32 q -- the run of consecutive pixels the
+        // stand-alone row-window launch gives wave wv of workgroup blockIdx.x (at 256 workgroups the same pixels in the same
+        // order, hence the same slabs bit for bit); past the wave's run: all loads out of range
+        const int mwave0 = (blockIdx.x * NWG + wv) * (64 * iters);
+        auto setup = [&](int q) {
+            const int m = mwave0 + q * 32 + kh * 16;
+            pbase = OOB;
+            xbase = 0;
+#pragma unroll
+            for (int ty = 0; ty < TH; ++ty) rowoff[ty] = OOB;
+            if (q < 2 * iters && m < p.M) {
+                const int ox = m % g.OW;
+                const int t2 = m / g.OW;
+                const int oy = t2 % g.OH;
+                const int b = t2 / g.OH;
+                pbase = (unsigned)(((long long)m * a.p_ld + l31) * 4);
+                xbase = ox + g.off_x + smin;
+#pragma unroll
+                for (int ty = 0; ty < TH; ++ty) {
+                    const int iy = oy + g.off_y + ty * g.tap_dy;
+                    if ((unsigned)iy < (unsigned)g.IH)
+                        rowoff[ty] = (unsigned)(((((long long)b * g.IH + iy) * g.IW + xbase) * a.q_ld + l31) * 4);
+                }
+            }
+        };
+        auto load_p = [&](float* dst) {
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+                dst[kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, pbase, kk * pstep, 0));
+        };
+        auto load_row = [&](int ty, float* dst) {
+#pragma unroll
+            for (int j = 0; j < WIN; ++j) {
+                const unsigned off = (((unsigned)(xbase + j) < (unsigned)g.IW) & (rowoff[ty] != OOB)) ? rowoff[ty] + (unsigned)(j * qstep) : OOB;
+                dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(qrs, off, 0, 0));
+            }
+        };
+        auto mfma_row = [&](int ty, const float* wvv) {
+#pragma unroll
+            for (int tx = 0; tx < TW; ++tx) {
+                const int sh = (DX > 0) ? tx : (TW - 1 - tx);
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) acc[ty * TW + tx] = mfma32(af[kk], wvv[kk + sh], acc[ty * TW + tx]);
+            }
+        };
+        setup(0);
+        load_p(af);
+        load_row(0, w0);
+        __syncthreads();                                                                   // barrier 0 (the first loads are in flight)
+        for (int q = 0; q < 2 * iters; ++q) {
+#pragma unroll
+            for (int ty = 0; ty < TH; ++ty) {
+                float* cur = (ty & 1) ? w1 : w0;
+                float* nxt = (ty & 1) ? w0 : w1;
+                __builtin_amdgcn_sched_barrier(0);
+                if (ty + 1 < TH) {
+                    load_row(ty + 1, nxt);
+                } else {
+                    setup(q + 1);
+                    load_p(an);
+                    load_row(0, nxt);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (ty == 0) {
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk) bsum += af[kk];
+                }
+                mfma_row(ty, cur);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) af[kk] = an[kk];
+#pragma unroll
+            for (int j = 0; j < WIN; ++j) w0[j] = w1[j];                                  // TH is odd: the next chunk's first row sits in w1
+            if ((q & 1) && (q >> 1) + 1 < iters) __syncthreads();                          // barrier (q >> 1) + 1: a tile of the other role
+        }
+        // ---- cross-wave sum through LDS (fixed order) and the workgroup's slab: reg_kernel_epilogue's arithmetic.  The halo
+        // buffers are free: every data-gradient wave is past its last tile when it joins the first barrier below.
+        float* Ls = &Hs[0][0];
+        constexpr int EPW = 16 / NWG;
+        float* slab = a.ws + (long long)blockIdx.x * p.slab_stride;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Ls[wv * 1024 + e * 64 + lane] = acc[t][e];
+            __syncthreads();
+            float v[EPW];
+#pragma unroll
+            for (int i = 0; i < EPW; ++i) {
+                const int e = wv * EPW + i;
+                v[i] = Ls[e * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < NWG; ++w) v[i] += Ls[w * 1024 + e * 64 + lane];
+            }
+#pragma unroll
+            for (int i = 0; i < EPW; ++i) {
+                const int e = wv * EPW + i;
+                slab[((long long)t * a.N + mfma32_row(e, lane)) * a.C + l31] = v[i];
+            }
+        }
+        if (do_bias) {
+            float* red = Ls + NWG * 1024;
+            __syncthreads();
+            red[wv * 64 + lane] = bsum;
+            __syncthreads();
+            if (wv == 0 && lane < 32) {
+                float s2 = 0.f;
+                for (int w = 0; w < NWG; ++w) s2 += red[w * 64 + lane] + red[w * 64 + lane + 32];
+                slab[(long long)p.T * a.N * a.C + lane] = s2;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Eligibility: d is a launch the halo-tile kernel takes (32 input and output channels, 3x3, stride 1, 64-pixel rows, whole
+// four-row tiles), w a 32 x 32 channel 3x3 weight gradient over the same pixel grid with the row-window geometry.
+extern "C" int mtd_conv_c32_bwd_ok(const mtd_conv_args* d, const mtd_wgrad_args* w) {
+    if (!d || !w || check_args(*d) != MTD_OK || check_wargs(*w) != MTD_OK) return 0;
+    if (d->N != 32 || d->C != 32 || w->N != 32 || w->C != 32 || !c32t_eligible(*d)) return 0;
+    if (geom_pixels(d->g) != geom_pixels(w->g) || geom_pixels(d->g) % (C32T_R * C32T_W)) return 0;
+    const mtd_geom& g = w->g;
+    if (g.TH != 3 || g.TW != 3 || !row_window_ok(*w) || g.OW != C32T_W || g.IW != C32T_W || g.IH != g.OH || (g.OH % C32T_R)) return 0;
+    if (g.B != d->g.B || g.OH != d->g.OH) return 0;
+    return 1;
+}
+
+extern "C" size_t mtd_conv_c32_bwd_ws_bytes(const mtd_conv_args* d, const mtd_wgrad_args* w) {
+    if (!mtd_conv_c32_bwd_ok(d, w)) return 0;
+    const int ntiles = (int)(geom_pixels(d->g) / (C32T_R * C32T_W));
+    const int grid = ntiles < 256 ? ntiles : 256;
+    return (size_t)grid * (size_t)(9 * 32 * 32 + 32) * sizeof(float);
+}
+
+// d: as for mtd_conv_igemm; w: as for mtd_conv_wgrad_slabs (slabs into w->ws, *nslab slabs of *slab_stride floats, to be
+// summed by mtd_conv_wgrad_reduce_multi / the per-layer reduce).
+extern "C" int mtd_conv_c32_bwd(const mtd_conv_args* d, const mtd_wgrad_args* w, int* nslab, long long* slab_stride, void* stream) {
+    if (!nslab || !slab_stride || !mtd_conv_c32_bwd_ok(d, w)) return MTD_EINVAL;
+    C32BwdParams fp;
+    Plan pl{};
+    pl.cfg = 10; pl.splitk = 1; pl.c_per_split = 32;
+    int rc = fill_params(d, pl, fp.d);
+    if (rc != MTD_OK) return rc;
+    WgradParams& p = fp.w;
+    p.a = *w;
+    p.M = (int)geom_pixels(w->g);
+    p.T = 9;
+    p.ppw = 0;
+    p.nCt = 1;
+    p.slab_stride = (long long)p.T * w->N * w->C + w->N;
+    {
+        const mtd_geom& gg = w->g;
+        for (int t = 0; t < 9; ++t) {
+            const int ty = t / gg.TW, tx = t % gg.TW;
+            p.tap_dy[t] = ty * gg.tap_dy;
+            p.tap_dx[t] = tx * gg.tap_dx;
+            p.tap_delta[t] = (int)((((long long)(ty * gg.tap_dy) * gg.IW + tx * gg.tap_dx) * w->q_ld) * 4);
+        }
+        const long long pb = (((long long)p.M - 1) * w->p_ld + w->N) * 4;
+        const long long qb = (((long long)gg.B * gg.IH * gg.IW - 1) * w->q_ld + w->C) * 4;
+        if (pb >= (1ll << 31) || qb >= (1ll << 31)) return MTD_EINVAL;
+        p.p_bytes = (unsigned)pb;
+        p.q_bytes = (unsigned)qb;
+    }
+    fp.ntiles = p.M / (C32T_R * C32T_W);
+    const int grid = fp.ntiles < 256 ? fp.ntiles : 256;
+    fp.iters = (fp.ntiles + grid - 1) / grid;
+    p.nslab = grid;
+    if (!w->ws || w->ws_bytes < (size_t)grid * (size_t)p.slab_stride * sizeof(float)) return MTD_EWS;
+    hipStream_t s = (hipStream_t)stream;
+    const int prof = mtd_prof_begin(0, 11, 1, 2ll * p.M, 32, 32, 9, s,
+                                    algorithmic_bytes(d) + 4.0 * ((double)p.M * 32 + (double)p.M * 32 + 9.0 * 32 * 32));
+    if (w->g.tap_dx > 0) MTD_LAUNCH((c32_bwd_kernel<1>), dim3(grid), dim3(512), 0, s, fp);
+    else MTD_LAUNCH((c32_bwd_kernel<-1>), dim3(grid), dim3(512), 0, s, fp);
+    mtd_prof_end(prof, s);
+    MTD_LAUNCH_CHECK();
+    *nslab = grid;
+    *slab_stride = p.slab_stride;
+    return MTD_OK;
+}

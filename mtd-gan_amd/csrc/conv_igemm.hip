@@ -1157,6 +1157,7 @@ int check_args(const mtd_conv_args& a) {
 
 }  // namespace
 
+#ifndef MTD_NO_API      // (conv_c32_bwd.hip includes this file for its kernels and helpers only)
 extern "C" int mtd_conv_igemm_override(int cfg, int splitk) {
     g_force_cfg = cfg;
     g_force_split = splitk;
@@ -1169,6 +1170,8 @@ extern "C" size_t mtd_conv_igemm_ws_bytes(const mtd_conv_args* a) {
     if (pl.splitk <= 1) return 0;
     return (size_t)pl.splitk * (size_t)geom_pixels(a->g) * a->N * sizeof(float);
 }
+
+#endif  // MTD_NO_API
 
 namespace {
 
@@ -1223,6 +1226,7 @@ double algorithmic_bytes(const mtd_conv_args* a) {
 
 }  // namespace
 
+#ifndef MTD_NO_API
 extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
     if (!a) return MTD_EINVAL;
     int rc = check_args(*a);
@@ -1361,3 +1365,4 @@ extern "C" int mtd_conv_igemm_multi(const mtd_conv_args* a, int count, void* str
     }
     return MTD_OK;
 }
+#endif  // MTD_NO_API

@@ -833,6 +833,7 @@ size_t wgrad_ws_floats(const mtd_wgrad_args& a, int nsplit) {
 
 }  // namespace
 
+#ifndef MTD_NO_API      // (conv_c32_bwd.hip includes this file for its kernels and helpers only)
 int mtd_direct_wgrad_launch(const mtd_wgrad_args* a, int* nslab_out, long long slab_stride, void* stream);
 int mtd_direct_wgrad_nslab(const mtd_wgrad_args* a);
 
@@ -1046,3 +1047,4 @@ extern "C" int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream) {
     }
     return MTD_OK;
 }
+#endif  // MTD_NO_API

@@ -55,9 +55,13 @@ def block_backward(g, saved, w_img, w_fft, grads, premask, defer=None, gm=None):
     # the block conv's weight gradient and the row transform that opens the spectral backward chain read the same
     # cotangent: one launch when the slab sums are deferred (kernels.wgrad rows=...), at the head of the spectral stream
     fused_rows = defer is not None and K.DEFER_WGRADS and K.FUSE_WGRAD_ROWS
-    if not fused_rows:
-        side.run(lambda: K.wgrad(gm, x, K.geom_fwd(B, H, W, 3, 1, 1), CH, CH, grads["dw_img"], CH * 9, 9, db=grads["db_img"],
-                                 defer=defer), gm, g)
+    # data gradient + weight gradient of the block's 3x3 conv in ONE launch (csrc/conv_c32_bwd.hip) where the pair is eligible
+    d1 = K.empty_nhwc(B, H, W, CH, x)
+    dgrad_call = ((gm, w_img, K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, d1), dict(add1=g))
+    wgrad_args = (gm, x, K.geom_fwd(B, H, W, 3, 1, 1), CH, CH, grads["dw_img"], CH * 9, 9)
+    fused_bwd = (not fused_rows) and K.conv_wgrad_fused(dgrad_call, (wgrad_args, dict(db=grads["db_img"])), defer)
+    if not fused_rows and not fused_bwd:
+        side.run(lambda: K.wgrad(*wgrad_args, db=grads["db_img"], defer=defer), gm, g)
     # spectral branch backward on a second side stream, beside the spatial data gradient on the main stream
     side1 = K.side_stream(x.device, 1)
     box = []
@@ -70,8 +74,8 @@ def block_backward(g, saved, w_img, w_fft, grads, premask, defer=None, gm=None):
             gR = K.rfft_rows(g, 1)                                                  # irfft2 backward
         box.append(K.spec_mix_bwd(gR, w_fft, S, Z, grads["dw_fft"], grads["db_fft"], defer=defer))
     side1.run(spectral, g, gm)
-    d1 = K.empty_nhwc(B, H, W, CH, x)
-    K.conv(gm, w_img, K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, d1, add1=g)  # dgrad(img branch) + residual
+    if not fused_bwd:
+        K.conv(*dgrad_call[0], **dgrad_call[1])                                     # dgrad(img branch) + residual
     gx = K.empty_nhwc(B, H, W, CH, x)
     side1.join()
     gT = box[0]
@@ -170,27 +174,33 @@ def generator_backward(g_out, tape, P, G):
         gpre_d = block_backward(gu, tape["blk"][L + 1 + k], *_blk_w(P, 2 * L + 1 - j), G.blk[2 * L + 1 - j], True, defer, gm)
         skip[j] = gpre_d                                    # flows unchanged into e_j
         uj = tape["u"][k]                                   # input of decoder[j]
-        side.run(lambda: K.wgrad(gpre_d, uj, gt, CH, CH, G.dec_w[j], 9, CH * 9, db=G.dec_b[j], defer=defer), gpre_d)
         gu = K.empty_nhwc(B, H, W, CH, x)
+        wg = ((gpre_d, uj, gt, CH, CH, G.dec_w[j], 9, CH * 9), dict(db=G.dec_b[j]))
         if fuse:                                            # consumer: block 2L - j (tape position L + k), or block L after the loop
             gm = K.empty_nhwc(B, H, W, CH, x)
-            K.conv(gpre_d, P.dec_w[j], gf, CH, CH, CH * 9, 9, gm, mask=tape["blk"][L + k][1], mask_slope=0.0, out2=gu)
+            dg = ((gpre_d, P.dec_w[j], gf, CH, CH, CH * 9, 9, gm), dict(mask=tape["blk"][L + k][1], mask_slope=0.0, out2=gu))
         else:
-            K.conv(gpre_d, P.dec_w[j], gf, CH, CH, CH * 9, 9, gu)
+            dg = ((gpre_d, P.dec_w[j], gf, CH, CH, CH * 9, 9, gu), {})
+        if not K.conv_wgrad_fused(dg, wg, defer):           # one launch for the layer's two gradients, else two
+            side.run(lambda: K.wgrad(*wg[0], db=G.dec_b[j], defer=defer), gpre_d)
+            K.conv(*dg[0], **dg[1])
     # gu is now the gradient of x_b (output of block 10)
     g_e = gu
     for i in range(L, -1, -1):                              # blocks 10..0, encoders 10..0
         gpre_t = block_backward(g_e, tape["blk"][i], *_blk_w(P, i), G.blk[i], True, defer, gm)
         if i > 0:
             e_prev = tape["e"][i - 1]
-            side.run(lambda: K.wgrad(gpre_t, e_prev, gf, CH, CH, G.enc_w[i], CH * 9, 9, db=G.enc_b[i], defer=defer), gpre_t)
             g_e = K.empty_nhwc(B, H, W, CH, x)
+            wg = ((gpre_t, e_prev, gf, CH, CH, G.enc_w[i], CH * 9, 9), dict(db=G.enc_b[i]))
             if fuse:
                 gm = K.empty_nhwc(B, H, W, CH, x)
-                K.conv(gpre_t, P.enc_w[i], K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, gm, add1=skip[i],
-                       mask=tape["blk"][i - 1][1], mask_slope=0.0, out2=g_e)
+                dg = ((gpre_t, P.enc_w[i], K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, gm),
+                      dict(add1=skip[i], mask=tape["blk"][i - 1][1], mask_slope=0.0, out2=g_e))
             else:
-                K.conv(gpre_t, P.enc_w[i], K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, g_e, add1=skip[i])
+                dg = ((gpre_t, P.enc_w[i], K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, g_e), dict(add1=skip[i]))
+            if not K.conv_wgrad_fused(dg, wg, defer):
+                side.run(lambda: K.wgrad(*wg[0], db=G.enc_b[i], defer=defer), gpre_t)
+                K.conv(*dg[0], **dg[1])
         else:
             side.run(lambda: K.wgrad(gpre_t, x, gf, CH, 1, G.enc_w[0], 9, 9, db=G.enc_b[0]), gpre_t)
     side.join()

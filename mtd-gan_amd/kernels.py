@@ -101,7 +101,7 @@ CALL_LOG = None     # tools/tune_igemm.py: a list collects ("igemm" | "wgrad", b
 
 IGEMM_CONFIGS = ["igemm_kernel<2, 1, 4, 1>", "igemm_kernel<1, 1, 4, 1>", "igemm_kernel<2, 2, 4, 1>",
                  "igemm_kernel<1, 1, 2, 2>", "igemm_kernel<2, 2, 2, 2>", "igemm_kernel<1, 1, 1, 4>",
-                 "igemm_tb_kernel<1>", "igemm_tb_kernel<2>", "igemm_v2_kernel<0>", "igemm_c32p_kernel", "igemm_c32t_kernel"]
+                 "igemm_tb_kernel<1>", "igemm_tb_kernel<2>", "igemm_v2_kernel<0>", "igemm_c32p_kernel", "igemm_c32t_kernel", "c32_bwd_kernel"]
 WGRAD_CONFIGS = ["wgrad_kernel<1, 1, 9>", "wgrad_kernel<1, 1, 4>", "wgrad_kernel<2, 2, 1>", "wgrad_kernel<1, 1, 8>",
                  "wgrad_kernel<1, 1, 3>", "wgrad_kernel<1, 1, 1>", "wgrad_kernel<2, 2, 3>",
                  "wgrad_row_kernel<3, 3, 1>", "wgrad_row_kernel<3, 3, -1>", "wgrad_row_kernel<1, 1, 1>",
@@ -404,6 +404,49 @@ def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumula
     if CALL_LOG is not None:
         CALL_LOG.append(("wgrad", bytes(a)))
     check(L.mtd_conv_wgrad(C.byref(a), stream_ptr()), "mtd_conv_wgrad")
+
+
+FUSE_C32_BWD = os.environ.get("MTD_NO_FUSED_C32_BWD", "0") != "1"
+
+
+def conv_wgrad_fused(conv_call, wgrad_call, defer):
+    """The data gradient and the weight gradient of one 32 -> 32 channel 3x3 generator layer in ONE launch
+    (mtd_conv_c32_bwd: the eight waves of a workgroup split by role) when the pair is eligible and the weight-gradient
+    slab sums are deferred; otherwise the two launches, the weight gradient through `side` as before.
+    conv_call = (args, kw) of conv(); wgrad_call = (args, kw) of wgrad() without `defer`.  Returns True if fused."""
+    (p_, q_, geom, N, Cc, dw, w_sn, w_sc), wkw = wgrad_call
+    if not (FUSE_C32_BWD and defer is not None and DEFER_WGRADS and N == 32 and Cc == 32 and not wkw.get("accumulate")):
+        return False
+    L = _lib.lib()
+    d = _conv_args(*conv_call[0], **conv_call[1])
+    a = WgradArgs()
+    a.g = geom
+    a.p, a.p_ld, a.N = p_.data_ptr(), ld_of(p_), N
+    a.q, a.q_ld, a.C = q_.data_ptr(), ld_of(q_), Cc
+    a.dw, a.w_sn, a.w_sc = dw.data_ptr(), w_sn, w_sc
+    db = wkw.get("db")
+    a.db = _ptr(db)
+    a.accumulate = 0
+    a.ws, a.ws_bytes = None, 0
+    if not L.mtd_conv_c32_bwd_ok(C.byref(d), C.byref(a)):
+        if FLOP_COUNT is not None:
+            FLOP_COUNT["conv_mfma"] -= 2.0 * geom.B * geom.OH * geom.OW * N * Cc * 9      # (_conv_args counted it; conv() will again)
+            FLOP_COUNT["launches"] -= 1
+        return False
+    if FLOP_COUNT is not None:
+        _count("wgrad_mfma", 2.0 * geom.B * geom.OH * geom.OW * N * Cc * 9)
+        FLOP_COUNT["launches"] -= 1                                                          # one launch for the two
+    need = max(L.mtd_conv_c32_bwd_ws_bytes(C.byref(d), C.byref(a)), L.mtd_conv_wgrad_ws_bytes(C.byref(a)))
+    ws = _layer_ws(need, defer, p_.device)
+    a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+    nslab, stride = C.c_int(0), C.c_longlong(0)
+    check(L.mtd_conv_c32_bwd(C.byref(d), C.byref(a), C.byref(nslab), C.byref(stride), stream_ptr()), "mtd_conv_c32_bwd")
+    r = _lib.WgradReduceDesc()
+    r.a, r.T, r.nslab, r.slab_stride = a, 9, nslab.value, stride.value
+    r.a.p, r.a.q = None, None
+    defer.conv.append(r)
+    defer.bufs.append(ws)
+    return True
 
 
 # ---------------------------------------------------------------------------------------------- spectral path

@@ -327,3 +327,57 @@ def test_igemm_generator_shaped_kernels(hip_lib, cfg):
     finally:
         L.mtd_conv_igemm_override(-1, -1)
         K._igemm_ws_cache.clear()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [2, 20, 32])
+def test_fused_c32_backward_launch(hip_lib, B):
+    """csrc/conv_c32_bwd.hip: the data gradient and the weight + bias gradient of a 32 -> 32 channel 3x3 generator layer in
+    ONE launch against the two launches it replaces -- both layer kinds (Conv2d: forward geometry for the weight gradient,
+    ConvTranspose2d: mirrored taps), full data-gradient epilogue (add, mask, second output).  B = 20: 320 tiles on 256
+    workgroups (workgroups with one and with two live tiles); B = 32: the stand-alone launch's own split, bit for bit."""
+    from mtd_gan_amd import kernels as K
+    H = W = 64
+    gen = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=gen).cuda()
+    p_, q_, add1, mask = r(B, H, W, 32), r(B, H, W, 32), r(B, H, W, 32), r(B, H, W, 32)
+    w = (torch.randn(32, 32, 3, 3, generator=gen) * 0.1).cuda()
+    gf, gt = K.geom_fwd(B, H, W, 3, 1, 1), K.geom_dgrad_s1(B, H, W, 3, 1)
+    for kind in ("conv", "convT"):
+        if kind == "conv":      # layer y = conv(x, w): dgrad gathers with the transposed view, wgrad with the forward geometry
+            dg = lambda out, out2: ((p_, w, gt, 32, 32, 9, 32 * 9, out), dict(add1=add1, mask=mask, mask_slope=0.0, out2=out2))
+            wgeo, wsn, wsc = gf, 32 * 9, 9
+        else:                   # layer y = conv_transpose(x, w): dgrad is a plain conv, wgrad has mirrored taps
+            dg = lambda out, out2: ((p_, w, gf, 32, 32, 32 * 9, 9, out), dict(add1=add1, mask=mask, mask_slope=0.0, out2=out2))
+            wgeo, wsn, wsc = gt, 9, 32 * 9
+        res = []
+        for fused in (False, True):
+            out, out2 = torch.zeros(B, H, W, 32, device="cuda"), torch.zeros(B, H, W, 32, device="cuda")
+            dw, db = torch.zeros(32, 32, 3, 3, device="cuda"), torch.zeros(32, device="cuda")
+            defer = K.DeferredWgrads()
+            wg = ((p_, q_, wgeo, 32, 32, dw, wsn, wsc), dict(db=db))
+            call = dg(out, out2)
+            if fused:
+                assert K.conv_wgrad_fused(call, wg, defer)
+            else:
+                K.wgrad(*wg[0], db=db, defer=defer)
+                K.conv(*call[0], **call[1])
+            K.flush_wgrads(defer)
+            torch.cuda.synchronize()
+            res.append((out, out2, dw, db))
+        (o_a, o2_a, dw_a, db_a), (o_b, o2_b, dw_b, db_b) = res
+        assert torch.equal(o_a, o_b) and torch.equal(o2_a, o2_b), kind            # the halo-tile kernel's arithmetic
+        if B == 32:
+            assert torch.equal(dw_a, dw_b) and torch.equal(db_a, db_b), kind
+        else:
+            assert relerr(dw_b.cpu(), dw_a.cpu()) < 1e-5 and relerr(db_b.cpu(), db_a.cpu()) < 1e-5, kind
+        # and against torch on the CPU (the layer's own autograd)
+        pc, qc = nchw(p_).double(), nchw(q_).double().requires_grad_(True)
+        wc = w.cpu().double().requires_grad_(True)
+        y = F.conv2d(qc, wc, None, padding=1) if kind == "conv" else F.conv_transpose2d(qc, wc, None, padding=1)
+        (y * pc).sum().backward()
+        assert relerr(dw_b.cpu(), wc.grad) < TOL, kind
+        assert relerr(db_b.cpu(), pc.sum((0, 2, 3))) < TOL, kind
+        want = (qc.grad + nchw(add1).double())
+        assert relerr(nchw(o2_b), want) < TOL, kind
+        assert relerr(nchw(o_b), want * (nchw(mask) > 0)) < TOL, kind
