@@ -318,6 +318,7 @@ int mtd_hu_window(const short* hu, long long n, float a_min, float a_max, float*
 int mtd_conv_c32_bwd_ok(const mtd_conv_args* d, const mtd_wgrad_args* w);
 size_t mtd_conv_c32_bwd_ws_bytes(const mtd_conv_args* d, const mtd_wgrad_args* w);
 int mtd_conv_c32_bwd(const mtd_conv_args* d, const mtd_wgrad_args* w, int* nslab, long long* slab_stride, void* stream);
+int mtd_conv_c32_bwd_stamps(unsigned long long* host256);   /* lab (MTD_C32F_STAMPS=1): clock stamps of the last launch's first 16 workgroups */
 
 /* ---- launch profiler (bench.py's roofline leg) ---------------------------------------------------------------
  * When enabled, mtd_conv_igemm / mtd_conv_wgrad time their MAIN kernel (not the split-K / slab reductions that

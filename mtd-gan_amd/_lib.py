@@ -98,7 +98,7 @@ def _preload_torch_hip_runtime():
 
 
 RECORDER = None      # kernels.LaunchList: while a step is being recorded, the list every launch is appended to
-_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "mtd_prof_", "_override")
+_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "mtd_prof_", "_override", "_bwd_ok", "_stamps")
 
 
 class _RecordingLib:

@@ -29,41 +29,65 @@ struct C32BwdParams {
     IgemmParams d;       // the data gradient as mtd_conv_igemm would run it (halo-tile eligible)
     WgradParams w;       // the weight gradient as mtd_conv_wgrad_slabs would run it (row window, one (n, c) tile)
     int ntiles, iters;   // halo tiles of the launch; tiles per workgroup (same for every workgroup: barrier counts)
+    int roles;           // lab switch MTD_C32F_ROLES: bit 0 = data-gradient waves compute, bit 1 = weight-gradient waves compute
+    unsigned long long* stamps;      // lab: per workgroup 16 clock stamps (tools/c32f_probe.py), or null
 };
+
+#define C32F_STAMP(i)                                                                              \
+    do {                                                                                           \
+        if (fp.stamps && lane == 0 && blockIdx.x < 16) {                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            fp.stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime();                       \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }                                                                                          \
+    } while (0)
 
 template <int DX>
 __global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) {
-    constexpr int T = 9, R = C32T_R, HP = (R + 2) * C32T_HW, NI = (HP + 7) / 8, ND = 4;      // ND: data-gradient waves
-    __shared__ __attribute__((aligned(1024))) float Hs[2][NI * 8 * 32];
+    // Private halo per data-gradient wave: the 3 x 34 pixels around its 32-pixel block (13 DMA instructions of 8 pixels),
+    // double-buffered.  Nothing in LDS is shared between waves except the weights, so the main loop has NO workgroup
+    // barrier: a wave waits only for its own DMA (counted vmcnt), and the two roles run free of each other -- with one
+    // barrier per shared four-row tile the weight-gradient waves stood at it for half of every tile (in-kernel stamps,
+    // tools/c32f_probe.py: 53 k clocks per tile for the data-gradient role, 27 k for the other).
+    constexpr int T = 9, ND = 4, PHW = C32T_W / 2 + 2, PHP = 3 * PHW, PNI = (PHP + 7) / 8;      // ND: data-gradient waves
+    __shared__ __attribute__((aligned(1024))) float Hs[ND][2][PNI * 256];
     __shared__ __attribute__((aligned(1024))) float Bs[T * 32 * 32];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kh = lane >> 5;
-    const int ntiles = fp.ntiles, iters = fp.iters;
+    const int iters = fp.iters;
+    const int nblk = 2 * iters;                              // 32-pixel blocks per wave, either role
+    (void)fp.ntiles;
 
     if (wave < ND) {
-        // ================================================================ data gradient: halo tiles (igemm_c32t_kernel)
+        // ================================================================ data gradient (the halo-tile kernel's arithmetic)
         const IgemmParams& p = fp.d;
         const mtd_conv_args& a = p.a;
         const mtd_geom& g = a.g;
-        const int tiles_per_image = g.OH / R;
         typedef __attribute__((address_space(3))) float lds_f;
         const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)p.in_bytes, 0x00020000);
         const int rsub = lane >> 3, piece = (lane & 7) ^ rsub;
-        auto stage_tile = [&](int tile, int buf) {
-            const int b = tile / tiles_per_image;
-            const int oy0 = (tile - b * tiles_per_image) * R;
-            for (int i = wave; i < NI; i += ND) {
+        const bool on = (fp.roles & 1) != 0;
+        // block k of this wave: 32 pixels from ((blockIdx.x * nblk + k) * ND + wave) * 32 -- half an image row
+        auto block_m = [&](int k) { return ((blockIdx.x * nblk + k) * ND + wave) * 32; };
+        auto stage = [&](int k, int buf) {
+            const int m = block_m(k);
+            const int ox0 = m % C32T_W;
+            const int t2 = m / C32T_W;
+            const int oy = t2 % g.OH, b = t2 / g.OH;
+            const bool live = on && m < p.M;
+#pragma unroll
+            for (int i = 0; i < PNI; ++i) {
                 const int hp = 8 * i + rsub;
-                const int hr = hp / C32T_HW, hc = hp - hr * C32T_HW;
-                const int iy = oy0 - 1 + hr, ix = hc - 1;
-                const bool ok = (hp < HP) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
+                const int hr = hp / PHW, hc = hp - hr * PHW;
+                const int iy = oy - 1 + hr, ix = ox0 - 1 + hc;
+                const bool ok = live & (hp < PHP) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
                 const unsigned voff = ok ? (unsigned)(((((long long)b * g.IH + iy) * g.IW + ix) * a.in_ld + piece * 4) * 4) : 0x80000000u;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_f*)&Hs[buf][i * 256], 16, voff, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_f*)&Hs[wave][buf][i * 256], 16, voff, 0, 0, 0);
             }
         };
-        int tile = blockIdx.x;
-        if (tile < ntiles) stage_tile(tile, 0);
+        if (wave == 0) C32F_STAMP(0);
+        stage(0, 0);
         {
             const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), (short)0, (int)p.w_bytes, 0x00020000);
             for (int i = wave; i < T * 4; i += ND) {
@@ -73,64 +97,62 @@ __global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) 
             }
         }
         const ScalePair sp = load_scale(a);
-        const int n = l31;
-        const float bias_n = a.bias ? a.bias[n] : 0.f;
+        f32x4 bias4[4];
+        epiw_bias(a, 4 * kh, bias4);
         const int bsw = l31 & 7;
+        const int nstores = a.out2 ? 8 : 4;                  // store instructions of one block's epilogue (16-byte vectors)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                                                   // barrier 0
-        int cur = 0;
-        for (int it = 0; it < iters; ++it) {
-            const int next = tile + gridDim.x;
-            const bool live = tile < ntiles;
-            if (live && next < ntiles) stage_tile(next, cur ^ 1);
-            if (live) {
-                const float* H = Hs[cur];
+        __syncthreads();                                                                   // barrier 0: the weights are in LDS
+        if (wave == 0) C32F_STAMP(1);
+        const int hp0 = PHW + l31 + 1;                        // the lane's own pixel in the private halo
 #pragma unroll 1
-                for (int half = 0; half < 2; ++half) {
-                    const int vw = wave + ND * half;                  // the block an eight-wave halo-tile workgroup gives wave vw
-                    const int hp0 = ((vw >> 1) + 1) * C32T_HW + (vw & 1) * 32 + l31 + 1;
-                    const int mbase = tile * (R * C32T_W) + vw * 32;
-                    EpiAddr<true, 0, 16> ead;
-                    EpiOps<16> eo;
-                    ead.init(p, mbase, lane, n);
-                    epi_load(p, ead, eo);
-                    __builtin_amdgcn_sched_barrier(0);
-                    auto frag = [&](int t, f32x4* af, f32x4* bf) {
-                        const int hp = hp0 + (g.off_y + p.tap_dy[t]) * C32T_HW + (g.off_x + p.tap_dx[t]);
-                        const float* px = &H[hp * 32];
-                        const int sw = hp & 7;
-                        const float* row = &Bs[(t * 32 + l31) * 32];
+        for (int k = 0; k < nblk; ++k) {
+            if (k + 1 < nblk) stage(k + 1, (k + 1) & 1);      // (its buffer was last read by block k - 1 of this same wave)
+            const int mbase = block_m(k);
+            const bool live = on && mbase < p.M;
+            if (live) {
+                const float* H = Hs[wave][k & 1];
+                EpiWide wad;
+                EpiWideOps weo;
+                wad.init(p, mbase, lane, 0, sp);
+                epiw_load(p, wad, weo);
+                __builtin_amdgcn_sched_barrier(0);
+                auto frag = [&](int t, f32x4* af, f32x4* bf) {
+                    const int hp = hp0 + (g.off_y + p.tap_dy[t]) * PHW + (g.off_x + p.tap_dx[t]);
+                    const float* px = &H[hp * 32];
+                    const int sw = hp & 7;
+                    const float* row = &Bs[(t * 32 + l31) * 32];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            af[q] = *reinterpret_cast<const f32x4*>(px + (((kh * 4 + q) ^ sw) << 2));
-                            bf[q] = *reinterpret_cast<const f32x4*>(row + (((kh * 4 + q) ^ bsw) << 2));
-                        }
-                    };
-                    f32x16 acc;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-                    f32x4 af[2][4], bf[2][4];
-                    frag(0, af[0], bf[0]);
-#pragma unroll
-                    for (int t = 0; t < T; ++t) {
-                        if (t + 1 < T) frag(t + 1, af[(t + 1) & 1], bf[(t + 1) & 1]);
-#pragma unroll
-                        for (int kk = 0; kk < 16; ++kk) acc = mfma32(af[t & 1][kk >> 2][kk & 3], bf[t & 1][kk >> 2][kk & 3], acc);
+                    for (int q = 0; q < 4; ++q) {
+                        af[q] = *reinterpret_cast<const f32x4*>(px + (((kh * 4 + q) ^ sw) << 2));
+                        bf[q] = *reinterpret_cast<const f32x4*>(row + (((kh * 4 + q) ^ bsw) << 2));
                     }
-                    epi_store(p, acc, ead, sp, bias_n, eo);          // stores drain under the next block's / tile's MFMAs
+                };
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                f32x4 af[2][4], bf[2][4];
+                frag(0, af[0], bf[0]);
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    if (t + 1 < T) frag(t + 1, af[(t + 1) & 1], bf[(t + 1) & 1]);
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk) acc = mfma32(bf[t & 1][kk >> 2][kk & 3], af[t & 1][kk >> 2][kk & 3], acc);   // transposed block
                 }
+                epiw_store(p, acc, wad, bias4, weo);             // 16-byte vectors; the stores drain under the next block's MFMAs
             }
-            if (it + 1 < iters) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile has landed (also when this one was not live)
-                __syncthreads();                                                           // barrier it + 1
-            }
-            tile = next;
-            cur ^= 1;
+            // the next block's halo has landed: every memory operation older than this block's stores is complete
+            // (s_waitcnt vmcnt(N): all but the N youngest vector-memory operations, loads, stores and LDS-DMA alike, in issue order)
+            if (!live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (nstores == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (wave == 0 && k < 4) C32F_STAMP(2 + k);
         }
         // the weight-gradient waves' cross-wave sum: 2 barriers per tap, 2 for the bias row
         const bool do_bias = fp.w.a.db != nullptr;
         for (int t = 0; t < T; ++t) { __syncthreads(); __syncthreads(); }
         if (do_bias) { __syncthreads(); __syncthreads(); }
+        if (wave == 0) C32F_STAMP(6);
         return;
     }
 
@@ -140,6 +162,8 @@ __global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) 
         const WgradParams& p = fp.w;
         const mtd_wgrad_args& a = p.a;
         const mtd_geom& g = a.g;
+        const int ntiles = fp.ntiles;
+        (void)ntiles;
         const int wv = wave - ND;                                  // 0 .. 3
         const bool do_bias = a.db != nullptr;
         const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p), (short)0, (int)p.p_bytes, 0x00020000);
@@ -201,18 +225,21 @@ __global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) 
                 for (int kk = 0; kk < 16; ++kk) acc[ty * TW + tx] = mfma32(af[kk], wvv[kk + sh], acc[ty * TW + tx]);
             }
         };
+        if (wv == 0) C32F_STAMP(8);
         setup(0);
         load_p(af);
         load_row(0, w0);
         __syncthreads();                                                                   // barrier 0 (the first loads are in flight)
+        if (wv == 0) C32F_STAMP(9);
         for (int q = 0; q < 2 * iters; ++q) {
+            if (fp.roles & 2)
 #pragma unroll
             for (int ty = 0; ty < TH; ++ty) {
                 float* cur = (ty & 1) ? w1 : w0;
                 float* nxt = (ty & 1) ? w0 : w1;
                 __builtin_amdgcn_sched_barrier(0);
                 if (ty + 1 < TH) {
-                    load_row(ty + 1, nxt);
+                    if (!(fp.roles & 4)) load_row(ty + 1, nxt);      // (lab, roles bit 2: skip two of the three window rows -- WRONG results, timing only)
                 } else {
                     setup(q + 1);
                     load_p(an);
@@ -230,11 +257,11 @@ __global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) 
             for (int kk = 0; kk < 16; ++kk) af[kk] = an[kk];
 #pragma unroll
             for (int j = 0; j < WIN; ++j) w0[j] = w1[j];                                  // TH is odd: the next chunk's first row sits in w1
-            if ((q & 1) && (q >> 1) + 1 < iters) __syncthreads();                          // barrier (q >> 1) + 1: a tile of the other role
+            if (wv == 0 && q < 4) C32F_STAMP(10 + q);
         }
         // ---- cross-wave sum through LDS (fixed order) and the workgroup's slab: reg_kernel_epilogue's arithmetic.  The halo
-        // buffers are free: every data-gradient wave is past its last tile when it joins the first barrier below.
-        float* Ls = &Hs[0][0];
+        // buffers are free: every data-gradient wave is past its last block when it joins the first barrier below.
+        float* Ls = &Hs[0][0][0];
         constexpr int EPW = 16 / NWG;
         float* slab = a.ws + (long long)blockIdx.x * p.slab_stride;
 #pragma unroll
@@ -268,8 +295,11 @@ __global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) 
                 slab[(long long)p.T * a.N * a.C + lane] = s2;
             }
         }
+        if (wv == 0) C32F_STAMP(14);
     }
 }
+
+unsigned long long* g_c32f_stamps = nullptr;     // lab: MTD_C32F_STAMPS=1
 
 }  // namespace
 
@@ -277,7 +307,7 @@ __global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) 
 // four-row tiles), w a 32 x 32 channel 3x3 weight gradient over the same pixel grid with the row-window geometry.
 extern "C" int mtd_conv_c32_bwd_ok(const mtd_conv_args* d, const mtd_wgrad_args* w) {
     if (!d || !w || check_args(*d) != MTD_OK || check_wargs(*w) != MTD_OK) return 0;
-    if (d->N != 32 || d->C != 32 || w->N != 32 || w->C != 32 || !c32t_eligible(*d)) return 0;
+    if (d->N != 32 || d->C != 32 || w->N != 32 || w->C != 32 || !c32t_eligible(*d) || !wide_epilogue_ok(*d)) return 0;
     if (geom_pixels(d->g) != geom_pixels(w->g) || geom_pixels(d->g) % (C32T_R * C32T_W)) return 0;
     const mtd_geom& g = w->g;
     if (g.TH != 3 || g.TW != 3 || !row_window_ok(*w) || g.OW != C32T_W || g.IW != C32T_W || g.IH != g.OH || (g.OH % C32T_R)) return 0;
@@ -326,6 +356,11 @@ extern "C" int mtd_conv_c32_bwd(const mtd_conv_args* d, const mtd_wgrad_args* w,
     const int grid = fp.ntiles < 256 ? fp.ntiles : 256;
     fp.iters = (fp.ntiles + grid - 1) / grid;
     p.nslab = grid;
+    static const int env_roles = [] { const char* e = getenv("MTD_C32F_ROLES"); return e ? atoi(e) : 3; }();
+    fp.roles = env_roles;
+    static const bool want_stamps = getenv("MTD_C32F_STAMPS") != nullptr;
+    if (want_stamps && !g_c32f_stamps && hipMalloc(&g_c32f_stamps, 256 * sizeof(unsigned long long)) != hipSuccess) g_c32f_stamps = nullptr;
+    fp.stamps = g_c32f_stamps;
     if (!w->ws || w->ws_bytes < (size_t)grid * (size_t)p.slab_stride * sizeof(float)) return MTD_EWS;
     hipStream_t s = (hipStream_t)stream;
     const int prof = mtd_prof_begin(0, 11, 1, 2ll * p.M, 32, 32, 9, s,
@@ -337,4 +372,11 @@ extern "C" int mtd_conv_c32_bwd(const mtd_conv_args* d, const mtd_wgrad_args* w,
     *nslab = grid;
     *slab_stride = p.slab_stride;
     return MTD_OK;
+}
+
+// lab (tools/c32f_probe.py): copy of the clock stamps of the last fused launch (MTD_C32F_STAMPS=1), 256 values
+extern "C" int mtd_conv_c32_bwd_stamps(unsigned long long* host256) {
+    if (!host256 || !g_c32f_stamps) return MTD_EINVAL;
+    if (hipDeviceSynchronize() != hipSuccess) return MTD_EINVAL;
+    return hipMemcpy(host256, g_c32f_stamps, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? MTD_OK : MTD_EINVAL;
 }

@@ -235,6 +235,95 @@ __device__ __forceinline__ void epilogue16(const IgemmParams& p, const f32x16& a
     }
 }
 
+// ---- wide epilogue of one 32 x 32 accumulator block computed TRANSPOSED -------------------------------------------
+// mfma32(b, a, acc) instead of mfma32(a, b, acc) -- the two operand fragments have the same per-lane format, so swapping
+// them costs nothing -- gives the transposed block: lane (l31, kh) then holds, for ITS OWN pixel mrow0 + l31, the 16
+// channels n0 + 8 g + 4 kh + j (g, j = 0..3; register 4 g + j): four groups of four CONSECUTIVE channels.  Every epilogue
+// operand and the result move as 16-byte vectors, 4 instructions per tensor and block instead of 16.  That is the point:
+// a vector-memory instruction costs the CU ~60-75 cycles whatever its width (in-kernel stamps and the per-launch
+// instruction counts of the generator's 32-channel layers), and the dword epilogue of a block with an add, a
+// mask and a second output is 64 of them for 144 MFMAs.  Same dot products in the same k order: bit-identical values.
+// Needs 16-byte aligned rows: bases aligned, every ld a multiple of 4 floats (wide_epilogue_ok).
+struct EpiWide {
+    long long pix;      // the lane's output pixel
+    int ch;             // first channel of group 0: n0 + 4 kh
+    float sc;
+    __device__ __forceinline__ void init(const IgemmParams& p, int mrow0, int lane, int n0, const ScalePair& sp) {
+        const int m = mrow0 + (lane & 31);
+        pix = p.out_identity ? (long long)m : out_pixel(p.a.g, m, 0);
+        ch = n0 + 4 * (lane >> 5);
+        sc = pick_scale(sp, m);
+    }
+};
+struct EpiWideOps { f32x4 e1[4], e2[4], em[4]; };
+
+__device__ __forceinline__ void epiw_load(const IgemmParams& p, const EpiWide& ad, EpiWideOps& o) {
+    const mtd_conv_args& a = p.a;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        o.e1[g] = f32x4{-0.0f, -0.0f, -0.0f, -0.0f};
+        o.e2[g] = f32x4{-0.0f, -0.0f, -0.0f, -0.0f};
+        o.em[g] = f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+    if (a.add1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) o.e1[g] = *reinterpret_cast<const f32x4*>(a.add1 + ad.pix * a.add1_ld + ad.ch + 8 * g);
+    }
+    if (a.add2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) o.e2[g] = *reinterpret_cast<const f32x4*>(a.add2 + ad.pix * a.add2_ld + ad.ch + 8 * g);
+    }
+    if (a.mask) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) o.em[g] = *reinterpret_cast<const f32x4*>(a.mask + ad.pix * a.mask_ld + ad.ch + 8 * g);
+    }
+}
+
+// bias4[g]: the bias of the lane's channel group g (zeros without a bias)
+__device__ __forceinline__ void epiw_store(const IgemmParams& p, const f32x16& acc, const EpiWide& ad, const f32x4 (&bias4)[4],
+                                           const EpiWideOps& o) {
+    const mtd_conv_args& a = p.a;
+    f32x4 v[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x = acc[4 * g + j] * ad.sc + bias4[g][j];      // the order of epilogue_value()
+            x += o.e1[g][j];
+            x += o.e2[g][j];
+            v[g][j] = x;
+        }
+    if (a.act == MTD_ACT_RELU) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[g][j] = v[g][j] > 0.f ? v[g][j] : 0.f;
+    } else if (a.act == MTD_ACT_LRELU) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[g][j] = v[g][j] > 0.f ? v[g][j] : 0.2f * v[g][j];
+    }
+    if (a.out2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(a.out2 + ad.pix * a.out2_ld + ad.ch + 8 * g) = v[g];
+    }
+    if (a.mask) {
+        const float slope = a.mask_slope;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[g][j] *= (o.em[g][j] > 0.f) ? 1.f : slope;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(a.out + ad.pix * a.out_ld + ad.ch + 8 * g) = v[g];
+}
+
+__device__ __forceinline__ void epiw_bias(const mtd_conv_args& a, int ch, f32x4 (&bias4)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[g] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + ch + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 // zk: this workgroup's split-K slice (blockIdx.z of a single launch; blockIdx.z % splitk of a multi launch, below)
 template <int WM, int WN, int WGM, int WGN>
 __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int zk) {
@@ -749,7 +838,7 @@ constexpr int C32T_W = 64, C32T_R = 4, C32T_HW = C32T_W + 2;
 // tile's MFMAs (R = 4).  !DB (R = 2, lab variant MTD_C32T_VARIANT=1): one halo buffer of half the size, TWO workgroups per CU
 // that are meant to alternate -- one in its memory phase (epilogue stores, next tile's DMA) while the other has the MFMA
 // pipes -- with the second workgroup of a CU held back by `stagger` x 64 clocks at the start.
-template <int R, bool DB>
+template <int R, bool DB, bool WIDE = false>
 __global__ __launch_bounds__(128 * R, DB ? 1 : 2) void igemm_c32t_kernel(const IgemmParams p, int ntiles, int stagger) {
     constexpr int T = 9, NW = 2 * R, HP = (R + 2) * C32T_HW, NI = (HP + 7) / 8;
     __shared__ __attribute__((aligned(1024))) float Hs[DB ? 2 : 1][NI * 8 * 32];
@@ -793,6 +882,8 @@ __global__ __launch_bounds__(128 * R, DB ? 1 : 2) void igemm_c32t_kernel(const I
     const ScalePair sp = load_scale(a);
     const int n = n0 + l31;
     const float bias_n = a.bias ? a.bias[n] : 0.f;
+    f32x4 bias4[4];
+    epiw_bias(a, n0 + 4 * kh, bias4);
     const int bsw = l31 & 7;
     // this wave's 32 pixels of a tile: tile row wave >> 1, columns 32 * (wave & 1) + l31; halo index of the pixel itself:
     const int hp0 = ((wave >> 1) + 1) * C32T_HW + (wave & 1) * 32 + l31 + 1;
@@ -809,8 +900,15 @@ __global__ __launch_bounds__(128 * R, DB ? 1 : 2) void igemm_c32t_kernel(const I
         const int mbase = tile * (R * C32T_W) + wave * 32;
         EpiAddr<true, 0, 16> ead;
         EpiOps<16> eo;
-        ead.init(p, mbase, lane, n);
-        epi_load(p, ead, eo);
+        EpiWide wad;
+        EpiWideOps weo;
+        if (WIDE) {
+            wad.init(p, mbase, lane, n0, sp);
+            epiw_load(p, wad, weo);
+        } else {
+            ead.init(p, mbase, lane, n);
+            epi_load(p, ead, eo);
+        }
         __builtin_amdgcn_sched_barrier(0);
         const float* H = Hs[DB ? cur : 0];
         auto frag = [&](int t, f32x4* af, f32x4* bf) {
@@ -833,13 +931,16 @@ __global__ __launch_bounds__(128 * R, DB ? 1 : 2) void igemm_c32t_kernel(const I
         for (int t = 0; t < T; ++t) {
             if (t + 1 < T) frag(t + 1, af[(t + 1) & 1], bf[(t + 1) & 1]);
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) acc = mfma32(af[t & 1][kk >> 2][kk & 3], bf[t & 1][kk >> 2][kk & 3], acc);
+            for (int kk = 0; kk < 16; ++kk)
+                acc = WIDE ? mfma32(bf[t & 1][kk >> 2][kk & 3], af[t & 1][kk >> 2][kk & 3], acc)      // transposed block (EpiWide)
+                           : mfma32(af[t & 1][kk >> 2][kk & 3], bf[t & 1][kk >> 2][kk & 3], acc);
         }
         MTD_STAMP(3 + 3 * (cur));
         if (DB) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile and this tile's epilogue operands have landed
             MTD_STAMP(4 + 3 * (cur));
-            epi_store(p, acc, ead, sp, bias_n, eo);                // stores drain under the next tile's MFMAs
+            if (WIDE) epiw_store(p, acc, wad, bias4, weo);
+            else epi_store(p, acc, ead, sp, bias_n, eo);           // stores drain under the next tile's MFMAs
             MTD_STAMP(5 + 3 * (cur));
             if (next >= ntiles) break;
             __syncthreads();
@@ -849,13 +950,25 @@ __global__ __launch_bounds__(128 * R, DB ? 1 : 2) void igemm_c32t_kernel(const I
             __syncthreads();                                       // every wave is done reading the halo tile
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this tile's epilogue operands have landed
             if (next < ntiles) stage_tile(next, 0);                // the next tile's DMA in flight under the stores ...
-            epi_store(p, acc, ead, sp, bias_n, eo);                // ... and under the other workgroup's MFMAs
+            if (WIDE) epiw_store(p, acc, wad, bias4, weo);
+            else epi_store(p, acc, ead, sp, bias_n, eo);           // ... and under the other workgroup's MFMAs
             if (next >= ntiles) break;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             tile = next;
         }
     }
+}
+
+// 16-byte epilogue vectors (EpiWide): every operand row 16-byte aligned
+bool wide_epilogue_ok(const mtd_conv_args& a) {
+    if (!aligned16(a.out) || (a.out_ld % 4)) return false;
+    if (a.bias && !aligned16(a.bias)) return false;
+    if (a.add1 && (!aligned16(a.add1) || (a.add1_ld % 4))) return false;
+    if (a.add2 && (!aligned16(a.add2) || (a.add2_ld % 4))) return false;
+    if (a.mask && (!aligned16(a.mask) || (a.mask_ld % 4))) return false;
+    if (a.out2 && (!aligned16(a.out2) || (a.out2_ld % 4))) return false;
+    return true;
 }
 
 // the halo-tile kernel's geometry: 3x3, stride 1, every tap within one pixel of the output position, 64-pixel rows
@@ -1248,6 +1361,10 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
             MTD_LAUNCH((igemm_c32t_kernel<2, false>), dim3(ntiles < 512 ? ntiles : 512, a->N / 32), dim3(256), 0, s, p, ntiles, env_stagger);
         } else {
             const int ntiles = p.M / (C32T_R * C32T_W);
+            static const int env_wide = [] { const char* e = getenv("MTD_C32T_WIDE"); return e ? atoi(e) : 1; }();
+            if (env_wide && wide_epilogue_ok(*a))
+                MTD_LAUNCH((igemm_c32t_kernel<C32T_R, true, true>), dim3(ntiles < 256 ? ntiles : 256, a->N / 32), dim3(512), 0, s, p, ntiles, 0);
+            else
             MTD_LAUNCH((igemm_c32t_kernel<C32T_R, true>), dim3(ntiles < 256 ? ntiles : 256, a->N / 32), dim3(512), 0, s, p, ntiles, 0);
         }
         mtd_prof_end(prof, s);

@@ -344,11 +344,12 @@ def test_fused_c32_backward_launch(hip_lib, B):
     w = (torch.randn(32, 32, 3, 3, generator=gen) * 0.1).cuda()
     gf, gt = K.geom_fwd(B, H, W, 3, 1, 1), K.geom_dgrad_s1(B, H, W, 3, 1)
     for kind in ("conv", "convT"):
+        second = B * H * W >= 32768          # (the unfused halo-tile launch takes a second output from 32768 pixels on)
         if kind == "conv":      # layer y = conv(x, w): dgrad gathers with the transposed view, wgrad with the forward geometry
-            dg = lambda out, out2: ((p_, w, gt, 32, 32, 9, 32 * 9, out), dict(add1=add1, mask=mask, mask_slope=0.0, out2=out2))
+            dg = lambda out, out2: ((p_, w, gt, 32, 32, 9, 32 * 9, out), dict(add1=add1, mask=mask, mask_slope=0.0, out2=out2 if second else None))
             wgeo, wsn, wsc = gf, 32 * 9, 9
         else:                   # layer y = conv_transpose(x, w): dgrad is a plain conv, wgrad has mirrored taps
-            dg = lambda out, out2: ((p_, w, gf, 32, 32, 32 * 9, 9, out), dict(add1=add1, mask=mask, mask_slope=0.0, out2=out2))
+            dg = lambda out, out2: ((p_, w, gf, 32, 32, 32 * 9, 9, out), dict(add1=add1, mask=mask, mask_slope=0.0, out2=out2 if second else None))
             wgeo, wsn, wsc = gt, 9, 32 * 9
         res = []
         for fused in (False, True):
@@ -379,5 +380,6 @@ def test_fused_c32_backward_launch(hip_lib, B):
         assert relerr(dw_b.cpu(), wc.grad) < TOL, kind
         assert relerr(db_b.cpu(), pc.sum((0, 2, 3))) < TOL, kind
         want = (qc.grad + nchw(add1).double())
-        assert relerr(nchw(o2_b), want) < TOL, kind
+        if second:
+            assert relerr(nchw(o2_b), want) < TOL, kind
         assert relerr(nchw(o_b), want * (nchw(mask) > 0)) < TOL, kind
