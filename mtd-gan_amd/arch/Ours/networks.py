@@ -333,6 +333,391 @@ class Multi_Task_Discriminator_Skip(nn.Module):
 
 
 # =================================================================================================
+# Ablation family (reference networks.py:478-1937): RED-CNN generator, the five partial discriminators
+# and the ten wrappers.  Same kernels and schedules as above -- the discriminators are the trunk of
+# Multi_Task_Discriminator_Skip with a subset of its heads (discriminator_path.disc_forward(heads=...)).
+# The wrappers' d_loss / g_loss return ONE scalar (engine.train_MTD_GAN_Ours runs them with
+# method_D=None: plain .backward(), engine.py:56-73), so they are composed from the autograd nodes of
+# this module and of losses.py.  Not mirrored: the reference's print() of the score maxima in every
+# d_loss / g_loss (a host synchronisation per call).
+# =================================================================================================
+class _RedcnnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, nlayers, *params):
+        n = nlayers + 1
+        enc_w, enc_b = list(params[0:2 * n:2]), list(params[1:2 * n:2])
+        dec_w, dec_b = list(params[2 * n:4 * n:2]), list(params[2 * n + 1:4 * n:2])
+        need = any(ctx.needs_input_grad)
+        xn = x.reshape(x.shape[0], x.shape[2], x.shape[3], 1)
+        out, tape = GP.redcnn_forward(xn, enc_w, enc_b, dec_w, dec_b, need)
+        if need:
+            ctx.tape, ctx.w = tape, (enc_w, dec_w, params)
+        return out.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        enc_w, dec_w, params = ctx.w
+        n = len(enc_w)
+        grads = [torch.empty_like(p) for p in params]
+        gn = g.contiguous().reshape(g.shape[0], g.shape[2], g.shape[3], 1)
+        GP.redcnn_backward(gn, ctx.tape, enc_w, dec_w, grads[0:2 * n:2], grads[1:2 * n:2], grads[2 * n:4 * n:2], grads[2 * n + 1:4 * n:2])
+        ctx.tape = None
+        return (None, None) + tuple(grads)
+
+
+class REDCNN_Generator(nn.Module):
+    """Reference networks.py:478-505: 11 conv + 11 conv-transpose (stride 1), additive skips from every encoder INPUT,
+    no Res-FFT blocks; every Conv* layer is re-initialised N(0, 0.01) (unlike ResFFT_Generator, whose ConvTranspose2d
+    layers keep PyTorch's default init).  HIP path: the ablation wrappers' configuration (1, 32, 10, 3, 1), 64 x 64 patches."""
+
+    def __init__(self, in_channels=1, out_channels=96, num_layers=10, kernel_size=5, padding=0):
+        super().__init__()
+        encoder = [nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=1, padding=padding)]
+        decoder = [nn.ConvTranspose2d(out_channels, in_channels, kernel_size=kernel_size, stride=1, padding=padding)]
+        for _ in range(num_layers):
+            encoder.append(nn.Conv2d(out_channels, out_channels, kernel_size=kernel_size, stride=1, padding=padding))
+            decoder.append(nn.ConvTranspose2d(out_channels, out_channels, kernel_size=kernel_size, stride=1, padding=padding))
+        self.encoder = nn.ModuleList(encoder)
+        self.decoder = nn.ModuleList(decoder)
+        self._cfg = (in_channels, out_channels, num_layers, kernel_size, padding)
+        self.__init_weights()
+
+    def __init_weights(self):
+        for m in self.modules():
+            if m.__class__.__name__.find("Conv") != -1:
+                m.weight.data.normal_(0, 0.01)
+                if hasattr(m.bias, "data"):
+                    m.bias.data.fill_(0)
+
+    def _flat_params(self):
+        flat = []
+        for m in self.encoder:
+            flat += [m.weight, m.bias]
+        for m in self.decoder:
+            flat += [m.weight, m.bias]
+        return flat
+
+    def forward(self, x: torch.Tensor):
+        _require_cuda(x, "REDCNN_Generator")
+        if self._cfg != (1, 32, 10, 3, 1):
+            raise NotImplementedError("REDCNN_Generator HIP path is built for the ablation wrappers' (1,32,10,3,1) configuration")
+        if x.dim() != 4 or tuple(x.shape[1:]) != (1, 64, 64):
+            raise NotImplementedError(f"REDCNN_Generator HIP path expects (B,1,64,64) patches, got {tuple(x.shape)}")
+        return _RedcnnFn.apply(x.contiguous().float(), self._cfg[2], *self._flat_params())
+
+
+class _PartialDiscFn(torch.autograd.Function):
+    """One pass of a partial discriminator as an autograd node (the generic twin of _DiscFn: parameter names are mapped
+    to Multi_Task_Discriminator_Skip's, absent heads give None)."""
+
+    @staticmethod
+    def forward(ctx, x, module, train, mask, *params):
+        ctx.set_materialize_grads(False)
+        names = module._canon_names
+        P = dict(zip(names, params))
+        P.update({module._canon(n): b for n, b in module.named_buffers()})
+        xn = x.reshape(x.shape[0], 64, 64, 1)
+        need = any(ctx.needs_input_grad)
+        (enc, dec, rec), tape = DP.disc_forward(P, xn, train, mask, True, need, heads=module.HEADS)
+        if need:
+            ctx.tape, ctx.P, ctx.module, ctx.names = tape, P, module, names
+        B = x.shape[0]
+        return (enc.reshape(B, 1) if enc is not None else None, dec.reshape(B, 1, 64, 64) if dec is not None else None,
+                rec.reshape(B, 1, 64, 64) if rec is not None else None)
+
+    @staticmethod
+    def backward(ctx, g_enc, g_dec, g_rec):
+        B = ctx.tape.B
+        names, P = ctx.names, ctx.P
+        needs = ctx.needs_input_grad[4:]
+        sink_t = {n: torch.zeros_like(P[n]) for n, need in zip(names, needs) if need and n not in ctx.module._unused}
+        f = lambda g, shape: g.contiguous().reshape(shape) if g is not None else None
+        gin = DP.disc_backward(ctx.module._rt, P, ctx.tape, f(g_enc, (B, 1, 1, 1)), f(g_dec, (B, 64, 64, 1)), f(g_rec, (B, 64, 64, 1)),
+                               DP.GradSink(sink_t) if sink_t else None, ctx.needs_input_grad[0])
+        K.side_stream(P[names[0]].device).join()
+        gx = gin.reshape(B, 1, 64, 64) if gin is not None else None
+        return (gx, None, None, None) + tuple(sink_t.get(n) for n in names)
+
+
+class _PartialDiscriminator(nn.Module):
+    """Trunk of Multi_Task_Discriminator_Skip + the heads in HEADS, attribute names as in the reference class.
+    SEG_PREFIX: '' for SEG_Discriminator (up1, dconv11, ...: networks.py:611-697), 's_' otherwise."""
+
+    HEADS = ()
+    SEG_PREFIX = "s_"
+    EXTRA_ENC_OUT = False          # SEG_Discriminator carries an enc_out Linear that its forward never uses (networks.py:695)
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        if (in_channels, out_channels) != (1, 64):
+            raise NotImplementedError("HIP path is built for the ablation wrappers' (1, 64) configuration")
+        sn = nn.utils.spectral_norm
+        c = out_channels
+        cin = in_channels
+        for l, co in enumerate([c, c * 2, c * 4, c * 8, c * 8, c * 8], start=1):
+            setattr(self, f"conv{l}1", sn(nn.Conv2d(cin, co, 3, 1, 1)))
+            setattr(self, f"relu{l}1", nn.LeakyReLU(0.2))
+            setattr(self, f"conv{l}2", sn(nn.Conv2d(co, co, 3, 1, 1)))
+            setattr(self, f"relu{l}2", nn.LeakyReLU(0.2))
+            setattr(self, f"down{l}", sn(nn.Conv2d(co, co, 4, 2, 1)))
+            cin = co
+        self.bconv1 = sn(nn.Conv2d(c * 8, c * 8, 1, 1, 0))
+        self.brelu1 = nn.LeakyReLU(0.2)
+        self.bconv2 = sn(nn.Conv2d(c * 8, c * 8, 1, 1, 0))
+        self.brelu2 = nn.LeakyReLU(0.2)
+        if "cls" in self.HEADS:
+            self.c_flatten = nn.Flatten()
+            self.c_fc = sn(nn.Linear(512, 512, True))
+            self.c_relu = nn.LeakyReLU(0.2)
+            self.c_drop = nn.Dropout(p=0.3)
+        for head, pre in (("seg", self.SEG_PREFIX), ("rec", "r_")):
+            if head not in self.HEADS:
+                continue
+            for l, (ci, co) in enumerate(DP.DEC, start=1):
+                if head == "seg":
+                    setattr(self, f"{pre}up{l}", nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False))
+                else:
+                    setattr(self, f"{pre}up{l}", UpsampleBlock(2, DP.RUP[l - 1][0], DP.RUP[l - 1][1]))
+                setattr(self, f"{pre}dconv{l}1", sn(nn.Conv2d(ci, co, 3, 1, 1)))
+                setattr(self, f"{pre}drelu{l}1", nn.LeakyReLU(0.2))
+                setattr(self, f"{pre}dconv{l}2", sn(nn.Conv2d(co, co, 3, 1, 1)))
+                setattr(self, f"{pre}drelu{l}2", nn.LeakyReLU(0.2))
+        if "cls" in self.HEADS or self.EXTRA_ENC_OUT:
+            self.enc_out = nn.Linear(512, 1)
+        if "seg" in self.HEADS:
+            self.dec_out = nn.Conv2d(in_channels, 1, 1)
+        if "rec" in self.HEADS:
+            self.rec_out = nn.Conv2d(in_channels, 1, 1)
+        self.__init_weights()
+        self._rt = DP.DiscRuntime()
+        self._canon_names = [self._canon(n) for n, _ in self.named_parameters()]
+        self._unused = {"enc_out.weight", "enc_out.bias"} if (self.EXTRA_ENC_OUT and "cls" not in self.HEADS) else set()
+        self._inject_masks = []
+
+    def __init_weights(self):
+        for m in self.modules():
+            if type(m) in {nn.Conv2d, nn.Linear}:
+                m.weight.data.normal_(0, 0.01)
+                if hasattr(m.bias, "data"):
+                    m.bias.data.fill_(0)
+
+    def _canon(self, name):
+        """This class's parameter / buffer name -> Multi_Task_Discriminator_Skip's (the schedules' vocabulary)."""
+        if self.SEG_PREFIX == "" and name.startswith("dconv"):
+            return "s_" + name
+        return name
+
+    def _next_mask(self, B, device):
+        if not self.training or "cls" not in self.HEADS:
+            return None
+        if self._inject_masks:
+            return self._inject_masks.pop(0).to(device)
+        p = self.c_drop.p
+        if p == 0.0:
+            return None
+        return (torch.rand(B, 512, device=device) >= p).to(torch.float32) / (1.0 - p)
+
+    def _run(self, input):
+        _require_cuda(input, type(self).__name__)
+        if input.dim() != 4 or tuple(input.shape[1:]) != (1, 64, 64):
+            raise NotImplementedError(f"discriminator expects (B,1,64,64), got {tuple(input.shape)}")
+        x = input.contiguous().float()
+        mask = self._next_mask(x.shape[0], x.device)
+        return _PartialDiscFn.apply(x, self, self.training, mask, *[p for _, p in self.named_parameters()])
+
+
+class CLS_Discriminator(_PartialDiscriminator):
+    """networks.py:507-609: trunk + image-level head; returns x_enc."""
+    HEADS = ("cls",)
+
+    def forward(self, input):
+        return self._run(input)[0]
+
+
+class SEG_Discriminator(_PartialDiscriminator):
+    """networks.py:611-764: trunk + bilinear pixel-level decoder (attributes up{l} / dconv{l}{j}, no prefix); returns x_dec."""
+    HEADS = ("seg",)
+    SEG_PREFIX = ""
+    EXTRA_ENC_OUT = True
+
+    def forward(self, input):
+        return self._run(input)[1]
+
+
+class CLS_SEG_Discriminator(_PartialDiscriminator):
+    """networks.py:766-932; returns (x_enc, x_dec)."""
+    HEADS = ("cls", "seg")
+
+    def forward(self, input):
+        e, d, _ = self._run(input)
+        return e, d
+
+
+class CLS_REC_Discriminator(_PartialDiscriminator):
+    """networks.py:934-1101; returns (x_enc, x_rec)."""
+    HEADS = ("cls", "rec")
+
+    def forward(self, input):
+        e, _, r = self._run(input)
+        return e, r
+
+
+class SEG_REC_Discriminator(_PartialDiscriminator):
+    """networks.py:1103-1322; returns (x_dec, x_rec)."""
+    HEADS = ("seg", "rec")
+
+    def forward(self, input):
+        _, d, r = self._run(input)
+        return d, r
+
+
+def _l1(a, b):
+    from ...losses import l1_loss
+    return l1_loss(a, b)
+
+
+def _mse(a, b):
+    from ...losses import mse_loss
+    return mse_loss(a, b)
+
+
+class _AblationBase(nn.Module):
+    """Shared body of the ten ablation wrappers (networks.py:1324-1937).  Class attributes say which generator and
+    discriminator the wrapper owns and which terms its losses have; the formulas below are the reference's, term by term,
+    including its quirks (Ablation_CLS_REC's generator loss scores the RESTORATION output with ls_gan and logs it as
+    'G/gen_dec', networks.py:1520-1538)."""
+
+    GEN = "redcnn"               # or "resfft"
+    DISC = None                  # discriminator class
+    OUTS = ()                    # what the discriminator returns, in order: "enc", "dec", "rec"
+    NDS = False                  # pixel-level adversarial terms through NDS_Loss(x - y) instead of ls_gan
+    RC = False                   # restoration-consistency terms
+
+    def __init__(self):
+        super().__init__()
+        self.Generator = (REDCNN_Generator if self.GEN == "redcnn" else ResFFT_Generator)(in_channels=1, out_channels=32, num_layers=10,
+                                                                                       kernel_size=3, padding=1)
+        self.Discriminator = self.DISC(in_channels=1, out_channels=64)
+        if self.NDS:
+            self.gan_metric_cls = ls_gan
+            self.gan_metric_seg = NDS_Loss
+        else:
+            self.gan_metric = ls_gan
+        self.pixel_loss = CharbonnierLoss()
+        self.edge_loss = EdgeLoss()
+
+    def _d(self, t):
+        o = self.Discriminator(t)
+        o = o if isinstance(o, tuple) else (o,)
+        return dict(zip(self.OUTS, o))
+
+    def _cls(self, t, target):
+        return ls_gan(t, target)
+
+    def _seg(self, t, target, x, y):
+        return NDS_Loss(t, target, x - y) if self.NDS else ls_gan(t, target)
+
+    def d_loss(self, x, y):
+        from ...losses import clip01
+        fake = self.Generator(x).detach()
+        real, fk = self._d(y), self._d(fake)
+        details = {}
+        if "enc" in real:
+            details["D/real_enc"], details["D/fake_enc"] = self._cls(real["enc"], 1.0), self._cls(fk["enc"], 0.0)
+        if "dec" in real:
+            details["D/real_dec"], details["D/fake_dec"] = self._seg(real["dec"], 1.0, x, y), self._seg(fk["dec"], 0.0, x, y)
+        if self.ENC_DEC_ORDER_INTERLEAVED:      # (summation order of the reference's expression, for bit-level agreement of the total)
+            order = ["D/real_enc", "D/real_dec", "D/fake_enc", "D/fake_dec"]
+        else:
+            order = ["D/real_enc", "D/fake_enc", "D/real_dec", "D/fake_dec"]
+        terms = [details[k] for k in order if k in details]
+        total = terms[0]
+        for t in terms[1:]:
+            total = total + t
+        # the reference recomputes every logged adversarial term (a second, identical kernel launch): same values
+        if "rec" in real:
+            details["D/rec_loss_real"] = _l1(real["rec"], y)
+            details["D/rec_loss_fake"] = _l1(fk["rec"], fake)
+            total = total + (details["D/rec_loss_real"] + details["D/rec_loss_fake"])
+        if self.RC:
+            rr, rf = self._d(clip01(real["rec"])), self._d(clip01(fk["rec"]))
+            c = {"D/consist_loss_real_enc": _mse(real["enc"], rr["enc"]), "D/consist_loss_real_dec": _mse(real["dec"], rr["dec"]),
+                 "D/consist_loss_fake_enc": _mse(fk["enc"], rf["enc"]), "D/consist_loss_fake_dec": _mse(fk["dec"], rf["dec"])}
+            details.update(c)
+            total = total + (((c["D/consist_loss_real_enc"] + c["D/consist_loss_real_dec"]) + c["D/consist_loss_fake_enc"])
+                             + c["D/consist_loss_fake_dec"])
+        return total, details
+
+    ENC_DEC_ORDER_INTERLEAVED = False
+
+    def g_loss(self, x, y):
+        fake = self.Generator(x)
+        gen = self._d(fake)
+        details = {}
+        adv = None
+        for out_key, name in self.G_TERMS:
+            # the reference's wrappers score whatever their discriminator returns FIRST / SECOND and log it as gen_enc / gen_dec
+            # (Ablation_SEG_REC: the pixel-level map and the restoration; Ablation_CLS_REC: the score and the restoration)
+            t = self._seg(gen[out_key], 1.0, x, y) if (out_key == "dec" and name == "G/gen_dec") else ls_gan(gen[out_key], 1.0)
+            details[name] = t
+            adv = t if adv is None else adv + t
+        pix = 50.0 * self.pixel_loss(fake, y)
+        edge = 50.0 * self.edge_loss(fake, y)
+        details["G/pix_loss"], details["G/edge_loss"] = pix, edge
+        return adv + pix + edge, details
+
+    G_TERMS = ()
+
+
+_G_ENC, _G_ENC_DEC = (("enc", "G/gen_enc"),), (("enc", "G/gen_enc"), ("dec", "G/gen_dec"))
+
+
+class Ablation_CLS(_AblationBase):
+    DISC, OUTS, G_TERMS = CLS_Discriminator, ("enc",), _G_ENC
+
+
+class Ablation_SEG(_AblationBase):
+    """networks.py:1374-1424: the pixel-level map is called *_enc throughout this wrapper (same keys as Ablation_CLS)."""
+    DISC, OUTS, G_TERMS = SEG_Discriminator, ("enc",), _G_ENC
+
+
+class Ablation_CLS_SEG(_AblationBase):
+    DISC, OUTS, G_TERMS = CLS_SEG_Discriminator, ("enc", "dec"), _G_ENC_DEC
+    ENC_DEC_ORDER_INTERLEAVED = True
+
+
+class Ablation_CLS_REC(_AblationBase):
+    DISC, OUTS, G_TERMS = CLS_REC_Discriminator, ("enc", "rec"), (("enc", "G/gen_enc"), ("rec", "G/gen_dec"))
+
+
+class Ablation_SEG_REC(_AblationBase):
+    DISC, OUTS, G_TERMS = SEG_REC_Discriminator, ("dec", "rec"), (("dec", "G/gen_enc"), ("rec", "G/gen_dec"))
+
+
+class Ablation_CLS_SEG_REC(_AblationBase):
+    DISC, OUTS, G_TERMS = Multi_Task_Discriminator_Skip, ("enc", "dec", "rec"), _G_ENC_DEC
+    ENC_DEC_ORDER_INTERLEAVED = True
+
+
+class Ablation_CLS_SEG_REC_NDS(_AblationBase):
+    DISC, OUTS, G_TERMS, NDS = Multi_Task_Discriminator_Skip, ("enc", "dec", "rec"), _G_ENC_DEC, True
+
+
+class Ablation_CLS_SEG_REC_RC(_AblationBase):
+    DISC, OUTS, G_TERMS, RC = Multi_Task_Discriminator_Skip, ("enc", "dec", "rec"), _G_ENC_DEC, True
+    ENC_DEC_ORDER_INTERLEAVED = True
+
+
+class Ablation_CLS_SEG_REC_NDS_RC(_AblationBase):
+    DISC, OUTS, G_TERMS, NDS, RC = Multi_Task_Discriminator_Skip, ("enc", "dec", "rec"), _G_ENC_DEC, True, True
+
+
+class Ablation_CLS_SEG_REC_NDS_RC_ResFFT(_AblationBase):
+    GEN = "resfft"
+    DISC, OUTS, G_TERMS, NDS, RC = Multi_Task_Discriminator_Skip, ("enc", "dec", "rec"), _G_ENC_DEC, True, True
+
+
+# =================================================================================================
 # MTD-GAN (reference networks.py:1940-2009)
 # =================================================================================================
 class MTD_GAN_Method(nn.Module):

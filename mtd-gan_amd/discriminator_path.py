@@ -62,7 +62,9 @@ def conv_views(P, backward):
     v = []
 
     def add(name, N, Cc, k, suffix=".weight_orig"):
-        w = P[name + suffix]
+        w = P.get(name + suffix)
+        if w is None:                                          # a head this discriminator does not have (ablation subsets)
+            return
         v.append((w, N, Cc, Cc * k * k, k * k))               # forward view (OIHW)
         if backward:
             v.append((w, Cc, N, k * k, Cc * k * k))           # data-gradient view (transposed)
@@ -114,6 +116,8 @@ def _sn_forward(P, train, device):
     v_save = torch.empty(SN_COLS_TOTAL, dtype=torch.float32, device=device)
     structs = []
     for i, (n, rows, cols) in enumerate(SN_SPECS):
+        if n + ".weight_orig" not in P:                        # ablation subsets: no such layer, its sigma slot stays unused
+            continue
         s = _lib.SnLayer()
         s.w = P[n + ".weight_orig"].data_ptr()
         s.u = P[n + ".weight_u"].data_ptr()
@@ -152,9 +156,13 @@ def _sn_conv(P, tape, name, x, out, geom, N, Cc, k, act):
                   **_scales(tape, name, geom))
 
 
-def disc_forward(P, x, train, drop_mask, need_rec, save, sn=None, sn2=None, pair=0):
+def disc_forward(P, x, train, drop_mask, need_rec, save, sn=None, sn2=None, pair=0, heads=("cls", "seg", "rec")):
     """x: (B,64,64,1) NHWC.  P: dict name -> tensor (reference state_dict names).  drop_mask: (B,512)
     multiplier or None.  Returns ((enc (B,1,1,1), dec (B,64,64,1), rec or None), tape).
+    heads: which of the image-level head ("cls"), the bilinear pixel-level decoder ("seg") and the PixelShuffle
+    restoration decoder ("rec") this discriminator has -- the reference's ablation discriminators (networks.py:507-1322:
+    CLS_, SEG_, CLS_SEG_, CLS_REC_, SEG_REC_Discriminator) are the same trunk with a subset of them; outputs of absent
+    heads are None.
     Paired mode (train_step.d_loss): x stacks TWO passes of the reference along the batch, the first `pair` images being
     the earlier pass; sn / sn2 are their power-iteration results (sigma table, u, v), run ahead of time in the reference's
     order.  Every conv then serves both passes in one launch with the 1/sigma of each half (scale2 / scale_split)."""
@@ -188,15 +196,17 @@ def disc_forward(P, x, train, drop_mask, need_rec, save, sn=None, sn2=None, pair
     tp.bot = K.empty_nhwc(B, 1, 1, 512, x)
     _sn_conv(P, tp, "bconv2", tp.b1, tp.bot, g1, 512, 512, 1, ACT_LRELU)
     # ---- CLS head (networks.py:414-417, 470)
-    tp.c = K.empty_nhwc(B, 1, 1, 512, x)
-    _sn_conv(P, tp, "c_fc", tp.bot, tp.c, g1, 512, 512, 1, ACT_LRELU)
-    tp.cm = K.mul(tp.c, drop_mask.reshape(B, 1, 1, 512)) if drop_mask is not None else tp.c
-    enc = K.empty_nhwc(B, 1, 1, 1, x)
-    K.conv(tp.cm, P["enc_out.weight"], g1, 1, 512, 512, 1, enc, bias=P["enc_out.bias"])
+    enc = None
+    if "cls" in heads:
+        tp.c = K.empty_nhwc(B, 1, 1, 512, x)
+        _sn_conv(P, tp, "c_fc", tp.bot, tp.c, g1, 512, 512, 1, ACT_LRELU)
+        tp.cm = K.mul(tp.c, drop_mask.reshape(B, 1, 1, 512)) if drop_mask is not None else tp.c
+        enc = K.empty_nhwc(B, 1, 1, 1, x)
+        K.conv(tp.cm, P["enc_out.weight"], g1, 1, 512, 512, 1, enc, bias=P["enc_out.bias"])
     # ---- SEG decoder (networks.py:420-442)
     tp.s_cat, tp.s_o1, tp.s_o2, tp.s_in = {}, {}, {}, {}
     t, r = tp.bot, 1
-    for lvl in range(1, 7):
+    for lvl in range(1, 7) if "seg" in heads else ():
         r *= 2
         cprev = t.shape[3]
         skip = tp.xs[7 - lvl]
@@ -212,11 +222,13 @@ def disc_forward(P, x, train, drop_mask, need_rec, save, sn=None, sn2=None, pair
         tp.s_in[lvl], tp.s_cat[lvl], tp.s_o1[lvl], tp.s_o2[lvl] = t, cat, o1, o2
         t = o2
     g64 = K.geom_fwd(B, 64, 64, 1, 1, 0)
-    dec = K.empty_nhwc(B, 64, 64, 1, x)
-    K.conv(t, P["dec_out.weight"], g64, 1, 1, 1, 1, dec, bias=P["dec_out.bias"])
+    dec = None
+    if "seg" in heads:
+        dec = K.empty_nhwc(B, 64, 64, 1, x)
+        K.conv(t, P["dec_out.weight"], g64, 1, 1, 1, 1, dec, bias=P["dec_out.bias"])
     # ---- REC decoder (networks.py:445-467)
     rec = None
-    if need_rec:
+    if need_rec and "rec" in heads:
         tp.r_cat, tp.r_o1, tp.r_o2, tp.r_in = {}, {}, {}, {}
         t, r = tp.bot, 1
         for lvl in range(1, 7):

@@ -14,9 +14,14 @@ def train_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp=None):
     optimizer_D.zero_grad()
     D.zero_grad()
     d_losses, d_details = model.d_loss(x, y)
-    method_D.backward(losses=d_losses, shared_parameters=list(D.shared_parameters()),
-                      task_specific_parameters=list(D.task_specific_parameters()),
-                      last_shared_parameters=list(D.last_shared_parameters()))
+    if method_D is not None:
+        method_D.backward(losses=d_losses, shared_parameters=list(D.shared_parameters()),
+                          task_specific_parameters=list(D.task_specific_parameters()),
+                          last_shared_parameters=list(D.last_shared_parameters()))
+    else:
+        d_losses.backward()                 # engine.py:56-63: the ablation wrappers return one scalar
+        if dp is not None:
+            dp.all_reduce_avg_list([p.grad for p in D.parameters() if p.grad is not None])
     optimizer_D.step()
     # ---- Generator
     optimizer_G.zero_grad()
@@ -27,8 +32,8 @@ def train_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp=None):
         dp.all_reduce_avg_list([p.grad for p in G.parameters()])
     optimizer_G.step()
     names = ["d_loss"] + list(d_details.keys()) + ["g_loss"] + list(g_details.keys())
-    vals = torch.stack([d_losses.sum()] + [v.reshape(()) for v in d_details.values()] + [g_loss.detach().reshape(())]
-                       + [v.reshape(()) for v in g_details.values()])
+    vals = torch.stack([d_losses.detach().sum()] + [v.detach().reshape(()) for v in d_details.values()] + [g_loss.detach().reshape(())]
+                       + [v.detach().reshape(()) for v in g_details.values()])
     return names, vals
 
 
@@ -48,8 +53,9 @@ class _Meter:
 def train_MTD_GAN_Ours(model, data_loader, optimizer_G, optimizer_D, device, epoch, print_freq, batch_size, method_D):
     model.Generator.train(True)
     model.Discriminator.train(True)
-    if method_D is None:
-        raise NotImplementedError("the reference's method_D=None branch calls .backward() on a 3-vector and raises; use WeightMethods('pcgrad')")
+    if method_D is None and type(model).__name__ == "MTD_GAN_Method":
+        raise NotImplementedError("the reference's method_D=None branch calls .backward() on MTD_GAN_Method's 3-vector and raises; "
+                                  "use WeightMethods('pcgrad') (method_D=None is the ablation wrappers' path)")
     meters = {}
     dp = getattr(getattr(method_D, "method", None), "dp", None)
     n_it = len(data_loader)

@@ -211,3 +211,82 @@ def generator_backward(g_out, tape, P, G):
 def _blk_w(P, i):
     w_img, b_img, w_fft, b_fft = P.blk[i]
     return w_img, w_fft
+
+
+# ------------------------------------------------------------------------------------------------ RED-CNN generator
+def redcnn_forward(x, enc_w, enc_b, dec_w, dec_b, save):
+    """reference arch/Ours/networks.py:498-505 (REDCNN_Generator.forward, the ablation family's generator):
+        residuals = inputs of the 11 encoder convs; x = relu(enc_k(x)); then, decoders in reverse,
+        x = relu(dec_k(x) + residual_k).
+    x: (B,64,64,1) NHWC.  Returns (out (B,64,64,1), tape).  Layers 1..10 are the 32 -> 32 channel 3x3 kernels of the
+    Res-FFT generator (halo-tile implicit GEMM), layer 0 the 1 -> 32 / 32 -> 1 vector kernels."""
+    B, H, W, _ = x.shape
+    L = len(enc_w) - 1
+    views = []
+    for i in range(1, L + 1):
+        views.append((enc_w[i], CH, CH, CH * 9, 9))
+        views.append((dec_w[i], CH, CH, 9, CH * 9))
+        if save:
+            views.append((enc_w[i], CH, CH, 9, CH * 9))
+            views.append((dec_w[i], CH, CH, CH * 9, 9))
+    K.prepack(views)
+    gf = K.geom_fwd(B, H, W, 3, 1, 1)
+    gt = K.geom_dgrad_s1(B, H, W, 3, 1)
+    t = [x]                                                 # t[k]: input of encoder k (the residual of decoder k)
+    for k in range(L + 1):
+        o = K.empty_nhwc(B, H, W, CH, x)
+        K.conv(t[k], enc_w[k], gf, CH, 1 if k == 0 else CH, (1 if k == 0 else CH) * 9, 9, o, bias=enc_b[k], act=ACT_RELU)
+        t.append(o)
+    u = {L + 1: t[L + 1]}                                   # u[k]: input of decoder k - 1 ... u[L + 1] = last encoder output
+    cur = t[L + 1]
+    for k in range(L, -1, -1):
+        n_out = 1 if k == 0 else CH
+        o = K.empty_nhwc(B, H, W, n_out, x)
+        K.conv(cur, dec_w[k], gt, n_out, CH, 9, n_out * 9, o, bias=dec_b[k], add1=t[k], act=ACT_RELU)
+        u[k] = o
+        cur = o
+    return cur, ({"t": t, "u": u, "x": x} if save else None)
+
+
+def redcnn_backward(g_out, tape, enc_w, dec_w, G_enc_w, G_enc_b, G_dec_w, G_dec_b):
+    """Autograd transpose of redcnn_forward: every parameter gradient is overwritten.  The 32 -> 32 layers use the fused
+    data + weight gradient launch (kernels.conv_wgrad_fused) where eligible."""
+    t, u, x = tape["t"], tape["u"], tape["x"]
+    B, H, W, _ = x.shape
+    L = len(enc_w) - 1
+    gf = K.geom_fwd(B, H, W, 3, 1, 1)
+    gt = K.geom_dgrad_s1(B, H, W, 3, 1)
+    side = K.side_stream(x.device)
+    defer = K.DeferredWgrads()
+    gpre = K.act_grad(g_out, u[0], 0.0)                     # through the output ReLU
+    # decoder 0: ConvTranspose 32 -> 1 (its residual is the network input: no gradient needed)
+    u1 = u[1]
+    side.run(lambda: K.wgrad(gpre, u1, gt, 1, CH, G_dec_w[0], 9, 9, db=G_dec_b[0]), gpre)
+    g = K.empty_nhwc(B, H, W, CH, x)
+    K.conv(gpre, dec_w[0], gf, CH, 1, 9, 9, g, mask=u[1], mask_slope=0.0)      # gradient of u[1]'s pre-activation
+    skip = [None] * (L + 2)
+    for k in range(1, L + 1):                               # decoders 1..L: pre-activation gradient g of u[k]
+        skip[k] = g                                         # flows unchanged into the residual t[k]
+        nxt = K.empty_nhwc(B, H, W, CH, x)
+        src = u[k + 1]                                      # input of decoder k (u[L + 1] = t[L + 1])
+        wg = ((g, src, gt, CH, CH, G_dec_w[k], 9, CH * 9), dict(db=G_dec_b[k]))
+        kw = dict(mask=src, mask_slope=0.0)                 # times (input > 0): the pre-activation gradient of the producer
+        dg = ((g, dec_w[k], gf, CH, CH, CH * 9, 9, nxt), kw)
+        if not K.conv_wgrad_fused(dg, wg, defer):
+            side.run(lambda wg=wg, k=k: K.wgrad(*wg[0], db=G_dec_b[k], defer=defer), g)
+            K.conv(*dg[0], **dg[1])
+        g = nxt
+    # g: pre-activation gradient of t[L + 1] (the last encoder's output feeds decoder L only)
+    for k in range(L, -1, -1):                              # encoders L..0; encoder k maps t[k] -> t[k + 1]
+        if k > 0:
+            nxt = K.empty_nhwc(B, H, W, CH, x)
+            wg = ((g, t[k], gf, CH, CH, G_enc_w[k], CH * 9, 9), dict(db=G_enc_b[k]))
+            dg = ((g, enc_w[k], K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, nxt), dict(add1=skip[k], mask=t[k], mask_slope=0.0))
+            if not K.conv_wgrad_fused(dg, wg, defer):
+                side.run(lambda wg=wg, k=k: K.wgrad(*wg[0], db=G_enc_b[k], defer=defer), g)
+                K.conv(*dg[0], **dg[1])
+            g = nxt
+        else:
+            side.run(lambda g=g: K.wgrad(g, x, gf, CH, 1, G_enc_w[0], 9, 9, db=G_enc_b[0]), g)
+    side.join()
+    K.flush_wgrads(defer)

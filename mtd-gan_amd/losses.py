@@ -47,6 +47,25 @@ def mse_loss(a, b):
     return _TermFn.apply(a, 0, b, 0.0, None, 1.0 / a.numel(), 0.0)
 
 
+class _ClipFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        xc = x.contiguous()
+        ctx.save_for_backward(xc)
+        return K.clip01(xc)
+
+    @staticmethod
+    def backward(ctx, g):
+        (xc,) = ctx.saved_tensors
+        return K.clip01_bwd(g.contiguous(), xc)
+
+
+def clip01(x):
+    """x.clip(0, 1) with torch's gradient (1 inside [0, 1], boundaries included; 0 outside): networks.py:1750-1751,
+    :1824-1825 (the restoration-consistency passes of the ablation wrappers)."""
+    return _ClipFn.apply(x)
+
+
 class CharbonnierLoss(torch.nn.Module):
     def __init__(self, eps=1e-3):
         super().__init__()

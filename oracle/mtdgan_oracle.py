@@ -26,6 +26,8 @@ Reference anchors (file:line under /root/reference):
   d_loss / g_loss         arch/Ours/networks.py:1957-2009
   pcgrad_*                module/weight_methods.py:429-468
   pcgrad_wrapper_merge    module/pcgrad.py:50-69 (the optimizer wrapper's projection + mean / sum reduction)
+  redcnn_forward          arch/Ours/networks.py:478-505
+  ablation_losses         arch/Ours/networks.py:1324-1937 (the ten Ablation_* wrappers; partial discriminators :507-1322)
   adamw_step              train.py:122-126, optimizers.py:8-9 (torch.optim.AdamW)
   train_step              engine.py:33-55
   psnr / ssim / rmse      metrics.py:172-244
@@ -281,10 +283,12 @@ class DState:
         return self.s[self.pre + k]
 
 
-def discriminator_forward(state, x, train=True, drop_mask=None, pre="", need_rec=True):
+def discriminator_forward(state, x, train=True, drop_mask=None, pre="", need_rec=True, heads=("cls", "seg", "rec"), seg_prefix="s_"):
     """arch/Ours/networks.py:383-474.  Mutates the u/v entries of `state` when train=True, exactly
     as the reference's forward pre-hook does.  drop_mask: (B,512) multiplier (0 or 1/(1-p)); None =
-    no dropout (eval, or p=0).  Module call order (and so the u/v update order) follows forward()."""
+    no dropout (eval, or p=0).  Module call order (and so the u/v update order) follows forward().
+    heads / seg_prefix: the ablation discriminators (networks.py:507-1322) are this network with a subset of the heads
+    (outputs of absent heads are None); SEG_Discriminator names its decoder layers without the 's_' prefix."""
     st = DState(state, pre)
     lrelu = lambda t: F.leaky_relu(t, 0.2)
     t = x
@@ -302,22 +306,24 @@ def discriminator_forward(state, x, train=True, drop_mask=None, pre="", need_rec
     w, b = st.sn("bconv2", train)
     bot = lrelu(F.conv2d(t, w, b))
     # CLS
-    w, b = st.sn("c_fc", train)
-    c = lrelu(F.linear(bot.flatten(1), w, b))
-    if drop_mask is not None:
-        c = c * drop_mask
+    c = None
+    if "cls" in heads:
+        w, b = st.sn("c_fc", train)
+        c = lrelu(F.linear(bot.flatten(1), w, b))
+        if drop_mask is not None:
+            c = c * drop_mask
     # SEG
     t = bot
-    for lvl in range(1, 7):
+    for lvl in range(1, 7) if "seg" in heads else ():
         t = F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False)
-        w, b = st.sn(f"s_dconv{lvl}1", train)
+        w, b = st.sn(f"{seg_prefix}dconv{lvl}1", train)
         t = lrelu(F.conv2d(torch.cat([t, skips[6 - lvl]], dim=1), w, b, padding=1))
-        w, b = st.sn(f"s_dconv{lvl}2", train)
+        w, b = st.sn(f"{seg_prefix}dconv{lvl}2", train)
         t = lrelu(F.conv2d(t, w, b, padding=1))
     seg = t
     # REC
     rec = None
-    if need_rec:
+    if need_rec and "rec" in heads:
         t = bot
         for lvl in range(1, 7):
             t = F.pixel_shuffle(F.conv2d(t, st[f"r_up{lvl}.upsample.0.weight"], st[f"r_up{lvl}.upsample.0.bias"]), 2)
@@ -326,9 +332,93 @@ def discriminator_forward(state, x, train=True, drop_mask=None, pre="", need_rec
             w, b = st.sn(f"r_dconv{lvl}2", train)
             t = lrelu(F.conv2d(t, w, b, padding=1))
         rec = F.conv2d(t, st["rec_out.weight"], st["rec_out.bias"])
-    x_enc = F.linear(c, st["enc_out.weight"], st["enc_out.bias"])
-    x_dec = F.conv2d(seg, st["dec_out.weight"], st["dec_out.bias"])
+    x_enc = F.linear(c, st["enc_out.weight"], st["enc_out.bias"]) if "cls" in heads else None
+    x_dec = F.conv2d(seg, st["dec_out.weight"], st["dec_out.bias"]) if "seg" in heads else None
     return x_enc, x_dec, rec
+
+
+# ----------------------------------------------------------------------------------------------
+# Ablation family (arch/Ours/networks.py:478-1937)
+# ----------------------------------------------------------------------------------------------
+def redcnn_forward(state, x, pre=""):
+    """arch/Ours/networks.py:498-505 (REDCNN_Generator with 1,32,10,3,1)."""
+    residuals = []
+    t = x
+    for i in range(G_LAYERS + 1):
+        residuals.append(t)
+        t = F.relu(F.conv2d(t, state[f"{pre}encoder.{i}.weight"], state[f"{pre}encoder.{i}.bias"], padding=1))
+    for i in range(G_LAYERS, -1, -1):
+        t = F.relu(F.conv_transpose2d(t, state[f"{pre}decoder.{i}.weight"], state[f"{pre}decoder.{i}.bias"], padding=1) + residuals[i])
+    return t
+
+
+# name -> (generator, discriminator heads, seg prefix, discriminator outputs in order, NDS, RC, terms of the generator's
+# adversarial loss as (output, logged name), 'real_enc + real_dec + fake_enc + fake_dec' summation order)
+ABLATIONS = {
+    "Ablation_CLS": ("redcnn", ("cls",), "s_", ("enc",), False, False, (("enc", "G/gen_enc"),), False),
+    "Ablation_SEG": ("redcnn", ("seg",), "", ("enc",), False, False, (("enc", "G/gen_enc"),), False),
+    "Ablation_CLS_SEG": ("redcnn", ("cls", "seg"), "s_", ("enc", "dec"), False, False, (("enc", "G/gen_enc"), ("dec", "G/gen_dec")), True),
+    "Ablation_CLS_REC": ("redcnn", ("cls", "rec"), "s_", ("enc", "rec"), False, False, (("enc", "G/gen_enc"), ("rec", "G/gen_dec")), False),
+    "Ablation_SEG_REC": ("redcnn", ("seg", "rec"), "s_", ("dec", "rec"), False, False, (("dec", "G/gen_enc"), ("rec", "G/gen_dec")), False),
+    "Ablation_CLS_SEG_REC": ("redcnn", ("cls", "seg", "rec"), "s_", ("enc", "dec", "rec"), False, False, (("enc", "G/gen_enc"), ("dec", "G/gen_dec")), True),
+    "Ablation_CLS_SEG_REC_NDS": ("redcnn", ("cls", "seg", "rec"), "s_", ("enc", "dec", "rec"), True, False, (("enc", "G/gen_enc"), ("dec", "G/gen_dec")), False),
+    "Ablation_CLS_SEG_REC_RC": ("redcnn", ("cls", "seg", "rec"), "s_", ("enc", "dec", "rec"), False, True, (("enc", "G/gen_enc"), ("dec", "G/gen_dec")), True),
+    "Ablation_CLS_SEG_REC_NDS_RC": ("redcnn", ("cls", "seg", "rec"), "s_", ("enc", "dec", "rec"), True, True, (("enc", "G/gen_enc"), ("dec", "G/gen_dec")), False),
+    "Ablation_CLS_SEG_REC_NDS_RC_ResFFT": ("resfft", ("cls", "seg", "rec"), "s_", ("enc", "dec", "rec"), True, True, (("enc", "G/gen_enc"), ("dec", "G/gen_dec")), False),
+}
+
+
+def ablation_losses(name, state, x, y, drop_masks, which, gpre="Generator.", dpre="Discriminator."):
+    """d_loss (which='d') or g_loss (which='g') of one of the ten ablation wrappers (networks.py:1324-1937), restated.
+    drop_masks: one (B,512) multiplier per discriminator pass of the call, in order (ignored by heads without the image-level
+    branch).  Returns (total, details).  Mutates the spectral-norm u/v of `state` like the reference."""
+    gen, heads, spre, outs, nds, rc, gterms, interleaved = ABLATIONS[name]
+    masks = list(drop_masks)
+    G = (lambda t: redcnn_forward(state, t, gpre)) if gen == "redcnn" else (lambda t: generator_forward(state, t, gpre))
+
+    def D(t):
+        m = masks.pop(0) if masks else None
+        e, d, r = discriminator_forward(state, t, True, m if "cls" in heads else None, dpre, True, heads, spre)
+        vals = [v for v in (e, d, r) if v is not None]
+        return dict(zip(outs, vals))
+    seg = (lambda t, tgt: nds_loss(t, tgt, x - y)) if nds else ls_gan
+    details = OrderedDict()
+    if which == "d":
+        with torch.no_grad():
+            fake = G(x)
+        real, fk = D(y), D(fake)
+        if "enc" in real:
+            details["D/real_enc"], details["D/fake_enc"] = ls_gan(real["enc"], 1.0), ls_gan(fk["enc"], 0.0)
+        if "dec" in real:
+            details["D/real_dec"], details["D/fake_dec"] = seg(real["dec"], 1.0), seg(fk["dec"], 0.0)
+        order = ["D/real_enc", "D/real_dec", "D/fake_enc", "D/fake_dec"] if interleaved else ["D/real_enc", "D/fake_enc", "D/real_dec", "D/fake_dec"]
+        terms = [details[k] for k in order if k in details]
+        total = terms[0]
+        for t in terms[1:]:
+            total = total + t
+        if "rec" in real:
+            details["D/rec_loss_real"] = F.l1_loss(real["rec"], y)
+            details["D/rec_loss_fake"] = F.l1_loss(fk["rec"], fake)
+            total = total + (details["D/rec_loss_real"] + details["D/rec_loss_fake"])
+        if rc:
+            rr, rf = D(real["rec"].clip(0, 1)), D(fk["rec"].clip(0, 1))
+            c1, c2 = F.mse_loss(real["enc"], rr["enc"]), F.mse_loss(real["dec"], rr["dec"])
+            c3, c4 = F.mse_loss(fk["enc"], rf["enc"]), F.mse_loss(fk["dec"], rf["dec"])
+            details["D/consist_loss_real_enc"], details["D/consist_loss_real_dec"] = c1, c2
+            details["D/consist_loss_fake_enc"], details["D/consist_loss_fake_dec"] = c3, c4
+            total = total + (c1 + c2 + c3 + c4)
+        return total, details
+    fake = G(x)
+    gen_out = D(fake)
+    adv = None
+    for key, nm in gterms:
+        t = seg(gen_out[key], 1.0) if (key == "dec" and nm == "G/gen_dec") else ls_gan(gen_out[key], 1.0)
+        details[nm] = t
+        adv = t if adv is None else adv + t
+    pix = 50.0 * charbonnier(fake, y)
+    edge = 50.0 * edge_loss(fake, y)
+    details["G/pix_loss"], details["G/edge_loss"] = pix, edge
+    return adv + pix + edge, details
 
 
 # ----------------------------------------------------------------------------------------------

@@ -434,6 +434,76 @@ def main():
                       post_pred_sample=pred[:, 0, ::16, ::16].tolist(), lr=1e-4, mask_seed=33, gfill=7, dfill=9, batch=32, data_seed=1234)
     with open(os.path.join(GOLD, "step_seeded_b32.json"), "w") as f:
         json.dump(gold32, f)
+    # ------------------------------------------------------------------ 9. ablation family (networks.py:478-1937)
+    print("ablation family: RED-CNN generator, partial discriminators, ten wrappers (B=2, seeded fill)")
+    import contextlib
+    import io
+    import arch.Ours.networks as ref_nets
+    xa, ya = orc.synthetic_ldct(2, seed=1234)
+    gold_abl = {}
+    for name in orc.ABLATIONS:
+        ref_m = getattr(ref_nets, name)()
+        gsh = {k: tuple(v.shape) for k, v in ref_m.Generator.state_dict().items()}
+        dsh = {k: tuple(v.shape) for k, v in ref_m.Discriminator.state_dict().items()}
+        gst, dst = orc.seeded_fill(gsh, seed=7), orc.seeded_fill(dsh, seed=9)
+        ref_m.Generator.load_state_dict(gst)
+        ref_m.Discriminator.load_state_dict(dst)
+        ref_m.train()
+        masks_a = mask_seq(5, 2, seed=41)
+        if hasattr(ref_m.Discriminator, "c_drop"):
+            ref_m.Discriminator.c_drop = RecDrop(0.3, inject=[k.clone() for k in masks_a])
+        full_a = {"Generator." + k: v.clone() for k, v in gst.items()}
+        full_a.update({"Discriminator." + k: v.clone() for k, v in dst.items()})
+        dnames = [n for n, _ in ref_m.Discriminator.named_parameters()]
+        gnames = [n for n, _ in ref_m.Generator.named_parameters()]
+        ost = {k: v.clone() for k, v in full_a.items()}
+        for n in dnames:
+            ost["Discriminator." + n] = ost["Discriminator." + n].requires_grad_(True)
+        npass = 4 if orc.ABLATIONS[name][5] else 2
+        with contextlib.redirect_stdout(io.StringIO()):
+            d_tot, d_det = ref_m.d_loss(xa, ya)
+        d_tot.backward()
+        o_tot, o_det = orc.ablation_losses(name, ost, xa, ya, masks_a[:npass], "d")
+        close(o_tot, d_tot, 1e-6, f"{name} d_loss")
+        assert list(o_det.keys()) == list(d_det.keys()), (name, list(o_det.keys()), list(d_det.keys()))
+        for k in d_det:
+            close(o_det[k], d_det[k], 1e-5, f"{name} {k}", atol=1e-9)
+        leaves = [ost["Discriminator." + n] for n in dnames]
+        og = torch.autograd.grad(o_tot, leaves, allow_unused=True)
+        dgn, worst = {}, 0.0
+        for n, p_, g_ in zip(dnames, ref_m.Discriminator.parameters(), og):
+            assert (p_.grad is None) == (g_ is None), (name, n)
+            if p_.grad is not None:
+                worst = max(worst, (g_ - p_.grad).abs().max().item() / (p_.grad.abs().max().item() + 1e-30))
+                dgn[n] = p_.grad.double().norm().item()
+        print(f"  {name}: D grads worst rel {worst:.2e} ({len(dgn)} of {len(dnames)} parameters reached)")
+        assert worst < 1e-4
+        # generator step on the same (u, v advanced) state
+        for p_ in ref_m.parameters():
+            p_.grad = None
+        for k_ in list(ost.keys()):
+            ost[k_] = ost[k_].detach()
+        for n in gnames:
+            ost["Generator." + n] = ost["Generator." + n].requires_grad_(True)
+        with contextlib.redirect_stdout(io.StringIO()):
+            g_tot, g_det = ref_m.g_loss(xa, ya)
+        g_tot.backward()
+        o_tot, o_det = orc.ablation_losses(name, ost, xa, ya, masks_a[npass:npass + 1], "g")
+        close(o_tot, g_tot, 1e-6, f"{name} g_loss")
+        assert list(o_det.keys()) == list(g_det.keys()), (name, list(o_det.keys()), list(g_det.keys()))
+        og = torch.autograd.grad(o_tot, [ost["Generator." + n] for n in gnames])
+        ggn, worst = {}, 0.0
+        for n, p_, g_ in zip(gnames, ref_m.Generator.parameters(), og):
+            worst = max(worst, (g_ - p_.grad).abs().max().item() / (p_.grad.abs().max().item() + 1e-30))
+            ggn[n] = p_.grad.double().norm().item()
+        print(f"  {name}: G grads worst rel {worst:.2e}")
+        assert worst < 1e-4
+        gold_abl[name] = dict(g_keys=list(gsh.keys()), g_shapes=[list(v) for v in gsh.values()], d_keys=list(dsh.keys()),
+                              d_shapes=[list(v) for v in dsh.values()], d_loss=float(d_tot), d_details={k: float(v) for k, v in d_det.items()},
+                              g_loss=float(g_tot), g_details={k: float(v) for k, v in g_det.items()}, d_grad_norms=dgn, g_grad_norms=ggn,
+                              d_no_grad=[n for n in dnames if n not in dgn], mask_seed=41, gfill=7, dfill=9, batch=2, data_seed=1234)
+    with open(os.path.join(GOLD, "ablation.json"), "w") as f:
+        json.dump(gold_abl, f)
     print(f"all pins OK in {time.time() - t0:.1f}s")
 
 

@@ -187,3 +187,25 @@ def test_full_step_b32_matches_reference_vectors():
         pred = orc.generator_forward(full, x, "Generator.")
     assert abs(float(orc.psnr(pred.clip(0, 1), y)) - z["post_metrics"]["psnr"]) < 1e-4
     assert rel(pred[:, 0, ::16, ::16], torch.tensor(z["post_pred_sample"])) < 1e-5
+
+
+def test_ablation_family_matches_reference_vectors():
+    """The ten ablation wrappers (networks.py:1324-1937) of the oracle against the losses the reference classes produced."""
+    z = json.load(open(os.path.join(GOLD, "ablation.json")))
+    assert list(z.keys()) == list(orc.ABLATIONS.keys())
+    x, y = orc.synthetic_ldct(2, seed=1234)
+    for name in ("Ablation_SEG", "Ablation_CLS_REC", "Ablation_CLS_SEG_REC_NDS_RC_ResFFT"):      # (the whole family: the GPU test)
+        c = z[name]
+        st = {"Generator." + k: v for k, v in orc.seeded_fill(dict(zip(c["g_keys"], map(tuple, c["g_shapes"]))), seed=c["gfill"]).items()}
+        st.update({"Discriminator." + k: v for k, v in orc.seeded_fill(dict(zip(c["d_keys"], map(tuple, c["d_shapes"]))), seed=c["dfill"]).items()})
+        g = torch.Generator().manual_seed(c["mask_seed"])
+        masks = [(torch.rand(2, 512, generator=g) >= 0.3).float() / 0.7 for _ in range(5)]
+        npass = 4 if orc.ABLATIONS[name][5] else 2
+        with torch.no_grad():
+            d_tot, d_det = orc.ablation_losses(name, st, x, y, masks[:npass], "d")
+            g_tot, g_det = orc.ablation_losses(name, st, x, y, masks[npass:npass + 1], "g")
+        assert abs(float(d_tot) - c["d_loss"]) <= 1e-5 * abs(c["d_loss"]) and abs(float(g_tot) - c["g_loss"]) <= 1e-5 * abs(c["g_loss"]), name
+        assert list(d_det.keys()) == list(c["d_details"].keys()) and list(g_det.keys()) == list(c["g_details"].keys()), name
+        for k, v in {**d_det, **g_det}.items():
+            want = {**c["d_details"], **c["g_details"]}[k]
+            assert abs(float(v) - want) <= 2e-5 * abs(want) + 1e-9, (name, k)
