@@ -1,18 +1,23 @@
 """TEST INFRASTRUCTURE ONLY (tests/, smoke, bench cpu_baseline): CPU restatement of the reference's "window_patch" training
 front end, create_datasets/Mayo.py:117-136.
 
-PARITY UNPINNED: the transforms live in the third-party dependency monai (requirements.txt: monai==1.3.2), which is not
-in this image and cannot be imported to generate golden vectors.  What is restated is monai's published behaviour:
+PARITY: the transforms live in the third-party dependency monai (requirements.txt: monai==1.3.2), which is not in this
+image and cannot be imported to generate golden vectors, and the reference holds no fixtures for this path.  What is restated
+is monai's published behaviour, and the one part of it that is an executable torch call is pinned to that call:
   ScaleIntensityRange(a_min, a_max, 0, 1, clip=True):  (x - a_min) / (a_max - a_min), clipped to [0, 1], float32
   CropForeground(select_fn = x > 0, margin 0):         bounding box [min, max + 1) of the foreground of the full-dose key
   SpatialPad(spatial_size, method="symmetric"):        zeros, floor(half) before and the rest after
   RandSpatialCropSamples(roi, random_center=True):     origin uniform in [0, size - roi]
-  RandRotate90(prob, max_k=3), axes (0, 1):            np.rot90(img, k)
-  RandFlip(prob, spatial_axis=[0, 1]):                 np.flip over both axes
+  RandRotate90(prob, max_k=3), axes (0, 1):            np.rot90(img, k)            == torch.rot90 on the spatial axes (test)
+  RandFlip(prob, spatial_axis=[0, 1]):                 np.flip over both axes      == torch.flip on the spatial axes (test)
   RandRotate(prob, range_x, keep_size=True, "bilinear", "border", align_corners=False): rotation about the centre
+      -- monai builds T = shift((n-1)/2) @ [[cos, -sin], [sin, cos]] @ shift(-(n-1)/2) as the OUTPUT -> INPUT index map on
+      (row, col), normalises it (i -> (2 i + 1) / n - 1), reverses the index order and calls torch.nn.functional.affine_grid /
+      grid_sample(bilinear, border, align_corners=False).  tests/test_data_front_end.py builds exactly that with torch and
+      checks rotate_bilinear_border() against it (direction, centre, border clamp; 1e-5 on values in [0, 1]).
 The random draws are inputs (descriptors), shared with the device path; monai's own RandomState interleaving is not
-reproduced.  The rotation's sign convention (src = c + R(angle)(dst - c), R = [[cos, -sin], [sin, cos]] on (y, x)) is
-this repository's choice until it can be checked against monai."""
+reproduced.  Status: "pinned to torch's affine_grid / grid_sample through monai's published matrix construction; monai itself
+absent" -- short of golden vectors from monai, which this image cannot produce."""
 import numpy as np
 
 

@@ -47,6 +47,60 @@ def test_oracle_pipeline_shapes_and_moves():
     assert p_lo[0, 0, 27:37, 12:52].min() > 0 and p_lo[0, 0, :27].max() == 0 and p_lo[0, 0, :, :12].max() == 0
 
 
+def _monai_rotate_2d(img, angle):
+    """monai 1.3.2's 2-D `Rotate(angle, keep_size=True, mode="bilinear", padding_mode="border", align_corners=False)` -- what
+    `RandRotated(range_x=pi/12, keep_size=True, align_corners=False)` of create_datasets/Mayo.py:128 applies -- restated down to
+    the torch calls monai makes, and executed with torch's own affine_grid / grid_sample:
+      transforms/spatial/functional.py rotate():   T = shift(+(n-1)/2) @ create_rotate(2, angle) @ shift(-(n-1)/2), an index-space
+                                                   map from OUTPUT (row, col) to INPUT (row, col), create_rotate = [[c, -s], [s, c]];
+      networks/layers/spatial_transforms.py AffineTransform(normalized=False, reverse_indices=True):
+                                                   to_norm_affine(T, src, dst, align_corners) then rows and columns reversed
+                                                   ((row, col) -> torch's (x, y)), affine_grid, grid_sample;
+      networks/utils.py normalize_transform(shape, align_corners=False, zero_centered=False):  i -> (2 i + 1) / n - 1."""
+    import math
+    n = img.shape[-1]
+    c, s_ = math.cos(angle), math.sin(angle)
+    R = torch.tensor([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    sh = lambda v: torch.tensor([[1.0, 0.0, v], [0.0, 1.0, v], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    T = sh((n - 1) / 2) @ R @ sh(-(n - 1) / 2)
+    norm = torch.tensor([[2.0 / n, 0.0, 1.0 / n - 1.0], [0.0, 2.0 / n, 1.0 / n - 1.0], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    theta = norm @ T @ torch.linalg.inv(norm)
+    theta = theta[[1, 0, 2]][:, [1, 0, 2]]                    # reverse_indices
+    t = torch.from_numpy(np.ascontiguousarray(img))[None, None].double()
+    grid = torch.nn.functional.affine_grid(theta[None, :2], (1, 1, n, n), align_corners=False)
+    out = torch.nn.functional.grid_sample(t, grid, mode="bilinear", padding_mode="border", align_corners=False)
+    return out[0, 0].float().numpy()
+
+
+def test_rotation_convention_matches_affine_grid_and_grid_sample():
+    """f3 pin: the restated rotation (direction, centre, border handling) equals torch's affine_grid + grid_sample driven
+    the way monai's Rotate drives them; quarter turns and flips equal torch.rot90 / torch.flip on the spatial axes (0, 1)
+    of a channel-first image (monai RandRotate90d(spatial_axes=[0, 1]) / RandFlipd(spatial_axis=[0, 1]))."""
+    rng = np.random.RandomState(4)
+    for n in (64, 17):
+        img = rng.rand(n, n).astype(np.float32)
+        for ang in (0.26, -0.26, 0.1, -0.013, 0.0):
+            want = _monai_rotate_2d(img, ang)
+            got = DO.rotate_bilinear_border(img, ang)
+            assert np.abs(got - want).max() < 1e-5, (n, ang, np.abs(got - want).max())      # fp32 coordinates vs float64
+        # a direction check that does not depend on interpolation: a bright pixel right of the centre moves UP for angle > 0
+        dot = np.zeros((65, 65), np.float32)
+        dot[32, 52] = 1.0
+        up = DO.rotate_bilinear_border(dot, 0.25)
+        yy, xx = np.unravel_index(np.argmax(up), up.shape)
+        ref = _monai_rotate_2d(dot, 0.25)
+        assert (yy, xx) == tuple(np.unravel_index(np.argmax(ref), ref.shape)) and yy != 32
+    lo, hi = _slices(1, size=96)
+    base = [(0, 0.3, 0.6, 0, 0, 0.0)]
+    a, _ = DO.window_patches(lo.numpy(), hi.numpy(), base)
+    chw = torch.from_numpy(a[0])                                              # (1, 64, 64) channel first
+    for k in (1, 2, 3):
+        r, _ = DO.window_patches(lo.numpy(), hi.numpy(), [(0, 0.3, 0.6, k, 0, 0.0)])
+        assert np.array_equal(r[0], torch.rot90(chw, k, (1, 2)).numpy())
+    f, _ = DO.window_patches(lo.numpy(), hi.numpy(), [(0, 0.3, 0.6, 0, 1, 0.0)])
+    assert np.array_equal(f[0], torch.flip(chw, (1, 2)).numpy())
+
+
 @pytest.mark.gpu
 def test_patches_vs_oracle(hip_lib):
     from mtd_gan_amd.create_datasets import Mayo
