@@ -351,6 +351,98 @@ __global__ __launch_bounds__(256) void fwd_n1_kernel(const FwdParams p, int nblk
     }
 }
 
+// N == 1 on whole image rows, 3x3 "same" geometry, C a multiple of 32 (the pixel-level heads s_/r_dconv61: 128 -> 1, the
+// generator's decoder.0: 32 -> 1, the data gradient of conv11: 64 -> 1).  fwd_n1_kernel above re-reads every input
+// pixel once per tap through L1 / L2 (nine 16-byte loads per lane and pixel) and reduces over the channel lanes with
+// shuffles: 134 MB of input took 99 us (1.35 TB/s).  Here every input pixel is loaded ONCE: its nine tap products
+//     plane_t[q] = sum_c in[q, c] * w[t, c]
+// are one small GEMM -- 32 pixels x C channels times C x 9 (padded to 32) taps -- on the matrix cores (A fragments straight
+// from global memory, 16-byte loads, as in the implicit GEMM; the 2 M C 32 flops are free beside the loads), the planes of
+// the workgroup's R + 2 input rows go to LDS, and an output pixel is the sum of nine plane values at its tap offsets, in
+// the launch's tap order.  Input traffic (R + 2) / R of the tensor, nothing else.
+struct N1PlaneParams {
+    mtd_conv_args a;
+    int M, T, R;
+    unsigned in_bytes;
+    int tap_kidx[9], ddy[9], ddx[9];
+};
+
+template <int NCH>      // 32-channel chunks
+__global__ __launch_bounds__(256) void fwd_n1_planes_kernel(const N1PlaneParams p) {
+    extern __shared__ float planes[];                       // [9][(R + 2) * 66], zero columns 0 and 65
+    const mtd_conv_args& a = p.a;
+    const mtd_geom& g = a.g;
+    constexpr int W = 64, PW = W + 2;
+    const int R = p.R, PR = R + 2, PSZ = PR * PW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int row0 = blockIdx.x * R;
+    const int b = row0 / g.OH, y0 = row0 - b * g.OH;
+    for (int i = tid; i < 9 * PSZ; i += 256) planes[i] = 0.f;
+    // weights as MFMA B fragments: lane (tap = l31, kh) holds w[tap][32 ch + 16 kh + kk]
+    float wf[NCH][16];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+            wf[ch][kk] = (l31 < p.T) ? a.w[(long long)(32 * ch + 16 * kh + kk) * a.w_sc + (long long)p.tap_kidx[l31] * a.w_st] : 0.f;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)p.in_bytes, 0x00020000);
+    __syncthreads();
+    // ---- phase 1: tap planes of input rows y0 - 1 .. y0 + R, one 32-pixel block (half a row) per wave and iteration
+    const int nblocks = PR * 2;
+    f32x4 an[4];
+    auto load = [&](int blk, int ch) {
+        const int pr = blk >> 1, x0 = (blk & 1) * 32;
+        const int iy = y0 - 1 + pr;
+        const bool ok = (blk < nblocks) & ((unsigned)iy < (unsigned)g.IH);
+        const unsigned voff = ok ? (unsigned)((((((long long)b * g.IH + iy) * g.IW + x0 + l31) * a.in_ld) + 32 * ch + 16 * kh) * 4) : 0x80000000u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) an[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 16 * j, 0));
+    };
+    int blk = wave;
+    load(blk, 0);
+    while (blk < nblocks) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            f32x4 ac[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ac[j] = an[j];
+            if (ch + 1 < NCH) load(blk, ch + 1);
+            else load(blk + 4, 0);                                   // past the last block: out of range, zeros
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) acc = mfma32(ac[kk >> 2][kk & 3], wf[ch][kk], acc);
+        }
+        if (l31 < 9) {
+            const int pr = blk >> 1, x0 = (blk & 1) * 32;
+            float* dst = planes + l31 * PSZ + pr * PW + 1 + x0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dst[mfma32_row(e, lane)] = acc[e];
+        }
+        blk += 4;
+    }
+    __syncthreads();
+    // ---- phase 2: nine plane values per output pixel, launch tap order, then the usual epilogue
+    const ScalePair sp = load_scale(a);
+    const float bias = a.bias ? a.bias[0] : 0.f;
+    for (int i = tid; i < R * W; i += 256) {
+        const int ry = i >> 6, rx = i & 63;
+        const float* pc = planes + (ry + 1) * PW + rx + 1;
+        float s = 0.f;
+        for (int t = 0; t < p.T; ++t) s += pc[t * PSZ + p.ddy[t] * PW + p.ddx[t]];
+        const int m = (row0 + ry) * W + rx;
+        const long long pix = m;
+        float v = s * pick_scale(sp, m) + bias;
+        if (a.add1) v += a.add1[pix * a.add1_ld];
+        if (a.add2) v += a.add2[pix * a.add2_ld];
+        v = apply_act(v, a.act);
+        if (a.mask) v *= (a.mask[pix * a.mask_ld] > 0.f) ? 1.f : a.mask_slope;
+        a.out[pix * a.out_ld] = v;
+    }
+}
+
 // ---- fast weight gradient: min(N, C) == 1, loop over the pixels of the wide tensor ---------------
 struct WideParams {
     mtd_wgrad_args a;
@@ -598,7 +690,10 @@ extern "C" int mtd_conv_direct(const mtd_conv_args* a, void* stream) {
             static const int env_tile = [] { const char* e = getenv("MTD_C1_TILE"); return e ? atoi(e) : 1; }();
             int R = 0;
             if (near && env_tile && g.OW % PL == 0 && (a->scale2 == nullptr || a->scale_split % (g.OH * g.OW) == 0)) {
-                R = (int)(ppb / g.OW);
+                // ~512 workgroups of 4 or 8 image rows: with one row each (2048 workgroups of four pixels per thread) the
+                // launch was ramp and tail (19 us for 16.8 MB of output)
+                R = (int)(((Mpix + 511) / 512) / g.OW);
+                if (R < 1) R = 1;
                 while (R > 1 && g.OH % R) --R;                                 // whole tiles per image
                 if (R < 1 || (long long)(R + 2) * (g.OW + 2) * 4 > 48 * 1024) R = 0;
             }
@@ -607,6 +702,37 @@ extern "C" int mtd_conv_direct(const mtd_conv_args* a, void* stream) {
                 hipLaunchKernelGGL(fwd_c1_tile_kernel, dim3((unsigned)((long long)g.B * g.OH / R)), dim3(256), lds, (hipStream_t)stream, p, R);
             } else
             hipLaunchKernelGGL(fwd_c1_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
+        } else if ([&] {
+                       // tap planes on the matrix cores (fwd_n1_planes_kernel): 3x3 "same" geometry on 64-pixel rows, C = 32 / 64 / 128
+                       static const int env_planes = [] { const char* e = getenv("MTD_N1_PLANES"); return e ? atoi(e) : 1; }();
+                       if (!env_planes || !(a->C == 32 || a->C == 64 || a->C == 128) || T > 9 || !identity) return false;
+                       if (g.in_sy != 1 || g.in_sx != 1 || g.OH != g.IH || g.OW != g.IW || g.OW != 64 || (g.OH % 8)) return false;
+                       if (a->w_sc <= 0 || (a->scale2 && a->scale_split % (g.OH * g.OW))) return false;
+                       bool seen[9] = {false, false, false, false, false, false, false, false, false};
+                       for (int t = 0; t < T; ++t) {
+                           const int dy = g.off_y + p.tap_dy[t], dx = g.off_x + p.tap_dx[t];
+                           if (dy < -1 || dy > 1 || dx < -1 || dx > 1 || seen[(dy + 1) * 3 + dx + 1]) return false;
+                           seen[(dy + 1) * 3 + dx + 1] = true;
+                       }
+                       const long long bytes = (((long long)g.B * g.IH * g.IW - 1) * a->in_ld + a->C) * 4;
+                       return bytes < (1ll << 31);
+                   }()) {
+            N1PlaneParams q;
+            q.a = *a;
+            q.M = (int)Mpix;
+            q.T = T;
+            q.R = 8;
+            q.in_bytes = (unsigned)((((long long)g.B * g.IH * g.IW - 1) * a->in_ld + a->C) * 4);
+            for (int t = 0; t < T; ++t) {
+                q.tap_kidx[t] = p.tap_kidx[t];
+                q.ddy[t] = g.off_y + p.tap_dy[t];
+                q.ddx[t] = g.off_x + p.tap_dx[t];
+            }
+            const size_t lds = (size_t)9 * (q.R + 2) * 66 * sizeof(float);
+            const dim3 grid((unsigned)((long long)g.B * g.OH / q.R));
+            if (a->C == 32) hipLaunchKernelGGL((fwd_n1_planes_kernel<1>), grid, dim3(256), lds, (hipStream_t)stream, q);
+            else if (a->C == 64) hipLaunchKernelGGL((fwd_n1_planes_kernel<2>), grid, dim3(256), lds, (hipStream_t)stream, q);
+            else hipLaunchKernelGGL((fwd_n1_planes_kernel<4>), grid, dim3(256), lds, (hipStream_t)stream, q);
         } else {
             p.G = a->C / 4;
             const int PPW = 64 / p.G;
