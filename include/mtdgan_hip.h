@@ -159,6 +159,13 @@ int mtd_spec_mix_fwd(const float* R, const float* w2t, const float* b2, float* T
 size_t mtd_spec_mix_bwd_ws_bytes(int B);
 int mtd_spec_mix_bwd(const float* gR, const float* w2, const float* S_save, const float* Z_save,
                      float* gT, float* ws, int B, void* stream);
+/* Four-wave forms of the two calls above (csrc/resfft4.hip): same mathematics, layouts and slab format; the saved
+ * pre-activation is a SIGN MASK of mtd_spec_mix_zmask_bytes(B) bytes (128 64-bit words per patch and kw pair) instead of
+ * a float tensor.  S_save and zmask may be NULL in the forward call (no tape). */
+size_t mtd_spec_mix_zmask_bytes(int B);
+int mtd_spec_mix_fwd4(const float* R, const float* w2t, const float* b2, float* T, float* S_save, void* zmask, int B, void* stream);
+int mtd_spec_mix_bwd4(const float* gR, const float* w2, const float* S_save, const void* zmask, float* gT, float* ws, int B,
+                      void* stream);
 int mtd_spec_mix_wgrad_reduce(const float* ws, int B, float* dw2, float* db2, int accumulate, void* stream);
 /* the same reduce for `count` blocks' slab sets in one launch (dw2 and ws 16-byte aligned) */
 typedef struct { const float* ws; float* dw2; float* db2; int nslab; int accumulate; } mtd_mix_reduce_desc;

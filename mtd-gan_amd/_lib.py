@@ -98,7 +98,7 @@ def _preload_torch_hip_runtime():
 
 
 RECORDER = None      # kernels.LaunchList: while a step is being recorded, the list every launch is appended to
-_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "mtd_prof_", "_override", "_bwd_ok", "_stamps")
+_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "mtd_prof_", "_override", "_bwd_ok", "_stamps", "_zmask_bytes")
 
 
 class _RecordingLib:
@@ -207,6 +207,9 @@ def lib():
     sig("mtd_window_patches", ci, vp, vp, ci, ci, ci, vp, vp, ci, cf, cf, ci, vp, vp, vp)
     sig("mtd_hu_window", ci, vp, ll, cf, cf, vp, vp)
     sig("mtd_prof_mode", ci, ci)
+    sig("mtd_spec_mix_zmask_bytes", sz, ci)
+    sig("mtd_spec_mix_fwd4", ci, vp, vp, vp, vp, vp, vp, ci, vp)
+    sig("mtd_spec_mix_bwd4", ci, vp, vp, vp, vp, vp, vp, ci, vp)
     sig("mtd_conv_c32_bwd_ok", ci, C.POINTER(ConvArgs), C.POINTER(WgradArgs))
     sig("mtd_conv_c32_bwd_ws_bytes", sz, C.POINTER(ConvArgs), C.POINTER(WgradArgs))
     sig("mtd_conv_c32_bwd", ci, C.POINTER(ConvArgs), C.POINTER(WgradArgs), C.POINTER(C.c_int), C.POINTER(C.c_longlong), vp)
@@ -231,6 +234,7 @@ EXPORTS = [
     "mtd_foreground_bbox", "mtd_window_patches", "mtd_hu_window", "mtd_add", "mtd_transpose64_multi", "mtd_upsample2x_bwd_masked",
     "mtd_prof_mode", "mtd_pcgrad_coeff", "mtd_pcgrad_axpy", "mtd_conv_igemm_multi_ws_bytes", "mtd_conv_igemm_multi",
     "mtd_conv_c32_bwd_ok", "mtd_conv_c32_bwd_ws_bytes", "mtd_conv_c32_bwd",
+    "mtd_spec_mix_zmask_bytes", "mtd_spec_mix_fwd4", "mtd_spec_mix_bwd4",
 ]
 
 

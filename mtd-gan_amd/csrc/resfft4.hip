@@ -1,0 +1,392 @@
+// Column transforms + channel mix of the Res-FFT-Conv block (arch/Ours/networks.py:24-30 and its backward), four waves
+// per unit.  Same mathematics, data layouts and slab format as spec_mix_fwd_kernel / spec_mix_bwd_kernel (resfft.hip):
+//   forward : S = FFT_h(R) / 8;  Z = W2 S + b2;  T = IFFT_h(relu(Z)) / 8          per (patch, kw column)
+//   backward: gZ = [Z > 0] FFT_h(gR) / 8;  gS = W2^T gZ;  dW2 += gZ S^T;  db2 += sum gZ;  gT = IFFT_h(gS) * sc
+//
+// Why a second form.  A unit is two kw columns of one patch (544 units at 32 patches).  The one-wave kernels run a unit's
+// phases one after the other in a single wave -- loads 2.3 us, 64-point transform in registers + LDS + spectrum store
+// 5.3, 256 dependent-chain MFMAs 11.9, inverse transform + stores 3.1 (in-kernel stamps) -- on 544 of the
+// chip's 1024 SIMDs: 28 / 40 us per launch at 0.14 / 0.19 MFMA utilisation, latency-bound.  Here a unit is a 256-thread
+// workgroup:
+//   * the columns arrive by LDS-DMA (32 x 1 KB instructions over the four waves instead of 128 dword loads per lane);
+//   * a 64-point transform is split over the FOUR lanes of a quad: lane j takes points 4 m + j through a 16-point
+//     register FFT (radix-2, immediates as twiddles), multiplies by w64^(j r) and the quad finishes with a 4-point
+//     butterfly through DPP quad_perm -- 64 transforms x 4 lanes = all 256 threads busy, ~45 % of the one-lane work each;
+//   * the 64 x 64 mix of a column is four 32 x 32 accumulator blocks: 64 MFMAs per wave instead of 256;
+//   * the saved pre-activation (only its sign is ever used) leaves as a BIT MASK, 1 KB per unit instead of 32 KB.
+// 2 176 waves on 1024 SIMDs, two workgroups per CU (66 KB of LDS each), so a unit's phases overlap its neighbour's.
+// Roofline: HBM (forward 17.3 MB in, 34.6 MB + 0.5 MB out per 32 patches; backward 17.3 + 17.3 + 0.5 in, 17.3 + 9.2 out).
+#include "common.h"
+#include "fft64.h"
+
+namespace {
+
+constexpr int XLD4 = 65;                  // LDS row stride (floats) of the [frequency][64 channel] operand image
+constexpr int MIX_SLAB4 = 64 * 64 + 128;  // dW2 partial + two db2 partial rows per unit (resfft.hip MIX_SLAB)
+typedef __attribute__((address_space(3))) float lds_float4k;
+
+__host__ __device__ constexpr int brev4(int k) { return ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3); }
+
+// In-place 16-point complex DFT, X[k] = sum_n x[n] e^{SIGN 2 pi i k n / 16}, unnormalised; radix-2 decimation in
+// frequency: the result for frequency k is left at index brev4(k).  Twiddles w16^t = w64^(4 t).
+template <int SIGN>
+__device__ __forceinline__ void fft16(float (&re)[16], float (&im)[16]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int half = 8 >> s;
+        const int tstep = 1 << s;
+#pragma unroll
+        for (int blk = 0; blk < 16; blk += 2 * half) {
+#pragma unroll
+            for (int j = 0; j < half; ++j) {
+                const int i0 = blk + j, i1 = i0 + half;
+                const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+                re[i0] = ar + br;
+                im[i0] = ai + bi;
+                const float dr = ar - br, di = ai - bi;
+                const int tw = j * tstep;                   // in units of 2 pi / 16
+                if (tw == 0) {
+                    re[i1] = dr;
+                    im[i1] = di;
+                } else if (tw == 4) {
+                    if (SIGN < 0) { re[i1] = di; im[i1] = -dr; }
+                    else { re[i1] = -di; im[i1] = dr; }
+                } else {
+                    const float c = COS64[4 * tw];
+                    const float sn = (SIGN < 0) ? -SIN64[4 * tw] : SIN64[4 * tw];
+                    re[i1] = dr * c - di * sn;
+                    im[i1] = dr * sn + di * c;
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float quad_bcast(float v, int k) {
+    // value of lane k of this lane's quad (DPP quad_perm broadcast)
+    const int x = __builtin_bit_cast(int, v);
+    int r;
+    switch (k) {
+        case 0: r = __builtin_amdgcn_update_dpp(0, x, 0x00, 0xf, 0xf, true); break;
+        case 1: r = __builtin_amdgcn_update_dpp(0, x, 0x55, 0xf, 0xf, true); break;
+        case 2: r = __builtin_amdgcn_update_dpp(0, x, 0xAA, 0xf, 0xf, true); break;
+        default: r = __builtin_amdgcn_update_dpp(0, x, 0xFF, 0xf, 0xf, true); break;
+    }
+    return __builtin_bit_cast(float, r);
+}
+
+// 64-point transform over a quad.  On entry lane j (= lane & 3) holds x[4 m + j] in (re, im)[m]; on exit it holds
+// X[16 j + r] in (re, im)[r], X[k] = sum_n x[n] e^{SIGN 2 pi i k n / 64} (unnormalised).  tc / ts: cos, sin of
+// 2 pi j r / 64 for this lane's j (quad_twiddles).
+template <int SIGN>
+__device__ __forceinline__ void fft64_quad(float (&re)[16], float (&im)[16], const float (&tc)[16], const float (&ts)[16], int j) {
+    fft16<SIGN>(re, im);
+    float gr[16], gi[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                          // G_j[r] = w64^(SIGN j r) F_j[r]
+        const float fr = re[brev4(r)], fi = im[brev4(r)];
+        if (SIGN < 0) { gr[r] = fr * tc[r] + fi * ts[r]; gi[r] = fi * tc[r] - fr * ts[r]; }
+        else { gr[r] = fr * tc[r] - fi * ts[r]; gi[r] = fi * tc[r] + fr * ts[r]; }
+    }
+    const bool odd = (j & 1) != 0;
+    const float sgn = (j & 2) ? -1.f : 1.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                          // X[16 q + r] = sum_j (SIGN i)^(j q) G_j[r], q = this lane
+        const float g0r = quad_bcast(gr[r], 0), g1r = quad_bcast(gr[r], 1), g2r = quad_bcast(gr[r], 2), g3r = quad_bcast(gr[r], 3);
+        const float g0i = quad_bcast(gi[r], 0), g1i = quad_bcast(gi[r], 1), g2i = quad_bcast(gi[r], 2), g3i = quad_bcast(gi[r], 3);
+        const float ar = g0r + g2r, ai = g0i + g2i, br = g0r - g2r, bi = g0i - g2i;
+        const float cr = g1r + g3r, ci = g1i + g3i, dr = g1r - g3r, di = g1i - g3i;
+        // q even: A +- C;  q odd: B +- (SIGN i) D,  (SIGN i) D = SIGN * (-D_im, D_re)
+        const float base_r = odd ? br : ar, base_i = odd ? bi : ai;
+        const float add_r = odd ? (SIGN < 0 ? di : -di) : cr;
+        const float add_i = odd ? (SIGN < 0 ? -dr : dr) : ci;
+        re[r] = fmaf(sgn, add_r, base_r);
+        im[r] = fmaf(sgn, add_i, base_i);
+    }
+}
+
+__device__ __forceinline__ void quad_twiddles(int j, float (&tc)[16], float (&ts)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int idx = j * r;                              // 0 .. 45, angle 2 pi idx / 64
+        const float s = (idx & 32) ? -1.f : 1.f;           // cos / sin (theta + pi) = -cos / -sin (theta)
+        tc[r] = s * COS64[idx & 31];
+        ts[r] = s * SIN64[idx & 31];
+    }
+}
+
+// 32 KB (two adjacent 16 KB column blocks) or 16 KB global -> LDS by the four waves of the workgroup
+__device__ __forceinline__ void dma_columns(const float* gsrc, float* lds_dst, int wave, int lane, bool two) {
+    const int n = two ? 32 : 16;
+    for (int i = wave; i < n; i += 4)
+        __builtin_amdgcn_global_load_lds(gsrc + i * 256 + lane * 4, (lds_float4k*)(lds_dst + i * 256), 16, 0, 0);
+}
+
+// position of element (row kh of a 64-row column, channel o) in the sign masks: word, bit
+__device__ __forceinline__ int mask_word(int k2, int kh, int o) {
+    const int i = kh >> 5, r32 = kh & 31;
+    const int e = (r32 & 3) + 4 * (r32 >> 3);
+    return ((k2 * 2 + i) * 2 + (o >> 5)) * 16 + e;
+}
+__device__ __forceinline__ int mask_bit(int kh, int o) { return (o & 31) + 32 * (((kh & 31) >> 2) & 1); }
+
+__global__ __launch_bounds__(256, 2) void spec_mix_fwd4_kernel(const float* __restrict__ R, const float* __restrict__ w2t,
+                                                               const float* __restrict__ b2, float* __restrict__ T,
+                                                               float* __restrict__ S_save, unsigned long long* __restrict__ zmask) {
+    __shared__ __attribute__((aligned(1024))) float Xin[2 * 64 * 64];
+    __shared__ float Xs[2 * 64 * XLD4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, unit = b * gridDim.x + blockIdx.x;
+    const bool two = (2 * blockIdx.x + 1) < NKW;                  // workgroup-uniform: does the second column exist
+    const long long cb0 = ((long long)(b * NKW + 2 * blockIdx.x) * 64) * 64;
+    dma_columns(R + cb0, Xin, wave, lane, two);
+    // transform lanes: f = transform (column kwl, channel c), j = position in the quad
+    const int f = tid >> 2, j = tid & 3, kwl = f >> 5, c = f & 31;
+    const bool valid = kwl == 0 || two;
+    float tc[16], ts[16];
+    quad_twiddles(j, tc, ts);
+    // mix lanes
+    const int l31 = lane & 31, kh2 = lane >> 5;
+    const int k2 = wave >> 1, ih = wave & 1;
+    const bool mix_valid = k2 == 0 || two;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float re[16], im[16];
+    // ---- column FFT, spectrum to LDS (MFMA operand image) and to S_save
+    {
+        const float* src = Xin + kwl * 4096 + j * 64 + c;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            re[m] = valid ? src[m * 256] : 0.f;
+            im[m] = valid ? src[m * 256 + 32] : 0.f;
+        }
+        fft64_quad<-1>(re, im, tc, ts, j);
+        const long long colbase = cb0 + kwl * 4096;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kh = 16 * j + r;
+            const float sr = re[r] * 0.125f, si = im[r] * 0.125f;
+            Xs[(kwl * 64 + kh) * XLD4 + c] = sr;
+            Xs[(kwl * 64 + kh) * XLD4 + 32 + c] = si;
+            if (S_save && valid) {
+                S_save[colbase + kh * 64 + c] = sr;
+                S_save[colbase + kh * 64 + 32 + c] = si;
+            }
+        }
+    }
+    // the mix weights as MFMA B fragments (one batch of loads, under the barrier)
+    float wf0[32], wf1[32];
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+        wf0[kk] = w2t[(2 * kk + kh2) * 64 + l31];
+        wf1[kk] = w2t[(2 * kk + kh2) * 64 + 32 + l31];
+    }
+    __syncthreads();
+    // ---- channel mix: wave (k2, ih) owns rows k2*64 + ih*32 .. +31 of the operand image, both output halves
+    if (mix_valid) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[jj][e] = 0.f;
+        const float* arow = Xs + (k2 * 64 + ih * 32 + l31) * XLD4 + kh2;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            const float a0 = arow[2 * kk];
+            acc[0] = mfma32(a0, wf0[kk], acc[0]);
+            acc[1] = mfma32(a0, wf1[kk], acc[1]);
+        }
+        // only this wave reads these rows: it may overwrite them once its own reads have been issued (LDS is in order per wave)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int o = jj * 32 + l31;
+            const float bo = b2[o];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int kh = ih * 32 + mfma32_row(e, lane);
+                const float z = acc[jj][e] + bo;
+                if (zmask) {
+                    const unsigned long long bm = __ballot(z > 0.f);
+                    if (lane == 0) zmask[(long long)unit * 128 + ((k2 * 2 + ih) * 2 + jj) * 16 + e] = bm;
+                }
+                Xs[(k2 * 64 + kh) * XLD4 + o] = z > 0.f ? z : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- inverse column FFT
+    {
+        const float* src = Xs + (kwl * 64 + j) * XLD4 + c;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            re[m] = src[4 * m * XLD4];
+            im[m] = src[4 * m * XLD4 + 32];
+        }
+        fft64_quad<+1>(re, im, tc, ts, j);
+        if (valid) {
+            float* dst = T + cb0 + kwl * 4096 + c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int h = 16 * j + r;
+                dst[h * 64] = re[r] * 0.125f;
+                dst[h * 64 + 32] = im[r] * 0.125f;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void spec_mix_bwd4_kernel(const float* __restrict__ gR, const float* __restrict__ w2,
+                                                               const float* __restrict__ S_save,
+                                                               const unsigned long long* __restrict__ zmask, float* __restrict__ gT,
+                                                               float* __restrict__ ws) {
+    __shared__ __attribute__((aligned(1024))) float Xin[2 * 64 * 64];      // gR columns, then the saved spectrum S
+    __shared__ float Gs[2 * 64 * XLD4];
+    __shared__ unsigned long long Zm[128];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, unit = b * gridDim.x + blockIdx.x;
+    const bool two = (2 * blockIdx.x + 1) < NKW;
+    const long long cb0 = ((long long)(b * NKW + 2 * blockIdx.x) * 64) * 64;
+    float* slab = ws + (long long)unit * MIX_SLAB4;
+    dma_columns(gR + cb0, Xin, wave, lane, two);
+    if (tid < 128) Zm[tid] = zmask[(long long)unit * 128 + tid];
+    const int f = tid >> 2, j = tid & 3, kwl = f >> 5, c = f & 31;
+    const bool valid = kwl == 0 || two;
+    float tc[16], ts[16];
+    quad_twiddles(j, tc, ts);
+    const int l31 = lane & 31, kh2 = lane >> 5;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float re[16], im[16];
+    // ---- column FFT of the cotangent, times the ReLU mask; bias-gradient partial sums
+    {
+        const float* src = Xin + kwl * 4096 + j * 64 + c;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            re[m] = valid ? src[m * 256] : 0.f;
+            im[m] = valid ? src[m * 256 + 32] : 0.f;
+        }
+        fft64_quad<-1>(re, im, tc, ts, j);
+        float dbr = 0.f, dbi = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kh = 16 * j + r;
+            float gr = re[r] * 0.125f, gi = im[r] * 0.125f;
+            const unsigned long long mr = Zm[mask_word(kwl, kh, c)], mi = Zm[mask_word(kwl, kh, 32 + c)];
+            const int bit = mask_bit(kh, c);
+            gr = (valid && ((mr >> bit) & 1ull)) ? gr : 0.f;
+            gi = (valid && ((mi >> bit) & 1ull)) ? gi : 0.f;
+            dbr += gr;
+            dbi += gi;
+            Gs[(kwl * 64 + kh) * XLD4 + c] = gr;
+            Gs[(kwl * 64 + kh) * XLD4 + 32 + c] = gi;
+        }
+        // quad sum in a fixed order (lanes 0, 1, 2, 3 of the quad)
+        const float sr = ((quad_bcast(dbr, 0) + quad_bcast(dbr, 1)) + quad_bcast(dbr, 2)) + quad_bcast(dbr, 3);
+        const float si = ((quad_bcast(dbi, 0) + quad_bcast(dbi, 1)) + quad_bcast(dbi, 2)) + quad_bcast(dbi, 3);
+        if (j == 0) {
+            slab[64 * 64 + kwl * 64 + c] = sr;
+            slab[64 * 64 + kwl * 64 + 32 + c] = si;
+        }
+    }
+    float wf0[32], wf1[32];
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+        wf0[kk] = w2[(2 * kk + kh2) * 64 + l31];
+        wf1[kk] = w2[(2 * kk + kh2) * 64 + 32 + l31];
+    }
+    __syncthreads();                                               // Gs complete, Xin dead
+    dma_columns(S_save + cb0, Xin, wave, lane, two);               // lands under the data-gradient MFMAs
+    // ---- data gradient  gS[f][k] = sum_o gZ[f][o] W2[o][k]: wave (k2, ih), both k halves
+    const int k2 = wave >> 1, ih = wave & 1;
+    const bool mix_valid = k2 == 0 || two;
+    f32x16 accd[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accd[jj][e] = 0.f;
+    if (mix_valid) {
+        const float* arow = Gs + (k2 * 64 + ih * 32 + l31) * XLD4 + kh2;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            const float a0 = arow[2 * kk];
+            accd[0] = mfma32(a0, wf0[kk], accd[0]);
+            accd[1] = mfma32(a0, wf1[kk], accd[1]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's share of S has landed
+    __syncthreads();                                               // ... and everybody's
+    // ---- weight gradient  dW2[o][k] += sum_f gZ[f][o] S[f][k]: wave (io, jk) owns one 32 x 32 block over both columns
+    {
+        const int io = wave >> 1, jk = wave & 1;
+        f32x16 accw;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accw[e] = 0.f;
+        const int ncol = two ? 2 : 1;
+        for (int col = 0; col < ncol; ++col) {
+            const float* ga = Gs + (col * 64 + kh2) * XLD4 + io * 32 + l31;
+            const float* sb = Xin + col * 4096 + kh2 * 64 + jk * 32 + l31;
+#pragma unroll 8
+            for (int kk = 0; kk < 32; ++kk) accw = mfma32(ga[2 * kk * XLD4], sb[2 * kk * 64], accw);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) slab[(io * 32 + mfma32_row(e, lane)) * 64 + jk * 32 + l31] = accw[e];
+    }
+    __syncthreads();                                               // every read of Gs (both MFMA phases) is done
+    if (mix_valid) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Gs[(k2 * 64 + ih * 32 + mfma32_row(e, lane)) * XLD4 + jj * 32 + l31] = accd[jj][e];
+    }
+    __syncthreads();
+    // ---- inverse column FFT of gS
+    {
+        const float* src = Gs + (kwl * 64 + j) * XLD4 + c;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            re[m] = src[4 * m * XLD4];
+            im[m] = src[4 * m * XLD4 + 32];
+        }
+        fft64_quad<+1>(re, im, tc, ts, j);
+        if (valid) {
+            const int kw = 2 * blockIdx.x + kwl;
+            const float sc = (kw == 0 || kw == 32) ? 0.125f : 0.0625f;      // rfft2 backward: columns 1..31 halved
+            float* dst = gT + cb0 + kwl * 4096 + c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int h = 16 * j + r;
+                dst[h * 64] = re[r] * sc;
+                dst[h * 64 + 32] = im[r] * sc;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// zmask: 128 64-bit words per unit (unit = patch * 17 + kw pair): the signs of the pre-activations, in the lane / register
+// order of the forward kernel's accumulator blocks (mask_word / mask_bit above).  S_save and zmask may be NULL (no tape).
+extern "C" size_t mtd_spec_mix_zmask_bytes(int B) { return B > 0 ? (size_t)B * 17 * 128 * sizeof(unsigned long long) : 0; }
+
+extern "C" int mtd_spec_mix_fwd4(const float* R, const float* w2t, const float* b2, float* T, float* S_save, void* zmask, int B,
+                                 void* stream) {
+    if (!R || !w2t || !b2 || !T || B <= 0) return MTD_EINVAL;
+    if (!aligned16(R)) return MTD_EALIGN;
+    hipLaunchKernelGGL(spec_mix_fwd4_kernel, dim3(17, B), dim3(256), 0, (hipStream_t)stream, R, w2t, b2, T, S_save,
+                       (unsigned long long*)zmask);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_spec_mix_bwd4(const float* gR, const float* w2, const float* S_save, const void* zmask, float* gT, float* ws, int B,
+                                 void* stream) {
+    if (!gR || !w2 || !S_save || !zmask || !gT || !ws || B <= 0) return MTD_EINVAL;
+    if (!aligned16(gR) || !aligned16(S_save)) return MTD_EALIGN;
+    hipLaunchKernelGGL(spec_mix_bwd4_kernel, dim3(17, B), dim3(256), 0, (hipStream_t)stream, gR, w2, S_save,
+                       (const unsigned long long*)zmask, gT, ws);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}

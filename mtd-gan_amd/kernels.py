@@ -458,14 +458,25 @@ def rfft_rows(x, col_weight):
     return R
 
 
+SPECMIX4 = os.environ.get("MTD_SPECMIX4", "1") != "0"      # four-wave column / mix kernels (csrc/resfft4.hip); 0 = the one-wave forms
+
+
 def spec_mix_fwd(R, w2t, b2, save):
+    """Returns (T, S, Z): Z is the saved pre-activation -- its sign mask (uint8 tensor) with the four-wave kernels, the float
+    tensor with the one-wave kernels; spec_mix_bwd takes whichever the forward produced."""
     B = R.shape[0]
     _count("spec_mix_mfma", B * 2112 * 2.0 * 64 * 64)
     _count("fft", 2 * B * 32 * _FFT_HALF_PLANE)
     T = torch.empty_like(R)
     S = torch.empty_like(R) if save else None
+    L = _lib.lib()
+    if SPECMIX4:
+        Z = torch.empty(L.mtd_spec_mix_zmask_bytes(B), dtype=torch.uint8, device=R.device) if save else None
+        check(L.mtd_spec_mix_fwd4(R.data_ptr(), w2t.data_ptr(), b2.data_ptr(), T.data_ptr(), _ptr(S), _ptr(Z), B, stream_ptr()),
+              "mtd_spec_mix_fwd4")
+        return T, S, Z
     Z = torch.empty_like(R) if save else None
-    check(_lib.lib().mtd_spec_mix_fwd(R.data_ptr(), w2t.data_ptr(), b2.data_ptr(), T.data_ptr(), _ptr(S), _ptr(Z), B, stream_ptr()),
+    check(L.mtd_spec_mix_fwd(R.data_ptr(), w2t.data_ptr(), b2.data_ptr(), T.data_ptr(), _ptr(S), _ptr(Z), B, stream_ptr()),
           "mtd_spec_mix_fwd")
     return T, S, Z
 
@@ -479,8 +490,12 @@ def spec_mix_bwd(gR, w2, S, Z, dw2, db2, accumulate=False, defer=None):
     deferred = defer is not None and DEFER_WGRADS and dw2.data_ptr() % 16 == 0 and B * 17 <= 4096
     need = L.mtd_spec_mix_bwd_ws_bytes(B)
     ws = _layer_ws(need, defer, gR.device) if deferred else workspace(need, gR.device)
-    check(L.mtd_spec_mix_bwd(gR.data_ptr(), w2.data_ptr(), S.data_ptr(), Z.data_ptr(), gT.data_ptr(), ws.data_ptr(), B, stream_ptr()),
-          "mtd_spec_mix_bwd")
+    if Z.dtype == torch.uint8:
+        check(L.mtd_spec_mix_bwd4(gR.data_ptr(), w2.data_ptr(), S.data_ptr(), Z.data_ptr(), gT.data_ptr(), ws.data_ptr(), B, stream_ptr()),
+              "mtd_spec_mix_bwd4")
+    else:
+        check(L.mtd_spec_mix_bwd(gR.data_ptr(), w2.data_ptr(), S.data_ptr(), Z.data_ptr(), gT.data_ptr(), ws.data_ptr(), B, stream_ptr()),
+              "mtd_spec_mix_bwd")
     if deferred:
         d = _lib.MixReduceDesc()
         d.ws, d.dw2, d.db2, d.nslab, d.accumulate = ws.data_ptr(), dw2.data_ptr(), db2.data_ptr(), B * 17, 1 if accumulate else 0

@@ -194,10 +194,20 @@ def test_upsample_and_pixel_shuffle(hip_lib):
     assert torch.equal(cat[..., 32:48].cpu(), 2 * out.cpu())
 
 
-def test_spectral_path_kernels(hip_lib):
-    """rows -> columns+mix -> rows against torch.fft on the CPU (forward and backward)."""
+@pytest.mark.parametrize("four_wave", [True, False])
+def test_spectral_path_kernels(hip_lib, four_wave):
+    """rows -> columns+mix -> rows against torch.fft on the CPU (forward and backward): the four-wave column / mix kernels
+    (csrc/resfft4.hip: quad-split transforms, sign mask) and the one-wave forms; B = 3 so that the last, single-column unit of a
+    patch is followed by another patch's data."""
     from mtd_gan_amd import kernels as K
-    B = 2
+    K.SPECMIX4 = four_wave
+    try:
+        _spectral_path_case(K, 3 if four_wave else 2, four_wave)
+    finally:
+        K.SPECMIX4 = True
+
+
+def _spectral_path_case(K, B, four_wave):
     x = rnd(B, 32, 64, 64, seed=41, scale=0.5).requires_grad_(True)
     w2 = rnd(64, 64, 1, 1, seed=42, scale=0.125).requires_grad_(True)
     b2 = rnd(64, seed=43, scale=0.1).requires_grad_(True)
@@ -219,7 +229,18 @@ def test_spectral_path_kernels(hip_lib):
     T, S, Z = K.spec_mix_fwd(R, K.transpose64(w2d), b2.detach().cuda(), True)
     Sr = S.cpu().reshape(B, 33, 64, 64)                           # [b, kw, kh, cat]
     assert relerr(Sr, cat.detach().permute(0, 3, 2, 1)) < 1e-5
-    assert relerr(Z.cpu().reshape(B, 33, 64, 64), z.detach().permute(0, 3, 2, 1)) < 1e-5
+    if four_wave:          # the saved pre-activation is its sign mask: 128 words per (patch, kw pair), accumulator-block order
+        assert Z.dtype == torch.uint8 and Z.numel() == B * 17 * 128 * 8
+        words = Z.cpu().numpy().view("<u8").reshape(B, 17, 2, 2, 2, 16)             # [b][pair][col][kh half][out half][register]
+        zs = (z.detach().permute(0, 3, 2, 1) > 0).numpy()                            # [b][kw][kh][o]
+        for (b_, kw_, kh_, o_) in [(0, 0, 0, 0), (1, 5, 37, 40), (2, 32, 63, 63), (0, 17, 12, 31), (2, 31, 45, 2)]:
+            r32 = kh_ & 31
+            e_ = (r32 & 3) + 4 * (r32 >> 3)
+            bit = (o_ & 31) + 32 * ((r32 >> 2) & 1)
+            got = (int(words[b_, kw_ // 2, kw_ % 2, kh_ >> 5, o_ >> 5, e_]) >> bit) & 1
+            assert got == int(zs[b_, kw_, kh_, o_]), (b_, kw_, kh_, o_)
+    else:
+        assert relerr(Z.cpu().reshape(B, 33, 64, 64), z.detach().permute(0, 3, 2, 1)) < 1e-5
     out = torch.empty(B, 64, 64, 32, device="cuda")
     K.irfft_rows(T, out)
     assert relerr(nchw(out), y.detach()) < 1e-5
