@@ -122,6 +122,18 @@ __device__ __forceinline__ void dma_columns(const float* gsrc, float* lds_dst, i
         __builtin_amdgcn_global_load_lds(gsrc + i * 256 + lane * 4, (lds_float4k*)(lds_dst + i * 256), 16, 0, 0);
 }
 
+// 32 rows (stride ld floats in LDS) x 64 floats -> 32 consecutive 256-byte rows of global memory, one wave, 16-byte stores
+// (a vector-memory store costs the CU about the same whatever its width: 8 instructions here instead of 32 dword ones)
+__device__ __forceinline__ void store_rows32(const float* lds_rows, int ld, float* gdst, int lane) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + (lane >> 4), q = lane & 15;
+        const float* s = lds_rows + row * ld + 4 * q;
+        const f32x4 v = {s[0], s[1], s[2], s[3]};
+        *reinterpret_cast<f32x4*>(gdst + row * 64 + 4 * q) = v;
+    }
+}
+
 // position of element (row kh of a 64-row column, channel o) in the sign masks: word, bit
 __device__ __forceinline__ int mask_word(int k2, int kh, int o) {
     const int i = kh >> 5, r32 = kh & 31;
@@ -162,17 +174,12 @@ __global__ __launch_bounds__(256, 2) void spec_mix_fwd4_kernel(const float* __re
             im[m] = valid ? src[m * 256 + 32] : 0.f;
         }
         fft64_quad<-1>(re, im, tc, ts, j);
-        const long long colbase = cb0 + kwl * 4096;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int kh = 16 * j + r;
             const float sr = re[r] * 0.125f, si = im[r] * 0.125f;
             Xs[(kwl * 64 + kh) * XLD4 + c] = sr;
             Xs[(kwl * 64 + kh) * XLD4 + 32 + c] = si;
-            if (S_save && valid) {
-                S_save[colbase + kh * 64 + c] = sr;
-                S_save[colbase + kh * 64 + 32 + c] = si;
-            }
         }
     }
     // the mix weights as MFMA B fragments (one batch of loads, under the barrier)
@@ -185,6 +192,7 @@ __global__ __launch_bounds__(256, 2) void spec_mix_fwd4_kernel(const float* __re
     __syncthreads();
     // ---- channel mix: wave (k2, ih) owns rows k2*64 + ih*32 .. +31 of the operand image, both output halves
     if (mix_valid) {
+        if (S_save) store_rows32(Xs + (k2 * 64 + ih * 32) * XLD4, XLD4, S_save + cb0 + (k2 * 64 + ih * 32) * 64, lane);   // the saved spectrum
         f32x16 acc[2];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
@@ -225,16 +233,17 @@ __global__ __launch_bounds__(256, 2) void spec_mix_fwd4_kernel(const float* __re
             im[m] = src[4 * m * XLD4 + 32];
         }
         fft64_quad<+1>(re, im, tc, ts, j);
-        if (valid) {
-            float* dst = T + cb0 + kwl * 4096 + c;
+        // through LDS (the input buffer is free) so that the result leaves as whole rows
+        float* st = Xin + kwl * 4096 + c;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int h = 16 * j + r;
-                dst[h * 64] = re[r] * 0.125f;
-                dst[h * 64 + 32] = im[r] * 0.125f;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int h = 16 * j + r;
+            st[h * 64] = re[r] * 0.125f;
+            st[h * 64 + 32] = im[r] * 0.125f;
         }
     }
+    __syncthreads();
+    if (mix_valid) store_rows32(Xin + (k2 * 64 + ih * 32) * 64, 64, T + cb0 + (k2 * 64 + ih * 32) * 64, lane);
 }
 
 __global__ __launch_bounds__(256, 2) void spec_mix_bwd4_kernel(const float* __restrict__ gR, const float* __restrict__ w2,
@@ -351,18 +360,18 @@ __global__ __launch_bounds__(256, 2) void spec_mix_bwd4_kernel(const float* __re
             im[m] = src[4 * m * XLD4 + 32];
         }
         fft64_quad<+1>(re, im, tc, ts, j);
-        if (valid) {
-            const int kw = 2 * blockIdx.x + kwl;
-            const float sc = (kw == 0 || kw == 32) ? 0.125f : 0.0625f;      // rfft2 backward: columns 1..31 halved
-            float* dst = gT + cb0 + kwl * 4096 + c;
+        const int kw = 2 * blockIdx.x + kwl;
+        const float sc = (kw == 0 || kw == 32) ? 0.125f : 0.0625f;          // rfft2 backward: columns 1..31 halved
+        float* st = Xin + kwl * 4096 + c;                                    // (S is no longer needed: barrier above)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int h = 16 * j + r;
-                dst[h * 64] = re[r] * sc;
-                dst[h * 64 + 32] = im[r] * sc;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int h = 16 * j + r;
+            st[h * 64] = re[r] * sc;
+            st[h * 64 + 32] = im[r] * sc;
         }
     }
+    __syncthreads();
+    if (mix_valid) store_rows32(Xin + (k2 * 64 + ih * 32) * 64, 64, gT + cb0 + (k2 * 64 + ih * 32) * 64, lane);
 }
 
 }  // namespace
