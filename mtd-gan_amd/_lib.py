@@ -30,7 +30,8 @@ class ConvArgs(C.Structure):
                 ("mask", C.c_void_p), ("mask_ld", C.c_int), ("mask_slope", C.c_float),
                 ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
                 ("scale2", C.c_void_p), ("scale_split", C.c_int),
-                ("out2", C.c_void_p), ("out2_ld", C.c_int)]
+                ("out2", C.c_void_p), ("out2_ld", C.c_int),
+                ("tile_ctr", C.c_void_p), ("tile_ctr_len", C.c_int)]
 
 
 class WgradArgs(C.Structure):

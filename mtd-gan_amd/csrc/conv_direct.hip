@@ -240,6 +240,10 @@ __global__ __launch_bounds__(256) void fwd_c1_kernel(const FwdParams p) {
 // offsets from three row pointers, the taps' weights sit in registers by NEIGHBOURHOOD position (zero where the
 // geometry has no tap), and the store addresses advance by constants.  Taps are summed in neighbourhood order (the
 // launch's tap order for a forward conv, its reverse for a data gradient).
+// PLAIN: no add / mask operands and 16-byte stores (the forward layers): the epilogue is scale, bias, ACT and one store.
+// With the general epilogue in the loop (uniform branches per value for operands that are not there) an iteration
+// was ~190 instructions and a dozen taken branches for 36 FMAs -- the kernel was bound by that, not by its stores.
+template <bool PLAIN, int ACT>
 __global__ __launch_bounds__(256) void fwd_c1_tile_kernel(const FwdParams p, int R) {
     extern __shared__ float c1tile[];
     const mtd_conv_args& a = p.a;
@@ -264,14 +268,22 @@ __global__ __launch_bounds__(256) void fwd_c1_tile_kernel(const FwdParams p, int
 #pragma unroll
         for (int q = 0; q < 9; ++q) w9[j][q] = 0.f;
     }
-    for (int t = 0; t < p.T; ++t) {
-        const int q = (g.off_y + p.tap_dy[t] + 1) * 3 + (g.off_x + p.tap_dx[t] + 1);      // neighbourhood position of tap t
+    {   // all 36 weight loads in flight at once (a loop over the launch's taps paid one memory round trip per tap, ~6 us
+        // of a 13 us launch), then sorted into neighbourhood positions
+        float wt[9][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float wv = a.w[(long long)(n + j) * a.w_sn + (long long)p.tap_kidx[t] * a.w_st];
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int qq = 0; qq < 9; ++qq)
-                if (qq == q) w9[j][qq] = wv;
+            for (int j = 0; j < 4; ++j)
+                wt[t][j] = (t < p.T) ? a.w[(long long)(n + j) * a.w_sn + (long long)p.tap_kidx[t] * a.w_st] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int q = (t < p.T) ? (g.off_y + p.tap_dy[t] + 1) * 3 + (g.off_x + p.tap_dx[t] + 1) : -1;     // neighbourhood position of tap t
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int qq = 0; qq < 9; ++qq)
+                    if (qq == q) w9[j][qq] = wt[t][j];
         }
     }
     const ScalePair sp = load_scale(a);
@@ -293,7 +305,14 @@ __global__ __launch_bounds__(256) void fwd_c1_tile_kernel(const FwdParams p, int
                 s = fmaf(v20, w9[j][6], s); s = fmaf(v21, w9[j][7], s); s = fmaf(v22, w9[j][8], s);
                 acc[j] = s;
             }
-            store_epilogue4(a, acc, sc, bias, (long long)m0 + rx, n, p.vec_store);
+            if constexpr (PLAIN) {
+                f32x4 q;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[j] = apply_act(acc[j] * sc + bias[j], ACT);
+                *reinterpret_cast<f32x4*>(a.out + ((long long)m0 + rx) * a.out_ld + n) = q;
+            } else {
+                store_epilogue4(a, acc, sc, bias, (long long)m0 + rx, n, p.vec_store);
+            }
         }
     }
 }
@@ -390,38 +409,52 @@ __global__ __launch_bounds__(256) void fwd_n1_planes_kernel(const N1PlaneParams 
     __syncthreads();
     // ---- phase 1: tap planes of input rows y0 - 1 .. y0 + R, one 32-pixel block (half a row) per wave and iteration
     const int nblocks = PR * 2;
-    f32x4 an[4];
-    auto load = [&](int blk, int ch) {
+    // Steps s = 0, 1, ... of this wave: (block wave + 4 * (s / NCH), chunk s % NCH).  TWO steps' loads are in flight while a
+    // third is multiplied (registers an[0], an[1] alternate: the step loop is unrolled by two): with one step ahead a
+    // chunk took a memory round trip (~1.5 us) for 0.43 us of MFMAs and the launch ran at 2.3-2.9 TB/s.
+    f32x4 an[2][4];
+    auto load = [&](int slot, int s) {
+        const int blk = wave + 4 * (s / NCH), ch = s % NCH;
         const int pr = blk >> 1, x0 = (blk & 1) * 32;
         const int iy = y0 - 1 + pr;
         const bool ok = (blk < nblocks) & ((unsigned)iy < (unsigned)g.IH);
         const unsigned voff = ok ? (unsigned)((((((long long)b * g.IH + iy) * g.IW + x0 + l31) * a.in_ld) + 32 * ch + 16 * kh) * 4) : 0x80000000u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) an[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 16 * j, 0));
+        for (int j = 0; j < 4; ++j) an[slot][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 16 * j, 0));
     };
-    int blk = wave;
-    load(blk, 0);
-    while (blk < nblocks) {
-        f32x16 acc;
+    const int nsteps = ((nblocks - wave + 3) / 4) * NCH;
+    f32x16 acc;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    auto step = [&](int slot, int s) {
+        const int blk = wave + 4 * (s / NCH), ch = s % NCH;
+        f32x4 ac[4];
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            f32x4 ac[4];
+        for (int j = 0; j < 4; ++j) ac[j] = an[slot][j];
+        load(slot, s + 2);                                          // past the last step: out of range, zeros
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ac[j] = an[j];
-            if (ch + 1 < NCH) load(blk, ch + 1);
-            else load(blk + 4, 0);                                   // past the last block: out of range, zeros
+        for (int c2 = 0; c2 < NCH; ++c2) {
+            if (c2 == ch) {
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) acc = mfma32(ac[kk >> 2][kk & 3], wf[ch][kk], acc);
+                for (int kk = 0; kk < 16; ++kk) acc = mfma32(ac[kk >> 2][kk & 3], wf[c2][kk], acc);
+            }
         }
-        if (l31 < 9) {
-            const int pr = blk >> 1, x0 = (blk & 1) * 32;
-            float* dst = planes + l31 * PSZ + pr * PW + 1 + x0;
+        if (ch == NCH - 1 && s < nsteps) {
+            if (l31 < 9) {
+                const int pr = blk >> 1, x0 = (blk & 1) * 32;
+                float* dst = planes + l31 * PSZ + pr * PW + 1 + x0;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) dst[mfma32_row(e, lane)] = acc[e];
+                for (int e = 0; e < 16; ++e) dst[mfma32_row(e, lane)] = acc[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
         }
-        blk += 4;
+    };
+    load(0, 0);
+    load(1, 1);
+    for (int s = 0; s < nsteps; s += 2) {       // (an odd count runs one step on zeros: nothing is stored for it)
+        step(0, s);
+        step(1, s + 1);
     }
     __syncthreads();
     // ---- phase 2: nine plane values per output pixel, launch tap order, then the usual epilogue
@@ -692,14 +725,20 @@ extern "C" int mtd_conv_direct(const mtd_conv_args* a, void* stream) {
             if (near && env_tile && g.OW % PL == 0 && (a->scale2 == nullptr || a->scale_split % (g.OH * g.OW) == 0)) {
                 // ~512 workgroups of 4 or 8 image rows: with one row each (2048 workgroups of four pixels per thread) the
                 // launch was ramp and tail (19 us for 16.8 MB of output)
-                R = (int)(((Mpix + 511) / 512) / g.OW);
+                static const int env_wgs = [] { const char* e = getenv("MTD_C1_WGS"); return e ? atoi(e) : 512; }();
+                R = (int)(((Mpix + env_wgs - 1) / env_wgs) / g.OW);
                 if (R < 1) R = 1;
                 while (R > 1 && g.OH % R) --R;                                 // whole tiles per image
                 if (R < 1 || (long long)(R + 2) * (g.OW + 2) * 4 > 48 * 1024) R = 0;
             }
             if (R > 0) {
                 const size_t lds = (size_t)(R + 2) * (g.OW + 2) * sizeof(float);
-                hipLaunchKernelGGL(fwd_c1_tile_kernel, dim3((unsigned)((long long)g.B * g.OH / R)), dim3(256), lds, (hipStream_t)stream, p, R);
+                const dim3 grid((unsigned)((long long)g.B * g.OH / R));
+                const bool plain = !a->add1 && !a->add2 && !a->mask && p.vec_store;
+                if (plain && a->act == MTD_ACT_LRELU) hipLaunchKernelGGL((fwd_c1_tile_kernel<true, MTD_ACT_LRELU>), grid, dim3(256), lds, (hipStream_t)stream, p, R);
+                else if (plain && a->act == MTD_ACT_RELU) hipLaunchKernelGGL((fwd_c1_tile_kernel<true, MTD_ACT_RELU>), grid, dim3(256), lds, (hipStream_t)stream, p, R);
+                else if (plain && a->act == MTD_ACT_NONE) hipLaunchKernelGGL((fwd_c1_tile_kernel<true, MTD_ACT_NONE>), grid, dim3(256), lds, (hipStream_t)stream, p, R);
+                else hipLaunchKernelGGL((fwd_c1_tile_kernel<false, 0>), grid, dim3(256), lds, (hipStream_t)stream, p, R);
             } else
             hipLaunchKernelGGL(fwd_c1_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
         } else if ([&] {
@@ -721,7 +760,8 @@ extern "C" int mtd_conv_direct(const mtd_conv_args* a, void* stream) {
             q.a = *a;
             q.M = (int)Mpix;
             q.T = T;
-            q.R = 8;
+            static const int env_r = [] { const char* e = getenv("MTD_N1_R"); return e ? atoi(e) : 8; }();
+            q.R = env_r;
             q.in_bytes = (unsigned)((((long long)g.B * g.IH * g.IW - 1) * a->in_ld + a->C) * 4);
             for (int t = 0; t < T; ++t) {
                 q.tap_kidx[t] = p.tap_kidx[t];

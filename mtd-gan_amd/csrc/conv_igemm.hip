@@ -55,6 +55,7 @@ struct IgemmParams {
     int out_linear;    // 32 consecutive launch-grid pixels (from a multiple of 32) map to output pixels pix0 + r * out_sx
     int xcd_map;       // tiles in XCD-contiguous, n-fastest order (tile_of below)
     int nt_store;      // lab switch MTD_IGEMM_NT=1: non-temporal output stores in the block epilogue
+    int fin;           // split-K: the last workgroup to arrive at a tile sums the slabs and runs the epilogue (a.tile_ctr)
 };
 
 // (m tile, n tile) of this workgroup.  Dispatch order is blockIdx.x fastest and consecutive workgroups land on different
@@ -324,8 +325,120 @@ __device__ __forceinline__ void epiw_bias(const mtd_conv_args& a, int ch, f32x4 
     for (int g = 0; g < 4; ++g) bias4[g] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + ch + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
+// ---- split-K finish inside the kernel ------------------------------------------------------------------------------
+// Every slice stores its partial tile to its slab as before, then arrives at the tile's counter (a.tile_ctr, zero on
+// entry).  The workgroup that completes the count re-reads ALL slabs of the tile in slice order 0 .. splitk-1 -- the
+// sum is the one splitk_epilogue_kernel forms, bit for bit, whichever slice arrives last -- and runs the ordinary
+// epilogue on it; it also puts the counter back to zero for the next launch.
+// The slabs cross XCDs (one L2 each).  A device-scope release / acquire fence pair does that with a write-back and an
+// invalidate of the WHOLE L2 per workgroup: measured +40 us per launch (full step 42.3 -> 48.2 ms).  Instead the slab
+// stores and the re-reads of a finishing launch are device-scope accesses themselves (relaxed atomics: written through
+// to / read from the memory side, no line left dirty or stale in an L2), and the arrival waits for the stores'
+// acknowledgements (vmcnt) before the counter is bumped.
+__device__ __forceinline__ void slab_store(float* p, float v, bool through) {
+    if (through) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+__device__ __forceinline__ bool splitk_last_arrival(const IgemmParams& p, int tile) {
+    __shared__ unsigned last_s;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(p.a.tile_ctr + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = old == (unsigned)p.splitk - 1u;
+        if (last) __hip_atomic_store(p.a.tile_ctr + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = last ? 1u : 0u;
+    }
+    __syncthreads();
+    return last_s != 0u;
+}
+
+// 16 bytes of a slab, device scope (the finishing workgroup: see above)
+__device__ __forceinline__ f32x4 slab_load4(const float* p) {
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __hip_atomic_load(p + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+
+// One output pixel x four consecutive channels: the slabs summed in slice order (from +0.0f), then the epilogue in the
+// order of epilogue_value().  16-byte slab reads, up to eight slices in flight; needs splitk_vec_ok().
+template <bool DEV>
+__device__ __forceinline__ void splitk_finish_vec4(const IgemmParams& p, const ScalePair& sp, unsigned m, unsigned n, long long total) {
+    const mtd_conv_args& a = p.a;
+    const float* base = a.ws + ((long long)m * a.N + n);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 8 <= p.splitk; z += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = DEV ? slab_load4(base + (long long)(z + j) * total) : *reinterpret_cast<const f32x4*>(base + (long long)(z + j) * total);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    if (z + 4 <= p.splitk) {
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = DEV ? slab_load4(base + (long long)(z + j) * total) : *reinterpret_cast<const f32x4*>(base + (long long)(z + j) * total);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += v[j];
+        z += 4;
+    }
+    for (; z < p.splitk; ++z) s += DEV ? slab_load4(base + (long long)z * total) : *reinterpret_cast<const f32x4*>(base + (long long)z * total);
+    const long long pix = out_pixel(a.g, (int)m, p.out_identity);
+    const float sc = pick_scale(sp, (int)m);
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f}, e1 = {-0.0f, -0.0f, -0.0f, -0.0f}, e2 = e1, em = {1.f, 1.f, 1.f, 1.f};
+    if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + n);
+    if (a.add1) e1 = *reinterpret_cast<const f32x4*>(a.add1 + pix * a.add1_ld + n);
+    if (a.add2) e2 = *reinterpret_cast<const f32x4*>(a.add2 + pix * a.add2_ld + n);
+    if (a.mask) em = *reinterpret_cast<const f32x4*>(a.mask + pix * a.mask_ld + n);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v = s[j] * sc + bias[j];      // the order of epilogue_value(); absent operands are neutral elements
+        v += e1[j];
+        v += e2[j];
+        v = apply_act(v, a.act);
+        if (a.mask) v *= (em[j] > 0.f) ? 1.f : a.mask_slope;
+        o[j] = v;
+    }
+    *reinterpret_cast<f32x4*>(a.out + pix * a.out_ld + n) = o;
+}
+
+template <bool DEV>
+__device__ __forceinline__ void splitk_finish_scalar(const IgemmParams& p, const ScalePair& sp, int m, int n, long long total) {
+    const mtd_conv_args& a = p.a;
+    const long long idx = (long long)m * a.N + n;
+    float s = 0.f;
+    for (int z = 0; z < p.splitk; ++z)
+        s += DEV ? __hip_atomic_load(a.ws + (long long)z * total + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.ws[(long long)z * total + idx];
+    const long long pix = out_pixel(a.g, m, p.out_identity);
+    const float bias_n = a.bias ? a.bias[n] : 0.f;
+    a.out[pix * a.out_ld + n] = epilogue_value(a, s, pick_scale(sp, m), bias_n, pix, n);
+}
+
+// the BM x BN tile at (m0, n0), by the 256 threads of the workgroup that arrived last (p.fin: 1 = 16-byte form, 2 = scalar)
+template <int BM, int BN>
+__device__ __forceinline__ void splitk_finish_tile(const IgemmParams& p, int m0, int n0) {
+    const long long total = (long long)p.M * p.a.N;
+    const ScalePair sp = load_scale(p.a);
+    if (p.fin == 1) {
+        constexpr int Q = BN / 4;
+        for (int i = threadIdx.x; i < BM * Q; i += 256) {
+            const int m = m0 + i / Q;
+            if (m < p.M) splitk_finish_vec4<true>(p, sp, (unsigned)m, (unsigned)(n0 + 4 * (i % Q)), total);
+        }
+    } else {
+        for (int i = threadIdx.x; i < BM * BN; i += 256) {
+            const int m = m0 + i / BN;
+            if (m < p.M) splitk_finish_scalar<true>(p, sp, m, n0 + i % BN, total);
+        }
+    }
+}
+
 // zk: this workgroup's split-K slice (blockIdx.z of a single launch; blockIdx.z % splitk of a multi launch, below)
-template <int WM, int WN, int WGM, int WGN>
+template <int WM, int WN, int WGM, int WGN, bool FIN = true>
 __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int zk) {
     constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN;
     constexpr int PB = BN / 32;     // 16-byte weight vectors staged per thread and chunk (BN rows x 8 vectors)
@@ -517,9 +630,12 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int zk) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int m = m0 + (wm * WM + i) * 32 + mfma32_row(e, lane);
-                    if (m < p.M) slab[(long long)m * a.N + n] = acc[i][j][e];
+                    if (m < p.M) slab_store(&slab[(long long)m * a.N + n], acc[i][j][e], p.fin != 0);
                 }
             }
+        if constexpr (FIN) {
+            if (p.fin && splitk_last_arrival(p, tile_m * (int)gridDim.y + tile_n)) splitk_finish_tile<BM, BN>(p, m0, n0);
+        }
         return;
     }
     const ScalePair sp = load_scale(a);
@@ -553,10 +669,10 @@ __global__ __launch_bounds__(256, (WM * WN >= 4) ? 2 : 1) void igemm_multi_kerne
     // (a switch, not an index: with a dynamic index into the kernel arguments the compiler moved the tap tables of the
     // register-blocked tiles to scratch memory)
     switch (set) {
-        case 0: igemm_body<WM, WN, WGM, WGN>(mp.p[0], zk); break;
-        case 1: igemm_body<WM, WN, WGM, WGN>(mp.p[1], zk); break;
-        case 2: igemm_body<WM, WN, WGM, WGN>(mp.p[2], zk); break;
-        default: igemm_body<WM, WN, WGM, WGN>(mp.p[3], zk); break;
+        case 0: igemm_body<WM, WN, WGM, WGN, false>(mp.p[0], zk); break;
+        case 1: igemm_body<WM, WN, WGM, WGN, false>(mp.p[1], zk); break;
+        case 2: igemm_body<WM, WN, WGM, WGN, false>(mp.p[2], zk); break;
+        default: igemm_body<WM, WN, WGM, WGN, false>(mp.p[3], zk); break;
     }
 }
 
@@ -709,8 +825,11 @@ __global__ __launch_bounds__(256, 2) void igemm_tb_kernel(const IgemmParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + (wave * WM + i) * 32 + mfma32_row(e, lane);
-                if (m < p.M) slab[(long long)m * a.N + n] = acc[i][e];
+                if (m < p.M) slab_store(&slab[(long long)m * a.N + n], acc[i][e], p.fin != 0);
             }
+        }
+        if constexpr (WM == 1) {      // (the two-block form has no registers to spare: fill_params keeps fin off for it)
+            if (p.fin && splitk_last_arrival(p, tile_m * (int)gridDim.y + tile_n)) splitk_finish_tile<BM, 32>(p, m0, n0);
         }
         return;
     }
@@ -1103,9 +1222,10 @@ __global__ __launch_bounds__(256, 2) void igemm_v2_kernel(const IgemmParams p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int m = m0 + wm * 64 + i * 32 + mfma32_row(e, lane);
-                    if (m < p.M) slab[(long long)m * a.N + n] = acc[i][j][e];
+                    if (m < p.M) slab_store(&slab[(long long)m * a.N + n], acc[i][j][e], p.fin != 0);
                 }
             }
+        if (p.fin && splitk_last_arrival(p, (int)(blockIdx.x * gridDim.y + blockIdx.y))) splitk_finish_tile<128, 128>(p, m0, n0);
         return;
     }
     const ScalePair sp = load_scale(a);
@@ -1122,20 +1242,12 @@ __global__ __launch_bounds__(256) void splitk_epilogue_scalar_kernel(const Igemm
     const mtd_conv_args& a = p.a;
     const long long total = (long long)p.M * a.N;
     const ScalePair sp = load_scale(a);
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int n = (int)(idx % a.N);
-        const int m = (int)(idx / a.N);
-        float s = 0.f;
-        for (int z = 0; z < p.splitk; ++z) s += a.ws[(long long)z * total + idx];
-        const long long pix = out_pixel(a.g, m, p.out_identity);
-        const float bias_n = a.bias ? a.bias[n] : 0.f;
-        a.out[pix * a.out_ld + n] = epilogue_value(a, s, pick_scale(sp, m), bias_n, pix, n);
-    }
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256)
+        splitk_finish_scalar<false>(p, sp, (int)(idx / a.N), (int)(idx % a.N), total);
 }
 
-// Four consecutive output channels of one pixel per thread: 16-byte slab reads with up to eight splits in flight (the
-// scalar loop above serialises one memory round trip per split), 16-byte operand reads and stores.  Needs every row
-// stride a multiple of 4 floats and 16-byte aligned bases (splitk_vec_ok); total < 2^31.
+// Four consecutive output channels of one pixel per thread (splitk_finish_vec4).  Needs every row stride a multiple of
+// 4 floats and 16-byte aligned bases (splitk_vec_ok); total < 2^31.
 __device__ __forceinline__ void splitk_epilogue_body(const IgemmParams& p) {
     const mtd_conv_args& a = p.a;
     const unsigned total4 = (unsigned)(((long long)p.M * a.N) >> 2);
@@ -1144,44 +1256,7 @@ __device__ __forceinline__ void splitk_epilogue_body(const IgemmParams& p) {
     const ScalePair sp = load_scale(a);
     for (unsigned i4 = blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += gridDim.x * 256) {
         const unsigned m = i4 / n4n;
-        const unsigned n = (i4 - m * n4n) << 2;
-        const float* base = a.ws + 4ll * i4;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        int z = 0;
-        for (; z + 8 <= p.splitk; z += 8) {
-            f32x4 v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(base + (long long)(z + j) * total);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s += v[j];
-        }
-        if (z + 4 <= p.splitk) {
-            f32x4 v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(base + (long long)(z + j) * total);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) s += v[j];
-            z += 4;
-        }
-        for (; z < p.splitk; ++z) s += *reinterpret_cast<const f32x4*>(base + (long long)z * total);
-        const long long pix = out_pixel(a.g, (int)m, p.out_identity);
-        const float sc = pick_scale(sp, (int)m);
-        f32x4 bias = {0.f, 0.f, 0.f, 0.f}, e1 = {-0.0f, -0.0f, -0.0f, -0.0f}, e2 = e1, em = {1.f, 1.f, 1.f, 1.f};
-        if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + n);
-        if (a.add1) e1 = *reinterpret_cast<const f32x4*>(a.add1 + pix * a.add1_ld + n);
-        if (a.add2) e2 = *reinterpret_cast<const f32x4*>(a.add2 + pix * a.add2_ld + n);
-        if (a.mask) em = *reinterpret_cast<const f32x4*>(a.mask + pix * a.mask_ld + n);
-        f32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v = s[j] * sc + bias[j];      // the order of epilogue_value(); absent operands are neutral elements
-            v += e1[j];
-            v += e2[j];
-            v = apply_act(v, a.act);
-            if (a.mask) v *= (em[j] > 0.f) ? 1.f : a.mask_slope;
-            o[j] = v;
-        }
-        *reinterpret_cast<f32x4*>(a.out + pix * a.out_ld + n) = o;
+        splitk_finish_vec4<false>(p, sp, m, (i4 - m * n4n) << 2, total);
     }
 }
 
@@ -1324,9 +1399,16 @@ int fill_params(const mtd_conv_args* a, const Plan& pl, IgemmParams& p) {
     p.xcd_map = env_xcd;
     static const int env_nt = [] { const char* e = getenv("MTD_IGEMM_NT"); return e ? atoi(e) : 0; }();
     p.nt_store = env_nt;
+    p.fin = 0;
     if (pl.splitk > 1) {
         size_t need = (size_t)pl.splitk * (size_t)p.M * a->N * sizeof(float);
         if (!a->ws || a->ws_bytes < need) return MTD_EWS;
+        // finish inside the kernel when the caller brought arrival counters for every output tile (MTD_SPLITK_FIN=0: lab
+        // switch back to the separate epilogue launch)
+        static const int env_fin = [] { const char* e = getenv("MTD_SPLITK_FIN"); return e ? atoi(e) : 1; }();
+        const long long tiles = (long long)((p.M + pl.BM - 1) / pl.BM) * (a->N / pl.BN);
+        static const int env_fin_max = [] { const char* e = getenv("MTD_SPLITK_FIN_MAX"); return e ? atoi(e) : 8; }();
+        p.fin = (env_fin && pl.cfg != 7 && a->tile_ctr && tiles <= (long long)a->tile_ctr_len && pl.splitk <= env_fin_max) ? (splitk_vec_ok(*a, p.M) ? 1 : 2) : 0;
     }
     return MTD_OK;
 }
@@ -1398,7 +1480,7 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
     }
     mtd_prof_end(prof, s);
     MTD_LAUNCH_CHECK();
-    if (pl.splitk > 1) {
+    if (pl.splitk > 1 && !p.fin) {
         const long long total = (long long)p.M * a->N;
         const bool vec = splitk_vec_ok(*a, p.M);
         int blocks = (int)(((vec ? total / 4 : total) + 255) / 256);
@@ -1445,6 +1527,9 @@ extern "C" int mtd_conv_igemm_multi(const mtd_conv_args* a, int count, void* str
         int rc = fill_params(&a[i < count ? i : 0], pl, mp.p[i]);
         if (rc != MTD_OK) return rc;
     }
+    // (split-K sets finish through splitk_epilogue_multi_kernel: with the in-kernel finish inlined four times the compiler
+    // merges the tails and selects the argument set dynamically -- 2.4 KB of scratch per lane)
+    for (int i = 0; i < MULTI_MAX; ++i) mp.p[i].fin = 0;
     hipStream_t s = (hipStream_t)stream;
     const int M = mp.p[0].M;
     double bytes = 0.0;
@@ -1461,7 +1546,7 @@ extern "C" int mtd_conv_igemm_multi(const mtd_conv_args* a, int count, void* str
     }
     mtd_prof_end(prof, s);
     MTD_LAUNCH_CHECK();
-    if (pl.splitk > 1) {
+    if (pl.splitk > 1 && !mp.p[0].fin) {
         bool vec = true;
         for (int i = 0; i < count; ++i) vec = vec && splitk_vec_ok(a[i], M);
         if (vec) {

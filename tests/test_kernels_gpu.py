@@ -312,6 +312,51 @@ def test_igemm_every_tile_config(hip_lib, cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 8])
+def test_splitk_finish_in_kernel_same_bits(hip_lib, cfg):
+    """Split-K launches that finish inside the kernel (arrival counters, mtd_conv_args.tile_ctr: the last slice to reach a
+    tile sums the slabs in slice order and runs the epilogue) against the separate epilogue launch: the same bits, with
+    the whole epilogue (1/sigma pair, bias, adds, LeakyReLU mask), ragged last tiles, unaligned output views (scalar form),
+    and the counters back at zero afterwards."""
+    import ctypes as C
+    from mtd_gan_amd import _lib, kernels as K
+    L = _lib.lib()
+    L.mtd_conv_igemm_override.argtypes = [C.c_int, C.c_int]
+    cases = [(3, 128, 128, 4, 4, 3, 1, 1, 2), (2, 512, 128, 2, 2, 3, 1, 1, 8), (5, 256, 64, 3, 3, 3, 1, 1, 4), (2, 64, 128, 8, 8, 1, 1, 0, 2)]
+    ctr = K.tile_counters(torch.device("cuda", 0))
+    fin_default = K.SPLITK_FIN
+    try:
+        for (B, Ci, Co, H, W, k, s, p, split) in cases:
+            x = rnd(B, Ci, H, W, seed=21)
+            w = rnd(Co, Ci, k, k, seed=22, scale=(Ci * k * k) ** -0.5)
+            a1, a2, mk = (nhwc(rnd(B, Co, H, W, seed=23 + i)) for i in range(3))
+            bias = rnd(Co, seed=26).cuda()
+            sc = torch.tensor([0.7, 1.3], device="cuda")
+            geom = K.geom_fwd(B, H, W, k, s, p)
+            kw = dict(add1=a1, add2=a2, mask=mk, mask_slope=0.2, bias=bias, act=0, scale=sc[0:1], scale2=sc[1:2], scale_split=(B // 2) * H * W)
+            L.mtd_conv_igemm_override(cfg, split)
+            for unaligned in (False, True):
+                outs = []
+                for fin in (False, True):
+                    K._igemm_ws_cache.clear()
+                    K.SPLITK_FIN = fin
+                    big = torch.zeros(B, H, W, Co + 4, device="cuda")
+                    out = big[..., 1:Co + 1] if unaligned else big[..., :Co]
+                    K.conv(nhwc(x), w.cuda(), geom, Co, Ci, Ci * k * k, k * k, out, **kw)
+                    outs.append(out.clone())
+                assert torch.equal(outs[0], outs[1]), (cfg, split, B, Ci, Co, H, unaligned)
+                ref = F.conv2d(x, w, None, stride=s, padding=p)
+                half = torch.cat([torch.full((B // 2, 1, 1, 1), 0.7), torch.full((B - B // 2, 1, 1, 1), 1.3)])
+                want = (ref * half + bias.cpu().reshape(1, -1, 1, 1) + nchw(a1) + nchw(a2)) * torch.where(nchw(mk) > 0, 1.0, 0.2)
+                assert relerr(nchw(outs[1]), want) < TOL, (cfg, split, B, Ci, Co, H, unaligned)
+            assert int(ctr.abs().sum()) == 0, "arrival counters must be left at zero"
+    finally:
+        K.SPLITK_FIN = fin_default
+        L.mtd_conv_igemm_override(-1, -1)
+        K._igemm_ws_cache.clear()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [-1, 9, 10])
 def test_igemm_generator_shaped_kernels(hip_lib, cfg):
     """The two kernels for the generator's 32-channel 3x3 layers on 64 x 64 maps (9 = persistent, 10 = halo tile, -1 = the
