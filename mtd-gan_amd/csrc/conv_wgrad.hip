@@ -426,6 +426,161 @@ __global__ __launch_bounds__(256, 2) void wgrad_row_rfft_kernel(const WgradParam
 }
 
 
+// ---- all-taps variant: 4x4 filters (the strided down convs of the discriminator trunk) --------------------------------
+// wgrad_kernel gives every group of 1-3 taps a workgroup of its own (grid.z): each re-reads the whole cotangent and its
+// own gather of the input -- 16 taps = 16 x (P + Q/4) through the L2s, 4.7 TB/s of fabric traffic at 72-76 TFLOP/s for
+// the 64..256-channel layers -- and on the 4x4 / 2x2 / 1x1 maps of the deep layers, where one pixel split suffices, its
+// workgroups scatter 4-byte values 64 bytes apart into the [n][c][4][4] gradient (16.8 MB written as 270 MB of sectors:
+// 34 us for 0.27 GFLOP).  Here ONE workgroup owns a 32 x 32 (n, c) tile for ALL 16 taps: wave ty takes the four taps of
+// filter row ty (4 x 16 accumulator registers), so the waves share the cotangent loads' cache lines, nobody splits pixels
+// inside the workgroup and there is no cross-wave sum.  Operands go straight to registers as in the row-window kernel
+// (lane = channel, k-step kk = pixels (kk, 16 + kk): one dword per lane and k-step, 128 contiguous bytes per 32 lanes;
+// out-of-image taps are out-of-range buffer offsets = 0), the next 32-pixel chunk is in flight under the current chunk's
+// 64 MFMAs.  With a single pixel split the tile is transposed through LDS to [n][c][16 taps] and leaves as 2 KB runs.
+__global__ __launch_bounds__(256, 1) void wgrad_taps_kernel(const WgradParams p) {
+    constexpr int TW = 4, T = 16;
+    __shared__ __attribute__((aligned(16))) float Ls[32 * 32 * T];
+    const mtd_wgrad_args& a = p.a;
+    const mtd_geom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, ty = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int ntile = blockIdx.y / p.nCt, ctile = blockIdx.y % p.nCt;
+    const int n0 = ntile * 32, c0 = ctile * 32;
+    const int m0 = blockIdx.x * p.ppw;                  // ppw: pixels per WORKGROUP here (a multiple of 32)
+    const bool do_bias = (a.db != nullptr) && ctile == 0;
+    const bool bias_wave = do_bias && ty == 0;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p), (short)0, (int)p.p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.q), (short)0, (int)p.q_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const unsigned qtx = (unsigned)(g.tap_dx * a.q_ld * 4);
+    const int dyrow = g.off_y + ty * g.tap_dy;
+
+    f32x16 acc[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    float bsum = 0.f;
+
+    // This lane's 16 pixels of chunk mc are m0 + mc + 16 kh + kk, walked incrementally from one index decomposition.
+    // The next chunk's loads (one P dword and four Q dwords per pixel, with their address arithmetic) are issued BETWEEN
+    // the current chunk's MFMAs, one piece per MFMA: an in-order wave that issues them in a block first (first version)
+    // spent ~3 k clocks there per chunk with the matrix pipe idle -- 57 TFLOP/s.
+    struct Walk { int m, ox, oy, b; bool live; };
+    auto walk_init = [&](int mc) {
+        Walk w;
+        w.m = m0 + mc + kh * 16;
+        w.live = mc < p.ppw;
+        w.ox = w.m % g.OW;
+        const int t2 = w.m / g.OW;
+        w.oy = t2 % g.OH;
+        w.b = t2 / g.OH;
+        return w;
+    };
+    unsigned qbase = 0;
+    bool rowok = false, pok = false;
+    int ix0 = 0;
+    float pa[16], qa[TW][16];
+    // loads of pixel kk, tap tx of the chunk `w` walks through: the Q dword, and with the row's last tap the P dword
+    // (ONE register set: an operand register is refilled right after the last MFMA that reads it)
+    auto piece = [&](Walk& w, int kk, int tx) {
+        if (tx == 0) {
+            pok = w.live && w.m < p.M;
+            const int iy = w.oy * g.in_sy + dyrow;
+            ix0 = w.ox * g.in_sx + g.off_x;
+            rowok = pok && ((unsigned)iy < (unsigned)g.IH);
+            qbase = (unsigned)(((((long long)w.b * g.IH + iy) * g.IW + ix0) * a.q_ld + c0 + l31) * 4);
+        }
+        const bool colok = (unsigned)(ix0 + tx * g.tap_dx) < (unsigned)g.IW;
+        const unsigned qoff = (rowok && colok) ? qbase + (unsigned)tx * qtx : OOB;
+        qa[tx][kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(qrs, qoff, 0, 0));
+        if (tx == TW - 1) {
+            const unsigned poff = pok ? (unsigned)(((long long)w.m * a.p_ld + n0 + l31) * 4) : OOB;
+            pa[kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, poff, 0, 0));
+            ++w.m;
+            if (++w.ox == g.OW) {
+                w.ox = 0;
+                if (++w.oy == g.OH) { w.oy = 0; ++w.b; }
+            }
+        }
+    };
+    {
+        Walk w = walk_init(0);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+            for (int tx = 0; tx < TW; ++tx) piece(w, kk, tx);
+    }
+    for (int mc = 0; mc < p.ppw; mc += 32) {
+        Walk w = walk_init(mc + 32);            // past the workgroup's range: every offset out of range, zeros
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+#pragma unroll
+            for (int tx = 0; tx < TW; ++tx) {
+                acc[tx] = mfma32(pa[kk], qa[tx][kk], acc[tx]);
+                // (the bias sum takes each P value where it is in a register anyway; summed at the top of the chunk it made
+                // wave 0 wait for ALL of the chunk's loads before its first MFMA)
+                if (tx == TW - 1) bsum += bias_wave ? pa[kk] : 0.f;
+                piece(w, kk, tx);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- epilogue
+    const bool direct = (p.nslab == 1);
+    const bool packed = direct && a.w_sc == T && (a.w_sn % 4) == 0 && ((((uintptr_t)a.dw) & 15) == 0) && g.ky0 == 0 && g.kx0 == 0 &&
+                        g.ky_step == 1 && g.kx_step == 1 && g.KW == TW;
+    if (packed) {
+        // [n][c][ty][tx] in LDS (a lane's four taps of a filter row are 16 contiguous bytes), then straight copies of 2 KB rows
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const f32x4 v = {acc[0][e], acc[1][e], acc[2][e], acc[3][e]};
+            *reinterpret_cast<f32x4*>(Ls + (mfma32_row(e, lane) * 32 + l31) * T + ty * TW) = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int i = tid; i < 32 * 32 * T / 4; i += 256) {
+            const int nl = i >> 7, rem = i & 127;
+            float* dst = a.dw + (long long)(n0 + nl) * a.w_sn + (long long)c0 * T + 4 * rem;
+            f32x4 v = *reinterpret_cast<const f32x4*>(Ls + 4 * i);
+            if (a.accumulate & 1) v += *reinterpret_cast<const f32x4*>(dst);
+            *reinterpret_cast<f32x4*>(dst) = v;
+        }
+    } else {
+        float* slab = a.ws + (long long)blockIdx.x * p.slab_stride;
+#pragma unroll
+        for (int tx = 0; tx < TW; ++tx) {
+            const int t = ty * TW + tx;
+            const int kidx = (g.ky0 + ty * g.ky_step) * g.KW + (g.kx0 + tx * g.kx_step);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + mfma32_row(e, lane), cc = c0 + l31;
+                if (direct) {
+                    float* dst = a.dw + (long long)n * a.w_sn + (long long)cc * a.w_sc + kidx;
+                    *dst = (a.accumulate & 1) ? (*dst + acc[tx][e]) : acc[tx][e];
+                } else {
+                    slab[((long long)t * a.N + n) * a.C + cc] = acc[tx][e];
+                }
+            }
+        }
+    }
+    if (do_bias) {
+        __syncthreads();
+        if (ty == 0) Ls[lane] = bsum;
+        __syncthreads();
+        if (tid < 32) {
+            const float s2 = Ls[tid] + Ls[tid + 32];
+            if (direct) {
+                float* dst = a.db + n0 + tid;
+                *dst = (a.accumulate & 2) ? (*dst + s2) : s2;
+            } else {
+                (a.ws + (long long)blockIdx.x * p.slab_stride)[(long long)p.T * a.N * a.C + n0 + tid] = s2;
+            }
+        }
+    }
+}
+
 // ---- block-window variant -------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolutions on the 8x8, 4x4 and 2x2 feature maps of the discriminator trunk (the layers
 // with 512 x 512 ... 256 x 1024 channels).  A lane's 16 pixels (k-steps) are two rows of an 8x8 image, a whole 4x4
@@ -728,6 +883,8 @@ constexpr int NWCFG = 7;
 const int kWcfgWN[NWCFG] = {1, 1, 2, 1, 1, 1, 2};
 const int kWcfgWC[NWCFG] = {1, 1, 2, 1, 1, 1, 2};
 const int kWcfgTG[NWCFG] = {9, 4, 1, 8, 3, 1, 3};
+// (cfg 13: wgrad_taps_kernel.  A 64 x 64 tile with a whole filter row per workgroup, wgrad_kernel<2, 2, 4>, needs 256
+// accumulator registers and spilled 600 bytes per lane: not instantiated.)
 
 // row-window kernel: stride 1, rows of a multiple of 16 output pixels, 3x3 (unit tap spacing) or 1x1
 bool row_window_ok(const mtd_wgrad_args& a) {
@@ -754,6 +911,26 @@ WPlan make_wplan(const mtd_wgrad_args& a) {
     else if (T <= 4) pl.cfg = 1;
     else if (T <= 9) pl.cfg = (M <= 2048) ? 4 : 0;              // few pixels, many tiles: 3 taps per wave, no pixel split
     else pl.cfg = (M >= 2048 && a.N % 64 == 0 && a.C % 64 == 0) ? 2 : 4;
+    static const int env_taps = [] { const char* e = getenv("MTD_WGRAD_TAPS"); return e ? atoi(e) : 1; }();
+    static const int env_taps_maxm = [] { const char* e = getenv("MTD_WGRAD_TAPS_MAXM"); return e ? atoi(e) : 128; }();
+    if (a.g.TH == 4 && a.g.TW == 4 && ((env_taps && g_wforce_cfg == -1 && M <= env_taps_maxm) || g_wforce_cfg == 13)) {
+        // all-taps kernel: ~one workgroup per CU; pixels per workgroup a multiple of 32
+        pl.cfg = 13;
+        pl.WN = 1; pl.WC = 1; pl.TG = T; pl.ntg = 1; pl.nw = 4;
+        const long long tiles = (long long)(a.N / 32) * (a.C / 32);
+        static const int env_wgs = [] { const char* e = getenv("MTD_WGRAD_TAPS_WGS"); return e ? atoi(e) : 256; }();
+        long long ns = (env_wgs + tiles - 1) / tiles;
+        if (g_wforce_split > 0) ns = g_wforce_split;
+        const long long max_splits = (M + 31) / 32;
+        if (ns > max_splits) ns = max_splits;
+        if (ns < 1) ns = 1;
+        long long ppw = (M + ns - 1) / ns;
+        ppw = ((ppw + 31) / 32) * 32;
+        ns = (M + ppw - 1) / ppw;
+        pl.ppw = (int)ppw;
+        pl.nsplit = (int)ns;
+        return pl;
+    }
     const int bw = block_window_w(a);
     if ((row_window_ok(a) || bw) && g_wforce_cfg != -2) {   // override cfg -2: keep the LDS-staged kernels (A/B comparison)
         pl.cfg = bw ? (bw == 8 ? 10 : (bw == 4 ? 11 : 12)) : ((T == 1) ? 9 : (a.g.tap_dx > 0 ? 7 : 8));
@@ -934,6 +1111,7 @@ static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, 
             case 12: if (pl.nw == 8) MTD_LAUNCH((wgrad_blk_kernel<2, 8>), grid, dim3(512), 0, s, p);
                      else MTD_LAUNCH((wgrad_blk_kernel<2, 4>), grid, dim3(256), 0, s, p);
                      break;
+            case 13: MTD_LAUNCH(wgrad_taps_kernel, grid, dim3(256), 0, s, p); break;
             case 5: MTD_LAUNCH((wgrad_kernel<1, 1, 1>), grid, dim3(256), 0, s, p); break;
             default: MTD_LAUNCH((wgrad_kernel<2, 2, 3>), grid, dim3(256), 0, s, p); break;
         }

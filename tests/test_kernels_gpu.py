@@ -37,6 +37,9 @@ CONV_CASES = [
     (3, 256, 512, 4, 4, 3, 1, 1),     # deep layer, M=48 -> 32x128 tiles, split-K, tap skipping
     (2, 512, 512, 2, 2, 3, 1, 1),
     (2, 512, 512, 2, 2, 4, 2, 1),     # -> 1x1
+    (3, 64, 64, 16, 16, 4, 2, 1),     # all-taps weight gradient: 4 tiles, six pixel splits (slabs)
+    (2, 512, 512, 4, 4, 4, 2, 1),     # all-taps: 8 pixels, single split, LDS-transposed [n][c][16] rows
+    (5, 256, 512, 8, 8, 4, 2, 1),     # all-taps: 80 pixels, two ragged splits
     (2, 512, 512, 1, 1, 1, 1, 0),     # bconv (1x1)
     (2, 128, 256, 8, 8, 1, 1, 0),
     (2, 1, 32, 64, 64, 3, 1, 1),      # direct: Cin = 1
@@ -84,6 +87,52 @@ def test_conv_fwd_dgrad_wgrad(hip_lib, case):
     # accumulate mode
     K.wgrad(gpre, xd, K.geom_fwd(B, H, W, k, s, p), Co, Ci, dw, Ci * k * k, k * k, db=db, accumulate=True)
     assert relerr(dw.cpu() * 0.35, w.grad) < TOL
+
+
+@pytest.mark.parametrize("case", [(3, 64, 64, 16, 16, 0), (3, 64, 64, 16, 16, 3), (2, 512, 512, 4, 4, 0), (5, 256, 512, 8, 8, 2), (1, 128, 128, 2, 2, 0)])
+def test_all_taps_weight_gradient_forced(hip_lib, case):
+    """wgrad_taps_kernel (one workgroup per (n, c) tile for all 16 taps of a 4x4 stride-2 layer) forced through the tuning
+    hook on shapes the plan gives to other kernels too: its own pixel split and forced ones (slabs + finish kernels), ragged
+    last chunks, a single pixel (2x2 -> 1x1), bias gradient, accumulate mode."""
+    import ctypes as C
+    from mtd_gan_amd import _lib, kernels as K
+    L = _lib.lib()
+    L.mtd_conv_wgrad_override.argtypes = [C.c_int, C.c_int]
+    B, Ci, Co, H, W, split = case
+    x = rnd(B, Ci, H, W, seed=41)
+    w = rnd(Co, Ci, 4, 4, seed=42, scale=0.02).requires_grad_(True)
+    b = rnd(Co, seed=43, scale=0.1).requires_grad_(True)
+    y = F.conv2d(x, w, b, stride=2, padding=1)
+    cot = rnd(*y.shape, seed=44)
+    (y * cot).sum().backward()
+    try:
+        L.mtd_conv_wgrad_override(13, split if split else -1)
+        dw = torch.full((Co, Ci, 4, 4), 0.25, device="cuda")
+        db = torch.full((Co,), 0.5, device="cuda")
+        geom = K.geom_fwd(B, H, W, 4, 2, 1)
+        K.wgrad(nhwc(cot), nhwc(x), geom, Co, Ci, dw, Ci * 16, 16, db=db)
+        assert relerr(dw.cpu(), w.grad) < TOL
+        assert relerr(db.cpu(), b.grad) < TOL
+        K.wgrad(nhwc(cot), nhwc(x), geom, Co, Ci, dw, Ci * 16, 16, db=db, accumulate=True)
+        assert relerr(dw.cpu() * 0.5, w.grad) < TOL
+        assert relerr(db.cpu() * 0.5, b.grad) < TOL
+    finally:
+        L.mtd_conv_wgrad_override(-1, -1)
+
+
+def test_strided_wgrad_into_transposed_view(hip_lib):
+    """The all-taps weight gradient of a 4x4 stride-2 layer writing an IOHW view (ConvTranspose2d-style parameter: channel
+    stride != 16, so the single-split launch scatters value by value instead of copying packed rows), with accumulation."""
+    from mtd_gan_amd import kernels as K
+    B, Ci, Co, H = 2, 128, 256, 4
+    x = rnd(B, Ci, H, H, seed=31)
+    w = rnd(Co, Ci, 4, 4, seed=32, scale=0.02).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=2, padding=1)
+    cot = rnd(*y.shape, seed=33)
+    (y * cot).sum().backward()
+    dwT = torch.full((Ci, Co, 4, 4), 0.5, device="cuda")            # [c][n][ky][kx]: W(n, c, tap) at c * Co * 16 + n * 16 + tap
+    K.wgrad(nhwc(cot), nhwc(x), K.geom_fwd(B, H, H, 4, 2, 1), Co, Ci, dwT, 16, Co * 16, accumulate=True)
+    assert relerr(dwT.cpu().permute(1, 0, 2, 3) - 0.5, w.grad) < TOL
 
 
 def test_conv_epilogue_adds_and_mask(hip_lib):
