@@ -238,7 +238,7 @@ def roofline_pass(wl, steps, pmc_tag):
     K.set_concurrency(True)
     by = {}
     for r in recs:
-        if r["kernel"].startswith("igemm"):
+        if r["kernel"].startswith(("igemm", "c32_bwd", "wgrad")):       # every profiled MFMA launch (the library's launch profiler)
             d = by.setdefault(r["kernel"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0, "shapes": {}})
             d["ms"] += r["ms"]
             d["flops"] += r["flops"]
@@ -269,7 +269,7 @@ def roofline_pass(wl, steps, pmc_tag):
                 "share_of_step_gpu_ms": round(d["ms"] / steps, 3),
                 "top_shapes": {k: {"us": round(1e3 * v[0] / v[2], 2), "tflops": round(v[1] / v[0] / 1e9, 2), "launches_per_step": v[2] // steps}
                                for k, v in top},
-                "other_igemm": {k: {"tflops": round(v["flops"] / v["ms"] / 1e9, 2), "ms_per_step": round(v["ms"] / steps, 3)}
+                "other_mfma_kernels": {k: {"tflops": round(v["flops"] / v["ms"] / 1e9, 2), "ms_per_step": round(v["ms"] / steps, 3)}
                                 for k, v in by.items() if k != name}}
     return roofline, extra
 

@@ -142,11 +142,15 @@ __device__ __forceinline__ int mask_word(int k2, int kh, int o) {
 }
 __device__ __forceinline__ int mask_bit(int kh, int o) { return (o & 31) + 32 * (((kh & 31) >> 2) & 1); }
 
-__global__ __launch_bounds__(256, 2) void spec_mix_fwd4_kernel(const float* __restrict__ R, const float* __restrict__ w2t,
+__global__ __launch_bounds__(256, 3) void spec_mix_fwd4_kernel(const float* __restrict__ R, const float* __restrict__ w2t,
                                                                const float* __restrict__ b2, float* __restrict__ T,
                                                                float* __restrict__ S_save, unsigned long long* __restrict__ zmask) {
-    __shared__ __attribute__((aligned(1024))) float Xin[2 * 64 * 64];
-    __shared__ float Xs[2 * 64 * XLD4];
+    // ONE LDS image, used in turn as the DMA target (rows of 64 floats), the MFMA operand image (rows of XLD4) and the
+    // staging area of the result rows (64 again): 33 KB per workgroup, so THREE workgroups per CU = 768 slots for the 544
+    // units of a 32-patch launch.  With an input and an operand buffer (66 KB, two per CU, 512 slots) the last 32 units
+    // ran as a second round on an empty chip: 26 us per launch for 13 us of work per unit.
+    __shared__ __attribute__((aligned(1024))) float Xs[2 * 64 * XLD4];
+    float* const Xin = Xs;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y, unit = b * gridDim.x + blockIdx.x;
@@ -173,6 +177,7 @@ __global__ __launch_bounds__(256, 2) void spec_mix_fwd4_kernel(const float* __re
             re[m] = valid ? src[m * 256] : 0.f;
             im[m] = valid ? src[m * 256 + 32] : 0.f;
         }
+        __syncthreads();                // every column is in registers: the image may be rewritten in operand layout
         fft64_quad<-1>(re, im, tc, ts, j);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -182,7 +187,8 @@ __global__ __launch_bounds__(256, 2) void spec_mix_fwd4_kernel(const float* __re
             Xs[(kwl * 64 + kh) * XLD4 + 32 + c] = si;
         }
     }
-    // the mix weights as MFMA B fragments (one batch of loads, under the barrier)
+    // the mix weights as MFMA B fragments (one batch of loads, under the barrier; issued before the transform instead they
+    // made the launch slower, 23.0 -> 24.4 us)
     float wf0[32], wf1[32];
 #pragma unroll
     for (int kk = 0; kk < 32; ++kk) {
@@ -232,8 +238,9 @@ __global__ __launch_bounds__(256, 2) void spec_mix_fwd4_kernel(const float* __re
             re[m] = src[4 * m * XLD4];
             im[m] = src[4 * m * XLD4 + 32];
         }
+        __syncthreads();                // every spectrum is in registers
         fft64_quad<+1>(re, im, tc, ts, j);
-        // through LDS (the input buffer is free) so that the result leaves as whole rows
+        // through LDS (rows of 64 floats again) so that the result leaves as whole rows
         float* st = Xin + kwl * 4096 + c;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -246,13 +253,17 @@ __global__ __launch_bounds__(256, 2) void spec_mix_fwd4_kernel(const float* __re
     if (mix_valid) store_rows32(Xin + (k2 * 64 + ih * 32) * 64, 64, T + cb0 + (k2 * 64 + ih * 32) * 64, lane);
 }
 
-__global__ __launch_bounds__(256, 2) void spec_mix_bwd4_kernel(const float* __restrict__ gR, const float* __restrict__ w2,
+__global__ __launch_bounds__(256, 3) void spec_mix_bwd4_kernel(const float* __restrict__ gR, const float* __restrict__ w2,
                                                                const float* __restrict__ S_save,
                                                                const unsigned long long* __restrict__ zmask, float* __restrict__ gT,
                                                                float* __restrict__ ws) {
-    __shared__ __attribute__((aligned(1024))) float Xin[2 * 64 * 64];      // gR columns, then the saved spectrum S
-    __shared__ float Gs[2 * 64 * XLD4];
+    // One LDS image as in the forward kernel (DMA target -> operand image of gZ -> operand image of gS -> staging of the
+    // result rows): three workgroups per CU.  The saved spectrum S, the second operand of the weight-gradient product, is
+    // read straight into registers in MFMA fragment order (lane = channel, k-step = frequency pair: one dword per lane and
+    // k-step, 128 contiguous bytes per 32 lanes) instead of through a second LDS buffer.
+    __shared__ __attribute__((aligned(1024))) float Gs[2 * 64 * XLD4];
     __shared__ unsigned long long Zm[128];
+    float* const Xin = Gs;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y, unit = b * gridDim.x + blockIdx.x;
@@ -263,20 +274,31 @@ __global__ __launch_bounds__(256, 2) void spec_mix_bwd4_kernel(const float* __re
     if (tid < 128) Zm[tid] = zmask[(long long)unit * 128 + tid];
     const int f = tid >> 2, j = tid & 3, kwl = f >> 5, c = f & 31;
     const bool valid = kwl == 0 || two;
-    float tc[16], ts[16];
-    quad_twiddles(j, tc, ts);
     const int l31 = lane & 31, kh2 = lane >> 5;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     float re[16], im[16];
+    // The saved spectrum of the first column as B fragments of the weight-gradient product (S comes from HBM: issued before
+    // the transform so that the round trip is under its arithmetic; the mix weights, L2 hits, follow after it)
+    const int io = wave >> 1, jk = wave & 1;        // weight gradient: wave (io, jk) owns one 32 x 32 block over both columns
+    float sf[32];
+    {
+        const float* sp = S_save + cb0 + kh2 * 64 + jk * 32 + l31;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) sf[kk] = sp[2 * kk * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     // ---- column FFT of the cotangent, times the ReLU mask; bias-gradient partial sums
     {
+        float tc[16], ts[16];
+        quad_twiddles(j, tc, ts);
         const float* src = Xin + kwl * 4096 + j * 64 + c;
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
             re[m] = valid ? src[m * 256] : 0.f;
             im[m] = valid ? src[m * 256 + 32] : 0.f;
         }
+        __syncthreads();                // every column is in registers: the image may be rewritten in operand layout
         fft64_quad<-1>(re, im, tc, ts, j);
         float dbr = 0.f, dbi = 0.f;
 #pragma unroll
@@ -300,45 +322,52 @@ __global__ __launch_bounds__(256, 2) void spec_mix_bwd4_kernel(const float* __re
             slab[64 * 64 + kwl * 64 + 32 + c] = si;
         }
     }
-    float wf0[32], wf1[32];
-#pragma unroll
-    for (int kk = 0; kk < 32; ++kk) {
-        wf0[kk] = w2[(2 * kk + kh2) * 64 + l31];
-        wf1[kk] = w2[(2 * kk + kh2) * 64 + 32 + l31];
-    }
-    __syncthreads();                                               // Gs complete, Xin dead
-    dma_columns(S_save + cb0, Xin, wave, lane, two);               // lands under the data-gradient MFMAs
-    // ---- data gradient  gS[f][k] = sum_o gZ[f][o] W2[o][k]: wave (k2, ih), both k halves
-    const int k2 = wave >> 1, ih = wave & 1;
+    const int k2 = wave >> 1, ih = wave & 1;        // data gradient: wave (k2, ih) owns rows k2*64 + ih*32 .. +31, both k halves
     const bool mix_valid = k2 == 0 || two;
     f32x16 accd[2];
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
         for (int e = 0; e < 16; ++e) accd[jj][e] = 0.f;
-    if (mix_valid) {
-        const float* arow = Gs + (k2 * 64 + ih * 32 + l31) * XLD4 + kh2;
+    {
+        float wf0[32], wf1[32];
 #pragma unroll
         for (int kk = 0; kk < 32; ++kk) {
-            const float a0 = arow[2 * kk];
-            accd[0] = mfma32(a0, wf0[kk], accd[0]);
-            accd[1] = mfma32(a0, wf1[kk], accd[1]);
+            wf0[kk] = w2[(2 * kk + kh2) * 64 + l31];
+            wf1[kk] = w2[(2 * kk + kh2) * 64 + 32 + l31];
+        }
+        __syncthreads();                                           // Gs complete
+        // ---- data gradient  gS[f][k] = sum_o gZ[f][o] W2[o][k]
+        if (mix_valid) {
+            const float* arow = Gs + (k2 * 64 + ih * 32 + l31) * XLD4 + kh2;
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) {
+                const float a0 = arow[2 * kk];
+                accd[0] = mfma32(a0, wf0[kk], accd[0]);
+                accd[1] = mfma32(a0, wf1[kk], accd[1]);
+            }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's share of S has landed
-    __syncthreads();                                               // ... and everybody's
-    // ---- weight gradient  dW2[o][k] += sum_f gZ[f][o] S[f][k]: wave (io, jk) owns one 32 x 32 block over both columns
+    // ---- weight gradient  dW2[o][k] += sum_f gZ[f][o] S[f][k]
     {
-        const int io = wave >> 1, jk = wave & 1;
         f32x16 accw;
 #pragma unroll
         for (int e = 0; e < 16; ++e) accw[e] = 0.f;
-        const int ncol = two ? 2 : 1;
-        for (int col = 0; col < ncol; ++col) {
-            const float* ga = Gs + (col * 64 + kh2) * XLD4 + io * 32 + l31;
-            const float* sb = Xin + col * 4096 + kh2 * 64 + jk * 32 + l31;
-#pragma unroll 8
-            for (int kk = 0; kk < 32; ++kk) accw = mfma32(ga[2 * kk * XLD4], sb[2 * kk * 64], accw);
+        float sg[32];
+        if (two) {                                                 // second column's fragments, under the first column's MFMAs
+            const float* sp = S_save + cb0 + 4096 + kh2 * 64 + jk * 32 + l31;
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) sg[kk] = sp[2 * kk * 64];
+        }
+        {
+            const float* ga = Gs + kh2 * XLD4 + io * 32 + l31;
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) accw = mfma32(ga[2 * kk * XLD4], sf[kk], accw);
+        }
+        if (two) {
+            const float* ga = Gs + (64 + kh2) * XLD4 + io * 32 + l31;
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) accw = mfma32(ga[2 * kk * XLD4], sg[kk], accw);
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) slab[(io * 32 + mfma32_row(e, lane)) * 64 + jk * 32 + l31] = accw[e];
@@ -353,16 +382,19 @@ __global__ __launch_bounds__(256, 2) void spec_mix_bwd4_kernel(const float* __re
     __syncthreads();
     // ---- inverse column FFT of gS
     {
+        float tc[16], ts[16];
+        quad_twiddles(j, tc, ts);
         const float* src = Gs + (kwl * 64 + j) * XLD4 + c;
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
             re[m] = src[4 * m * XLD4];
             im[m] = src[4 * m * XLD4 + 32];
         }
+        __syncthreads();                // every spectrum is in registers
         fft64_quad<+1>(re, im, tc, ts, j);
         const int kw = 2 * blockIdx.x + kwl;
         const float sc = (kw == 0 || kw == 32) ? 0.125f : 0.0625f;          // rfft2 backward: columns 1..31 halved
-        float* st = Xin + kwl * 4096 + c;                                    // (S is no longer needed: barrier above)
+        float* st = Xin + kwl * 4096 + c;                                    // rows of 64 floats again
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int h = 16 * j + r;
