@@ -56,6 +56,7 @@ struct IgemmParams {
     int xcd_map;       // tiles in XCD-contiguous, n-fastest order (tile_of below)
     int nt_store;      // lab switch MTD_IGEMM_NT=1: non-temporal output stores in the block epilogue
     int fin;           // split-K: the last workgroup to arrive at a tile sums the slabs and runs the epilogue (a.tile_ctr)
+    int wide;          // igemm_body: bit 0 = every epilogue operand row is 16-byte aligned (EpiWide), bit 1 = the slabs are
 };
 
 // (m tile, n tile) of this workgroup.  Dispatch order is blockIdx.x fastest and consecutive workgroups land on different
@@ -564,7 +565,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int zk) {
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j] = mfma32(ac[i][kk >> 2][kk & 3], bc[j][kk >> 2][kk & 3], acc[i][j]);
+                for (int j = 0; j < WN; ++j) acc[i][j] = mfma32(bc[j][kk >> 2][kk & 3], ac[i][kk >> 2][kk & 3], acc[i][j]);   // transposed block (EpiWide)
         }
     };
 
@@ -619,18 +620,28 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int zk) {
     }
     MTD_STAMP(60);
 
-    // ---- epilogue
+    // ---- epilogue.  The accumulator blocks are TRANSPOSED (operands swapped in mfma_steps): lane (l31, kh) holds, for its own
+    //      pixel, channels nb0 + 8 g + 4 kh + j -- every operand, the result and the split-K slabs move as 16-byte vectors
+    //      (EpiWide above; the dword form was 16 instructions per tensor and block, and the strided data gradients with two
+    //      adds and a mask are bound by exactly that traffic).
     if (p.splitk > 1) {
         float* slab = a.ws + (long long)zk * p.M * a.N;
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
-                const int n = n0 + (wn * WN + j) * 32 + l31;
+                const int m = m0 + (wm * WM + i) * 32 + l31;
+                if (m < p.M) {
+                    float* row = slab + (long long)m * a.N + (n0 + (wn * WN + j) * 32 + 4 * kh);
+                    const bool through = p.fin != 0;
+                    if ((p.wide & 2) && !through) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = m0 + (wm * WM + i) * 32 + mfma32_row(e, lane);
-                    if (m < p.M) slab_store(&slab[(long long)m * a.N + n], acc[i][j][e], p.fin != 0);
+                        for (int g4 = 0; g4 < 4; ++g4)
+                            *reinterpret_cast<f32x4*>(row + 8 * g4) = f32x4{acc[i][j][4 * g4], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3]};
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) slab_store(row + 8 * (e >> 2) + (e & 3), acc[i][j][e], through);
+                    }
                 }
             }
         if constexpr (FIN) {
@@ -643,8 +654,24 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int zk) {
     for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
-            const int n = n0 + (wn * WN + j) * 32 + l31;
-            epilogue16<4>(p, acc[i][j], m0 + (wm * WM + i) * 32, lane, n, sp);
+            const int mrow0 = m0 + (wm * WM + i) * 32, nb0 = n0 + (wn * WN + j) * 32;
+            if (mrow0 + l31 < p.M) {
+                EpiWide wad;
+                wad.init(p, mrow0, lane, nb0, sp);
+                if (p.wide & 1) {
+                    f32x4 bias4[4];
+                    epiw_bias(a, wad.ch, bias4);
+                    EpiWideOps weo;
+                    epiw_load(p, wad, weo);
+                    epiw_store(p, acc[i][j], wad, bias4, weo);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int n = wad.ch + 8 * (e >> 2) + (e & 3);
+                        a.out[wad.pix * a.out_ld + n] = epilogue_value(a, acc[i][j][e], wad.sc, a.bias ? a.bias[n] : 0.f, wad.pix, n);
+                    }
+                }
+            }
         }
     MTD_STAMP(61);
 }
@@ -754,7 +781,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tb_kernel(const IgemmParams p) {
 #pragma unroll
         for (int kk = k0; kk < k1; ++kk)
 #pragma unroll
-            for (int i = 0; i < WM; ++i) acc[i] = mfma32(ac[i][kk >> 2][kk & 3], bc[kk >> 2][kk & 3], acc[i]);
+            for (int i = 0; i < WM; ++i) acc[i] = mfma32(bc[kk >> 2][kk & 3], ac[i][kk >> 2][kk & 3], acc[i]);      // transposed block (EpiWide)
     };
     // one (tap, chunk) step; the A fragments of the following step (nt, nc) are requested in between the MFMAs
     auto step = [&](int t, int nt, int nc, bool live) {
@@ -816,16 +843,23 @@ __global__ __launch_bounds__(256, 2) void igemm_tb_kernel(const IgemmParams p) {
         }
     }
 
-    // ---- epilogue (same as igemm_kernel)
+    // ---- epilogue (same as igemm_body: transposed blocks, 16-byte vectors)
     if (p.splitk > 1) {
         float* slab = a.ws + (long long)blockIdx.z * p.M * a.N;
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
-            const int n = n0 + l31;
+            const int m = m0 + (wave * WM + i) * 32 + l31;
+            if (m < p.M) {
+                float* row = slab + (long long)m * a.N + (n0 + 4 * kh);
+                const bool through = p.fin != 0;
+                if ((p.wide & 2) && !through) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + (wave * WM + i) * 32 + mfma32_row(e, lane);
-                if (m < p.M) slab_store(&slab[(long long)m * a.N + n], acc[i][e], p.fin != 0);
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        *reinterpret_cast<f32x4*>(row + 8 * g4) = f32x4{acc[i][4 * g4], acc[i][4 * g4 + 1], acc[i][4 * g4 + 2], acc[i][4 * g4 + 3]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) slab_store(row + 8 * (e >> 2) + (e & 3), acc[i][e], through);
+                }
             }
         }
         if constexpr (WM == 1) {      // (the two-block form has no registers to spare: fill_params keeps fin off for it)
@@ -836,7 +870,24 @@ __global__ __launch_bounds__(256, 2) void igemm_tb_kernel(const IgemmParams p) {
     const ScalePair sp = load_scale(a);
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
-        epilogue16<(WM > 1) ? 4 : 8>(p, acc[i], m0 + (wave * WM + i) * 32, lane, n0 + l31, sp);
+        const int mrow0 = m0 + (wave * WM + i) * 32;
+        if (mrow0 + l31 < p.M) {
+            EpiWide wad;
+            wad.init(p, mrow0, lane, n0, sp);
+            if (p.wide & 1) {
+                f32x4 bias4[4];
+                epiw_bias(a, wad.ch, bias4);
+                EpiWideOps weo;
+                epiw_load(p, wad, weo);
+                epiw_store(p, acc[i], wad, bias4, weo);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int n = wad.ch + 8 * (e >> 2) + (e & 3);
+                    a.out[wad.pix * a.out_ld + n] = epilogue_value(a, acc[i][e], wad.sc, a.bias ? a.bias[n] : 0.f, wad.pix, n);
+                }
+            }
+        }
     }
 }
 
@@ -1399,6 +1450,7 @@ int fill_params(const mtd_conv_args* a, const Plan& pl, IgemmParams& p) {
     p.xcd_map = env_xcd;
     static const int env_nt = [] { const char* e = getenv("MTD_IGEMM_NT"); return e ? atoi(e) : 0; }();
     p.nt_store = env_nt;
+    p.wide = (wide_epilogue_ok(*a) ? 1 : 0) | ((pl.splitk > 1 && aligned16(a->ws)) ? 2 : 0);
     p.fin = 0;
     if (pl.splitk > 1) {
         size_t need = (size_t)pl.splitk * (size_t)p.M * a->N * sizeof(float);
