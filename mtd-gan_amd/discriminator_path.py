@@ -9,6 +9,7 @@ weight_orig in place and scale their accumulators by 1/sigma; the weight gradien
  is one batched mtd_sn_grad per backward.  NHWC fp32 throughout.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -16,6 +17,7 @@ from . import _lib
 from . import kernels as K
 from .kernels import ACT_LRELU, ACT_NONE
 
+PS_FUSED = os.environ.get("MTD_NO_PS_FUSE", "0") != "1"     # r_up{l}: conv1x1 + PixelShuffle as four strided-output classes in one grid
 CH = [64, 128, 256, 512, 512, 512]                    # trunk channels per level (out_channels = 64)
 DEC = [(1024, 512), (1024, 512), (1024, 256), (512, 128), (256, 64), (128, 1)]   # (cat channels, out) per decoder level
 RUP = [(512, 512), (512, 512), (512, 512), (256, 256), (128, 128), (64, 64)]      # r_up{l}: cin -> cout' (conv to 4*cout')
@@ -233,14 +235,23 @@ def disc_forward(P, x, train, drop_mask, need_rec, save, sn=None, sn2=None, pair
         t, r = tp.bot, 1
         for lvl in range(1, 7):
             cin_up, cup = RUP[lvl - 1]
-            up = K.empty_nhwc(B, r, r, 4 * cup, x)
-            K.conv(t, P[f"r_up{lvl}.upsample.0.weight"], K.geom_fwd(B, r, r, 1, 1, 0), 4 * cup, cin_up, cin_up, 1, up,
-                   bias=P[f"r_up{lvl}.upsample.0.bias"])
-            r *= 2
             skip = tp.xs[7 - lvl]
             ccat, co = DEC[lvl - 1]
-            cat = K.empty_nhwc(B, r, r, ccat, x)
-            K.pixel_shuffle2_fwd(up, cat[..., :cup])
+            cat = K.empty_nhwc(B, 2 * r, 2 * r, ccat, x)
+            # conv1x1 (C -> 4C') + PixelShuffle(2) without the intermediate tensor: the four sub-pixel classes (i, j) are four
+            # 1x1 convs over output channels c*4 + 2i + j (weight rows 4 apart) that write every other pixel of the
+            # concatenated buffer -- one grid (conv_multi), like the parity classes of the stride-2 data gradients
+            wu = P[f"r_up{lvl}.upsample.0.weight"]
+            if PS_FUSED:
+                bu = K.regrouped_bias(P[f"r_up{lvl}.upsample.0.bias"], 4)
+                wq = wu.detach().view(cup, 4, cin_up)
+                K.conv_multi([((t, wq[:, q], K.geom_pixel_shuffle2(B, r, r, q >> 1, q & 1), cup, cin_up, 4 * cin_up, 1, cat[..., :cup]),
+                               dict(bias=bu[q * cup:(q + 1) * cup])) for q in range(4)])
+            else:
+                up = K.empty_nhwc(B, r, r, 4 * cup, x)
+                K.conv(t, wu, K.geom_fwd(B, r, r, 1, 1, 0), 4 * cup, cin_up, cin_up, 1, up, bias=P[f"r_up{lvl}.upsample.0.bias"])
+                K.pixel_shuffle2_fwd(up, cat[..., :cup])
+            r *= 2
             K.copy_channels(skip, cat[..., cup:])
             g3 = K.geom_fwd(B, r, r, 3, 1, 1)
             o1 = K.empty_nhwc(B, r, r, co, x)

@@ -83,6 +83,19 @@ def packed_weight_view(w, N, Cc, w_sn, w_sc):
         hit = (dst, w)          # keep the source alive so its data_ptr cannot be recycled under the same key
         _remember(_pack_cache, (w.data_ptr(), N, Cc, w_sn, w_sc), key, hit)
     return hit[0], Cc, 1, N * Cc
+
+
+def regrouped_bias(b, groups):
+    """out[q * n + c] = b[c * groups + q]: the bias of a conv whose output channels are taken group by group (PixelShuffle
+    classes, geom_pixel_shuffle2).  Cached like the packed weight views (dropped by weights_changed)."""
+    key = (b.data_ptr(), b._version, _pack_epoch, "bias groups", groups)
+    hit = _pack_cache.get(key)
+    if hit is None:
+        hit = (b.detach().view(-1, groups).t().contiguous().view(-1), b)
+        _remember(_pack_cache, (b.data_ptr(), "bias groups", groups), key, hit)
+    return hit[0]
+
+
 STATS = {"table_hit": 0, "table_miss": 0, "zero_copy_reads": 0}
 # bench.py: while this is a dict, the helpers below add the dense algorithmic flop count of every launch they make
 # (2*M*N*C*taps for convolutions and weight gradients, 2*64*64 per frequency for the spectral mix, 2.5*N*log2(N) per
@@ -232,6 +245,12 @@ def geom_dgrad_s2(B, H, W, py, px):
     ky0, kx0 = (py + 1) & 1, (px + 1) & 1
     oy, ox = (py + 1 - ky0) // 2, (px + 1 - kx0) // 2
     return Geom(B, H // 2, W // 2, H // 2, W // 2, 1, 1, oy, ox, -1, -1, 2, 2, 4, ky0, kx0, 2, 2, H, W, 2, 2, py, px)
+
+
+def geom_pixel_shuffle2(B, H, W, i, j):
+    """1x1 conv over a (H, W) map whose result lands at pixel (2y + i, 2x + j) of a (2H, 2W) map: class (i, j) of
+    conv1x1 + PixelShuffle(2) (networks.py:166-175) written in place, with the output channels c * 4 + 2 i + j as its N."""
+    return Geom(B, H, W, H, W, 1, 1, 0, 0, 1, 1, 1, 1, 1, 0, 0, 1, 1, 2 * H, 2 * W, 2, 2, i, j)
 
 
 def _ptr(t):
