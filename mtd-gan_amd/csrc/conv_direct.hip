@@ -531,6 +531,54 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(const WideParams p) {
         }
         __syncthreads();
         const float* wrow = wide + (long long)mb * wide_ld + VEC * cl;
+        if (p.T == 9 && 4 * PPW <= GW) {
+            // The nine tap offsets inside the tile are launch constants and a lane's pixels advance by a fixed stride: no
+            // division, no per-tap branch or address arithmetic in the loop (the general form below is ~150 instructions
+            // per 16-byte load of the wide tensor -- 28 us for 33 MB; this one ~55).  Same pixel and tap order per lane.
+            int offs[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) offs[t] = p.ddy[t] * TW2 + p.ddx[t];
+            const int step = 4 * PPW;
+            int i = wave * PPW + pg;
+            int ry = i / GW, rx = i - ry * GW;
+            constexpr int U = 4;                    // wide-tensor loads in flight per lane (one at a time: 1.4 TB/s, latency-bound)
+            const int n = me - mb;
+            while (i < n) {
+                f32x4 q4[U];
+                float w1[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int iu = i + u * step;
+                    const long long off = (long long)(iu < n ? iu : i) * wide_ld;
+                    if (VEC == 4) q4[u] = *reinterpret_cast<const f32x4*>(wrow + off);
+                    else w1[u] = wrow[off];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (i < n) {
+                        float wv[VEC];
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) wv[j] = (VEC == 4) ? q4[u][j] : w1[u];
+                        const float* tc = tile + (ry + 1) * TW2 + rx + 1;
+                        if (!n1) {
+#pragma unroll
+                            for (int j = 0; j < VEC; ++j) bacc[j] += wv[j];
+                        } else if (cl == 0) {
+                            bacc[0] += tc[0];
+                        }
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) {
+                            const float s = tc[offs[t]];
+#pragma unroll
+                            for (int j = 0; j < VEC; ++j) acc[j][t] = fmaf(s, wv[j], acc[j][t]);
+                        }
+                    }
+                    i += step;
+                    rx += step;
+                    if (rx >= GW) { rx -= GW; ++ry; }
+                }
+            }
+        } else
         for (int i = wave * PPW + pg; i < me - mb; i += 4 * PPW) {
             const int ry = i / GW, rx = i - ry * GW;
             float wv[VEC];
@@ -654,7 +702,11 @@ bool wide_plan(const mtd_wgrad_args& a, WideParams& p) {
         if ((ld % 4) || !aligned16(wide)) return false;
     }
     if ((long long)(p.T * p.V + p.V) * 4 * 4 > 48 * 1024) return false;
-    long long ppb = (p.Mw + 2047) / 2048;      // many short workgroups: 8 per CU hide the latency of the one wide load per pixel
+    // ~512 workgroups (tools/wide_probe.py, MTD_WIDE_WGS = 256 / 512 / 1024 / 2048: 25.4 / 22.9 / 23.1 / 31.5 us for conv11 at 32
+    // images, main kernel + slab sum): with four wide loads in flight per lane a workgroup of four image rows amortises
+    // its tile load and its cross-wave sum; the 2048 one-row workgroups of the first version were all prologue and epilogue
+    static const int env_wgs = [] { const char* e = getenv("MTD_WIDE_WGS"); return e ? atoi(e) : 512; }();
+    long long ppb = (p.Mw + env_wgs - 1) / env_wgs;
     const long long min_ppb = 4ll * (64 / p.CL) * 4;
     if (ppb < min_ppb) ppb = min_ppb;
     p.ppb = (int)ppb;

@@ -120,6 +120,25 @@ def test_all_taps_weight_gradient_forced(hip_lib, case):
         L.mtd_conv_wgrad_override(-1, -1)
 
 
+def test_conv1x1_pixel_shuffle_in_place(hip_lib):
+    """conv1x1 (C -> 4C') + PixelShuffle(2) (networks.py:166-175) as four strided-output classes in one grid, written
+    into the first C' channels of a wider (concatenated) buffer, against F.pixel_shuffle(F.conv2d)."""
+    from mtd_gan_amd import kernels as K
+    for (B, Ci, Cu, r) in [(3, 64, 32, 4), (2, 512, 128, 1), (2, 128, 64, 8)]:
+        x = rnd(B, Ci, r, r, seed=51)
+        w = rnd(4 * Cu, Ci, 1, 1, seed=52, scale=Ci ** -0.5)
+        b = rnd(4 * Cu, seed=53)
+        ref = F.pixel_shuffle(F.conv2d(x, w, b), 2)
+        cat = torch.full((B, 2 * r, 2 * r, Cu + 32), 7.0, device="cuda")
+        wd, bd = w.cuda(), b.cuda()
+        bu = K.regrouped_bias(bd, 4)
+        wq = wd.view(Cu, 4, Ci)
+        K.conv_multi([((nhwc(x), wq[:, q], K.geom_pixel_shuffle2(B, r, r, q >> 1, q & 1), Cu, Ci, 4 * Ci, 1, cat[..., :Cu]),
+                       dict(bias=bu[q * Cu:(q + 1) * Cu])) for q in range(4)])
+        assert relerr(nchw(cat[..., :Cu]), ref) < TOL, (B, Ci, Cu, r)
+        assert bool((cat[..., Cu:] == 7.0).all())
+
+
 def test_strided_wgrad_into_transposed_view(hip_lib):
     """The all-taps weight gradient of a 4x4 stride-2 layer writing an IOHW view (ConvTranspose2d-style parameter: channel
     stride != 16, so the single-split launch scatters value by value instead of copying packed rows), with accumulation."""
@@ -216,7 +235,7 @@ def test_linear_as_1x1(hip_lib):
 
 def test_upsample_and_pixel_shuffle(hip_lib):
     from mtd_gan_amd import kernels as K
-    for (B, C, H, W) in [(2, 64, 1, 1), (2, 32, 2, 2), (2, 16, 8, 8), (1, 8, 5, 3)]:
+    for (B, C, H, W) in [(2, 64, 1, 1), (2, 32, 2, 2), (2, 16, 8, 8), (1, 8, 5, 3), (1, 6, 3, 4)]:     # (6 channels: the scalar kernels)
         x = rnd(B, C, H, W, seed=31).requires_grad_(True)
         ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
         cot = rnd(*ref.shape, seed=32)
@@ -235,6 +254,15 @@ def test_upsample_and_pixel_shuffle(hip_lib):
     back = torch.empty(2, 4, 4, 64, device="cuda")
     K.pixel_shuffle2_bwd(out, back)
     assert torch.equal(nchw(back), x)
+    # the value-by-value kernels (source rows that are not 16-byte aligned)
+    wide = torch.zeros(2, 4, 4, 65, device="cuda")
+    wide[..., :64] = nhwc(x)
+    out2 = torch.empty(2, 8, 8, 16, device="cuda")
+    K.pixel_shuffle2_fwd(wide[..., :64], out2)
+    assert torch.equal(nchw(out2), ref)
+    back2 = torch.zeros(2, 4, 4, 65, device="cuda")
+    K.pixel_shuffle2_bwd(out2, back2[..., :64])
+    assert torch.equal(nchw(back2[..., :64]), x)
     # strided copy into a concat buffer
     cat = torch.zeros(2, 8, 8, 48, device="cuda")
     K.copy_channels(out, cat[..., 32:48])
