@@ -142,21 +142,30 @@ __device__ __forceinline__ int mask_word(int k2, int kh, int o) {
 }
 __device__ __forceinline__ int mask_bit(int kh, int o) { return (o & 31) + 32 * (((kh & 31) >> 2) & 1); }
 
-__global__ __launch_bounds__(256, 3) void spec_mix_fwd4_kernel(const float* __restrict__ R, const float* __restrict__ w2t,
+// COLS: kw columns per workgroup (2: 256 threads, a pair; 1: 128 threads, one column of a pair -- twice the units in flight)
+template <int COLS>
+__global__ __launch_bounds__(128 * COLS, 3) void spec_mix_fwd4_kernel(const float* __restrict__ R, const float* __restrict__ w2t,
                                                                const float* __restrict__ b2, float* __restrict__ T,
                                                                float* __restrict__ S_save, unsigned long long* __restrict__ zmask) {
     // ONE LDS image, used in turn as the DMA target (rows of 64 floats), the MFMA operand image (rows of XLD4) and the
     // staging area of the result rows (64 again): 33 KB per workgroup, so THREE workgroups per CU = 768 slots for the 544
     // units of a 32-patch launch.  With an input and an operand buffer (66 KB, two per CU, 512 slots) the last 32 units
     // ran as a second round on an empty chip: 26 us per launch for 13 us of work per unit.
-    __shared__ __attribute__((aligned(1024))) float Xs[2 * 64 * XLD4];
+    __shared__ __attribute__((aligned(1024))) float Xs[COLS * 64 * XLD4];
     float* const Xin = Xs;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y, unit = b * gridDim.x + blockIdx.x;
-    const bool two = (2 * blockIdx.x + 1) < NKW;                  // workgroup-uniform: does the second column exist
-    const long long cb0 = ((long long)(b * NKW + 2 * blockIdx.x) * 64) * 64;
-    dma_columns(R + cb0, Xin, wave, lane, two);
+    const int b = blockIdx.y;
+    const int kw0 = COLS == 2 ? 2 * (int)blockIdx.x : (int)blockIdx.x;      // first (only) column of this workgroup
+    const int unit = b * 17 + (kw0 >> 1);                         // the pair the sign masks are filed under
+    const int kpos = COLS == 2 ? 0 : (kw0 & 1);                   // position of column kwl = 0 inside its pair
+    const bool two = COLS == 2 && (kw0 + 1) < NKW;                // workgroup-uniform: does the second column exist
+    const long long cb0 = ((long long)(b * NKW + kw0) * 64) * 64;
+    {
+        const int n = two ? 32 : 16;
+        for (int i = wave; i < n; i += 2 * COLS)
+            __builtin_amdgcn_global_load_lds(R + cb0 + i * 256 + lane * 4, (lds_float4k*)(Xin + i * 256), 16, 0, 0);
+    }
     // transform lanes: f = transform (column kwl, channel c), j = position in the quad
     const int f = tid >> 2, j = tid & 3, kwl = f >> 5, c = f & 31;
     const bool valid = kwl == 0 || two;
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(256, 3) void spec_mix_fwd4_kernel(const float* __re
                 const float z = acc[jj][e] + bo;
                 if (zmask) {
                     const unsigned long long bm = __ballot(z > 0.f);
-                    if (lane == 0) zmask[(long long)unit * 128 + ((k2 * 2 + ih) * 2 + jj) * 16 + e] = bm;
+                    if (lane == 0) zmask[(long long)unit * 128 + (((k2 + kpos) * 2 + ih) * 2 + jj) * 16 + e] = bm;
                 }
                 Xs[(k2 * 64 + kh) * XLD4 + o] = z > 0.f ? z : 0.f;
             }
@@ -416,8 +425,14 @@ extern "C" int mtd_spec_mix_fwd4(const float* R, const float* w2t, const float* 
                                  void* stream) {
     if (!R || !w2t || !b2 || !T || B <= 0) return MTD_EINVAL;
     if (!aligned16(R)) return MTD_EALIGN;
-    hipLaunchKernelGGL(spec_mix_fwd4_kernel, dim3(17, B), dim3(256), 0, (hipStream_t)stream, R, w2t, b2, T, S_save,
-                       (unsigned long long*)zmask);
+    // one column per workgroup (1056 + B units of 128 threads: four per CU in flight) or a pair (544 of 256); MTD_SPECMIX_COLS
+    static const int env_cols = [] { const char* e = getenv("MTD_SPECMIX_COLS"); return e ? atoi(e) : 1; }();
+    if (env_cols == 2)
+        hipLaunchKernelGGL((spec_mix_fwd4_kernel<2>), dim3(17, B), dim3(256), 0, (hipStream_t)stream, R, w2t, b2, T, S_save,
+                           (unsigned long long*)zmask);
+    else
+        hipLaunchKernelGGL((spec_mix_fwd4_kernel<1>), dim3(NKW, B), dim3(128), 0, (hipStream_t)stream, R, w2t, b2, T, S_save,
+                           (unsigned long long*)zmask);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }
