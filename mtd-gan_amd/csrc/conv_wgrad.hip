@@ -426,6 +426,76 @@ __global__ __launch_bounds__(256, 2) void wgrad_row_rfft_kernel(const WgradParam
 }
 
 
+// Epilogue of the kernels whose wave ty holds the four taps (ty, 0..3) of a 4x4 filter for one 32 x 32 (n, c) tile: slab, or
+// -- single pixel split -- the gradient view itself, through LDS as [n][c][16] rows of 2 KB where the view is packed.
+// Ls: >= 64 KB of LDS nobody reads any more (the caller has passed a barrier).
+// NP: passes of the packed form (1: all 32 n rows at once, 64 KB; 2: 16 rows each, 32 KB).
+template <int NP>
+__device__ __forceinline__ void taps_epilogue(const WgradParams& p, f32x16 (&acc)[4], float bsum, float* Ls, int ty, int n0, int c0,
+                                              bool do_bias) {
+    constexpr int TW = 4, T = 16;
+    const mtd_wgrad_args& a = p.a;
+    const mtd_geom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31;
+    const bool direct = (p.nslab == 1);
+    const bool packed = direct && a.w_sc == T && (a.w_sn % 4) == 0 && ((((uintptr_t)a.dw) & 15) == 0) && g.ky0 == 0 && g.kx0 == 0 &&
+                        g.ky_step == 1 && g.kx_step == 1 && g.KW == TW;
+    if (packed) {
+        // [n][c][ty][tx] in LDS (a lane's four taps of a filter row are 16 contiguous bytes), then straight copies of 2 KB rows.
+        // Accumulator registers 16 h / NP .. hold the n rows 32 h / NP .. of the tile (mfma32_row), so a pass is a register range.
+        constexpr int RP = 32 / NP, EP = 16 / NP;
+#pragma unroll
+        for (int h = 0; h < NP; ++h) {
+            if (h > 0) __syncthreads();
+#pragma unroll
+            for (int e = h * EP; e < (h + 1) * EP; ++e) {
+                const f32x4 v = {acc[0][e], acc[1][e], acc[2][e], acc[3][e]};
+                *reinterpret_cast<f32x4*>(Ls + ((mfma32_row(e, lane) - h * RP) * 32 + l31) * T + ty * TW) = v;
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int i = tid; i < RP * 32 * T / 4; i += 256) {
+                const int nl = h * RP + (i >> 7), rem = i & 127;
+                float* dst = a.dw + (long long)(n0 + nl) * a.w_sn + (long long)c0 * T + 4 * rem;
+                f32x4 v = *reinterpret_cast<const f32x4*>(Ls + 4 * i);
+                if (a.accumulate & 1) v += *reinterpret_cast<const f32x4*>(dst);
+                *reinterpret_cast<f32x4*>(dst) = v;
+            }
+        }
+    } else {
+        float* slab = a.ws + (long long)blockIdx.x * p.slab_stride;
+#pragma unroll
+        for (int tx = 0; tx < TW; ++tx) {
+            const int t = ty * TW + tx;
+            const int kidx = (g.ky0 + ty * g.ky_step) * g.KW + (g.kx0 + tx * g.kx_step);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + mfma32_row(e, lane), cc = c0 + l31;
+                if (direct) {
+                    float* dst = a.dw + (long long)n * a.w_sn + (long long)cc * a.w_sc + kidx;
+                    *dst = (a.accumulate & 1) ? (*dst + acc[tx][e]) : acc[tx][e];
+                } else {
+                    slab[((long long)t * a.N + n) * a.C + cc] = acc[tx][e];
+                }
+            }
+        }
+    }
+    if (do_bias) {
+        __syncthreads();
+        if (ty == 0) Ls[lane] = bsum;
+        __syncthreads();
+        if (tid < 32) {
+            const float s2 = Ls[tid] + Ls[tid + 32];
+            if (direct) {
+                float* dst = a.db + n0 + tid;
+                *dst = (a.accumulate & 2) ? (*dst + s2) : s2;
+            } else {
+                (a.ws + (long long)blockIdx.x * p.slab_stride)[(long long)p.T * a.N * a.C + n0 + tid] = s2;
+            }
+        }
+    }
+}
+
 // ---- all-taps variant: 4x4 filters (the strided down convs of the discriminator trunk) --------------------------------
 // wgrad_kernel gives every group of 1-3 taps a workgroup of its own (grid.z): each re-reads the whole cotangent and its
 // own gather of the input -- 16 taps = 16 x (P + Q/4) through the L2s, 4.7 TB/s of fabric traffic at 72-76 TFLOP/s for
@@ -527,58 +597,156 @@ __global__ __launch_bounds__(256, 1) void wgrad_taps_kernel(const WgradParams p)
         }
     }
 
-    // ---- epilogue
-    const bool direct = (p.nslab == 1);
-    const bool packed = direct && a.w_sc == T && (a.w_sn % 4) == 0 && ((((uintptr_t)a.dw) & 15) == 0) && g.ky0 == 0 && g.kx0 == 0 &&
-                        g.ky_step == 1 && g.kx_step == 1 && g.KW == TW;
-    if (packed) {
-        // [n][c][ty][tx] in LDS (a lane's four taps of a filter row are 16 contiguous bytes), then straight copies of 2 KB rows
+    taps_epilogue<1>(p, acc, bsum, Ls, ty, n0, c0, do_bias);
+}
+
+// ---- halo-window variant: 4x4 / stride 2 / pad 1 on maps whose output side is a multiple of 8 (down1..3) -------------
+// The LDS-staged kernel above runs these layers with one workgroup per tap (grid.z = 16): every tap re-reads the cotangent
+// and its own gather of the input through the L2s -- 268 MB per launch for 42 MB of operands, 57 us at 75 TFLOP/s.  The
+// all-taps kernel reads each operand dword straight into registers, 80 loads per 64 MFMAs and wave: 57-67 TFLOP/s.
+// Here a workgroup owns a 32 x 32 (n, c) tile for all 16 taps (wave ty = filter row ty, as in the all-taps kernel) and
+// walks 8 x 8 blocks of output pixels: the block's cotangent tile [64 px][32 n] and its 18 x 18 input window [324 px][32 c]
+// arrive by LDS-DMA (49 one-KB instructions over the four waves, out-of-image pixels as out-of-range offsets = zeros),
+// double-buffered, so the next block is in flight under this block's MFMAs and no operand passes through a register on
+// its way in.  Every tap of every pixel is then an immediate offset into the window: per block and wave 32 + 128 LDS
+// dword reads (lane = channel: 128 contiguous bytes per half-wave, conflict-free) for 128 MFMAs.  The input is read
+// (18/16)^2 = 1.27 times, the cotangent once.
+constexpr int S2_WPX = 18 * 18;                 // window pixels
+constexpr int S2_QI = (S2_WPX + 7) / 8;         // 41 DMA instructions (8 pixels x 128 bytes each) for the window
+constexpr int S2_PI = 8;                        // ... and 8 for the 64 cotangent pixels
+constexpr int S2_NI = 52;                       // padded to 13 per wave (the rest land in a dummy KB): one vmcnt value for all
+
+// DB: double-buffered, one workgroup per CU (100 KB of LDS); !DB: one buffer set, two workgroups per CU take turns
+template <bool DB>
+__global__ __launch_bounds__(256, DB ? 1 : 2) void wgrad_s2_kernel(const WgradParams p) {
+    constexpr int TW = 4;
+    typedef __attribute__((address_space(3))) float lds_f;
+    // two buffer sets as SEPARATE LDS objects, the block loop unrolled by two: the compiler's wait insertion knows which
+    // object a pending LDS-DMA writes, and with one array indexed by `buf` it put a vmcnt(0) -- a wait for the NEXT block's
+    // loads too -- in front of every block's reads
+    __shared__ __attribute__((aligned(1024))) float Qw0[S2_QI * 256];
+    __shared__ __attribute__((aligned(1024))) float Qw1[S2_QI * 256];
+    __shared__ __attribute__((aligned(1024))) float Pt0[S2_PI * 256];
+    __shared__ __attribute__((aligned(1024))) float Pt1[S2_PI * 256];
+    __shared__ __attribute__((aligned(1024))) float dummy[256];
+    const mtd_wgrad_args& a = p.a;
+    const mtd_geom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int ntile = blockIdx.y / p.nCt, ctile = blockIdx.y % p.nCt;
+    const int n0 = ntile * 32, c0 = ctile * 32;
+    const bool do_bias = (a.db != nullptr) && ctile == 0;
+    const bool bias_wave = do_bias && ty == 0;
+    const int nbx = g.OW >> 3, nby = g.OH >> 3;
+    const int NB = g.B * nby * nbx;
+    const int blk0 = blockIdx.x * p.ppw;                // ppw: 8 x 8 pixel blocks per WORKGROUP here
+    const int blk1 = min(NB, blk0 + p.ppw);
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p), (short)0, (int)p.p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.q), (short)0, (int)p.q_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int rsub = lane >> 3, piece = lane & 7;
+
+    auto stage = [&](int blk, float* Qd, float* Pd) {
+        const int bx = blk % nbx;
+        const int t2 = blk / nbx;
+        const int by = t2 % nby, b = t2 / nby;
+        const bool live = blk < blk1;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const f32x4 v = {acc[0][e], acc[1][e], acc[2][e], acc[3][e]};
-            *reinterpret_cast<f32x4*>(Ls + (mfma32_row(e, lane) * 32 + l31) * T + ty * TW) = v;
+        for (int k = 0; k < S2_NI / 4; ++k) {
+            const int i = ty + 4 * k;                   // instruction index, wave-uniform
+            if (i < S2_QI) {
+                const int wp = 8 * i + rsub;
+                const int wy = wp / 18, wx = wp - wy * 18;
+                const int iy = 16 * by - 1 + wy, ix = 16 * bx - 1 + wx;
+                const bool ok = live & (wp < S2_WPX) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
+                const unsigned voff = ok ? (unsigned)(((((long long)b * g.IH + iy) * g.IW + ix) * a.q_ld + c0 + piece * 4) * 4) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (lds_f*)(Qd + i * 256), 16, voff, 0, 0, 0);
+            } else if (i < S2_QI + S2_PI) {
+                const int r = i - S2_QI;                // output row of the block; rsub = column
+                const long long m = ((long long)b * g.OH + 8 * by + r) * g.OW + 8 * bx + rsub;
+                const unsigned voff = live ? (unsigned)((m * a.p_ld + n0 + piece * 4) * 4) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (lds_f*)(Pd + r * 256), 16, voff, 0, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (lds_f*)&dummy[0], 16, OOB, 0, 0, 0);
+            }
         }
-        __syncthreads();
-#pragma unroll 4
-        for (int i = tid; i < 32 * 32 * T / 4; i += 256) {
-            const int nl = i >> 7, rem = i & 127;
-            float* dst = a.dw + (long long)(n0 + nl) * a.w_sn + (long long)c0 * T + 4 * rem;
-            f32x4 v = *reinterpret_cast<const f32x4*>(Ls + 4 * i);
-            if (a.accumulate & 1) v += *reinterpret_cast<const f32x4*>(dst);
-            *reinterpret_cast<f32x4*>(dst) = v;
+    };
+
+    f32x16 acc[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    float bsum = 0.f;
+
+    // one block from LDS: k-step kk = output pixels (2 kk, 2 kk + 1) of the block = row kk >> 2, columns 2 (kk & 3) + kh.
+    // The operands of the NEXT two k-steps (2 + 8 dword reads) are issued before the eight MFMAs of the current two: read on
+    // demand (the compiler's order) every pair of MFMAs waited a full LDS round trip -- 55 % of the MFMA rate.
+    auto compute = [&](const float* Pbuf, const float* Qbuf) {
+        const float* Pb = Pbuf + l31 + 32 * kh;
+        const float* Qb = Qbuf + (ty * 18 + 2 * kh) * 32 + l31;
+        float pa[2][2], qa[2][2][TW];
+        auto load_group = [&](int gi, int slot) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int kk = 2 * gi + u;
+                pa[slot][u] = Pb[64 * kk];
+#pragma unroll
+                for (int tx = 0; tx < TW; ++tx) qa[slot][u][tx] = Qb[((2 * (kk >> 2)) * 18 + 4 * (kk & 3) + tx) * 32];
+            }
+        };
+        load_group(0, 0);
+#pragma unroll
+        for (int gi = 0; gi < 16; ++gi) {
+            if (gi + 1 < 16) load_group(gi + 1, (gi + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (bias_wave) bsum += pa[gi & 1][u];
+#pragma unroll
+                for (int tx = 0; tx < TW; ++tx) acc[tx] = mfma32(pa[gi & 1][u], qa[gi & 1][u][tx], acc[tx]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // Bare s_barrier, not __syncthreads(): the latter's workgroup-scope fence makes the compiler wait for EVERY outstanding
+    // LDS-DMA (vmcnt(0): they are LDS writes) -- the next block's too, which is the overlap this loop exists for.  What the
+    // barriers need is stated by hand: before the first, this wave's DMA of the CURRENT block has landed (13 newer ones may
+    // be in flight); before the second, its LDS reads have returned (the MFMAs consumed them).
+    if constexpr (!DB) {
+        for (int blk = blk0; blk < blk1; ++blk) {
+            stage(blk, Qw0, Pt0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            compute(Pt0, Qw0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
     } else {
-        float* slab = a.ws + (long long)blockIdx.x * p.slab_stride;
-#pragma unroll
-        for (int tx = 0; tx < TW; ++tx) {
-            const int t = ty * TW + tx;
-            const int kidx = (g.ky0 + ty * g.ky_step) * g.KW + (g.kx0 + tx * g.kx_step);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int n = n0 + mfma32_row(e, lane), cc = c0 + l31;
-                if (direct) {
-                    float* dst = a.dw + (long long)n * a.w_sn + (long long)cc * a.w_sc + kidx;
-                    *dst = (a.accumulate & 1) ? (*dst + acc[tx][e]) : acc[tx][e];
-                } else {
-                    slab[((long long)t * a.N + n) * a.C + cc] = acc[tx][e];
-                }
-            }
+    stage(blk0, Qw0, Pt0);
+    for (int blk = blk0; blk < blk1; blk += 2) {
+        stage(blk + 1, Qw1, Pt1);                       // (past the range: zeros)
+        asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        compute(Pt0, Qw0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                   // every read of this buffer is done before it is staged again
+        if (blk + 1 < blk1) {
+            stage(blk + 2, Qw0, Pt0);
+            asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            compute(Pt1, Qw1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
     }
-    if (do_bias) {
-        __syncthreads();
-        if (ty == 0) Ls[lane] = bsum;
-        __syncthreads();
-        if (tid < 32) {
-            const float s2 = Ls[tid] + Ls[tid + 32];
-            if (direct) {
-                float* dst = a.db + n0 + tid;
-                *dst = (a.accumulate & 2) ? (*dst + s2) : s2;
-            } else {
-                (a.ws + (long long)blockIdx.x * p.slab_stride)[(long long)p.T * a.N * a.C + n0 + tid] = s2;
-            }
-        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the trailing (all out-of-range) stage
+    __syncthreads();
+    static_assert(S2_QI * 256 >= 16 * 32 * 16, "epilogue staging: 16 n rows per pass fit one window buffer");
+    taps_epilogue<2>(p, acc, bsum, Qw0, ty, n0, c0, do_bias);
 }
 
 // ---- block-window variant -------------------------------------------------------------------------
@@ -911,6 +1079,26 @@ WPlan make_wplan(const mtd_wgrad_args& a) {
     else if (T <= 4) pl.cfg = 1;
     else if (T <= 9) pl.cfg = (M <= 2048) ? 4 : 0;              // few pixels, many tiles: 3 taps per wave, no pixel split
     else pl.cfg = (M >= 2048 && a.N % 64 == 0 && a.C % 64 == 0) ? 2 : 4;
+    static const int env_s2 = [] { const char* e = getenv("MTD_WGRAD_S2"); return e ? atoi(e) : 1; }();
+    if (a.g.TH == 4 && a.g.TW == 4 && a.g.in_sy == 2 && a.g.in_sx == 2 && a.g.off_y == -1 && a.g.off_x == -1 && a.g.tap_dy == 1 &&
+        a.g.tap_dx == 1 && (a.g.OH % 8) == 0 && (a.g.OW % 8) == 0 && ((env_s2 && g_wforce_cfg == -1) || g_wforce_cfg == 15)) {
+        // halo-window kernel: 8 x 8 pixel blocks; ~512 workgroups of the single-buffer form, two per CU (51 KB of LDS each), which take
+        // turns on the matrix cores: 46.6-49.6 us per layer against 51-54 for 256 double-buffered workgroups and 57 for wgrad_kernel<2,2,1>
+        pl.cfg = 15;
+        pl.WN = 1; pl.WC = 1; pl.TG = T; pl.ntg = 1; pl.nw = 4;
+        const long long tiles = (long long)(a.N / 32) * (a.C / 32);
+        const long long NB = (long long)a.g.B * (a.g.OH / 8) * (a.g.OW / 8);
+        static const int env_s2wgs = [] { const char* e = getenv("MTD_WGRAD_S2_WGS"); return e ? atoi(e) : 512; }();
+        long long ns = (env_s2wgs + tiles - 1) / tiles;
+        if (g_wforce_split > 0) ns = g_wforce_split;
+        if (ns > NB) ns = NB;
+        if (ns < 1) ns = 1;
+        const long long bpw = (NB + ns - 1) / ns;
+        ns = (NB + bpw - 1) / bpw;
+        pl.ppw = (int)bpw;
+        pl.nsplit = (int)ns;
+        return pl;
+    }
     static const int env_taps = [] { const char* e = getenv("MTD_WGRAD_TAPS"); return e ? atoi(e) : 1; }();
     static const int env_taps_maxm = [] { const char* e = getenv("MTD_WGRAD_TAPS_MAXM"); return e ? atoi(e) : 128; }();
     if (a.g.TH == 4 && a.g.TW == 4 && ((env_taps && g_wforce_cfg == -1 && M <= env_taps_maxm) || g_wforce_cfg == 13)) {
@@ -1112,6 +1300,12 @@ static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, 
                      else MTD_LAUNCH((wgrad_blk_kernel<2, 4>), grid, dim3(256), 0, s, p);
                      break;
             case 13: MTD_LAUNCH(wgrad_taps_kernel, grid, dim3(256), 0, s, p); break;
+            case 15: {
+                static const int env_db = [] { const char* e = getenv("MTD_WGRAD_S2_DB"); return e ? atoi(e) : 0; }();
+                if (env_db) MTD_LAUNCH((wgrad_s2_kernel<true>), grid, dim3(256), 0, s, p);
+                else MTD_LAUNCH((wgrad_s2_kernel<false>), grid, dim3(256), 0, s, p);
+                break;
+            }
             case 5: MTD_LAUNCH((wgrad_kernel<1, 1, 1>), grid, dim3(256), 0, s, p); break;
             default: MTD_LAUNCH((wgrad_kernel<2, 2, 3>), grid, dim3(256), 0, s, p); break;
         }

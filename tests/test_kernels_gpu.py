@@ -89,16 +89,19 @@ def test_conv_fwd_dgrad_wgrad(hip_lib, case):
     assert relerr(dw.cpu() * 0.35, w.grad) < TOL
 
 
-@pytest.mark.parametrize("case", [(3, 64, 64, 16, 16, 0), (3, 64, 64, 16, 16, 3), (2, 512, 512, 4, 4, 0), (5, 256, 512, 8, 8, 2), (1, 128, 128, 2, 2, 0)])
+@pytest.mark.parametrize("case", [(3, 64, 64, 16, 16, 0), (3, 64, 64, 16, 16, 3), (2, 512, 512, 4, 4, 0), (5, 256, 512, 8, 8, 2), (1, 128, 128, 2, 2, 0),
+                                  (3, 64, 96, 32, 32, 0, 15), (3, 32, 64, 32, 32, 5, 15), (2, 128, 64, 16, 16, 1, 15), (1, 64, 64, 64, 64, 7, 15)])
 def test_all_taps_weight_gradient_forced(hip_lib, case):
-    """wgrad_taps_kernel (one workgroup per (n, c) tile for all 16 taps of a 4x4 stride-2 layer) forced through the tuning
-    hook on shapes the plan gives to other kernels too: its own pixel split and forced ones (slabs + finish kernels), ragged
+    """wgrad_taps_kernel (one workgroup per (n, c) tile for all 16 taps of a 4x4 stride-2 layer) and wgrad_s2_kernel (the same
+    ownership, operands from a double-buffered LDS window) forced through the tuning hook on shapes the plan gives to other
+    kernels too: its own pixel split and forced ones (slabs + finish kernels), ragged
     last chunks, a single pixel (2x2 -> 1x1), bias gradient, accumulate mode."""
     import ctypes as C
     from mtd_gan_amd import _lib, kernels as K
     L = _lib.lib()
     L.mtd_conv_wgrad_override.argtypes = [C.c_int, C.c_int]
-    B, Ci, Co, H, W, split = case
+    B, Ci, Co, H, W, split = case[:6]
+    cfg = case[6] if len(case) > 6 else 13          # 15: the halo-window kernel (8 x 8 pixel blocks from LDS)
     x = rnd(B, Ci, H, W, seed=41)
     w = rnd(Co, Ci, 4, 4, seed=42, scale=0.02).requires_grad_(True)
     b = rnd(Co, seed=43, scale=0.1).requires_grad_(True)
@@ -106,7 +109,7 @@ def test_all_taps_weight_gradient_forced(hip_lib, case):
     cot = rnd(*y.shape, seed=44)
     (y * cot).sum().backward()
     try:
-        L.mtd_conv_wgrad_override(13, split if split else -1)
+        L.mtd_conv_wgrad_override(cfg, split if split else -1)
         dw = torch.full((Co, Ci, 4, 4), 0.25, device="cuda")
         db = torch.full((Co,), 0.5, device="cuda")
         geom = K.geom_fwd(B, H, W, 4, 2, 1)
