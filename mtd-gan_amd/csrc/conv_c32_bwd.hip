@@ -50,7 +50,11 @@ __global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) 
     // barrier per shared four-row tile the weight-gradient waves stood at it for half of every tile (in-kernel stamps,
     // tools/c32f_probe.py: 53 k clocks per tile for the data-gradient role, 27 k for the other).
     constexpr int T = 9, ND = 4, PHW = C32T_W / 2 + 2, PHP = 3 * PHW, PNI = (PHP + 7) / 8;      // ND: data-gradient waves
-    __shared__ __attribute__((aligned(1024))) float Hs[ND][2][PNI * 256];
+    // (the two buffers are separate LDS OBJECTS and the block loop is unrolled by two: with one array indexed by the block's
+    // parity the compiler cannot tell a pending LDS-DMA into the other buffer from one into the buffer it is about to read,
+    // and put a vmcnt(0) -- a wait for the NEXT block's halo -- in front of every block's first LDS read)
+    __shared__ __attribute__((aligned(1024))) float Hs0[ND][PNI * 256];
+    __shared__ __attribute__((aligned(1024))) float Hs1[ND][PNI * 256];
     __shared__ __attribute__((aligned(1024))) float Bs[T * 32 * 32];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) 
         const bool on = (fp.roles & 1) != 0;
         // block k of this wave: 32 pixels from ((blockIdx.x * nblk + k) * ND + wave) * 32 -- half an image row
         auto block_m = [&](int k) { return ((blockIdx.x * nblk + k) * ND + wave) * 32; };
-        auto stage = [&](int k, int buf) {
+        auto stage = [&](int k, float* Hd) {
             const int m = block_m(k);
             const int ox0 = m % C32T_W;
             const int t2 = m / C32T_W;
@@ -83,11 +87,11 @@ __global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) 
                 const int iy = oy - 1 + hr, ix = ox0 - 1 + hc;
                 const bool ok = live & (hp < PHP) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
                 const unsigned voff = ok ? (unsigned)(((((long long)b * g.IH + iy) * g.IW + ix) * a.in_ld + piece * 4) * 4) : 0x80000000u;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_f*)&Hs[wave][buf][i * 256], 16, voff, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_f*)(Hd + i * 256), 16, voff, 0, 0, 0);
             }
         };
         if (wave == 0) C32F_STAMP(0);
-        stage(0, 0);
+        stage(0, Hs0[wave]);
         {
             const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), (short)0, (int)p.w_bytes, 0x00020000);
             for (int i = wave; i < T * 4; i += ND) {
@@ -105,13 +109,11 @@ __global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) 
         __syncthreads();                                                                   // barrier 0: the weights are in LDS
         if (wave == 0) C32F_STAMP(1);
         const int hp0 = PHW + l31 + 1;                        // the lane's own pixel in the private halo
-#pragma unroll 1
-        for (int k = 0; k < nblk; ++k) {
-            if (k + 1 < nblk) stage(k + 1, (k + 1) & 1);      // (its buffer was last read by block k - 1 of this same wave)
+        auto one_block = [&](int k, const float* H, float* Hnext) {
+            if (k + 1 < nblk) stage(k + 1, Hnext);            // (that buffer was last read by block k - 1 of this same wave)
             const int mbase = block_m(k);
             const bool live = on && mbase < p.M;
             if (live) {
-                const float* H = Hs[wave][k & 1];
                 EpiWide wad;
                 EpiWideOps weo;
                 wad.init(p, mbase, lane, 0, sp);
@@ -147,6 +149,11 @@ __global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) 
             else if (nstores == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             if (wave == 0 && k < 4) C32F_STAMP(2 + k);
+        };
+#pragma unroll 1
+        for (int k = 0; k < nblk; k += 2) {                  // nblk = 2 * iters is even
+            one_block(k, Hs0[wave], Hs1[wave]);
+            one_block(k + 1, Hs1[wave], Hs0[wave]);
         }
         // the weight-gradient waves' cross-wave sum: 2 barriers per tap, 2 for the bias row
         const bool do_bias = fp.w.a.db != nullptr;
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) 
         }
         // ---- cross-wave sum through LDS (fixed order) and the workgroup's slab: reg_kernel_epilogue's arithmetic.  The halo
         // buffers are free: every data-gradient wave is past its last block when it joins the first barrier below.
-        float* Ls = &Hs[0][0][0];
+        float* Ls = &Hs0[0][0];
         constexpr int EPW = 16 / NWG;
         float* slab = a.ws + (long long)blockIdx.x * p.slab_stride;
 #pragma unroll

@@ -1011,7 +1011,11 @@ constexpr int C32T_W = 64, C32T_R = 4, C32T_HW = C32T_W + 2;
 template <int R, bool DB, bool WIDE = false>
 __global__ __launch_bounds__(128 * R, DB ? 1 : 2) void igemm_c32t_kernel(const IgemmParams p, int ntiles, int stagger) {
     constexpr int T = 9, NW = 2 * R, HP = (R + 2) * C32T_HW, NI = (HP + 7) / 8;
-    __shared__ __attribute__((aligned(1024))) float Hs[DB ? 2 : 1][NI * 8 * 32];
+    // The two halo buffers are separate LDS OBJECTS and the tile loop is unrolled by two: with one array indexed by `cur` the
+    // compiler cannot tell the pending LDS-DMA of the NEXT tile from one into the buffer it is about to read, and put a
+    // vmcnt(0) in front of every tile's first LDS read -- the double buffering overlapped nothing.
+    __shared__ __attribute__((aligned(1024))) float Hs0[NI * 8 * 32];
+    __shared__ __attribute__((aligned(1024))) float Hs1[DB ? NI * 8 * 32 : 64];
     __shared__ __attribute__((aligned(1024))) float Bs[T * 32 * 32];
     const mtd_conv_args& a = p.a;
     const mtd_geom& g = a.g;
@@ -1025,7 +1029,7 @@ __global__ __launch_bounds__(128 * R, DB ? 1 : 2) void igemm_c32t_kernel(const I
     const int rsub = lane >> 3, piece = (lane & 7) ^ rsub;
 
     // DMA instruction i of a tile moves halo pixels 8i .. 8i+7: lane L -> pixel 8i + (L >> 3), LDS piece L & 7
-    auto stage_tile = [&](int tile, int buf) {
+    auto stage_tile = [&](int tile, float* Hd) {
         const int b = tile / tiles_per_image;
         const int oy0 = (tile - b * tiles_per_image) * R;
         for (int i = wave; i < NI; i += NW) {
@@ -1034,12 +1038,12 @@ __global__ __launch_bounds__(128 * R, DB ? 1 : 2) void igemm_c32t_kernel(const I
             const int iy = oy0 - 1 + hr, ix = hc - 1;
             const bool ok = (hp < HP) & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW);
             const unsigned voff = ok ? (unsigned)(((((long long)b * g.IH + iy) * g.IW + ix) * a.in_ld + piece * 4) * 4) : 0x80000000u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_f*)&Hs[buf][i * 256], 16, voff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_f*)(Hd + i * 256), 16, voff, 0, 0, 0);
         }
     };
     MTD_STAMP(0);
     int tile = blockIdx.x;
-    stage_tile(tile, 0);
+    stage_tile(tile, Hs0);
     {   // weights: row r = tap * 32 + n of a [288][32 c] matrix, same piece permutation
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), (short)0, (int)p.w_bytes, 0x00020000);
         for (int i = wave; i < T * 4; i += NW) {
@@ -1063,10 +1067,10 @@ __global__ __launch_bounds__(128 * R, DB ? 1 : 2) void igemm_c32t_kernel(const I
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     MTD_STAMP(2);
-    int cur = 0;
-    while (true) {
+    // one tile from halo buffer H (DB: the next tile's DMA goes to Hn meanwhile); false = that was the last tile
+    auto one_tile = [&](const float* H, float* Hn, int cur) -> bool {
         const int next = tile + gridDim.x;
-        if (DB && next < ntiles) stage_tile(next, cur ^ 1);      // every wave is past its MFMAs on that buffer (barrier below)
+        if (DB && next < ntiles) stage_tile(next, Hn);           // every wave is past its MFMAs on that buffer (barrier below)
         const int mbase = tile * (R * C32T_W) + wave * 32;
         EpiAddr<true, 0, 16> ead;
         EpiOps<16> eo;
@@ -1080,7 +1084,6 @@ __global__ __launch_bounds__(128 * R, DB ? 1 : 2) void igemm_c32t_kernel(const I
             epi_load(p, ead, eo);
         }
         __builtin_amdgcn_sched_barrier(0);
-        const float* H = Hs[DB ? cur : 0];
         auto frag = [&](int t, f32x4* af, f32x4* bf) {
             const int hp = hp0 + (g.off_y + p.tap_dy[t]) * C32T_HW + (g.off_x + p.tap_dx[t]);
             const float* px = &H[hp * 32];
@@ -1112,21 +1115,26 @@ __global__ __launch_bounds__(128 * R, DB ? 1 : 2) void igemm_c32t_kernel(const I
             if (WIDE) epiw_store(p, acc, wad, bias4, weo);
             else epi_store(p, acc, ead, sp, bias_n, eo);           // stores drain under the next tile's MFMAs
             MTD_STAMP(5 + 3 * (cur));
-            if (next >= ntiles) break;
+            if (next >= ntiles) return false;
             __syncthreads();
             tile = next;
-            cur ^= 1;
         } else {
             __syncthreads();                                       // every wave is done reading the halo tile
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this tile's epilogue operands have landed
-            if (next < ntiles) stage_tile(next, 0);                // the next tile's DMA in flight under the stores ...
+            if (next < ntiles) stage_tile(next, Hs0);              // the next tile's DMA in flight under the stores ...
             if (WIDE) epiw_store(p, acc, wad, bias4, weo);
             else epi_store(p, acc, ead, sp, bias_n, eo);           // ... and under the other workgroup's MFMAs
-            if (next >= ntiles) break;
+            if (next >= ntiles) return false;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             tile = next;
         }
+        return true;
+    };
+    if (DB) {
+        while (one_tile(Hs0, Hs1, 0) && one_tile(Hs1, Hs0, 1)) {}
+    } else {
+        while (one_tile(Hs0, Hs0, 0)) {}
     }
 }
 
