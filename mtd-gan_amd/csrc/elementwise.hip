@@ -267,6 +267,46 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const mtd_pack_desc* 
     const float inv_per = 1.f / (float)per, inv_t = 1.f / (float)T;
     const int nrow = c_inner ? 33 : 17;            // LDS row stride of an n
     const float* src = d.src + (long long)n0 * d.sn + (long long)c0 * d.sc;
+    // OIHW storage (the 32 c x T taps of one n are one contiguous, 16-byte aligned run): 16-byte reads, four at a time
+    const bool vec = c_inner && d.sc == T && (d.sn % 4) == 0 && ((((uintptr_t)d.src) & 15) == 0) && (d.C % 4) == 0 &&
+                     ((((uintptr_t)d.dst) & 15) == 0);
+    if (vec) {
+        const int per4 = per / 4, total4 = 16 * per4;
+        for (int base = 0; base < total4; base += 4 * 256) {
+            f32x4 v[4];
+            int i4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                i4[u] = base + u * 256 + threadIdx.x;
+                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (i4[u] < total4) {
+                    const int outer = i4[u] / per4, r4 = i4[u] - outer * per4;
+                    v[u] = *reinterpret_cast<const f32x4*>(src + (long long)outer * d.sn + 4 * r4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i4[u] < total4) {
+                    const int outer = i4[u] / per4, rem = 4 * (i4[u] - outer * per4);
+                    int inner = pack_div(rem, inv_t), t = rem - inner * T;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        tile[t * PACK_TS + outer * nrow + inner] = v[u][e];
+                        if (++t == T) { t = 0; ++inner; }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        float* dst = d.dst + (long long)n0 * d.C + c0;
+        const long long tstride = (long long)d.N * d.C;
+        for (int i = threadIdx.x; i < total / 4; i += 256) {       // rows of 32 c as eight 16-byte stores
+            const int c = (i & 7) * 4, n = (i >> 3) & 15, t = i >> 7;
+            const float* tp = tile + t * PACK_TS + n * nrow + c;
+            *reinterpret_cast<f32x4*>(dst + t * tstride + (long long)n * d.C + c) = f32x4{tp[0], tp[1], tp[2], tp[3]};
+        }
+        return;
+    }
     for (int base = 0; base < total; base += 8 * 256) {      // eight loads in flight per thread
         float v[8];
         int li[8];
