@@ -1365,6 +1365,22 @@ Plan make_plan(const mtd_conv_args& a, int sets = 1) {
         const long long sk6 = b6 <= 256 ? 512 / b6 : 1;
         if (b6 * sk6 <= 768) pl.cfg = 6;
     }
+    // Round 2, after the transposed accumulator blocks (the 256 x 64 tile lost its scratch spill and both tap-block forms their
+    // dword epilogues): the standalone sweep of the step's 98 shapes (profiles/r2_igemm_tile_sweep.txt) puts the 256 x 64 tile
+    // 5-9 % ahead on every large 3x3 grid, 1.25 ms per step over all shapes.  INSIDE the step the rules below (MTD_IGEMM_PLAN=2)
+    // move 7.0 ms of launches onto that tile and 1.6 ms onto the two-block tap-block kernel and the family's total does not
+    // change (20.63 -> 20.58 ms in the one-stream trace, step 40.26 vs 40.40 ms): standalone timings on repeated launches
+    // do not predict the in-step ranking at this margin.  Off by default.
+    static const int env_plan = [] { const char* e = getenv("MTD_IGEMM_PLAN"); return e ? atoi(e) : 1; }();
+    const int T9 = a.g.TH * a.g.TW == TB_MAXT;
+    if (env_plan >= 2 && sets == 1 && T9) {
+        const long long MN = M * a.N;
+        if ((a.N % 64) == 0 && a.C >= 64 && MN >= (4ll << 20) && !(M >= 65536 && a.N >= 256 && a.C <= 64)) {
+            pl.cfg = 2;         // 256 x 64, four blocks per wave: 5-9 % over the 128 / 256 x 32 tiles on every grid this large
+        } else if (a.C >= 128 && MN >= (2ll << 20) && MN < (4ll << 20) && (M / 256) * (a.N / 32) >= 256 && a.N <= 256) {
+            pl.cfg = 7;         // tap-block kernel with two blocks per wave: 16384 x 128, 32768 x 64, 8192 x 256
+        }
+    }
     pl.BM = kCfgBM[pl.cfg];
     pl.BN = kCfgBN[pl.cfg];
     const long long Mset = geom_pixels(a.g);
@@ -1372,6 +1388,12 @@ Plan make_plan(const mtd_conv_args& a, int sets = 1) {
     int chunks = a.C / KC;
     int sk = blocks <= 256 ? (int)(512 / blocks) : 1;      // fill ~2 workgroups per CU; never split a grid that already does
     if (blocks > 256 && blocks <= 512 && chunks * a.g.TH * a.g.TW <= 32) sk = 2;      // ... unless its workgroups are short (2x2-tap data gradients: -22 %)
+    if (env_plan >= 2 && sets == 1 && T9 && blocks == 256) {
+        // a grid of exactly one workgroup per CU: the register-blocked tiles do not want the split at all, the tap-block
+        // kernel only when its K loop is long (4096 x 256 x 256: 45 us unsplit, 51 split; 2048 x 512 x 512: 91 / 87)
+        if (pl.cfg == 2 || pl.cfg == 7) sk = 1;
+        else if (pl.cfg == 6 && (long long)a.C * 9 < 4096) sk = 1;
+    }
     if (sk > chunks) sk = chunks;
     if (sk > 32) sk = 32;
     if (sk < 1) sk = 1;
