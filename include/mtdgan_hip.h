@@ -153,6 +153,16 @@ int mtd_conv_wgrad_reduce_multi(const mtd_wgrad_reduce_desc* table_dev, const mt
  * 1 = w(kw) in {1,2,...,2,1} (irfft2 backward). */
 int mtd_rfft_rows(const float* x, int x_ld, float* R, int B, int col_weight, void* stream);
 
+/* Tail of a Res-FFT-Conv block in ONE launch (arch/Ours/networks.py:32-36: `x + relu(img_conv(x)) + irfft2(...)`):
+ *     out2 = act(conv3x3(in) + bias)        the spatial branch (kept: the backward pass uses it as its ReLU mask; may be NULL)
+ *     out  = in + out2 + irfft_rows(T)      T = output of mtd_spec_mix_fwd / _fwd4
+ * i.e. mtd_conv_igemm(out = out2) + mtd_irfft_rows(T, out, add1 = in, add2 = out2) without the second launch and its
+ * re-reads: the halo-tile conv kernel's tiles are complete image rows, so the inverse row transform runs between its MFMA
+ * loop and its epilogue and `in` is taken from the halo tile.  C = N = 32, 3x3 stride 1 "same", 64 x 64 maps, >= 32768
+ * pixels, no add / mask / scale2 operands: mtd_resfft_block_tail_ok() says whether a->... qualifies (else MTD_EINVAL). */
+int mtd_resfft_block_tail_ok(const mtd_conv_args* a);
+int mtd_resfft_block_tail(const mtd_conv_args* a, const float* T, void* stream);
+
 /* columns + channel mix + columns back, one kernel:
  *   S = FFT_H(R)/8 ; Z = W2 . [Re S; Im S] + b2 ; T = IFFT_H(relu(Z))/8
  * w2t is W2 transposed ([k][o], 64x64).  S_save / Z_save ([B][33][64][64]) may be NULL (inference). */

@@ -99,7 +99,7 @@ def _preload_torch_hip_runtime():
 
 
 RECORDER = None      # kernels.LaunchList: while a step is being recorded, the list every launch is appended to
-_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "mtd_prof_", "_override", "_bwd_ok", "_stamps", "_zmask_bytes")
+_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "mtd_prof_", "_override", "_bwd_ok", "_stamps", "_zmask_bytes", "_tail_ok")
 
 
 class _RecordingLib:
@@ -216,6 +216,8 @@ def lib():
     sig("mtd_conv_c32_bwd", ci, C.POINTER(ConvArgs), C.POINTER(WgradArgs), C.POINTER(C.c_int), C.POINTER(C.c_longlong), vp)
     sig("mtd_conv_igemm_multi_ws_bytes", sz, C.POINTER(ConvArgs), ci)
     sig("mtd_conv_igemm_multi", ci, C.POINTER(ConvArgs), ci, vp)
+    sig("mtd_resfft_block_tail_ok", ci, C.POINTER(ConvArgs))
+    sig("mtd_resfft_block_tail", ci, C.POINTER(ConvArgs), vp, vp)
     sig("mtd_pcgrad_coeff", ci, vp, vp, ci, vp, vp)
     sig("mtd_pcgrad_axpy", ci, vp, vp, vp, vp, ci, ll, vp, cf, vp, vp)
     _lib = L
@@ -236,6 +238,7 @@ EXPORTS = [
     "mtd_prof_mode", "mtd_pcgrad_coeff", "mtd_pcgrad_axpy", "mtd_conv_igemm_multi_ws_bytes", "mtd_conv_igemm_multi",
     "mtd_conv_c32_bwd_ok", "mtd_conv_c32_bwd_ws_bytes", "mtd_conv_c32_bwd",
     "mtd_spec_mix_zmask_bytes", "mtd_spec_mix_fwd4", "mtd_spec_mix_bwd4",
+    "mtd_resfft_block_tail_ok", "mtd_resfft_block_tail",
 ]
 
 

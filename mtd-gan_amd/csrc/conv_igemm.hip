@@ -17,6 +17,7 @@
 //
 // Roofline: fp32 MFMA, 64 FLOP/clk/SIMD (157.3 TFLOP/s chip).  Algorithmic flops = 2*M*N*K.
 #include "common.h"
+#include "fft64.h"
 
 // In-kernel phase stamps for the diagnostic build only (tools/igemm_stamp.hip defines MTD_STAMPS and includes this
 // file); in the library build MTD_STAMP expands to nothing.
@@ -319,6 +320,35 @@ __device__ __forceinline__ void epiw_store(const IgemmParams& p, const f32x16& a
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(a.out + ad.pix * a.out_ld + ad.ch + 8 * g) = v[g];
+}
+
+// Res-FFT block tail (igemm_c32t_kernel SPEC): out2 = act(acc * sc + bias), out = out2 + xs, xs = the lane's pieces of
+// x + irfft_rows (halo tile).  No add / mask operands.
+__device__ __forceinline__ void epiw_store_spec(const IgemmParams& p, const f32x16& acc, const EpiWide& ad, const f32x4 (&bias4)[4],
+                                                const f32x4 (&xs)[4]) {
+    const mtd_conv_args& a = p.a;
+    f32x4 v[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[g][j] = acc[4 * g + j] * ad.sc + bias4[g][j];
+    if (a.act == MTD_ACT_RELU) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[g][j] = v[g][j] > 0.f ? v[g][j] : 0.f;
+    } else if (a.act == MTD_ACT_LRELU) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[g][j] = v[g][j] > 0.f ? v[g][j] : 0.2f * v[g][j];
+    }
+    if (a.out2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(a.out2 + ad.pix * a.out2_ld + ad.ch + 8 * g) = v[g];
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(a.out + ad.pix * a.out_ld + ad.ch + 8 * g) = v[g] + xs[g];
 }
 
 __device__ __forceinline__ void epiw_bias(const mtd_conv_args& a, int ch, f32x4 (&bias4)[4]) {
@@ -1008,8 +1038,22 @@ constexpr int C32T_W = 64, C32T_R = 4, C32T_HW = C32T_W + 2;
 // tile's MFMAs (R = 4).  !DB (R = 2, lab variant MTD_C32T_VARIANT=1): one halo buffer of half the size, TWO workgroups per CU
 // that are meant to alternate -- one in its memory phase (epilogue stores, next tile's DMA) while the other has the MFMA
 // pipes -- with the second workgroup of a CU held back by `stagger` x 64 clocks at the start.
-template <int R, bool DB, bool WIDE = false>
-__global__ __launch_bounds__(128 * R, DB ? 1 : 2) void igemm_c32t_kernel(const IgemmParams p, int ntiles, int stagger) {
+//
+// SPEC (R = 4, DB, WIDE; mtd_resfft_block_tail): the launch is the tail of a Res-FFT-Conv block (arch/Ours/networks.py:32-36).
+// The tile's rows are COMPLETE image rows, so the inverse row transform of the spectral branch -- mtd_irfft_rows, a launch of
+// its own that re-read x and the conv branch -- rides on the same accumulator layout as a 33-step GEMM on the matrix cores:
+//     irfft_rows[p][c] = sum_kw  D[p][kw, re] * T[kw][re][c] + D[p][kw, im] * T[kw][im][c],
+//     D[p][kw, re] = w cos(2 pi kw p / 64) / 8,  D[p][kw, im] = -w sin(2 pi kw p / 64) / 8,  w = 1 for kw in {0, 32}, else 2
+// (the Hermitian half folded into w; the sines vanish at kw = 0 and 32, which IS torch.fft.irfft2's "imaginary parts of columns
+// 0 and W/2 are ignored").  A wave's lanes already are (pixel l31, k half kh) for the conv; the spectrum row
+// T[b][kw][h][kh][c = l31] is the other operand, one coalesced 256-byte load per kw requested before the conv's MFMA loop.
+// 33 MFMAs on top of the conv's 144 per tile and wave -- no barrier, no LDS round trip, no vector-ALU transform (a first form
+// with a quad-split register FFT between the MFMA loop and the epilogue cost two barriers and ~5 us per tile).  D (64 x 66
+// floats) sits in LDS; x is read from the halo tile:   out2 = act(conv + bias)   out = out2 + x + irfft_rows(specT).
+template <int R, bool DB, bool WIDE = false, bool SPEC = false>
+__global__ __launch_bounds__(128 * R, DB ? 1 : 2) void igemm_c32t_kernel(const IgemmParams p, int ntiles, int stagger,
+                                                                         const float* __restrict__ specT) {
+    static_assert(!SPEC || (R == 4 && DB && WIDE), "the spectral tail needs four-row tiles, two halo buffers and the wide epilogue");
     constexpr int T = 9, NW = 2 * R, HP = (R + 2) * C32T_HW, NI = (HP + 7) / 8;
     // The two halo buffers are separate LDS OBJECTS and the tile loop is unrolled by two: with one array indexed by `cur` the
     // compiler cannot tell the pending LDS-DMA of the NEXT tile from one into the buffer it is about to read, and put a
@@ -1017,6 +1061,8 @@ __global__ __launch_bounds__(128 * R, DB ? 1 : 2) void igemm_c32t_kernel(const I
     __shared__ __attribute__((aligned(1024))) float Hs0[NI * 8 * 32];
     __shared__ __attribute__((aligned(1024))) float Hs1[DB ? NI * 8 * 32 : 64];
     __shared__ __attribute__((aligned(1024))) float Bs[T * 32 * 32];
+    constexpr int DLD = 67;                                       // row stride of the inverse-DFT matrix (odd: conflict-free over l31)
+    __shared__ float Ds[SPEC ? 64 * DLD : 1];
     const mtd_conv_args& a = p.a;
     const mtd_geom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1025,8 +1071,19 @@ __global__ __launch_bounds__(128 * R, DB ? 1 : 2) void igemm_c32t_kernel(const I
     const int n0 = blockIdx.y * 32;
     const int tiles_per_image = g.OH / R;
     typedef __attribute__((address_space(3))) float lds_f;
+    if (SPEC) {
+        for (int e = tid; e < 64 * 66; e += 128 * R) {
+            const int px = e / 66, kap = e - px * 66, kw = kap >> 1;
+            const int ang = (kw * px) & 63;                                   // angle 2 pi ang / 64: the transforms' own tables
+            const float tv = (kap & 1) ? SIN64[ang & 31] : COS64[ang & 31];
+            const float wgt = (kw == 0 || kw == 32) ? 0.125f : 0.25f;
+            Ds[px * DLD + kap] = (((ang & 32) != 0) != ((kap & 1) != 0)) ? -wgt * tv : wgt * tv;      // cos, sin (t + pi) = -cos, -sin t; the sine enters negated
+        }
+    }
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)p.in_bytes, 0x00020000);
     const int rsub = lane >> 3, piece = (lane & 7) ^ rsub;
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SPEC ? specT : a.in), (short)0,
+                                                                         SPEC ? g.B * NKW * 16384 : 0, 0x00020000);
 
     // DMA instruction i of a tile moves halo pixels 8i .. 8i+7: lane L -> pixel 8i + (L >> 3), LDS piece L & 7
     auto stage_tile = [&](int tile, float* Hd) {
@@ -1068,7 +1125,7 @@ __global__ __launch_bounds__(128 * R, DB ? 1 : 2) void igemm_c32t_kernel(const I
     __syncthreads();
     MTD_STAMP(2);
     // one tile from halo buffer H (DB: the next tile's DMA goes to Hn meanwhile); false = that was the last tile
-    auto one_tile = [&](const float* H, float* Hn, int cur) -> bool {
+    auto one_tile = [&](float* H, float* Hn, int cur) -> bool {
         const int next = tile + gridDim.x;
         if (DB && next < ntiles) stage_tile(next, Hn);           // every wave is past its MFMAs on that buffer (barrier below)
         const int mbase = tile * (R * C32T_W) + wave * 32;
@@ -1076,7 +1133,18 @@ __global__ __launch_bounds__(128 * R, DB ? 1 : 2) void igemm_c32t_kernel(const I
         EpiOps<16> eo;
         EpiWide wad;
         EpiWideOps weo;
-        if (WIDE) {
+        // SPEC: this wave's spectrum row as MFMA operand fragments, tb[kw] = T[b][kw][h][kh][c = l31] (one lane offset + a
+        // scalar offset per load)
+        float tb[NKW];
+        if (SPEC) {
+            const int b = tile / tiles_per_image;
+            const int h = (tile - b * tiles_per_image) * R + (wave >> 1);
+            const unsigned base = (unsigned)((((b * NKW) * 64 + h) * 64 + kh * 32 + l31) * 4);
+#pragma unroll
+            for (int kw = 0; kw < NKW; ++kw)
+                tb[kw] = (stagger & 2) ? 1.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(trs, base, kw * 16384, 0));
+            wad.init(p, mbase, lane, n0, sp);
+        } else if (WIDE) {
             wad.init(p, mbase, lane, n0, sp);
             epiw_load(p, wad, weo);
         } else {
@@ -1085,7 +1153,11 @@ __global__ __launch_bounds__(128 * R, DB ? 1 : 2) void igemm_c32t_kernel(const I
         }
         __builtin_amdgcn_sched_barrier(0);
         auto frag = [&](int t, f32x4* af, f32x4* bf) {
-            const int hp = hp0 + (g.off_y + p.tap_dy[t]) * C32T_HW + (g.off_x + p.tap_dx[t]);
+            int hp = hp0 + (g.off_y + p.tap_dy[t]) * C32T_HW + (g.off_x + p.tap_dx[t]);
+            // SPEC: the swizzled piece addresses are re-derived per tap (about eight VALU operations under sixteen 64-clock MFMAs).
+            // Left to itself the compiler keeps all 9 taps x 4 pieces x 2 halo buffers = 72 address registers live across the
+            // whole tile loop, which with the spectrum's 32 registers no longer fits the 256 of two waves per SIMD.
+            if (SPEC) asm volatile("" : "+v"(hp));
             const float* px = &H[hp * 32];
             const int sw = hp & 7;
             const float* row = &Bs[(t * 32 + l31) * 32];
@@ -1108,11 +1180,31 @@ __global__ __launch_bounds__(128 * R, DB ? 1 : 2) void igemm_c32t_kernel(const I
                 acc = WIDE ? mfma32(bf[t & 1][kk >> 2][kk & 3], af[t & 1][kk >> 2][kk & 3], acc)      // transposed block (EpiWide)
                            : mfma32(af[t & 1][kk >> 2][kk & 3], bf[t & 1][kk >> 2][kk & 3], acc);
         }
+        f32x16 acc2;
+        if (SPEC) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+            const float* drow = &Ds[((wave & 1) * 32 + l31) * DLD + kh];
+            if (!(stagger & 1))
+#pragma unroll
+            for (int kw = 0; kw < NKW; ++kw) acc2 = mfma32(tb[kw], drow[2 * kw], acc2);      // (channel, pixel) block like the conv's
+        }
         MTD_STAMP(3 + 3 * (cur));
         if (DB) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile and this tile's epilogue operands have landed
             MTD_STAMP(4 + 3 * (cur));
-            if (WIDE) epiw_store(p, acc, wad, bias4, weo);
+            if (SPEC) {
+                const float* px = &H[hp0 * 32];
+                const int sw = hp0 & 7;
+                f32x4 xs[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    xs[g] = *reinterpret_cast<const f32x4*>(px + (((kh + 2 * g) ^ sw) << 2));      // x: the pixel itself, in the halo tile
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xs[g][j] += acc2[4 * g + j];
+                }
+                epiw_store_spec(p, acc, wad, bias4, xs);
+            } else if (WIDE) epiw_store(p, acc, wad, bias4, weo);
             else epi_store(p, acc, ead, sp, bias_n, eo);           // stores drain under the next tile's MFMAs
             MTD_STAMP(5 + 3 * (cur));
             if (next >= ntiles) return false;
@@ -1522,14 +1614,14 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
         static const int env_stagger = [] { const char* e = getenv("MTD_C32T_STAGGER"); return e ? atoi(e) : 0; }();
         if (env_variant == 1) {
             const int ntiles = p.M / (2 * C32T_W);
-            MTD_LAUNCH((igemm_c32t_kernel<2, false>), dim3(ntiles < 512 ? ntiles : 512, a->N / 32), dim3(256), 0, s, p, ntiles, env_stagger);
+            MTD_LAUNCH((igemm_c32t_kernel<2, false>), dim3(ntiles < 512 ? ntiles : 512, a->N / 32), dim3(256), 0, s, p, ntiles, env_stagger, (const float*)nullptr);
         } else {
             const int ntiles = p.M / (C32T_R * C32T_W);
             static const int env_wide = [] { const char* e = getenv("MTD_C32T_WIDE"); return e ? atoi(e) : 1; }();
             if (env_wide && wide_epilogue_ok(*a))
-                MTD_LAUNCH((igemm_c32t_kernel<C32T_R, true, true>), dim3(ntiles < 256 ? ntiles : 256, a->N / 32), dim3(512), 0, s, p, ntiles, 0);
+                MTD_LAUNCH((igemm_c32t_kernel<C32T_R, true, true>), dim3(ntiles < 256 ? ntiles : 256, a->N / 32), dim3(512), 0, s, p, ntiles, 0, (const float*)nullptr);
             else
-            MTD_LAUNCH((igemm_c32t_kernel<C32T_R, true>), dim3(ntiles < 256 ? ntiles : 256, a->N / 32), dim3(512), 0, s, p, ntiles, 0);
+            MTD_LAUNCH((igemm_c32t_kernel<C32T_R, true>), dim3(ntiles < 256 ? ntiles : 256, a->N / 32), dim3(512), 0, s, p, ntiles, 0, (const float*)nullptr);
         }
         mtd_prof_end(prof, s);
         MTD_LAUNCH_CHECK();
@@ -1571,6 +1663,38 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
         else hipLaunchKernelGGL(splitk_epilogue_scalar_kernel, dim3(blocks), dim3(256), 0, s, p);
         MTD_LAUNCH_CHECK();
     }
+    return MTD_OK;
+}
+
+// Tail of a Res-FFT-Conv block in one launch (arch/Ours/networks.py:32-36):
+//     out2 = act(conv3x3(in) + bias)          (the spatial branch; the backward pass needs it as its ReLU mask)
+//     out  = in + out2 + irfft_rows(T)        (T: output of mtd_spec_mix_fwd*, [B][33][64][2][32])
+// = mtd_conv_igemm(out = out2) followed by mtd_irfft_rows(T, out, add1 = in, add2 = out2), without the second launch and its
+// re-reads of `in` and `out2`.  Halo-tile kernel only: C = N = 32, 3x3 stride 1 "same", 64-pixel rows, >= 32768 pixels, no
+// add / mask operands, a->out2 may be NULL.  MTD_EINVAL otherwise (the caller then issues the two launches).
+extern "C" int mtd_resfft_block_tail_ok(const mtd_conv_args* a) {
+    if (!a || check_args(*a) != MTD_OK) return 0;
+    if (a->N != 32 || a->C != 32 || a->g.TH * a->g.TW != 9 || geom_pixels(a->g) < 32768 || !c32t_eligible(*a)) return 0;
+    if (a->add1 || a->add2 || a->mask || a->scale2 || !wide_epilogue_ok(*a)) return 0;
+    if (a->g.OH != 64) return 0;                     // T is the spectrum of 64 x 64 patches
+    return 1;
+}
+
+extern "C" int mtd_resfft_block_tail(const mtd_conv_args* a, const float* T, void* stream) {
+    if (!a || !T || !mtd_resfft_block_tail_ok(a)) return MTD_EINVAL;
+    if (!aligned16(T)) return MTD_EALIGN;
+    Plan pl = make_plan(*a);
+    IgemmParams p;
+    int rc = fill_params(a, pl, p);
+    if (rc != MTD_OK) return rc;
+    if ((long long)a->g.B * NKW * 4096 * 4 >= (1ll << 31)) return MTD_EINVAL;      // 32-bit offsets into T
+    hipStream_t s = (hipStream_t)stream;
+    const int ntiles = p.M / (C32T_R * C32T_W);
+    const int prof = mtd_prof_begin(0, 12, 1, p.M, a->N, a->C, 9, s, algorithmic_bytes(a) + 4.0 * a->g.B * NKW * 4096);
+    static const int env_lab = [] { const char* e = getenv("MTD_TAIL_LAB"); return e ? atoi(e) : 0; }();      // lab: wrong results
+    MTD_LAUNCH((igemm_c32t_kernel<C32T_R, true, true, true>), dim3(ntiles < 256 ? ntiles : 256, 1), dim3(512), 0, s, p, ntiles, env_lab, T);
+    mtd_prof_end(prof, s);
+    MTD_LAUNCH_CHECK();
     return MTD_OK;
 }
 
@@ -1617,7 +1741,7 @@ extern "C" int mtd_conv_igemm_multi(const mtd_conv_args* a, int count, void* str
     double bytes = 0.0;
     for (int i = 0; i < count; ++i) bytes += algorithmic_bytes(&a[i]);
     dim3 grid((M + pl.BM - 1) / pl.BM, a[0].N / pl.BN, pl.splitk * count);
-    const int prof = mtd_prof_begin(0, pl.cfg, pl.splitk, (long long)M * count, a[0].N, a[0].C, a[0].g.TH * a[0].g.TW, s, bytes);
+    const int prof = mtd_prof_begin(0, 16 + pl.cfg, pl.splitk, (long long)M * count, a[0].N, a[0].C, a[0].g.TH * a[0].g.TW, s, bytes);   // (16 + cfg: igemm_multi_kernel<cfg>)
     switch (pl.cfg) {
         case 0: MTD_LAUNCH((igemm_multi_kernel<2, 1, 4, 1>), grid, dim3(256), 0, s, mp); break;
         case 1: MTD_LAUNCH((igemm_multi_kernel<1, 1, 4, 1>), grid, dim3(256), 0, s, mp); break;

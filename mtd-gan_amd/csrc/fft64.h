@@ -55,6 +55,111 @@ __device__ __forceinline__ void fft64(float (&re)[64], float (&im)[64]) {
     }
 }
 
+// ---- 64-point transform split over the four lanes of a quad (resfft4.hip, and the spectral epilogue of the halo-tile conv)
+__host__ __device__ constexpr int brev4(int k) { return ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3); }
+
+// In-place 16-point complex DFT, X[k] = sum_n x[n] e^{SIGN 2 pi i k n / 16}, unnormalised; radix-2 decimation in
+// frequency: the result for frequency k is left at index brev4(k).  Twiddles w16^t = w64^(4 t).
+template <int SIGN>
+__device__ __forceinline__ void fft16(float (&re)[16], float (&im)[16]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int half = 8 >> s;
+        const int tstep = 1 << s;
+#pragma unroll
+        for (int blk = 0; blk < 16; blk += 2 * half) {
+#pragma unroll
+            for (int j = 0; j < half; ++j) {
+                const int i0 = blk + j, i1 = i0 + half;
+                const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+                re[i0] = ar + br;
+                im[i0] = ai + bi;
+                const float dr = ar - br, di = ai - bi;
+                const int tw = j * tstep;                   // in units of 2 pi / 16
+                if (tw == 0) {
+                    re[i1] = dr;
+                    im[i1] = di;
+                } else if (tw == 4) {
+                    if (SIGN < 0) { re[i1] = di; im[i1] = -dr; }
+                    else { re[i1] = -di; im[i1] = dr; }
+                } else {
+                    const float c = COS64[4 * tw];
+                    const float sn = (SIGN < 0) ? -SIN64[4 * tw] : SIN64[4 * tw];
+                    re[i1] = dr * c - di * sn;
+                    im[i1] = dr * sn + di * c;
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float quad_bcast(float v, int k) {
+    // value of lane k of this lane's quad (DPP quad_perm broadcast)
+    const int x = __builtin_bit_cast(int, v);
+    int r;
+    switch (k) {
+        case 0: r = __builtin_amdgcn_update_dpp(0, x, 0x00, 0xf, 0xf, true); break;
+        case 1: r = __builtin_amdgcn_update_dpp(0, x, 0x55, 0xf, 0xf, true); break;
+        case 2: r = __builtin_amdgcn_update_dpp(0, x, 0xAA, 0xf, 0xf, true); break;
+        default: r = __builtin_amdgcn_update_dpp(0, x, 0xFF, 0xf, 0xf, true); break;
+    }
+    return __builtin_bit_cast(float, r);
+}
+
+// 64-point transform over a quad.  On entry lane j (= lane & 3) holds x[4 m + j] in (re, im)[m]; on exit it holds
+// X[16 j + r] in (re, im)[r], X[k] = sum_n x[n] e^{SIGN 2 pi i k n / 64} (unnormalised).  tc / ts: cos, sin of
+// 2 pi j r / 64 for this lane's j (quad_twiddles).
+template <int SIGN>
+__device__ __forceinline__ void fft64_quad(float (&re)[16], float (&im)[16], const float (&tc)[16], const float (&ts)[16], int j) {
+    fft16<SIGN>(re, im);
+    float gr[16], gi[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                          // G_j[r] = w64^(SIGN j r) F_j[r]
+        const float fr = re[brev4(r)], fi = im[brev4(r)];
+        if (SIGN < 0) { gr[r] = fr * tc[r] + fi * ts[r]; gi[r] = fi * tc[r] - fr * ts[r]; }
+        else { gr[r] = fr * tc[r] - fi * ts[r]; gi[r] = fi * tc[r] + fr * ts[r]; }
+    }
+    const bool odd = (j & 1) != 0;
+    const float sgn = (j & 2) ? -1.f : 1.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                          // X[16 q + r] = sum_j (SIGN i)^(j q) G_j[r], q = this lane
+        const float g0r = quad_bcast(gr[r], 0), g1r = quad_bcast(gr[r], 1), g2r = quad_bcast(gr[r], 2), g3r = quad_bcast(gr[r], 3);
+        const float g0i = quad_bcast(gi[r], 0), g1i = quad_bcast(gi[r], 1), g2i = quad_bcast(gi[r], 2), g3i = quad_bcast(gi[r], 3);
+        const float ar = g0r + g2r, ai = g0i + g2i, br = g0r - g2r, bi = g0i - g2i;
+        const float cr = g1r + g3r, ci = g1i + g3i, dr = g1r - g3r, di = g1i - g3i;
+        // q even: A +- C;  q odd: B +- (SIGN i) D,  (SIGN i) D = SIGN * (-D_im, D_re)
+        const float base_r = odd ? br : ar, base_i = odd ? bi : ai;
+        const float add_r = odd ? (SIGN < 0 ? di : -di) : cr;
+        const float add_i = odd ? (SIGN < 0 ? -dr : dr) : ci;
+        re[r] = fmaf(sgn, add_r, base_r);
+        im[r] = fmaf(sgn, add_i, base_i);
+    }
+}
+
+__device__ __forceinline__ void quad_twiddles(int j, float (&tc)[16], float (&ts)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int idx = j * r;                              // 0 .. 45, angle 2 pi idx / 64
+        const float s = (idx & 32) ? -1.f : 1.f;           // cos / sin (theta + pi) = -cos / -sin (theta)
+        tc[r] = s * COS64[idx & 31];
+        ts[r] = s * SIN64[idx & 31];
+    }
+}
+
+// the same twiddles without a table read: j is 0..3, so every value is one of four immediates (three selects per value)
+__device__ __forceinline__ void quad_twiddles_sel(int j, float (&tc)[16], float (&ts)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float c1 = COS64[r], s1 = SIN64[r];
+        const float c2 = ((2 * r) & 32) ? -COS64[(2 * r) & 31] : COS64[(2 * r) & 31];
+        const float s2 = ((2 * r) & 32) ? -SIN64[(2 * r) & 31] : SIN64[(2 * r) & 31];
+        const float c3 = ((3 * r) & 32) ? -COS64[(3 * r) & 31] : COS64[(3 * r) & 31];
+        const float s3 = ((3 * r) & 32) ? -SIN64[(3 * r) & 31] : SIN64[(3 * r) & 31];
+        tc[r] = j == 0 ? 1.f : (j == 1 ? c1 : (j == 2 ? c2 : c3));
+        ts[r] = j == 0 ? 0.f : (j == 1 ? s1 : (j == 2 ? s2 : s3));
+    }
+}
+
 constexpr int NKW = 33;
 
 // rows forward: two image rows (h, h+1) of one channel per lane; `pair` = index of this half-wave's row pair

@@ -29,12 +29,20 @@ def block_forward(x, w_img, b_img, w_fft, b_fft, save, w2t=None):
         out = K.empty_nhwc(B, H, W, CH, x)
         K.spectral_branch_any(x, K.transpose64(w_fft), b_fft, out, add1=x, add2=img)
         return out, None
+    if w2t is None:
+        w2t = K.transpose64(w_fft)
+    if K.BLOCK_TAIL and K.block_tail_ok(x, w_img, g, img, b_img):
+        # spectral branch first; the spatial branch's launch then carries the inverse row transform and the residual:
+        # img = relu(conv3x3(x) + b), out = x + img + irfft_rows(T) (mtd_resfft_block_tail)
+        R = K.rfft_rows(x, 0)
+        T, S, Z = K.spec_mix_fwd(R, w2t, b_fft, save)
+        out = K.empty_nhwc(B, H, W, CH, x)
+        K.block_tail(x, w_img, g, T, img, out, bias=b_img, act=ACT_RELU)
+        return out, ((x, img, S, Z) if save else None)
     # the spatial branch (fp32-MFMA conv) runs on a side stream beside the spectral branch (FFT rows / columns)
     side = K.side_stream(x.device, 1)
     side.run(lambda: K.conv(x, w_img, g, CH, CH, CH * 9, 9, img, bias=b_img, act=ACT_RELU), x)   # relu(conv3x3(x)+b)
     R = K.rfft_rows(x, 0)
-    if w2t is None:
-        w2t = K.transpose64(w_fft)
     T, S, Z = K.spec_mix_fwd(R, w2t, b_fft, save)
     out = K.empty_nhwc(B, H, W, CH, x)
     side.join()

@@ -114,7 +114,10 @@ CALL_LOG = None     # tools/tune_igemm.py: a list collects ("igemm" | "wgrad", b
 
 IGEMM_CONFIGS = ["igemm_kernel<2, 1, 4, 1>", "igemm_kernel<1, 1, 4, 1>", "igemm_kernel<2, 2, 4, 1>",
                  "igemm_kernel<1, 1, 2, 2>", "igemm_kernel<2, 2, 2, 2>", "igemm_kernel<1, 1, 1, 4>",
-                 "igemm_tb_kernel<1>", "igemm_tb_kernel<2>", "igemm_v2_kernel<0>", "igemm_c32p_kernel", "igemm_c32t_kernel", "c32_bwd_kernel"]
+                 "igemm_tb_kernel<1>", "igemm_tb_kernel<2>", "igemm_v2_kernel<0>", "igemm_c32p_kernel", "igemm_c32t_kernel", "c32_bwd_kernel",
+                 "igemm_c32t_kernel<4, true, true, true>", "?", "?", "?",        # 12: Res-FFT block tail (mtd_resfft_block_tail)
+                 "igemm_multi_kernel<2, 1, 4, 1>", "igemm_multi_kernel<1, 1, 4, 1>", "igemm_multi_kernel<2, 2, 4, 1>",      # 16 + cfg
+                 "igemm_multi_kernel<1, 1, 2, 2>", "igemm_multi_kernel<2, 2, 2, 2>", "igemm_multi_kernel<1, 1, 1, 4>"]
 WGRAD_CONFIGS = ["wgrad_kernel<1, 1, 9>", "wgrad_kernel<1, 1, 4>", "wgrad_kernel<2, 2, 1>", "wgrad_kernel<1, 1, 8>",
                  "wgrad_kernel<1, 1, 3>", "wgrad_kernel<1, 1, 1>", "wgrad_kernel<2, 2, 3>",
                  "wgrad_row_kernel<3, 3, 1>", "wgrad_row_kernel<3, 3, -1>", "wgrad_row_kernel<1, 1, 1>",
@@ -259,7 +262,7 @@ def _ptr(t):
 
 # ---------------------------------------------------------------------------------------------- conv
 def _conv_args(x, w, geom, N, Cc, w_sn, w_sc, out, scale=None, bias=None, add1=None, add2=None, act=ACT_NONE,
-               mask=None, mask_slope=0.0, scale2=None, scale_split=0, out2=None):
+               mask=None, mask_slope=0.0, scale2=None, scale_split=0, out2=None, count=True):
     a = ConvArgs()
     a.g = geom
     a.inp, a.in_ld, a.C = x.data_ptr(), ld_of(x), Cc
@@ -276,7 +279,7 @@ def _conv_args(x, w, geom, N, Cc, w_sn, w_sc, out, scale=None, bias=None, add1=N
     a.mask, a.mask_ld, a.mask_slope = _ptr(mask), (ld_of(mask) if mask is not None else 0), mask_slope
     a.out2, a.out2_ld = _ptr(out2), (ld_of(out2) if out2 is not None else 0)
     a.ws, a.ws_bytes = None, 0
-    if FLOP_COUNT is not None:
+    if FLOP_COUNT is not None and count:
         _count("conv_mfma" if (Cc % 32 == 0 and N % 32 == 0) else "conv_valu", 2.0 * geom.B * geom.OH * geom.OW * N * Cc * geom.TH * geom.TW)
     return a
 
@@ -553,6 +556,27 @@ def irfft_rows(T, out, add1=None, add2=None, mask=None):
     check(_lib.lib().mtd_irfft_rows(T.data_ptr(), out.data_ptr(), ld_of(out), _ptr(add1), ld_of(add1) if add1 is not None else 0,
                                     _ptr(add2), ld_of(add2) if add2 is not None else 0, _ptr(mask),
                                     ld_of(mask) if mask is not None else 0, B, stream_ptr()), "mtd_irfft_rows")
+    return out
+
+
+CH32 = 32
+BLOCK_TAIL = os.environ.get("MTD_NO_BLOCK_TAIL", "0") != "1"      # conv3x3 + inverse row transform + residual in one launch
+
+
+def block_tail_ok(x, w, geom, img, bias):
+    """Does the layer qualify for mtd_resfft_block_tail (halo-tile kernel: 32 -> 32 channels, 64 x 64 maps, >= 32768 pixels)?"""
+    a = _conv_args(x, w, geom, CH32, CH32, CH32 * 9, 9, img, bias=bias, act=ACT_RELU, out2=img, count=False)
+    return bool(_lib.lib().mtd_resfft_block_tail_ok(C.byref(a)))
+
+
+def block_tail(x, w, geom, T, img, out, bias=None, act=ACT_RELU):
+    """img = act(conv3x3(x) + bias); out = x + img + irfft_rows(T) in one launch (mtd_resfft_block_tail)."""
+    L = _lib.lib()
+    a = _conv_args(x, w, geom, CH32, CH32, CH32 * 9, 9, out, bias=bias, act=act, out2=img)
+    _count("fft", x.shape[0] * 32 * _FFT_HALF_PLANE)
+    if FLOP_COUNT is not None:
+        FLOP_COUNT["launches"] -= 1                          # one launch for the conv and the row transform
+    check(L.mtd_resfft_block_tail(C.byref(a), T.data_ptr(), stream_ptr()), "mtd_resfft_block_tail")
     return out
 
 

@@ -529,3 +529,41 @@ def test_fused_c32_backward_launch(hip_lib, B):
         if second:
             assert relerr(nchw(o2_b), want) < TOL, kind
         assert relerr(nchw(o_b), want * (nchw(mask) > 0)) < TOL, kind
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [8, 32, 44])
+def test_resfft_block_tail_one_launch(hip_lib, B):
+    """mtd_resfft_block_tail (arch/Ours/networks.py:32-36): img = relu(conv3x3(x) + b) and out = x + img + irfft_rows(T) in
+    ONE launch of the halo-tile kernel against (a) the two launches it replaces and (b) torch on the CPU: conv2d + the c2r
+    row transform of torch.fft (ortho scale 1/8 per direction, imaginary parts of columns 0 and 32 ignored -- T is given
+    NON-Hermitian values there, as the post-ReLU spectrum of the block is).  B = 8: the smallest launch the halo-tile
+    kernel takes (128 tiles); 32: two tiles per workgroup; 44: 704 tiles on 256 workgroups (two and three tiles, so the
+    third tile's halo lands in a buffer the epilogue of the first has read x + irfft from)."""
+    from mtd_gan_amd import kernels as K
+    H = W = 64
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(B, H, W, 32, generator=gen).cuda()
+    T = torch.randn(B, 33, 64, 64, generator=gen).cuda()          # [b][kw][h][re 32 | im 32]
+    w = (torch.randn(32, 32, 3, 3, generator=gen) * 0.1).cuda()
+    bias = (torch.randn(32, generator=gen) * 0.1).cuda()
+    g = K.geom_fwd(B, H, W, 3, 1, 1)
+    img_a, out_a = torch.zeros(B, H, W, 32, device="cuda"), torch.zeros(B, H, W, 32, device="cuda")
+    K.conv(x, w, g, 32, 32, 32 * 9, 9, img_a, bias=bias, act=K.ACT_RELU)
+    K.irfft_rows(T, out_a, add1=x, add2=img_a)
+    img_b, out_b = torch.zeros(B, H, W, 32, device="cuda"), torch.zeros(B, H, W, 32, device="cuda")
+    assert K.block_tail_ok(x, w, g, img_b, bias)
+    K.block_tail(x, w, g, T, img_b, out_b, bias=bias, act=K.ACT_RELU)
+    torch.cuda.synchronize()
+    assert torch.equal(img_a, img_b)                               # the same MFMA sums and epilogue arithmetic
+    assert relerr(out_b.cpu(), out_a.cpu()) < 1e-5                 # (the two row transforms associate differently)
+    # torch on the CPU
+    xc, Tc = nchw(x).double(), T.cpu().double()
+    spec = torch.complex(Tc[..., :32], Tc[..., 32:]).permute(0, 3, 2, 1)          # (B, c, h, kw)
+    rows = torch.fft.irfft(spec, n=64, dim=-1, norm="ortho")                        # (B, c, h, w)
+    img = F.relu(F.conv2d(xc, w.cpu().double(), bias.cpu().double(), padding=1))
+    assert relerr(nchw(img_b), img) < TOL
+    assert relerr(nchw(out_b), xc + img + rows) < TOL
+    # shapes outside the halo-tile kernel's domain are refused, nothing is launched
+    small = torch.zeros(2, H, W, 32, device="cuda")
+    assert not K.block_tail_ok(small, w, K.geom_fwd(2, H, W, 3, 1, 1), small, bias)
