@@ -341,6 +341,12 @@ int mtd_hu_window(const short* hu, long long n, float a_min, float a_max, float*
 int mtd_conv_c32_bwd_ok(const mtd_conv_args* d, const mtd_wgrad_args* w);
 size_t mtd_conv_c32_bwd_ws_bytes(const mtd_conv_args* d, const mtd_wgrad_args* w);
 int mtd_conv_c32_bwd(const mtd_conv_args* d, const mtd_wgrad_args* w, int* nslab, long long* slab_stride, void* stream);
+/* The same launch closing the backward pass of a Res-FFT-Conv block (autograd of arch/Ours/networks.py:21-36):
+ *     d->out = mask'( dgrad + add1 + add2 + irfft_rows(gT) ),   gT = output of mtd_spec_mix_bwd / _bwd4,
+ * i.e. mtd_conv_c32_bwd followed by mtd_irfft_rows(gT, out, add1 = that result, mask) without the second launch: the
+ * rfft2-backward row transform is 33 more MFMAs per 32-pixel block against an inverse-DFT matrix in LDS.  64 x 64 maps. */
+int mtd_conv_c32_bwd_irfft(const mtd_conv_args* d, const mtd_wgrad_args* w, const float* gT, int* nslab, long long* slab_stride,
+                           void* stream);
 int mtd_conv_c32_bwd_stamps(unsigned long long* host256);   /* lab (MTD_C32F_STAMPS=1): clock stamps of the last launch's first 16 workgroups */
 
 /* ---- launch profiler (bench.py's roofline leg) ---------------------------------------------------------------

@@ -214,6 +214,7 @@ def lib():
     sig("mtd_conv_c32_bwd_ok", ci, C.POINTER(ConvArgs), C.POINTER(WgradArgs))
     sig("mtd_conv_c32_bwd_ws_bytes", sz, C.POINTER(ConvArgs), C.POINTER(WgradArgs))
     sig("mtd_conv_c32_bwd", ci, C.POINTER(ConvArgs), C.POINTER(WgradArgs), C.POINTER(C.c_int), C.POINTER(C.c_longlong), vp)
+    sig("mtd_conv_c32_bwd_irfft", ci, C.POINTER(ConvArgs), C.POINTER(WgradArgs), vp, C.POINTER(C.c_int), C.POINTER(C.c_longlong), vp)
     sig("mtd_conv_igemm_multi_ws_bytes", sz, C.POINTER(ConvArgs), ci)
     sig("mtd_conv_igemm_multi", ci, C.POINTER(ConvArgs), ci, vp)
     sig("mtd_resfft_block_tail_ok", ci, C.POINTER(ConvArgs))
@@ -238,7 +239,7 @@ EXPORTS = [
     "mtd_prof_mode", "mtd_pcgrad_coeff", "mtd_pcgrad_axpy", "mtd_conv_igemm_multi_ws_bytes", "mtd_conv_igemm_multi",
     "mtd_conv_c32_bwd_ok", "mtd_conv_c32_bwd_ws_bytes", "mtd_conv_c32_bwd",
     "mtd_spec_mix_zmask_bytes", "mtd_spec_mix_fwd4", "mtd_spec_mix_bwd4",
-    "mtd_resfft_block_tail_ok", "mtd_resfft_block_tail",
+    "mtd_resfft_block_tail_ok", "mtd_resfft_block_tail", "mtd_conv_c32_bwd_irfft",
 ]
 
 

@@ -31,6 +31,7 @@ struct C32BwdParams {
     int ntiles, iters;   // halo tiles of the launch; tiles per workgroup (same for every workgroup: barrier counts)
     int roles;           // lab switch MTD_C32F_ROLES: bit 0 = data-gradient waves compute, bit 1 = weight-gradient waves compute
     unsigned long long* stamps;      // lab: per workgroup 16 clock stamps (tools/c32f_probe.py), or null
+    const float* specT;              // SPEC: row spectrum [B][33][64][2][32] whose inverse row transform joins the data gradient
 };
 
 #define C32F_STAMP(i)                                                                              \
@@ -42,7 +43,11 @@ struct C32BwdParams {
         }                                                                                          \
     } while (0)
 
-template <int DX>
+// SPEC (mtd_conv_c32_bwd_irfft): the layer is the 3x3 conv of a Res-FFT-Conv block and the launch closes the block's backward
+// pass -- data gradient + irfft_rows(specT), the rfft2-backward row transform that was mtd_irfft_rows, a launch of its own
+// re-reading the data gradient -- as 33 more MFMAs per 32-pixel block against the inverse-DFT matrix in LDS, exactly as in
+// the forward tail (conv_igemm.hip, igemm_c32t_kernel SPEC).  The transform's result enters the epilogue as the second add.
+template <int DX, bool SPEC = false>
 __global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) {
     // Private halo per data-gradient wave: the 3 x 34 pixels around its 32-pixel block (13 DMA instructions of 8 pixels),
     // double-buffered.  Nothing in LDS is shared between waves except the weights, so the main loop has NO workgroup
@@ -56,10 +61,21 @@ __global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) 
     __shared__ __attribute__((aligned(1024))) float Hs0[ND][PNI * 256];
     __shared__ __attribute__((aligned(1024))) float Hs1[ND][PNI * 256];
     __shared__ __attribute__((aligned(1024))) float Bs[T * 32 * 32];
+    constexpr int DLD = 67;
+    __shared__ float Ds[SPEC ? 64 * DLD : 1];                // inverse row-DFT matrix (igemm_c32t_kernel SPEC)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kh = lane >> 5;
     const int iters = fp.iters;
+    if (SPEC) {
+        for (int e = tid; e < 64 * 66; e += 512) {           // (both roles; barrier 0 follows)
+            const int px = e / 66, kap = e - px * 66, kw = kap >> 1;
+            const int ang = (kw * px) & 63;
+            const float tv = (kap & 1) ? SIN64[ang & 31] : COS64[ang & 31];
+            const float wgt = (kw == 0 || kw == 32) ? 0.125f : 0.25f;
+            Ds[px * DLD + kap] = (((ang & 32) != 0) != ((kap & 1) != 0)) ? -wgt * tv : wgt * tv;
+        }
+    }
     const int nblk = 2 * iters;                              // 32-pixel blocks per wave, either role
     (void)fp.ntiles;
 
@@ -70,6 +86,8 @@ __global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) 
         const mtd_geom& g = a.g;
         typedef __attribute__((address_space(3))) float lds_f;
         const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)p.in_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SPEC ? fp.specT : a.in), (short)0,
+                                                                             SPEC ? g.B * NKW * 16384 : 0, 0x00020000);
         const int rsub = lane >> 3, piece = (lane & 7) ^ rsub;
         const bool on = (fp.roles & 1) != 0;
         // block k of this wave: 32 pixels from ((blockIdx.x * nblk + k) * ND + wave) * 32 -- half an image row
@@ -118,9 +136,19 @@ __global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) 
                 EpiWideOps weo;
                 wad.init(p, mbase, lane, 0, sp);
                 epiw_load(p, wad, weo);
+                float tb[NKW];                                // SPEC: the block's spectrum row, tb[kw] = T[b][kw][oy][kh][c = l31]
+                if (SPEC) {
+                    const int t2 = mbase / C32T_W;
+                    const int oy = t2 % g.OH, b = t2 / g.OH;
+                    const unsigned base = (unsigned)((((b * NKW) * 64 + oy) * 64 + kh * 32 + l31) * 4);
+#pragma unroll
+                    for (int kw = 0; kw < NKW; ++kw)
+                        tb[kw] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(trs, base, kw * 16384, 0));
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 auto frag = [&](int t, f32x4* af, f32x4* bf) {
-                    const int hp = hp0 + (g.off_y + p.tap_dy[t]) * PHW + (g.off_x + p.tap_dx[t]);
+                    int hp = hp0 + (g.off_y + p.tap_dy[t]) * PHW + (g.off_x + p.tap_dx[t]);
+                    if (SPEC) asm volatile("" : "+v"(hp));       // piece addresses re-derived per tap (register budget: conv_igemm.hip)
                     const float* px = &H[hp * 32];
                     const int sw = hp & 7;
                     const float* row = &Bs[(t * 32 + l31) * 32];
@@ -140,6 +168,18 @@ __global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) 
                     if (t + 1 < T) frag(t + 1, af[(t + 1) & 1], bf[(t + 1) & 1]);
 #pragma unroll
                     for (int kk = 0; kk < 16; ++kk) acc = mfma32(bf[t & 1][kk >> 2][kk & 3], af[t & 1][kk >> 2][kk & 3], acc);   // transposed block
+                }
+                if (SPEC) {
+                    f32x16 acc2;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+                    const float* drow = &Ds[((mbase % C32T_W) + l31) * DLD + kh];
+#pragma unroll
+                    for (int kw = 0; kw < NKW; ++kw) acc2 = mfma32(tb[kw], drow[2 * kw], acc2);
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) weo.e2[g4][j] += acc2[4 * g4 + j];      // (absent add2 = -0.0f: the sum is acc2 exactly)
                 }
                 epiw_store(p, acc, wad, bias4, weo);             // 16-byte vectors; the stores drain under the next block's MFMAs
             }
@@ -329,9 +369,30 @@ extern "C" size_t mtd_conv_c32_bwd_ws_bytes(const mtd_conv_args* d, const mtd_wg
     return (size_t)grid * (size_t)(9 * 32 * 32 + 32) * sizeof(float);
 }
 
+namespace {
+int c32_bwd_launch(const mtd_conv_args* d, const mtd_wgrad_args* w, const float* specT, int* nslab, long long* slab_stride, void* stream);
+}
+
 // d: as for mtd_conv_igemm; w: as for mtd_conv_wgrad_slabs (slabs into w->ws, *nslab slabs of *slab_stride floats, to be
 // summed by mtd_conv_wgrad_reduce_multi / the per-layer reduce).
 extern "C" int mtd_conv_c32_bwd(const mtd_conv_args* d, const mtd_wgrad_args* w, int* nslab, long long* slab_stride, void* stream) {
+    return c32_bwd_launch(d, w, nullptr, nslab, slab_stride, stream);
+}
+
+// The same launch closing the backward pass of a Res-FFT-Conv block (arch/Ours/networks.py:21-36 backward):
+//     d->out = mask'( dgrad + add1 + add2 + irfft_rows(gT) )        gT = output of mtd_spec_mix_bwd / _bwd4
+// = mtd_conv_c32_bwd followed by mtd_irfft_rows(gT, out, add1 = its result, mask), in one launch.  64 x 64 maps, d->add2 may
+// be used as before (the transform joins it).
+extern "C" int mtd_conv_c32_bwd_irfft(const mtd_conv_args* d, const mtd_wgrad_args* w, const float* gT, int* nslab, long long* slab_stride,
+                                      void* stream) {
+    if (!gT || !d || d->g.OH != 64) return MTD_EINVAL;
+    if (!aligned16(gT)) return MTD_EALIGN;
+    if ((long long)d->g.B * NKW * 16384 >= (1ll << 31)) return MTD_EINVAL;
+    return c32_bwd_launch(d, w, gT, nslab, slab_stride, stream);
+}
+
+namespace {
+int c32_bwd_launch(const mtd_conv_args* d, const mtd_wgrad_args* w, const float* specT, int* nslab, long long* slab_stride, void* stream) {
     if (!nslab || !slab_stride || !mtd_conv_c32_bwd_ok(d, w)) return MTD_EINVAL;
     C32BwdParams fp;
     Plan pl{};
@@ -368,18 +429,26 @@ extern "C" int mtd_conv_c32_bwd(const mtd_conv_args* d, const mtd_wgrad_args* w,
     static const bool want_stamps = getenv("MTD_C32F_STAMPS") != nullptr;
     if (want_stamps && !g_c32f_stamps && hipMalloc(&g_c32f_stamps, 256 * sizeof(unsigned long long)) != hipSuccess) g_c32f_stamps = nullptr;
     fp.stamps = g_c32f_stamps;
+    fp.specT = specT;
     if (!w->ws || w->ws_bytes < (size_t)grid * (size_t)p.slab_stride * sizeof(float)) return MTD_EWS;
     hipStream_t s = (hipStream_t)stream;
-    const int prof = mtd_prof_begin(0, 11, 1, 2ll * p.M, 32, 32, 9, s,
-                                    algorithmic_bytes(d) + 4.0 * ((double)p.M * 32 + (double)p.M * 32 + 9.0 * 32 * 32));
-    if (w->g.tap_dx > 0) MTD_LAUNCH((c32_bwd_kernel<1>), dim3(grid), dim3(512), 0, s, fp);
-    else MTD_LAUNCH((c32_bwd_kernel<-1>), dim3(grid), dim3(512), 0, s, fp);
+    const int prof = mtd_prof_begin(0, specT ? 13 : 11, 1, 2ll * p.M, 32, 32, 9, s,
+                                    algorithmic_bytes(d) + 4.0 * ((double)p.M * 32 + (double)p.M * 32 + 9.0 * 32 * 32) +
+                                        (specT ? 4.0 * d->g.B * NKW * 4096 : 0.0));
+    if (specT) {
+        if (w->g.tap_dx > 0) MTD_LAUNCH((c32_bwd_kernel<1, true>), dim3(grid), dim3(512), 0, s, fp);
+        else MTD_LAUNCH((c32_bwd_kernel<-1, true>), dim3(grid), dim3(512), 0, s, fp);
+    } else {
+        if (w->g.tap_dx > 0) MTD_LAUNCH((c32_bwd_kernel<1>), dim3(grid), dim3(512), 0, s, fp);
+        else MTD_LAUNCH((c32_bwd_kernel<-1>), dim3(grid), dim3(512), 0, s, fp);
+    }
     mtd_prof_end(prof, s);
     MTD_LAUNCH_CHECK();
     *nslab = grid;
     *slab_stride = p.slab_stride;
     return MTD_OK;
 }
+}  // namespace
 
 // lab (tools/c32f_probe.py): copy of the clock stamps of the last fused launch (MTD_C32F_STAMPS=1), 256 values
 extern "C" int mtd_conv_c32_bwd_stamps(unsigned long long* host256) {

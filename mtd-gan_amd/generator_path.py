@@ -60,6 +60,18 @@ def block_backward(g, saved, w_img, w_fft, grads, premask, defer=None, gm=None):
     side = K.side_stream(x.device)
     if gm is None:
         gm = K.act_grad(g, img, 0.0)                                                # g * (img > 0)
+    if K.BLOCK_TAIL and defer is not None and K.DEFER_WGRADS and not K.FUSE_WGRAD_ROWS:
+        # spectral chain first; the block conv's fused data + weight gradient launch then also takes the closing row
+        # transform: gx = (dgrad(gm) + g + irfft_rows(gT)) * (x > 0)  (mtd_conv_c32_bwd_irfft)
+        gx = K.empty_nhwc(B, H, W, CH, x)
+        dg = ((gm, w_img, K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, gx),
+              dict(add1=g, mask=x if premask else None, mask_slope=0.0))
+        wg = ((gm, x, K.geom_fwd(B, H, W, 3, 1, 1), CH, CH, grads["dw_img"], CH * 9, 9), dict(db=grads["db_img"]))
+        if K.conv_wgrad_fusable(dg, wg):
+            gR = K.rfft_rows(g, 1)                                                  # irfft2 backward
+            gT = K.spec_mix_bwd(gR, w_fft, S, Z, grads["dw_fft"], grads["db_fft"], defer=defer)
+            assert K.conv_wgrad_fused(dg, wg, defer, spec=gT)
+            return gx
     # the block conv's weight gradient and the row transform that opens the spectral backward chain read the same
     # cotangent: one launch when the slab sums are deferred (kernels.wgrad rows=...), at the head of the spectral stream
     fused_rows = defer is not None and K.DEFER_WGRADS and K.FUSE_WGRAD_ROWS

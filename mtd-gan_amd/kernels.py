@@ -115,7 +115,7 @@ CALL_LOG = None     # tools/tune_igemm.py: a list collects ("igemm" | "wgrad", b
 IGEMM_CONFIGS = ["igemm_kernel<2, 1, 4, 1>", "igemm_kernel<1, 1, 4, 1>", "igemm_kernel<2, 2, 4, 1>",
                  "igemm_kernel<1, 1, 2, 2>", "igemm_kernel<2, 2, 2, 2>", "igemm_kernel<1, 1, 1, 4>",
                  "igemm_tb_kernel<1>", "igemm_tb_kernel<2>", "igemm_v2_kernel<0>", "igemm_c32p_kernel", "igemm_c32t_kernel", "c32_bwd_kernel",
-                 "igemm_c32t_kernel<4, true, true, true>", "?", "?", "?",        # 12: Res-FFT block tail (mtd_resfft_block_tail)
+                 "igemm_c32t_kernel<4, true, true, true>", "c32_bwd_kernel<spec>", "?", "?",      # 12: Res-FFT block tail; 13: c32_bwd + irfft
                  "igemm_multi_kernel<2, 1, 4, 1>", "igemm_multi_kernel<1, 1, 4, 1>", "igemm_multi_kernel<2, 2, 4, 1>",      # 16 + cfg
                  "igemm_multi_kernel<1, 1, 2, 2>", "igemm_multi_kernel<2, 2, 2, 2>", "igemm_multi_kernel<1, 1, 1, 4>"]
 WGRAD_CONFIGS = ["wgrad_kernel<1, 1, 9>", "wgrad_kernel<1, 1, 4>", "wgrad_kernel<2, 2, 1>", "wgrad_kernel<1, 1, 8>",
@@ -452,11 +452,28 @@ def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumula
 FUSE_C32_BWD = os.environ.get("MTD_NO_FUSED_C32_BWD", "0") != "1"
 
 
-def conv_wgrad_fused(conv_call, wgrad_call, defer):
+def conv_wgrad_fusable(conv_call, wgrad_call):
+    """Would conv_wgrad_fused take this pair (given deferred slab sums)?  Nothing is launched or counted."""
+    (p_, q_, geom, N, Cc, dw, w_sn, w_sc), wkw = wgrad_call
+    if not (FUSE_C32_BWD and DEFER_WGRADS and N == 32 and Cc == 32 and not wkw.get("accumulate")):
+        return False
+    d = _conv_args(*conv_call[0], count=False, **conv_call[1])
+    a = WgradArgs()
+    a.g = geom
+    a.p, a.p_ld, a.N = p_.data_ptr(), ld_of(p_), N
+    a.q, a.q_ld, a.C = q_.data_ptr(), ld_of(q_), Cc
+    a.dw, a.w_sn, a.w_sc = dw.data_ptr(), w_sn, w_sc
+    a.db = _ptr(wkw.get("db"))
+    return bool(_lib.lib().mtd_conv_c32_bwd_ok(C.byref(d), C.byref(a)))
+
+
+def conv_wgrad_fused(conv_call, wgrad_call, defer, spec=None):
     """The data gradient and the weight gradient of one 32 -> 32 channel 3x3 generator layer in ONE launch
     (mtd_conv_c32_bwd: the eight waves of a workgroup split by role) when the pair is eligible and the weight-gradient
     slab sums are deferred; otherwise the two launches, the weight gradient through `side` as before.
-    conv_call = (args, kw) of conv(); wgrad_call = (args, kw) of wgrad() without `defer`.  Returns True if fused."""
+    conv_call = (args, kw) of conv(); wgrad_call = (args, kw) of wgrad() without `defer`.  Returns True if fused.
+    spec = gT (output of spec_mix_bwd): the launch closes a Res-FFT-Conv block's backward pass, its data gradient also takes
+    irfft_rows(gT) (mtd_conv_c32_bwd_irfft instead of a mtd_irfft_rows launch)."""
     (p_, q_, geom, N, Cc, dw, w_sn, w_sc), wkw = wgrad_call
     if not (FUSE_C32_BWD and defer is not None and DEFER_WGRADS and N == 32 and Cc == 32 and not wkw.get("accumulate")):
         return False
@@ -483,7 +500,14 @@ def conv_wgrad_fused(conv_call, wgrad_call, defer):
     ws = _layer_ws(need, defer, p_.device)
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     nslab, stride = C.c_int(0), C.c_longlong(0)
-    check(L.mtd_conv_c32_bwd(C.byref(d), C.byref(a), C.byref(nslab), C.byref(stride), stream_ptr()), "mtd_conv_c32_bwd")
+    if spec is not None:
+        _count("fft", spec.shape[0] * 32 * _FFT_HALF_PLANE)
+        if FLOP_COUNT is not None:
+            FLOP_COUNT["launches"] -= 1
+        check(L.mtd_conv_c32_bwd_irfft(C.byref(d), C.byref(a), spec.data_ptr(), C.byref(nslab), C.byref(stride), stream_ptr()),
+              "mtd_conv_c32_bwd_irfft")
+    else:
+        check(L.mtd_conv_c32_bwd(C.byref(d), C.byref(a), C.byref(nslab), C.byref(stride), stream_ptr()), "mtd_conv_c32_bwd")
     r = _lib.WgradReduceDesc()
     r.a, r.T, r.nslab, r.slab_stride = a, 9, nslab.value, stride.value
     r.a.p, r.a.q = None, None

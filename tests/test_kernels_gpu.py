@@ -567,3 +567,46 @@ def test_resfft_block_tail_one_launch(hip_lib, B):
     # shapes outside the halo-tile kernel's domain are refused, nothing is launched
     small = torch.zeros(2, H, W, 32, device="cuda")
     assert not K.block_tail_ok(small, w, K.geom_fwd(2, H, W, 3, 1, 1), small, bias)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [2, 20, 32])
+def test_fused_c32_backward_launch_with_row_transform(hip_lib, B):
+    """mtd_conv_c32_bwd_irfft: the fused data + weight gradient launch of a block's 3x3 conv also takes the closing row
+    transform of the block's backward pass, gx = (dgrad(gm) + g + irfft_rows(gT)) * (x > 0), against the two launches it
+    replaces (mtd_conv_c32_bwd, then mtd_irfft_rows with the data gradient as its add) and against torch on the CPU."""
+    from mtd_gan_amd import kernels as K
+    H = W = 64
+    gen = torch.Generator().manual_seed(13)
+    r = lambda *s: torch.randn(*s, generator=gen).cuda()
+    gm, x, g = r(B, H, W, 32), r(B, H, W, 32), r(B, H, W, 32)
+    gT = r(B, 33, 64, 64)
+    w = (torch.randn(32, 32, 3, 3, generator=gen) * 0.1).cuda()
+    gd, gf = K.geom_dgrad_s1(B, H, W, 3, 1), K.geom_fwd(B, H, W, 3, 1, 1)
+    res = []
+    for fused in (False, True):
+        dw, db = torch.zeros(32, 32, 3, 3, device="cuda"), torch.zeros(32, device="cuda")
+        gx = torch.zeros(B, H, W, 32, device="cuda")
+        defer = K.DeferredWgrads()
+        wg = ((gm, x, gf, 32, 32, dw, 32 * 9, 9), dict(db=db))
+        if fused:
+            dg = ((gm, w, gd, 32, 32, 9, 32 * 9, gx), dict(add1=g, mask=x, mask_slope=0.0))
+            assert K.conv_wgrad_fusable(dg, wg)
+            assert K.conv_wgrad_fused(dg, wg, defer, spec=gT)
+        else:
+            d1 = torch.zeros(B, H, W, 32, device="cuda")
+            assert K.conv_wgrad_fused(((gm, w, gd, 32, 32, 9, 32 * 9, d1), dict(add1=g)), wg, defer)
+            K.irfft_rows(gT, gx, add1=d1, mask=x)
+        K.flush_wgrads(defer)
+        torch.cuda.synchronize()
+        res.append((gx, dw, db))
+    (gx_a, dw_a, db_a), (gx_b, dw_b, db_b) = res
+    assert torch.equal(dw_a, dw_b) and torch.equal(db_a, db_b)       # the weight-gradient role is untouched
+    assert relerr(gx_b.cpu(), gx_a.cpu()) < 1e-5
+    # torch on the CPU: conv's input gradient + g + c2r row transform, masked
+    spec = torch.complex(gT.cpu().double()[..., :32], gT.cpu().double()[..., 32:]).permute(0, 3, 2, 1)
+    rows = torch.fft.irfft(spec, n=64, dim=-1, norm="ortho")
+    xin = torch.zeros(B, 32, H, W, dtype=torch.double, requires_grad=True)
+    (F.conv2d(xin, w.cpu().double(), None, padding=1) * nchw(gm).double()).sum().backward()
+    want = (xin.grad + nchw(g).double() + rows) * (nchw(x) > 0)
+    assert relerr(nchw(gx_b), want) < TOL
