@@ -70,6 +70,22 @@ def launch_ranks(args, argv):
         env = dict(env0, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+
+    def stop(signum, _frame):
+        # the launcher was told to stop (scheduler, watchdog): ranks blocked in a collective would otherwise keep the GPUs
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        deadline = time.time() + 5.0
+        while time.time() < deadline and any(q.poll() is None for q in procs):
+            time.sleep(0.05)
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+        sys.exit(128 + signum)
+    import signal
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, stop)
     rc = 0
     pending = list(procs)
     while pending:
@@ -343,12 +359,20 @@ def main(argv=None):
         return dry_run(args, rank, world)
     import torch
     import torch.distributed as dist
+    # MTD_DP_SHARE_GPU=1: rehearsal of the N > 1 schedule on a one-GPU box -- every rank on device 0, gloo instead of RCCL
+    # (RCCL refuses two ranks on one device).  The line then says so (config.parallelism) and is no scaling figure.
+    share_gpu = os.environ.get("MTD_DP_SHARE_GPU", "0") == "1" and world > 1
+    if share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 or os.environ.get("MTD_FORCE_DP", "0") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     ranks_seen = dist.get_world_size() if dist.is_initialized() else 1
 
     import __graft_entry__ as ge
@@ -415,6 +439,8 @@ def main(argv=None):
                 "n_gpus": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": getattr(wl, "dtype", "f32"), "data": "synthetic",
                 "config": wl.config(ranks_seen), "roofline": roofline, "cpu_baseline": cpu}
+        if share_gpu:
+            line["config"]["parallelism"] += " (rehearsal: all ranks on ONE GPU, gloo through the host -- not a scaling figure)"
         line.update(wl.extra())
         line.update(extra)
         if "algorithmic_gflop_per_patch" in line:          # whole-step rate against the same peak, from the timed region

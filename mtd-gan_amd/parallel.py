@@ -19,6 +19,9 @@ class DataParallelSync:
         self.force = os.environ.get("MTD_FORCE_DP", "0") == "1"
         self.device = device
         self.cuda = device is not None and torch.device(device).type == "cuda"
+        # RCCL averages inside the collective (ReduceOp.AVG); gloo -- CPU tests, and the two-ranks-on-one-GPU rehearsal of
+        # tests/dp_two_ranks_one_gpu.py, where RCCL cannot put two ranks on one device -- only sums: scale afterwards
+        self.has_avg = dist.get_backend() == "nccl"
         self.side = torch.cuda.Stream(device=device) if self.cuda else None
         self._pending = []
 
@@ -74,7 +77,11 @@ class DataParallelSync:
             self.side.wait_event(ev)
             flat.record_stream(self.side)
             with torch.cuda.stream(self.side):
-                dist.all_reduce(flat, op=dist.ReduceOp.AVG)      # RCCL scales inside the collective: no extra pass over 114 MB
+                if self.has_avg:
+                    dist.all_reduce(flat, op=dist.ReduceOp.AVG)  # RCCL scales inside the collective: no extra pass over 114 MB
+                else:
+                    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                    flat.mul_(1.0 / self.world)
             done = torch.cuda.Event()
             done.record(self.side)
             self._pending.append(done)
@@ -98,7 +105,7 @@ class DataParallelSync:
             return
         self.wait()
         flat = torch.cat([t.reshape(-1) for t in tensors])
-        if self.cuda:
+        if self.cuda and self.has_avg:
             dist.all_reduce(flat, op=dist.ReduceOp.AVG)
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)          # gloo has no AVG
