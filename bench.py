@@ -443,6 +443,12 @@ def main(argv=None):
             line["config"]["parallelism"] += " (rehearsal: all ranks on ONE GPU, gloo through the host -- not a scaling figure)"
         line.update(wl.extra())
         line.update(extra)
+        if hasattr(wl, "engine_api_ms") and world == 1:
+            # the same iterations through the kept API (engine.train_MTD_GAN_Ours, reference engine.py:26-76): the timed step above
+            # is that loop's body, this is the loop itself
+            ams = wl.engine_api_ms(args.steps)
+            line["engine_api"] = {"ms_per_step": round(ams, 3), "value": round(per_gpu_units * 1e3 / ams, 2), "unit": "img/s",
+                                  "what": "engine.train_MTD_GAN_Ours over the same resident batch, steps iterations, logging included"}
         if "algorithmic_gflop_per_patch" in line:          # whole-step rate against the same peak, from the timed region
             tf = line["algorithmic_gflop_per_patch"] * per_gpu_units / (ms * 1e-3) / 1e3
             line["step_tflops_per_gpu"] = round(tf, 2)

@@ -197,7 +197,55 @@ class UpsampleBlock(nn.Module):
             nn.PixelShuffle(upscale_factor=scale))
 
     def forward(self, input):
-        raise RuntimeError("UpsampleBlock is executed inside Multi_Task_Discriminator_Skip's fused HIP schedule")
+        """Stand-alone use (inside Multi_Task_Discriminator_Skip the same two steps run in place in the decoder's concatenated
+        buffer, discriminator_path.disc_forward): conv1x1 on the implicit GEMM, PixelShuffle(2) as its own kernel."""
+        _require_cuda(input, "UpsampleBlock")
+        conv, ps = self.upsample[0], self.upsample[1]
+        if ps.upscale_factor != 2:
+            raise NotImplementedError("UpsampleBlock HIP path: PixelShuffle(2) only (the only scale the reference uses, networks.py:267-301)")
+        if input.dim() != 4 or input.shape[1] != conv.in_channels:
+            raise RuntimeError(f"UpsampleBlock: expected (B, {conv.in_channels}, H, W), got {tuple(input.shape)}")
+        if conv.in_channels % 32 or conv.out_channels % 32:
+            raise NotImplementedError("UpsampleBlock HIP path: channel counts in multiples of 32 (the implicit-GEMM and weight-gradient "
+                                      "kernels' tiles; the reference's six instances are 512 / 256 / 128 / 64 -> the same)")
+        return _UpsampleFn.apply(input.contiguous().float(), conv.weight, conv.bias)
+
+
+class _UpsampleFn(torch.autograd.Function):
+    """conv1x1 (C -> 4 C') + PixelShuffle(2) and its autograd transpose on the HIP kernels (reference networks.py:166-175)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        B, Ci, H, W = x.shape
+        C4 = w.shape[0]
+        xn = x.permute(0, 2, 3, 1).contiguous()                              # NHWC
+        up = K.empty_nhwc(B, H, W, C4, xn)
+        K.conv(xn, w.detach(), K.geom_fwd(B, H, W, 1, 1, 0), C4, Ci, Ci, 1, up, bias=b.detach() if b is not None else None)
+        out = K.empty_nhwc(B, 2 * H, 2 * W, C4 // 4, xn)
+        K.pixel_shuffle2_fwd(up, out)
+        ctx.save_for_backward(xn, w)
+        ctx.has_bias = b is not None
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        xn, w = ctx.saved_tensors
+        B, H, W, Ci = xn.shape
+        C4 = w.shape[0]
+        gn = g.permute(0, 2, 3, 1).contiguous().float()
+        gr = K.empty_nhwc(B, H, W, C4, xn)
+        K.pixel_shuffle2_bwd(gn, gr)
+        gq = K.geom_fwd(B, H, W, 1, 1, 0)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gxn = K.empty_nhwc(B, H, W, Ci, xn)
+            K.conv(gr, w.detach(), gq, Ci, C4, 1, Ci, gxn)                  # W^T: W(n = ci, c = co) = w[co*Ci + ci]
+            gx = gxn.permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw = torch.zeros_like(w)
+            gb = torch.zeros(C4, dtype=torch.float32, device=w.device) if ctx.has_bias else None
+            K.wgrad(gr, xn, gq, C4, Ci, gw, Ci, 1, db=gb)
+        return gx, gw, gb
 
 
 class _DiscFn(torch.autograd.Function):

@@ -50,25 +50,66 @@ class _Meter:
         return self.total / self.count
 
 
-def train_MTD_GAN_Ours(model, data_loader, optimizer_G, optimizer_D, device, epoch, print_freq, batch_size, method_D):
+class LoggedScalars:
+    """The iteration's ONE device -> host copy, taken off the host's critical path: the 17 logged values go to a pinned
+    buffer with an asynchronous copy and are read one iteration later (or at once when a line is due to be printed), so the
+    host keeps enqueuing the next iteration instead of waiting for this one to finish on the GPU.  The reference's
+    MetricLogger.update calls `.item()` 16 times per iteration (utils.py:60-65)."""
+
+    def __init__(self, meters, batch_size):
+        self.meters, self.batch_size, self.pending = meters, batch_size, None
+
+    def push(self, names, vals, lr):
+        if vals.is_cuda:
+            host = torch.empty(vals.shape, dtype=vals.dtype, pin_memory=True)
+            host.copy_(vals, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            host, ev = vals, None
+        self.drain()
+        self.pending = (names, host, ev, lr)
+
+    def drain(self):
+        if self.pending is None:
+            return
+        names, host, ev, lr = self.pending
+        self.pending = None
+        if ev is not None:
+            ev.synchronize()
+        for k, v in zip(names, host.tolist()):
+            self.meters.setdefault(k, _Meter()).update(v, self.batch_size)
+        self.meters.setdefault("lr", _Meter()).update(lr, self.batch_size)
+
+
+def train_MTD_GAN_Ours(model, data_loader, optimizer_G, optimizer_D, device, epoch, print_freq, batch_size, method_D, dp=None):
+    """`dp`: optional data-parallel hook (parallel.DataParallelSync).  With PCGrad it defaults to the hook attached to the
+    weight method (method_D.method.dp); the ablation wrappers' path (method_D=None) has no weight method to carry it, so a
+    multi-process run passes it here -- and a process group of more than one rank without a hook is refused rather than
+    left to train unsynchronised replicas."""
     model.Generator.train(True)
     model.Discriminator.train(True)
     if method_D is None and type(model).__name__ == "MTD_GAN_Method":
         raise NotImplementedError("the reference's method_D=None branch calls .backward() on MTD_GAN_Method's 3-vector and raises; "
                                   "use WeightMethods('pcgrad') (method_D=None is the ablation wrappers' path)")
     meters = {}
-    dp = getattr(getattr(method_D, "method", None), "dp", None)
+    if dp is None:
+        dp = getattr(getattr(method_D, "method", None), "dp", None)
+    if dp is None and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        raise RuntimeError("train_MTD_GAN_Ours: torch.distributed is initialised with more than one rank but no data-parallel hook was "
+                           "given (pass dp=parallel.DataParallelSync(device), or attach it to the weight method): the ranks would "
+                           "train unsynchronised replicas")
     n_it = len(data_loader)
+    logged = LoggedScalars(meters, batch_size)
     for it, batch_data in enumerate(data_loader):
         x = batch_data["n_20"].to(device).float()
         y = batch_data["n_100"].to(device).float()
         names, vals = train_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp)
-        host = vals.tolist()                          # the iteration's single device -> host copy
-        for k, v in zip(names, host):
-            meters.setdefault(k, _Meter()).update(v, batch_size)
-        meters.setdefault("lr", _Meter()).update(optimizer_G.param_groups[0]["lr"], batch_size)
+        logged.push(names, vals, optimizer_G.param_groups[0]["lr"])
         if print_freq and (it % print_freq == 0 or it == n_it - 1):
+            logged.drain()                            # a printed line shows this iteration, as the reference's does
             print(f"Train: [epoch:{epoch}] [{it}/{n_it}] " + "  ".join(f"{k}: {m.global_avg:.4f}" for k, m in meters.items()), flush=True)
+    logged.drain()
     order = ["lr"] + [k for k in meters if k != "lr"]
     return {k: round(meters[k].global_avg, 7) for k in order}
 

@@ -473,8 +473,26 @@ class FullStepWorkload:
             self.step_eager()
 
     def step_eager(self):
+        # one iteration as engine.train_MTD_GAN_Ours runs it: the schedule plus the logged scalars' lagged device -> host copy
         from . import engine
-        engine.train_iteration(self.model, self.x, self.y, self.oG, self.oD, self.wm, self.dp)
+        if getattr(self, "_logged", None) is None:
+            self._meters = {}
+            self._logged = engine.LoggedScalars(self._meters, self.batch)
+        names, vals = engine.train_iteration(self.model, self.x, self.y, self.oG, self.oD, self.wm, self.dp)
+        self._logged.push(names, vals, self.oG.param_groups[0]["lr"])
+
+    def engine_api_ms(self, steps):
+        """ms per iteration of `steps` iterations through the kept API itself, engine.train_MTD_GAN_Ours (same 9 positional
+        arguments as reference engine.py:26), on a loader of `steps` resident batches -- what a caller of the reference's
+        training loop sees, host-side logging included."""
+        import time
+        from . import engine
+        loader = [dict(n_20=self.x, n_100=self.y)] * steps
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        engine.train_MTD_GAN_Ours(self.model, loader, self.oG, self.oD, self.x.device, 0, 0, self.batch, self.wm)
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / steps
 
     def config(self, world):
         return {"workload": "Full G+D+PCGrad train step (BASELINE configs[2]; configs[3] when N>1)", "per_gpu_batch": self.batch,

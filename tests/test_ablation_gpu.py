@@ -15,6 +15,28 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TOL = 1e-3
 
 
+def _sample_idx(numel, k):
+    return [(i * 2654435761 + 12345) % numel for i in range(k)]
+
+
+def _check_elements(tag, named_grads, gold):
+    """Sampled ELEMENTS of every gradient tensor against tests/golden/ablation_grad_samples.json (oracle/pin_grad_samples.py):
+    the float64 value at each sampled position, bound max(1e-3, 2 x the reference's own fp32-vs-float64 error on that tensor)
+    relative to the tensor's max-abs.  A gradient with the right norm but permuted or mis-scattered entries fails here."""
+    bad = []
+    for n, g in named_grads:
+        e = gold[n]
+        flat = g.detach().reshape(-1)
+        idx = _sample_idx(flat.numel(), len(e["f64"]))
+        got = flat[torch.tensor(idx, device=flat.device)].double().cpu().tolist()
+        bound = max(TOL, 2 * e["err32"]) * e["maxabs"]
+        for j, (a, b) in enumerate(zip(got, e["f64"])):
+            if abs(a - b) > bound + 1e-30:
+                bad.append((tag, n, j, a, b, bound))
+        assert abs(flat.abs().max().item() - e["maxabs"]) <= 5e-3 * e["maxabs"] + 1e-30, (tag, n)
+    assert not bad, bad[:8]
+
+
 def _build(name, c):
     from mtd_gan_amd.arch.Ours import networks as N
     m = getattr(N, name)()
@@ -54,6 +76,9 @@ def test_ablation_wrapper_vs_reference_vectors(hip_lib, name):
         if abs(p.grad.double().norm().item() - want) > 5e-3 * want + 1e-12:
             bad.append((n, p.grad.double().norm().item(), want))
     assert not bad, (name, bad[:6])
+    gs = json.load(open(os.path.join(GOLD, "ablation_grad_samples.json")))[name]
+    assert set(gs["d"].keys()) == {n for n, p in m.Discriminator.named_parameters() if p.grad is not None}, name
+    _check_elements(name + " d_loss", [(n, p.grad) for n, p in m.Discriminator.named_parameters() if p.grad is not None], gs["d"])
     for p in m.parameters():
         p.grad = None
     g_tot, g_det = m.g_loss(xd, yd)
@@ -69,6 +94,7 @@ def test_ablation_wrapper_vs_reference_vectors(hip_lib, name):
         if abs(p.grad.double().norm().item() - want) > 5e-3 * want + 1e-12:
             bad.append((n, p.grad.double().norm().item(), want))
     assert not bad, (name, bad[:6])
+    _check_elements(name + " g_loss", list((n, p.grad) for n, p in m.Generator.named_parameters()), gs["g"])
 
 
 def test_redcnn_generator_gradients_vs_fp64_oracle(hip_lib):

@@ -129,3 +129,63 @@ def test_projection_order_is_a_collective_decision():
         for rank in range(2):
             assert res[rank][step][1][:9] == expect[step], (rank, step, res[rank][step])
     assert any(res[1][s][0] != res[0][s][0] for s in range(3))        # the ranks' own draws did differ
+
+
+def _ablation_worker(rank, world, port, out):
+    """engine.train_MTD_GAN_Ours on the ablation wrappers' path (method_D=None: no weight method to carry the data-parallel
+    hook) in a two-rank group: without a hook it must refuse to train unsynchronised replicas; with dp= it averages the
+    discriminator and generator gradients across the ranks (a tiny CPU stand-in for the wrapper: the collective logic and
+    the engine's control flow are the product's, no kernel runs)."""
+    import torch.nn as nn
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mtd_gan_amd import engine
+    from mtd_gan_amd.parallel import DataParallelSync
+
+    class Wrapper(nn.Module):                       # an Ablation_* look-alike: d_loss / g_loss return one scalar + a dict
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(3)
+            self.Generator, self.Discriminator = nn.Linear(4, 4), nn.Linear(4, 1)
+
+        def d_loss(self, x, y):
+            lo = (self.Discriminator(y) - 1).pow(2).mean() + self.Discriminator(self.Generator(x).detach()).pow(2).mean()
+            return lo, {"D/a": lo.detach()}
+
+        def g_loss(self, x, y):
+            lo = (self.Generator(x) - y).abs().mean()
+            return lo, {"G/a": lo.detach()}
+    m = Wrapper()
+    oG, oD = torch.optim.SGD(m.Generator.parameters(), lr=0.1), torch.optim.SGD(m.Discriminator.parameters(), lr=0.1)
+    g = torch.Generator().manual_seed(10 + rank)       # every rank its own shard
+    loader = [dict(n_20=torch.randn(8, 4, generator=g), n_100=torch.randn(8, 4, generator=g))]
+    refused = False
+    try:
+        engine.train_MTD_GAN_Ours(m, loader, oG, oD, torch.device("cpu"), 0, 0, 8, None)
+    except RuntimeError as e:
+        refused = "data-parallel hook" in str(e)
+    engine.train_MTD_GAN_Ours(m, loader, oG, oD, torch.device("cpu"), 0, 0, 8, None, dp=DataParallelSync(device=None))
+    w = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    both = [torch.zeros_like(w) for _ in range(world)]
+    dist.all_gather(both, w)
+    out.put((rank, refused, bool(torch.equal(both[0], both[1]))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_ablation_path_needs_and_uses_the_dp_hook():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ablation_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get() for _ in procs]
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    for rank, refused, same in res:
+        assert refused, rank          # no hook in a two-rank group: refused
+        assert same, rank             # with the hook: the replicas stay identical (gradients averaged before each update)

@@ -96,3 +96,34 @@ def test_eval_loops_mirror_reference_surface(hip_lib, tmp_path):
     assert abs(t["pred_ssim"] - orc.ssim(ref.clip(0, 1), y).item()) < 2e-5
     assert abs(t["input_rmse"] - orc.rmse(x, y).item()) < 1e-6
     assert os.path.exists(os.path.join(str(tmp_path), "pred_results.csv"))
+
+
+def test_whole_slice_512_batch_8(hip_lib):
+    """BASELINE configs[4] at its stated batch: eight 512 x 512 slices through the generator in ONE call (reference
+    engine.py:89,129 runs whole slices), PSNR / SSIM / RMSE of the clipped prediction (metrics.py:172-244).  Two of the slices
+    are checked against the CPU oracle (output 1e-3, PSNR 0.01 dB, SSIM 2e-5); for every slice the batched call must give what
+    a one-slice call gives (slices are independent: bit for bit), and the batch metrics must be the mean of the per-slice ones."""
+    from mtd_gan_amd import metrics as M
+    G, g = _generator()
+    x, y = orc.synthetic_ldct(8, seed=21, size=512)
+    xd, yd = x.cuda(), y.cuda()
+    with torch.no_grad():
+        out = G(xd)
+        singles = [G(xd[i:i + 1]) for i in range(8)]
+    assert tuple(out.shape) == (8, 1, 512, 512) and torch.isfinite(out).all()
+    for i in range(8):
+        assert torch.equal(out[i:i + 1], singles[i]), i
+    pred = out.clip(0, 1)
+    per = [M.pixel_metrics(xd[i:i + 1], yd[i:i + 1], pred[i:i + 1]) for i in range(8)]
+    for i in (0, 5):
+        ref = orc.generator_forward(g, x[i:i + 1])
+        assert (out[i:i + 1].cpu() - ref).abs().max().item() / ref.abs().max().item() < 1e-3
+        rp = ref.clip(0, 1)
+        assert abs(per[i]["psnr"][2] - orc.psnr(rp, y[i:i + 1]).item()) < 0.01
+        assert abs(per[i]["ssim"][2] - orc.ssim(rp, y[i:i + 1]).item()) < 2e-5
+        assert abs(per[i]["rmse"][2] - orc.rmse(rp, y[i:i + 1]).item()) < 1e-6
+    # the reference's metric functions average over the batch (metrics.py:184-244): PSNR from the batch MSE, SSIM as the mean map
+    allm = M.pixel_metrics(xd, yd, pred)
+    mse = np.mean([per[i]["rmse"][2] ** 2 for i in range(8)])
+    assert abs(allm["rmse"][2] - mse ** 0.5) < 1e-6
+    assert abs(allm["ssim"][2] - np.mean([per[i]["ssim"][2] for i in range(8)])) < 2e-5

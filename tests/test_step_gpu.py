@@ -2,6 +2,7 @@
 AdamW, G step, AdamW) against the CPU oracle and the reference-generated golden step, plus the loss,
 PCGrad and AdamW kernels on their own."""
 import json
+import math
 import os
 import random
 
@@ -362,6 +363,109 @@ def test_d_step_task_gradients_vs_oracle(hip_lib):
     assert not bad, bad[:12]
     assert gram_err < TOL                                             # relative to |g_a||g_b|
     assert D.c_fc.weight_orig.grad is None
+
+
+def test_d_step_task_gradients_b32_vs_reference_samples(hip_lib):
+    """The D step at BASELINE size (32 patches): the three per-task shared gradients, the merged gradient PCGrad writes and the
+    task-specific gradients, PER TENSOR, against tests/golden/grad_samples_b32.json -- elements of the gradients the REFERENCE
+    computed at B = 32 (captured on their way into weight_methods.py:449's projection; oracle/pin_grad_samples.py), compared at
+    the float64 value with the bound max(1e-3, 2 x the reference's own fp32-vs-float64 error on that tensor) relative to the
+    tensor's max-abs.  The post-step checks of test_full_step_b32_vs_golden see update SIGNS; this sees magnitudes."""
+    from mtd_gan_amd.module.weight_methods import WeightMethods
+    gs = json.load(open(os.path.join(GOLD, "grad_samples_b32.json")))
+    m, full, masks, _ = _model(32)
+    m.Discriminator._inject_masks = [k.clone() for k in masks[:4]]
+    x, y = orc.synthetic_ldct(32, seed=1234)
+    wm = WeightMethods("pcgrad", n_tasks=3, device=torch.device("cuda"))
+    random.seed(77)
+    losses, _ = m.d_loss(x.cuda(), y.cuda())
+    D = m.Discriminator
+    wm.backward(losses=losses, shared_parameters=list(D.shared_parameters()), task_specific_parameters=list(D.task_specific_parameters()),
+                last_shared_parameters=list(D.last_shared_parameters()))
+    tape = losses._mtd_tape
+    assert tape.orders == gs["orders"]
+    assert rel(losses, torch.tensor(gs["losses"])) < TOL
+    assert rel(tape.coeff[:3], torch.tensor(gs["pc_weights_f64"])) < TOL
+    names = {id(p): n for n, p in D.named_parameters()}
+    shared = [names[id(p)] for p in D.shared_parameters()]
+    assert shared == gs["shared"] and [names[id(p)] for p in D.task_specific_parameters()] == gs["task_specific"]
+    bad, worst, checked = [], 0.0, 0
+
+    def check(tag, flat, e):
+        nonlocal worst, checked
+        idx = [(i * 2654435761 + 12345) % flat.numel() for i in range(len(e["f64"]))]
+        got = flat.reshape(-1)[torch.tensor(idx, device=flat.device)].double().cpu().tolist()
+        bound = max(TOL, 2 * e["err32"]) * e["maxabs"]
+        for j, (a, b) in enumerate(zip(got, e["f64"])):
+            worst = max(worst, abs(a - b) / (e["maxabs"] + 1e-30))
+            checked += 1
+            if abs(a - b) > bound + 1e-30:
+                bad.append((tag, j, a, b, bound))
+        mx = flat.abs().max().item()
+        if abs(mx - e["maxabs"]) > 5e-3 * e["maxabs"] + 1e-30:
+            bad.append((tag, "maxabs", mx, e["maxabs"]))
+    sizes = [p.numel() for p in D.shared_parameters()]
+    for i in range(3):
+        ofs = 0
+        for n, sz in zip(shared, sizes):
+            check(f"task{i} {n}", tape.task_vectors[i][ofs:ofs + sz], gs["tasks"][i][n])
+            ofs += sz
+    ofs = 0
+    for n, sz in zip(shared, sizes):
+        check("merged " + n, tape.task_vectors[3][ofs:ofs + sz], gs["merged"][n])
+        ofs += sz
+    for p in D.task_specific_parameters():
+        check("task-specific " + names[id(p)], p.grad, gs["ts"][names[id(p)]])
+    print(f"{checked} gradient elements at B=32, worst error relative to the tensor's max-abs {worst:.2e}; {len(bad)} over the bound")
+    assert not bad, bad[:12]
+
+
+def test_readme_batch_of_160_patches(hip_lib):
+    """The reference's documented training configuration: `--batch-size 20` (README.md:77) x 8 random crops per slice
+    (create_datasets/Mayo.py:126, list_data_collate) = 160 patches per iteration; the paired discriminator passes then run on
+    320 images (largest activation 320 x 64 x 64 x 128 floats = 671 MB: still inside the kernels' 32-bit byte offsets).
+    One complete iteration from the seeded-fill state must be finite and move every listed parameter; the generator on the
+    160-patch batch must equal its 32-patch chunks (patches are independent); the discriminator's three outputs on two of the
+    160 patches (eval mode, first and last) must match the CPU oracle."""
+    from mtd_gan_amd import engine
+    from mtd_gan_amd.module.weight_methods import WeightMethods
+    from mtd_gan_amd.optimizers import FusedAdamW
+    B = 160
+    m, full, masks, z = _model(B)
+    x, y = orc.synthetic_ldct(B, seed=4321)
+    xd, yd = x.cuda(), y.cuda()
+    # ---- forward properties at this size, before the step
+    m.eval()
+    with torch.no_grad():
+        out = m.Generator(xd)
+        for i in range(0, B, 32):
+            assert rel(m.Generator(xd[i:i + 32]), out[i:i + 32]) < 1e-6, i
+        e, s, r = m.Discriminator(yd)
+    dstate = {k[len("Discriminator."):]: v for k, v in full.items() if k.startswith("Discriminator.")}
+    pick = torch.tensor([0, B - 1])
+    eo, so, ro = orc.discriminator_forward({k: v.clone() for k, v in dstate.items()}, y[pick], train=False)
+    assert rel(e[pick.cuda()], eo) < TOL and rel(s[pick.cuda()], so) < TOL and rel(r[pick.cuda()], ro) < TOL
+    with torch.no_grad():
+        gref = orc.generator_forward({k[len("Generator."):]: v for k, v in full.items() if k.startswith("Generator.")}, x[pick])
+    assert rel(out[pick.cuda()], gref) < TOL
+    # ---- one iteration
+    m.train()
+    m.Discriminator._inject_masks = [k.clone() for k in masks]
+    wm = WeightMethods("pcgrad", n_tasks=3, device=torch.device("cuda"))
+    kw = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+    oD = FusedAdamW([dict(params=m.Discriminator.parameters(), lr=1e-4, **kw), dict(params=wm.parameters(), lr=0.025, **kw)])
+    oG = FusedAdamW(m.Generator.parameters(), lr=1e-4, **kw)
+    random.seed(77)
+    stats = engine.train_MTD_GAN_Ours(m, [dict(n_20=x, n_100=y)], oG, oD, torch.device("cuda"), 0, 0, 20, wm)
+    assert len(stats) == 17 and all(math.isfinite(v) for v in stats.values()), stats
+    post = m.state_dict()
+    names = {id(p): n for n, p in m.Discriminator.named_parameters()}
+    listed = {"Discriminator." + names[id(p)] for p in list(m.Discriminator.shared_parameters()) + list(m.Discriminator.task_specific_parameters())}
+    listed |= {"Generator." + n for n, _ in m.Generator.named_parameters()}
+    for k in listed:
+        assert torch.isfinite(post[k]).all(), k
+        assert not torch.equal(post[k].cpu(), full[k]), k                    # AdamW moved it
+    assert torch.equal(post["Discriminator.c_fc.weight_orig"].cpu(), full["Discriminator.c_fc.weight_orig"])
 
 
 def test_full_batch_step_runs_and_is_finite(hip_lib):
