@@ -254,7 +254,7 @@ def roofline_pass(wl, steps, pmc_tag):
     K.set_concurrency(True)
     by = {}
     for r in recs:
-        if r["kernel"].startswith(("igemm", "c32_bwd", "wgrad")):       # every profiled MFMA launch (the library's launch profiler)
+        if r["kernel"].startswith(("igemm", "c32_bwd", "wgrad", "wino")):       # every profiled MFMA launch (the library's launch profiler)
             d = by.setdefault(r["kernel"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0, "shapes": {}})
             d["ms"] += r["ms"]
             d["flops"] += r["flops"]
@@ -264,9 +264,10 @@ def roofline_pass(wl, steps, pmc_tag):
             sh = d["shapes"].setdefault(key, [0.0, 0.0, 0])
             sh[0] += r["ms"]; sh[1] += r["flops"]; sh[2] += 1
     units = getattr(wl, "batch", None) or getattr(wl, "slices", PER_GPU_BATCH)
-    executed = {k: round(v / steps / 1e9 / units, 4) for k, v in counted.items() if k != "launches"}
+    executed = {k: round(v / steps / 1e9 / units, 4) for k, v in counted.items() if k not in ("launches", "conv_winograd_saved")}
     executed_total = round(sum(executed.values()), 3)
     extra = {"executed_gflop_per_patch": executed_total, "executed_gflop_per_patch_by_kind": executed,
+             "winograd_saved_gflop_per_patch": round(counted.get("conv_winograd_saved", 0.0) / steps / 1e9 / units, 4),
              "counted_launches_per_step": counted.get("launches", 0) // steps}
     if not by:
         return None, extra

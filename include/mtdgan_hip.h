@@ -91,6 +91,23 @@ typedef struct {
 
 size_t mtd_conv_igemm_ws_bytes(const mtd_conv_args* a);
 int mtd_conv_igemm(const mtd_conv_args* a, void* stream);
+/* ---- Winograd F(2x2, 3x3) form of the same contract (csrc/conv_winograd.hip) for the 3x3 stride-1 "same" layers
+ * (arch/Ours/networks.py:181-221 conv{l}1/2, :230-301 *_dconv{l}1/2 and their data gradients): 16 instead of 36
+ * multiplications per 2x2 output tile, fp32 MFMA, same epilogue, same split-K workspace contract.
+ *   mtd_winograd_weights   transforms `count` weight views (once per optimizer step) into [xi 0..15][C/8][N][8] floats;
+ *                          kmap[a*3+b] = index in the kh x kw plane of the filter entry that multiplies input offset
+ *                          (-1+a, -1+b) (mtd_winograd_kmap derives it from a geometry: a forward conv and the data
+ *                          gradient of the same layer use different maps); table in device memory + the same on the host.
+ *   mtd_conv_winograd      a->w = the transformed weights (w_sn / w_sc / w_st ignored).  Requires 3x3, stride 1, OH x OW ==
+ *                          IH x IW both even, C % 16 == 0, N % 64 == 0, no out2: mtd_conv_winograd_ok(). */
+typedef struct { const float* src; float* dst; long long sn, sc, st; int N, C; int kmap[9]; int pad_; } mtd_wino_weight_desc;
+size_t mtd_winograd_weight_floats(int N, int C);
+int mtd_winograd_kmap(const mtd_geom* g, int* kmap9);
+int mtd_winograd_weights(const mtd_wino_weight_desc* table_dev, const mtd_wino_weight_desc* table_host, int count, void* stream);
+int mtd_conv_winograd_ok(const mtd_conv_args* a);
+size_t mtd_conv_winograd_ws_bytes(const mtd_conv_args* a);
+int mtd_conv_winograd(const mtd_conv_args* a, void* stream);
+
 /* Up to four launches of ONE shape (same pixels, N, C, taps) as one grid -- the four input-parity classes of a stride-2
  * data gradient (arch/Ours/networks.py down{l}: Conv2d(k4, s2, p1) backward w.r.t. its input), each a 2x2-tap stride-1
  * gather that writes every other pixel of the same output.  a[0..count) are complete argument sets; with split-K each

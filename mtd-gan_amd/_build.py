@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmtdgan_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "conv_c32_bwd.hip", "conv_direct.hip", "resfft.hip", "resfft4.hip", "resfft_any.hip", "elementwise.hip",
+SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "conv_c32_bwd.hip", "conv_winograd.hip", "conv_direct.hip", "resfft.hip", "resfft4.hip", "resfft_any.hip", "elementwise.hip",
            "specnorm.hip", "losses.hip", "metrics.hip", "sampler.hip", "pcgrad.hip", "adamw.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

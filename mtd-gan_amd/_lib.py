@@ -48,6 +48,11 @@ class PackDesc(C.Structure):
                 ("sn", C.c_longlong), ("sc", C.c_longlong)]
 
 
+class WinoWeightDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("sn", C.c_longlong), ("sc", C.c_longlong), ("st", C.c_longlong),
+                ("N", C.c_int), ("C", C.c_int), ("kmap", C.c_int * 9), ("pad_", C.c_int)]
+
+
 class SnLayer(C.Structure):
     _fields_ = [("w", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("sigma", C.c_void_p),
                 ("u_save", C.c_void_p), ("v_save", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int)]
@@ -99,7 +104,7 @@ def _preload_torch_hip_runtime():
 
 
 RECORDER = None      # kernels.LaunchList: while a step is being recorded, the list every launch is appended to
-_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "mtd_prof_", "_override", "_bwd_ok", "_stamps", "_zmask_bytes", "_tail_ok")
+_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "mtd_prof_", "_override", "_bwd_ok", "_stamps", "_zmask_bytes", "_tail_ok", "_winograd_ok", "_weight_floats", "_kmap")
 
 
 class _RecordingLib:
@@ -219,6 +224,12 @@ def lib():
     sig("mtd_conv_igemm_multi", ci, C.POINTER(ConvArgs), ci, vp)
     sig("mtd_resfft_block_tail_ok", ci, C.POINTER(ConvArgs))
     sig("mtd_resfft_block_tail", ci, C.POINTER(ConvArgs), vp, vp)
+    sig("mtd_winograd_weight_floats", sz, ci, ci)
+    sig("mtd_winograd_kmap", ci, C.POINTER(Geom), C.POINTER(C.c_int))
+    sig("mtd_winograd_weights", ci, vp, vp, ci, vp)
+    sig("mtd_conv_winograd_ok", ci, C.POINTER(ConvArgs))
+    sig("mtd_conv_winograd_ws_bytes", sz, C.POINTER(ConvArgs))
+    sig("mtd_conv_winograd", ci, C.POINTER(ConvArgs), vp)
     sig("mtd_pcgrad_coeff", ci, vp, vp, ci, vp, vp)
     sig("mtd_pcgrad_axpy", ci, vp, vp, vp, vp, ci, ll, vp, cf, vp, vp)
     _lib = L
@@ -240,6 +251,7 @@ EXPORTS = [
     "mtd_conv_c32_bwd_ok", "mtd_conv_c32_bwd_ws_bytes", "mtd_conv_c32_bwd",
     "mtd_spec_mix_zmask_bytes", "mtd_spec_mix_fwd4", "mtd_spec_mix_bwd4",
     "mtd_resfft_block_tail_ok", "mtd_resfft_block_tail", "mtd_conv_c32_bwd_irfft",
+    "mtd_winograd_weight_floats", "mtd_winograd_kmap", "mtd_winograd_weights", "mtd_conv_winograd_ok", "mtd_conv_winograd_ws_bytes", "mtd_conv_winograd",
 ]
 
 

@@ -89,6 +89,35 @@ def conv_views(P, backward):
     return v
 
 
+def winograd_views(P, backward):
+    """The 3x3 stride-1 layers whose maps are large enough for kernels.conv() to send them to the Winograd kernel
+    (kernels.winograd_takes), as (w, N, C, w_sn, w_sc, geometry) for kernels.prepack_winograd: their transformed weights are
+    then built in ONE launch per optimizer step.  The geometry only selects the tap order (forward / data gradient) and the
+    size thresholds, so batch 1 stands in for the real batch."""
+    v = []
+
+    def add(name, N, Cc, r):
+        w = P.get(name + ".weight_orig")
+        if w is None:
+            return
+        v.append((w, N, Cc, Cc * 9, 9, K.geom_fwd(1, r, r, 3, 1, 1)))
+        if backward:
+            v.append((w, Cc, N, 9, Cc * 9, K.geom_dgrad_s1(1, r, r, 3, 1)))
+
+    cin, r = 1, 64
+    for l, co in enumerate(CH, start=1):
+        add(f"conv{l}1", co, cin, r)
+        add(f"conv{l}2", co, co, r)
+        cin, r = co, r // 2
+    for pre in ("s", "r"):
+        r = 2
+        for l, (ci, co) in enumerate(DEC, start=1):
+            add(f"{pre}_dconv{l}1", co, ci, r)
+            add(f"{pre}_dconv{l}2", co, co, r)
+            r *= 2
+    return v
+
+
 class DiscRuntime:
     """Per-module scratch: the raw weight-gradient temp (one flat buffer shared by all SN layers)."""
 
@@ -172,6 +201,7 @@ def disc_forward(P, x, train, drop_mask, need_rec, save, sn=None, sn2=None, pair
     dev = x.device
     tp = Tape()
     K.prepack(conv_views(P, save))
+    K.prepack_winograd(winograd_views(P, save))
     tp.sig, tp.u_save, tp.v_save = sn if sn is not None else _sn_forward(P, train, dev)
     tp.pair = int(pair)
     if tp.pair:

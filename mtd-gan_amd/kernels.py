@@ -85,6 +85,85 @@ def packed_weight_view(w, N, Cc, w_sn, w_sc):
     return hit[0], Cc, 1, N * Cc
 
 
+# ---- Winograd F(2x2, 3x3) for the 3x3 stride-1 layers (csrc/conv_winograd.hip).  MTD_WINOGRAD=0 switches it off;
+# MTD_WINOGRAD_MIN_HW / _MIN_C / _MIN_N bound the layers that take it (maps below 8 x 8 keep the implicit GEMM, whose
+# whole-tile tap skipping already drops the padding taps that Winograd would multiply).
+WINOGRAD = os.environ.get("MTD_WINOGRAD", "1") != "0"
+WINO_MIN_HW = int(os.environ.get("MTD_WINOGRAD_MIN_HW", "8"))
+WINO_MIN_C = int(os.environ.get("MTD_WINOGRAD_MIN_C", "64"))
+WINO_MIN_N = int(os.environ.get("MTD_WINOGRAD_MIN_N", "64"))
+_kmap_cache = {}
+
+
+def _wino_kmap(geom):
+    key = bytes(geom)
+    km = _kmap_cache.get(key)
+    if km is None:
+        arr = (C.c_int * 9)()
+        rc = _lib.lib().mtd_winograd_kmap(C.byref(geom), arr)
+        km = tuple(arr) if rc == 0 else ()
+        _kmap_cache[key] = km
+    return km
+
+
+def winograd_takes(geom, N, Cc, kw):
+    """Host-side mirror of mtd_conv_winograd_ok plus the size thresholds: does conv() send this launch to the Winograd kernel?"""
+    if not WINOGRAD or geom.TH != 3 or geom.TW != 3 or geom.in_sy != 1 or geom.in_sx != 1:
+        return False
+    if geom.IH != geom.OH or geom.IW != geom.OW or (geom.OH & 1) or (geom.OW & 1) or geom.OH < WINO_MIN_HW or geom.OW < WINO_MIN_HW:
+        return False
+    if not (geom.out_sy == 1 and geom.out_sx == 1 and geom.out_oy == 0 and geom.out_ox == 0 and geom.OHF == geom.OH and geom.OWF == geom.OW):
+        return False
+    if (Cc % 16) or Cc < WINO_MIN_C or (N % 64) or N < WINO_MIN_N or kw.get("out2") is not None:
+        return False
+    return len(_wino_kmap(geom)) == 9
+
+
+def _wino_desc(w, N, Cc, w_sn, w_sc, kmap, device):
+    dst = torch.empty(16 * N * Cc, dtype=torch.float32, device=device)
+    d = _lib.WinoWeightDesc()
+    d.src, d.dst, d.sn, d.sc, d.st, d.N, d.C = w.data_ptr(), dst.data_ptr(), w_sn, w_sc, 1, N, Cc
+    for i, k in enumerate(kmap):
+        d.kmap[i] = k
+    return d, dst
+
+
+def prepack_winograd(views):
+    """Transform many weight views in ONE launch.  views: iterable of (w, N, C, w_sn, w_sc, geom) exactly as conv() will ask
+    for them; cached views and views conv() would not send to the Winograd kernel are skipped."""
+    todo = []
+    dev = None
+    for (w, N, Cc, w_sn, w_sc, geom) in views:
+        if not winograd_takes(geom, N, Cc, {}):
+            continue
+        kmap = _wino_kmap(geom)
+        key = (w.data_ptr(), w._version, _pack_epoch, N, Cc, w_sn, w_sc, "wino", kmap)
+        if key in _pack_cache:
+            continue
+        d, dst = _wino_desc(w, N, Cc, w_sn, w_sc, kmap, w.device)
+        todo.append(d)
+        dev = w.device
+        _remember(_pack_cache, (w.data_ptr(), N, Cc, w_sn, w_sc, "wino", kmap), key, (dst, w))
+    if todo:
+        tab, host = device_table(todo, dev)
+        check(_lib.lib().mtd_winograd_weights(tab.data_ptr(), C.cast(host, C.c_void_p), len(todo), stream_ptr()), "mtd_winograd_weights")
+
+
+def winograd_weight_view(w, N, Cc, w_sn, w_sc, geom):
+    """The transformed weights [xi][C/8][N][8] of the view W(n,c,tap) = w[n*w_sn + c*w_sc + tap] for this geometry's tap
+    order.  Cached until the weights change (like the packed [tap][n][c] views)."""
+    kmap = _wino_kmap(geom)
+    key = (w.data_ptr(), w._version, _pack_epoch, N, Cc, w_sn, w_sc, "wino", kmap)
+    hit = _pack_cache.get(key)
+    if hit is None:
+        d, dst = _wino_desc(w, N, Cc, w_sn, w_sc, kmap, w.device)
+        tab, host = device_table([d], w.device)
+        check(_lib.lib().mtd_winograd_weights(tab.data_ptr(), C.cast(host, C.c_void_p), 1, stream_ptr()), "mtd_winograd_weights")
+        hit = (dst, w)
+        _remember(_pack_cache, (w.data_ptr(), N, Cc, w_sn, w_sc, "wino", kmap), key, hit)
+    return hit[0]
+
+
 def regrouped_bias(b, groups):
     """out[q * n + c] = b[c * groups + q]: the bias of a conv whose output channels are taken group by group (PixelShuffle
     classes, geom_pixel_shuffle2).  Cached like the packed weight views (dropped by weights_changed)."""
@@ -115,7 +194,7 @@ CALL_LOG = None     # tools/tune_igemm.py: a list collects ("igemm" | "wgrad", b
 IGEMM_CONFIGS = ["igemm_kernel<2, 1, 4, 1>", "igemm_kernel<1, 1, 4, 1>", "igemm_kernel<2, 2, 4, 1>",
                  "igemm_kernel<1, 1, 2, 2>", "igemm_kernel<2, 2, 2, 2>", "igemm_kernel<1, 1, 1, 4>",
                  "igemm_tb_kernel<1>", "igemm_tb_kernel<2>", "igemm_v2_kernel<0>", "igemm_c32p_kernel", "igemm_c32t_kernel", "c32_bwd_kernel",
-                 "igemm_c32t_kernel<4, true, true, true>", "c32_bwd_kernel<spec>", "?", "?",      # 12: Res-FFT block tail; 13: c32_bwd + irfft
+                 "igemm_c32t_kernel<4, true, true, true>", "c32_bwd_kernel<spec>", "wino_conv_kernel", "?",      # 12: Res-FFT block tail; 13: c32_bwd + irfft; 14: Winograd
                  "igemm_multi_kernel<2, 1, 4, 1>", "igemm_multi_kernel<1, 1, 4, 1>", "igemm_multi_kernel<2, 2, 4, 1>",      # 16 + cfg
                  "igemm_multi_kernel<1, 1, 2, 2>", "igemm_multi_kernel<2, 2, 2, 2>", "igemm_multi_kernel<1, 1, 1, 4>"]
 WGRAD_CONFIGS = ["wgrad_kernel<1, 1, 9>", "wgrad_kernel<1, 1, 4>", "wgrad_kernel<2, 2, 1>", "wgrad_kernel<1, 1, 8>",
@@ -262,12 +341,12 @@ def _ptr(t):
 
 # ---------------------------------------------------------------------------------------------- conv
 def _conv_args(x, w, geom, N, Cc, w_sn, w_sc, out, scale=None, bias=None, add1=None, add2=None, act=ACT_NONE,
-               mask=None, mask_slope=0.0, scale2=None, scale_split=0, out2=None, count=True):
+               mask=None, mask_slope=0.0, scale2=None, scale_split=0, out2=None, count=True, pack=True):
     a = ConvArgs()
     a.g = geom
     a.inp, a.in_ld, a.C = x.data_ptr(), ld_of(x), Cc
     w_st = 1
-    if (Cc % 32 == 0) and (N % 32 == 0) and (w_sc != 1 or w.data_ptr() % 16 or w_sn % 4):
+    if pack and (Cc % 32 == 0) and (N % 32 == 0) and (w_sc != 1 or w.data_ptr() % 16 or w_sn % 4):
         w, w_sn, w_sc, w_st = packed_weight_view(w, N, Cc, w_sn, w_sc)
     a.w, a.w_sn, a.w_sc, a.w_st, a.N = w.data_ptr(), w_sn, w_sc, w_st, N
     a.out, a.out_ld = out.data_ptr(), ld_of(out)
@@ -289,6 +368,26 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, **kw):
     add2, act, mask, mask_slope, scale2, scale_split, out2 (see fuses_masked_cotangent: also store the value before the
     mask factor)."""
     L = _lib.lib()
+    if winograd_takes(geom, N, Cc, kw):
+        a = _conv_args(x, w, geom, N, Cc, w_sn, w_sc, out, pack=False, **kw)
+        if L.mtd_conv_winograd_ok(C.byref(a)):
+            a.w = winograd_weight_view(w, N, Cc, w_sn, w_sc, geom).data_ptr()
+            wkey = ("wino", bytes(geom), N, Cc)
+            need = _igemm_ws_cache.get(wkey)
+            if need is None:
+                need = L.mtd_conv_winograd_ws_bytes(C.byref(a))
+                _igemm_ws_cache[wkey] = need
+            if need:
+                ws = workspace(need, x.device)
+                a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+            if FLOP_COUNT is not None:          # executed MFMA flops: 16 instead of 36 multiplications per 2 x 2 output tile
+                FLOP_COUNT["conv_mfma"] -= 2.0 * geom.B * geom.OH * geom.OW * N * Cc * 5
+                FLOP_COUNT["conv_winograd_saved"] = FLOP_COUNT.get("conv_winograd_saved", 0.0) + 2.0 * geom.B * geom.OH * geom.OW * N * Cc * 5
+            check(L.mtd_conv_winograd(C.byref(a), stream_ptr()), "mtd_conv_winograd")
+            return out
+        if FLOP_COUNT is not None:
+            FLOP_COUNT["conv_mfma"] -= 2.0 * geom.B * geom.OH * geom.OW * N * Cc * 9
+            FLOP_COUNT["launches"] -= 1
     a = _conv_args(x, w, geom, N, Cc, w_sn, w_sc, out, **kw)
     if (Cc % 32 == 0) and (N % 32 == 0):
         wkey = (bytes(geom), N, Cc)

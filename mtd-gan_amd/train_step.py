@@ -267,6 +267,7 @@ def d_loss(method, x, y):
     # first, in the reference's order, and every conv applies the 1/sigma of the half it is computing (scale2 /
     # scale_split).  Same arithmetic per image; half the launches, twice the pixels per launch on the deep 4x4 .. 1x1 layers.
     K.prepack(DP.conv_views(P, True))
+    K.prepack_winograd(DP.winograd_views(P, True))
     sn = [DP._sn_forward(P, train, dev) for _ in range(4)]
     masks = [D._next_mask(B, dev) for _ in range(4)]
     cat_mask = lambda a, b: None if a is None else torch.cat([a, b], 0)

@@ -610,3 +610,59 @@ def test_fused_c32_backward_launch_with_row_transform(hip_lib, B):
     (F.conv2d(xin, w.cpu().double(), None, padding=1) * nchw(gm).double()).sum().backward()
     want = (xin.grad + nchw(g).double() + rows) * (nchw(x) > 0)
     assert relerr(nchw(gx_b), want) < TOL
+
+
+WINO_CASES = [
+    # B, Cin, Cout, H, W, what
+    (2, 64, 64, 64, 64, "fwd"),        # one tile row of 32 tiles per workgroup, BN = 64
+    (2, 64, 128, 16, 16, "fwd"),       # four tile rows per workgroup, BN = 128 (or 64 + more workgroups)
+    (3, 256, 256, 8, 8, "fwd"),        # 48 tiles: ragged last workgroup (two images per workgroup), split-K
+    (2, 128, 64, 32, 32, "dgrad"),     # data gradient: mirrored taps, transposed weight view
+    (5, 512, 512, 8, 8, "dgrad"),      # 80 tiles, deep K with split-K slabs + the shared split-K epilogue
+    (1, 80, 192, 10, 12, "fwd"),       # C a multiple of 16 only, odd tile counts
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_winograd_conv_vs_torch(hip_lib, case):
+    """csrc/conv_winograd.hip, F(2x2, 3x3): forward conv and data gradient with the full epilogue (two scales by batch half,
+    bias, two adds, LeakyReLU, mask) against torch on the CPU in float64 and against the implicit GEMM on the same inputs
+    (the two differ by fp32 rounding only: 1e-5)."""
+    from mtd_gan_amd import kernels as K
+    B, Ci, Co, H, W, what = case
+    gen = torch.Generator().manual_seed(17)
+    r = lambda *s: torch.randn(*s, generator=gen)
+    x = r(B, H, W, Ci if what == "fwd" else Co).cuda()
+    w = (r(Co, Ci, 3, 3) * (9 * Ci) ** -0.5).cuda()
+    N, Cc = (Co, Ci) if what == "fwd" else (Ci, Co)
+    bias, add1, add2, mask = (r(N) * 0.1).cuda(), r(B, H, W, N).cuda(), r(B, H, W, N).cuda(), r(B, H, W, N).cuda()
+    s1, s2 = torch.tensor([0.7], device="cuda"), torch.tensor([1.3], device="cuda")
+    split = (B // 2) * H * W if B > 1 else 0
+    if what == "fwd":
+        geom, wsn, wsc = K.geom_fwd(B, H, W, 3, 1, 1), Ci * 9, 9
+    else:
+        geom, wsn, wsc = K.geom_dgrad_s1(B, H, W, 3, 1), 9, Ci * 9
+    kw = dict(scale=s1, bias=bias, add1=add1, add2=add2, act=K.ACT_LRELU, mask=mask, mask_slope=0.2)
+    if split:
+        kw.update(scale2=s2, scale_split=split)
+    assert K.winograd_takes(geom, N, Cc, kw)
+    outs = []
+    for wino in (True, False):
+        K.WINOGRAD = wino
+        try:
+            out = torch.zeros(B, H, W, N, device="cuda")
+            K.conv(x, w, geom, N, Cc, wsn, wsc, out, **kw)
+            torch.cuda.synchronize()
+            outs.append(out)
+        finally:
+            K.WINOGRAD = True
+    assert relerr(outs[0].cpu(), outs[1].cpu()) < 1e-5
+    xc, wc = nchw(x).double(), w.cpu().double()
+    y = F.conv2d(xc, wc, None, padding=1) if what == "fwd" else F.conv_transpose2d(xc, wc, None, padding=1)
+    sc = torch.full((B, 1, 1, 1), 0.7, dtype=torch.double)
+    if split:
+        sc[B // 2:] = 1.3
+    v = y * sc + bias.cpu().double().view(1, -1, 1, 1) + nchw(add1).double() + nchw(add2).double()
+    v = F.leaky_relu(v, 0.2) * torch.where(nchw(mask) > 0, 1.0, 0.2)
+    assert relerr(nchw(outs[0]), v) < TOL
