@@ -35,7 +35,7 @@ namespace {
 
 constexpr int WT = 32;        // tiles per workgroup
 constexpr int WALD = 20;      // LDS row stride (floats) of As[xi][tile][16 c]: 16-byte aligned, b128 reads of 16 rows hit 16 x 4 distinct banks
-constexpr int WXLD = 33;      // LDS row stride of the exchange image X[xi][tile][32 n]
+constexpr int WXLD = 36;      // LDS row stride (floats) of the exchange image X[xi][tile][32 n]: 16-byte aligned rows
 
 struct WinoParams {
     IgemmParams p;            // args, M, split-K (c_per_split in channels), buffer extents, out_identity
@@ -94,10 +94,13 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const WinoWDesc* __re
 }
 
 // ---- the convolution
-template <int NB>
-__global__ __launch_bounds__(512, 1) void wino_conv_kernel(const WinoParams wp) {
+// LEAN (NB = 2): at most 128 registers, so TWO workgroups share a CU (2 x 80 KB of LDS) and one's prologue / epilogue / waits run
+// under the other's MFMAs -- for the layers with few K steps (C <= 128) or N = 64, where a lone workgroup per CU spends as long
+// outside its K loop as inside.  One weight-fragment register set instead of two.
+template <int NB, bool LEAN = false>
+__global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const WinoParams wp) {
     // As: two buffers of 16 positions x 32 tiles x 16 channels (row stride WALD floats, 40 KB each); the exchange image of the
-    // epilogue (16 x 32 x WXLD floats = 66 KB) reuses the same memory after the K loop.
+    // epilogue (16 x 32 x WXLD floats = 72 KB) reuses the same memory after the K loop.
     constexpr int AS_BUF = 16 * WT * WALD;
     constexpr int X_SIZE = 16 * WT * WXLD;
     __shared__ __attribute__((aligned(16))) float Ls[(2 * AS_BUF > X_SIZE) ? 2 * AS_BUF : X_SIZE];
@@ -116,66 +119,60 @@ __global__ __launch_bounds__(512, 1) void wino_conv_kernel(const WinoParams wp) 
     const int nst = st_end - st_beg;
     const int st_last = st_end - 1;
 
-    // ---- transform role: thread (tile tt, channel tc of the step).  The 16 patch pixels are ONE lane offset (out of range
-    // for a tile past the end) + a scalar displacement per pixel, with a 16-bit validity mask for the image border.
-    const int tt = tid >> 4, tc = tid & 15;
+    // ---- transform role: thread (tile tt, channel quad tq, patch row ti) -- the four rows of a patch are the four lanes of a
+    // quad.  A thread loads its row as four 16-byte vectors (4 channels x 4 pixels: a quarter of the vector-memory and LDS
+    // instructions of a dword-per-lane form, which had the K loop waiting on instruction issue), applies B along the row in
+    // registers and B^T across the quad with DPP, and stores row ti of the 4 x 4 result as four 16-byte vectors.
+    const int ti = tid & 3, tq = (tid >> 2) & 3, tt = tid >> 4;
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)p.in_bytes, 0x00020000);
-    unsigned pbase, pvalid = 0;
+    unsigned pbase, pvalid = 0;            // offset of patch pixel (ti, 0), channels 4 tq ..; validity of the row's four pixels
     {
         const int tg = tile0 + tt;
         const bool tv = tg < wp.ntiles;
         const int b = tg / wp.tiles_per_image;
         const int r = tg - b * wp.tiles_per_image;
         const int ty = r / wp.tiles_x, tx = r - ty * wp.tiles_x;
-        // offset of patch pixel (0, 0) = image pixel (2 ty - 1, 2 tx - 1), which may lie outside: formed modulo 2^32, every
-        // VALID pixel's offset pbase + displacement is inside the buffer
-        pbase = (unsigned)(((((long long)b * g.IH + (2 * ty - 1)) * g.IW + (2 * tx - 1)) * a.in_ld + tc) * 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int iy = 2 * ty - 1 + i, ix = 2 * tx - 1 + j;
-                if (tv & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW)) pvalid |= 1u << (i * 4 + j);
-            }
-    }
-    const int row_b = g.IW * a.in_ld * 4, px_b = a.in_ld * 4;      // byte displacements of one image row / one pixel
-    float d[16];
-    auto load_patch = [&](int st) {        // step st (absolute, clamped by the caller): channels 16 st + tc
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned vo = ((pvalid >> (i * 4 + j)) & 1u) ? pbase + (unsigned)(i * row_b + j * px_b) : 0x80000000u;
-                d[i * 4 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars, vo, st * 64, 0));
-            }
-    };
-    // B^T d B -> As[xi][tt][tc], in three pieces that the K loop places between groups of MFMAs
-    float t[16];
-    auto transform_cols = [&]() {             // columns: B^T d
+        const int iy = 2 * ty - 1 + ti;
+        // (pixel (iy, 2 tx - 1) may lie outside the image: the offset is formed modulo 2^32, every VALID pixel's is in range)
+        pbase = (unsigned)(((((long long)b * g.IH + iy) * g.IW + (2 * tx - 1)) * a.in_ld + 4 * tq) * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float d0 = d[j], d1 = d[4 + j], d2 = d[8 + j], d3 = d[12 + j];
-            t[j] = d0 - d2;
-            t[4 + j] = d1 + d2;
-            t[8 + j] = d2 - d1;
-            t[12 + j] = d1 - d3;
+            const int ix = 2 * tx - 1 + j;
+            if (tv & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW)) pvalid |= 1u << j;
+        }
+    }
+    const int px_b = a.in_ld * 4;          // byte displacement of one pixel
+    f32x4 d[4];
+    auto load_patch = [&](int st) {        // step st (absolute, clamped by the caller): channels 16 st + 4 tq .. + 3
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned vo = ((pvalid >> j) & 1u) ? pbase + (unsigned)(j * px_b) : 0x80000000u;
+            d[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, vo, st * 64, 0));
         }
     };
-    auto transform_rows = [&](float* As, int i0) {   // rows i0, i0 + 1: (.) B, and the stores
-        float* o = As + tt * WALD + tc;
+    // B^T d B -> As[xi = 4 ti + j][tt][4 tq ..]: columns j0, j0 + 1 of the result (the K loop places the halves between MFMA groups)
+    const float qsign = ti == 1 ? 1.f : -1.f;
+    auto quad_get = [&](float v, int ctrl) {
+        const int x = __builtin_bit_cast(int, v);
+        return __builtin_bit_cast(float, ctrl == 0 ? __builtin_amdgcn_update_dpp(0, x, 0x64, 0xf, 0xf, true)      // lanes [0, 1, 2, 1]
+                                                  : __builtin_amdgcn_update_dpp(0, x, 0xDA, 0xf, 0xf, true));    // lanes [2, 2, 1, 3]
+    };
+    auto transform_cols = [&](float* As, int j0) {
+        float* o = As + tt * WALD + 4 * tq;
 #pragma unroll
-        for (int i = i0; i < i0 + 2; ++i) {
-            const float t0 = t[4 * i], t1 = t[4 * i + 1], t2 = t[4 * i + 2], t3 = t[4 * i + 3];
-            o[(4 * i + 0) * (WT * WALD)] = t0 - t2;
-            o[(4 * i + 1) * (WT * WALD)] = t1 + t2;
-            o[(4 * i + 2) * (WT * WALD)] = t2 - t1;
-            o[(4 * i + 3) * (WT * WALD)] = t1 - t3;
+        for (int j = j0; j < j0 + 2; ++j) {
+            // along the row: (d B)[j]
+            const f32x4 rj = j == 0 ? d[0] - d[2] : (j == 1 ? d[1] + d[2] : (j == 2 ? d[2] - d[1] : d[1] - d[3]));
+            // across the quad: (B^T .)[ti] = r[0]-r[2] | r[1]+r[2] | r[2]-r[1] | r[1]-r[3]
+            f32x4 u;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) u[c] = fmaf(qsign, quad_get(rj[c], 1), quad_get(rj[c], 0));
+            *reinterpret_cast<f32x4*>(o + (4 * ti + j) * (WT * WALD)) = u;
         }
     };
     auto transform_store = [&](float* As) {
-        transform_cols();
-        transform_rows(As, 0);
-        transform_rows(As, 2);
+        transform_cols(As, 0);
+        transform_cols(As, 2);
     };
 
     // ---- MFMA role: positions 2 wave, 2 wave + 1; B fragments straight from the transformed weights
@@ -195,18 +192,16 @@ __global__ __launch_bounds__(512, 1) void wino_conv_kernel(const WinoParams wp) 
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[x][nb][e] = 0.f;
-    f32x4 af[2][2];                                              // [sub-chunk][position]
-    auto load_af = [&](const float* Ac) {
+    f32x4 af[2];                                                 // this sub-chunk's A fragments, one per position
+    auto load_af = [&](const float* Ac, int u) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int x = 0; x < 2; ++x) af[u][x] = *reinterpret_cast<const f32x4*>(Ac + ((2 * wave + x) * WT + l31) * WALD + u * 8 + kh * 4);
+        for (int x = 0; x < 2; ++x) af[x] = *reinterpret_cast<const f32x4*>(Ac + ((2 * wave + x) * WT + l31) * WALD + u * 8 + kh * 4);
     };
-    auto mfma_group = [&](int u, int s, const f32x4 (&bf)[2][NB]) {      // k-step s of sub-chunk u: 2 NB MFMAs
+    auto mfma_group = [&](int s, const f32x4 (&bf)[2][NB]) {      // k-step s of the sub-chunk in af: 2 NB MFMAs
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[x][nb] = mfma32(af[u][x][s], bf[x][nb][s], acc[x][nb]);
+            for (int nb = 0; nb < NB; ++nb) acc[x][nb] = mfma32(af[x][s], bf[x][nb][s], acc[x][nb]);
     };
 
     // ---- prologue: step 0 transformed into buffer 0, step 1's patch in flight, step 0's first weights in registers.
@@ -214,69 +209,116 @@ __global__ __launch_bounds__(512, 1) void wino_conv_kernel(const WinoParams wp) 
     // the waits the compiler places count exactly the loads that are younger than the registers an MFMA needs.  (With the
     // loads under `if (k + 1 < n)` the path that skips them set the wait counts for all, and every chunk stood for a full
     // memory round trip of its own prefetches: half speed.)
-    f32x4 b0[2][NB], b1[2][NB];
+    f32x4 b0[2][NB], b1[2][NB];        // (LEAN never touches b1)
     if (nst > 0) {
         load_patch(st_beg);
         load_b(2 * st_beg, b0);
         transform_store(Ls);
-        load_patch(min(st_beg + 1, st_last));
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): nothing of the prologue is pending inside the loop
     __syncthreads();
-    // One K step.  Issue order of the loads (vmcnt counts in this order): b1 (second half of this step), the patch of step
-    // j + 2, b0 (first half of step j + 1) -- each is needed a whole group of MFMAs after it was requested.  The transform of
-    // step j + 1 (vector ALU + LDS stores) sits in three pieces between the MFMA groups of the first half; the scheduling
-    // fences keep the compiler from sinking the loads next to their uses (it did: every chunk then waited for its own loads).
+    // One K step.  The patch of step j + 1 is requested at the TOP of step j and transformed at its END, between the last MFMA
+    // groups: a whole step of MFMAs (8192 clocks of the pipe) covers its way from HBM.  (Requested in the middle of a step and
+    // transformed early in the next, the transform stood for it: 25 of 140 us on the 64-channel layers.)  Weight fragments:
+    // b1 (second half of this step) at the top, b0 (first half of the next step) after the first half's MFMAs -- each a
+    // sub-chunk of MFMAs ahead of its use.  vmcnt counts in issue order: patch, b1 | b0; the scheduling fences keep the
+    // compiler from sinking the loads next to their uses.
 #pragma unroll 1
     for (int j = 0; j < nst; ++j) {
         const int st = st_beg + j;
         const float* Ac = Ls + (j & 1) * AS_BUF;
         float* An = Ls + ((j + 1) & 1) * AS_BUF;
-        load_af(Ac);
-        load_b(2 * st + 1, b1);
+        load_af(Ac, 0);
+        load_patch(min(st + 1, st_last));
+        if constexpr (!LEAN) load_b(2 * st + 1, b1);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_group(0, 0, b0);
+        mfma_group(0, b0); mfma_group(1, b0); mfma_group(2, b0); mfma_group(3, b0);
         __builtin_amdgcn_sched_barrier(0);
-        transform_cols();
+        if constexpr (LEAN) load_b(2 * st + 1, b0);            // one register set: requested right before its use, the other
+        load_af(Ac, 1);                                        // workgroup of the CU has the matrix pipe meanwhile
         __builtin_amdgcn_sched_barrier(0);
-        mfma_group(0, 1, b0);
+        // second half: its 8 NB MFMAs and the transform of step j + 1 (vector ALU, DPP, four LDS stores) in ONE scheduling region,
+        // interleaved one MFMA : a few VALU operations -- in separate clusters both waves of a SIMD reach their VALU cluster
+        // together (they run the same program between the same barriers) and the matrix pipe stands
+        if constexpr (LEAN) {
+            mfma_group(0, b0); mfma_group(1, b0); mfma_group(2, b0); mfma_group(3, b0);
+            transform_cols(An, 0);
+            transform_cols(An, 2);
+        } else {
+            load_b(2 * min(st + 1, st_last), b0);              // (the first half's MFMAs have read b0)
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(0, b1); mfma_group(1, b1); mfma_group(2, b1); mfma_group(3, b1);
+            transform_cols(An, 0);
+            transform_cols(An, 2);
+        }
+#pragma unroll
+        for (int i = 0; i < 8 * NB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, NB == 4 ? 3 : 6, 0);     // a few VALU / DPP operations
+            if ((i & (NB == 4 ? 7 : 3)) == (NB == 4 ? 7 : 3)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // an LDS store
+        }
         __builtin_amdgcn_sched_barrier(0);
-        transform_rows(An, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_group(0, 2, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        transform_rows(An, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_group(0, 3, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_patch(min(st + 2, st_last));
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_group(1, 0, b1);
-        mfma_group(1, 1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        load_b(2 * min(st + 1, st_last), b0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_group(1, 2, b1);
-        mfma_group(1, 3, b1);
+        if constexpr (LEAN) load_b(2 * min(st + 1, st_last), b0);
         __syncthreads();
     }
 
-    // ---- epilogue: one n block at a time through the exchange image X[xi][tile][n].  A thread finishes channel n = tid & 31
-    // of tiles (tid >> 5) and (tid >> 5) + 16: A^T m A, then the conv epilogue on its 2 x 4 output pixels -- operands first
-    // (uniform tests around whole batches of loads, as in conv_igemm.hip's epi_group), arithmetic in epilogue_value()'s order.
+    // ---- epilogue: one n block at a time through the exchange image X[xi][tile][n] (row stride WXLD: 16-byte aligned rows).
+    // Thread (tile tl, channel quad nq, output row ei) finishes 2 pixels x 4 channels: A^T m A on 16-byte vectors, then the conv
+    // epilogue in epilogue_value()'s order.  Its operands -- up to three tensors -- are requested BEFORE the accumulators go to
+    // LDS, so their way from memory is under the exchange; everything moves as 16-byte vectors (the dword form of this
+    // epilogue cost the data gradients, with two adds and a mask, up to 60 us per launch).
     const ScalePair sp = load_scale(a);
-    const int en = tid & 31;
-    long long pix0[2];                                            // top-left output pixel of the thread's two tiles (-1: none)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int tg = tile0 + (tid >> 5) + 16 * h;
+    const int ei = tid & 1, enq = (tid >> 1) & 7, etl = tid >> 4;
+    int epix;                                                      // left pixel of the thread's output row (-1: no such tile)
+    {
+        const int tg = tile0 + etl;
         const int bimg = tg / wp.tiles_per_image;
         const int r = tg - bimg * wp.tiles_per_image;
         const int ty = r / wp.tiles_x, tx = r - ty * wp.tiles_x;
-        pix0[h] = tg < wp.ntiles ? ((long long)bimg * g.OH + 2 * ty) * g.OW + 2 * tx : -1;
+        epix = tg < wp.ntiles ? (bimg * g.OH + 2 * ty + ei) * g.OW + 2 * tx : -1;
     }
+    const bool evalid = epix >= 0;
+    const float esc0 = pick_scale(sp, epix < 0 ? 0 : epix), esc1 = pick_scale(sp, epix < 0 ? 0 : epix + 1);
+    const bool vec = (p.wide & 1) != 0;                            // every epilogue operand row 16-byte aligned (wide_epilogue_ok)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {        // (unrolled: a run-time index into the accumulators would put them in scratch memory)
+        const int n = n0 + nb * 32 + 4 * enq;
+        f32x4 e1[2], e2[2], em[2], bias4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            e1[q] = f32x4{-0.0f, -0.0f, -0.0f, -0.0f};
+            e2[q] = e1[q];
+            em[q] = f32x4{1.f, 1.f, 1.f, 1.f};
+        }
+        if (p.splitk == 1 && evalid) {
+            if (vec) {
+                if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n);
+                if (a.add1) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) e1[q] = *reinterpret_cast<const f32x4*>(a.add1 + (long long)(epix + q) * a.add1_ld + n);
+                }
+                if (a.add2) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) e2[q] = *reinterpret_cast<const f32x4*>(a.add2 + (long long)(epix + q) * a.add2_ld + n);
+                }
+                if (a.mask) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) em[q] = *reinterpret_cast<const f32x4*>(a.mask + (long long)(epix + q) * a.mask_ld + n);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (a.bias) bias4[c] = a.bias[n + c];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (a.add1) e1[q][c] = a.add1[(long long)(epix + q) * a.add1_ld + n + c];
+                        if (a.add2) e2[q][c] = a.add2[(long long)(epix + q) * a.add2_ld + n + c];
+                        if (a.mask) em[q][c] = a.mask[(long long)(epix + q) * a.mask_ld + n + c];
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
             float* X = Ls + (2 * wave + x) * (WT * WXLD) + l31;
@@ -284,76 +326,69 @@ __global__ __launch_bounds__(512, 1) void wino_conv_kernel(const WinoParams wp) 
             for (int e = 0; e < 16; ++e) X[mfma32_row(e, lane) * WXLD] = acc[x][nb][e];
         }
         __syncthreads();
-        const int n = n0 + nb * 32 + en;
-        float y[8];
-        long long pp[8];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int tl = (tid >> 5) + 16 * h;
-            float m[16];
-#pragma unroll
-            for (int xi = 0; xi < 16; ++xi) m[xi] = Ls[(xi * WT + tl) * WXLD + en];
-            float t2[2][4];
+        f32x4 y[2];
+        {
+            f32x4 t[4];
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                t2[0][b] = m[b] + m[4 + b] + m[8 + b];
-                t2[1][b] = m[4 + b] - m[8 + b] - m[12 + b];
+                const float* col = Ls + (b * WT + etl) * WXLD + 4 * enq;              // position xi = 4 a + b at col + a * 4 * WT * WXLD
+                const f32x4 m1 = *reinterpret_cast<const f32x4*>(col + 1 * 4 * WT * WXLD);
+                const f32x4 m2 = *reinterpret_cast<const f32x4*>(col + 2 * 4 * WT * WXLD);
+                const f32x4 m03 = *reinterpret_cast<const f32x4*>(col + (ei ? 3 : 0) * 4 * WT * WXLD);
+                t[b] = ei ? m1 - m2 - m03 : m03 + m1 + m2;                             // row ei of A^T m
             }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                y[h * 4 + 2 * i] = t2[i][0] + t2[i][1] + t2[i][2];
-                y[h * 4 + 2 * i + 1] = t2[i][1] - t2[i][2] - t2[i][3];
-                pp[h * 4 + 2 * i] = pix0[h] + (long long)i * g.OW;
-                pp[h * 4 + 2 * i + 1] = pix0[h] + (long long)i * g.OW + 1;
-            }
+            y[0] = t[0] + t[1] + t[2];
+            y[1] = t[1] - t[2] - t[3];
         }
-        if (p.splitk > 1) {
-            float* slab = a.ws + (long long)zk * ((long long)p.M * a.N) + n;
+        if (evalid) {
+            if (p.splitk > 1) {
+                float* slab = a.ws + (long long)zk * ((long long)p.M * a.N) + n;
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (pix0[q >> 2] >= 0) slab[pp[q] * a.N] = y[q];
-        } else {
-            const float bias_n = a.bias ? a.bias[n] : 0.f;
-            float e1[8], e2[8], em[8];
+                for (int q = 0; q < 2; ++q) {
+                    if (vec && (p.wide & 2)) *reinterpret_cast<f32x4*>(slab + (long long)(epix + q) * a.N) = y[q];
+                    else
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { e1[q] = -0.0f; e2[q] = -0.0f; em[q] = 1.f; }
-            if (a.add1) {
+                        for (int c = 0; c < 4; ++c) slab[(long long)(epix + q) * a.N + c] = y[q][c];
+                }
+            } else {
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (pix0[q >> 2] >= 0) e1[q] = a.add1[pp[q] * a.add1_ld + n];
+                for (int q = 0; q < 2; ++q) {
+                    const float sc = q ? esc1 : esc0;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float v = y[q][c] * sc + bias4[c];
+                        v += e1[q][c];
+                        v += e2[q][c];
+                        y[q][c] = v;
+                    }
+                }
+                if (a.act == MTD_ACT_RELU) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) y[q][c] = y[q][c] > 0.f ? y[q][c] : 0.f;
+                } else if (a.act == MTD_ACT_LRELU) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) y[q][c] = y[q][c] > 0.f ? y[q][c] : 0.2f * y[q][c];
+                }
+                if (a.mask) {
+                    const float slope = a.mask_slope;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) y[q][c] *= (em[q][c] > 0.f) ? 1.f : slope;
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float* o = a.out + (long long)(epix + q) * a.out_ld + n;
+                    if (vec) *reinterpret_cast<f32x4*>(o) = y[q];
+                    else
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] = y[q][c];
+                }
             }
-            if (a.add2) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (pix0[q >> 2] >= 0) e2[q] = a.add2[pp[q] * a.add2_ld + n];
-            }
-            if (a.mask) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (pix0[q >> 2] >= 0) em[q] = a.mask[pp[q] * a.mask_ld + n];
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                float v = y[q] * pick_scale(sp, (int)pp[q]) + bias_n;
-                v += e1[q];
-                v += e2[q];
-                y[q] = v;
-            }
-            if (a.act == MTD_ACT_RELU) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) y[q] = y[q] > 0.f ? y[q] : 0.f;
-            } else if (a.act == MTD_ACT_LRELU) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) y[q] = y[q] > 0.f ? y[q] : 0.2f * y[q];
-            }
-            if (a.mask) {
-                const float slope = a.mask_slope;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) y[q] *= (em[q] > 0.f) ? 1.f : slope;
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (pix0[q >> 2] >= 0) a.out[pp[q] * a.out_ld + n] = y[q];
         }
         __syncthreads();
     }
@@ -375,7 +410,7 @@ bool wino_eligible(const mtd_conv_args& a) {
     return true;
 }
 
-struct WinoPlan { int nb, splitk, c_per_split; };
+struct WinoPlan { int nb, lean, splitk, c_per_split; };
 
 WinoPlan wino_plan(const mtd_conv_args& a) {
     WinoPlan pl{};
@@ -396,6 +431,11 @@ WinoPlan wino_plan(const mtd_conv_args& a) {
     const int cps = (chunks + sk - 1) / sk;
     pl.splitk = (chunks + cps - 1) / cps;
     pl.c_per_split = cps * 16;
+    // two lean workgroups per CU where a workgroup has few K steps and the grid has at least two per CU (MTD_WINO_LEAN: 0 never,
+    // 1 by this rule, 2 whenever NB = 2)
+    static const int env_lean = [] { const char* e = getenv("MTD_WINO_LEAN"); return e ? atoi(e) : 1; }();
+    const long long grid = ((tiles + WT - 1) / WT) * (a.N / (32 * pl.nb)) * pl.splitk;
+    pl.lean = pl.nb == 2 && env_lean && (env_lean == 2 || (cps <= 8 && grid >= 512));
     return pl;
 }
 
@@ -481,7 +521,7 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
     p.xcd_map = 0;
     p.nt_store = 0;
     p.fin = 0;
-    p.wide = 0;
+    p.wide = (wide_epilogue_ok(*a) ? 1 : 0) | ((pl.splitk > 1 && aligned16(a->ws) && (a->N % 4) == 0) ? 2 : 0);
     wp.tiles_x = a->g.OW / 2;
     wp.tiles_per_image = (a->g.OH / 2) * wp.tiles_x;
     wp.ntiles = a->g.B * wp.tiles_per_image;
@@ -494,6 +534,7 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
     const dim3 grid((wp.ntiles + WT - 1) / WT, a->N / (32 * pl.nb), pl.splitk);
     const int prof = mtd_prof_begin(0, 14, pl.splitk, p.M, a->N, a->C, 9, s, algorithmic_bytes(a));
     if (pl.nb == 4) MTD_LAUNCH((wino_conv_kernel<4>), grid, dim3(512), 0, s, wp);
+    else if (pl.lean) MTD_LAUNCH((wino_conv_kernel<2, true>), grid, dim3(512), 0, s, wp);
     else MTD_LAUNCH((wino_conv_kernel<2>), grid, dim3(512), 0, s, wp);
     mtd_prof_end(prof, s);
     MTD_LAUNCH_CHECK();
