@@ -620,6 +620,8 @@ WINO_CASES = [
     (2, 128, 64, 32, 32, "dgrad"),     # data gradient: mirrored taps, transposed weight view
     (5, 512, 512, 8, 8, "dgrad"),      # 80 tiles, deep K with split-K slabs + the shared split-K epilogue
     (1, 80, 192, 10, 12, "fwd"),       # C a multiple of 16 only, odd tile counts
+    (6, 512, 512, 4, 4, "fwd"),        # the deep levels: four tiles per image, mostly padding; split-K
+    (7, 512, 1024, 2, 2, "dgrad"),     # one tile per image
 ]
 
 
