@@ -1043,6 +1043,8 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(const mtd_wgra
     finish_scatter4(a, d.T, i4, s);
 }
 
+#include "conv_wgrad_wino.h"
+
 struct WPlan { int cfg, WN, WC, TG, ppw, nsplit, ntg, nw; };
 
 int g_wforce_cfg = -1, g_wforce_split = -1;     // tuning hook (mtd_conv_wgrad_override)
@@ -1118,6 +1120,30 @@ WPlan make_wplan(const mtd_wgrad_args& a) {
         pl.ppw = (int)ppw;
         pl.nsplit = (int)ns;
         return pl;
+    }
+    // Winograd F(2x2, 3x3) form (conv_wgrad_wino.h): 3x3 stride-1 layers with N, C multiples of 64 on maps of at least
+    // MTD_WGRAD_WINO_MIN_HW pixels a side.  cfg 16; ppw = chunks of eight tiles per pixel split.
+    static const int env_wino = [] { const char* e = getenv("MTD_WGRAD_WINO"); return e ? atoi(e) : 1; }();
+    static const int env_wino_hw = [] { const char* e = getenv("MTD_WGRAD_WINO_MIN_HW"); return e ? atoi(e) : 8; }();
+    if (((env_wino && g_wforce_cfg == -1) || g_wforce_cfg == 16) && wgrad_wino_ok(a) && a.g.OH >= env_wino_hw && a.g.OW >= env_wino_hw) {
+        pl.cfg = 16;
+        pl.WN = 2; pl.WC = 2; pl.TG = T; pl.ntg = 1; pl.nw = 8;
+        const long long blocks = (long long)(a.N / 64) * (a.C / 64);
+        const long long chunks = (M / 4 + WGW_T - 1) / WGW_T;
+        long long ns = (256 + blocks - 1) / blocks;              // about one workgroup per CU
+        if (g_wforce_split > 0) ns = g_wforce_split;
+        if (ns > chunks / 4) ns = chunks / 4;                    // at least four chunks per slice
+        if (ns < 2) ns = 2;                                      // (always through slabs: the kernel has no direct-store form)
+        if (ns > chunks) ns = chunks;
+        const long long cps = (chunks + ns - 1) / ns;
+        ns = (chunks + cps - 1) / cps;
+        if (ns >= 2) {
+            pl.ppw = (int)cps;
+            pl.nsplit = (int)ns;
+            return pl;
+        }
+        pl = WPlan{};
+        pl.cfg = (M <= 2048) ? 4 : 0;
     }
     const int bw = block_window_w(a);
     if ((row_window_ok(a) || bw) && g_wforce_cfg != -2) {   // override cfg -2: keep the LDS-staged kernels (A/B comparison)
@@ -1269,6 +1295,18 @@ static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, 
         // side stream beside the data-gradient chain, a second workgroup on a CU took the slots of the other stream's
         // kernel: 44.47 -> 44.03 ms per step (three A/B runs each, tools/wgrad_pad_full.sh).  MTD_WGRAD_LDS_PAD=0 is the old launch.
         static const unsigned lds_pad = [] { const char* e = getenv("MTD_WGRAD_LDS_PAD"); return e ? (unsigned)atoi(e) : 65536u; }();
+        if (pl.cfg == 16) {
+            WgradWinoParams wp;
+            wp.w = p;
+            wp.tiles_x = a->g.OW / 2;
+            wp.tiles_per_image = (a->g.OH / 2) * wp.tiles_x;
+            wp.ntiles = a->g.B * wp.tiles_per_image;
+            wp.chunks_per_split = pl.ppw;
+            MTD_LAUNCH(wgrad_wino_kernel, dim3(pl.nsplit, (a->N / 64) * (a->C / 64)), dim3(512), 0, s, wp);
+            mtd_prof_end(prof, s);
+            MTD_LAUNCH_CHECK();
+            return MTD_OK;
+        }
         switch (pl.cfg) {
             case 0: MTD_LAUNCH((wgrad_kernel<1, 1, 9>), grid, dim3(256), 0, s, p); break;
             case 1: MTD_LAUNCH((wgrad_kernel<1, 1, 4>), grid, dim3(256), 0, s, p); break;

@@ -1,0 +1,234 @@
+// Winograd F(2x2, 3x3) weight gradient on fp32 MFMA (included by conv_wgrad.hip inside its anonymous namespace).
+//
+//   dW = G^T [ sum over 2x2 output tiles  (A dY A^T) (.) (B^T d B) ] G        dY: the tile's cotangent, d: its 4x4 input patch
+//
+// -- the transpose of conv_winograd.hip's forward form: 16 multiplications per tile and (n, c) pair instead of 36.  For each
+// of the 16 transform positions xi an independent product over the TILES:
+//     dU_xi[n][c] += V_xi[tile][n] * U_xi[tile][c],     V = A dY A^T (4x4 from 2x2),  U = B^T d B.
+// A 512-thread workgroup owns a 64 (n) x 64 (c) block for all 16 positions -- wave w holds positions 2w, 2w+1 as 2 x 2 x 2
+// accumulator blocks of 32 x 32 (128 registers) -- over one slice of the tiles (pixel split: the slices' results go to slabs
+// that the existing fixed-order reduce sums, conv_wgrad.hip).  K runs in chunks of 8 tiles:
+//   * both operands need a transform, so both go through LDS, [xi][tile][64 channels]: a fragment of a k-step is one
+//     ds_read_b32 per lane (lane = channel, k half = tile parity), conflict-free;
+//   * thread (tile, channel quad, patch row) loads its row of the input patch as four 16-byte vectors, applies B along the row
+//     in registers and B^T across the quad with DPP (conv_winograd.hip's transform), stores one row of U as four 16-byte
+//     vectors; thread (tile, channel quad, pixel) loads its pixel of the cotangent tile as one 16-byte vector, gathers the
+//     quad's four pixels with DPP, forms row a = its quad position of A dY A^T, stores four 16-byte vectors -- and sums the
+//     cotangent for the bias gradient on the way;
+//   * the next chunk's loads are requested at the top of a chunk and transformed at its end, between the MFMAs; two LDS
+//     buffers, one workgroup barrier per chunk;
+//   * at the end the 16 positions of an (n, c) pair sit in 8 waves: they meet in LDS one 32 x 32 sub-block at a time, thread
+//     (n, c) applies G^T . G (16 -> 9 values) and writes the nine taps of the slab.
+// Slab layout = the other weight-gradient kernels': slab[(tap * N + n) * C + c], bias row at tap = 9.
+// Domain: forward-oriented 3x3 / stride 1 / pad 1 geometry, even map sides, N and C multiples of 64.
+// Roofline: fp32 MFMA; executed flops 2 M N C 4 of the algorithmic 2 M N C 9.
+
+constexpr int WGW_T = 8;                       // tiles per chunk
+constexpr int WGW_PL = WGW_T * 64 + 4;         // plane stride (floats) of one position: 16 bytes of skew per position keeps the four
+                                               // quad lanes' 16-byte stores (positions 4 i' + j) on different banks
+constexpr int WGW_BUF = 2 * 16 * WGW_PL;       // one chunk buffer: U planes then V planes
+constexpr int WGW_XLD = 33;
+
+struct WgradWinoParams {
+    WgradParams w;
+    int ntiles, tiles_x, tiles_per_image;
+    int chunks_per_split;
+};
+
+__device__ __forceinline__ float wgw_quad(float v, int ctrl) {
+    const int x = __builtin_bit_cast(int, v);
+    int r;
+    switch (ctrl) {
+        case 0: r = __builtin_amdgcn_update_dpp(0, x, 0x64, 0xf, 0xf, true); break;      // lanes [0, 1, 2, 1]
+        case 1: r = __builtin_amdgcn_update_dpp(0, x, 0xDA, 0xf, 0xf, true); break;      // lanes [2, 2, 1, 3]
+        case 2: r = __builtin_amdgcn_update_dpp(0, x, 0x00, 0xf, 0xf, true); break;      // lane 0
+        case 3: r = __builtin_amdgcn_update_dpp(0, x, 0x55, 0xf, 0xf, true); break;      // lane 1
+        case 4: r = __builtin_amdgcn_update_dpp(0, x, 0xAA, 0xf, 0xf, true); break;      // lane 2
+        default: r = __builtin_amdgcn_update_dpp(0, x, 0xFF, 0xf, 0xf, true); break;     // lane 3
+    }
+    return __builtin_bit_cast(float, r);
+}
+
+__global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgradWinoParams wp) {
+    __shared__ __attribute__((aligned(16))) float Ls[2 * WGW_BUF];         // 2 x 66 KB; the exchange image of the epilogue reuses it
+    const WgradParams& p = wp.w;
+    const mtd_wgrad_args& a = p.a;
+    const mtd_geom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int ncb = a.C / 64;
+    const int nblk = blockIdx.y / ncb, cblk = blockIdx.y - nblk * ncb;
+    const int n0 = nblk * 64, c0 = cblk * 64;
+    const int zk = blockIdx.x;
+    const int ck_beg = zk * wp.chunks_per_split;
+    const int nchunks_all = (wp.ntiles + WGW_T - 1) / WGW_T;
+    const int ck_end = min(nchunks_all, ck_beg + wp.chunks_per_split);
+    const int nck = ck_end - ck_beg;
+    const int ck_last = ck_end - 1;
+
+    // ---- transform roles: thread (tile t8 of the chunk, channel quad cq, quad position qp)
+    const int qp = tid & 3, cq = (tid >> 2) & 15, t8 = tid >> 6;
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.q), (short)0, (int)p.q_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p), (short)0, (int)p.p_bytes, 0x00020000);
+    const int qpx_b = a.q_ld * 4;
+    f32x4 d[4], yv;
+    f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
+    auto load_chunk = [&](int ck) {
+        const int tg = ck * WGW_T + t8;
+        const bool tv = tg < wp.ntiles;
+        const int b = tg / wp.tiles_per_image;
+        const int r = tg - b * wp.tiles_per_image;
+        const int ty = r / wp.tiles_x, tx = r - ty * wp.tiles_x;
+        // U: patch row qp = image row 2 ty - 1 + qp, pixels 2 tx - 1 .. 2 tx + 2, channels c0 + 4 cq ..
+        const int iy = 2 * ty - 1 + qp;
+        const unsigned ubase = (unsigned)(((((long long)b * g.IH + iy) * g.IW + (2 * tx - 1)) * a.q_ld + c0 + 4 * cq) * 4);
+        const bool rowok = tv & ((unsigned)iy < (unsigned)g.IH);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ix = 2 * tx - 1 + j;
+            const unsigned vo = (rowok & ((unsigned)ix < (unsigned)g.IW)) ? ubase + (unsigned)(j * qpx_b) : 0x80000000u;
+            d[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qrs, vo, 0, 0));
+        }
+        // V: cotangent pixel (2 ty + (qp >> 1), 2 tx + (qp & 1)), channels n0 + 4 cq ..
+        const long long pix = ((long long)b * g.OH + 2 * ty + (qp >> 1)) * g.OW + 2 * tx + (qp & 1);
+        const unsigned vo = tv ? (unsigned)((pix * a.p_ld + n0 + 4 * cq) * 4) : 0x80000000u;
+        yv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, vo, 0, 0));
+    };
+    const float usign = qp == 1 ? 1.f : -1.f;
+    // A = [1 0; 1 1; 1 -1; 0 -1]: row a = qp of A dY A^T is  alpha * R0 + beta * R1,  R_i[b] = (dY A^T)[i][b]
+    const float valpha = qp == 3 ? 0.f : 1.f, vbeta = qp == 0 ? 0.f : (qp == 1 ? 1.f : -1.f);
+    auto transform_store = [&](float* Lb) {
+        float* uo = Lb + t8 * 64 + 4 * cq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 rj = j == 0 ? d[0] - d[2] : (j == 1 ? d[1] + d[2] : (j == 2 ? d[2] - d[1] : d[1] - d[3]));
+            f32x4 u;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) u[c] = fmaf(usign, wgw_quad(rj[c], 1), wgw_quad(rj[c], 0));
+            *reinterpret_cast<f32x4*>(uo + (4 * qp + j) * WGW_PL) = u;
+        }
+        float* vo = Lb + 16 * WGW_PL + t8 * 64 + 4 * cq;
+        f32x4 y00, y01, y10, y11;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            y00[c] = wgw_quad(yv[c], 2);
+            y01[c] = wgw_quad(yv[c], 3);
+            y10[c] = wgw_quad(yv[c], 4);
+            y11[c] = wgw_quad(yv[c], 5);
+        }
+        dbacc += yv;
+        // R_i = [y_i0, y_i0 + y_i1, y_i0 - y_i1, -y_i1]
+        const f32x4 r0[4] = {y00, y00 + y01, y00 - y01, -y01};
+        const f32x4 r1[4] = {y10, y10 + y11, y10 - y11, -y11};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) *reinterpret_cast<f32x4*>(vo + (4 * qp + b) * WGW_PL) = valpha * r0[b] + vbeta * r1[b];
+    };
+
+    f32x16 acc[2][2][2];                       // [position][n half][c half]
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[x][h][h2][e] = 0.f;
+
+    if (nck > 0) {
+        load_chunk(ck_beg);
+        transform_store(Ls);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < nck; ++k) {
+        const float* Lc = Ls + (k & 1) * WGW_BUF;
+        float* Ln = Ls + ((k + 1) & 1) * WGW_BUF;
+        const bool more = k + 1 < nck;
+        load_chunk(min(ck_beg + k + 1, ck_last));                     // (clamped: the loop has one path; a repeated chunk is not stored)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const float* up = Lc + (2 * wave + x) * WGW_PL + (2 * s + kh) * 64 + l31;
+                const float* vp = up + 16 * WGW_PL;
+                const float a0 = vp[0], a1 = vp[32], b0 = up[0], b1 = up[32];
+                acc[x][0][0] = mfma32(a0, b0, acc[x][0][0]);
+                acc[x][0][1] = mfma32(a0, b1, acc[x][0][1]);
+                acc[x][1][0] = mfma32(a1, b0, acc[x][1][0]);
+                acc[x][1][1] = mfma32(a1, b1, acc[x][1][1]);
+            }
+        }
+        if (more) transform_store(Ln);
+        __syncthreads();
+    }
+
+    // ---- epilogue: G^T dU G per (n, c), one 32 x 32 sub-block at a time through X[xi][n][c]; the bias gradient
+    float* slab = a.ws + (long long)zk * p.slab_stride;
+    const int en_c = tid & 31, en_n = tid >> 5;                        // this thread's c and n (+16) inside the sub-block
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                float* X = Ls + (2 * wave + x) * (32 * WGW_XLD) + l31;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) X[mfma32_row(e, lane) * WGW_XLD] = acc[x][h][h2][e];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int nl = en_n + 16 * r;
+                float m[16];
+#pragma unroll
+                for (int xi = 0; xi < 16; ++xi) m[xi] = Ls[(xi * 32 + nl) * WGW_XLD + en_c];
+                // t = G^T m (3 x 4), out = t G (3 x 3);  G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]
+                float t[3][4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float hs = 0.5f * (m[4 + b] + m[8 + b]), hd = 0.5f * (m[4 + b] - m[8 + b]);
+                    t[0][b] = m[b] + hs;
+                    t[1][b] = hd;
+                    t[2][b] = hs + m[12 + b];
+                }
+                float* o = slab + ((long long)(n0 + 32 * h + nl)) * a.C + c0 + 32 * h2 + en_c;
+                const long long tap_stride = (long long)a.N * a.C;
+#pragma unroll
+                for (int pr = 0; pr < 3; ++pr) {
+                    const float hs = 0.5f * (t[pr][1] + t[pr][2]), hd = 0.5f * (t[pr][1] - t[pr][2]);
+                    o[(pr * 3 + 0) * tap_stride] = t[pr][0] + hs;
+                    o[(pr * 3 + 1) * tap_stride] = hd;
+                    o[(pr * 3 + 2) * tap_stride] = hs + t[pr][3];
+                }
+            }
+            __syncthreads();
+        }
+    if (a.db && cblk == 0) {
+        // bias gradient of the slice: the quad's four pixels, then the chunk's eight tiles (= the eight waves: t8 == wave)
+        f32x4 s;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[c] = ((wgw_quad(dbacc[c], 2) + wgw_quad(dbacc[c], 3)) + wgw_quad(dbacc[c], 4)) + wgw_quad(dbacc[c], 5);
+        if (qp == 0) *reinterpret_cast<f32x4*>(Ls + t8 * 64 + 4 * cq) = s;
+        __syncthreads();
+        if (tid < 64) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += Ls[w * 64 + tid];
+            slab[(long long)p.T * a.N * a.C + n0 + tid] = v;
+        }
+    }
+}
+
+// the kernel's domain
+bool wgrad_wino_ok(const mtd_wgrad_args& a) {
+    const mtd_geom& g = a.g;
+    if (g.TH != 3 || g.TW != 3 || g.in_sy != 1 || g.in_sx != 1 || g.tap_dy != 1 || g.tap_dx != 1 || g.off_y != -1 || g.off_x != -1) return false;
+    if (g.ky0 != 0 || g.kx0 != 0 || g.ky_step != 1 || g.kx_step != 1 || g.KW != 3) return false;
+    if (g.IH != g.OH || g.IW != g.OW || (g.OH & 1) || (g.OW & 1)) return false;
+    if ((a.N % 64) || (a.C % 64)) return false;
+    if (!aligned16(a.p) || !aligned16(a.q) || (a.p_ld % 4) || (a.q_ld % 4)) return false;
+    return true;
+}

@@ -201,7 +201,8 @@ IGEMM_CONFIGS = ["igemm_kernel<2, 1, 4, 1>", "igemm_kernel<1, 1, 4, 1>", "igemm_
 WGRAD_CONFIGS = ["wgrad_kernel<1, 1, 9>", "wgrad_kernel<1, 1, 4>", "wgrad_kernel<2, 2, 1>", "wgrad_kernel<1, 1, 8>",
                  "wgrad_kernel<1, 1, 3>", "wgrad_kernel<1, 1, 1>", "wgrad_kernel<2, 2, 3>",
                  "wgrad_row_kernel<3, 3, 1>", "wgrad_row_kernel<3, 3, -1>", "wgrad_row_kernel<1, 1, 1>",
-                 "wgrad_blk_kernel<8>", "wgrad_blk_kernel<4>", "wgrad_blk_kernel<2>", "wgrad_taps_kernel", "?", "wgrad_s2_kernel"]
+                 "wgrad_blk_kernel<8>", "wgrad_blk_kernel<4>", "wgrad_blk_kernel<2>", "wgrad_taps_kernel", "?", "wgrad_s2_kernel",
+                 "wgrad_wino_kernel"]
 
 
 def prof_enable(capacity):

@@ -668,3 +668,42 @@ def test_winograd_conv_vs_torch(hip_lib, case):
     v = y * sc + bias.cpu().double().view(1, -1, 1, 1) + nchw(add1).double() + nchw(add2).double()
     v = F.leaky_relu(v, 0.2) * torch.where(nchw(mask) > 0, 1.0, 0.2)
     assert relerr(nchw(outs[0]), v) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 64, 64, 64, 64), (3, 128, 64, 16, 16), (5, 256, 512, 8, 8), (2, 64, 128, 10, 12), (32, 64, 64, 32, 32)])
+def test_winograd_weight_gradient_vs_torch(hip_lib, case):
+    """csrc/conv_wgrad_wino.h, F(2x2, 3x3) weight + bias gradient (both operands transformed, 16 multiplications per tile and
+    (n, c) pair) against torch's autograd on the CPU in float64 and against the row-window / block-window kernels on the same
+    inputs; with and without accumulation into an existing gradient.  (5, 256, 512, 8, 8): 80 tiles = 10 chunks, ragged
+    slices; (2, 64, 128, 10, 12): odd tile counts per row."""
+    from mtd_gan_amd import _lib
+    from mtd_gan_amd import kernels as K
+    B, Ci, Co, H, W = case
+    gen = torch.Generator().manual_seed(23)
+    x = torch.randn(B, H, W, Ci, generator=gen).cuda()
+    gy = torch.randn(B, H, W, Co, generator=gen).cuda()
+    geom = K.geom_fwd(B, H, W, 3, 1, 1)
+    L = _lib.lib()
+    L.mtd_conv_wgrad_override.argtypes = [_lib.C.c_int, _lib.C.c_int]
+    res = {}
+    for name, cfg in (("wino", 16), ("direct", -2)):
+        L.mtd_conv_wgrad_override(cfg, -1)
+        try:
+            dw = torch.full((Co, Ci, 3, 3), 0.5, device="cuda")
+            db = torch.full((Co,), -1.0, device="cuda")
+            K.wgrad(gy, x, geom, Co, Ci, dw, Ci * 9, 9, db=db, accumulate=True)
+            dw2, db2 = torch.empty(Co, Ci, 3, 3, device="cuda"), torch.empty(Co, device="cuda")
+            K.wgrad(gy, x, geom, Co, Ci, dw2, Ci * 9, 9, db=db2)
+            torch.cuda.synchronize()
+            res[name] = (dw, db, dw2, db2)
+        finally:
+            L.mtd_conv_wgrad_override(-1, -1)
+    xc = nchw(x).double()
+    wc = torch.zeros(Co, Ci, 3, 3, dtype=torch.double, requires_grad=True)
+    bc = torch.zeros(Co, dtype=torch.double, requires_grad=True)
+    (F.conv2d(xc, wc, bc, padding=1) * nchw(gy).double()).sum().backward()
+    dw, db, dw2, db2 = res["wino"]
+    assert relerr(dw2.cpu(), wc.grad) < TOL and relerr(db2.cpu(), bc.grad) < TOL
+    assert relerr((dw - 0.5).cpu(), wc.grad) < TOL and relerr((db + 1.0).cpu(), bc.grad) < TOL
+    assert relerr(dw2.cpu(), res["direct"][2].cpu()) < 1e-4 and relerr(db2.cpu(), res["direct"][3].cpu()) < 1e-4
