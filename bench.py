@@ -42,6 +42,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-generator", action="store_true", help="skip the configs[1] generator object of the default workload")
+    ap.add_argument("--no-engine-api", action="store_true", help="skip the engine.train_MTD_GAN_Ours leg (profiling runs: only the timed steps)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / collective plumbing only: gloo on the CPU, a trivial step (no GPU, no HIP library)")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # launcher test: this rank exits with 3
@@ -454,7 +455,7 @@ def main(argv=None):
             line["config"]["parallelism"] += " (rehearsal: all ranks on ONE GPU, gloo through the host -- not a scaling figure)"
         line.update(wl.extra())
         line.update(extra)
-        if hasattr(wl, "engine_api_ms") and world == 1:
+        if hasattr(wl, "engine_api_ms") and world == 1 and not args.no_engine_api:
             # the same iterations through the kept API (engine.train_MTD_GAN_Ours, reference engine.py:26-76): the timed step above
             # is that loop's body, this is the loop itself
             ams = wl.engine_api_ms(args.steps)

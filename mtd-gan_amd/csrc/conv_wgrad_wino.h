@@ -72,14 +72,14 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgradWinoParam
     const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.q), (short)0, (int)p.q_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p), (short)0, (int)p.p_bytes, 0x00020000);
     const int qpx_b = a.q_ld * 4;
-    f32x4 d[4], yv;
+    struct Pre { f32x4 d[4]; f32x4 y; };      // one chunk's operands of this thread, on their way from memory
     f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
-    auto load_chunk = [&](int ck) {
+    auto load_chunk = [&](int ck, Pre& r) {
         const int tg = ck * WGW_T + t8;
         const bool tv = tg < wp.ntiles;
         const int b = tg / wp.tiles_per_image;
-        const int r = tg - b * wp.tiles_per_image;
-        const int ty = r / wp.tiles_x, tx = r - ty * wp.tiles_x;
+        const int rr = tg - b * wp.tiles_per_image;
+        const int ty = rr / wp.tiles_x, tx = rr - ty * wp.tiles_x;
         // U: patch row qp = image row 2 ty - 1 + qp, pixels 2 tx - 1 .. 2 tx + 2, channels c0 + 4 cq ..
         const int iy = 2 * ty - 1 + qp;
         const unsigned ubase = (unsigned)(((((long long)b * g.IH + iy) * g.IW + (2 * tx - 1)) * a.q_ld + c0 + 4 * cq) * 4);
@@ -88,41 +88,51 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgradWinoParam
         for (int j = 0; j < 4; ++j) {
             const int ix = 2 * tx - 1 + j;
             const unsigned vo = (rowok & ((unsigned)ix < (unsigned)g.IW)) ? ubase + (unsigned)(j * qpx_b) : 0x80000000u;
-            d[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qrs, vo, 0, 0));
+            r.d[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qrs, vo, 0, 0));
         }
         // V: cotangent pixel (2 ty + (qp >> 1), 2 tx + (qp & 1)), channels n0 + 4 cq ..
         const long long pix = ((long long)b * g.OH + 2 * ty + (qp >> 1)) * g.OW + 2 * tx + (qp & 1);
         const unsigned vo = tv ? (unsigned)((pix * a.p_ld + n0 + 4 * cq) * 4) : 0x80000000u;
-        yv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, vo, 0, 0));
+        r.y = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, vo, 0, 0));
     };
     const float usign = qp == 1 ? 1.f : -1.f;
     // A = [1 0; 1 1; 1 -1; 0 -1]: row a = qp of A dY A^T is  alpha * R0 + beta * R1,  R_i[b] = (dY A^T)[i][b]
     const float valpha = qp == 3 ? 0.f : 1.f, vbeta = qp == 0 ? 0.f : (qp == 1 ? 1.f : -1.f);
-    auto transform_store = [&](float* Lb) {
-        float* uo = Lb + t8 * 64 + 4 * cq;
+    // The transform of one chunk in six pieces (the K loop places them between groups of MFMAs): U columns 0 .. 3, then the
+    // cotangent's quad gather, then its two store pairs.  `live` = 1 for a chunk of the slice, 0 for the clamped repeat past
+    // its end (stored into a buffer nobody reads, not summed into the bias gradient).
+    f32x4 vr0[4], vr1[4];
+    auto tr_u = [&](float* Lb, const Pre& r, int j) {
+        const f32x4 rj = j == 0 ? r.d[0] - r.d[2] : (j == 1 ? r.d[1] + r.d[2] : (j == 2 ? r.d[2] - r.d[1] : r.d[1] - r.d[3]));
+        f32x4 u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 rj = j == 0 ? d[0] - d[2] : (j == 1 ? d[1] + d[2] : (j == 2 ? d[2] - d[1] : d[1] - d[3]));
-            f32x4 u;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) u[c] = fmaf(usign, wgw_quad(rj[c], 1), wgw_quad(rj[c], 0));
-            *reinterpret_cast<f32x4*>(uo + (4 * qp + j) * WGW_PL) = u;
-        }
-        float* vo = Lb + 16 * WGW_PL + t8 * 64 + 4 * cq;
+        for (int c = 0; c < 4; ++c) u[c] = fmaf(usign, wgw_quad(rj[c], 1), wgw_quad(rj[c], 0));
+        *reinterpret_cast<f32x4*>(Lb + t8 * 64 + 4 * cq + (4 * qp + j) * WGW_PL) = u;
+    };
+    auto tr_v_gather = [&](const Pre& r, float live) {
         f32x4 y00, y01, y10, y11;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            y00[c] = wgw_quad(yv[c], 2);
-            y01[c] = wgw_quad(yv[c], 3);
-            y10[c] = wgw_quad(yv[c], 4);
-            y11[c] = wgw_quad(yv[c], 5);
+            y00[c] = wgw_quad(r.y[c], 2);
+            y01[c] = wgw_quad(r.y[c], 3);
+            y10[c] = wgw_quad(r.y[c], 4);
+            y11[c] = wgw_quad(r.y[c], 5);
         }
-        dbacc += yv;
+        dbacc += live * r.y;
         // R_i = [y_i0, y_i0 + y_i1, y_i0 - y_i1, -y_i1]
-        const f32x4 r0[4] = {y00, y00 + y01, y00 - y01, -y01};
-        const f32x4 r1[4] = {y10, y10 + y11, y10 - y11, -y11};
+        vr0[0] = y00; vr0[1] = y00 + y01; vr0[2] = y00 - y01; vr0[3] = -y01;
+        vr1[0] = y10; vr1[1] = y10 + y11; vr1[2] = y10 - y11; vr1[3] = -y11;
+    };
+    auto tr_v_store = [&](float* Lb, int b0) {
+        float* vo = Lb + 16 * WGW_PL + t8 * 64 + 4 * cq;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) *reinterpret_cast<f32x4*>(vo + (4 * qp + b) * WGW_PL) = valpha * r0[b] + vbeta * r1[b];
+        for (int b = b0; b < b0 + 2; ++b) *reinterpret_cast<f32x4*>(vo + (4 * qp + b) * WGW_PL) = valpha * vr0[b] + vbeta * vr1[b];
+    };
+    auto transform_store = [&](float* Lb, const Pre& r, float live) {
+        tr_u(Lb, r, 0); tr_u(Lb, r, 1); tr_u(Lb, r, 2); tr_u(Lb, r, 3);
+        tr_v_gather(r, live);
+        tr_v_store(Lb, 0);
+        tr_v_store(Lb, 2);
     };
 
     f32x16 acc[2][2][2];                       // [position][n half][c half]
@@ -135,34 +145,55 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgradWinoParam
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[x][h][h2][e] = 0.f;
 
+    Pre pa, pb;
     if (nck > 0) {
-        load_chunk(ck_beg);
-        transform_store(Ls);
+        load_chunk(ck_beg, pa);
+        transform_store(Ls, pa, 1.f);
+        load_chunk(min(ck_beg + 1, ck_last), pa);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
-#pragma unroll 1
-    for (int k = 0; k < nck; ++k) {
+    // One chunk: the operands of chunk k + 2 are requested at the top (TWO chunks of MFMAs cover their way from HBM: two
+    // register sets alternate), the 32 MFMAs of chunk k run with their fragments read from LDS one group ahead, and the
+    // transform of chunk k + 1 (requested a chunk ago) is interleaved with the second half of the MFMAs.  One path through
+    // the loop (indices clamped), so the compiler's wait counts are exact.
+    auto one_chunk = [&](int k, const Pre& cur, Pre& nxt) {
         const float* Lc = Ls + (k & 1) * WGW_BUF;
         float* Ln = Ls + ((k + 1) & 1) * WGW_BUF;
-        const bool more = k + 1 < nck;
-        load_chunk(min(ck_beg + k + 1, ck_last));                     // (clamped: the loop has one path; a repeated chunk is not stored)
+        load_chunk(min(ck_beg + k + 2, ck_last), nxt);
         __builtin_amdgcn_sched_barrier(0);
+        float fa[2][2], fb[2][2];                                      // [ping-pong][half]
+        auto frag = [&](int gi, int pp) {                             // group gi = 2 s + x
+            const int sst = gi >> 1, x = gi & 1;
+            const float* up = Lc + (2 * wave + x) * WGW_PL + (2 * sst + kh) * 64 + l31;
+            const float* vp = up + 16 * WGW_PL;
+            fa[pp][0] = vp[0]; fa[pp][1] = vp[32];
+            fb[pp][0] = up[0]; fb[pp][1] = up[32];
+        };
+        frag(0, 0);
+        const float live = (k + 1 < nck) ? 1.f : 0.f;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                const float* up = Lc + (2 * wave + x) * WGW_PL + (2 * s + kh) * 64 + l31;
-                const float* vp = up + 16 * WGW_PL;
-                const float a0 = vp[0], a1 = vp[32], b0 = up[0], b1 = up[32];
-                acc[x][0][0] = mfma32(a0, b0, acc[x][0][0]);
-                acc[x][0][1] = mfma32(a0, b1, acc[x][0][1]);
-                acc[x][1][0] = mfma32(a1, b0, acc[x][1][0]);
-                acc[x][1][1] = mfma32(a1, b1, acc[x][1][1]);
-            }
+        for (int gi = 0; gi < 8; ++gi) {
+            const int pp = gi & 1, x = gi & 1;
+            __builtin_amdgcn_sched_barrier(0);
+            if (gi + 1 < 8) frag(gi + 1, pp ^ 1);                      // the next group's fragments, under this group's MFMAs
+            acc[x][0][0] = mfma32(fa[pp][0], fb[pp][0], acc[x][0][0]);
+            acc[x][0][1] = mfma32(fa[pp][0], fb[pp][1], acc[x][0][1]);
+            acc[x][1][0] = mfma32(fa[pp][1], fb[pp][0], acc[x][1][0]);
+            acc[x][1][1] = mfma32(fa[pp][1], fb[pp][1], acc[x][1][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            // the transform of chunk k + 1, a piece per group from the second group on (its operands were requested a chunk ago)
+            if (gi >= 1 && gi <= 4) tr_u(Ln, cur, gi - 1);
+            else if (gi == 5) tr_v_gather(cur, live);
+            else if (gi == 6) tr_v_store(Ln, 0);
+            else if (gi == 7) tr_v_store(Ln, 2);
         }
-        if (more) transform_store(Ln);
         __syncthreads();
+    };
+#pragma unroll 1
+    for (int k = 0; k < nck; k += 2) {
+        one_chunk(k, pa, pb);
+        if (k + 1 < nck) one_chunk(k + 1, pb, pa);
     }
 
     // ---- epilogue: G^T dU G per (n, c), one 32 x 32 sub-block at a time through X[xi][n][c]; the bias gradient

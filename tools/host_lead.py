@@ -61,3 +61,11 @@ for label, th, ev in marks:
     g = a_ev.elapsed_time(ev)
     print(f"{label:26s} host {h:8.2f} ms (+{h - prev_h:6.2f})   gpu {g:8.2f} ms (+{g - prev_g:6.2f})   lead {g - h:7.2f} ms")
     prev_h, prev_g = h, g
+starts = [(th - t0) / 1e6 for label, th, ev in marks if label == "step start"]
+ends = [(th - t0) / 1e6 for label, th, ev in marks if label == "G adamw done"]
+gstart = [a_ev.elapsed_time(ev) for label, th, ev in marks if label == "step start"]
+gend = [a_ev.elapsed_time(ev) for label, th, ev in marks if label == "G adamw done"]
+host_ms = [e - s for s, e in zip(starts, ends)]
+print(f"host enqueue per step: {sum(host_ms) / len(host_ms):.2f} ms (min {min(host_ms):.2f}, max {max(host_ms):.2f}); "
+      f"GPU per step: {(gend[-1] - gstart[0]) / len(gstart):.2f} ms; host / GPU = {sum(host_ms) / len(host_ms) / ((gend[-1] - gstart[0]) / len(gstart)):.2f} "
+      f"(pid {os.getpid()}, {os.cpu_count()} CPUs visible)")

@@ -1,28 +1,27 @@
 #!/bin/bash
-# Copies the summaries of the last tools/r2_check.sh + tools/r2_pmc.sh run from gpurun_out/ (scratch) to profiles/ (tracked)
+# Copies the summaries of the last tools/r3_measure.sh run from gpurun_out/ (scratch) to profiles/ (tracked)
 # and rewrites profiles/pmc_manifest.json with the kernel-source hash the PMC passes were taken at.  Run after a gpurun call
 # of both scripts, with the same kernel sources checked out.
 set -e
 cd "$(dirname "$0")/.."
-R=${1:-r2}
+R=${1:-r3}
 O=gpurun_out
 cp $O/bench_full.json profiles/${R}_full_step_bench.json
-cp $O/bench_full_bracket.json profiles/${R}_full_step_bench_bracket_timing.json
 cp $O/prof_full/full_results_kernel_stats.csv profiles/${R}_full_step_kernel_stats_single_stream.csv
 cp $O/prof_gen/gen_results_kernel_stats.csv profiles/${R}_generator_kernel_stats_single_stream.csv
 for wl in full_step generator; do
-  for k in fetch write mfma_util; do cp $O/r2_pmc_${wl}_$k.csv profiles/${R}_pmc_${wl}_$k.csv; done
+  for k in fetch write mfma_util; do cp $O/pmc_${wl}_$k.csv profiles/${R}_pmc_${wl}_$k.csv; done
 done
 python - "$R" <<'PY'
 import json, subprocess, sys
 sys.path.insert(0, ".")
 import bench
 R = sys.argv[1]
-h_run = open("gpurun_out/r2_pmc_source_hash.txt").read().strip()
+h_run = open("gpurun_out/pmc_source_hash.txt").read().strip()
 h_now = bench._kernel_source_hash()
 assert h_run == h_now, f"PMC passes were taken at source hash {h_run}, the tree is at {h_now}"
 commit = subprocess.check_output(["git", "rev-parse", "HEAD"], text=True).strip()
-cmd = "tools/r2_pmc.sh (rocprofv3 --pmc <counter(s)> --kernel-trace, one pass per counter set, eager single-stream launches)"
+cmd = "tools/r3_measure.sh (rocprofv3 --pmc <counter(s)> --kernel-trace, one pass per counter set, eager single-stream launches)"
 man = {wl: {"files": {"fetch": f"{R}_pmc_{wl}_fetch.csv", "write": f"{R}_pmc_{wl}_write.csv", "mfma": f"{R}_pmc_{wl}_mfma_util.csv"},
             "commit": commit, "source_hash": h_now, "command": cmd} for wl in ("full_step", "generator")}
 json.dump(man, open("profiles/pmc_manifest.json", "w"), indent=1)
