@@ -12,8 +12,8 @@
 // accumulator registers across the workgroup's whole pixel range).  A SIMD hosts one wave of each role: while one waits
 // for its fragments, its epilogue operands or its stores, the other has the matrix pipe -- the pipe sees 2 x 288 MFMAs
 // per tile back to back, and prologue, tail and launch cost are paid once per layer.
-// The workgroup barrier is shared by the roles: both execute one per tile (the halo buffers' hand-over), and the data-
-// gradient waves join the barriers of the weight-gradient waves' final cross-wave sum.
+// The main loops have NO workgroup barrier (private halos, counted vmcnt waits per wave); the roles meet at barrier 0 (the
+// weights are in LDS) and at the barriers of the weight-gradient waves' final cross-wave sum, which the data-gradient waves join.
 //
 // Results: the data gradient's arithmetic (tap order, accumulation order, epilogue) is the halo-tile kernel's; the weight
 // gradient waves take the pixel runs the stand-alone row-window launch would give them, so at 256 workgroups (32 patches)
@@ -185,7 +185,9 @@ __global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) 
             }
             // the next block's halo has landed: every memory operation older than this block's stores is complete
             // (s_waitcnt vmcnt(N): all but the N youngest vector-memory operations, loads, stores and LDS-DMA alike, in issue order)
-            if (!live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (the counts assume that epiw_store issues exactly `nstores` vector-memory instructions after the DMAs of stage():
+            //  roles bit 3, MTD_C32F_SAFE_WAIT=1, waits for everything instead -- tests compare the two bit for bit)
+            if (!live || (fp.roles & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (nstores == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             if (wave == 0 && k < 4) C32F_STAMP(2 + k);
@@ -425,7 +427,8 @@ int c32_bwd_launch(const mtd_conv_args* d, const mtd_wgrad_args* w, const float*
     fp.iters = (fp.ntiles + grid - 1) / grid;
     p.nslab = grid;
     static const int env_roles = [] { const char* e = getenv("MTD_C32F_ROLES"); return e ? atoi(e) : 3; }();
-    fp.roles = env_roles;
+    const char* safe = getenv("MTD_C32F_SAFE_WAIT");        // (read per call: the test flips it)
+    fp.roles = env_roles | ((safe && safe[0] == '1') ? 8 : 0);
     static const bool want_stamps = getenv("MTD_C32F_STAMPS") != nullptr;
     if (want_stamps && !g_c32f_stamps && hipMalloc(&g_c32f_stamps, 256 * sizeof(unsigned long long)) != hipSuccess) g_c32f_stamps = nullptr;
     fp.stamps = g_c32f_stamps;

@@ -1702,10 +1702,17 @@ extern "C" int mtd_resfft_block_tail(const mtd_conv_args* a, const float* T, voi
 // strides and epilogue operand KINDS (each set brings its own pointers / geometry offsets); every set with split-K needs
 // its own workspace of mtd_conv_igemm_multi_ws_bytes(a, count) bytes.  Falls back to `count` single launches when the
 // plan picks a kernel without a multi form.
+// does a multi call run as `count` single launches (count 1, a plan without a multi form, a forced configuration, the
+// generator-shaped kernels)?  One predicate for the workspace size and the launcher.
+static bool multi_falls_back(const mtd_conv_args* a, int count, const Plan& pl) {
+    const bool gen_shape = a[0].C == 32 && a[0].g.TH * a[0].g.TW == 9 && geom_pixels(a[0].g) >= 32768;
+    return count == 1 || pl.cfg > 5 || g_force_cfg >= 6 || gen_shape;
+}
+
 extern "C" size_t mtd_conv_igemm_multi_ws_bytes(const mtd_conv_args* a, int count) {
     if (!a || count < 1 || count > MULTI_MAX || check_args(a[0]) != MTD_OK) return 0;
     Plan pl = make_plan(a[0], count);
-    if (pl.cfg > 5) pl = make_plan(a[0]);
+    if (multi_falls_back(a, count, pl)) return mtd_conv_igemm_ws_bytes(&a[0]);      // the single launches' own plan
     if (pl.splitk <= 1) return 0;
     return (size_t)pl.splitk * (size_t)geom_pixels(a[0].g) * a[0].N * sizeof(float);
 }
@@ -1718,10 +1725,16 @@ extern "C" int mtd_conv_igemm_multi(const mtd_conv_args* a, int count, void* str
         if (a[i].out2) return MTD_EINVAL;
         if (geom_pixels(a[i].g) != geom_pixels(a[0].g) || a[i].N != a[0].N || a[i].C != a[0].C || a[i].g.TH != a[0].g.TH ||
             a[i].g.TW != a[0].g.TW) return MTD_EINVAL;
+        // one kernel body serves every set: the weight-view strides and the KINDS of the epilogue operands must agree (each set
+        // brings its own pointers), or a set would read through another set's null operand
+        if (a[i].w_sn != a[0].w_sn || a[i].w_sc != a[0].w_sc || a[i].w_st != a[0].w_st || a[i].act != a[0].act ||
+            a[i].mask_slope != a[0].mask_slope || a[i].scale_split != a[0].scale_split) return MTD_EINVAL;
+        if ((a[i].bias == nullptr) != (a[0].bias == nullptr) || (a[i].add1 == nullptr) != (a[0].add1 == nullptr) ||
+            (a[i].add2 == nullptr) != (a[0].add2 == nullptr) || (a[i].mask == nullptr) != (a[0].mask == nullptr) ||
+            (a[i].scale == nullptr) != (a[0].scale == nullptr) || (a[i].scale2 == nullptr) != (a[0].scale2 == nullptr)) return MTD_EINVAL;
     }
     Plan pl = make_plan(a[0], count);
-    const bool gen_shape = a[0].C == 32 && a[0].g.TH * a[0].g.TW == 9 && geom_pixels(a[0].g) >= 32768;
-    if (count == 1 || pl.cfg > 5 || g_force_cfg >= 6 || gen_shape) {
+    if (multi_falls_back(a, count, pl)) {
         for (int i = 0; i < count; ++i) {
             int rc = mtd_conv_igemm(&a[i], stream);
             if (rc != MTD_OK) return rc;

@@ -707,3 +707,32 @@ def test_winograd_weight_gradient_vs_torch(hip_lib, case):
     assert relerr(dw2.cpu(), wc.grad) < TOL and relerr(db2.cpu(), bc.grad) < TOL
     assert relerr((dw - 0.5).cpu(), wc.grad) < TOL and relerr((db + 1.0).cpu(), bc.grad) < TOL
     assert relerr(dw2.cpu(), res["direct"][2].cpu()) < 1e-4 and relerr(db2.cpu(), res["direct"][3].cpu()) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,second", [(4, False), (12, True), (20, True), (40, True)])
+def test_fused_c32_backward_counted_waits_same_bits(hip_lib, monkeypatch, B, second):
+    """conv_c32_bwd.hip hands a 32-pixel block's halo buffer to the next DMA after `s_waitcnt vmcnt(4 | 8)` -- counts that assume
+    the epilogue issues exactly that many vector-memory instructions after the DMAs.  MTD_C32F_SAFE_WAIT=1 waits for everything
+    instead; both must give the same bits, with and without the second output, on grids below 256 workgroups (B = 4: 64 tiles),
+    with one and two live tiles per workgroup (B = 20), and with several iterations per workgroup (B = 40: 640 tiles)."""
+    from mtd_gan_amd import kernels as K
+    H = W = 64
+    gen = torch.Generator().manual_seed(29)
+    r = lambda *s: torch.randn(*s, generator=gen).cuda()
+    p_, q_, add1, mask = r(B, H, W, 32), r(B, H, W, 32), r(B, H, W, 32), r(B, H, W, 32)
+    w = (torch.randn(32, 32, 3, 3, generator=gen) * 0.1).cuda()
+    gf, gt = K.geom_fwd(B, H, W, 3, 1, 1), K.geom_dgrad_s1(B, H, W, 3, 1)
+    res = []
+    for safe in ("0", "1"):
+        monkeypatch.setenv("MTD_C32F_SAFE_WAIT", safe)
+        out, out2 = torch.zeros(B, H, W, 32, device="cuda"), torch.zeros(B, H, W, 32, device="cuda")
+        dw, db = torch.zeros(32, 32, 3, 3, device="cuda"), torch.zeros(32, device="cuda")
+        defer = K.DeferredWgrads()
+        call = ((p_, w, gt, 32, 32, 9, 32 * 9, out), dict(add1=add1, mask=mask, mask_slope=0.0, out2=out2 if second else None))
+        assert K.conv_wgrad_fused(call, ((p_, q_, gf, 32, 32, dw, 32 * 9, 9), dict(db=db)), defer)
+        K.flush_wgrads(defer)
+        torch.cuda.synchronize()
+        res.append((out, out2, dw, db))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
