@@ -1075,7 +1075,7 @@ def set_concurrency(on):
     torch.cuda.synchronize()
     on = bool(on) and os.environ.get("MTD_NO_SIDE_STREAMS", "0") != "1"
     SIDE_STREAMS = on
-    CHAINS = on and os.environ.get("MTD_NO_CHAINS", "0") != "1"
+    CHAINS = on and os.environ.get("MTD_CHAINS", "0") == "1"
     for s in _side.values():
         s.enabled = on
 
@@ -1201,7 +1201,11 @@ def chain_stream(device, idx):
     return s
 
 
-CHAINS = os.environ.get("MTD_NO_CHAINS", "0") != "1" and os.environ.get("MTD_NO_SIDE_STREAMS", "0") != "1"
+# The three PCGrad task passes of the D step as concurrent chains (main + two chain streams): +2 % in rounds 1-2, when the small-map
+# launches of one chain filled the ramps and tails of another's.  With the Winograd kernels -- one workgroup per CU at 246 registers,
+# nothing co-resides -- the chains no longer overlap and their ~140 event records / waits per step only cost the host: 993 img/s with,
+# 1 006 without (round 3).  Off by default; MTD_CHAINS=1 switches them on.
+CHAINS = os.environ.get("MTD_CHAINS", "0") == "1" and os.environ.get("MTD_NO_SIDE_STREAMS", "0") != "1"
 
 
 def crosses_streams(*tensors):
