@@ -195,7 +195,7 @@ CALL_LOG = None     # tools/tune_igemm.py: a list collects ("igemm" | "wgrad", b
 IGEMM_CONFIGS = ["igemm_kernel<2, 1, 4, 1>", "igemm_kernel<1, 1, 4, 1>", "igemm_kernel<2, 2, 4, 1>",
                  "igemm_kernel<1, 1, 2, 2>", "igemm_kernel<2, 2, 2, 2>", "igemm_kernel<1, 1, 1, 4>",
                  "igemm_tb_kernel<1>", "igemm_tb_kernel<2>", "igemm_v2_kernel<0>", "igemm_c32p_kernel", "igemm_c32t_kernel", "c32_bwd_kernel",
-                 "igemm_c32t_kernel<4, true, true, true>", "c32_bwd_kernel<spec>", "wino_conv_kernel", "?",      # 12: Res-FFT block tail; 13: c32_bwd + irfft; 14: Winograd
+                 "igemm_c32t_kernel<4, true, true, true>", "c32_bwd_kernel<1, true>", "wino_conv_kernel", "?",      # 12: Res-FFT block tail; 13: c32_bwd + irfft; 14: Winograd
                  "igemm_multi_kernel<2, 1, 4, 1>", "igemm_multi_kernel<1, 1, 4, 1>", "igemm_multi_kernel<2, 2, 4, 1>",      # 16 + cfg
                  "igemm_multi_kernel<1, 1, 2, 2>", "igemm_multi_kernel<2, 2, 2, 2>", "igemm_multi_kernel<1, 1, 1, 4>"]
 WGRAD_CONFIGS = ["wgrad_kernel<1, 1, 9>", "wgrad_kernel<1, 1, 4>", "wgrad_kernel<2, 2, 1>", "wgrad_kernel<1, 1, 8>",
