@@ -63,27 +63,31 @@ def conv_views(P, backward):
     that they can be packed in one launch per optimizer step instead of one per layer."""
     v = []
 
-    def add(name, N, Cc, k, suffix=".weight_orig"):
+    def add(name, N, Cc, k, suffix=".weight_orig", r=0):
         w = P.get(name + suffix)
         if w is None:                                          # a head this discriminator does not have (ablation subsets)
             return
-        v.append((w, N, Cc, Cc * k * k, k * k))               # forward view (OIHW)
-        if backward:
+        # (3x3 layers on r x r maps that kernels.conv() sends to the Winograd kernel need no [tap][n][c] view: winograd_views)
+        if not (r and K.winograd_takes(K.geom_fwd(1, r, r, 3, 1, 1), N, Cc, {})):
+            v.append((w, N, Cc, Cc * k * k, k * k))           # forward view (OIHW)
+        if backward and not (r and K.winograd_takes(K.geom_dgrad_s1(1, r, r, 3, 1), Cc, N, {})):
             v.append((w, Cc, N, k * k, Cc * k * k))           # data-gradient view (transposed)
 
-    cin = 1
+    cin, r = 1, 64
     for l, co in enumerate(CH, start=1):
-        add(f"conv{l}1", co, cin, 3)
-        add(f"conv{l}2", co, co, 3)
+        add(f"conv{l}1", co, cin, 3, r=r)
+        add(f"conv{l}2", co, co, 3, r=r)
         add(f"down{l}", co, co, 4)
-        cin = co
+        cin, r = co, r // 2
     add("bconv1", 512, 512, 1)
     add("bconv2", 512, 512, 1)
     add("c_fc", 512, 512, 1)
     for pre in ("s", "r"):
+        r = 2
         for l, (ci, co) in enumerate(DEC, start=1):
-            add(f"{pre}_dconv{l}1", co, ci, 3)
-            add(f"{pre}_dconv{l}2", co, co, 3)
+            add(f"{pre}_dconv{l}1", co, ci, 3, r=r)
+            add(f"{pre}_dconv{l}2", co, co, 3, r=r)
+            r *= 2
     for l, (ci, cu) in enumerate(RUP, start=1):
         add(f"r_up{l}.upsample.0", 4 * cu, ci, 1, ".weight")
     return v
