@@ -310,13 +310,20 @@ class GradSink:
         return self.t.get(name)
 
 
-def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0, dec_export=None, dec_import=None):
+FLUSH_LEVEL = 4      # trunk levels 6 .. FLUSH_LEVEL + both bottleneck convs: 91 % of the shared parameters, done 60 % into the trunk
+
+
+def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0, dec_export=None, dec_import=None, flush=None):
     """Replay one recorded pass.  g_enc (B,1,1,1) / g_dec (B,64,64,1) / g_rec (B,64,64,1): output
     cotangents (any may be None).  sink: GradSink or None.  All parameter gradients are ACCUMULATED.
     The decoders are task-specific: their parameter gradient is the SUM over the tasks that reach them through this tape,
     and a weight gradient is linear in the cotangent -- so a pass may hand its decoder cotangents over instead of computing
     the decoder weight gradients (dec_export: dict to fill, layer -> cotangent tensor) and the last pass over the tape
-    computes them once from the sums (dec_import: the dicts of the earlier passes merged)."""
+    computes them once from the sums (dec_import: the dicts of the earlier passes merged).
+    flush: optional callable(stage) for a caller that ships finished gradients while the pass is still running (data
+    parallelism: the all-reduce of a slice overlaps the rest of this pass).  Called with "heads" when every decoder / head
+    gradient of this pass has been enqueued, spectral-norm corrections included, and with "trunk_low" when the same holds
+    for the bottleneck and trunk levels 6 .. FLUSH_LEVEL; the work it waits for is on the side stream (side.run orders after it)."""
     B = tp.B
     x = tp.x_in
     dev = x.device
@@ -374,6 +381,43 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0
         gd = K.geom_dgrad_s1(B, r, r, k, (k - 1) // 2)
         return K.conv(gpre, P[name + ".weight_orig"], gd, N, Cc, k * k, N * k * k, out, add1=add1, mask=mask, mask_slope=0.2,
                       **_scales(tp, name, gd))
+
+    def sn_fix():
+        """Corrects and accumulates the raw weight gradients taken since the last call (one launch, on the side stream:
+        the stream of the weight gradients it corrects; callers join() before reading the sink)."""
+        if not sn_touched:
+            return
+        L = _lib.lib()
+        structs = []
+        for name in sn_touched:
+            i = SN_INDEX[name]
+            s = _lib.SnGradLayer()
+            s.G = rt.gtemp(name, dev, 0, chain).data_ptr()
+            s.w = P[name + ".weight_orig"].data_ptr()
+            s.u = tp.u_save.data_ptr() + 4 * SN_ROW_OFF[i]
+            s.v = tp.v_save.data_ptr() + 4 * SN_COL_OFF[i]
+            s.sigma = tp.sig.data_ptr() + 8 * i
+            s.g_out = sink.get(name + ".weight_orig").data_ptr()
+            s.rows, s.cols, s.accumulate = SN_SPECS[i][1], SN_SPECS[i][2], 1
+            if Bh:      # the second half's own sigma, u, v: corrected and added in the same launch, after the first
+                s.G2 = rt.gtemp(name, dev, 1, chain).data_ptr()
+                s.u2 = tp.u_save2.data_ptr() + 4 * SN_ROW_OFF[i]
+                s.v2 = tp.v_save2.data_ptr() + 4 * SN_COL_OFF[i]
+                s.sigma2 = tp.sig2.data_ptr() + 8 * i
+            structs.append(s)
+        del sn_touched[:]
+        dev_tab, host_arr = K.device_table(structs, dev)
+        need = L.mtd_sn_grad_ws_bytes(C.cast(host_arr, C.c_void_p), len(structs))
+
+        def fix():
+            ws = K.workspace(need, dev)
+            K.check(L.mtd_sn_grad(dev_tab.data_ptr(), C.cast(host_arr, C.c_void_p), len(structs), ws.data_ptr(), K.stream_ptr()), "mtd_sn_grad")
+        side.run(fix)
+
+    def flush_point(stage):
+        if flush is not None:
+            sn_fix()
+            flush(stage)
 
     g_bot_parts = []
     g_skip = {l: [] for l in range(1, 7)}
@@ -444,6 +488,8 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0
         K.conv(gpre, P[wn], g1, 512, 512, 1, 512, gb, **_scales(tp, "c_fc", g1))
         g_bot_parts.append(gb)
 
+    flush_point("heads")
+
     # ---- bottleneck
     gbot = g_bot_parts[0]
     for extra in g_bot_parts[1:]:
@@ -482,6 +528,8 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0
         gpre1 = K.empty_nhwc(B, h, h, co, x)
         dgrad_s1(f"conv{l}2", gpre2, h, co, co, gpre1, mask=a)
         wgrad_sn(f"conv{l}1", gpre1, tin, (h, 3, 1, 1), co, ci, 3)
+        if l == FLUSH_LEVEL:
+            flush_point("trunk_low")
         if l > 1:
             g = K.empty_nhwc(B, h, h, ci, x)
             dgrad_s1(f"conv{l}1", gpre1, h, ci, co, g)
@@ -490,30 +538,5 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0
             dgrad_s1("conv11", gpre1, h, 1, co, g_in)
 
     # ---- spectral-norm correction of the raw weight gradients, accumulated into the sink
-    if sn_touched:
-        L = _lib.lib()
-        structs = []
-        for name in sn_touched:
-            i = SN_INDEX[name]
-            s = _lib.SnGradLayer()
-            s.G = rt.gtemp(name, dev, 0, chain).data_ptr()
-            s.w = P[name + ".weight_orig"].data_ptr()
-            s.u = tp.u_save.data_ptr() + 4 * SN_ROW_OFF[i]
-            s.v = tp.v_save.data_ptr() + 4 * SN_COL_OFF[i]
-            s.sigma = tp.sig.data_ptr() + 8 * i
-            s.g_out = sink.get(name + ".weight_orig").data_ptr()
-            s.rows, s.cols, s.accumulate = SN_SPECS[i][1], SN_SPECS[i][2], 1
-            if Bh:      # the second half's own sigma, u, v: corrected and added in the same launch, after the first
-                s.G2 = rt.gtemp(name, dev, 1, chain).data_ptr()
-                s.u2 = tp.u_save2.data_ptr() + 4 * SN_ROW_OFF[i]
-                s.v2 = tp.v_save2.data_ptr() + 4 * SN_COL_OFF[i]
-                s.sigma2 = tp.sig2.data_ptr() + 8 * i
-            structs.append(s)
-        dev_tab, host_arr = K.device_table(structs, dev)
-        need = L.mtd_sn_grad_ws_bytes(C.cast(host_arr, C.c_void_p), len(structs))
-
-        def fix():
-            ws = K.workspace(need, dev)
-            K.check(L.mtd_sn_grad(dev_tab.data_ptr(), C.cast(host_arr, C.c_void_p), len(structs), ws.data_ptr(), K.stream_ptr()), "mtd_sn_grad")
-        side.run(fix)        # same stream as the weight gradients it corrects; callers join() before reading the sink
+    sn_fix()
     return g_in

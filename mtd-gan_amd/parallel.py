@@ -3,8 +3,8 @@ xGMI.  Replaces the reference's single-process nn.DataParallel (train.py:93-98),
 PCGrad path at all.  To reproduce the large-batch step exactly, PCGrad is nonlinear in
 the gradients, so each per-task shared-gradient vector is averaged across ranks BEFORE the projection:
 three 114 MB all-reduces per iteration, each enqueued on a side stream as soon as that task's backward
-has been issued so that it overlaps the next task's backward kernels; all ranks draw the same shuffle
-order (same `random` seed).  On CPU the same code runs on the gloo backend (tests)."""
+has been issued so that it overlaps the next task's backward kernels (the last task ships its finished
+slices while it still runs: train_step.DStepTape.run_pcgrad); rank 0's shuffle order is broadcast.  On CPU the same code runs on the gloo backend (tests)."""
 import torch
 import torch.distributed as dist
 

@@ -10,6 +10,7 @@ one autograd node: G forward, one D pass without the restoration decoder, loss k
 replays D for the input gradient only (the reference's D weight gradients in the G step are discarded by
 the next zero_grad) and then the generator.  Nothing here synchronises with the host.
 """
+import os
 import random
 
 import torch
@@ -19,6 +20,8 @@ from . import generator_path as GP
 from . import kernels as K
 
 NPIX = 64 * 64
+# data parallelism: ship finished gradient slices of the last task pass while it runs (MTD_DP_EARLY_SHIP=0: after the pass)
+EARLY_SHIP = os.environ.get("MTD_DP_EARLY_SHIP", "1") == "1"
 
 
 def _nhwc1(t):
@@ -118,9 +121,27 @@ class DStepTape:
         def consistency34(chain):       # through D(rec.clip), passes 3 and 4 ...
             return DP.disc_backward(rt, P, t34, G2["c3_e"], G2["c3_d"], None, sink_c, True, chain=chain)
 
-        def consistency12(chain, gin34):  # ... and back into the restoration decoder of passes 1 and 2
+        def consistency12(chain, gin34, flush=None):  # ... and back into the restoration decoder of passes 1 and 2
             DP.disc_backward(rt, P, t12, G2["c_e"], G2["c_d"], K.clip01_bwd(gin34, r12), sink_c, False, chain=chain,
-                             dec_import={**exp_s, **exp_r})
+                             dec_import={**exp_s, **exp_r}, flush=flush)
+
+        # Data parallelism: the LAST pass has no later backward to hide its collectives under, so it ships what is final while
+        # it runs -- the task-specific bucket (158 MB) once the decoders and heads are done (before the whole trunk), the tail
+        # of the task vector (bottleneck + trunk levels 6 .. FLUSH_LEVEL: 91 % of 114 MB) once those levels are, under the
+        # large-map levels that remain.  Only the head of the vector (10 MB) is reduced after the pass.
+        tail_ofs, shipped = self._low_tail(sh_names, sizes), {"ts": False, "tail": False}
+
+        def ship(stage):
+            side = K.side_stream(dev)          # the weight gradients and their spectral-norm corrections are on this stream
+            if stage == "heads" and ts_names:
+                def ts():
+                    TSflat.add_(TSc)
+                    dp.all_reduce_avg(TSflat)
+                side.run(ts)
+                shipped["ts"] = True
+            elif stage == "trunk_low" and tail_ofs is not None:
+                side.run(lambda: dp.all_reduce_avg(S[2, tail_ofs:]))
+                shipped["tail"] = True
 
         if K.CHAINS and not torch.cuda.is_current_stream_capturing():
             # main stream + two chain streams, each with its own side stream for weight gradients: every kernel boundary in
@@ -164,14 +185,20 @@ class DStepTape:
             self._sync_task(dp, S, 0)
             restoration(0)                                                                   # task 1
             self._sync_task(dp, S, 1)
-            consistency12(0, consistency34(0))                                               # task 2
-            self._sync_task(dp, S, 2)
+            consistency12(0, consistency34(0), ship if dp is not None and EARLY_SHIP else None)   # task 2
+            if shipped["tail"]:
+                if dp is not None:
+                    K.side_stream(dev).join()
+                    dp.all_reduce_avg(S[2, :tail_ofs])
+            else:
+                self._sync_task(dp, S, 2)
             K.side_stream(dev).join()          # weight gradients / spectral-norm corrections ran on the side stream
         if dp is not None:
             dp.wait()                          # the three averaged task vectors are needed by the Gram kernel
-        TSflat.add_(TSc)
-        if dp is not None and ts_names:
-            dp.all_reduce_avg(TSflat)      # 158 MB, in flight under the Gram / combine kernels; joined below
+        if not shipped["ts"]:
+            TSflat.add_(TSc)
+            if dp is not None and ts_names:
+                dp.all_reduce_avg(TSflat)      # 158 MB, in flight under the Gram / combine kernels; joined below
         # ---- PCGrad: Gram of the original task gradients, replay of the projections, combine
         vecs = [S[0], S[1], S[2]]
         gram = K.pcgrad_gram(vecs)
@@ -194,6 +221,22 @@ class DStepTape:
         # (under data parallelism `orders` is this rank's own draw; the order applied is rank 0's, in orders_dev)
         self.gram, self.coeff, self.orders, self.orders_dev, self.task_vectors = gram, coeff, orders, orders_dev, S
         self.consumed = True
+
+    @staticmethod
+    def _low_tail(names, sizes):
+        """Offset in a task vector from which on every entry belongs to the bottleneck or to trunk levels >= FLUSH_LEVEL (the
+        layers disc_backward has finished at its "trunk_low" flush), or None if those entries are not one contiguous tail."""
+        import re
+        low = []
+        for nme in names:
+            m = re.match(r"(?:conv|down)(\d)", nme)
+            low.append(nme.startswith("bconv") or (m is not None and int(m.group(1)) >= DP.FLUSH_LEVEL))
+        if True not in low:
+            return None
+        first = low.index(True)
+        if not all(low[first:]) or first == 0:
+            return None
+        return sum(sizes[:first])
 
     @staticmethod
     def _sync_task(dp, S, i):
