@@ -141,6 +141,16 @@ typedef struct {
 size_t mtd_conv_wgrad_ws_bytes(const mtd_wgrad_args* a);
 int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream);
 
+/* The two image ranges [0, b_first), [b_first, B) of one batch, a weight gradient each (a->dw and dw2; both bias
+ * gradients into a->db, the second accumulated) from ONE launch of the slab-producing kernel: the paired discriminator
+ * passes of the D step (D(y) | D(fake) as one batch of 2B, networks.py:1959-1970) need the halves' gradients apart,
+ * because each half has its own spectral-norm sigma, u, v.  Same arithmetic per range as mtd_conv_wgrad on that range
+ * up to the order of the slab sums.  _ok: 1 if the layer qualifies (3x3 stride-1, N and C multiples of 64, maps of
+ * at least 8x8, B == 2 b_first), else the caller runs mtd_conv_wgrad twice.  _ws_bytes: 0 if it does not qualify. */
+int mtd_conv_wgrad_pair_ok(const mtd_wgrad_args* a, int b_first);
+size_t mtd_conv_wgrad_pair_ws_bytes(const mtd_wgrad_args* a, int b_first);
+int mtd_conv_wgrad_pair(const mtd_wgrad_args* a, float* dw2, int b_first, void* stream);
+
 /* Deferred form for a backward pass with many small layers (the generator: 41 conv layers of 32 channels, each with
  * 256 partial-sum slabs).  mtd_conv_wgrad_slabs runs only the slab-producing kernel into a->ws, which must stay
  * untouched until the reduce; *nslab == 0 means the kernel wrote dw / db itself and nothing is left to do.

@@ -1302,6 +1302,7 @@ static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, 
             wp.tiles_per_image = (a->g.OH / 2) * wp.tiles_x;
             wp.ntiles = a->g.B * wp.tiles_per_image;
             wp.chunks_per_split = pl.ppw;
+            wp.ns_first = wp.first_tiles = 0;
             MTD_LAUNCH(wgrad_wino_kernel, dim3(pl.nsplit, (a->N / 64) * (a->C / 64)), dim3(512), 0, s, wp);
             mtd_prof_end(prof, s);
             MTD_LAUNCH_CHECK();
@@ -1411,18 +1412,103 @@ extern "C" int mtd_conv_wgrad_reduce_multi(const mtd_wgrad_reduce_desc* table_de
     return MTD_OK;
 }
 
+static int wgrad_reduce_slabs_impl(const WgradParams& p, const float* cur, int ns, float* next, bool direct, hipStream_t s);
+static int wgrad_reduce_slabs(const WgradParams& p, const float* cur, int ns, float* next, bool direct, hipStream_t s) {
+    return wgrad_reduce_slabs_impl(p, cur, ns, next, direct, s);
+}
+
 extern "C" int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream) {
     WgradParams p;
     int nsplit = 0;
     bool direct = false;
     int rc = wgrad_partial(a, stream, p, nsplit, direct);
     if (rc != MTD_OK) return rc;
-    hipStream_t s = (hipStream_t)stream;
     if (!direct && nsplit == 1) return MTD_OK;      // single split: the kernel wrote dw / db itself
-    // staged, order-fixed reduction of the slabs
-    const float* cur = a->ws;
-    int ns = nsplit;
-    float* next = a->ws + (long long)ns * p.slab_stride;
+    return wgrad_reduce_slabs(p, a->ws, nsplit, a->ws + (long long)nsplit * p.slab_stride, direct, (hipStream_t)stream);
+}
+
+// ---- the two batch halves of a paired discriminator pass in ONE launch (discriminator_path.wgrad_sn: each half has its own
+// spectral-norm sigma, u, v, so its raw weight gradient is needed by itself).  a describes the whole batch; images
+// [0, b_first) give a->dw, images [b_first, B) give dw2; both bias gradients go to a->db (the second is accumulated).
+// The slab-producing kernel runs once with its slices aligned to the image ranges -- twice the work per workgroup of two
+// launches that each fill the chip, i.e. half the prologues, epilogues, slabs -- and each range's slabs are summed into
+// its own gradient.  Winograd plan only (wgrad_wino_kernel); mtd_conv_wgrad_pair_ok says whether a layer qualifies.
+static bool wgrad_pair_plan(const mtd_wgrad_args& a, int b_first, int& ns_half, int& cps) {
+    if (check_wargs(a) != MTD_OK || is_direct(a)) return false;
+    if (b_first <= 0 || 2 * b_first != a.g.B) return false;
+    static const int env_pair = [] { const char* e = getenv("MTD_WGRAD_PAIR"); return e ? atoi(e) : 1; }();
+    if (!env_pair) return false;
+    mtd_wgrad_args h = a;
+    h.g.B = b_first;
+    if (make_wplan(h).cfg != 16) return false;
+    const long long blocks = (long long)(a.N / 64) * (a.C / 64);
+    const long long chunks = ((long long)b_first * (a.g.OH / 2) * (a.g.OW / 2) + WGW_T - 1) / WGW_T;
+    long long ns = (128 + blocks - 1) / blocks;                  // the two ranges together: about one workgroup per CU
+    if (ns > chunks / 4) ns = chunks / 4;
+    if (ns < 1) ns = 1;
+    const long long c = (chunks + ns - 1) / ns;
+    ns = (chunks + c - 1) / c;
+    ns_half = (int)ns;
+    cps = (int)c;
+    return true;
+}
+
+extern "C" int mtd_conv_wgrad_pair_ok(const mtd_wgrad_args* a, int b_first) {
+    int ns, cps;
+    return a && wgrad_pair_plan(*a, b_first, ns, cps) ? 1 : 0;
+}
+
+extern "C" size_t mtd_conv_wgrad_pair_ws_bytes(const mtd_wgrad_args* a, int b_first) {
+    int ns, cps;
+    if (!a || !wgrad_pair_plan(*a, b_first, ns, cps)) return 0;
+    return wgrad_ws_floats(*a, 2 * ns) * sizeof(float);
+}
+
+extern "C" int mtd_conv_wgrad_pair(const mtd_wgrad_args* a, float* dw2, int b_first, void* stream) {
+    int ns_half = 0, cps = 0;
+    if (!a || !dw2 || !wgrad_pair_plan(*a, b_first, ns_half, cps)) return MTD_EINVAL;
+    const int nsplit = 2 * ns_half;
+    if (!a->ws || a->ws_bytes < wgrad_ws_floats(*a, nsplit) * sizeof(float)) return MTD_EWS;
+    WgradWinoParams wp;
+    WgradParams& p = wp.w;
+    p.a = *a;
+    p.M = (int)geom_pixels(a->g);
+    p.T = 9;
+    p.nslab = nsplit;
+    p.slab_stride = (long long)p.T * a->N * a->C + a->N;
+    for (int t = 0; t < 16; ++t) p.tap_dy[t] = p.tap_dx[t] = p.tap_delta[t] = 0;
+    {
+        const long long pb = (((long long)p.M - 1) * a->p_ld + a->N) * 4;
+        const long long qb = (((long long)a->g.B * a->g.IH * a->g.IW - 1) * a->q_ld + a->C) * 4;
+        if (pb >= (1ll << 31) || qb >= (1ll << 31)) return MTD_EINVAL;
+        p.p_bytes = (unsigned)pb;
+        p.q_bytes = (unsigned)qb;
+    }
+    p.ppw = cps;
+    p.nCt = a->C / 64;
+    wp.tiles_x = a->g.OW / 2;
+    wp.tiles_per_image = (a->g.OH / 2) * wp.tiles_x;
+    wp.ntiles = a->g.B * wp.tiles_per_image;
+    wp.chunks_per_split = cps;
+    wp.ns_first = ns_half;
+    wp.first_tiles = b_first * wp.tiles_per_image;
+    hipStream_t s = (hipStream_t)stream;
+    const int prof = mtd_prof_begin(1, 16, nsplit, geom_pixels(a->g), a->N, a->C, 9, s,
+                                    4.0 * ((double)geom_pixels(a->g) * a->N + (double)a->g.B * a->g.IH * a->g.IW * a->C + 2.0 * 9 * a->N * a->C));
+    MTD_LAUNCH(wgrad_wino_kernel, dim3(nsplit, (a->N / 64) * (a->C / 64)), dim3(512), 0, s, wp);
+    mtd_prof_end(prof, s);
+    MTD_LAUNCH_CHECK();
+    float* stage = a->ws + (long long)nsplit * p.slab_stride;
+    int rc = wgrad_reduce_slabs(p, a->ws, ns_half, stage, false, s);
+    if (rc != MTD_OK) return rc;
+    p.a.dw = dw2;
+    p.a.accumulate = a->accumulate | 2;          // the bias gradient of the second range joins the first's
+    return wgrad_reduce_slabs(p, a->ws + (long long)ns_half * p.slab_stride, ns_half, stage, false, s);
+}
+
+// staged, order-fixed reduction of ns slabs at cur into p.a.dw / p.a.db (staging area: next)
+static int wgrad_reduce_slabs_impl(const WgradParams& p, const float* cur, int ns, float* next, bool direct, hipStream_t s) {
+    const mtd_wgrad_args* a = &p.a;
     const long long count = p.slab_stride;
     const bool vec = !direct;      // MFMA layers: N, C multiples of 32, so every slab offset is a multiple of 4 floats
     if (vec && (!aligned16(a->ws) || (long long)p.T * a->N * a->C >= (1ll << 31))) return MTD_EINVAL;   // float4 reads, 32-bit indices

@@ -33,6 +33,9 @@ struct WgradWinoParams {
     WgradParams w;
     int ntiles, tiles_x, tiles_per_image;
     int chunks_per_split;
+    // pair form (mtd_conv_wgrad_pair): the batch is two image ranges with a weight gradient each -- slabs 0 .. ns_first - 1 are
+    // sums over tiles [0, first_tiles), the others over [first_tiles, ntiles).  ns_first = 0: one range.
+    int ns_first, first_tiles;
 };
 
 __device__ __forceinline__ float wgw_quad(float v, int ctrl) {
@@ -60,9 +63,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgradWinoParam
     const int ncb = a.C / 64;
     const int nblk = blockIdx.y / ncb, cblk = blockIdx.y - nblk * ncb;
     const int n0 = nblk * 64, c0 = cblk * 64;
-    const int zk = blockIdx.x;
+    const int second = (wp.ns_first > 0 && (int)blockIdx.x >= wp.ns_first) ? 1 : 0;
+    const int zk = blockIdx.x - second * wp.ns_first;                       // slice within its image range
+    const int tile_lo = second ? wp.first_tiles : 0;
+    const int tile_hi = (wp.ns_first > 0 && !second) ? wp.first_tiles : wp.ntiles;
     const int ck_beg = zk * wp.chunks_per_split;
-    const int nchunks_all = (wp.ntiles + WGW_T - 1) / WGW_T;
+    const int nchunks_all = (tile_hi - tile_lo + WGW_T - 1) / WGW_T;
     const int ck_end = min(nchunks_all, ck_beg + wp.chunks_per_split);
     const int nck = ck_end - ck_beg;
     const int ck_last = ck_end - 1;
@@ -75,8 +81,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgradWinoParam
     struct Pre { f32x4 d[4]; f32x4 y; };      // one chunk's operands of this thread, on their way from memory
     f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
     auto load_chunk = [&](int ck, Pre& r) {
-        const int tg = ck * WGW_T + t8;
-        const bool tv = tg < wp.ntiles;
+        const int tg = tile_lo + ck * WGW_T + t8;
+        const bool tv = tg < tile_hi;
         const int b = tg / wp.tiles_per_image;
         const int rr = tg - b * wp.tiles_per_image;
         const int ty = rr / wp.tiles_x, tx = rr - ty * wp.tiles_x;
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgradWinoParam
     }
 
     // ---- epilogue: G^T dU G per (n, c), one 32 x 32 sub-block at a time through X[xi][n][c]; the bias gradient
-    float* slab = a.ws + (long long)zk * p.slab_stride;
+    float* slab = a.ws + (long long)blockIdx.x * p.slab_stride;
     const int en_c = tid & 31, en_n = tid >> 5;                        // this thread's c and n (+16) inside the sub-block
 #pragma unroll
     for (int h = 0; h < 2; ++h)

@@ -360,13 +360,11 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0
                 return
             hh, kk, ss, pp = gspec
             if Bh:
-                qa, qb = q[:Bh], q[Bh:]
-                ga, gb_ = K.geom_fwd(Bh, hh, hh, kk, ss, pp), K.geom_fwd(B - Bh, hh, hh, kk, ss, pp)
+                gfull = K.geom_fwd(B, hh, hh, kk, ss, pp)
 
-                def both():
-                    pe = src()
-                    K.wgrad(pe[:Bh], qa, ga, N, Cc, rt.gtemp(name, dev, 0, chain), Cc * k * k, k * k, db=sink.get(bn), accumulate=False, accumulate_bias=True)
-                    K.wgrad(pe[Bh:], qb, gb_, N, Cc, rt.gtemp(name, dev, 1, chain), Cc * k * k, k * k, db=sink.get(bn), accumulate=False, accumulate_bias=True)
+                def both():         # (one launch for both halves where the library's plan allows it)
+                    K.wgrad_pair(src(), q, gfull, Bh, N, Cc, rt.gtemp(name, dev, 0, chain), rt.gtemp(name, dev, 1, chain), Cc * k * k, k * k,
+                                 db=sink.get(bn), accumulate_bias=True)
                 side.run(both, p, q)
             else:
                 geom = K.geom_fwd(B, hh, hh, kk, ss, pp)

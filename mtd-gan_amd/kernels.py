@@ -550,6 +550,41 @@ def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumula
     check(L.mtd_conv_wgrad(C.byref(a), stream_ptr()), "mtd_conv_wgrad")
 
 
+def wgrad_pair(p, q, geom, b_first, N, Cc, dw1, dw2, w_sn, w_sc, db=None, accumulate_bias=True):
+    """The raw weight gradients of the two image ranges [0, b_first), [b_first, B) of one batch (a paired discriminator
+    pass: each range has its own spectral-norm statistics) into dw1 / dw2 and the sum of both bias gradients into db: ONE
+    launch of the slab-producing kernel where the library's plan allows it (mtd_conv_wgrad_pair), two launches otherwise.
+    geom: the forward geometry of the whole batch."""
+    L = _lib.lib()
+    a = WgradArgs()
+    a.g = geom
+    a.p, a.p_ld, a.N = p.data_ptr(), ld_of(p), N
+    a.q, a.q_ld, a.C = q.data_ptr(), ld_of(q), Cc
+    a.dw, a.w_sn, a.w_sc = dw1.data_ptr(), w_sn, w_sc
+    a.db = _ptr(db)
+    a.accumulate = 2 if accumulate_bias else 0
+    a.ws, a.ws_bytes = None, 0
+    need = L.mtd_conv_wgrad_pair_ws_bytes(C.byref(a), b_first) if (N % 64 == 0 and Cc % 64 == 0) else 0
+    if need == 0:
+        B = geom.B
+        ga, gb = mtd_geom_with_batch(geom, b_first), mtd_geom_with_batch(geom, B - b_first)
+        wgrad(p[:b_first], q[:b_first], ga, N, Cc, dw1, w_sn, w_sc, db=db, accumulate=False, accumulate_bias=accumulate_bias)
+        wgrad(p[b_first:], q[b_first:], gb, N, Cc, dw2, w_sn, w_sc, db=db, accumulate=False, accumulate_bias=True)
+        return
+    if FLOP_COUNT is not None:
+        _count("wgrad_mfma", 2.0 * geom.B * geom.OH * geom.OW * N * Cc * geom.TH * geom.TW)
+    ws = workspace(need, p.device)
+    a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+    check(L.mtd_conv_wgrad_pair(C.byref(a), dw2.data_ptr(), b_first, stream_ptr()), "mtd_conv_wgrad_pair")
+
+
+def mtd_geom_with_batch(geom, B):
+    g = type(geom)()
+    C.memmove(C.byref(g), C.byref(geom), C.sizeof(g))
+    g.B = B
+    return g
+
+
 FUSE_C32_BWD = os.environ.get("MTD_NO_FUSED_C32_BWD", "0") != "1"
 
 

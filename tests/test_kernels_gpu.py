@@ -711,6 +711,45 @@ def test_winograd_weight_gradient_vs_torch(hip_lib, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [(4, 64, 64, 64, 64), (6, 128, 64, 16, 16), (10, 256, 512, 8, 8), (2, 64, 128, 10, 12), (64, 128, 128, 32, 32),
+                                  (4, 32, 64, 16, 16), (6, 512, 512, 4, 4)])
+def test_weight_gradient_pair_equals_two_launches(hip_lib, case):
+    """mtd_conv_wgrad_pair: the weight gradients of the two halves of one batch from ONE launch of the slab-producing kernel
+    (its slices aligned to the halves; discriminator_path.wgrad_sn) against mtd_conv_wgrad on each half and torch's autograd in
+    float64; the bias gradient is the accumulated sum of both halves.  (10, 256, 512, 8, 8): 80 tiles per half = ragged
+    slices; (2, 64, 128, 10, 12): one image per half, odd tile rows; the last two do not qualify (C = 32; 4x4 maps) and
+    must take the two-launch path with the same results."""
+    from mtd_gan_amd import _lib
+    from mtd_gan_amd import kernels as K
+    B, Ci, Co, H, W = case
+    Bh = B // 2
+    gen = torch.Generator().manual_seed(29)
+    x = torch.randn(B, H, W, Ci, generator=gen).cuda()
+    gy = torch.randn(B, H, W, Co, generator=gen).cuda()
+    geom = K.geom_fwd(B, H, W, 3, 1, 1)
+    d1, d2 = torch.full((Co, Ci, 3, 3), 7.0, device="cuda"), torch.full((Co, Ci, 3, 3), 7.0, device="cuda")
+    a = K.WgradArgs()
+    a.g = geom
+    a.p, a.p_ld, a.N, a.q, a.q_ld, a.C = gy.data_ptr(), Co, Co, x.data_ptr(), Ci, Ci
+    a.dw, a.w_sn, a.w_sc = d1.data_ptr(), Ci * 9, 9
+    qualifies = _lib.lib().mtd_conv_wgrad_pair_ok(_lib.C.byref(a), Bh) == 1
+    assert qualifies == (Ci % 64 == 0 and Co % 64 == 0 and H >= 8)
+    db = torch.full((Co,), -1.0, device="cuda")
+    K.wgrad_pair(gy, x, geom, Bh, Co, Ci, d1, d2, Ci * 9, 9, db=db, accumulate_bias=True)
+    r1, r2 = torch.empty_like(d1), torch.empty_like(d2)
+    rb = torch.zeros(Co, device="cuda")
+    gh = K.geom_fwd(Bh, H, W, 3, 1, 1)
+    K.wgrad(gy[:Bh], x[:Bh], gh, Co, Ci, r1, Ci * 9, 9, db=rb, accumulate=False, accumulate_bias=True)
+    K.wgrad(gy[Bh:], x[Bh:], gh, Co, Ci, r2, Ci * 9, 9, db=rb, accumulate=False, accumulate_bias=True)
+    torch.cuda.synchronize()
+    assert relerr(d1.cpu(), r1.cpu()) < 2e-5 and relerr(d2.cpu(), r2.cpu()) < 2e-5 and relerr((db + 1.0).cpu(), rb.cpu()) < 2e-5
+    for half, got in ((slice(0, Bh), d1), (slice(Bh, B), d2)):
+        wc = torch.zeros(Co, Ci, 3, 3, dtype=torch.double, requires_grad=True)
+        (F.conv2d(nchw(x[half]).double(), wc, None, padding=1) * nchw(gy[half]).double()).sum().backward()
+        assert relerr(got.cpu(), wc.grad) < TOL
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,second", [(4, False), (12, True), (20, True), (40, True)])
 def test_fused_c32_backward_counted_waits_same_bits(hip_lib, monkeypatch, B, second):
     """conv_c32_bwd.hip hands a 32-pixel block's halo buffer to the next DMA after `s_waitcnt vmcnt(4 | 8)` -- counts that assume
