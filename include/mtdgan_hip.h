@@ -145,9 +145,14 @@ int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream);
  * gradients into a->db, the second accumulated) from ONE launch of the slab-producing kernel: the paired discriminator
  * passes of the D step (D(y) | D(fake) as one batch of 2B, networks.py:1959-1970) need the halves' gradients apart,
  * because each half has its own spectral-norm sigma, u, v.  Same arithmetic per range as mtd_conv_wgrad on that range
- * up to the order of the slab sums.  _ok: 1 if the layer qualifies (3x3 stride-1, N and C multiples of 64, maps of
- * at least 8x8, B == 2 b_first), else the caller runs mtd_conv_wgrad twice.  _ws_bytes: 0 if it does not qualify. */
+ * up to the order of the slab sums.  _ok: 1 if the layer qualifies (B == 2 b_first, N and C multiples of 32, and a plan
+ * whose kernel has the pair form: all but the row-window kernels of the 16-pixel-aligned 3x3 / 1x1 stride-1 layers below
+ * 64 channels), else the caller runs mtd_conv_wgrad twice.  _ws_bytes: 0 if it does not qualify. */
 int mtd_conv_wgrad_pair_ok(const mtd_wgrad_args* a, int b_first);
+/* which plans pair: 0 none, 1 the default rule (Winograd and stride-2 halo-window kernels: the ones a pair launch is
+ * faster for), 2 Winograd only, 3 every kernel that has the pair form (tests), -1 the MTD_WGRAD_PAIR environment
+ * variable's choice (default 1).  Returns the previous mode. */
+int mtd_conv_wgrad_pair_mode(int mode);
 size_t mtd_conv_wgrad_pair_ws_bytes(const mtd_wgrad_args* a, int b_first);
 int mtd_conv_wgrad_pair(const mtd_wgrad_args* a, float* dw2, int b_first, void* stream);
 

@@ -27,7 +27,23 @@ struct WgradParams {
     long long slab_stride;   // floats per slab = T*N*C + N
     unsigned p_bytes, q_bytes;          // extents for the buffer-load range checks
     int tap_dy[16], tap_dx[16], tap_delta[16];   // per-tap input displacement (pixels / bytes)
+    // pair form (mtd_conv_wgrad_pair): the launch covers TWO problems of the shape a / M describe -- workgroups with
+    // blockIdx.x >= pair_ns work on the second one, whose operands start pair_p_off / pair_q_off floats after a.p / a.q.
+    // Slabs stay indexed by blockIdx.x: 0 .. pair_ns - 1 sum to the first gradient, the rest to the second.  0: one problem.
+    int pair_ns = 0;
+    long long pair_p_off = 0, pair_q_off = 0;
 };
+
+struct PairSel { int bx; const float* P; const float* Q; };
+__device__ __forceinline__ PairSel pair_select(const WgradParams& p) {
+    PairSel r{(int)blockIdx.x, p.a.p, p.a.q};
+    if (p.pair_ns > 0 && r.bx >= p.pair_ns) {
+        r.bx -= p.pair_ns;
+        r.P += p.pair_p_off;
+        r.Q += p.pair_q_off;
+    }
+    return r;
+}
 
 template <int WN, int WC, int TG>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
@@ -46,12 +62,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     const int ntap = min(TG, p.T - tap0);
     float* Ps = Ls + wave * WAVE_FLOATS;
     float* Qs = Ps + 32 * PLD;
-    const int mwave0 = (blockIdx.x * 4 + wave) * p.ppw;
+    const PairSel ps = pair_select(p);
+    const int mwave0 = (ps.bx * 4 + wave) * p.ppw;
     const bool do_bias = (a.db != nullptr) && ctile == 0 && blockIdx.z == 0;
     // Both operands are read with buffer loads: 32-bit byte offsets, an out-of-range offset returns 0 (zero
     // padding and the pixel tail without branches, so the compiler's vmcnt bookkeeping stays exact).
-    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p), (short)0, (int)p.p_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.q), (short)0, (int)p.q_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ps.P), (short)0, (int)p.p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ps.Q), (short)0, (int)p.q_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
 
     f32x16 acc[TG][WN][WC];
@@ -516,11 +533,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_taps_kernel(const WgradParams p)
     const int l31 = lane & 31, kh = lane >> 5;
     const int ntile = blockIdx.y / p.nCt, ctile = blockIdx.y % p.nCt;
     const int n0 = ntile * 32, c0 = ctile * 32;
-    const int m0 = blockIdx.x * p.ppw;                  // ppw: pixels per WORKGROUP here (a multiple of 32)
+    const PairSel ps = pair_select(p);
+    const int m0 = ps.bx * p.ppw;                       // ppw: pixels per WORKGROUP here (a multiple of 32)
     const bool do_bias = (a.db != nullptr) && ctile == 0;
     const bool bias_wave = do_bias && ty == 0;
-    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p), (short)0, (int)p.p_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.q), (short)0, (int)p.q_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ps.P), (short)0, (int)p.p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ps.Q), (short)0, (int)p.q_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     const unsigned qtx = (unsigned)(g.tap_dx * a.q_ld * 4);
     const int dyrow = g.off_y + ty * g.tap_dy;
@@ -640,10 +658,11 @@ __global__ __launch_bounds__(256, DB ? 1 : 2) void wgrad_s2_kernel(const WgradPa
     const bool bias_wave = do_bias && ty == 0;
     const int nbx = g.OW >> 3, nby = g.OH >> 3;
     const int NB = g.B * nby * nbx;
-    const int blk0 = blockIdx.x * p.ppw;                // ppw: 8 x 8 pixel blocks per WORKGROUP here
+    const PairSel ps = pair_select(p);
+    const int blk0 = ps.bx * p.ppw;                     // ppw: 8 x 8 pixel blocks per WORKGROUP here
     const int blk1 = min(NB, blk0 + p.ppw);
-    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p), (short)0, (int)p.p_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.q), (short)0, (int)p.q_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ps.P), (short)0, (int)p.p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ps.Q), (short)0, (int)p.q_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     const int rsub = lane >> 3, piece = lane & 7;
 
@@ -767,10 +786,11 @@ __global__ __launch_bounds__(NW * 64, (W == 8 || NW == 8) ? 1 : 2) void wgrad_bl
     const int l31 = lane & 31, kh = lane >> 5;
     const int ntile = blockIdx.y / p.nCt, ctile = blockIdx.y % p.nCt;
     const int n0 = ntile * 32, c0 = ctile * 32;
-    const int mwave0 = (blockIdx.x * NW + wave) * p.ppw;
+    const PairSel ps = pair_select(p);
+    const int mwave0 = (ps.bx * NW + wave) * p.ppw;
     const bool do_bias = (a.db != nullptr) && ctile == 0;
-    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p), (short)0, (int)p.p_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.q), (short)0, (int)p.q_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ps.P), (short)0, (int)p.p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ps.Q), (short)0, (int)p.q_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     const int pstep = a.p_ld * 4, qstep = a.q_ld * 4;
 
@@ -1048,6 +1068,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(const mtd_wgra
 struct WPlan { int cfg, WN, WC, TG, ppw, nsplit, ntg, nw; };
 
 int g_wforce_cfg = -1, g_wforce_split = -1;     // tuning hook (mtd_conv_wgrad_override)
+int g_wplan_div = 1;                            // 2 while planning ONE of the two problems of a pair launch: half the workgroup targets
 int g_wforce_nw = 0;                            // waves per workgroup of the register-operand kernels (env MTD_WGRAD_NW, lab only)
 constexpr int NWCFG = 7;
 const int kWcfgWN[NWCFG] = {1, 1, 2, 1, 1, 1, 2};
@@ -1091,7 +1112,7 @@ WPlan make_wplan(const mtd_wgrad_args& a) {
         const long long tiles = (long long)(a.N / 32) * (a.C / 32);
         const long long NB = (long long)a.g.B * (a.g.OH / 8) * (a.g.OW / 8);
         static const int env_s2wgs = [] { const char* e = getenv("MTD_WGRAD_S2_WGS"); return e ? atoi(e) : 512; }();
-        long long ns = (env_s2wgs + tiles - 1) / tiles;
+        long long ns = (env_s2wgs / g_wplan_div + tiles - 1) / tiles;
         if (g_wforce_split > 0) ns = g_wforce_split;
         if (ns > NB) ns = NB;
         if (ns < 1) ns = 1;
@@ -1109,7 +1130,7 @@ WPlan make_wplan(const mtd_wgrad_args& a) {
         pl.WN = 1; pl.WC = 1; pl.TG = T; pl.ntg = 1; pl.nw = 4;
         const long long tiles = (long long)(a.N / 32) * (a.C / 32);
         static const int env_wgs = [] { const char* e = getenv("MTD_WGRAD_TAPS_WGS"); return e ? atoi(e) : 256; }();
-        long long ns = (env_wgs + tiles - 1) / tiles;
+        long long ns = (env_wgs / g_wplan_div + tiles - 1) / tiles;
         if (g_wforce_split > 0) ns = g_wforce_split;
         const long long max_splits = (M + 31) / 32;
         if (ns > max_splits) ns = max_splits;
@@ -1150,7 +1171,7 @@ WPlan make_wplan(const mtd_wgrad_args& a) {
         pl.cfg = bw ? (bw == 8 ? 10 : (bw == 4 ? 11 : 12)) : ((T == 1) ? 9 : (a.g.tap_dx > 0 ? 7 : 8));
         pl.WN = 1; pl.WC = 1; pl.TG = T; pl.ntg = 1;
         long long tiles = (long long)(a.N / 32) * (a.C / 32);
-        long long want_splits = (256 + tiles - 1) / tiles;      // sweep: ~one workgroup per CU, longer pixel runs per wave
+        long long want_splits = (256 / g_wplan_div + tiles - 1) / tiles;      // sweep: ~one workgroup per CU, longer pixel runs per wave
         if (g_wforce_split > 0) want_splits = g_wforce_split;
         long long max_splits = (M + 127) / 128;
         long long ns = want_splits < 1 ? 1 : want_splits;
@@ -1174,7 +1195,7 @@ WPlan make_wplan(const mtd_wgrad_args& a) {
     pl.nw = 4;
     long long tiles = (long long)(a.N / (32 * pl.WN)) * (a.C / (32 * pl.WC)) * pl.ntg;
     // aim for >= 512 workgroups; every wave gets a multiple of 32 pixels
-    long long want_splits = (512 + tiles - 1) / tiles;
+    long long want_splits = (512 / g_wplan_div + tiles - 1) / tiles;
     if (g_wforce_split > 0) want_splits = g_wforce_split;
     long long max_splits = (M + 127) / 128;             // at least 32 px per wave
     long long ns = want_splits < 1 ? 1 : want_splits;
@@ -1241,11 +1262,16 @@ extern "C" size_t mtd_conv_wgrad_ws_bytes(const mtd_wgrad_args* a) {
     return wgrad_ws_floats(*a, pl.nsplit) * sizeof(float);
 }
 
+// plans whose kernels implement the pair form (pair_select): wgrad_kernel<> (0-6), the block-window kernels (10-12), the all-taps
+// kernel (13), the stride-2 halo-window kernel (15).  (16, the Winograd kernel, has its own: mtd_conv_wgrad_pair.)
+static bool wgrad_cfg_pairs(int cfg) { return (cfg >= 0 && cfg < NWCFG) || (cfg >= 10 && cfg <= 13) || cfg == 15; }
+
 // the slab-producing kernel of one layer; fills p, nsplit, direct
 // (rows != nullptr: also run the forward row transform `rows` describes, inside the same launch if the plan is the row-window
 // kernel on one (n, c) tile -- *rows_done says whether it was)
+// (pair: a describes ONE of two equal problems laid out back to back in p / q; the launch covers both, see WgradParams::pair_ns)
 static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, int& nsplit, bool& direct_out,
-                         const RowsArgs* rows = nullptr, bool* rows_done = nullptr) {
+                         const RowsArgs* rows = nullptr, bool* rows_done = nullptr, bool pair = false) {
     if (!a) return MTD_EINVAL;
     static const int env_nw = [] { const char* e = getenv("MTD_WGRAD_NW"); return e ? atoi(e) : 0; }();
     if (env_nw == 4 || env_nw == 8) g_wforce_nw = env_nw;
@@ -1255,7 +1281,19 @@ static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, 
     direct_out = direct;
     WPlan pl{};
     if (direct) nsplit = mtd_direct_wgrad_nslab(a);
-    else { pl = make_wplan(*a); nsplit = pl.nsplit; }
+    else if (!pair) { pl = make_wplan(*a); nsplit = pl.nsplit; }
+    if (pair) {
+        if (direct) return MTD_EINVAL;
+        g_wplan_div = 2;
+        pl = make_wplan(*a);
+        g_wplan_div = 1;
+        if (!wgrad_cfg_pairs(pl.cfg)) return MTD_EINVAL;
+        p.pair_ns = pl.nsplit;
+        p.pair_p_off = geom_pixels(a->g) * a->p_ld;
+        p.pair_q_off = (long long)a->g.B * a->g.IH * a->g.IW * a->q_ld;
+        pl.nsplit *= 2;
+        nsplit = pl.nsplit;
+    }
     if (!a->ws || a->ws_bytes < wgrad_ws_floats(*a, nsplit) * sizeof(float)) return MTD_EWS;
     p.a = *a;
     p.M = (int)geom_pixels(a->g);
@@ -1433,14 +1471,25 @@ extern "C" int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream) {
 // The slab-producing kernel runs once with its slices aligned to the image ranges -- twice the work per workgroup of two
 // launches that each fill the chip, i.e. half the prologues, epilogues, slabs -- and each range's slabs are summed into
 // its own gradient.  Winograd plan only (wgrad_wino_kernel); mtd_conv_wgrad_pair_ok says whether a layer qualifies.
+static int g_wpair_mode = -1;            // -1: MTD_WGRAD_PAIR (default 1); set by mtd_conv_wgrad_pair_mode (tests, lab)
 static bool wgrad_pair_plan(const mtd_wgrad_args& a, int b_first, int& ns_half, int& cps) {
     if (check_wargs(a) != MTD_OK || is_direct(a)) return false;
     if (b_first <= 0 || 2 * b_first != a.g.B) return false;
-    static const int env_pair = [] { const char* e = getenv("MTD_WGRAD_PAIR"); return e ? atoi(e) : 1; }();
+    static const int env_pair_default = [] { const char* e = getenv("MTD_WGRAD_PAIR"); return e ? atoi(e) : 1; }();
+    const int env_pair = g_wpair_mode >= 0 ? g_wpair_mode : env_pair_default;
     if (!env_pair) return false;
     mtd_wgrad_args h = a;
     h.g.B = b_first;
-    if (make_wplan(h).cfg != 16) return false;
+    const int cfg = make_wplan(h).cfg;
+    if (cfg != 16) {                       // the general kernels: planned inside wgrad_partial
+        // By default only the stride-2 halo-window kernel (cfg 15: `down` layers with output maps of at least 8x8: 14-21 us less
+        // per pair).  The small-map kernels lose: their single launches have one pixel split and write the gradient themselves,
+        // a pair launch has two slabs per (n, c) tile and a reduce (down4 132 -> 210 us, down6 26 -> 102 us, conv5x 47 -> 66 us;
+        // tools/wgrad_pair_probe.py).  MTD_WGRAD_PAIR=2: Winograd kernel only, 3: every kernel with the pair form (lab, tests).
+        if (env_pair == 2 || (env_pair != 3 && cfg != 15)) return false;
+        ns_half = cps = 0;
+        return wgrad_cfg_pairs(cfg);
+    }
     const long long blocks = (long long)(a.N / 64) * (a.C / 64);
     const long long chunks = ((long long)b_first * (a.g.OH / 2) * (a.g.OW / 2) + WGW_T - 1) / WGW_T;
     long long ns = (128 + blocks - 1) / blocks;                  // the two ranges together: about one workgroup per CU
@@ -1453,6 +1502,14 @@ static bool wgrad_pair_plan(const mtd_wgrad_args& a, int b_first, int& ns_half, 
     return true;
 }
 
+// 0: never pair, 1: the default rule, 2: Winograd kernel only, 3: every kernel that has the pair form, -1: back to the
+// environment's choice.  Returns the previous mode.
+extern "C" int mtd_conv_wgrad_pair_mode(int mode) {
+    const int prev = g_wpair_mode;
+    g_wpair_mode = mode;
+    return prev;
+}
+
 extern "C" int mtd_conv_wgrad_pair_ok(const mtd_wgrad_args* a, int b_first) {
     int ns, cps;
     return a && wgrad_pair_plan(*a, b_first, ns, cps) ? 1 : 0;
@@ -1461,12 +1518,34 @@ extern "C" int mtd_conv_wgrad_pair_ok(const mtd_wgrad_args* a, int b_first) {
 extern "C" size_t mtd_conv_wgrad_pair_ws_bytes(const mtd_wgrad_args* a, int b_first) {
     int ns, cps;
     if (!a || !wgrad_pair_plan(*a, b_first, ns, cps)) return 0;
+    if (ns == 0) {
+        mtd_wgrad_args h = *a;
+        h.g.B = b_first;
+        g_wplan_div = 2;
+        ns = make_wplan(h).nsplit;
+        g_wplan_div = 1;
+    }
     return wgrad_ws_floats(*a, 2 * ns) * sizeof(float);
 }
 
 extern "C" int mtd_conv_wgrad_pair(const mtd_wgrad_args* a, float* dw2, int b_first, void* stream) {
     int ns_half = 0, cps = 0;
     if (!a || !dw2 || !wgrad_pair_plan(*a, b_first, ns_half, cps)) return MTD_EINVAL;
+    if (ns_half == 0) {                    // one of the general kernels over both problems
+        mtd_wgrad_args h = *a;
+        h.g.B = b_first;
+        WgradParams p;
+        int ns = 0;
+        bool direct = false;
+        int rc = wgrad_partial(&h, stream, p, ns, direct, nullptr, nullptr, true);
+        if (rc != MTD_OK) return rc;
+        float* stage = a->ws + (long long)ns * p.slab_stride;
+        rc = wgrad_reduce_slabs(p, a->ws, ns / 2, stage, false, (hipStream_t)stream);
+        if (rc != MTD_OK) return rc;
+        p.a.dw = dw2;
+        p.a.accumulate = a->accumulate | 2;
+        return wgrad_reduce_slabs(p, a->ws + (long long)(ns / 2) * p.slab_stride, ns / 2, stage, false, (hipStream_t)stream);
+    }
     const int nsplit = 2 * ns_half;
     if (!a->ws || a->ws_bytes < wgrad_ws_floats(*a, nsplit) * sizeof(float)) return MTD_EWS;
     WgradWinoParams wp;

@@ -564,7 +564,7 @@ def wgrad_pair(p, q, geom, b_first, N, Cc, dw1, dw2, w_sn, w_sc, db=None, accumu
     a.db = _ptr(db)
     a.accumulate = 2 if accumulate_bias else 0
     a.ws, a.ws_bytes = None, 0
-    need = L.mtd_conv_wgrad_pair_ws_bytes(C.byref(a), b_first) if (N % 64 == 0 and Cc % 64 == 0) else 0
+    need = L.mtd_conv_wgrad_pair_ws_bytes(C.byref(a), b_first)       # 0: this layer's plan has no pair form
     if need == 0:
         B = geom.B
         ga, gb = mtd_geom_with_batch(geom, b_first), mtd_geom_with_batch(geom, B - b_first)

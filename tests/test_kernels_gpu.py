@@ -711,41 +711,57 @@ def test_winograd_weight_gradient_vs_torch(hip_lib, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", [(4, 64, 64, 64, 64), (6, 128, 64, 16, 16), (10, 256, 512, 8, 8), (2, 64, 128, 10, 12), (64, 128, 128, 32, 32),
-                                  (4, 32, 64, 16, 16), (6, 512, 512, 4, 4)])
+@pytest.mark.parametrize("case", [(4, 64, 64, 64, 64, 3, 1), (6, 128, 64, 16, 16, 3, 1), (10, 256, 512, 8, 8, 3, 1), (2, 64, 128, 10, 12, 3, 1),
+                                  (64, 128, 128, 32, 32, 3, 1), (4, 32, 64, 16, 16, 3, 0), (6, 512, 512, 4, 4, 3, 1), (10, 256, 256, 2, 2, 3, 1),
+                                  (6, 64, 64, 32, 32, 4, 1), (4, 128, 128, 8, 8, 4, 1), (10, 512, 512, 2, 2, 4, 1), (6, 512, 512, 1, 1, 1, 1),
+                                  (4, 96, 32, 6, 6, 3, 1)])
 def test_weight_gradient_pair_equals_two_launches(hip_lib, case):
     """mtd_conv_wgrad_pair: the weight gradients of the two halves of one batch from ONE launch of the slab-producing kernel
     (its slices aligned to the halves; discriminator_path.wgrad_sn) against mtd_conv_wgrad on each half and torch's autograd in
     float64; the bias gradient is the accumulated sum of both halves.  (10, 256, 512, 8, 8): 80 tiles per half = ragged
-    slices; (2, 64, 128, 10, 12): one image per half, odd tile rows; the last two do not qualify (C = 32; 4x4 maps) and
-    must take the two-launch path with the same results."""
+    slices; (2, 64, 128, 10, 12): one image per half, odd tile rows.  case = (B, Cin, Cout, H, W, k, pairs): k = 3 the 3x3
+    stride-1 layers (Winograd, block-window and LDS-staged kernels by map size), k = 4 the stride-2 4x4 `down` layers
+    (H, W = output size: halo-window and all-taps kernels), k = 1 the bottleneck's 1x1 layers; pairs = 0: the plan is the
+    row-window kernel, which has no pair form -- two launches, same results."""
     from mtd_gan_amd import _lib
     from mtd_gan_amd import kernels as K
-    B, Ci, Co, H, W = case
+    B, Ci, Co, H, W, k, pairs = case
     Bh = B // 2
+    L = _lib.lib()
+    default_rule = pairs and k != 1 and H >= 8 and Ci % 64 == 0 and Co % 64 == 0      # Winograd and stride-2 halo-window plans
+    for mode, expect in ((1, int(default_rule)), (3, pairs)):
+        prev = L.mtd_conv_wgrad_pair_mode(mode)
+        try:
+            _pair_case(K, _lib, B, Bh, Ci, Co, H, W, k, expect)
+        finally:
+            L.mtd_conv_wgrad_pair_mode(prev)
+
+
+def _pair_case(K, _lib, B, Bh, Ci, Co, H, W, k, pairs):
     gen = torch.Generator().manual_seed(29)
-    x = torch.randn(B, H, W, Ci, generator=gen).cuda()
+    stride, pad = (2, 1) if k == 4 else (1, (k - 1) // 2)
+    x = torch.randn(B, H * stride, W * stride, Ci, generator=gen).cuda()
     gy = torch.randn(B, H, W, Co, generator=gen).cuda()
-    geom = K.geom_fwd(B, H, W, 3, 1, 1)
-    d1, d2 = torch.full((Co, Ci, 3, 3), 7.0, device="cuda"), torch.full((Co, Ci, 3, 3), 7.0, device="cuda")
+    geom = K.geom_fwd(B, H * stride, W * stride, k, stride, pad)
+    kk = k * k
+    d1, d2 = torch.full((Co, Ci, k, k), 7.0, device="cuda"), torch.full((Co, Ci, k, k), 7.0, device="cuda")
     a = K.WgradArgs()
     a.g = geom
     a.p, a.p_ld, a.N, a.q, a.q_ld, a.C = gy.data_ptr(), Co, Co, x.data_ptr(), Ci, Ci
-    a.dw, a.w_sn, a.w_sc = d1.data_ptr(), Ci * 9, 9
-    qualifies = _lib.lib().mtd_conv_wgrad_pair_ok(_lib.C.byref(a), Bh) == 1
-    assert qualifies == (Ci % 64 == 0 and Co % 64 == 0 and H >= 8)
+    a.dw, a.w_sn, a.w_sc = d1.data_ptr(), Ci * kk, kk
+    assert _lib.lib().mtd_conv_wgrad_pair_ok(_lib.C.byref(a), Bh) == pairs
     db = torch.full((Co,), -1.0, device="cuda")
-    K.wgrad_pair(gy, x, geom, Bh, Co, Ci, d1, d2, Ci * 9, 9, db=db, accumulate_bias=True)
+    K.wgrad_pair(gy, x, geom, Bh, Co, Ci, d1, d2, Ci * kk, kk, db=db, accumulate_bias=True)
     r1, r2 = torch.empty_like(d1), torch.empty_like(d2)
     rb = torch.zeros(Co, device="cuda")
-    gh = K.geom_fwd(Bh, H, W, 3, 1, 1)
-    K.wgrad(gy[:Bh], x[:Bh], gh, Co, Ci, r1, Ci * 9, 9, db=rb, accumulate=False, accumulate_bias=True)
-    K.wgrad(gy[Bh:], x[Bh:], gh, Co, Ci, r2, Ci * 9, 9, db=rb, accumulate=False, accumulate_bias=True)
+    gh = K.geom_fwd(Bh, H * stride, W * stride, k, stride, pad)
+    K.wgrad(gy[:Bh], x[:Bh], gh, Co, Ci, r1, Ci * kk, kk, db=rb, accumulate=False, accumulate_bias=True)
+    K.wgrad(gy[Bh:], x[Bh:], gh, Co, Ci, r2, Ci * kk, kk, db=rb, accumulate=False, accumulate_bias=True)
     torch.cuda.synchronize()
     assert relerr(d1.cpu(), r1.cpu()) < 2e-5 and relerr(d2.cpu(), r2.cpu()) < 2e-5 and relerr((db + 1.0).cpu(), rb.cpu()) < 2e-5
     for half, got in ((slice(0, Bh), d1), (slice(Bh, B), d2)):
-        wc = torch.zeros(Co, Ci, 3, 3, dtype=torch.double, requires_grad=True)
-        (F.conv2d(nchw(x[half]).double(), wc, None, padding=1) * nchw(gy[half]).double()).sum().backward()
+        wc = torch.zeros(Co, Ci, k, k, dtype=torch.double, requires_grad=True)
+        (F.conv2d(nchw(x[half]).double(), wc, None, stride=stride, padding=pad) * nchw(gy[half]).double()).sum().backward()
         assert relerr(got.cpu(), wc.grad) < TOL
 
 
