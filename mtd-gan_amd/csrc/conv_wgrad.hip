@@ -967,14 +967,19 @@ __global__ __launch_bounds__(256) void slab_group_sum_kernel(const float* __rest
 
 // final: sum <= gs slabs and scatter into the strided weight-gradient view (+ bias gradient).  A thread owns four
 // consecutive c of one (tap, n); index arithmetic in 32 bits (T * N * C < 2^31, checked by the caller).
-__global__ __launch_bounds__(256) void wgrad_finish_kernel(const WgradParams p, const float* __restrict__ in, int nslab, long long stride_in) {
+// (pair launches, gridDim.y == 2: row y sums slabs y nslab .. (y + 1) nslab - 1 into its own gradient -- a.dw, dw2 -- and row 0
+// sums the bias rows of ALL slabs)
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const WgradParams p, const float* __restrict__ in, int nslab, long long stride_in,
+                                                           float* __restrict__ dw2) {
     const mtd_wgrad_args& a = p.a;
     const mtd_geom& g = a.g;
     const unsigned nw4 = (unsigned)(p.T * a.N * a.C) >> 2;
-    const unsigned count4 = nw4 + (a.db ? ((unsigned)a.N >> 2) : 0u);
+    const unsigned count4 = nw4 + ((a.db && blockIdx.y == 0) ? ((unsigned)a.N >> 2) : 0u);
     const unsigned c4n = (unsigned)a.C >> 2;
+    float* const dw = blockIdx.y ? dw2 : a.dw;
+    const float* const in_w = in + (long long)blockIdx.y * nslab * stride_in;
     for (unsigned i4 = blockIdx.x * 256 + threadIdx.x; i4 < count4; i4 += gridDim.x * 256) {
-        const f32x4 s = slab_sum4(in, stride_in, 0, nslab, i4);
+        const f32x4 s = i4 < nw4 ? slab_sum4(in_w, stride_in, 0, nslab, i4) : slab_sum4(in, stride_in, 0, nslab * (int)gridDim.y, i4);
         if (i4 < nw4) {
             const unsigned t2 = i4 / c4n;
             const unsigned c = (i4 - t2 * c4n) << 2;
@@ -982,7 +987,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const WgradParams p, 
             const unsigned n = t2 - tap * (unsigned)a.N;
             const int ty = (int)tap / g.TW, tx = (int)tap % g.TW;
             const int kidx = (g.ky0 + ty * g.ky_step) * g.KW + (g.kx0 + tx * g.kx_step);
-            float* dst = a.dw + (long long)n * a.w_sn + (long long)c * a.w_sc + kidx;
+            float* dst = dw + (long long)n * a.w_sn + (long long)c * a.w_sc + kidx;
             if (a.accumulate & 1) {
                 float o[4];
 #pragma unroll
@@ -1004,7 +1009,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const WgradParams p, 
 // the two reduce stages and the scatter in one launch (workgroup of 16 float4 columns x SQ * SQ slab runs, common.h
 // block_slab_sum): the 256-slab sums of the 32-channel 3x3 layers cost one 5 us launch instead of two
 // scatter one summed float4 (four consecutive c of one (tap, n), or four bias entries) into the strided gradient views
-__device__ __forceinline__ void finish_scatter4(const mtd_wgrad_args& a, int T, unsigned i4, const f32x4 s) {
+__device__ __forceinline__ void finish_scatter4(const mtd_wgrad_args& a, float* dw, int T, unsigned i4, const f32x4 s) {
     const mtd_geom& g = a.g;
     const unsigned nw4 = (unsigned)(T * a.N * a.C) >> 2;
     const unsigned c4n = (unsigned)a.C >> 2;
@@ -1015,7 +1020,7 @@ __device__ __forceinline__ void finish_scatter4(const mtd_wgrad_args& a, int T, 
         const unsigned n = t2 - tap * (unsigned)a.N;
         const int ty = (int)tap / g.TW, tx = (int)tap % g.TW;
         const int kidx = (g.ky0 + ty * g.ky_step) * g.KW + (g.kx0 + tx * g.kx_step);
-        float* dst = a.dw + (long long)n * a.w_sn + (long long)c * a.w_sc + kidx;
+        float* dst = dw + (long long)n * a.w_sn + (long long)c * a.w_sc + kidx;
         if (a.accumulate & 1) {
             float o[4];
 #pragma unroll
@@ -1033,16 +1038,21 @@ __device__ __forceinline__ void finish_scatter4(const mtd_wgrad_args& a, int T, 
     }
 }
 
+// (pair launches, gridDim.y == 2: as wgrad_finish_kernel; a workgroup's 16 columns are all weights or all bias: N, C multiples of 32)
 template <int SQ>
 __global__ __launch_bounds__(16 * SQ * SQ) void wgrad_reduce_finish_kernel(const WgradParams p, const float* __restrict__ in, int nslab,
-                                                                           long long stride_in) {
+                                                                           long long stride_in, float* __restrict__ dw2) {
     __shared__ f32x4 red[16 * SQ * (SQ + 1)];
     const mtd_wgrad_args& a = p.a;
-    const unsigned count4 = ((unsigned)(p.T * a.N * a.C) >> 2) + (a.db ? ((unsigned)a.N >> 2) : 0u);
+    const unsigned nw4 = (unsigned)(p.T * a.N * a.C) >> 2;
+    const unsigned count4 = nw4 + (a.db ? ((unsigned)a.N >> 2) : 0u);
+    const bool bias_cols = blockIdx.x * 16 >= nw4;                 // workgroup-uniform
+    if (bias_cols && blockIdx.y != 0) return;
     const unsigned i4 = blockIdx.x * 16 + (threadIdx.x & 15);
-    const f32x4 s = block_slab_sum<SQ>(in, stride_in, nslab, i4, i4 < count4, red);
+    const f32x4 s = bias_cols ? block_slab_sum<SQ>(in, stride_in, nslab * (int)gridDim.y, i4, i4 < count4, red)
+                              : block_slab_sum<SQ>(in + (long long)blockIdx.y * nslab * stride_in, stride_in, nslab, i4, i4 < count4, red);
     if ((threadIdx.x >> 4) != 0 || i4 >= count4) return;
-    finish_scatter4(a, p.T, i4, s);
+    finish_scatter4(a, blockIdx.y ? dw2 : a.dw, p.T, i4, s);
 }
 
 // the same for many layers in one launch: workgroup -> (layer, 16-column chunk) through the table's block prefix sums
@@ -1060,7 +1070,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(const mtd_wgra
     const unsigned i4 = (blockIdx.x - d.first_block) * 16 + (threadIdx.x & 15);
     const f32x4 s = block_slab_sum<8>(a.ws, d.slab_stride, d.nslab, i4, i4 < count4, red);
     if ((threadIdx.x >> 4) != 0 || i4 >= count4) return;
-    finish_scatter4(a, d.T, i4, s);
+    finish_scatter4(a, a.dw, d.T, i4, s);
 }
 
 #include "conv_wgrad_wino.h"
@@ -1450,9 +1460,24 @@ extern "C" int mtd_conv_wgrad_reduce_multi(const mtd_wgrad_reduce_desc* table_de
     return MTD_OK;
 }
 
-static int wgrad_reduce_slabs_impl(const WgradParams& p, const float* cur, int ns, float* next, bool direct, hipStream_t s);
+static int wgrad_fused_reduce_enabled() {
+    static const int env_fused = [] { const char* e = getenv("MTD_WGRAD_FUSED_REDUCE"); return e ? atoi(e) : 1; }();
+    return env_fused;
+}
+static int wgrad_reduce_slabs_impl(const WgradParams& p, const float* cur, int ns, float* next, bool direct, hipStream_t s, float* dw2);
 static int wgrad_reduce_slabs(const WgradParams& p, const float* cur, int ns, float* next, bool direct, hipStream_t s) {
-    return wgrad_reduce_slabs_impl(p, cur, ns, next, direct, s);
+    return wgrad_reduce_slabs_impl(p, cur, ns, next, direct, s, nullptr);
+}
+// the 2 ns slabs of a pair launch: slabs 0 .. ns - 1 into p.a.dw, the others into dw2, both bias rows into p.a.db
+static int wgrad_reduce_pair(WgradParams& p, const float* cur, int ns, float* next, float* dw2, int accumulate, hipStream_t s) {
+    const long long units = p.slab_stride / 4;
+    if (ns <= GS || (wgrad_fused_reduce_enabled() && ns <= 1024 && units <= 16 * 4096))
+        return wgrad_reduce_slabs_impl(p, cur, ns, next, false, s, dw2);                    // one launch for both
+    int rc = wgrad_reduce_slabs_impl(p, cur, ns, next, false, s, nullptr);
+    if (rc != MTD_OK) return rc;
+    p.a.dw = dw2;
+    p.a.accumulate = accumulate | 2;             // the bias gradient of the second range joins the first's
+    return wgrad_reduce_slabs_impl(p, cur + (long long)ns * p.slab_stride, ns, next, false, s, nullptr);
 }
 
 extern "C" int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream) {
@@ -1539,12 +1564,7 @@ extern "C" int mtd_conv_wgrad_pair(const mtd_wgrad_args* a, float* dw2, int b_fi
         bool direct = false;
         int rc = wgrad_partial(&h, stream, p, ns, direct, nullptr, nullptr, true);
         if (rc != MTD_OK) return rc;
-        float* stage = a->ws + (long long)ns * p.slab_stride;
-        rc = wgrad_reduce_slabs(p, a->ws, ns / 2, stage, false, (hipStream_t)stream);
-        if (rc != MTD_OK) return rc;
-        p.a.dw = dw2;
-        p.a.accumulate = a->accumulate | 2;
-        return wgrad_reduce_slabs(p, a->ws + (long long)(ns / 2) * p.slab_stride, ns / 2, stage, false, (hipStream_t)stream);
+        return wgrad_reduce_pair(p, a->ws, ns / 2, a->ws + (long long)ns * p.slab_stride, dw2, a->accumulate, (hipStream_t)stream);
     }
     const int nsplit = 2 * ns_half;
     if (!a->ws || a->ws_bytes < wgrad_ws_floats(*a, nsplit) * sizeof(float)) return MTD_EWS;
@@ -1577,16 +1597,12 @@ extern "C" int mtd_conv_wgrad_pair(const mtd_wgrad_args* a, float* dw2, int b_fi
     MTD_LAUNCH(wgrad_wino_kernel, dim3(nsplit, (a->N / 64) * (a->C / 64)), dim3(512), 0, s, wp);
     mtd_prof_end(prof, s);
     MTD_LAUNCH_CHECK();
-    float* stage = a->ws + (long long)nsplit * p.slab_stride;
-    int rc = wgrad_reduce_slabs(p, a->ws, ns_half, stage, false, s);
-    if (rc != MTD_OK) return rc;
-    p.a.dw = dw2;
-    p.a.accumulate = a->accumulate | 2;          // the bias gradient of the second range joins the first's
-    return wgrad_reduce_slabs(p, a->ws + (long long)ns_half * p.slab_stride, ns_half, stage, false, s);
+    return wgrad_reduce_pair(p, a->ws, ns_half, a->ws + (long long)nsplit * p.slab_stride, dw2, a->accumulate, s);
 }
 
 // staged, order-fixed reduction of ns slabs at cur into p.a.dw / p.a.db (staging area: next)
-static int wgrad_reduce_slabs_impl(const WgradParams& p, const float* cur, int ns, float* next, bool direct, hipStream_t s) {
+// (dw2 != nullptr: the pair form of the one-launch paths, see wgrad_reduce_pair)
+static int wgrad_reduce_slabs_impl(const WgradParams& p, const float* cur, int ns, float* next, bool direct, hipStream_t s, float* dw2) {
     const mtd_wgrad_args* a = &p.a;
     const long long count = p.slab_stride;
     const bool vec = !direct;      // MFMA layers: N, C multiples of 32, so every slab offset is a multiple of 4 floats
@@ -1594,14 +1610,15 @@ static int wgrad_reduce_slabs_impl(const WgradParams& p, const float* cur, int n
     const long long units = vec ? count / 4 : count;
     // 16 < ns <= 1024 slabs of a layer small enough that 16-column workgroups still fill the chip's launch slots quickly:
     // one fused launch.  (Large layers have few slabs and keep the one-thread-per-float4 finish kernel.)
-    static const int env_fused = [] { const char* e = getenv("MTD_WGRAD_FUSED_REDUCE"); return e ? atoi(e) : 1; }();
+    const int env_fused = wgrad_fused_reduce_enabled();
     if (vec && env_fused && ns > 16 && ns <= 1024 && units <= 16 * 4096) {
         const int bx = (int)((units + 15) / 16);
-        if (ns > 128) hipLaunchKernelGGL((wgrad_reduce_finish_kernel<8>), dim3(bx), dim3(1024), 0, s, p, cur, ns, p.slab_stride);
-        else hipLaunchKernelGGL((wgrad_reduce_finish_kernel<4>), dim3(bx), dim3(256), 0, s, p, cur, ns, p.slab_stride);
+        if (ns > 128) hipLaunchKernelGGL((wgrad_reduce_finish_kernel<8>), dim3(bx, dw2 ? 2 : 1), dim3(1024), 0, s, p, cur, ns, p.slab_stride, dw2);
+        else hipLaunchKernelGGL((wgrad_reduce_finish_kernel<4>), dim3(bx, dw2 ? 2 : 1), dim3(256), 0, s, p, cur, ns, p.slab_stride, dw2);
         MTD_LAUNCH_CHECK();
         return MTD_OK;
     }
+    if (dw2 && ns > GS) return MTD_EINVAL;       // (wgrad_reduce_pair sends only the one-launch cases here)
     while (ns > GS) {
         int ng = (ns + GS - 1) / GS;
         int bx = (int)((units + 255) / 256);
@@ -1616,7 +1633,7 @@ static int wgrad_reduce_slabs_impl(const WgradParams& p, const float* cur, int n
     {
         int bx = (int)((units + 255) / 256);
         if (bx > 2048) bx = 2048;
-        if (vec) hipLaunchKernelGGL(wgrad_finish_kernel, dim3(bx), dim3(256), 0, s, p, cur, ns, p.slab_stride);
+        if (vec) hipLaunchKernelGGL(wgrad_finish_kernel, dim3(bx, dw2 ? 2 : 1), dim3(256), 0, s, p, cur, ns, p.slab_stride, dw2);
         else hipLaunchKernelGGL(wgrad_finish_scalar_kernel, dim3(bx), dim3(256), 0, s, p, cur, ns, p.slab_stride);
         MTD_LAUNCH_CHECK();
     }
