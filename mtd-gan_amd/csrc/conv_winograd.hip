@@ -41,6 +41,7 @@ struct WinoParams {
     IgemmParams p;            // args, M, split-K (c_per_split in channels), buffer extents, out_identity
     int ntiles, tiles_x, tiles_per_image;
     int nchunk;               // C / 8
+    int xcd_order;            // 0: workgroup = blockIdx; 1, 2: XCD-contiguous orders (see the kernel)
 };
 
 // ---- weight transform:  Uw[xi][C/8][N][8] = (G g G^T)[xi],  g[a][b] = W(n, c, kmap[a * 3 + b])  (a, b = correlation position
@@ -110,9 +111,32 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kh = lane >> 5;
-    const int tile0 = blockIdx.x * WT;
-    const int n0 = blockIdx.y * (32 * NB);
-    const int zk = blockIdx.z;
+    // Which (tile block, n block, K slice) is this workgroup's?  Consecutive workgroups go round-robin over the eight XCDs, each
+    // with an L2 of its own, so with the plain mapping every L2 fetches every weight slice AND every input slice of the launch.
+    // xcd_order gives each XCD one contiguous run of an order in which the workgroups of a run share operands:
+    //   1 (weights >= input bytes: the small maps) = the dispatch order itself, tile block fastest -- an XCD holds a few
+    //     (n block, K slice) weight slices, each fetched by ONE L2 and used by all its tile blocks;
+    //   2 (input > weights: the large maps) = tile block slowest, n block fastest -- an XCD holds a contiguous run of image rows
+    //     (the halo rows of neighbouring tile blocks meet in its L2) and each input slice is fetched once for all its n blocks.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (wp.xcd_order) {
+        const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+        const int v = xcd_contiguous_block(bx + gx * (by + gy * bz), gx * gy * gz);
+        if (wp.xcd_order == 1) {
+            bz = v / (gx * gy);
+            const int r = v - bz * (gx * gy);
+            by = r / gx;
+            bx = r - by * gx;
+        } else {
+            bx = v / (gy * gz);
+            const int r = v - bx * (gy * gz);
+            bz = r / gy;
+            by = r - bz * gy;
+        }
+    }
+    const int tile0 = bx * WT;
+    const int n0 = by * (32 * NB);
+    const int zk = bz;
     // K runs in steps of 16 channels (one transform per thread and step), each step two MFMA sub-chunks of 8
     const int st_beg = zk * (p.c_per_split >> 4);
     const int st_end = min(wp.nchunk >> 1, st_beg + (p.c_per_split >> 4));
@@ -526,6 +550,11 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
     wp.tiles_per_image = (a->g.OH / 2) * wp.tiles_x;
     wp.ntiles = a->g.B * wp.tiles_per_image;
     wp.nchunk = a->C / 8;
+    {
+        static const int env_xcd = [] { const char* e = getenv("MTD_WINO_XCD"); return e ? atoi(e) : -1; }();
+        const double wbytes = 16.0 * a->C * a->N * 4, ibytes = (double)p.M * a->C * 4;
+        wp.xcd_order = env_xcd >= 0 ? env_xcd : (wbytes >= ibytes ? 1 : 2);
+    }
     if (pl.splitk > 1) {
         const size_t need = (size_t)pl.splitk * (size_t)p.M * a->N * sizeof(float);
         if (!a->ws || a->ws_bytes < need) return MTD_EWS;
