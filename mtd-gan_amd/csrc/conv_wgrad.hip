@@ -1336,8 +1336,9 @@ static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, 
         p.ppw = pl.ppw;
         p.nCt = a->C / (32 * pl.WC);
         dim3 grid(pl.nsplit, (a->N / (32 * pl.WN)) * p.nCt, pl.ntg);
-        const int prof = mtd_prof_begin(1, pl.cfg, pl.nsplit, geom_pixels(a->g), a->N, a->C, a->g.TH * a->g.TW, s,
-                                            4.0 * ((double)geom_pixels(a->g) * a->N + (double)a->g.B * a->g.IH * a->g.IW * a->C + (double)a->g.TH * a->g.TW * a->N * a->C));
+        const int np = pair ? 2 : 1;         // problems in this launch
+        const int prof = mtd_prof_begin(1, pl.cfg, pl.nsplit, np * geom_pixels(a->g), a->N, a->C, a->g.TH * a->g.TW, s,
+                                            4.0 * np * ((double)geom_pixels(a->g) * a->N + (double)a->g.B * a->g.IH * a->g.IW * a->C + (double)a->g.TH * a->g.TW * a->N * a->C));
         // Row-window kernel: 64 KB of dynamic LDS nobody uses caps it at ONE workgroup (one wave per SIMD) per CU.  Alone in
         // a stream that changes nothing (generator step: 31.7 us per launch either way); in the full step, where it runs on a
         // side stream beside the data-gradient chain, a second workgroup on a CU took the slots of the other stream's

@@ -4,6 +4,8 @@ Same 9 positional arguments and the same returned dict {meter name: round(global
 of one iteration is `train_iteration` (D step with PCGrad, then G step); the reference performs ~25 host
 synchronisations per iteration (16 `.item()` in MetricLogger.update plus 9 `if dot < 0` in PCGrad), this
 one gathers the 17 logged scalars into one device vector and copies it to the host once per iteration."""
+import os
+
 import torch
 
 
@@ -50,6 +52,24 @@ class _Meter:
         return self.total / self.count
 
 
+_gc_frozen = [False]
+
+
+def freeze_long_lived_objects():
+    """Once per process, before the first training iteration: collect, then move everything alive (modules, parameter tables,
+    cached descriptors, the interpreter's own ~1e6 objects) to the garbage collector's permanent generation.  A full
+    collection otherwise walks all of them every ~160 iterations -- 90-120 ms on the host (tools/hiccup_probe.py), three
+    iterations' worth of GPU work for which the host's 5 ms of lead per iteration cannot make up.  Nothing is leaked that
+    would have been freed: reference counting still frees frozen objects; only cycles among them are never looked for again.
+    MTD_GC_FREEZE=0 keeps the interpreter's default."""
+    if _gc_frozen[0] or os.environ.get("MTD_GC_FREEZE", "1") != "1":
+        return
+    import gc
+    gc.collect()
+    gc.freeze()
+    _gc_frozen[0] = True
+
+
 class LoggedScalars:
     """The iteration's ONE device -> host copy, taken off the host's critical path: the 17 logged values go to a pinned
     buffer with an asynchronous copy and are read one iteration later (or at once when a line is due to be printed), so the
@@ -58,10 +78,14 @@ class LoggedScalars:
 
     def __init__(self, meters, batch_size):
         self.meters, self.batch_size, self.pending = meters, batch_size, None
+        self._ring, self._turn = [None, None], 0       # two pinned buffers, used in turn (one is pending while the other fills)
 
     def push(self, names, vals, lr):
         if vals.is_cuda:
-            host = torch.empty(vals.shape, dtype=vals.dtype, pin_memory=True)
+            self._turn ^= 1
+            host = self._ring[self._turn]
+            if host is None or host.shape != vals.shape or host.dtype != vals.dtype:
+                host = self._ring[self._turn] = torch.empty(vals.shape, dtype=vals.dtype, pin_memory=True)
             host.copy_(vals, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
@@ -100,6 +124,7 @@ def train_MTD_GAN_Ours(model, data_loader, optimizer_G, optimizer_D, device, epo
                            "given (pass dp=parallel.DataParallelSync(device), or attach it to the weight method): the ranks would "
                            "train unsynchronised replicas")
     n_it = len(data_loader)
+    freeze_long_lived_objects()
     logged = LoggedScalars(meters, batch_size)
     for it, batch_data in enumerate(data_loader):
         x = batch_data["n_20"].to(device).float()

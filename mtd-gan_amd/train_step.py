@@ -522,6 +522,7 @@ class FullStepWorkload:
         if getattr(self, "_logged", None) is None:
             self._meters = {}
             self._logged = engine.LoggedScalars(self._meters, self.batch)
+            engine.freeze_long_lived_objects()        # as train_MTD_GAN_Ours does before its first iteration
         names, vals = engine.train_iteration(self.model, self.x, self.y, self.oG, self.oD, self.wm, self.dp)
         self._logged.push(names, vals, self.oG.param_groups[0]["lr"])
 

@@ -20,7 +20,10 @@ R = sys.argv[1]
 h_run = open("gpurun_out/pmc_source_hash.txt").read().strip()
 h_now = bench._kernel_source_hash()
 assert h_run == h_now, f"PMC passes were taken at source hash {h_run}, the tree is at {h_now}"
-commit = subprocess.check_output(["git", "rev-parse", "HEAD"], text=True).strip()
+try:
+    commit = subprocess.check_output(["git", "rev-parse", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
+except Exception:
+    commit = "unknown (no .git on the GPU box; the builder's install_profiles.sh run records it)"
 cmd = "tools/r3_measure.sh (rocprofv3 --pmc <counter(s)> --kernel-trace, one pass per counter set, eager single-stream launches)"
 man = {wl: {"files": {"fetch": f"{R}_pmc_{wl}_fetch.csv", "write": f"{R}_pmc_{wl}_write.csv", "mfma": f"{R}_pmc_{wl}_mfma_util.csv"},
             "commit": commit, "source_hash": h_now, "command": cmd} for wl in ("full_step", "generator")}

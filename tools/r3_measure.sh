@@ -34,3 +34,8 @@ sys.path.insert(0, ".")
 import bench
 open("gpurun_out/pmc_source_hash.txt", "w").write(bench._kernel_source_hash())
 PY
+# the bench line once more, now that profiles/ on this box holds PMC passes of THESE kernel sources (its roofline object quotes
+# traffic and MFMA utilisation only from passes whose source hash matches)
+unset MTD_GRAPH MTD_NO_SIDE_STREAMS
+bash tools/install_profiles.sh r3 nogit && timeout -k 10 300 python bench.py > $O/bench_full.json 2> $O/bench_full.err || { echo "second bench failed"; tail -5 $O/bench_full.err; exit 1; }
+cut -c1-300 $O/bench_full.json; echo
