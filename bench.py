@@ -261,7 +261,7 @@ def roofline_pass(wl, steps, pmc_tag):
             d["ms"] += r["ms"]
             d["flops"] += r["flops"]
             # the Winograd kernel executes 16 of the 36 multiplications per 2 x 2 output tile that the layer's definition counts
-            d["exec"] += r["flops"] * (WINOGRAD_EXECUTED if r["kernel"].startswith("wino") else 1.0)
+            d["exec"] += r["flops"] * (WINOGRAD_EXECUTED if "wino" in r["kernel"] else 1.0)      # (wino_conv_kernel, wgrad_wino_kernel)
             d["bytes"] += r["bytes"]
             d["n"] += 1
             key = f"M{r['M']}_N{r['N']}_C{r['C']}_T{r['taps']}_S{r['splitk']}"
@@ -292,11 +292,12 @@ def roofline_pass(wl, steps, pmc_tag):
                 "flops_per_launch": round(d["exec"] / d["n"]), "algorithmic_flops_per_launch": round(d["flops"] / d["n"]),
                 "algorithmic_tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2),
                 "flop_model": ("Winograd F(2x2,3x3): executed MFMA flops = 2 M N C 4 per launch (`achieved`, `flops_per_launch`, `frac`); the layer's "
-                               "algorithmic count is 2 M N C 9 (`algorithmic_*`)" if name.startswith("wino") else "executed = algorithmic = 2 M N C taps"),
+                               "algorithmic count is 2 M N C 9 (`algorithmic_*`)" if "wino" in name else "executed = algorithmic = 2 M N C taps"),
                 "measured": "second pass of the same steps, all kernels in one stream",
                 "share_of_step_gpu_ms": round(d["ms"] / steps, 3),
-                "top_shapes": {k: {"us": round(1e3 * v[0] / v[2], 2), "tflops": round(v[1] / v[0] / 1e9 * (WINOGRAD_EXECUTED if name.startswith("wino") else 1.0), 2),
+                "top_shapes": {k: {"us": round(1e3 * v[0] / v[2], 2), "tflops": round(v[1] / v[0] / 1e9 * (WINOGRAD_EXECUTED if "wino" in name else 1.0), 2),
                                    "launches_per_step": v[2] // steps} for k, v in top},
+                # (executed MFMA flops, like `achieved`: the two Winograd kernels at 4 / 9 of their layers' algorithmic count)
                 "other_mfma_kernels": {k: {"tflops": round(v["exec"] / v["ms"] / 1e9, 2), "ms_per_step": round(v["ms"] / steps, 3)}
                                 for k, v in by.items() if k != name}}
     return roofline, extra
