@@ -14,9 +14,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TOL = 1e-3   # north_star: 1e-3 relative fp32
 
 
-def rel(a, b):
-    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
-    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+from _metrics import rel  # noqa: E402  (tensor-wide AND element-wise bound)
 
 
 def test_block_vs_oracle_and_golden(hip_lib):

@@ -17,8 +17,7 @@ def nchw(t):   # NHWC cuda -> NCHW cpu
     return t.permute(0, 3, 1, 2).contiguous().cpu()
 
 
-def relerr(a, b):
-    return (a.double() - b.double()).abs().max().item() / (b.double().abs().max().item() + 1e-30)
+from _metrics import rel as relerr  # noqa: E402  (tensor-wide AND element-wise bound)
 
 
 def rnd(*shape, seed=0, scale=1.0):

@@ -17,9 +17,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TOL = 1e-3
 
 
-def rel(a, b):
-    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
-    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+from _metrics import rel  # noqa: E402  (tensor-wide AND element-wise bound)
 
 
 def test_loss_kernels_vs_torch(hip_lib):
