@@ -313,13 +313,16 @@ class GradSink:
 FLUSH_LEVEL = 4      # trunk levels 6 .. FLUSH_LEVEL + both bottleneck convs: 91 % of the shared parameters, done 60 % into the trunk
 
 
-def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0, dec_export=None, dec_import=None, flush=None):
+def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0, dec_export=None, dec_import=None, flush=None,
+                  overwrite=frozenset()):
     """Replay one recorded pass.  g_enc (B,1,1,1) / g_dec (B,64,64,1) / g_rec (B,64,64,1): output
     cotangents (any may be None).  sink: GradSink or None.  All parameter gradients are ACCUMULATED.
     The decoders are task-specific: their parameter gradient is the SUM over the tasks that reach them through this tape,
     and a weight gradient is linear in the cotangent -- so a pass may hand its decoder cotangents over instead of computing
     the decoder weight gradients (dec_export: dict to fill, layer -> cotangent tensor) and the last pass over the tape
     computes them once from the sums (dec_import: the dicts of the earlier passes merged).
+    overwrite: names of spectral-norm layers whose corrected weight gradient REPLACES what the sink holds instead of being added
+    to it (the first pass into a gradient buffer: the buffer then needs no zero fill and is not read).
     flush: optional callable(stage) for a caller that ships finished gradients while the pass is still running (data
     parallelism: the all-reduce of a slice overlaps the rest of this pass).  Called with "heads" when every decoder / head
     gradient of this pass has been enqueued, spectral-norm corrections included, and with "trunk_low" when the same holds
@@ -396,7 +399,7 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0
             s.v = tp.v_save.data_ptr() + 4 * SN_COL_OFF[i]
             s.sigma = tp.sig.data_ptr() + 8 * i
             s.g_out = sink.get(name + ".weight_orig").data_ptr()
-            s.rows, s.cols, s.accumulate = SN_SPECS[i][1], SN_SPECS[i][2], 1
+            s.rows, s.cols, s.accumulate = SN_SPECS[i][1], SN_SPECS[i][2], 0 if name in overwrite else 1
             if Bh:      # the second half's own sigma, u, v: corrected and added in the same launch, after the first
                 s.G2 = rt.gtemp(name, dev, 1, chain).data_ptr()
                 s.u2 = tp.u_save2.data_ptr() + 4 * SN_ROW_OFF[i]

@@ -12,6 +12,7 @@ the next zero_grad) and then the generator.  Nothing here synchronises with the 
 """
 import os
 import random
+import re
 
 import torch
 
@@ -20,6 +21,10 @@ from . import generator_path as GP
 from . import kernels as K
 
 NPIX = 64 * 64
+# the first pass into a task vector overwrites its spectral-norm weight gradients (MTD_FIRST_WRITE=0: zero fill + accumulate)
+FIRST_WRITE = os.environ.get("MTD_FIRST_WRITE", "1") == "1"
+POISON = os.environ.get("MTD_POISON_TASK_VECTORS", "0") == "1"
+_TRUNK_SN_WEIGHT = re.compile(r"(?:conv\d\d|down\d|bconv\d)\.weight_orig$")
 # data parallelism: ship finished gradient slices of the last task pass while it runs (MTD_DP_EARLY_SHIP=0: after the pass)
 EARLY_SHIP = os.environ.get("MTD_DP_EARLY_SHIP", "1") == "1"
 
@@ -47,8 +52,15 @@ class DStepTape:
         ts_names = [by_id[id(p)] for p in (task_specific_params or [])]
         sizes = [D.get_parameter(nme).numel() for nme in sh_names]
         total = sum(sizes)
-        S = torch.empty((4, total), dtype=torch.float32, device=dev)       # 3 task vectors (accumulated into: zeroed) + merged (written whole)
-        S[:3].zero_()
+        S = torch.empty((4, total), dtype=torch.float32, device=dev)       # 3 task vectors + merged (written whole)
+        # The trunk's spectral-norm weights are 99.9 % of a task vector, and every backward pass writes all of them: the FIRST
+        # pass into a vector overwrites (disc_backward(overwrite=...)) instead of adding to zeros -- no 343 MB fill per step and
+        # no read of it by the correction kernel.  Only the rest (the biases, which the weight-gradient kernels accumulate)
+        # is zeroed.  (Task chains: passes into one vector may run in any order -- zero everything, accumulate everything.)
+        first_write = frozenset() if (K.CHAINS or not FIRST_WRITE) else frozenset(
+            nme[:-len(".weight_orig")] for nme in sh_names if _TRUNK_SN_WEIGHT.match(nme))
+        if POISON:
+            S[:3].fill_(float("nan"))          # (test hook: an element no pass writes stays NaN)
         # task-specific gradients: views of one flat buffer, so that N > 1 averages them with a single collective
         ts_sizes = [D.get_parameter(nme).numel() for nme in ts_names]
         # (each view starts on a 16-byte boundary: the spectral-norm correction then moves float4s)
@@ -64,6 +76,11 @@ class DStepTape:
                 t[nme] = S[i, ofs:ofs + sz]
                 ofs += sz
             sinks.append(DP.GradSink(t))
+        rest = [sk.t[nme] for sk in sinks for nme in sh_names if not (nme.endswith(".weight_orig") and nme[:-len(".weight_orig")] in first_write)]
+        if first_write and rest:
+            torch._foreach_zero_(rest)
+        elif not first_write:
+            S[:3].zero_()
         # ---- the projection order of this step: Python's `random`, as the reference draws it.  Under data parallelism
         # it is a collective decision (rank 0's draw, broadcast on the RCCL stream under the backward passes): ranks with
         # different `random` states would otherwise project the same averaged gradients differently and drift apart.
@@ -113,13 +130,13 @@ class DStepTape:
         exp_s, exp_r = {}, {}
 
         def adversarial(chain):         # image-level + pixel-level heads on passes 1 and 2
-            DP.disc_backward(rt, P, t12, G2["d_e"], G2["d_d"], None, sinks[0], False, chain=chain, dec_export=exp_s)
+            DP.disc_backward(rt, P, t12, G2["d_e"], G2["d_d"], None, sinks[0], False, chain=chain, dec_export=exp_s, overwrite=first_write)
 
         def restoration(chain):
-            DP.disc_backward(rt, P, t12, None, None, G2["r_r"], sinks[1], False, chain=chain, dec_export=exp_r)
+            DP.disc_backward(rt, P, t12, None, None, G2["r_r"], sinks[1], False, chain=chain, dec_export=exp_r, overwrite=first_write)
 
         def consistency34(chain):       # through D(rec.clip), passes 3 and 4 ...
-            return DP.disc_backward(rt, P, t34, G2["c3_e"], G2["c3_d"], None, sink_c, True, chain=chain)
+            return DP.disc_backward(rt, P, t34, G2["c3_e"], G2["c3_d"], None, sink_c, True, chain=chain, overwrite=first_write)
 
         def consistency12(chain, gin34, flush=None):  # ... and back into the restoration decoder of passes 1 and 2
             DP.disc_backward(rt, P, t12, G2["c_e"], G2["c_d"], K.clip01_bwd(gin34, r12), sink_c, False, chain=chain,

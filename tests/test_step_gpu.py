@@ -363,6 +363,37 @@ def test_d_step_task_gradients_vs_oracle(hip_lib):
     assert D.c_fc.weight_orig.grad is None
 
 
+def test_first_pass_overwrites_task_vectors_same_bits(hip_lib, monkeypatch):
+    """train_step.DStepTape.run_pcgrad: the first backward pass into a task vector OVERWRITES its spectral-norm weight
+    gradients (no zero fill of the 3 x 114 MB, no read of it by the correction kernel).  With the vectors poisoned with NaN
+    beforehand, every element must have been written, and the three task vectors, the merged gradient and the task-specific
+    gradients must equal the zero-fill-and-accumulate form bit for bit (0 + x == x)."""
+    from mtd_gan_amd import train_step as TS
+    from mtd_gan_amd.module.weight_methods import WeightMethods
+    res = {}
+    for mode in ("accumulate", "overwrite"):
+        monkeypatch.setattr(TS, "FIRST_WRITE", mode == "overwrite")
+        monkeypatch.setattr(TS, "POISON", mode == "overwrite")
+        m, full, masks, z = _model(2)
+        m.Discriminator._inject_masks = [k.clone() for k in masks[:4]]
+        x, y = orc.synthetic_ldct(2, seed=1234)
+        wm = WeightMethods("pcgrad", n_tasks=3, device=torch.device("cuda"))
+        random.seed(77)
+        losses, _ = m.d_loss(x.cuda(), y.cuda())
+        D = m.Discriminator
+        wm.backward(losses=losses, shared_parameters=list(D.shared_parameters()), task_specific_parameters=list(D.task_specific_parameters()),
+                    last_shared_parameters=list(D.last_shared_parameters()))
+        tape = losses._mtd_tape
+        torch.cuda.synchronize()
+        res[mode] = (tape.task_vectors.clone(), [p.grad.clone() for p in D.task_specific_parameters()])
+    S0, ts0 = res["accumulate"]
+    S1, ts1 = res["overwrite"]
+    assert torch.isfinite(S1).all()
+    assert torch.equal(S0, S1)
+    assert all(torch.equal(a, b) for a, b in zip(ts0, ts1))
+
+
+@pytest.mark.gpu
 def test_d_step_task_gradients_b32_vs_reference_samples(hip_lib):
     """The D step at BASELINE size (32 patches): the three per-task shared gradients, the merged gradient PCGrad writes and the
     task-specific gradients, PER TENSOR, against tests/golden/grad_samples_b32.json -- elements of the gradients the REFERENCE
