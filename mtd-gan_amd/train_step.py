@@ -25,6 +25,7 @@ NPIX = 64 * 64
 FIRST_WRITE = os.environ.get("MTD_FIRST_WRITE", "1") == "1"
 POISON = os.environ.get("MTD_POISON_TASK_VECTORS", "0") == "1"
 _TRUNK_SN_WEIGHT = re.compile(r"(?:conv\d\d|down\d|bconv\d)\.weight_orig$")
+re_dec = {"s": re.compile(r"s_dconv\d\d\.weight_orig$"), "r": re.compile(r"r_dconv\d\d\.weight_orig$")}
 # data parallelism: ship finished gradient slices of the last task pass while it runs (MTD_DP_EARLY_SHIP=0: after the pass)
 EARLY_SHIP = os.environ.get("MTD_DP_EARLY_SHIP", "1") == "1"
 
@@ -64,7 +65,16 @@ class DStepTape:
         # task-specific gradients: views of one flat buffer, so that N > 1 averages them with a single collective
         ts_sizes = [D.get_parameter(nme).numel() for nme in ts_names]
         # (each view starts on a 16-byte boundary: the spectral-norm correction then moves float4s)
-        TSflat = torch.zeros(max(sum((sz + 3) // 4 * 4 for sz in ts_sizes), 4), dtype=torch.float32, device=dev)
+        TSflat = torch.empty(max(sum((sz + 3) // 4 * 4 for sz in ts_sizes), 4), dtype=torch.float32, device=dev)
+        # ... and the same for the decoders' spectral-norm weights (97 % of the task-specific bucket): the SEG decoder's are first
+        # written by the pass over tape 3+4, the REC decoder's by the last pass over tape 1+2 (the others hand their decoder
+        # cotangents over, see below)
+        dec_first = {"s": frozenset(), "r": frozenset()}
+        if first_write:
+            for pre in "sr":
+                dec_first[pre] = frozenset(nme[:-len(".weight_orig")] for nme in ts_names if re_dec[pre].match(nme))
+        if POISON:
+            TSflat.fill_(float("nan"))
         TSbuf, tofs = {}, 0
         for nme, sz in zip(ts_names, ts_sizes):
             TSbuf[nme] = TSflat[tofs:tofs + sz].view_as(D.get_parameter(nme))
@@ -77,10 +87,12 @@ class DStepTape:
                 ofs += sz
             sinks.append(DP.GradSink(t))
         rest = [sk.t[nme] for sk in sinks for nme in sh_names if not (nme.endswith(".weight_orig") and nme[:-len(".weight_orig")] in first_write)]
+        rest += [TSbuf[nme] for nme in ts_names if not (nme.endswith(".weight_orig") and nme[:-len(".weight_orig")] in (dec_first["s"] | dec_first["r"]))]
         if first_write and rest:
             torch._foreach_zero_(rest)
         elif not first_write:
             S[:3].zero_()
+            TSflat.zero_()
         # ---- the projection order of this step: Python's `random`, as the reference draws it.  Under data parallelism
         # it is a collective decision (rank 0's draw, broadcast on the RCCL stream under the backward passes): ranks with
         # different `random` states would otherwise project the same averaged gradients differently and drift apart.
@@ -116,12 +128,16 @@ class DStepTape:
         # The consistency task touches the decoders of both other tasks, so its task-specific gradients go to a buffer of
         # their own, added at the end (tasks 0 and 1 own disjoint decoders): the three task backward passes then share only
         # read-only tapes and can run as concurrent chains.
-        TSc = torch.zeros_like(TSflat)
-        t2, tofs = dict(sinks[2].t), 0
-        for nme, sz in zip(ts_names, ts_sizes):
-            t2[nme] = TSc[tofs:tofs + sz].view_as(D.get_parameter(nme))
-            tofs += (sz + 3) // 4 * 4
-        sink_c = DP.GradSink(t2)
+        # (Without chains the passes run one after the other on one stream pair and all add into the one buffer.)
+        if K.CHAINS:
+            TSc = torch.zeros_like(TSflat)
+            t2, tofs = dict(sinks[2].t), 0
+            for nme, sz in zip(ts_names, ts_sizes):
+                t2[nme] = TSc[tofs:tofs + sz].view_as(D.get_parameter(nme))
+                tofs += (sz + 3) // 4 * 4
+            sink_c = DP.GradSink(t2)
+        else:
+            TSc, sink_c = None, sinks[2]
 
         # The decoders' gradients are sums over the tasks that reach them through passes 1+2 (SEG decoder: adversarial +
         # consistency, REC decoder: restoration + consistency) and a weight gradient is linear in its cotangent: the
@@ -136,11 +152,11 @@ class DStepTape:
             DP.disc_backward(rt, P, t12, None, None, G2["r_r"], sinks[1], False, chain=chain, dec_export=exp_r, overwrite=first_write)
 
         def consistency34(chain):       # through D(rec.clip), passes 3 and 4 ...
-            return DP.disc_backward(rt, P, t34, G2["c3_e"], G2["c3_d"], None, sink_c, True, chain=chain, overwrite=first_write)
+            return DP.disc_backward(rt, P, t34, G2["c3_e"], G2["c3_d"], None, sink_c, True, chain=chain, overwrite=first_write | dec_first["s"])
 
         def consistency12(chain, gin34, flush=None):  # ... and back into the restoration decoder of passes 1 and 2
             DP.disc_backward(rt, P, t12, G2["c_e"], G2["c_d"], K.clip01_bwd(gin34, r12), sink_c, False, chain=chain,
-                             dec_import={**exp_s, **exp_r}, flush=flush)
+                             dec_import={**exp_s, **exp_r}, flush=flush, overwrite=dec_first["r"])
 
         # Data parallelism: the LAST pass has no later backward to hide its collectives under, so it ships what is final while
         # it runs -- the task-specific bucket (158 MB) once the decoders and heads are done (before the whole trunk), the tail
@@ -152,7 +168,8 @@ class DStepTape:
             side = K.side_stream(dev)          # the weight gradients and their spectral-norm corrections are on this stream
             if stage == "heads" and ts_names:
                 def ts():
-                    TSflat.add_(TSc)
+                    if TSc is not None:
+                        TSflat.add_(TSc)
                     dp.all_reduce_avg(TSflat)
                 side.run(ts)
                 shipped["ts"] = True
@@ -213,7 +230,8 @@ class DStepTape:
         if dp is not None:
             dp.wait()                          # the three averaged task vectors are needed by the Gram kernel
         if not shipped["ts"]:
-            TSflat.add_(TSc)
+            if TSc is not None:
+                TSflat.add_(TSc)
             if dp is not None and ts_names:
                 dp.all_reduce_avg(TSflat)      # 158 MB, in flight under the Gram / combine kernels; joined below
         # ---- PCGrad: Gram of the original task gradients, replay of the projections, combine
