@@ -145,7 +145,7 @@ int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream);
  * gradients into a->db, the second accumulated) from ONE launch of the slab-producing kernel: the paired discriminator
  * passes of the D step (D(y) | D(fake) as one batch of 2B, networks.py:1959-1970) need the halves' gradients apart,
  * because each half has its own spectral-norm sigma, u, v.  Same arithmetic per range as mtd_conv_wgrad on that range
- * up to the order of the slab sums.  _ok: 1 if the layer qualifies (B == 2 b_first, N and C multiples of 32, and a plan
+ * up to the order of the slab sums.  _ok: nonzero if the layer qualifies (B == 2 b_first, N and C multiples of 32, and a plan
  * whose kernel has the pair form: all but the row-window kernels of the 16-pixel-aligned 3x3 / 1x1 stride-1 layers below
  * 64 channels), else the caller runs mtd_conv_wgrad twice.  _ws_bytes: 0 if it does not qualify. */
 int mtd_conv_wgrad_pair_ok(const mtd_wgrad_args* a, int b_first);
@@ -155,6 +155,11 @@ int mtd_conv_wgrad_pair_ok(const mtd_wgrad_args* a, int b_first);
 int mtd_conv_wgrad_pair_mode(int mode);
 size_t mtd_conv_wgrad_pair_ws_bytes(const mtd_wgrad_args* a, int b_first);
 int mtd_conv_wgrad_pair(const mtd_wgrad_args* a, float* dw2, int b_first, void* stream);
+/* The same with the gradients taken from a->p + p_add, added as the operands are loaded (the decoders' weight gradients of
+ * the D step are sums over two task passes' cotangents -- discriminator_path.cot -- and a weight gradient is linear in its
+ * cotangent: no pass of its own for the sum).  p_add: shape, pixel stride and alignment of a->p.  Only where
+ * mtd_conv_wgrad_pair_ok returns 2 (1: pair form without the second cotangent, 0: no pair form). */
+int mtd_conv_wgrad_pair_sum(const mtd_wgrad_args* a, const float* p_add, float* dw2, int b_first, void* stream);
 
 /* Deferred form for a backward pass with many small layers (the generator: 41 conv layers of 32 channels, each with
  * 256 partial-sum slabs).  mtd_conv_wgrad_slabs runs only the slab-producing kernel into a->ws, which must stay

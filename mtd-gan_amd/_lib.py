@@ -167,6 +167,7 @@ def lib():
     sig("mtd_conv_wgrad_pair_mode", ci, ci)
     sig("mtd_conv_wgrad_pair_ws_bytes", sz, C.POINTER(WgradArgs), ci)
     sig("mtd_conv_wgrad_pair", ci, C.POINTER(WgradArgs), vp, ci, vp)
+    sig("mtd_conv_wgrad_pair_sum", ci, C.POINTER(WgradArgs), vp, vp, ci, vp)
     sig("mtd_conv_wgrad_slabs", ci, C.POINTER(WgradArgs), C.POINTER(C.c_int), C.POINTER(C.c_longlong), vp)
     sig("mtd_conv_wgrad_slabs_rfft", ci, C.POINTER(WgradArgs), C.POINTER(C.c_int), C.POINTER(C.c_longlong), vp, ci, vp, ci, ci, vp)
     sig("mtd_conv_wgrad_reduce_blocks", ci, C.POINTER(WgradReduceDesc))
@@ -242,7 +243,7 @@ def lib():
 
 EXPORTS = [
     "mtd_version", "mtd_conv_igemm_ws_bytes", "mtd_conv_igemm", "mtd_conv_direct", "mtd_conv_wgrad_ws_bytes",
-    "mtd_conv_wgrad", "mtd_conv_wgrad_pair_ok", "mtd_conv_wgrad_pair_mode", "mtd_conv_wgrad_pair_ws_bytes", "mtd_conv_wgrad_pair", "mtd_rfft_rows", "mtd_spec_mix_fwd", "mtd_spec_mix_bwd_ws_bytes", "mtd_spec_mix_bwd",
+    "mtd_conv_wgrad", "mtd_conv_wgrad_pair_ok", "mtd_conv_wgrad_pair_mode", "mtd_conv_wgrad_pair_ws_bytes", "mtd_conv_wgrad_pair", "mtd_conv_wgrad_pair_sum", "mtd_rfft_rows", "mtd_spec_mix_fwd", "mtd_spec_mix_bwd_ws_bytes", "mtd_spec_mix_bwd",
     "mtd_spec_mix_wgrad_reduce", "mtd_irfft_rows", "mtd_transpose64", "mtd_act_grad", "mtd_copy_channels",
     "mtd_upsample2x_fwd", "mtd_upsample2x_bwd", "mtd_pixel_shuffle2_fwd", "mtd_pixel_shuffle2_bwd", "mtd_mul", "mtd_pack_weights",
     "mtd_sn_ws_bytes", "mtd_sn_power_iter", "mtd_sn_grad_ws_bytes", "mtd_sn_grad", "mtd_pcgrad_ws_bytes",

@@ -1352,6 +1352,7 @@ static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, 
             wp.ntiles = a->g.B * wp.tiles_per_image;
             wp.chunks_per_split = pl.ppw;
             wp.ns_first = wp.first_tiles = 0;
+            wp.p_add = nullptr;
             MTD_LAUNCH(wgrad_wino_kernel, dim3(pl.nsplit, (a->N / 64) * (a->C / 64)), dim3(512), 0, s, wp);
             mtd_prof_end(prof, s);
             MTD_LAUNCH_CHECK();
@@ -1536,9 +1537,11 @@ extern "C" int mtd_conv_wgrad_pair_mode(int mode) {
     return prev;
 }
 
+// 0: no pair form; 1: mtd_conv_wgrad_pair; 2: also mtd_conv_wgrad_pair_sum (the Winograd plan: a second cotangent added on load)
 extern "C" int mtd_conv_wgrad_pair_ok(const mtd_wgrad_args* a, int b_first) {
     int ns, cps;
-    return a && wgrad_pair_plan(*a, b_first, ns, cps) ? 1 : 0;
+    if (!a || !wgrad_pair_plan(*a, b_first, ns, cps)) return 0;
+    return ns > 0 ? 2 : 1;
 }
 
 extern "C" size_t mtd_conv_wgrad_pair_ws_bytes(const mtd_wgrad_args* a, int b_first) {
@@ -1554,9 +1557,17 @@ extern "C" size_t mtd_conv_wgrad_pair_ws_bytes(const mtd_wgrad_args* a, int b_fi
     return wgrad_ws_floats(*a, 2 * ns) * sizeof(float);
 }
 
+extern "C" int mtd_conv_wgrad_pair_sum(const mtd_wgrad_args* a, const float* p_add, float* dw2, int b_first, void* stream);
 extern "C" int mtd_conv_wgrad_pair(const mtd_wgrad_args* a, float* dw2, int b_first, void* stream) {
+    return mtd_conv_wgrad_pair_sum(a, nullptr, dw2, b_first, stream);
+}
+
+// as mtd_conv_wgrad_pair with the gradients taken from a->p + p_add (p_add: same shape, pixel stride and alignment as a->p; NULL:
+// none).  Only where mtd_conv_wgrad_pair_ok says 2.
+extern "C" int mtd_conv_wgrad_pair_sum(const mtd_wgrad_args* a, const float* p_add, float* dw2, int b_first, void* stream) {
     int ns_half = 0, cps = 0;
     if (!a || !dw2 || !wgrad_pair_plan(*a, b_first, ns_half, cps)) return MTD_EINVAL;
+    if (p_add && (ns_half == 0 || !aligned16(p_add))) return MTD_EINVAL;
     if (ns_half == 0) {                    // one of the general kernels over both problems
         mtd_wgrad_args h = *a;
         h.g.B = b_first;
@@ -1592,6 +1603,7 @@ extern "C" int mtd_conv_wgrad_pair(const mtd_wgrad_args* a, float* dw2, int b_fi
     wp.chunks_per_split = cps;
     wp.ns_first = ns_half;
     wp.first_tiles = b_first * wp.tiles_per_image;
+    wp.p_add = p_add;
     hipStream_t s = (hipStream_t)stream;
     const int prof = mtd_prof_begin(1, 16, nsplit, geom_pixels(a->g), a->N, a->C, 9, s,
                                     4.0 * ((double)geom_pixels(a->g) * a->N + (double)a->g.B * a->g.IH * a->g.IW * a->C + 2.0 * 9 * a->N * a->C));

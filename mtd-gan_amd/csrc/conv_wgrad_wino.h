@@ -36,6 +36,9 @@ struct WgradWinoParams {
     // pair form (mtd_conv_wgrad_pair): the batch is two image ranges with a weight gradient each -- slabs 0 .. ns_first - 1 are
     // sums over tiles [0, first_tiles), the others over [first_tiles, ntiles).  ns_first = 0: one range.
     int ns_first, first_tiles;
+    // second cotangent (mtd_conv_wgrad_pair_sum): the gradient is taken from p + p_add, summed as the operands arrive (a decoder
+    // layer's cotangents of two task passes: a weight gradient is linear in its cotangent).  Same layout and extent as a.p; NULL: none.
+    const float* p_add;
 };
 
 __device__ __forceinline__ float wgw_quad(float v, int ctrl) {
@@ -78,7 +81,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgradWinoParam
     const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.q), (short)0, (int)p.q_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p), (short)0, (int)p.p_bytes, 0x00020000);
     const int qpx_b = a.q_ld * 4;
-    struct Pre { f32x4 d[4]; f32x4 y; };      // one chunk's operands of this thread, on their way from memory
+    struct Pre { f32x4 d[4]; f32x4 y, y2; };  // one chunk's operands of this thread, on their way from memory
+    // (no second cotangent: the same loads with an out-of-range offset -- zeros, no memory traffic, one path through the loop)
+    const __amdgpu_buffer_rsrc_t p2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp.p_add ? wp.p_add : a.p), (short)0, (int)p.p_bytes, 0x00020000);
+    const bool has_p2 = wp.p_add != nullptr;
     f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
     auto load_chunk = [&](int ck, Pre& r) {
         const int tg = tile_lo + ck * WGW_T + t8;
@@ -100,6 +106,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgradWinoParam
         const long long pix = ((long long)b * g.OH + 2 * ty + (qp >> 1)) * g.OW + 2 * tx + (qp & 1);
         const unsigned vo = tv ? (unsigned)((pix * a.p_ld + n0 + 4 * cq) * 4) : 0x80000000u;
         r.y = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, vo, 0, 0));
+        r.y2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(p2rs, has_p2 ? vo : 0x80000000u, 0, 0));
     };
     const float usign = qp == 1 ? 1.f : -1.f;
     // A = [1 0; 1 1; 1 -1; 0 -1]: row a = qp of A dY A^T is  alpha * R0 + beta * R1,  R_i[b] = (dY A^T)[i][b]
@@ -117,14 +124,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgradWinoParam
     };
     auto tr_v_gather = [&](const Pre& r, float live) {
         f32x4 y00, y01, y10, y11;
+        const f32x4 ys = r.y + r.y2;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            y00[c] = wgw_quad(r.y[c], 2);
-            y01[c] = wgw_quad(r.y[c], 3);
-            y10[c] = wgw_quad(r.y[c], 4);
-            y11[c] = wgw_quad(r.y[c], 5);
+            y00[c] = wgw_quad(ys[c], 2);
+            y01[c] = wgw_quad(ys[c], 3);
+            y10[c] = wgw_quad(ys[c], 4);
+            y11[c] = wgw_quad(ys[c], 5);
         }
-        dbacc += live * r.y;
+        dbacc += live * ys;
         // R_i = [y_i0, y_i0 + y_i1, y_i0 - y_i1, -y_i1]
         vr0[0] = y00; vr0[1] = y00 + y01; vr0[2] = y00 - y01; vr0[3] = -y01;
         vr1[0] = y10; vr1[1] = y10 + y11; vr1[2] = y10 - y11; vr1[3] = -y11;

@@ -349,7 +349,9 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0
             return None
         if dec_import is not None and key in dec_import:
             other = dec_import[key]
-            return lambda: K.add(p, other)          # evaluated on the side stream, right before the weight gradient
+            f = lambda: K.add(p, other)             # evaluated on the side stream, right before the weight gradient
+            f.parts = (p, other)                    # (a launch that adds the two as it loads them takes these instead)
+            return f
         return lambda: p
 
     def wgrad_sn(name, p, q, gspec, N, Cc, k):
@@ -366,8 +368,9 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0
                 gfull = K.geom_fwd(B, hh, hh, kk, ss, pp)
 
                 def both():         # (one launch for both halves where the library's plan allows it)
-                    K.wgrad_pair(src(), q, gfull, Bh, N, Cc, rt.gtemp(name, dev, 0, chain), rt.gtemp(name, dev, 1, chain), Cc * k * k, k * k,
-                                 db=sink.get(bn), accumulate_bias=True)
+                    pe, pe2 = getattr(src, "parts", None) or (src(), None)
+                    K.wgrad_pair(pe, q, gfull, Bh, N, Cc, rt.gtemp(name, dev, 0, chain), rt.gtemp(name, dev, 1, chain), Cc * k * k, k * k,
+                                 db=sink.get(bn), accumulate_bias=True, p_add=pe2)
                 side.run(both, p, q)
             else:
                 geom = K.geom_fwd(B, hh, hh, kk, ss, pp)

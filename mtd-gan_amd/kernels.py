@@ -550,12 +550,18 @@ def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumula
     check(L.mtd_conv_wgrad(C.byref(a), stream_ptr()), "mtd_conv_wgrad")
 
 
-def wgrad_pair(p, q, geom, b_first, N, Cc, dw1, dw2, w_sn, w_sc, db=None, accumulate_bias=True):
+WGRAD_SUM = os.environ.get("MTD_WGRAD_SUM", "1") == "1"      # second cotangent added inside the pair launch (0: by kernels.add)
+
+
+def wgrad_pair(p, q, geom, b_first, N, Cc, dw1, dw2, w_sn, w_sc, db=None, accumulate_bias=True, p_add=None):
     """The raw weight gradients of the two image ranges [0, b_first), [b_first, B) of one batch (a paired discriminator
     pass: each range has its own spectral-norm statistics) into dw1 / dw2 and the sum of both bias gradients into db: ONE
     launch of the slab-producing kernel where the library's plan allows it (mtd_conv_wgrad_pair), two launches otherwise.
-    geom: the forward geometry of the whole batch."""
+    geom: the forward geometry of the whole batch.  p_add: a second cotangent -- the gradients are those of p + p_add; added
+    inside the launch where the plan can (mtd_conv_wgrad_pair_sum), by a pass of its own otherwise."""
     L = _lib.lib()
+    if p_add is not None and (ld_of(p_add) != ld_of(p) or not WGRAD_SUM):
+        p, p_add = add(p, p_add), None
     a = WgradArgs()
     a.g = geom
     a.p, a.p_ld, a.N = p.data_ptr(), ld_of(p), N
@@ -565,6 +571,9 @@ def wgrad_pair(p, q, geom, b_first, N, Cc, dw1, dw2, w_sn, w_sc, db=None, accumu
     a.accumulate = 2 if accumulate_bias else 0
     a.ws, a.ws_bytes = None, 0
     need = L.mtd_conv_wgrad_pair_ws_bytes(C.byref(a), b_first)       # 0: this layer's plan has no pair form
+    if p_add is not None and (need == 0 or L.mtd_conv_wgrad_pair_ok(C.byref(a), b_first) != 2):
+        p, p_add = add(p, p_add), None
+        a.p = p.data_ptr()
     if need == 0:
         B = geom.B
         ga, gb = mtd_geom_with_batch(geom, b_first), mtd_geom_with_batch(geom, B - b_first)
@@ -575,7 +584,7 @@ def wgrad_pair(p, q, geom, b_first, N, Cc, dw1, dw2, w_sn, w_sc, db=None, accumu
         _count("wgrad_mfma", 2.0 * geom.B * geom.OH * geom.OW * N * Cc * geom.TH * geom.TW)
     ws = workspace(need, p.device)
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
-    check(L.mtd_conv_wgrad_pair(C.byref(a), dw2.data_ptr(), b_first, stream_ptr()), "mtd_conv_wgrad_pair")
+    check(L.mtd_conv_wgrad_pair_sum(C.byref(a), _ptr(p_add), dw2.data_ptr(), b_first, stream_ptr()), "mtd_conv_wgrad_pair_sum")
 
 
 def mtd_geom_with_batch(geom, B):

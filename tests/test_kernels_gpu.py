@@ -748,7 +748,8 @@ def _pair_case(K, _lib, B, Bh, Ci, Co, H, W, k, pairs):
     a.g = geom
     a.p, a.p_ld, a.N, a.q, a.q_ld, a.C = gy.data_ptr(), Co, Co, x.data_ptr(), Ci, Ci
     a.dw, a.w_sn, a.w_sc = d1.data_ptr(), Ci * kk, kk
-    assert _lib.lib().mtd_conv_wgrad_pair_ok(_lib.C.byref(a), Bh) == pairs
+    ok = _lib.lib().mtd_conv_wgrad_pair_ok(_lib.C.byref(a), Bh)                 # 2: the plan also adds a second cotangent on load
+    assert (ok != 0) == bool(pairs)
     db = torch.full((Co,), -1.0, device="cuda")
     K.wgrad_pair(gy, x, geom, Bh, Co, Ci, d1, d2, Ci * kk, kk, db=db, accumulate_bias=True)
     r1, r2 = torch.empty_like(d1), torch.empty_like(d2)
@@ -756,7 +757,19 @@ def _pair_case(K, _lib, B, Bh, Ci, Co, H, W, k, pairs):
     gh = K.geom_fwd(Bh, H * stride, W * stride, k, stride, pad)
     K.wgrad(gy[:Bh], x[:Bh], gh, Co, Ci, r1, Ci * kk, kk, db=rb, accumulate=False, accumulate_bias=True)
     K.wgrad(gy[Bh:], x[Bh:], gh, Co, Ci, r2, Ci * kk, kk, db=rb, accumulate=False, accumulate_bias=True)
+    # a second cotangent (the decoders' sums over two task passes): gradients of gy + gz, added inside the launch where ok == 2,
+    # by kernels.add otherwise -- against the two-launch form on the materialised sum
+    gz = torch.randn(B, H, W, Co, generator=gen).cuda()
+    e1, e2 = torch.empty_like(d1), torch.empty_like(d2)
+    eb = torch.zeros(Co, device="cuda")
+    K.wgrad_pair(gy, x, geom, Bh, Co, Ci, e1, e2, Ci * kk, kk, db=eb, accumulate_bias=True, p_add=gz)
+    gs = gy + gz
+    s1, s2 = torch.empty_like(d1), torch.empty_like(d2)
+    sb = torch.zeros(Co, device="cuda")
+    K.wgrad(gs[:Bh], x[:Bh], gh, Co, Ci, s1, Ci * kk, kk, db=sb, accumulate=False, accumulate_bias=True)
+    K.wgrad(gs[Bh:], x[Bh:], gh, Co, Ci, s2, Ci * kk, kk, db=sb, accumulate=False, accumulate_bias=True)
     torch.cuda.synchronize()
+    assert relerr(e1.cpu(), s1.cpu()) < 2e-5 and relerr(e2.cpu(), s2.cpu()) < 2e-5 and relerr(eb.cpu(), sb.cpu()) < 2e-5
     assert relerr(d1.cpu(), r1.cpu()) < 2e-5 and relerr(d2.cpu(), r2.cpu()) < 2e-5 and relerr((db + 1.0).cpu(), rb.cpu()) < 2e-5
     for half, got in ((slice(0, Bh), d1), (slice(Bh, B), d2)):
         wc = torch.zeros(Co, Ci, k, k, dtype=torch.double, requires_grad=True)
