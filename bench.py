@@ -443,6 +443,13 @@ def main(argv=None):
             gen.update(gextra)
         del gw
 
+    # the same iterations through the kept API (engine.train_MTD_GAN_Ours, reference engine.py:26-76): the timed step above is that
+    # loop's body, this is the loop itself.  (Before the CPU baseline: run after it -- 32 host threads that have just been busy --
+    # this leg sporadically read 1 ms per iteration slower than the timed step, 31.2 against 30.2-30.4.)
+    api_ms = None
+    if rank == 0 and world == 1 and hasattr(wl, "engine_api_ms") and not args.no_engine_api:
+        api_ms = wl.engine_api_ms(args.steps)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(wl)
@@ -456,10 +463,8 @@ def main(argv=None):
             line["config"]["parallelism"] += " (rehearsal: all ranks on ONE GPU, gloo through the host -- not a scaling figure)"
         line.update(wl.extra())
         line.update(extra)
-        if hasattr(wl, "engine_api_ms") and world == 1 and not args.no_engine_api:
-            # the same iterations through the kept API (engine.train_MTD_GAN_Ours, reference engine.py:26-76): the timed step above
-            # is that loop's body, this is the loop itself
-            ams = wl.engine_api_ms(args.steps)
+        if api_ms is not None:
+            ams = api_ms
             line["engine_api"] = {"ms_per_step": round(ams, 3), "value": round(per_gpu_units * 1e3 / ams, 2), "unit": "img/s",
                                   "what": "engine.train_MTD_GAN_Ours over the same resident batch, steps iterations, logging included"}
         if "algorithmic_gflop_per_patch" in line:          # whole-step rate against the same peak, from the timed region

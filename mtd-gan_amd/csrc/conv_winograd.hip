@@ -439,9 +439,10 @@ struct WinoPlan { int nb, lean, splitk, c_per_split; };
 WinoPlan wino_plan(const mtd_conv_args& a) {
     WinoPlan pl{};
     pl.nb = (a.N % 128 == 0) ? 4 : 2;
-    // few K steps (C <= 64: four): the narrow form, whose lean variant puts two workgroups on a CU -- a workgroup spends as long
-    // outside its K loop as inside (64 -> 128 / 256 channels: 123 -> 116 us, 226 -> 213 us; C = 128: no gain).  MTD_WINO_NB2_MAXC=0: off
-    static const int env_nb2_c = [] { const char* e = getenv("MTD_WINO_NB2_MAXC"); return e ? atoi(e) : 64; }();
+    // (lab, MTD_WINO_NB2_MAXC=64: the narrow form with its lean variant for layers with four K steps whatever their N -- 5 % less time
+    // for those launches (123 -> 116 us, 226 -> 213 us), 0.08 ms per step, but the input is then read per 64 instead of per 128 output
+    // channels: 62 -> 80 MB of fabric traffic per launch.  Off.)
+    static const int env_nb2_c = [] { const char* e = getenv("MTD_WINO_NB2_MAXC"); return e ? atoi(e) : 0; }();
     if (a.C <= env_nb2_c) pl.nb = 2;
     const long long tiles = geom_pixels(a.g) / 4;
     long long blocks = ((tiles + WT - 1) / WT) * (a.N / (32 * pl.nb));

@@ -622,7 +622,7 @@ WINO_CASES = [
     (6, 512, 512, 4, 4, "fwd"),        # the deep levels: four tiles per image, mostly padding; split-K
     (7, 512, 1024, 2, 2, "dgrad"),     # one tile per image
     (16, 64, 64, 64, 64, "dgrad"),     # 512 workgroups with four K steps: the lean form, two workgroups per CU
-    (16, 64, 256, 32, 32, "fwd"),      # C = 64 with wide N: the narrow (BN = 64) lean form instead of BN = 128
+    (16, 64, 256, 32, 32, "fwd"),      # C = 64 with wide N: four K steps under BN = 128 (MTD_WINO_NB2_MAXC=64: the narrow lean form)
 ]
 
 
