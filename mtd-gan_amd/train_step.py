@@ -66,7 +66,7 @@ class DStepTape:
         ts_sizes = [D.get_parameter(nme).numel() for nme in ts_names]
         # (each view starts on a 16-byte boundary: the spectral-norm correction then moves float4s)
         TSflat = torch.empty(max(sum((sz + 3) // 4 * 4 for sz in ts_sizes), 4), dtype=torch.float32, device=dev)
-        # ... and the same for the decoders' spectral-norm weights (97 % of the task-specific bucket): the SEG decoder's are first
+        # ... and the same for the decoders' spectral-norm weights (91 % of the task-specific bucket): the SEG decoder's are first
         # written by the pass over tape 3+4, the REC decoder's by the last pass over tape 1+2 (the others hand their decoder
         # cotangents over, see below)
         dec_first = {"s": frozenset(), "r": frozenset()}

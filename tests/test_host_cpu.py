@@ -131,3 +131,34 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
         assert vals[0] == ctypes.sizeof(cls), cname
         for f, off in zip(fields, vals[1:]):
             assert getattr(cls, inv.get(f, f)).offset == off, (cname, f)
+
+
+def test_gradient_buffer_name_rules_cover_the_discriminator():
+    """train_step's first-pass-overwrite and early-shipping rules select layers BY NAME: the trunk's spectral-norm weights
+    (overwritten by the first pass into a task vector), the decoders' (overwritten in the task-specific bucket), and the
+    contiguous tail of a task vector that trunk levels >= FLUSH_LEVEL + the bottleneck form.  Here against the module's own
+    parameter partition: every shared weight is covered, nothing else is, and the tail is what the rule says."""
+    from mtd_gan_amd import train_step as TS
+    from mtd_gan_amd import discriminator_path as DP
+    from mtd_gan_amd.arch.Ours.networks import Multi_Task_Discriminator_Skip
+    D = Multi_Task_Discriminator_Skip(1, 64)
+    by_id = {id(p): n for n, p in D.named_parameters()}
+    shared = [by_id[id(p)] for p in D.shared_parameters()]
+    tspec = [by_id[id(p)] for p in D.task_specific_parameters()]
+    assert "c_fc.weight_orig" not in shared + tspec                       # the reference's omission (frozen), kept
+    sh_w = [n for n in shared if n.endswith(".weight_orig")]
+    assert len(sh_w) == 20 and all(TS._TRUNK_SN_WEIGHT.match(n) for n in sh_w)
+    assert not any(TS._TRUNK_SN_WEIGHT.match(n) for n in shared if not n.endswith(".weight_orig"))
+    assert not any(TS._TRUNK_SN_WEIGHT.match(n) for n in tspec)
+    dec = {pre: [n for n in tspec if TS.re_dec[pre].match(n)] for pre in "sr"}
+    assert len(dec["s"]) == 12 and len(dec["r"]) == 12
+    covered = sum(D.get_parameter(n).numel() for n in dec["s"] + dec["r"])
+    assert covered > 0.9 * sum(D.get_parameter(n).numel() for n in tspec)        # (the rest: the 1x1 up-convs, heads, biases)
+    # every name the rules select is a spectral-norm layer the backward pass corrects (discriminator_path.SN_INDEX)
+    for n in sh_w + dec["s"] + dec["r"]:
+        assert n[:-len(".weight_orig")] in DP.SN_INDEX
+    sizes = [D.get_parameter(n).numel() for n in shared]
+    tail = TS.DStepTape._low_tail(shared, sizes)
+    assert tail is not None
+    first_low = next(i for i, n in enumerate(shared) if n.startswith(f"conv{DP.FLUSH_LEVEL}1"))
+    assert tail == sum(sizes[:first_low]) and (sum(sizes) - tail) / sum(sizes) > 0.9
