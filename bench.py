@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 PER_GPU_BATCH = 32
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA peak (dense)
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E
 WINOGRAD_EXECUTED = 4.0 / 9.0     # csrc/conv_winograd.hip: 16 multiplications per 2 x 2 output tile instead of 36
 
 
@@ -42,6 +43,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-generator", action="store_true", help="skip the configs[1] generator object of the default workload")
+    ap.add_argument("--no-inference", action="store_true", help="skip the configs[4] whole-slice inference object of the default workload")
     ap.add_argument("--no-engine-api", action="store_true", help="skip the engine.train_MTD_GAN_Ours leg (profiling runs: only the timed steps)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / collective plumbing only: gloo on the CPU, a trivial step (no GPU, no HIP library)")
@@ -153,9 +155,9 @@ def cpu_baseline(wl):
         dt = time.perf_counter() - t0
         return {"value": round(1.0 / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
                 "sample": f"oracle generator forward + pixel metrics on one 512x512 slice, torch CPU {torch.__version__}, {cores} threads"}
-    # full training iteration: oracle.train_step (engine.py:33-55 restated) on the workload's own batch of 32 patches,
-    # ONE iteration with no warm-up (about 20-30 s of CPU work)
-    nb, iters = PER_GPU_BATCH, 1
+    # full training iteration: oracle.train_step (engine.py:33-55 restated) on the workload's own batch of 32 patches:
+    # one warm-up iteration, then two timed ones (about 10 s each on this box's host cores)
+    nb, iters = PER_GPU_BATCH, 2
     x, y = orc.synthetic_ldct(nb, seed=1234)
     state = {"Generator." + k: v for k, v in orc.seeded_fill(orc.g_param_shapes(), seed=7).items()}
     state.update({"Discriminator." + k: v for k, v in orc.seeded_fill(orc.d_state_shapes(), seed=8).items()})
@@ -163,12 +165,16 @@ def cpu_baseline(wl):
     masks = [(torch.rand(nb, 512, generator=g) >= 0.3).float() / 0.7 for _ in range(5)]
     opt = {}
     orders = [[1, 2, 0], [0, 2, 1], [2, 0, 1]]
-    t0 = time.perf_counter()
+    orc.train_step(state, opt, x, y, masks, orders)
+    per_iter = []
     for _ in range(iters):
+        t0 = time.perf_counter()
         orc.train_step(state, opt, x, y, masks, orders)
-    dt = time.perf_counter() - t0
+        per_iter.append(time.perf_counter() - t0)
+    dt = sum(per_iter)
     return {"value": round(nb * iters / dt, 3), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": f"oracle full G+D+PCGrad+AdamW step, {iters} x {nb} patches (the workload's batch, no warm-up), torch CPU {torch.__version__}, {cores} threads"}
+            "seconds_per_iteration": [round(t, 2) for t in per_iter],
+            "sample": f"oracle full G+D+PCGrad+AdamW step, 1 warm-up + {iters} timed x {nb} patches (the workload's batch), torch CPU {torch.__version__}, {cores} threads"}
 
 
 # ====================================================================================================== PMC provenance
@@ -221,14 +227,33 @@ def pmc_summary(kernel, tag):
         return None, None, prov
 
     def lookup(fn, col):
+        """Launch-weighted mean of `col` over EVERY row of the table whose kernel is `kernel` -- one row when the name carries its
+        template arguments (one symbol), all instantiations of the family when it does not.  (Round 3 took the first matching
+        row, and the first row differed from table to table.)  Returns (mean, dispatches) or (None, 0)."""
         path = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(path):
-            return None
+            return None, 0
+        tot, n = 0.0, 0
         for row in csv.DictReader(open(path)):
             if _kernel_base(row["Kernel_Name"], "<" in kernel) == kernel:          # exact name, not a substring hit
-                return float(row[col])
-        return None
-    f, w, u = lookup(man["files"]["fetch"], "AvgPerDispatch"), lookup(man["files"]["write"], "AvgPerDispatch"), lookup(man["files"]["mfma"], "MfmaUtil")
+                d = int(float(row["Dispatches"]))
+                tot += float(row[col]) * d
+                n += d
+        return (tot / n, n) if n else (None, 0)
+    (f, nf), (w, nw) = lookup(man["files"]["fetch"], "AvgPerDispatch"), lookup(man["files"]["write"], "AvgPerDispatch")
+    # MFMA utilisation of the family = busy cycles summed over its rows (tools/pmc_mfma_util.py: MFMA_BUSY / (32 x SQ_BUSY))
+    mb = sb = 0.0
+    nu = 0
+    mpath2 = os.path.join(ROOT, "profiles", man["files"]["mfma"])
+    for row in (csv.DictReader(open(mpath2)) if os.path.exists(mpath2) else ()):
+        if _kernel_base(row["Kernel_Name"], "<" in kernel) == kernel:
+            mb += float(row["SQ_VALU_MFMA_BUSY_CYCLES"])
+            sb += float(row["SQ_BUSY_CYCLES"])
+            nu += int(float(row["Dispatches"]))
+    u = mb / (32.0 * sb) if sb else None
+    prov["dispatches"] = {"fetch": nf, "write": nw, "mfma": nu}
+    if u is not None:
+        u = round(u, 4)
     traffic = round(2.0 * f * 1024.0 + w * 1024.0) if (f is not None and w is not None) else None
     return traffic, u, prov
 
@@ -256,7 +281,7 @@ def roofline_pass(wl, steps, pmc_tag):
     K.set_concurrency(True)
     by = {}
     for r in recs:
-        if r["kernel"].startswith(("igemm", "c32_bwd", "wgrad", "wino")):       # every profiled MFMA launch (the library's launch profiler)
+        if r["kernel"].startswith(("igemm", "c32_bwd", "wgrad", "wino")) or r["kernel"] in K.SPECTRAL_KERNELS:       # every profiled launch (the library's launch profiler)
             d = by.setdefault(r["kernel"], {"ms": 0.0, "flops": 0.0, "exec": 0.0, "bytes": 0.0, "n": 0, "shapes": {}})
             d["ms"] += r["ms"]
             d["flops"] += r["flops"]
@@ -268,14 +293,28 @@ def roofline_pass(wl, steps, pmc_tag):
             sh = d["shapes"].setdefault(key, [0.0, 0.0, 0])
             sh[0] += r["ms"]; sh[1] += r["flops"]; sh[2] += 1
     units = getattr(wl, "batch", None) or getattr(wl, "slices", PER_GPU_BATCH)
-    executed = {k: round(v / steps / 1e9 / units, 4) for k, v in counted.items() if k not in ("launches", "conv_winograd_saved")}
+    executed = {k: round(v / steps / 1e9 / units, 4) for k, v in counted.items() if k not in ("launches", "conv_winograd_saved", "wgrad_winograd_saved")}
     executed_total = round(sum(executed.values()), 3)
     extra = {"executed_gflop_per_patch": executed_total, "executed_gflop_per_patch_by_kind": executed,
-             "winograd_saved_gflop_per_patch": round(counted.get("conv_winograd_saved", 0.0) / steps / 1e9 / units, 4),
+             "winograd_saved_gflop_per_patch": round((counted.get("conv_winograd_saved", 0.0) + counted.get("wgrad_winograd_saved", 0.0)) / steps / 1e9 / units, 4),
              "counted_launches_per_step": counted.get("launches", 0) // steps}
     if not by:
         return None, extra
     name, d = max(by.items(), key=lambda kv: kv[1]["ms"])
+    if name in K.SPECTRAL_KERNELS:
+        # HBM-bound kernel (the spectral path of whole-slice inference): algorithmic bytes of a launch -- every operand element
+        # read once, every result written once -- over its measured duration, against the 8 TB/s of MI355X_MICROARCH.md
+        gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        traffic, _util, prov = pmc_summary(name, pmc_tag) if pmc_tag is not None else (None, None, None)
+        roofline = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": round(d["bytes"] / d["n"]),
+                    "pmc_provenance": prov, "launches_timed": d["n"], "avg_launch_us": round(1e3 * d["ms"] / d["n"], 2),
+                    "timing": "HIP events on the kernel's dispatch packet" if attach == 1 else "HIP events recorded before / after the launch",
+                    "measured": "second pass of the same steps, all kernels in one stream", "share_of_step_gpu_ms": round(d["ms"] / steps, 3),
+                    "other_kernels": {k: ({"gb_per_s": round(v["bytes"] / v["ms"] / 1e6, 1)} if k in K.SPECTRAL_KERNELS else
+                                          {"tflops": round(v["exec"] / v["ms"] / 1e9, 2)}) | {"ms_per_step": round(v["ms"] / steps, 3)}
+                                      for k, v in by.items() if k != name}}
+        return roofline, extra
     # `achieved` is what the matrix cores do per second -- executed MFMA flops, the quantity the fp32-MFMA peak bounds.  For the
     # implicit-GEMM kernels that is the layer's algorithmic count 2 M N C taps; the Winograd kernel multiplies 4 / 9 of it, and
     # its rate in algorithmic (direct-convolution-equivalent) flops -- which may exceed the peak -- is `algorithmic_tflops`.
@@ -412,7 +451,7 @@ def main(argv=None):
     value = per_gpu_units * ranks_seen * args.steps / dt
 
     roofline, extra = None, {}
-    pmc_tag = {"full_step": "full_step", "generator_fwd_bwd": "generator"}.get(wl.name)
+    pmc_tag = {"full_step": "full_step", "generator_fwd_bwd": "generator", "inference512": "inference512"}.get(wl.name)
     if not args.no_roofline and wl.name in ("full_step", "generator_fwd_bwd", "inference512"):
         roofline, extra = roofline_pass(wl, args.steps, pmc_tag)
     if roofline is None and not args.no_roofline and hasattr(wl, "roofline_bytes_per_step"):
@@ -442,6 +481,24 @@ def main(argv=None):
             gen["roofline"] = groof
             gen.update(gextra)
         del gw
+
+    # ---- BASELINE configs[4] beside the headline workload: whole-slice generator inference, 8 x 512 x 512 (engine.py:89,129)
+    inf = None
+    if wl.name == "full_step" and not args.no_inference and world == 1:
+        iw = BW.make("inference512", dev, rank, world, PER_GPU_BATCH)
+        isteps, iwarm = min(args.steps, 20), min(args.warmup, 3)
+        idt = timed(iw, isteps, iwarm, barrier)
+        ims = 1e3 * idt / isteps
+        itf = iw.gflop_per_patch * iw.slices / (ims * 1e-3) / 1e3
+        inf = {"config": iw.config(ranks_seen), "value": round(iw.slices * isteps / idt, 2), "unit": "slice/s", "steps": isteps,
+               "warmup": iwarm, "ms_per_step": round(ims, 3), "algorithmic_gflop_per_slice": iw.gflop_per_patch,
+               "step_tflops_per_gpu": round(itf, 2), "step_frac_of_fp32_mfma_peak": round(itf / PEAK_F32_MFMA_TFLOPS, 4)}
+        if not args.no_roofline:
+            iroof, iextra = roofline_pass(iw, isteps, "inference512")
+            inf["roofline"] = iroof
+            inf.update(iextra)
+        inf["pixel_metrics_last_batch"] = iw.last
+        del iw
 
     # the same iterations through the kept API (engine.train_MTD_GAN_Ours, reference engine.py:26-76): the timed step above is that
     # loop's body, this is the loop itself.  (Before the CPU baseline: run after it -- 32 host threads that have just been busy --
@@ -477,6 +534,8 @@ def main(argv=None):
                 line["step_executed_frac_of_fp32_mfma_peak"] = round(tfe / PEAK_F32_MFMA_TFLOPS, 4)
         if gen is not None:
             line["generator_fwd_bwd"] = gen
+        if inf is not None:
+            line["inference512"] = inf
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -140,6 +140,10 @@ typedef struct {
 
 size_t mtd_conv_wgrad_ws_bytes(const mtd_wgrad_args* a);
 int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream);
+/* The kernel the plan picks for these arguments: index into the weight-gradient name table of the launch profiler
+ * (16 = wgrad_wino_kernel, Winograd F(2x2,3x3): 4/9 of the layer's multiplications), -1 = the vector-ALU kernels of
+ * mtd_conv_direct's domain, MTD_EINVAL = invalid arguments.  Nothing is launched.  (Host-side flop accounting of bench.py.) */
+int mtd_conv_wgrad_plan_cfg(const mtd_wgrad_args* a);
 
 /* The two image ranges [0, b_first), [b_first, B) of one batch, a weight gradient each (a->dw and dw2; both bias
  * gradients into a->db, the second accumulated) from ONE launch of the slab-producing kernel: the paired discriminator
@@ -389,7 +393,8 @@ int mtd_conv_c32_bwd_stamps(unsigned long long* host256);   /* lab (MTD_C32F_STA
 /* ---- launch profiler (bench.py's roofline leg) ---------------------------------------------------------------
  * When enabled, mtd_conv_igemm / mtd_conv_wgrad time their MAIN kernel (not the split-K / slab reductions that
  * follow it) with a pair of HIP events on the stream they were given (see mtd_prof_mode).  mtd_prof_collect synchronises those events
- * and returns one record per launch.  kernel: 0 = igemm_kernel, 1 = wgrad_kernel; cfg = tile configuration index
+ * and returns one record per launch.  kernel: 0 = igemm_kernel, 1 = wgrad_kernel, 2 = the HBM-bound spectral kernels of the
+ * whole-slice inference path (cfg 0 rfft_rows_any, 1 spec_mix_any, 2 irfft_rows_any: flops 0, bytes set); cfg = tile configuration index
  * (the template instantiation); flops = 2*M*N*C*taps (dense algorithmic count).
  * Not for use while a hipGraph is being captured. */
 /* Tuning hook (tools/tune_igemm.py): force the tile configuration (0..8, -1 = automatic) and the split-K factor of

@@ -104,7 +104,7 @@ def _preload_torch_hip_runtime():
 
 
 RECORDER = None      # kernels.LaunchList: while a step is being recorded, the list every launch is appended to
-_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "mtd_prof_", "_override", "_bwd_ok", "_stamps", "_zmask_bytes", "_tail_ok", "_winograd_ok", "_weight_floats", "_kmap")
+_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "mtd_prof_", "_override", "_bwd_ok", "_stamps", "_zmask_bytes", "_tail_ok", "_winograd_ok", "_weight_floats", "_kmap", "_plan_cfg", "_pair_ok", "_pair_mode")
 
 
 class _RecordingLib:
@@ -163,6 +163,7 @@ def lib():
     sig("mtd_conv_direct", ci, C.POINTER(ConvArgs), vp)
     sig("mtd_conv_wgrad_ws_bytes", sz, C.POINTER(WgradArgs))
     sig("mtd_conv_wgrad", ci, C.POINTER(WgradArgs), vp)
+    sig("mtd_conv_wgrad_plan_cfg", ci, C.POINTER(WgradArgs))
     sig("mtd_conv_wgrad_pair_ok", ci, C.POINTER(WgradArgs), ci)
     sig("mtd_conv_wgrad_pair_mode", ci, ci)
     sig("mtd_conv_wgrad_pair_ws_bytes", sz, C.POINTER(WgradArgs), ci)
@@ -257,6 +258,7 @@ EXPORTS = [
     "mtd_spec_mix_zmask_bytes", "mtd_spec_mix_fwd4", "mtd_spec_mix_bwd4",
     "mtd_resfft_block_tail_ok", "mtd_resfft_block_tail", "mtd_conv_c32_bwd_irfft",
     "mtd_winograd_weight_floats", "mtd_winograd_kmap", "mtd_winograd_weights", "mtd_conv_winograd_ok", "mtd_conv_winograd_ws_bytes", "mtd_conv_winograd",
+    "mtd_conv_wgrad_plan_cfg",
 ]
 
 

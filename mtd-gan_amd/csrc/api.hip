@@ -38,7 +38,7 @@ int mtd_prof_begin(int kernel, int cfg, int splitk, long long M, int N, int C, i
     ProfSlot sl;
     sl.rec.kernel = kernel; sl.rec.cfg = cfg; sl.rec.splitk = splitk;
     sl.rec.M = M; sl.rec.N = N; sl.rec.C = C; sl.rec.taps = taps;
-    sl.rec.flops = 2.0 * (double)M * N * C * taps;
+    sl.rec.flops = 2.0 * (double)M * N * C * taps;      // (0 for the byte-moving kernels of class 2: taps == 0)
     sl.rec.ms = 0.f;
     sl.rec.bytes = bytes;
     if (hipEventCreate(&sl.e0) != hipSuccess) return -1;

@@ -1691,7 +1691,11 @@ extern "C" int mtd_resfft_block_tail(const mtd_conv_args* a, const float* T, voi
     hipStream_t s = (hipStream_t)stream;
     const int ntiles = p.M / (C32T_R * C32T_W);
     const int prof = mtd_prof_begin(0, 12, 1, p.M, a->N, a->C, 9, s, algorithmic_bytes(a) + 4.0 * a->g.B * NKW * 4096);
-    static const int env_lab = [] { const char* e = getenv("MTD_TAIL_LAB"); return e ? atoi(e) : 0; }();      // lab: wrong results
+#ifdef MTD_LAB       // lab builds only (stage switches that produce WRONG results); never read from the environment by the shipped library
+    static const int env_lab = [] { const char* e = getenv("MTD_TAIL_LAB"); return e ? atoi(e) : 0; }();
+#else
+    const int env_lab = 0;
+#endif
     MTD_LAUNCH((igemm_c32t_kernel<C32T_R, true, true, true>), dim3(ntiles < 256 ? ntiles : 256, 1), dim3(512), 0, s, p, ntiles, env_lab, T);
     mtd_prof_end(prof, s);
     MTD_LAUNCH_CHECK();

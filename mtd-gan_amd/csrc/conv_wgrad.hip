@@ -1078,7 +1078,6 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(const mtd_wgra
 struct WPlan { int cfg, WN, WC, TG, ppw, nsplit, ntg, nw; };
 
 int g_wforce_cfg = -1, g_wforce_split = -1;     // tuning hook (mtd_conv_wgrad_override)
-int g_wplan_div = 1;                            // 2 while planning ONE of the two problems of a pair launch: half the workgroup targets
 int g_wforce_nw = 0;                            // waves per workgroup of the register-operand kernels (env MTD_WGRAD_NW, lab only)
 constexpr int NWCFG = 7;
 const int kWcfgWN[NWCFG] = {1, 1, 2, 1, 1, 1, 2};
@@ -1103,7 +1102,9 @@ int block_window_w(const mtd_wgrad_args& a) {
     return (g.OW == 8 || g.OW == 4 || g.OW == 2) ? g.OW : 0;
 }
 
-WPlan make_wplan(const mtd_wgrad_args& a) {
+// g_wplan_div: 2 while planning ONE of the two problems of a pair launch (half the workgroup targets); a parameter, not a
+// global, so that concurrent callers (main thread + autograd's backward thread, several devices) cannot see each other's value
+WPlan make_wplan(const mtd_wgrad_args& a, const int g_wplan_div = 1) {
     WPlan pl{};
     const int T = a.g.TH * a.g.TW;
     const long long M = geom_pixels(a.g);
@@ -1272,6 +1273,15 @@ extern "C" size_t mtd_conv_wgrad_ws_bytes(const mtd_wgrad_args* a) {
     return wgrad_ws_floats(*a, pl.nsplit) * sizeof(float);
 }
 
+// The plan's kernel for these arguments: index into the profiler's weight-gradient name table (16 = the Winograd kernel, which
+// executes 4/9 of the layer's multiplications), -1 for the direct (vector-ALU) kernels, MTD_EINVAL for invalid arguments.
+// Host-side flop accounting (kernels.wgrad) asks this instead of mirroring the plan.
+extern "C" int mtd_conv_wgrad_plan_cfg(const mtd_wgrad_args* a) {
+    if (!a || check_wargs(*a) != MTD_OK) return MTD_EINVAL;
+    if (is_direct(*a)) return -1;
+    return make_wplan(*a).cfg;
+}
+
 // plans whose kernels implement the pair form (pair_select): wgrad_kernel<> (0-6), the block-window kernels (10-12), the all-taps
 // kernel (13), the stride-2 halo-window kernel (15).  (16, the Winograd kernel, has its own: mtd_conv_wgrad_pair.)
 static bool wgrad_cfg_pairs(int cfg) { return (cfg >= 0 && cfg < NWCFG) || (cfg >= 10 && cfg <= 13) || cfg == 15; }
@@ -1294,9 +1304,7 @@ static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, 
     else if (!pair) { pl = make_wplan(*a); nsplit = pl.nsplit; }
     if (pair) {
         if (direct) return MTD_EINVAL;
-        g_wplan_div = 2;
-        pl = make_wplan(*a);
-        g_wplan_div = 1;
+        pl = make_wplan(*a, 2);
         if (!wgrad_cfg_pairs(pl.cfg)) return MTD_EINVAL;
         p.pair_ns = pl.nsplit;
         p.pair_p_off = geom_pixels(a->g) * a->p_ld;
@@ -1550,9 +1558,7 @@ extern "C" size_t mtd_conv_wgrad_pair_ws_bytes(const mtd_wgrad_args* a, int b_fi
     if (ns == 0) {
         mtd_wgrad_args h = *a;
         h.g.B = b_first;
-        g_wplan_div = 2;
-        ns = make_wplan(h).nsplit;
-        g_wplan_div = 1;
+        ns = make_wplan(h, 2).nsplit;
     }
     return wgrad_ws_floats(*a, 2 * ns) * sizeof(float);
 }

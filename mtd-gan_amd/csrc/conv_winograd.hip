@@ -566,7 +566,8 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
     }
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((wp.ntiles + WT - 1) / WT, a->N / (32 * pl.nb), pl.splitk);
-    const int prof = mtd_prof_begin(0, 14, pl.splitk, p.M, a->N, a->C, 9, s, algorithmic_bytes(a));
+    // (one profiler id per INSTANTIATION -- 14: <2, false>, 15: <4, false>, 22: <2, true> -- so that a record's name is one kernel symbol of a rocprofv3 table)
+    const int prof = mtd_prof_begin(0, pl.nb == 4 ? 15 : (pl.lean ? 22 : 14), pl.splitk, p.M, a->N, a->C, 9, s, algorithmic_bytes(a));
     if (pl.nb == 4) MTD_LAUNCH((wino_conv_kernel<4>), grid, dim3(512), 0, s, wp);
     else if (pl.lean) MTD_LAUNCH((wino_conv_kernel<2, true>), grid, dim3(512), 0, s, wp);
     else MTD_LAUNCH((wino_conv_kernel<2>), grid, dim3(512), 0, s, wp);

@@ -261,7 +261,10 @@ extern "C" int mtd_rfft_rows_any(const float* x, int x_ld, float* R, int B, int 
     const size_t lds = (size_t)S * 256 + (size_t)S * 4;
     int rc = set_lds(rfft_rows_any_kernel, lds);
     if (rc != MTD_OK) return rc;
-    hipLaunchKernelGGL(rfft_rows_any_kernel, dim3(B * S / 2), dim3(1024), lds, (hipStream_t)stream, x, x_ld, R, S, logS);
+    // (launch profiler, kernel class 2 = the HBM-bound spectral kernels: bytes = every operand element once, no flops)
+    const int prof = mtd_prof_begin(2, 0, 1, (long long)B * S * S, 32, 32, 0, (hipStream_t)stream, 4.0 * B * S * 32.0 * (S + 2.0 * (S / 2 + 1)));
+    MTD_LAUNCH(rfft_rows_any_kernel, dim3(B * S / 2), dim3(1024), lds, (hipStream_t)stream, x, x_ld, R, S, logS);
+    mtd_prof_end(prof, (hipStream_t)stream);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }
@@ -272,7 +275,9 @@ extern "C" int mtd_spec_mix_any(const float* R, const float* w2t, const float* b
     const size_t lds = (size_t)S * 256 + (size_t)S * 4;
     int rc = set_lds(spec_mix_any_kernel, lds);
     if (rc != MTD_OK) return rc;
-    hipLaunchKernelGGL(spec_mix_any_kernel, dim3(B * (S / 2 + 1)), dim3(1024), lds, (hipStream_t)stream, R, w2t, b2, T, S, logS);
+    const int prof = mtd_prof_begin(2, 1, 1, (long long)B * S * (S / 2 + 1), 64, 64, 0, (hipStream_t)stream, 2.0 * 4.0 * B * S * 64.0 * (S / 2 + 1));
+    MTD_LAUNCH(spec_mix_any_kernel, dim3(B * (S / 2 + 1)), dim3(1024), lds, (hipStream_t)stream, R, w2t, b2, T, S, logS);
+    mtd_prof_end(prof, (hipStream_t)stream);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }
@@ -285,8 +290,11 @@ extern "C" int mtd_irfft_rows_any(const float* T, float* out, int out_ld, const 
     const size_t lds = (size_t)S * 256 + (size_t)S * 4;
     int rc = set_lds(irfft_rows_any_kernel, lds);
     if (rc != MTD_OK) return rc;
-    hipLaunchKernelGGL(irfft_rows_any_kernel, dim3(B * S / 2), dim3(1024), lds, (hipStream_t)stream, T, out, out_ld, add1, add1_ld, add2,
-                       add2_ld, S, logS);
+    const int prof = mtd_prof_begin(2, 2, 1, (long long)B * S * S, 32, 32, 0, (hipStream_t)stream,
+                                    4.0 * B * S * 32.0 * (2.0 * (S / 2 + 1) + S * (1.0 + (add1 ? 1 : 0) + (add2 ? 1 : 0))));
+    MTD_LAUNCH(irfft_rows_any_kernel, dim3(B * S / 2), dim3(1024), lds, (hipStream_t)stream, T, out, out_ld, add1, add1_ld, add2,
+               add2_ld, S, logS);
+    mtd_prof_end(prof, (hipStream_t)stream);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }

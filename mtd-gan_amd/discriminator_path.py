@@ -128,13 +128,12 @@ class DiscRuntime:
     def __init__(self):
         self._gtemp = {}
 
-    def gtemp(self, name, device, which=0, chain=0):
-        """which: 0 / 1 = first / second pass of a paired tape (each pass has its own sigma, u, v); chain: backward passes
-        that run concurrently on different streams (train_step.DStepTape.run_pcgrad) each own a set."""
-        buf = self._gtemp.get((which, chain))
+    def gtemp(self, name, device, which=0):
+        """which: 0 / 1 = first / second pass of a paired tape (each pass has its own sigma, u, v)."""
+        buf = self._gtemp.get(which)
         if buf is None or buf.device != device:
             buf = torch.empty(SN_W_TOTAL, dtype=torch.float32, device=device)
-            self._gtemp[(which, chain)] = buf
+            self._gtemp[which] = buf
         i = SN_INDEX[name]
         return buf[SN_W_OFF[i]:SN_W_OFF[i] + SN_SPECS[i][1] * SN_SPECS[i][2]]
 
@@ -313,7 +312,7 @@ class GradSink:
 FLUSH_LEVEL = 4      # trunk levels 6 .. FLUSH_LEVEL + both bottleneck convs: 91 % of the shared parameters, done 60 % into the trunk
 
 
-def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0, dec_export=None, dec_import=None, flush=None,
+def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_export=None, dec_import=None, flush=None,
                   overwrite=frozenset()):
     """Replay one recorded pass.  g_enc (B,1,1,1) / g_dec (B,64,64,1) / g_rec (B,64,64,1): output
     cotangents (any may be None).  sink: GradSink or None.  All parameter gradients are ACCUMULATED.
@@ -331,7 +330,7 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0
     x = tp.x_in
     dev = x.device
     sn_touched = []
-    side = K.side_stream(dev, 10 + chain if chain else 0)   # weight gradients run beside the data-gradient chain (one side stream per chain)
+    side = K.side_stream(dev)   # weight gradients run beside the data-gradient chain
 
     def want(name):
         return sink is not None and sink.get(name) is not None
@@ -369,12 +368,12 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0
 
                 def both():         # (one launch for both halves where the library's plan allows it)
                     pe, pe2 = getattr(src, "parts", None) or (src(), None)
-                    K.wgrad_pair(pe, q, gfull, Bh, N, Cc, rt.gtemp(name, dev, 0, chain), rt.gtemp(name, dev, 1, chain), Cc * k * k, k * k,
+                    K.wgrad_pair(pe, q, gfull, Bh, N, Cc, rt.gtemp(name, dev, 0), rt.gtemp(name, dev, 1), Cc * k * k, k * k,
                                  db=sink.get(bn), accumulate_bias=True, p_add=pe2)
                 side.run(both, p, q)
             else:
                 geom = K.geom_fwd(B, hh, hh, kk, ss, pp)
-                side.run(lambda: K.wgrad(src(), q, geom, N, Cc, rt.gtemp(name, dev, 0, chain), Cc * k * k, k * k, db=sink.get(bn), accumulate=False,
+                side.run(lambda: K.wgrad(src(), q, geom, N, Cc, rt.gtemp(name, dev, 0), Cc * k * k, k * k, db=sink.get(bn), accumulate=False,
                                          accumulate_bias=True), p, q)
             sn_touched.append(name)
         elif want(bn):
@@ -396,7 +395,7 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0
         for name in sn_touched:
             i = SN_INDEX[name]
             s = _lib.SnGradLayer()
-            s.G = rt.gtemp(name, dev, 0, chain).data_ptr()
+            s.G = rt.gtemp(name, dev, 0).data_ptr()
             s.w = P[name + ".weight_orig"].data_ptr()
             s.u = tp.u_save.data_ptr() + 4 * SN_ROW_OFF[i]
             s.v = tp.v_save.data_ptr() + 4 * SN_COL_OFF[i]
@@ -404,7 +403,7 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, chain=0
             s.g_out = sink.get(name + ".weight_orig").data_ptr()
             s.rows, s.cols, s.accumulate = SN_SPECS[i][1], SN_SPECS[i][2], 0 if name in overwrite else 1
             if Bh:      # the second half's own sigma, u, v: corrected and added in the same launch, after the first
-                s.G2 = rt.gtemp(name, dev, 1, chain).data_ptr()
+                s.G2 = rt.gtemp(name, dev, 1).data_ptr()
                 s.u2 = tp.u_save2.data_ptr() + 4 * SN_ROW_OFF[i]
                 s.v2 = tp.v_save2.data_ptr() + 4 * SN_COL_OFF[i]
                 s.sigma2 = tp.sig2.data_ptr() + 8 * i

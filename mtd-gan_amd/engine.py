@@ -55,14 +55,15 @@ class _Meter:
 _gc_frozen = [False]
 
 
-def freeze_long_lived_objects():
-    """Once per process, before the first training iteration: collect, then move everything alive (modules, parameter tables,
-    cached descriptors, the interpreter's own ~1e6 objects) to the garbage collector's permanent generation.  A full
-    collection otherwise walks all of them every ~160 iterations -- 90-120 ms on the host (tools/hiccup_probe.py), three
-    iterations' worth of GPU work for which the host's 5 ms of lead per iteration cannot make up.  Nothing is leaked that
+def freeze_long_lived_objects(force=False):
+    """Collect, then move everything alive (modules, parameter tables, cached descriptors, the interpreter's own ~1e6 objects)
+    to the garbage collector's permanent generation.  A full collection otherwise walks all of them every ~160 eager
+    iterations -- 90-120 ms on the host (tools/hiccup_probe.py), three iterations' worth of GPU work.  Nothing is leaked that
     would have been freed: reference counting still frees frozen objects; only cycles among them are never looked for again.
-    MTD_GC_FREEZE=0 keeps the interpreter's default."""
-    if _gc_frozen[0] or os.environ.get("MTD_GC_FREEZE", "1") != "1":
+    This changes PROCESS-WIDE interpreter state, so a library entry point does it only when asked: `MTD_GC_FREEZE=1` in the
+    environment (train_MTD_GAN_Ours then calls it before its first iteration) or an explicit call with force=True (bench.py's
+    workloads do, and say so in their line).  Once per process."""
+    if _gc_frozen[0] or not (force or os.environ.get("MTD_GC_FREEZE", "0") == "1"):
         return
     import gc
     gc.collect()

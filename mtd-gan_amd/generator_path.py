@@ -70,7 +70,8 @@ def block_backward(g, saved, w_img, w_fft, grads, premask, defer=None, gm=None):
         if K.conv_wgrad_fusable(dg, wg):
             gR = K.rfft_rows(g, 1)                                                  # irfft2 backward
             gT = K.spec_mix_bwd(gR, w_fft, S, Z, grads["dw_fft"], grads["db_fft"], defer=defer)
-            assert K.conv_wgrad_fused(dg, wg, defer, spec=gT)
+            if not K.conv_wgrad_fused(dg, wg, defer, spec=gT):      # (a launch: never inside an assert, python -O strips those)
+                raise RuntimeError("block_backward: mtd_conv_c32_bwd_irfft refused a layer that mtd_conv_c32_bwd_ok accepted")
             return gx
     # the block conv's weight gradient and the row transform that opens the spectral backward chain read the same
     # cotangent: one launch when the slab sums are deferred (kernels.wgrad rows=...), at the head of the spectral stream

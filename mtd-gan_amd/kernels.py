@@ -185,6 +185,20 @@ FLOP_COUNT = None
 _FFT_HALF_PLANE = 2.5 * 4096 * 12 / 2
 
 
+WGRAD_CFG_WINO = 16      # mtd_conv_wgrad_plan_cfg: wgrad_wino_kernel
+
+
+def _count_wgrad(geom, N, Cc, winograd):
+    """Executed flops of one weight-gradient launch: 2 M N C taps on the matrix cores (or the vector ALU for the degenerate
+    channel counts); the Winograd kernel multiplies 16 instead of 36 times per 2 x 2 tile, the rest is `wgrad_winograd_saved`."""
+    full = 2.0 * geom.B * geom.OH * geom.OW * N * Cc * geom.TH * geom.TW
+    if winograd:
+        _count("wgrad_mfma", full * 4.0 / 9.0)
+        FLOP_COUNT["wgrad_winograd_saved"] = FLOP_COUNT.get("wgrad_winograd_saved", 0.0) + full * 5.0 / 9.0
+    else:
+        _count("wgrad_mfma" if (Cc % 32 == 0 and N % 32 == 0) else "wgrad_valu", full)
+
+
 def _count(kind, flops):
     if FLOP_COUNT is not None:
         FLOP_COUNT[kind] = FLOP_COUNT.get(kind, 0.0) + float(flops)
@@ -195,14 +209,18 @@ CALL_LOG = None     # tools/tune_igemm.py: a list collects ("igemm" | "wgrad", b
 IGEMM_CONFIGS = ["igemm_kernel<2, 1, 4, 1>", "igemm_kernel<1, 1, 4, 1>", "igemm_kernel<2, 2, 4, 1>",
                  "igemm_kernel<1, 1, 2, 2>", "igemm_kernel<2, 2, 2, 2>", "igemm_kernel<1, 1, 1, 4>",
                  "igemm_tb_kernel<1>", "igemm_tb_kernel<2>", "igemm_v2_kernel<0>", "igemm_c32p_kernel", "igemm_c32t_kernel", "c32_bwd_kernel",
-                 "igemm_c32t_kernel<4, true, true, true>", "c32_bwd_kernel<1, true>", "wino_conv_kernel", "?",      # 12: Res-FFT block tail; 13: c32_bwd + irfft; 14: Winograd
+                 "igemm_c32t_kernel<4, true, true, true>", "c32_bwd_kernel<1, true>", "wino_conv_kernel<2, false>", "wino_conv_kernel<4, false>",      # 12: Res-FFT block tail; 13: c32_bwd + irfft; 14, 15, 22: Winograd
                  "igemm_multi_kernel<2, 1, 4, 1>", "igemm_multi_kernel<1, 1, 4, 1>", "igemm_multi_kernel<2, 2, 4, 1>",      # 16 + cfg
-                 "igemm_multi_kernel<1, 1, 2, 2>", "igemm_multi_kernel<2, 2, 2, 2>", "igemm_multi_kernel<1, 1, 1, 4>"]
+                 "igemm_multi_kernel<1, 1, 2, 2>", "igemm_multi_kernel<2, 2, 2, 2>", "igemm_multi_kernel<1, 1, 1, 4>",
+                 "wino_conv_kernel<2, true>"]                                                                                 # 22
 WGRAD_CONFIGS = ["wgrad_kernel<1, 1, 9>", "wgrad_kernel<1, 1, 4>", "wgrad_kernel<2, 2, 1>", "wgrad_kernel<1, 1, 8>",
                  "wgrad_kernel<1, 1, 3>", "wgrad_kernel<1, 1, 1>", "wgrad_kernel<2, 2, 3>",
                  "wgrad_row_kernel<3, 3, 1>", "wgrad_row_kernel<3, 3, -1>", "wgrad_row_kernel<1, 1, 1>",
                  "wgrad_blk_kernel<8>", "wgrad_blk_kernel<4>", "wgrad_blk_kernel<2>", "wgrad_taps_kernel", "?", "wgrad_s2_kernel",
                  "wgrad_wino_kernel"]
+
+
+SPECTRAL_KERNELS = ["rfft_rows_any_kernel", "spec_mix_any_kernel", "irfft_rows_any_kernel"]      # profiler class 2 (HBM-bound)
 
 
 def prof_enable(capacity):
@@ -225,7 +243,7 @@ def prof_collect(capacity):
     n = L.mtd_prof_collect(C.cast(buf, C.c_void_p), capacity)
     out = []
     for r in buf[:min(n, capacity)]:
-        names = IGEMM_CONFIGS if r.kernel == 0 else WGRAD_CONFIGS
+        names = (IGEMM_CONFIGS, WGRAD_CONFIGS, SPECTRAL_KERNELS)[r.kernel] if 0 <= r.kernel <= 2 else []
         out.append({"kernel": names[r.cfg] if 0 <= r.cfg < len(names) else "?", "splitk": r.splitk, "M": r.M, "N": r.N,
                     "C": r.C, "taps": r.taps, "flops": r.flops, "ms": r.ms, "bytes": r.bytes})
     return out
@@ -509,8 +527,6 @@ def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumula
         wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=db, accumulate=accumulate, accumulate_bias=accumulate_bias, defer=defer)
         return rfft_rows(rows[0], rows[1])
     L = _lib.lib()
-    if FLOP_COUNT is not None:
-        _count("wgrad_mfma" if (Cc % 32 == 0 and N % 32 == 0) else "wgrad_valu", 2.0 * geom.B * geom.OH * geom.OW * N * Cc * geom.TH * geom.TW)
     a = WgradArgs()
     a.g = geom
     a.p, a.p_ld, a.N = p.data_ptr(), ld_of(p), N
@@ -521,6 +537,8 @@ def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumula
         accumulate_bias = accumulate
     a.accumulate = (1 if accumulate else 0) | (2 if accumulate_bias else 0)
     a.ws, a.ws_bytes = None, 0
+    if FLOP_COUNT is not None:
+        _count_wgrad(geom, N, Cc, L.mtd_conv_wgrad_plan_cfg(C.byref(a)) == WGRAD_CFG_WINO)
     need = L.mtd_conv_wgrad_ws_bytes(C.byref(a))
     if need == 0:
         raise RuntimeError(f"mtd_conv_wgrad: unsupported arguments N={N} C={Cc}")
@@ -581,7 +599,7 @@ def wgrad_pair(p, q, geom, b_first, N, Cc, dw1, dw2, w_sn, w_sc, db=None, accumu
         wgrad(p[b_first:], q[b_first:], gb, N, Cc, dw2, w_sn, w_sc, db=db, accumulate=False, accumulate_bias=True)
         return
     if FLOP_COUNT is not None:
-        _count("wgrad_mfma", 2.0 * geom.B * geom.OH * geom.OW * N * Cc * geom.TH * geom.TW)
+        _count_wgrad(geom, N, Cc, L.mtd_conv_wgrad_pair_ok(C.byref(a), b_first) == 2)      # (2: the Winograd kernel's pair form)
     ws = workspace(need, p.device)
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     check(L.mtd_conv_wgrad_pair_sum(C.byref(a), _ptr(p_add), dw2.data_ptr(), b_first, stream_ptr()), "mtd_conv_wgrad_pair_sum")
@@ -1113,13 +1131,12 @@ SIDE_STREAMS = os.environ.get("MTD_NO_SIDE_STREAMS", "0") != "1"
 
 
 def set_concurrency(on):
-    """Side streams and task chains on / off at run time (bench.py times single kernels with everything in one stream:
-    under concurrency a launch's duration includes the time it shares the chip with other kernels).  Synchronises."""
-    global SIDE_STREAMS, CHAINS
+    """Side streams on / off at run time (bench.py times single kernels with everything in one stream: under concurrency a
+    launch's duration includes the time it shares the chip with other kernels).  Synchronises."""
+    global SIDE_STREAMS
     torch.cuda.synchronize()
     on = bool(on) and os.environ.get("MTD_NO_SIDE_STREAMS", "0") != "1"
     SIDE_STREAMS = on
-    CHAINS = on and os.environ.get("MTD_CHAINS", "0") == "1"
     for s in _side.values():
         s.enabled = on
 
@@ -1229,27 +1246,6 @@ def side_stream(device, idx=0):
         s = SideStream(device)
         _side[key] = s
     return s
-
-
-_chain = {}
-
-
-def chain_stream(device, idx):
-    """Extra streams for independent kernel chains of one step (the three PCGrad task backward passes): each kernel
-    boundary in a stream drains the chip, so chains that do not depend on each other run side by side."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), idx)
-    s = _chain.get(key)
-    if s is None:
-        s = torch.cuda.Stream(device=device)
-        _chain[key] = s
-    return s
-
-
-# The three PCGrad task passes of the D step as concurrent chains (main + two chain streams): +2 % in rounds 1-2, when the small-map
-# launches of one chain filled the ramps and tails of another's.  With the Winograd kernels -- one workgroup per CU at 246 registers,
-# nothing co-resides -- the chains no longer overlap and their ~140 event records / waits per step only cost the host: 993 img/s with,
-# 1 006 without (round 3).  Off by default; MTD_CHAINS=1 switches them on.
-CHAINS = os.environ.get("MTD_CHAINS", "0") == "1" and os.environ.get("MTD_NO_SIDE_STREAMS", "0") != "1"
 
 
 def crosses_streams(*tensors):

@@ -57,8 +57,8 @@ class DStepTape:
         # The trunk's spectral-norm weights are 99.9 % of a task vector, and every backward pass writes all of them: the FIRST
         # pass into a vector overwrites (disc_backward(overwrite=...)) instead of adding to zeros -- no 343 MB fill per step and
         # no read of it by the correction kernel.  Only the rest (the biases, which the weight-gradient kernels accumulate)
-        # is zeroed.  (Task chains: passes into one vector may run in any order -- zero everything, accumulate everything.)
-        first_write = frozenset() if (K.CHAINS or not FIRST_WRITE) else frozenset(
+        # is zeroed.
+        first_write = frozenset() if not FIRST_WRITE else frozenset(
             nme[:-len(".weight_orig")] for nme in sh_names if _TRUNK_SN_WEIGHT.match(nme))
         if POISON:
             S[:3].fill_(float("nan"))          # (test hook: an element no pass writes stays NaN)
@@ -125,19 +125,7 @@ class DStepTape:
             T(0, rd, rrd, grad_out=g["c_rd"], coef=1.0 / n), T(0, rrd, rd, grad_out=g["c_rrd"], coef=1.0 / n),
             T(0, fe, rfe, grad_out=g["c_fe"], coef=1.0 / B), T(0, rfe, fe, grad_out=g["c_rfe"], coef=1.0 / B),
             T(0, fd, rfd, grad_out=g["c_fd"], coef=1.0 / n), T(0, rfd, fd, grad_out=g["c_rfd"], coef=1.0 / n)], dev)
-        # The consistency task touches the decoders of both other tasks, so its task-specific gradients go to a buffer of
-        # their own, added at the end (tasks 0 and 1 own disjoint decoders): the three task backward passes then share only
-        # read-only tapes and can run as concurrent chains.
-        # (Without chains the passes run one after the other on one stream pair and all add into the one buffer.)
-        if K.CHAINS:
-            TSc = torch.zeros_like(TSflat)
-            t2, tofs = dict(sinks[2].t), 0
-            for nme, sz in zip(ts_names, ts_sizes):
-                t2[nme] = TSc[tofs:tofs + sz].view_as(D.get_parameter(nme))
-                tofs += (sz + 3) // 4 * 4
-            sink_c = DP.GradSink(t2)
-        else:
-            TSc, sink_c = None, sinks[2]
+        sink_c = sinks[2]       # the passes run one after the other on one stream pair and all add into the one task-specific bucket
 
         # The decoders' gradients are sums over the tasks that reach them through passes 1+2 (SEG decoder: adversarial +
         # consistency, REC decoder: restoration + consistency) and a weight gradient is linear in its cotangent: the
@@ -145,17 +133,17 @@ class DStepTape:
         # that tape, computes every decoder weight gradient once from the sums -- two decoder weight-gradient sweeps less.
         exp_s, exp_r = {}, {}
 
-        def adversarial(chain):         # image-level + pixel-level heads on passes 1 and 2
-            DP.disc_backward(rt, P, t12, G2["d_e"], G2["d_d"], None, sinks[0], False, chain=chain, dec_export=exp_s, overwrite=first_write)
+        def adversarial():              # image-level + pixel-level heads on passes 1 and 2
+            DP.disc_backward(rt, P, t12, G2["d_e"], G2["d_d"], None, sinks[0], False, dec_export=exp_s, overwrite=first_write)
 
-        def restoration(chain):
-            DP.disc_backward(rt, P, t12, None, None, G2["r_r"], sinks[1], False, chain=chain, dec_export=exp_r, overwrite=first_write)
+        def restoration():
+            DP.disc_backward(rt, P, t12, None, None, G2["r_r"], sinks[1], False, dec_export=exp_r, overwrite=first_write)
 
-        def consistency34(chain):       # through D(rec.clip), passes 3 and 4 ...
-            return DP.disc_backward(rt, P, t34, G2["c3_e"], G2["c3_d"], None, sink_c, True, chain=chain, overwrite=first_write | dec_first["s"])
+        def consistency34():            # through D(rec.clip), passes 3 and 4 ...
+            return DP.disc_backward(rt, P, t34, G2["c3_e"], G2["c3_d"], None, sink_c, True, overwrite=first_write | dec_first["s"])
 
-        def consistency12(chain, gin34, flush=None):  # ... and back into the restoration decoder of passes 1 and 2
-            DP.disc_backward(rt, P, t12, G2["c_e"], G2["c_d"], K.clip01_bwd(gin34, r12), sink_c, False, chain=chain,
+        def consistency12(gin34, flush=None):         # ... and back into the restoration decoder of passes 1 and 2
+            DP.disc_backward(rt, P, t12, G2["c_e"], G2["c_d"], K.clip01_bwd(gin34, r12), sink_c, False,
                              dec_import={**exp_s, **exp_r}, flush=flush, overwrite=dec_first["r"])
 
         # Data parallelism: the LAST pass has no later backward to hide its collectives under, so it ships what is final while
@@ -167,73 +155,28 @@ class DStepTape:
         def ship(stage):
             side = K.side_stream(dev)          # the weight gradients and their spectral-norm corrections are on this stream
             if stage == "heads" and ts_names:
-                def ts():
-                    if TSc is not None:
-                        TSflat.add_(TSc)
-                    dp.all_reduce_avg(TSflat)
-                side.run(ts)
+                side.run(lambda: dp.all_reduce_avg(TSflat))
                 shipped["ts"] = True
             elif stage == "trunk_low" and tail_ofs is not None:
                 side.run(lambda: dp.all_reduce_avg(S[2, tail_ofs:]))
                 shipped["tail"] = True
 
-        if K.CHAINS and not torch.cuda.is_current_stream_capturing():
-            # main stream + two chain streams, each with its own side stream for weight gradients: every kernel boundary in
-            # a stream drains the chip, three independent chains fill each other's ramps and tails.  Longest chain first.
-            main = torch.cuda.current_stream()
-            start = torch.cuda.Event()
-            start.record(main)
-            st_c, st_r = K.chain_stream(dev, 2), K.chain_stream(dev, 1)
-            st_c.wait_event(start)
-            with torch.cuda.stream(st_c):
-                gin34 = consistency34(2)
-            st_r.wait_event(start)
-            with torch.cuda.stream(st_r):
-                restoration(1)
-                ev_r_cot = torch.cuda.Event()
-                ev_r_cot.record(st_r)                    # its decoder cotangents exist (data-gradient chain)
-                K.side_stream(dev, 11).join()
-                if dp is not None:
-                    dp.all_reduce_avg(S[1])
-                ev_r = torch.cuda.Event()
-                ev_r.record(st_r)
-            adversarial(0)
-            ev_d_cot = torch.cuda.Event()
-            ev_d_cot.record(main)
-            K.side_stream(dev).join()
+        adversarial()                                                                    # task 0
+        self._sync_task(dp, S, 0)
+        restoration()                                                                    # task 1
+        self._sync_task(dp, S, 1)
+        consistency12(consistency34(), ship if dp is not None and EARLY_SHIP else None)  # task 2
+        if shipped["tail"]:
             if dp is not None:
-                dp.all_reduce_avg(S[0])
-            with torch.cuda.stream(st_c):
-                st_c.wait_event(ev_r_cot)
-                st_c.wait_event(ev_d_cot)
-                consistency12(2, gin34)
-                K.side_stream(dev, 12).join()
-                if dp is not None:
-                    dp.all_reduce_avg(S[2])
-                ev_c = torch.cuda.Event()
-                ev_c.record(st_c)
-            main.wait_event(ev_r)
-            main.wait_event(ev_c)
+                K.side_stream(dev).join()
+                dp.all_reduce_avg(S[2, :tail_ofs])
         else:
-            adversarial(0)                                                                   # task 0
-            self._sync_task(dp, S, 0)
-            restoration(0)                                                                   # task 1
-            self._sync_task(dp, S, 1)
-            consistency12(0, consistency34(0), ship if dp is not None and EARLY_SHIP else None)   # task 2
-            if shipped["tail"]:
-                if dp is not None:
-                    K.side_stream(dev).join()
-                    dp.all_reduce_avg(S[2, :tail_ofs])
-            else:
-                self._sync_task(dp, S, 2)
-            K.side_stream(dev).join()          # weight gradients / spectral-norm corrections ran on the side stream
+            self._sync_task(dp, S, 2)
+        K.side_stream(dev).join()              # weight gradients / spectral-norm corrections ran on the side stream
         if dp is not None:
             dp.wait()                          # the three averaged task vectors are needed by the Gram kernel
-        if not shipped["ts"]:
-            if TSc is not None:
-                TSflat.add_(TSc)
-            if dp is not None and ts_names:
-                dp.all_reduce_avg(TSflat)      # 158 MB, in flight under the Gram / combine kernels; joined below
+        if not shipped["ts"] and dp is not None and ts_names:
+            dp.all_reduce_avg(TSflat)          # 158 MB, in flight under the Gram / combine kernels; joined below
         # ---- PCGrad: Gram of the original task gradients, replay of the projections, combine
         vecs = [S[0], S[1], S[2]]
         gram = K.pcgrad_gram(vecs)
@@ -557,7 +500,7 @@ class FullStepWorkload:
         if getattr(self, "_logged", None) is None:
             self._meters = {}
             self._logged = engine.LoggedScalars(self._meters, self.batch)
-            engine.freeze_long_lived_objects()        # as train_MTD_GAN_Ours does before its first iteration
+            engine.freeze_long_lived_objects(force=True)      # (process-wide gc.freeze(): opt-in for the API, MTD_GC_FREEZE=1)
         names, vals = engine.train_iteration(self.model, self.x, self.y, self.oG, self.oD, self.wm, self.dp)
         self._logged.push(names, vals, self.oG.param_groups[0]["lr"])
 

@@ -5,8 +5,8 @@
 
 A gpurun box has one MI355X and RCCL does not put two ranks on one device, so the two ranks share device 0 and talk over
 gloo (which moves device tensors through the host; parallel.DataParallelSync then sums and scales instead of ReduceOp.AVG).
-Everything else is the schedule an 8-GPU run executes: train_step.PCGradTape.run_pcgrad's three concurrent task chains, each
-enqueuing its all-reduce on the collective side stream, rank 0's projection order broadcast to every rank, the 158 MB
+Everything else is the schedule an 8-GPU run executes: train_step.DStepTape.run_pcgrad's three task passes one after the other,
+each task vector's all-reduce enqueued on the collective side stream under the next pass (the last pass ships its finished slices while it runs), rank 0's projection order broadcast to every rank, the 158 MB
 task-specific bucket under the Gram / combine kernels, the generator bucket.
 
 What is checked, per rank: ONE iteration of engine.train_MTD_GAN_Ours on this rank's 16 patches of the 32-patch batch of

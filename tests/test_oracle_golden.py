@@ -209,3 +209,42 @@ def test_ablation_family_matches_reference_vectors():
         for k, v in {**d_det, **g_det}.items():
             want = {**c["d_details"], **c["g_details"]}[k]
             assert abs(float(v) - want) <= 2e-5 * abs(want) + 1e-9, (name, k)
+
+
+def test_three_iterations_match_reference_vectors():
+    """tests/golden/step_seeded_x3.json (oracle/pin_three_iterations.py): the reference's engine.train_MTD_GAN_Ours on three
+    batches in a row -- AdamW at steps 1-3, u / v after 15 discriminator forwards.  The oracle restatement reproduces the 17
+    logged scalars of EVERY iteration and the sampled state after every iteration (an Adam update is ~ +-lr whatever the
+    gradient's size: updates within 0.05 lr, at most 1 % of the samples may miss -- elements whose gradient is rounding noise)."""
+    z = json.load(open(os.path.join(GOLD, "step_seeded_x3.json")))
+    full = {"Generator." + k: v for k, v in orc.seeded_fill(orc.g_param_shapes(), seed=z["gfill"]).items()}
+    full.update({"Discriminator." + k: v for k, v in orc.seeded_fill(orc.d_state_shapes(), seed=z["dfill"]).items()})
+    st = {k: v.clone() for k, v in full.items()}
+    g = torch.Generator().manual_seed(z["mask_seed"])
+    masks = [(torch.rand(z["batch"], 512, generator=g) >= 0.3).float() / 0.7 for _ in range(5 * z["iters"])]
+    random.seed(z["random_seed"])
+    opt = {}
+    for i in range(z["iters"]):
+        x, y = orc.synthetic_ldct(z["batch"], seed=z["data_seed"] + i)
+        orders = orc.shuffle_orders(3)
+        assert orders == z["orders"][i]
+        res = orc.train_step(st, opt, x, y, masks[5 * i:5 * i + 5], orders, lr=z["lr"])
+        got = {"d_loss": float(sum(res["d_losses"])), "g_loss": float(res["g_loss"])}
+        got.update({k: float(v) for k, v in res["d_details"].items()})
+        got.update({k: float(v) for k, v in res["g_details"].items()})
+        for k, v in got.items():
+            want = z["per_iter"][i][k]
+            assert abs(v - want) <= 1e-4 * abs(want) + 2e-7, (i, k, v, want)
+        bad, n = 0, 0
+        for k, samples in z["post_samples"][i].items():
+            t = st[k].detach().reshape(-1)
+            for j, sv in enumerate(samples):
+                idx = (j * 2654435761 + 12345) % t.numel()
+                tol = 1e-3 * max(abs(sv), 1e-3) if k.endswith(("weight_u", "weight_v")) else 0.05 * z["lr"] + 1e-9
+                bad += abs(t[idx].item() - sv) > tol
+                n += 1
+        assert bad <= 0.01 * n, (i, bad, n)
+    for k, v in z["loader_stats"].items():          # the three-batch loader's averages are the mean of the three iterations
+        if k != "lr":
+            mean = sum(s[k] for s in z["per_iter"]) / z["iters"]
+            assert abs(v - mean) <= 1e-6 * abs(mean) + 2e-7

@@ -522,6 +522,52 @@ def test_full_batch_step_runs_and_is_finite(hip_lib):
             assert abs(v.norm().item() - 1.0) < 1e-4, k
 
 
+@pytest.mark.parametrize("opt_kind", ["fused", "torch"])
+def test_three_iterations_vs_reference(hip_lib, opt_kind):
+    """Iterations 2 and 3 pinned to the reference (tests/golden/step_seeded_x3.json, oracle/pin_three_iterations.py: the
+    reference's engine.train_MTD_GAN_Ours on three batches in a row from the seeded fill).  What a one-iteration golden step
+    cannot see: AdamW's bias correction at steps 2 and 3, the spectral-norm vectors after 15 discriminator forwards, and the
+    derived weight views (packed, Winograd-transformed, transposed) that have to be rebuilt after every update -- with
+    FusedAdamW (raw-pointer updates, kernels.weights_changed) and with torch.optim.AdamW (in-place updates, version counters).
+    Per iteration: the 17 logged scalars at 1e-3; sampled post-iteration parameters (updates within 0.05 lr, <= 1 % of the
+    samples may miss, the rule of the one-step tests) and u / v at 1e-3."""
+    from mtd_gan_amd import engine
+    from mtd_gan_amd.arch.Ours.networks import MTD_GAN_Method
+    from mtd_gan_amd.module.weight_methods import WeightMethods
+    from mtd_gan_amd.optimizers import FusedAdamW
+    z = json.load(open(os.path.join(GOLD, "step_seeded_x3.json")))
+    full = {"Generator." + k: v for k, v in orc.seeded_fill(orc.g_param_shapes(), seed=z["gfill"]).items()}
+    full.update({"Discriminator." + k: v for k, v in orc.seeded_fill(orc.d_state_shapes(), seed=z["dfill"]).items()})
+    m = MTD_GAN_Method()
+    m.load_state_dict(full)
+    m.cuda().train()
+    g = torch.Generator().manual_seed(z["mask_seed"])
+    m.Discriminator._inject_masks = [(torch.rand(z["batch"], 512, generator=g) >= 0.3).float() / 0.7 for _ in range(5 * z["iters"])]
+    wm = WeightMethods("pcgrad", n_tasks=3, device=torch.device("cuda"))
+    kw = dict(lr=z["lr"], betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+    Opt = FusedAdamW if opt_kind == "fused" else torch.optim.AdamW
+    oD, oG = Opt(m.Discriminator.parameters(), **kw), Opt(m.Generator.parameters(), **kw)
+    random.seed(z["random_seed"])
+    for i in range(z["iters"]):
+        x, y = orc.synthetic_ldct(z["batch"], seed=z["data_seed"] + i)
+        stats = engine.train_MTD_GAN_Ours(m, [dict(n_20=x, n_100=y)], oG, oD, torch.device("cuda"), i, 0, z["batch"], wm)
+        for k, v in z["per_iter"][i].items():
+            assert abs(stats[k] - v) <= TOL * abs(v) + 2e-6, (opt_kind, i, k, stats[k], v)
+        post = m.state_dict()
+        bad, n = [], 0
+        for k, samples in z["post_samples"][i].items():
+            t = post[k].reshape(-1).cpu()
+            for j, sv in enumerate(samples):
+                idx = (j * 2654435761 + 12345) % t.numel()
+                tol = TOL * max(abs(sv), 1e-3) if k.endswith(("weight_u", "weight_v")) else 0.05 * z["lr"] + 1e-9
+                if abs(t[idx].item() - sv) > tol:
+                    bad.append((k, j, t[idx].item(), sv))
+                n += 1
+        assert len(bad) <= 0.01 * n, (opt_kind, i, len(bad), bad[:8])
+    assert torch.equal(m.state_dict()["Discriminator.c_fc.weight_orig"].cpu(), full["Discriminator.c_fc.weight_orig"])      # frozen (quirk 1)
+    assert not m.Discriminator._inject_masks                    # 15 masks, 15 discriminator forwards
+
+
 def test_graph_replay_equals_eager(hip_lib):
     """hipGraph capture/replay of the whole iteration (GraphedTrainStep) must reproduce eager execution:
     same kernels in the same order, host-side state (PCGrad order, AdamW step scalars) refreshed per replay."""
