@@ -253,6 +253,17 @@ int mtd_act_grad(const float* g, int g_ld, const float* y, int y_ld, float* out,
 /* out[i] = a[i] * b[i]  (Dropout mask at networks.py:417 and its gradient), n contiguous floats */
 int mtd_mul(const float* a, const float* b, float* out, long long n, void* stream);
 int mtd_add(const float* a, const float* b, float* out, long long n, void* stream);      /* out = a + b (sum of two tasks' cotangents before a shared weight gradient) */
+/* Round 4: the iteration's remaining bookkeeping as library launches, so that the whole step is a list of C-ABI calls
+ * (kernels.LaunchList records and replays it).  They replace torch ops of the host mirror, not reference call sites of their
+ * own: nn.Dropout's multiplier (networks.py:313 c_drop; the uniform draws stay torch's generator), the upstream scalar of
+ * g_loss.backward() (engine.py:52), the sums behind d_loss's stack (networks.py:1992) and the 17 logged values (engine.py:64-73),
+ * and the zero fill of the gradient buffers' non-overwritten entries. */
+int mtd_dropout_mask(const float* r, float p, float keep_scale, float* out, long long n, void* stream);   /* out = r >= p ? keep_scale : 0 */
+int mtd_scale_by(const float* a, const float* s, float* out, long long n, void* stream);                  /* out = a * s[0], s in device memory */
+typedef struct { const float* a; const float* b; int na, nb; } mtd_sum_desc;                              /* sum(a[0..na)) + sum(b[0..nb)) */
+int mtd_scalar_sums(const mtd_sum_desc* table_dev, int count, float* out, void* stream);
+typedef struct { float* p; long long n; } mtd_zero_desc;
+int mtd_zero_multi(const mtd_zero_desc* table_dev, const mtd_zero_desc* table_host, int count, void* stream);
 /* dst[0..bytes) = src_pinned[0..bytes): src is page-locked host memory mapped into the device address space
  * (hipHostMalloc / torch pin_memory), read by a kernel on `stream`; bytes % 16 == 0, both 16-byte aligned.
  * Used for the descriptor tables (mtd_*_layer / mtd_loss_term / mtd_adamw_tensor arrays). */

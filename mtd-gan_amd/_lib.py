@@ -87,6 +87,14 @@ class PatchDesc(C.Structure):
     _fields_ = [("slice", C.c_int), ("uy", C.c_float), ("ux", C.c_float), ("rot_k", C.c_int), ("flip", C.c_int), ("angle", C.c_float)]
 
 
+class SumDesc(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("na", C.c_int), ("nb", C.c_int)]
+
+
+class ZeroDesc(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("n", C.c_longlong)]
+
+
 class AdamwTensor(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_longlong)]
 
@@ -194,6 +202,10 @@ def lib():
     sig("mtd_pixel_shuffle2_bwd", ci, vp, ci, vp, ci, ci, ci, ci, ci, vp)
     sig("mtd_mul", ci, vp, vp, vp, ll, vp)
     sig("mtd_add", ci, vp, vp, vp, ll, vp)
+    sig("mtd_dropout_mask", ci, vp, cf, cf, vp, ll, vp)
+    sig("mtd_scale_by", ci, vp, vp, vp, ll, vp)
+    sig("mtd_scalar_sums", ci, vp, ci, vp, vp)
+    sig("mtd_zero_multi", ci, vp, vp, ci, vp)
     sig("mtd_pack_weights", ci, vp, vp, ci, vp)
     sig("mtd_upload", ci, vp, vp, sz, vp)
     sig("mtd_sn_ws_bytes", sz, vp, ci)
@@ -258,7 +270,7 @@ EXPORTS = [
     "mtd_spec_mix_zmask_bytes", "mtd_spec_mix_fwd4", "mtd_spec_mix_bwd4",
     "mtd_resfft_block_tail_ok", "mtd_resfft_block_tail", "mtd_conv_c32_bwd_irfft",
     "mtd_winograd_weight_floats", "mtd_winograd_kmap", "mtd_winograd_weights", "mtd_conv_winograd_ok", "mtd_conv_winograd_ws_bytes", "mtd_conv_winograd",
-    "mtd_conv_wgrad_plan_cfg",
+    "mtd_conv_wgrad_plan_cfg", "mtd_dropout_mask", "mtd_scale_by", "mtd_scalar_sums", "mtd_zero_multi",
 ]
 
 

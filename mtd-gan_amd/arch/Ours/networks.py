@@ -361,14 +361,23 @@ class Multi_Task_Discriminator_Skip(nn.Module):
         return P
 
     def _next_mask(self, B, device):
+        return self._next_masks(B, device, 1)
+
+    def _next_masks(self, B, device, count):
+        """The dropout multipliers (networks.py:313 c_drop, p = 0.3) of the next `count` forward passes of B images, stacked
+        along the batch: (count * B, 512), or None in eval mode / for p = 0.  The uniform draws are torch's generator (so
+        `torch.manual_seed` governs them as it governs nn.Dropout), one draw for all `count` passes; thresholding and the
+        1 / (1 - p) scale are a library launch (mtd_dropout_mask) -- both recordable by kernels.LaunchList."""
         if not self.training:
             return None
-        if self._inject_masks:
-            return self._inject_masks.pop(0).to(device)
+        if self._inject_masks:                              # tests: recorded masks of the reference, one per pass
+            return torch.cat([self._inject_masks.pop(0).to(device) for _ in range(count)], 0)
         p = self.c_drop.p
         if p == 0.0:
             return None
-        return (torch.rand(B, 512, device=device) >= p).to(torch.float32) / (1.0 - p)     # RNG draw only
+        r = torch.empty((count * B, 512), dtype=torch.float32, device=device)
+        K.rec(r.uniform_)                                   # RNG draw only
+        return K.dropout_mask(r, p, torch.empty_like(r))
 
     def forward(self, input, need_rec=True):
         _require_cuda(input, "Multi_Task_Discriminator_Skip")

@@ -337,6 +337,41 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const mtd_pack_desc* 
     }
 }
 
+// ---- the step's small bookkeeping ops as library launches (so that a recorded launch list holds the whole iteration) ----
+__global__ __launch_bounds__(256) void dropout_mask_kernel(const float* __restrict__ r, float p, float keep_scale, float* __restrict__ out,
+                                                           long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = r[i] >= p ? keep_scale : 0.f;
+}
+
+__global__ __launch_bounds__(256) void scale_by_kernel(const float* __restrict__ a, const float* __restrict__ s, float* __restrict__ out, long long n) {
+    const float f = s[0];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = a[i] * f;
+}
+
+// out[i] = sum(a[0 .. na)) + sum(b[0 .. nb)), left to right in fp32 (a handful of scalars: task losses, logged values)
+__global__ __launch_bounds__(64) void scalar_sums_kernel(const mtd_sum_desc* __restrict__ T, int count, float* __restrict__ out) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= count) return;
+    const mtd_sum_desc d = T[i];
+    float acc = 0.f;
+    for (int j = 0; j < d.na; ++j) acc += d.a[j];
+    for (int j = 0; j < d.nb; ++j) acc += d.b[j];
+    out[i] = acc;
+}
+
+// zero many small tensors in one launch: block b clears floats [256 b, 256 b + 256) of the concatenation
+__global__ __launch_bounds__(256) void zero_multi_kernel(const mtd_zero_desc* __restrict__ T, int count) {
+    long long first = (long long)blockIdx.x * 1024;
+    int t = 0;
+    long long base = 0;
+    while (t < count && first >= base + ((T[t].n + 1023) / 1024) * 1024) { base += ((T[t].n + 1023) / 1024) * 1024; ++t; }
+    if (t >= count) return;
+    const mtd_zero_desc d = T[t];
+    const long long local = first - base;
+    for (int i = threadIdx.x; i < 1024; i += 256)
+        if (local + i < d.n) d.p[local + i] = 0.f;
+}
+
 inline unsigned grid_for(long long n) {
     long long b = (n + 255) / 256;
     if (b > 4096) b = 4096;
@@ -364,6 +399,43 @@ extern "C" int mtd_act_grad(const float* g, int g_ld, const float* y, int y_ld, 
 extern "C" int mtd_mul(const float* a, const float* b, float* out, long long n, void* stream) {
     if (!a || !b || !out || n <= 0) return MTD_EINVAL;
     hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+// out[i] = r[i] >= p ? keep_scale : 0: the multiplier of nn.Dropout(p) (networks.py c_drop, train mode) from uniform draws r
+// (the draws stay torch's generator: `torch.manual_seed` governs them as in the reference); keep_scale = 1 / (1 - p).
+extern "C" int mtd_dropout_mask(const float* r, float p, float keep_scale, float* out, long long n, void* stream) {
+    if (!r || !out || n <= 0 || !(p >= 0.f && p < 1.f)) return MTD_EINVAL;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, r, p, keep_scale, out, n);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+// out = a * s[0] (s: one float in device memory): the upstream scalar of g_loss.backward() applied to the cotangent
+extern "C" int mtd_scale_by(const float* a, const float* s, float* out, long long n, void* stream) {
+    if (!a || !s || !out || n <= 0) return MTD_EINVAL;
+    hipLaunchKernelGGL(scale_by_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, s, out, n);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_scalar_sums(const mtd_sum_desc* table_dev, int count, float* out, void* stream) {
+    if (!table_dev || !out || count <= 0) return MTD_EINVAL;
+    hipLaunchKernelGGL(scalar_sums_kernel, dim3((count + 63) / 64), dim3(64), 0, (hipStream_t)stream, table_dev, count, out);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_zero_multi(const mtd_zero_desc* table_dev, const mtd_zero_desc* table_host, int count, void* stream) {
+    if (!table_dev || !table_host || count <= 0) return MTD_EINVAL;
+    long long blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!table_host[i].p || table_host[i].n <= 0) return MTD_EINVAL;
+        blocks += (table_host[i].n + 1023) / 1024;
+    }
+    if (blocks >= (1ll << 31)) return MTD_EINVAL;
+    hipLaunchKernelGGL(zero_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, table_dev, count);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }

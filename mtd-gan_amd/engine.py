@@ -31,12 +31,30 @@ def train_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp=None):
     g_loss, g_details = model.g_loss(x, y)
     g_loss.backward()
     if dp is not None:
-        dp.all_reduce_avg_list([p.grad for p in G.parameters()])
+        _all_reduce_generator_grads(model, G, dp)
     optimizer_G.step()
     names = ["d_loss"] + list(d_details.keys()) + ["g_loss"] + list(g_details.keys())
-    vals = torch.stack([d_losses.detach().sum()] + [v.detach().reshape(()) for v in d_details.values()] + [g_loss.detach().reshape(())]
-                       + [v.detach().reshape(()) for v in g_details.values()])
+    if d_losses.is_cuda:
+        from . import kernels as K
+        one = lambda t: (t.detach().reshape(-1).float().contiguous(), None)
+        vals = K.scalar_sums([one(d_losses)] + [one(v) for v in d_details.values()] + [one(g_loss)] + [one(v) for v in g_details.values()],
+                             d_losses.device)     # the 17 logged values in one launch (d_loss = the sum of the stacked task losses)
+    else:       # (host tensors: the loop's own CPU tests drive it with stand-in models; the networks themselves refuse CPU tensors)
+        vals = torch.stack([d_losses.detach().sum()] + [v.detach().reshape(()) for v in d_details.values()] + [g_loss.detach().reshape(())]
+                           + [v.detach().reshape(()) for v in g_details.values()])
     return names, vals
+
+
+def _all_reduce_generator_grads(model, G, dp):
+    """The generator's gradients across ranks: one in-place collective on the flat buffer they are views of
+    (train_step._GStepFn.backward), on the RCCL side stream; the generic bucket-and-scatter route for anything else."""
+    flat = getattr(model, "_ggrad_flat", None)
+    grads = [p.grad for p in G.parameters()]
+    if flat is not None and all(g is not None and g.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for g in grads):
+        dp.all_reduce_avg(flat)
+        dp.wait()
+    else:
+        dp.all_reduce_avg_list(grads)
 
 
 class _Meter:
@@ -127,10 +145,13 @@ def train_MTD_GAN_Ours(model, data_loader, optimizer_G, optimizer_D, device, epo
     n_it = len(data_loader)
     freeze_long_lived_objects()
     logged = LoggedScalars(meters, batch_size)
+    from .train_step import recorded_iteration
     for it, batch_data in enumerate(data_loader):
         x = batch_data["n_20"].to(device).float()
         y = batch_data["n_100"].to(device).float()
-        names, vals = train_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp)
+        # (a recorded launch list replays the iteration from its third occurrence on where that applies -- train_step.
+        # RecordedTrainStep: same launches, none of the Python around them; MTD_LIST=0 keeps every iteration eager)
+        names, vals = recorded_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp)
         logged.push(names, vals, optimizer_G.param_groups[0]["lr"])
         if print_freq and (it % print_freq == 0 or it == n_it - 1):
             logged.drain()                            # a printed line shows this iteration, as the reference's does

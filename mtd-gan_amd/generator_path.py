@@ -113,8 +113,9 @@ class GenParams:
         self.enc_w, self.enc_b, self.dec_w, self.dec_b, self.blk = enc_w, enc_b, dec_w, dec_b, blk   # blk[i] = (w_img,b_img,w_fft,b_fft)
 
 
-def generator_forward(x, P, save):
-    """x: (B,64,64,1) NHWC.  Returns (out (B,64,64,1), tape)."""
+def generator_forward(x, P, save, out=None):
+    """x: (B,64,64,1) NHWC.  Returns (out (B,64,64,1), tape).  out: optional destination of the result (train_step.d_loss
+    hands in the second half of the discriminator's paired input batch: no concatenation pass)."""
     B, H, W, _ = x.shape
     L = len(P.enc_w) - 1                                   # 10
     views = []
@@ -158,7 +159,8 @@ def generator_forward(x, P, save):
             tape["d"].append(d)
             tape["blk"].append(sv)
         cur = u
-    out = K.empty_nhwc(B, H, W, 1, x)
+    if out is None:
+        out = K.empty_nhwc(B, H, W, 1, x)
     K.conv(cur, P.dec_w[0], gt, 1, CH, 9, 9, out, bias=P.dec_b[0], add1=x, act=ACT_RELU)
     if save:
         tape["u"].append(cur)

@@ -17,6 +17,20 @@ _latest = {}        # (cache id, identity of a derived view without its version)
 _pack_epoch = 0
 
 
+_view_bufs = {}     # identity of a derived weight view -> its buffer.  A view is REWRITTEN IN PLACE when its weights change
+# (same address for the life of the process), so a recorded launch list -- whose launches carry addresses -- can pack in one
+# iteration what the next iteration's first launches read, exactly like consecutive eager iterations share their views.  Safe
+# in stream order: views are packed on the main stream, after the joins that precede an optimizer step.
+
+
+def _view_buffer(ident, shape, device):
+    buf = _view_bufs.get(ident)
+    if buf is None or buf.device != device or tuple(buf.shape) != tuple(shape):
+        buf = torch.empty(shape, dtype=torch.float32, device=device)
+        _view_bufs[ident] = buf
+    return buf
+
+
 def _remember(cache, ident, key, value):
     """cache[key] = value, dropping the entry of an older version of the same view (an optimizer that updates in place,
     e.g. torch.optim.AdamW, bumps the version counter on every step; without this the old generations would pile up)."""
@@ -58,7 +72,7 @@ def prepack(views):
         if key in _pack_cache:
             continue
         T = w.numel() // (N * Cc)
-        dst = torch.empty((T, N, Cc), dtype=torch.float32, device=w.device)
+        dst = _view_buffer((w.data_ptr(), N, Cc, w_sn, w_sc), (T, N, Cc), w.device)
         d = _lib.PackDesc()
         d.src, d.dst, d.N, d.C, d.T, d.sn, d.sc = w.data_ptr(), dst.data_ptr(), N, Cc, T, w_sn, w_sc
         todo.append(d)
@@ -75,7 +89,7 @@ def packed_weight_view(w, N, Cc, w_sn, w_sc):
     key = (w.data_ptr(), w._version, _pack_epoch, N, Cc, w_sn, w_sc)
     hit = _pack_cache.get(key)
     if hit is None:
-        dst = torch.empty((T, N, Cc), dtype=torch.float32, device=w.device)
+        dst = _view_buffer((w.data_ptr(), N, Cc, w_sn, w_sc), (T, N, Cc), w.device)
         d = _lib.PackDesc()
         d.src, d.dst, d.N, d.C, d.T, d.sn, d.sc = w.data_ptr(), dst.data_ptr(), N, Cc, T, w_sn, w_sc
         tab, host = device_table([d], w.device)
@@ -121,7 +135,7 @@ def winograd_takes(geom, N, Cc, kw):
 
 
 def _wino_desc(w, N, Cc, w_sn, w_sc, kmap, device):
-    dst = torch.empty(16 * N * Cc, dtype=torch.float32, device=device)
+    dst = _view_buffer((w.data_ptr(), N, Cc, w_sn, w_sc, "wino", kmap), (16 * N * Cc,), device)
     d = _lib.WinoWeightDesc()
     d.src, d.dst, d.sn, d.sc, d.st, d.N, d.C = w.data_ptr(), dst.data_ptr(), w_sn, w_sc, 1, N, Cc
     for i, k in enumerate(kmap):
@@ -171,7 +185,9 @@ def regrouped_bias(b, groups):
     key = (b.data_ptr(), b._version, _pack_epoch, "bias groups", groups)
     hit = _pack_cache.get(key)
     if hit is None:
-        hit = (b.detach().view(-1, groups).t().contiguous().view(-1), b)
+        dst = _view_buffer((b.data_ptr(), "bias groups", groups), (b.numel(),), b.device)
+        rec(dst.view(groups, -1).copy_, b.detach().view(-1, groups).t())
+        hit = (dst, b)
         _remember(_pack_cache, (b.data_ptr(), "bias groups", groups), key, hit)
     return hit[0]
 
@@ -788,7 +804,7 @@ def transpose64_all(weights):
         key = (w.data_ptr(), w._version, _pack_epoch)
         hit = _t64_cache.get(key)
         if hit is None:
-            dst = torch.empty((64, 64), dtype=torch.float32, device=w.device)
+            dst = _view_buffer((w.data_ptr(), "t64"), (64, 64), w.device)
             d = _lib.PtrPair()
             d.src, d.dst = w.data_ptr(), dst.data_ptr()
             todo.append(d)
@@ -875,6 +891,48 @@ def add(a, b):
     return out
 
 
+def dropout_mask(r, p, out):
+    """out = (r >= p) / (1 - p): nn.Dropout(p)'s multiplier from uniform draws r (mtd_dropout_mask)."""
+    check(_lib.lib().mtd_dropout_mask(r.data_ptr(), float(p), 1.0 / (1.0 - float(p)), out.data_ptr(), r.numel(), stream_ptr()), "mtd_dropout_mask")
+    return out
+
+
+def scale_by(a, s, out=None):
+    """out = a * s[0] (s: a one-element device tensor)."""
+    if out is None:
+        out = torch.empty_like(a)
+    check(_lib.lib().mtd_scale_by(a.data_ptr(), s.data_ptr(), out.data_ptr(), a.numel(), stream_ptr()), "mtd_scale_by")
+    return out
+
+
+def scalar_sums(parts, device):
+    """parts: list of (a, b) -- b may be None -- of small contiguous fp32 tensors; returns the vector of sum(a) + sum(b)
+    (one launch: the stacked task losses, the logged values of an iteration)."""
+    structs = []
+    for a, b in parts:
+        d = _lib.SumDesc()
+        d.a, d.na = a.data_ptr(), a.numel()
+        d.b, d.nb = (b.data_ptr(), b.numel()) if b is not None else (None, 0)
+        structs.append(d)
+    tab, _host = device_table(structs, device)
+    out = torch.empty(len(parts), dtype=torch.float32, device=device)
+    check(_lib.lib().mtd_scalar_sums(tab.data_ptr(), len(parts), out.data_ptr(), stream_ptr()), "mtd_scalar_sums")
+    return out
+
+
+def zero_multi(tensors):
+    """Zero many (small) contiguous fp32 tensors in one launch."""
+    structs = []
+    for t in tensors:
+        if not t.is_contiguous():
+            raise ValueError("zero_multi: contiguous tensors only")
+        d = _lib.ZeroDesc()
+        d.p, d.n = t.data_ptr(), t.numel()
+        structs.append(d)
+    tab, host = device_table(structs, tensors[0].device)
+    check(_lib.lib().mtd_zero_multi(tab.data_ptr(), C.cast(host, C.c_void_p), len(structs), stream_ptr()), "mtd_zero_multi")
+
+
 # ---------------------------------------------------------------------------------------------- descriptor tables
 _desc_cache = {}
 
@@ -895,10 +953,18 @@ class _Arena:
         n = (nbytes + 255) & ~255
         if self.ofs + n > self.host.numel():
             if not self.recycle:
-                raise RuntimeError("descriptor arena of the captured graph exhausted")
-            torch.cuda.synchronize()                 # every kernel that reads an old table has finished
-            _desc_cache.clear()
-            self.ofs = 0
+                # tables of captured graphs / recorded lists are never recycled: start a new chunk (the old one stays alive
+                # through the views its tables are, which the graphs' / lists' owners hold).  Not while a capture is running.
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("descriptor arena of the captured graph exhausted")
+                size = max(self.host.numel(), 2 * n)
+                self.host = torch.empty(size, dtype=torch.uint8).pin_memory()
+                self.dev = torch.empty(size, dtype=torch.uint8, device=self.dev.device)
+                self.ofs = 0
+            else:
+                torch.cuda.synchronize()             # every kernel that reads an old table has finished
+                _desc_cache.clear()
+                self.ofs = 0
         o = self.ofs
         self.ofs += n
         return self.host[o:o + n], self.dev[o:o + n]
@@ -984,6 +1050,19 @@ class HostScalars:
     def device_ptr(self):
         """Pointer a kernel may dereference (pinned memory is mapped into the device address space)."""
         STATS["zero_copy_reads"] += 1
+        if RECORDING is not None and all(self is not sl for sl in RECORDING.slots):
+            RECORDING.slots.append(self)             # a recorded launch reads this slot: LaunchList patches its address per replay
+        return self.slots[self.cur].data_ptr()
+
+    def next_for_replay(self, values):
+        """A launch-list replay: move to the next slot of the ring (waiting, if it is still pending, for the launch that read
+        it RING replays ago), write the values, return the address the recorded launch must be given this time."""
+        self.cur = (self.cur + 1) % self.RING
+        ev = self.events[self.cur]
+        if ev is not None:
+            ev.synchronize()
+            self.events[self.cur] = None
+        self.set_inplace(values)
         return self.slots[self.cur].data_ptr()
 
     def consumed(self):
@@ -1151,6 +1230,29 @@ def _order(later, earlier):
         RECORDING.ops.append((later.wait_event, (ev,)))
 
 
+order_streams = _order
+
+
+def rec(fn, *args):
+    """A torch operation inside a recordable step (the few that are not library launches: the uniform draws of the dropout
+    masks, RCCL collectives, a test hook's fill): runs now and, when a LaunchList is being recorded, on every replay.  It has
+    to write into tensors that exist already (in place / out=) and read only tensors that live as long as the list."""
+    fn(*args)
+    if RECORDING is not None:
+        RECORDING.add_call(fn, args)
+
+
+class _OnStream:
+    """A recorded torch operation that ran on a stream other than the list's main stream: re-issued under that stream."""
+
+    def __init__(self, stream, fn):
+        self.stream, self.fn = stream, fn
+
+    def __call__(self, *args):
+        with torch.cuda.stream(self.stream):
+            self.fn(*args)
+
+
 class LaunchList:
     """One step of a static-shape schedule as a flat list of (C entry point, arguments) and stream-order operations,
     recorded while the step runs eagerly and re-issued by replay() with none of the Python around the calls (tensor
@@ -1164,14 +1266,26 @@ class LaunchList:
 
     def __init__(self):
         self.ops, self.keep = [], []
+        self.main = None        # the stream that was current while recording: replay() must run under it
+        self.slots = []         # HostScalars that recorded launches read (the PCGrad order, AdamW's step scalars)
+        self.sites = {}         # id(slot) -> [(op index, argument index)] of the launches that take its address
 
-    def record(self, fn, device):
+    def add_call(self, fn, args):
+        cur = torch.cuda.current_stream()
+        self.ops.append((fn if cur == self.main else _OnStream(cur, fn), args))
+
+    def record(self, fn, device, repack=True):
+        """repack: drop every derived weight view first, so that the list packs the views it reads (a list that is replayed
+        while something ELSE updates the weights).  A list that contains the optimizer steps itself (train_step.
+        RecordedTrainStep) keeps the views: its own pack launches rewrite them in place (_view_buffer)."""
         global RECORDING, CAPTURE_TAG
         if RECORDING is not None or torch.cuda.is_current_stream_capturing():
             raise RuntimeError("LaunchList.record: a recording or a hipGraph capture is already in progress")
         prepare_capture(device)
-        weights_changed()                 # packed / transposed weight views are produced inside the list
+        if repack:
+            weights_changed()             # packed / transposed weight views are produced inside the list
         torch.cuda.synchronize()
+        self.main = torch.cuda.current_stream()
         real_empty, real_empty_like = torch.empty, torch.empty_like
 
         # (the storages are kept, not the tensors: autograd takes a gradient tensor over as .grad without a copy only
@@ -1196,13 +1310,47 @@ class LaunchList:
             _lib.RECORDER = None
             RECORDING = None
         torch.cuda.synchronize()
+        self._find_slot_sites()
         return out
 
+    def _find_slot_sites(self):
+        """Which recorded launches take the address of a HostScalars slot (as a c_void_p or an integer argument)?"""
+        self.sites = {}
+        for sl in self.slots:
+            ptr = sl.slots[sl.cur].data_ptr()
+            found = []
+            for i, (_f, args) in enumerate(self.ops):
+                for j, a in enumerate(args):
+                    if a.__class__ is C.c_void_p:
+                        a = a.value
+                    if a.__class__ is int and a == ptr:
+                        found.append((i, j))
+            if not found:
+                raise RuntimeError("LaunchList: a pinned scalar slot was read while recording but no recorded launch takes its address")
+            self.sites[id(sl)] = found
+
+    def set_slot(self, slot, values):
+        """Before a replay: new contents for a pinned slot that recorded launches read.  The slot's ring advances (the launch
+        of an earlier replay may not have run yet) and the recorded launches are re-pointed."""
+        ptr = slot.next_for_replay(values)
+        for i, j in self.sites[id(slot)]:
+            f, args = self.ops[i]
+            args = list(args)
+            args[j] = C.c_void_p(ptr) if args[j].__class__ is C.c_void_p else ptr
+            self.ops[i] = (f, tuple(args))
+
     def replay(self):
+        if torch.cuda.current_stream() != self.main:
+            raise RuntimeError("LaunchList.replay: the current stream is not the one the list was recorded under")
         for f, args in self.ops:
             rc = f(*args)
-            if rc:
+            if rc.__class__ is int and rc:
                 raise RuntimeError(f"LaunchList.replay: {getattr(f, '__name__', f)} failed with code {rc}")
+        if self.slots:
+            ev = torch.cuda.Event()
+            ev.record()                   # every reader of the pinned slots has been enqueued before this point
+            for sl in self.slots:
+                sl.events[sl.cur] = ev
 
 
 class SideStream:

@@ -47,9 +47,11 @@ class FusedAdamW(torch.optim.Optimizer):
         bc2 = 1.0 - b2 ** step
         return (1.0 - group["lr"] * group["weight_decay"], group["lr"] / bc1, 1.0 / math.sqrt(bc2))
 
-    def advance_for_replay(self):
-        """Host-side bookkeeping of one replayed (hipGraph) step: bump the step counters of the parameters the
-        captured step updated and refresh the scalars its kernels read from device memory."""
+    def advance_for_replay(self, set_slot=None):
+        """Host-side bookkeeping of one replayed step: bump the step counters of the parameters the captured / recorded step
+        updated and refresh the scalars its kernels read from pinned memory.  A hipGraph replay rewrites the one slot the
+        graph is pinned to (its owner waits for the previous replay first); a launch-list replay passes
+        set_slot = LaunchList.set_slot, which moves on in the slot's ring and re-points the recorded launch."""
         for (slot, gi, members) in self._captured:
             group = self.param_groups[gi]
             step = 0
@@ -57,7 +59,10 @@ class FusedAdamW(torch.optim.Optimizer):
                 st = self.state[p]
                 st["step"] += 1
                 step = st["step"]
-            slot.set_inplace(self._scalars(group, step))
+            if set_slot is not None:
+                set_slot(slot, self._scalars(group, step))
+            else:
+                slot.set_inplace(self._scalars(group, step))
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -23,7 +23,7 @@ class DataParallelSync:
         # tests/dp_two_ranks_one_gpu.py, where RCCL cannot put two ranks on one device -- only sums: scale afterwards
         self.has_avg = dist.get_backend() == "nccl"
         self.side = torch.cuda.Stream(device=device) if self.cuda else None
-        self._pending = []
+        self._pending = False
 
     def broadcast_module(self, module):
         """Rank 0's parameters and buffers to every rank.  The weights change under every cache of derived quantities
@@ -51,20 +51,23 @@ class DataParallelSync:
         if self.cuda:
             t = upload(flat) if upload is not None else torch.tensor(flat, dtype=torch.int32).to(device or self.device)
             if self.world > 1 or self.force:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
-                self.side.wait_event(ev)
-                t.record_stream(self.side)
-                with torch.cuda.stream(self.side):
-                    dist.broadcast(t, src=0)
-                done = torch.cuda.Event()
-                done.record(self.side)
-                self._pending.append(done)
+                self._on_side(lambda: dist.broadcast(t, src=0), t)
             return t
         t = torch.tensor(flat, dtype=torch.int32)
         if self.world > 1:
             dist.broadcast(t, src=0)
         return t
+
+    def _on_side(self, collective, tensor):
+        """Enqueue `collective` on the RCCL side stream, ordered after everything enqueued on the current stream so far.
+        Stream order and the call itself go through kernels.order_streams / kernels.rec, so a kernels.LaunchList that is
+        recording the step records them too (a replay re-issues the collective on the same tensor)."""
+        from . import kernels as K
+        K.order_streams(self.side, torch.cuda.current_stream())
+        tensor.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            K.rec(collective)
+        self._pending = True
 
     def all_reduce_avg(self, flat):
         """Average `flat` (a contiguous tensor) across ranks.  On GPUs the collective runs on a side stream
@@ -72,32 +75,26 @@ class DataParallelSync:
         if self.world == 1 and not self.force:
             return
         if self.cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self.side.wait_event(ev)
-            flat.record_stream(self.side)
-            with torch.cuda.stream(self.side):
-                if self.has_avg:
-                    dist.all_reduce(flat, op=dist.ReduceOp.AVG)  # RCCL scales inside the collective: no extra pass over 114 MB
-                else:
+            if self.has_avg:
+                # RCCL scales inside the collective: no extra pass over 114 MB
+                self._on_side(lambda: dist.all_reduce(flat, op=dist.ReduceOp.AVG), flat)
+            else:
+                def sum_and_scale():
                     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
                     flat.mul_(1.0 / self.world)
-            done = torch.cuda.Event()
-            done.record(self.side)
-            self._pending.append(done)
-            # consumers of `flat` are enqueued later on the current stream: make it wait right away for
-            # correctness; the overlap window is the backward kernels issued before the next consumer.
-            # (PCGrad's Gram kernel is the first consumer, after all three tasks.)
+                self._on_side(sum_and_scale, flat)
+            # consumers of `flat` are enqueued later on the current stream, after wait(): the overlap window is the backward
+            # kernels issued before the next consumer (PCGrad's Gram kernel is the first, after all three tasks)
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             flat.mul_(1.0 / self.world)
 
     def wait(self):
-        if self.cuda:
-            cur = torch.cuda.current_stream()
-            for ev in self._pending:
-                cur.wait_event(ev)
-        self._pending = []
+        """The current stream waits for every collective enqueued so far."""
+        if self.cuda and self._pending:
+            from . import kernels as K
+            K.order_streams(torch.cuda.current_stream(), self.side)
+        self._pending = False
 
     def all_reduce_avg_list(self, tensors):
         """Bucket a list of tensors into one flat buffer, average, scatter back."""

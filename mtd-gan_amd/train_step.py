@@ -61,7 +61,7 @@ class DStepTape:
         first_write = frozenset() if not FIRST_WRITE else frozenset(
             nme[:-len(".weight_orig")] for nme in sh_names if _TRUNK_SN_WEIGHT.match(nme))
         if POISON:
-            S[:3].fill_(float("nan"))          # (test hook: an element no pass writes stays NaN)
+            K.rec(S[:3].fill_, float("nan"))   # (test hook: an element no pass writes stays NaN)
         # task-specific gradients: views of one flat buffer, so that N > 1 averages them with a single collective
         ts_sizes = [D.get_parameter(nme).numel() for nme in ts_names]
         # (each view starts on a 16-byte boundary: the spectral-norm correction then moves float4s)
@@ -74,7 +74,7 @@ class DStepTape:
             for pre in "sr":
                 dec_first[pre] = frozenset(nme[:-len(".weight_orig")] for nme in ts_names if re_dec[pre].match(nme))
         if POISON:
-            TSflat.fill_(float("nan"))
+            K.rec(TSflat.fill_, float("nan"))
         TSbuf, tofs = {}, 0
         for nme, sz in zip(ts_names, ts_sizes):
             TSbuf[nme] = TSflat[tofs:tofs + sz].view_as(D.get_parameter(nme))
@@ -89,10 +89,10 @@ class DStepTape:
         rest = [sk.t[nme] for sk in sinks for nme in sh_names if not (nme.endswith(".weight_orig") and nme[:-len(".weight_orig")] in first_write)]
         rest += [TSbuf[nme] for nme in ts_names if not (nme.endswith(".weight_orig") and nme[:-len(".weight_orig")] in (dec_first["s"] | dec_first["r"]))]
         if first_write and rest:
-            torch._foreach_zero_(rest)
+            K.zero_multi(rest)                 # ~100 small tensors, one launch
         elif not first_write:
-            S[:3].zero_()
-            TSflat.zero_()
+            K.rec(S[:3].zero_)
+            K.rec(TSflat.zero_)
         # ---- the projection order of this step: Python's `random`, as the reference draws it.  Under data parallelism
         # it is a collective decision (rank 0's draw, broadcast on the RCCL stream under the backward passes): ranks with
         # different `random` states would otherwise project the same averaged gradients differently and drift apart.
@@ -187,7 +187,8 @@ class DStepTape:
             slot.consumed()
         merged = S[3]
         if reduction == "mean":
-            merged = merged / 3.0
+            merged = torch.empty_like(S[3])
+            K.rec(lambda: torch.div(S[3], 3.0, out=merged))
         ofs = 0
         for p, sz in zip(shared_params, sizes):
             p.grad = merged[ofs:ofs + sz].view_as(p)
@@ -278,7 +279,10 @@ def d_loss(method, x, y):
     gflat = G._flat_params()
     GPm = N._unflatten_gen(gflat, G._cfg[2])
     keep = torch.is_grad_enabled() and any(p.requires_grad for p in gflat)
-    fn, gtape = GP.generator_forward(xn, GPm, keep)
+    # (the generator writes its output straight into the second half of the first pair's input batch: no concatenation pass)
+    pair12 = torch.empty((2 * B, 64, 64, 1), dtype=torch.float32, device=dev)
+    K.copy_channels(yn, pair12[:B])
+    fn, gtape = GP.generator_forward(xn, GPm, keep, out=pair12[B:])
     # (the entry holds x itself: a strong reference keeps its address from being recycled for another batch)
     method._gcache = (x, _gkey(x, gflat), fn, gtape, GPm) if keep else None
     P = D._param_dict()
@@ -290,12 +294,10 @@ def d_loss(method, x, y):
     K.prepack(DP.conv_views(P, True))
     K.prepack_winograd(DP.winograd_views(P, True))
     sn = [DP._sn_forward(P, train, dev) for _ in range(4)]
-    masks = [D._next_mask(B, dev) for _ in range(4)]
-    cat_mask = lambda a, b: None if a is None else torch.cat([a, b], 0)
-    (e12, d12, r12), t12 = DP.disc_forward(P, torch.cat([yn, fn], 0), train, cat_mask(masks[0], masks[1]), True, True,
-                                           sn=sn[0], sn2=sn[1], pair=B)
-    (e34, d34, _), t34 = DP.disc_forward(P, K.clip01(r12), train, cat_mask(masks[2], masks[3]), False, True,
-                                         sn=sn[2], sn2=sn[3], pair=B)
+    masks = D._next_masks(B, dev, 4)          # the four passes' dropout multipliers, stacked: (4B, 512) or None
+    m12, m34 = (None, None) if masks is None else (masks[:2 * B], masks[2 * B:])
+    (e12, d12, r12), t12 = DP.disc_forward(P, pair12, train, m12, True, True, sn=sn[0], sn2=sn[1], pair=B)
+    (e34, d34, _), t34 = DP.disc_forward(P, K.clip01(r12), train, m34, False, True, sn=sn[2], sn2=sn[3], pair=B)
     re, fe, rd, fd, rr, fr = e12[:B], e12[B:], d12[:B], d12[B:], r12[:B], r12[B:]
     rre, rfe, rrd, rfd = e34[:B], e34[B:], d34[:B], d34[B:]
     n = B * NPIX
@@ -305,7 +307,7 @@ def d_loss(method, x, y):
         T(0, rd, tconst=1.0, mx=xn, my=yn, scale=1.0 / n), T(0, fd, tconst=0.0, mx=xn, my=yn, scale=1.0 / n),
         T(1, rr, yn, scale=1.0 / n), T(1, fr, fn, scale=1.0 / n),
         T(0, re, rre, scale=1.0 / B), T(0, rd, rrd, scale=1.0 / n), T(0, fe, rfe, scale=1.0 / B), T(0, fd, rfd, scale=1.0 / n)], dev)
-    losses = torch.stack([v[0:4].sum(), v[4:6].sum(), v[6:10].sum()])        # 10 scalars: host-side bookkeeping
+    losses = K.scalar_sums([(v[0:4], None), (v[4:6], None), (v[6:10], None)], dev)        # stack[disc, rec, consist] (networks.py:1992)
     keys = ["D/real_enc", "D/fake_enc", "D/real_dec", "D/fake_dec", "D/rec_loss_real", "D/rec_loss_fake",
             "D/consist_loss_real_enc", "D/consist_loss_real_dec", "D/consist_loss_fake_enc", "D/consist_loss_fake_dec"]
     details = {k: v[i] for i, k in enumerate(keys)}
@@ -342,7 +344,7 @@ class _GStepFn(torch.autograd.Function):
         v = K.loss_terms([T(0, ge, tconst=1.0, scale=1.0 / B), T(0, gd, tconst=1.0, mx=xn, my=yn, scale=1.0 / n),
                           T(2, fake, yn, scale=50.0 / n, eps=method.pixel_loss.eps)], dev)
         edge = K.edge_loss(fake, yn, 50.0 / n, method.edge_loss.loss.eps)
-        total = v.sum() + edge[0]
+        total = K.scalar_sums([(v, edge)], dev).reshape(())              # adv + 50 Charbonnier + 50 Edge (networks.py:2003)
         if need:
             ctx.state = (method, GPm, nlayers, gtape, dtape, P, ge, gd, fake, xn, yn)
         ctx.mark_non_differentiable(v, edge)
@@ -362,10 +364,25 @@ class _GStepFn(torch.autograd.Function):
         g_fake = DP.disc_backward(D._rt, P, dtape, g_e, g_d, None, None, True)        # input gradient only
         K.loss_term_grads([T(2, fake, yn, eps=method.pixel_loss.eps, grad_out=g_fake, coef=50.0 / n, accumulate=True)], dev)
         K.edge_loss(fake, yn, 50.0 / n, method.edge_loss.loss.eps, grad_out=g_fake, coef=50.0 / n, accumulate=True)
-        g_fake = g_fake * g_total                                                        # upstream scalar (== 1 from .backward())
+        g_up = g_total.detach().reshape(1).contiguous().float()
+        if K.RECORDING is not None:
+            K.RECORDING.keep.append(g_up)        # (autograd's tensor: a replay reads it again)
+        g_fake = K.scale_by(g_fake, g_up)                                                # upstream scalar (== 1 from .backward())
         flat = N._flatten_gen(GPm)
-        gflat = [torch.empty_like(p) for p in flat]
+        # One flat buffer, the parameter gradients are views of it (each on a 16-byte boundary): under data parallelism the
+        # generator's gradients are then ONE in-place all-reduce on the RCCL stream (engine.train_iteration), like the
+        # discriminator's task vectors -- no torch.cat, no 128 copies back.  (The views are handed to autograd and not kept
+        # here: AccumulateGrad takes a gradient over as .grad without a copy only while nothing else refers to the tensor object.)
+        sizes = [(p.numel() + 3) // 4 * 4 for p in flat]
+        gbuf = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        gflat, ofs = [], 0
+        for p, sz in zip(flat, sizes):
+            gflat.append(gbuf[ofs:ofs + p.numel()].view_as(p))
+            ofs += sz
+        if ofs > sum(p.numel() for p in flat):
+            K.zero_multi([gbuf])                            # the padding between views travels through the collective: keep it finite
         GP.generator_backward(g_fake, gtape, GPm, N._unflatten_gen(gflat, nlayers, as_grad=True))
+        method._ggrad_flat = gbuf
         ctx.state = None
         return (None, None, None, None) + tuple(gflat)
 
@@ -444,6 +461,119 @@ class GraphedTrainStep:
         return self.names, self.vals
 
 
+# ================================================================================================ launch-list replay
+LIST_MODE = os.environ.get("MTD_LIST", "1") != "0"      # engine.train_MTD_GAN_Ours / bench: recorded launch list after two eager iterations
+
+
+class RecordedTrainStep:
+    """One full training iteration recorded as a kernels.LaunchList and re-issued per iteration: every C-ABI launch with the
+    arguments it had, every stream-order operation (the weight-gradient side stream stays a side stream, unlike in a
+    captured hipGraph, whose multi-stream sections ROCm 7.2 serialises), the uniform draws of the dropout masks and -- under
+    data parallelism -- the RCCL collectives; none of the Python around them (tensor allocation, geometry and plan look-ups,
+    the autograd engine).  The eager step costs the host ~24 ms per 30 ms of GPU work; the replay a fraction.
+
+    The recording IS an iteration (it executes).  Host-side state of an iteration is refreshed per replay exactly as the
+    eager step would produce it: the PCGrad projection order (Python's `random`, as reference module/weight_methods.py:452)
+    and AdamW's step-dependent scalars go through pinned slots whose ring advances per replay; the dropout draws come from
+    torch's generator at replay time.  Inputs are copied into the buffers the list reads.  Every tensor the recorded
+    iteration allocated stays allocated (the list owns ~4 GB of activations and gradient buffers at 32 patches); parameter
+    .grad tensors stay the recorded views, rewritten by every replay.
+
+    Conditions (checked by `usable`; anything else runs eagerly): both optimizers are FusedAdamW, reduction 'sum', no
+    injected dropout masks, fp32 CUDA inputs of the recorded shape, unchanged parameter storage and training mode."""
+
+    def __init__(self, model, optimizer_G, optimizer_D, method_D, x, y, dp=None, warmup=2):
+        from . import engine
+        self.model, self.oG, self.oD, self.wm, self.dp = model, optimizer_G, optimizer_D, method_D, dp
+        self.x, self.y = x.detach().float().contiguous().clone(), y.detach().float().contiguous().clone()
+        dev = x.device
+        optimizer_G.graph_mode = optimizer_D.graph_mode = True     # step scalars through pinned slots from now on (same kernel, same values)
+        for _ in range(warmup):                                    # optimizer state, workspaces and derived weight views exist
+            self.names, self.vals = engine.train_iteration(model, self.x, self.y, optimizer_G, optimizer_D, method_D, dp)
+        self.list = K.LaunchList()
+        self.names, self.vals = self.list.record(
+            lambda: engine.train_iteration(model, self.x, self.y, optimizer_G, optimizer_D, method_D, dp), dev, repack=False)
+        self.slot = orders_slot(dev)
+        if all(self.slot is not sl for sl in self.list.slots):
+            raise RuntimeError("RecordedTrainStep: the recorded iteration did not read the PCGrad order slot")
+        self.signature = self._signature(model, optimizer_G, optimizer_D, method_D, dp)
+        self.grads = [(p, p.grad) for p in list(model.Discriminator.parameters()) + list(model.Generator.parameters())]
+        self.iterations = warmup + 1
+
+    @staticmethod
+    def _signature(model, oG, oD, wm, dp):
+        D, G = model.Discriminator, model.Generator
+        return (tuple(p.data_ptr() for p in D.parameters()), tuple(p.data_ptr() for p in G.parameters()),
+                tuple(b.data_ptr() for b in D.buffers()), D.training, G.training, D.c_drop.p,
+                tuple(p.requires_grad for p in model.parameters()), id(oG), id(oD), id(wm), id(dp),
+                tuple((g["betas"], g["eps"]) for g in oD.param_groups + oG.param_groups))
+
+    @staticmethod
+    def usable(model, optimizer_G, optimizer_D, method_D, x, y):
+        """Can an iteration with these objects be recorded / replayed at all?"""
+        from .optimizers import FusedAdamW
+        from .module.weight_methods import PCGrad, WeightMethods
+        D = getattr(model, "Discriminator", None)
+        return (LIST_MODE and type(model).__name__ == "MTD_GAN_Method" and isinstance(optimizer_G, FusedAdamW) and isinstance(optimizer_D, FusedAdamW)
+                and isinstance(method_D, WeightMethods) and isinstance(method_D.method, PCGrad) and method_D.method.reduction == "sum"
+                and x.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32 and x.shape == y.shape and tuple(x.shape[1:]) == (1, 64, 64)
+                and not D._inject_masks and torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing() and not POISON)
+
+    def matches(self, model, optimizer_G, optimizer_D, method_D, x, y, dp):
+        return (x.shape == self.x.shape and x.device == self.x.device and torch.cuda.current_stream() == self.list.main
+                and self.signature == self._signature(model, optimizer_G, optimizer_D, method_D, dp)
+                and not model.Discriminator._inject_masks)
+
+    def step(self, x=None, y=None):
+        """One iteration.  x, y: the batch (copied into the list's input buffers) or None to run on the resident batch."""
+        if x is not None and x is not self.x:
+            self.x.copy_(x)
+            self.y.copy_(y)
+        lst = self.list
+        orders = shuffle_orders(3)                                  # this iteration's projection order, drawn as the reference draws it
+        lst.set_slot(self.slot, [j for o in orders for j in o] + [0] * 7)
+        self.oD.advance_for_replay(lst.set_slot)
+        self.oG.advance_for_replay(lst.set_slot)
+        lst.replay()
+        self.orders = orders
+        K.weights_changed(None)      # the parameters moved: nothing outside the list may trust a cached derived view
+        if self.grads[0][0].grad is not self.grads[0][1]:           # someone cleared .grad (zero_grad): hand the recorded views back
+            for p, g in self.grads:
+                p.grad = g
+        self.iterations += 1
+        return self.names, self.vals
+
+
+def recorded_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp=None):
+    """engine.train_iteration through a RecordedTrainStep where one applies: the first two iterations of a configuration run
+    eagerly, the third is recorded while it runs, later ones replay.  The step object lives on the model (it is tied to the
+    model's parameter storage).  Returns (names, device tensor of the logged values) like engine.train_iteration."""
+    from . import engine
+    if not RecordedTrainStep.usable(model, optimizer_G, optimizer_D, method_D, x, y):
+        return engine.train_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp)
+    st = getattr(model, "_mtd_recorded", None)
+    if isinstance(st, RecordedTrainStep):
+        if st.matches(model, optimizer_G, optimizer_D, method_D, x, y, dp):
+            return st.step(x, y)
+        if x.shape != st.x.shape:                                   # e.g. the last, smaller batch of an epoch: eager, keep the list
+            return engine.train_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp)
+        model._mtd_recorded = st = None                             # different objects / storage: start over
+    seen = (st or 0) if isinstance(st, int) else 0
+    key = (tuple(x.shape), id(optimizer_G), id(optimizer_D))
+    if getattr(model, "_mtd_recorded_key", None) != key:
+        model._mtd_recorded_key, seen = key, 0
+    if seen < 2:
+        model._mtd_recorded = seen + 1
+        return engine.train_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp)
+    try:
+        st = RecordedTrainStep(model, optimizer_G, optimizer_D, method_D, x, y, dp, warmup=0)
+    except Exception:
+        model._mtd_recorded = -(1 << 30)                            # recording failed: stay eager for good, and say why once
+        raise
+    model._mtd_recorded = st
+    return st.names, st.vals
+
+
 # ================================================================================================ bench workload
 class FullStepWorkload:
     """BASELINE config 3: full G + D + PCGrad training iteration (engine.train_MTD_GAN_Ours body) on
@@ -477,9 +607,10 @@ class FullStepWorkload:
             self.wm.method.dp = self.dp
         self.graphed = None
         self.graph_error = None
+        self.recorded = None
         import os
-        # hipGraph replay is opt-in: measured 84.6 ms/step replayed vs 73.9 ms/step launched eagerly over three
-        # streams (ROCm 7.2 serialises the captured multi-stream sections), see DESIGN.md
+        # hipGraph replay is opt-in (MTD_GRAPH=1): a captured step is slower than the launches it replaces, because ROCm 7.2
+        # serialises the captured multi-stream sections; the default is the recorded launch list (MTD_LIST=0: eager)
         if world == 1 and os.environ.get("MTD_GRAPH", "0") == "1":
             try:
                 self.graphed = GraphedTrainStep(self.model, self.oG, self.oD, self.wm, self.x, self.y)
@@ -491,8 +622,21 @@ class FullStepWorkload:
     def step(self):
         if self.graphed is not None:
             self.graphed.step()
+        elif LIST_MODE:
+            self.step_list()
         else:
             self.step_eager()
+
+    def step_list(self):
+        # the iteration as engine.train_MTD_GAN_Ours runs it by default: eager twice, recorded once, replayed from then on
+        from . import engine
+        if getattr(self, "_logged", None) is None:
+            self._meters = {}
+            self._logged = engine.LoggedScalars(self._meters, self.batch)
+            engine.freeze_long_lived_objects(force=True)
+        names, vals = recorded_iteration(self.model, self.x, self.y, self.oG, self.oD, self.wm, self.dp)
+        self.recorded = getattr(self.model, "_mtd_recorded", None)
+        self._logged.push(names, vals, self.oG.param_groups[0]["lr"])
 
     def step_eager(self):
         # one iteration as engine.train_MTD_GAN_Ours runs it: the schedule plus the logged scalars' lagged device -> host copy
@@ -523,5 +667,10 @@ class FullStepWorkload:
 
     def extra(self):
         return {"algorithmic_gflop_per_patch": self.gflop_per_patch,
-                "launch_mode": "hipGraph replay" if getattr(self, "graphed", None) is not None else "eager launches",
+                "launch_mode": ("hipGraph replay" if getattr(self, "graphed", None) is not None else
+                                "recorded launch list (side streams kept), replayed" if isinstance(getattr(self, "recorded", None), RecordedTrainStep)
+                                else "eager launches"),
+                "launches_per_step": (sum(1 for f, _a in self.recorded.list.ops if getattr(f, "__name__", "").startswith("mtd_"))
+                                      if isinstance(getattr(self, "recorded", None), RecordedTrainStep) else None),
+                "list_ops_per_step": len(self.recorded.list.ops) if isinstance(getattr(self, "recorded", None), RecordedTrainStep) else None,
                 "graph_error": getattr(self, "graph_error", None), "table_stats": dict(K.STATS)}

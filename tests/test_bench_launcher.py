@@ -31,6 +31,24 @@ def test_gpus_2_launches_two_ranks_unwrapped():
         assert key in line, key
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("n", [4, 8])
+def test_gpus_4_and_8_report_the_ranks_seen(n):
+    """The driver's scaling run is `--gpus 1, 2, 4, 8` back to back: both launch forms at 4 and 8 ranks -- bench.py's own
+    launcher, and `python -m torch.distributed.run --nproc-per-node N` with bench.py as one of the ranks (the driver's form)."""
+    r = _run("--gpus", str(n))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == n, r.stdout
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29600 + n), os.path.join(ROOT, "bench.py"), "--dry-run", "--gpus", str(n), "--steps", "3",
+                        "--warmup", "1"], env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == n, r.stdout
+
+
 @pytest.mark.timeout(300)
 def test_a_failing_rank_fails_the_launch():
     r = _run("--gpus", "2", "--dry-run-fail-rank", "1")

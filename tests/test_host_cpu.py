@@ -112,7 +112,9 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
               ("mtd_wgrad_reduce_desc", L.WgradReduceDesc, ["a", "T", "nslab", "slab_stride", "first_block"], {}),
               ("mtd_mix_reduce_desc", L.MixReduceDesc, ["ws", "dw2", "db2", "nslab", "accumulate"], {}),
               ("mtd_pack_desc", L.PackDesc, ["src", "dst", "N", "T", "sn", "sc"], {}),
-              ("mtd_prof_record", L.ProfRecord, ["kernel", "taps", "M", "flops", "ms", "bytes"], {})]
+              ("mtd_prof_record", L.ProfRecord, ["kernel", "taps", "M", "flops", "ms", "bytes"], {}),
+              ("mtd_sum_desc", L.SumDesc, ["a", "b", "na", "nb"], {}),
+              ("mtd_zero_desc", L.ZeroDesc, ["p", "n"], {})]
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT}/include/mtdgan_hip.h"', "int main(void) {"]
     for cname, _cls, fields, _ren in checks:
         lines.append(f'  printf("%zu", sizeof({cname}));')

@@ -603,6 +603,83 @@ def test_graph_replay_equals_eager(hip_lib):
         assert rel(sd_g[k], sd_e[k]) < 1e-5, k
 
 
+def test_launch_list_replay_equals_eager_bit_for_bit(hip_lib):
+    """The recorded launch list (train_step.RecordedTrainStep: what engine.train_MTD_GAN_Ours replays from its third iteration
+    on) against eager execution: five eager iterations == two eager + one recorded + two replayed, BIT-IDENTICAL -- parameters,
+    spectral-norm vectors, optimizer moments, the 17 logged values of every iteration, with dropout ON (the masks are drawn
+    from torch's generator at replay time) and a fresh batch per iteration (inputs are copied into the list's buffers).
+    Between replays the test allocates and poisons device memory: a tensor the list still reads but no longer owns would pick
+    that up.  Also through the API: train_MTD_GAN_Ours on a five-batch loader returns the same averages either way."""
+    from mtd_gan_amd import engine, train_step as TS
+    from mtd_gan_amd.arch.Ours.networks import MTD_GAN_Method
+    from mtd_gan_amd.module.weight_methods import WeightMethods
+    from mtd_gan_amd.optimizers import FusedAdamW
+    dev = torch.device("cuda")
+    batches = [tuple(t.cuda() for t in orc.synthetic_ldct(4, seed=70 + i)) for i in range(5)]
+
+    def build():
+        torch.manual_seed(5)
+        m = MTD_GAN_Method().cuda().train()
+        wm = WeightMethods("pcgrad", n_tasks=3, device=dev)
+        oD = FusedAdamW(m.Discriminator.parameters(), lr=1e-4, weight_decay=5e-4)
+        oG = FusedAdamW(m.Generator.parameters(), lr=1e-4, weight_decay=5e-4)
+        random.seed(123)
+        torch.manual_seed(99)                                   # the dropout draws of the five iterations
+        return m, wm, oD, oG
+
+    def snapshot(m, oD, oG):
+        st = {k: v.clone() for k, v in m.state_dict().items()}
+        for tag, o in (("D", oD), ("G", oG)):
+            for i, p in enumerate(o.param_groups[0]["params"]):
+                if p in o.state:
+                    st[f"{tag}.m{i}"], st[f"{tag}.v{i}"] = o.state[p]["exp_avg"].clone(), o.state[p]["exp_avg_sq"].clone()
+        return st
+
+    runs = {}
+    for mode in ("eager", "list"):
+        m, wm, oD, oG = build()
+        logged = []
+        for i, (x, y) in enumerate(batches):
+            if mode == "eager":
+                names, vals = engine.train_iteration(m, x, y, oG, oD, wm, None)
+            else:
+                names, vals = TS.recorded_iteration(m, x, y, oG, oD, wm, None)
+                if i >= 2:
+                    assert isinstance(m._mtd_recorded, TS.RecordedTrainStep)
+                    junk = [torch.full((n,), float("nan"), device=dev) for n in (1 << 10, 1 << 16, 1 << 20, 1 << 24, 3 << 24)]   # poison freed memory
+                    del junk
+            logged.append(vals.clone())
+        torch.cuda.synchronize()
+        runs[mode] = (snapshot(m, oD, oG), logged, oD.state[m.Discriminator.enc_out.weight]["step"], m)
+    (sd_e, log_e, st_e, _), (sd_l, log_l, st_l, m_l) = runs["eager"], runs["list"]
+    assert st_e == st_l == 5
+    assert m_l._mtd_recorded.iterations == 3                  # recorded at the third iteration, two replays
+    for i in range(5):
+        assert torch.equal(log_l[i], log_e[i]), (i, log_l[i], log_e[i])
+    for k in sd_e:
+        assert torch.equal(sd_l[k], sd_e[k]), k
+    # .grad of every parameter is what the last (replayed) iteration produced: usable by the caller as after an eager iteration
+    m_e = runs["eager"][3]
+    for (n, p), (_n, q) in zip(m_l.named_parameters(), m_e.named_parameters()):
+        assert (p.grad is None) == (q.grad is None), n
+        if p.grad is not None:
+            assert torch.equal(p.grad, q.grad), n
+    # ---- the API: same five batches through engine.train_MTD_GAN_Ours, list on / off
+    stats = {}
+    for mode in ("eager", "list"):
+        m, wm, oD, oG = build()
+        TS.LIST_MODE = mode == "list"
+        try:
+            stats[mode] = engine.train_MTD_GAN_Ours(m, [dict(n_20=x, n_100=y) for x, y in batches], oG, oD, dev, 0, 0, 4, wm)
+            # an evaluation right after replays must see the UPDATED weights (no stale derived view outside the list)
+            with torch.no_grad():
+                stats[mode + "_pred"] = m.Generator(batches[0][0]).clone()
+        finally:
+            TS.LIST_MODE = True
+    assert stats["eager"] == stats["list"], (stats["eager"], stats["list"])
+    assert torch.equal(stats["eager_pred"], stats["list_pred"])
+
+
 def test_checkpoint_resume_like_train_py(hip_lib, tmp_path):
     """train.py:276-288 saves {model_state_dict, optimizer_D, scheduler_D, optimizer_G, scheduler_G, epoch}; train.py:146-159
     loads it on the CPU map and resumes.  A run that is saved and resumed that way continues exactly like the run that
