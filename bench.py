@@ -424,7 +424,20 @@ def main(argv=None):
         if share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # RCCL prints a version banner on STDOUT when its communicator comes up; stdout carries exactly one JSON line
+            # (the contract), so the file descriptor points at stderr while the communicator is created and first used
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                warm = torch.zeros(1, device=dev)
+                dist.all_reduce(warm)
+                torch.cuda.synchronize()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
     ranks_seen = dist.get_world_size() if dist.is_initialized() else 1
 
     import __graft_entry__ as ge

@@ -1,13 +1,18 @@
-// Res-FFT-Conv spectral path for square maps of any power-of-two size 128 .. 512 (inference on whole slices:
+// Res-FFT-Conv spectral path for square maps of any power-of-two size 64 .. 512 (inference on whole slices:
 // reference engine.py:89,129 runs the generator on 512 x 512 images, where rfft2 is a 512-point transform).
-// The 64 x 64 training path keeps its register-resident kernels (resfft.hip); here one workgroup owns one image line
-// (a row, or a frequency column) for all 32 channels and transforms it in LDS: [S points][32 channels] re + im = S * 256
-// bytes (128 KB at S = 512, 160 KB per CU), radix-2, one barrier per stage, lane = channel so every LDS access is
-// stride-1 across lanes.  Forward transforms are decimation-in-frequency (natural in, bit-reversed out), inverse ones
-// decimation-in-time (bit-reversed in, natural out): the 1x1 spectral conv between them is per frequency, so the
-// column kernel never reorders anything.  Spectra: [B][kw 0..S/2][h 0..S-1][Re 32 | Im 32], ortho scaling 1/sqrt(S)
-// per dimension.  HBM-bound in principle (two passes over 3 x the activation size per block); these kernels are the
-// simple, exact version -- the work of a slice is dominated by the 3x3 convolutions.
+// The 64 x 64 training path keeps its register-resident kernels (resfft.hip); here a workgroup of 1024 threads (512 at S = 512: 256 registers per lane for the prefetched line) owns one image
+// line at a time (a pair of rows, or a frequency column) for all 32 channels and transforms it in LDS: [S points][32 channels]
+// re + im = S * 256 bytes (128 KB at S = 512, one workgroup per CU), radix-4 passes, lane = channel so every LDS access of the
+// transform is stride-1 across lanes.  Forward transforms are decimation-in-frequency (natural in, bit-reversed out), inverse
+// ones decimation-in-time (bit-reversed in, natural out): the 1x1 spectral conv between them is per frequency, so the column
+// kernel never reorders anything.  Spectra: [B][kw 0..S/2][h 0..S-1][Re 32 | Im 32], ortho scaling 1/sqrt(S) per dimension.
+// HBM-bound: a block moves 2.1 GB at S = 512, B = 8 (rows 0.54, columns 0.54, rows back 1.07 with the two residual operands).
+// Round 4 (the round-1 kernels loaded, transformed and stored one line per workgroup, serially, with 4-byte accesses: 2.7 /
+// 0.9 / 2.0 TB/s): the workgroups are PERSISTENT and walk their lines; the next line's global loads are issued as 16-byte
+// vectors into registers before the current line's transform and land under it (one workgroup per CU has nothing else to hide
+// them under), stores are 16-byte vectors, and the channel mix runs on the matrix cores (v_mfma_f32_32x32x2_f32 with the
+// spectrum as the B operand: rows of the LDS column are padded to 33 floats so that lanes along the frequency index hit 32
+// different banks) instead of 64 broadcast-read FMAs per lane and frequency.
 #include "common.h"
 
 namespace {
@@ -35,7 +40,7 @@ __device__ __forceinline__ void twiddle(const float* tw, int hS, int idx, float&
     sn = (SIGN < 0) ? -tw[hS + idx] : tw[hS + idx];
 }
 
-template <int SIGN, bool DIF>
+template <int SIGN, bool DIF, int LD>
 __device__ __forceinline__ void lds_fft(float* re, float* im, const float* tw, int S, int logS) {
     const int hS = S >> 1;
     int st = 0;
@@ -46,7 +51,7 @@ __device__ __forceinline__ void lds_fft(float* re, float* im, const float* tw, i
         for (int e = threadIdx.x; e < hS * 32; e += blockDim.x) {
             const int c = e & 31, pidx = e >> 5;
             const int grp = pidx >> lh, j = pidx & (half - 1);
-            const int i0 = (((grp << 1) << lh) + j) * 32 + c, i1 = i0 + half * 32;
+            const int i0 = (((grp << 1) << lh) + j) * LD + c, i1 = i0 + half * LD;
             float cs, sn;
             twiddle<SIGN>(tw, hS, j << tshift, cs, sn);
             const float ur = re[i0], ui = im[i0], vr = re[i1], vi = im[i1];
@@ -73,7 +78,7 @@ __device__ __forceinline__ void lds_fft(float* re, float* im, const float* tw, i
             for (int e = threadIdx.x; e < nq; e += blockDim.x) {
                 const int c = e & 31, q = e >> 5;
                 const int blk = q >> (lH - 1), j = q & (Q - 1);
-                const int ia = ((blk << (lH + 1)) + j) * 32 + c, ib = ia + Q * 32, ic = ia + H * 32, id = ic + Q * 32;
+                const int ia = ((blk << (lH + 1)) + j) * LD + c, ib = ia + Q * LD, ic = ia + H * LD, id = ic + Q * LD;
                 float c1, s1, c2, s2, c3, s3;
                 twiddle<SIGN>(tw, hS, j << ts1, c1, s1);
                 twiddle<SIGN>(tw, hS, (j + Q) << ts1, c2, s2);
@@ -96,7 +101,7 @@ __device__ __forceinline__ void lds_fft(float* re, float* im, const float* tw, i
             for (int e = threadIdx.x; e < nq; e += blockDim.x) {
                 const int c = e & 31, q = e >> 5;
                 const int blk = q >> lh, j = q & (h - 1);
-                const int ia = ((blk << (lh + 2)) + j) * 32 + c, ib = ia + h * 32, ic = ib + h * 32, id = ic + h * 32;
+                const int ia = ((blk << (lh + 2)) + j) * LD + c, ib = ia + h * LD, ic = ib + h * LD, id = ic + h * LD;
                 float c1, s1, c2, s2, c3, s3;
                 twiddle<SIGN>(tw, hS, j << ts1, c1, s1);
                 twiddle<SIGN>(tw, hS, j << ts2, c2, s2);
@@ -118,125 +123,229 @@ __device__ __forceinline__ void lds_fft(float* re, float* im, const float* tw, i
     }
 }
 
-// rows forward: one workgroup per PAIR of image rows (b, h), (b, h + 1): the two real rows are the real and imaginary
-// part of one complex transform Z; X_h[k] = (Z[k] + conj Z[-k]) / 2, X_{h+1}[k] = (Z[k] - conj Z[-k]) / 2i
-__global__ __launch_bounds__(1024) void rfft_rows_any_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ R, int S, int logS) {
-    extern __shared__ float lds[];
-    float* re = lds;
-    float* im = lds + S * 32;
-    float* tw = lds + S * 64;
-    fill_twiddles(tw, S);
-    const int hp = S >> 1;
-    const int b = blockIdx.x / hp, h = (blockIdx.x % hp) * 2;
-    const int nkw = S / 2 + 1;
-    const float* src = x + ((long long)(b * S + h) * S) * x_ld;
-    for (int e = threadIdx.x; e < S * 32; e += blockDim.x) {
-        const int c = e & 31, w = e >> 5;
-        re[e] = src[(long long)w * x_ld + c];
-        im[e] = src[(long long)(S + w) * x_ld + c];
-    }
-    __syncthreads();
-    lds_fft<-1, true>(re, im, tw, S, logS);
-    const float sc = 0.5f * rsqrtf((float)S);
-    for (int e = threadIdx.x; e < nkw * 32; e += blockDim.x) {
-        const int c = e & 31, kw = e >> 5;
-        const int pk = brev_n(kw, logS) * 32 + c, pm = brev_n((S - kw) & (S - 1), logS) * 32 + c;
-        const float zkr = re[pk], zki = im[pk], zmr = re[pm], zmi = im[pm];
-        float* o = R + (((long long)(b * nkw + kw) * S + h) * 64) + c;
-        o[0] = (zkr + zmr) * sc;
-        o[32] = (zki - zmi) * sc;
-        o[64] = (zki + zmi) * sc;
-        o[64 + 32] = (zmr - zkr) * sc;
-    }
-}
+constexpr int NCU = 256;       // MI355X: persistent grids are sized in workgroups per CU
 
-// columns + channel mix + columns back: one workgroup per (b, kw)
-__global__ __launch_bounds__(1024) void spec_mix_any_kernel(const float* __restrict__ R, const float* __restrict__ w2t,
-                                                           const float* __restrict__ b2, float* __restrict__ T, int S, int logS) {
+template <int S> struct Log2 { static constexpr int v = 1 + Log2<S / 2>::v; };
+template <> struct Log2<1> { static constexpr int v = 0; };
+
+// rows forward: a pair of image rows (b, h), (b, h + 1) per step -- the two real rows are the real and imaginary part of one
+// complex transform Z; X_h[k] = (Z[k] + conj Z[-k]) / 2, X_{h+1}[k] = (Z[k] - conj Z[-k]) / 2i.  unit u = b * S/2 + h/2.
+template <int S, int NT>
+__global__ __launch_bounds__(NT) void rfft_rows_any_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ R, int units) {
+    constexpr int logS = Log2<S>::v, NV = (S * 16 + NT - 1) / NT, nkw = S / 2 + 1;
     extern __shared__ float lds[];
     float* re = lds;
     float* im = lds + S * 32;
     float* tw = lds + S * 64;
     fill_twiddles(tw, S);
-    const long long colbase = (long long)blockIdx.x * S * 64;
-    for (int e = threadIdx.x; e < S * 32; e += blockDim.x) {
-        const int c = e & 31, h = e >> 5;
-        re[e] = R[colbase + (long long)h * 64 + c];
-        im[e] = R[colbase + (long long)h * 64 + 32 + c];
-    }
-    __syncthreads();
-    lds_fft<-1, true>(re, im, tw, S, logS);
-    // channel mix at every frequency (order of the frequencies is irrelevant): lane = output channel o, its 64 weights in
-    // registers; a wave owns whole rows, reads all 64 inputs of a row (broadcast reads) before it writes the 64 outputs
-    {
-        const int o = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-        float wreg[64];
+    const int tid = threadIdx.x;
+    f32x4 v[NV];
+    auto issue = [&](int u) {
+        const int b = u / (S / 2), h = (u % (S / 2)) * 2;
+        const float* src = x + ((long long)(b * S + h) * S) * x_ld;           // rows h, h + 1: 2 S consecutive pixels
 #pragma unroll
-        for (int k = 0; k < 64; ++k) wreg[k] = w2t[k * 64 + o];
-        const float bo = b2[o];
-        const float sc = rsqrtf((float)S);
-        for (int n = wv; n < S; n += nwv) {
-            float acc = 0.f;
-#pragma unroll
-            for (int k = 0; k < 32; ++k) acc = fmaf(re[n * 32 + k], wreg[k], acc);
-#pragma unroll
-            for (int k = 0; k < 32; ++k) acc = fmaf(im[n * 32 + k], wreg[32 + k], acc);
-            const float z = fmaxf(acc * sc + bo, 0.f);
-            __builtin_amdgcn_wave_barrier();
-            if (o < 32) re[n * 32 + o] = z;
-            else im[n * 32 + o - 32] = z;
+        for (int j = 0; j < NV; ++j) {
+            const int q = tid + NT * j, p = q >> 3, c4 = q & 7;
+            if (NV * NT == S * 16 || q < S * 16) v[j] = *reinterpret_cast<const f32x4*>(src + (long long)p * x_ld + c4 * 4);
         }
-    }
-    __syncthreads();
-    lds_fft<+1, false>(re, im, tw, S, logS);
-    const float sc = rsqrtf((float)S);
-    for (int e = threadIdx.x; e < S * 32; e += blockDim.x) {
-        const int c = e & 31, h = e >> 5;
-        T[colbase + (long long)h * 64 + c] = re[e] * sc;
-        T[colbase + (long long)h * 64 + 32 + c] = im[e] * sc;
+    };
+    int u = blockIdx.x;
+    if (u < units) issue(u);
+    for (; u < units; u += gridDim.x) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int q = tid + NT * j, p = q >> 3, c4 = q & 7;
+            if (NV * NT == S * 16 || q < S * 16) *reinterpret_cast<f32x4*>((p >= S ? im : re) + (p & (S - 1)) * 32 + c4 * 4) = v[j];
+        }
+        __syncthreads();
+        if (u + (int)gridDim.x < units) issue(u + gridDim.x);                  // lands under this pair's transform
+        lds_fft<-1, true, 32>(re, im, tw, S, logS);
+        const int b = u / (S / 2), h = (u % (S / 2)) * 2;
+        const float sc = 0.5f * rsqrtf((float)S);
+        for (int it = tid; it < nkw * 8; it += NT) {
+            const int kw = it >> 3, c4 = it & 7;
+            const int pk = brev_n(kw, logS) * 32 + c4 * 4, pm = brev_n((S - kw) & (S - 1), logS) * 32 + c4 * 4;
+            const f32x4 zkr = *reinterpret_cast<const f32x4*>(re + pk), zki = *reinterpret_cast<const f32x4*>(im + pk);
+            const f32x4 zmr = *reinterpret_cast<const f32x4*>(re + pm), zmi = *reinterpret_cast<const f32x4*>(im + pm);
+            float* o = R + (((long long)(b * nkw + kw) * S + h) * 64) + c4 * 4;
+            *reinterpret_cast<f32x4*>(o) = (zkr + zmr) * sc;
+            *reinterpret_cast<f32x4*>(o + 32) = (zki - zmi) * sc;
+            *reinterpret_cast<f32x4*>(o + 64) = (zki + zmi) * sc;
+            *reinterpret_cast<f32x4*>(o + 96) = (zmr - zkr) * sc;
+        }
+        __syncthreads();
     }
 }
 
-// rows back (c2r): one workgroup per pair of image rows; out = y + add1 + add2.  With A = X_h, B = X_{h+1} (Hermitian,
-// the imaginary parts of columns 0 and S/2 ignored as torch's c2r does) the complex spectrum Z = A + iB transforms
-// back to row h in the real part and row h + 1 in the imaginary part.
-__global__ __launch_bounds__(1024) void irfft_rows_any_kernel(const float* __restrict__ T, float* __restrict__ out, int out_ld,
+// columns + channel mix + columns back: a column (b, kw) per step.  LDS rows are CLD = 33 floats apart (see the header).
+constexpr int CLD = 33;
+template <int S, int NT>
+__global__ __launch_bounds__(NT) void spec_mix_any_kernel(const float* __restrict__ R, const float* __restrict__ w2t,
+                                                           const float* __restrict__ b2, float* __restrict__ T, int units) {
+    constexpr int logS = Log2<S>::v, NV = (S * 16 + NT - 1) / NT;
+    extern __shared__ float lds[];
+    float* re = lds;
+    float* im = lds + S * CLD;
+    float* tw = lds + 2 * S * CLD;
+    float* wl = tw + S;                    // w2t [k 64][o 64] + bias [64]
+    fill_twiddles(tw, S);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < 64 * 64 + 64; i += NT) wl[i] = i < 4096 ? w2t[i] : b2[i - 4096];
+    f32x4 v[NV];
+    auto issue = [&](int u) {
+        const float* src = R + (long long)u * S * 64;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int q = tid + NT * j;
+            if (NV * NT == S * 16 || q < S * 16) v[j] = *reinterpret_cast<const f32x4*>(src + (long long)q * 4);
+        }
+    };
+    int u = blockIdx.x;
+    if (u < units) issue(u);
+    const float sc = rsqrtf((float)S);
+    for (; u < units; u += gridDim.x) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int q = tid + NT * j, h = q >> 4, part = q & 15;
+            if (NV * NT == S * 16 || q < S * 16) {
+                float* d = (part >= 8 ? im : re) + h * CLD + (part & 7) * 4;
+                d[0] = v[j][0]; d[1] = v[j][1]; d[2] = v[j][2]; d[3] = v[j][3];
+            }
+        }
+        __syncthreads();
+        if (u + (int)gridDim.x < units) issue(u + gridDim.x);
+        lds_fft<-1, true, CLD>(re, im, tw, S, logS);
+        // channel mix at every frequency on the matrix cores: D[o][n] = sum_k W[k][o] * Z[n][k], k = (re 0..31 | im 32..63).
+        // A operand: lane (o = l & 31, k = l >> 5) of W from LDS; B operand: lane (n = l & 31, k = l >> 5) of the column.
+        // work items = (32-row tile, output half): S / 32 * 2 over the 16 waves; results stay in registers until every
+        // wave has read its operands (two waves may share a tile), then replace the column.
+        constexpr int NW = NT / 64, ITEMS = S / 32 * 2, PER = (ITEMS + NW - 1) / NW;
+        f32x16 acc[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int item = wv + NW * i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            if (item < ITEMS) {
+                const int tile = item % (S / 32), ob = item / (S / 32);
+                const float* zr = re + (tile * 32 + (lane & 31)) * CLD + (lane >> 5);
+                const float* zi = im + (tile * 32 + (lane & 31)) * CLD + (lane >> 5);
+                const float* wp = wl + (lane >> 5) * 64 + ob * 32 + (lane & 31);
+#pragma unroll 4
+                for (int s2 = 0; s2 < 16; ++s2) acc[i] = mfma32(wp[s2 * 128], zr[s2 * 2], acc[i]);
+#pragma unroll 4
+                for (int s2 = 0; s2 < 16; ++s2) acc[i] = mfma32(wp[(16 + s2) * 128], zi[s2 * 2], acc[i]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int item = wv + NW * i;
+            if (item < ITEMS) {
+                const int tile = item % (S / 32), ob = item / (S / 32);
+                float* dst = (ob ? im : re) + (tile * 32 + (lane & 31)) * CLD;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = mfma32_row(r, lane);
+                    dst[o] = fmaxf(acc[i][r] * sc + wl[4096 + ob * 32 + o], 0.f);
+                }
+            }
+        }
+        __syncthreads();
+        lds_fft<+1, false, CLD>(re, im, tw, S, logS);
+        float* dstg = T + (long long)u * S * 64;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int q = tid + NT * j, h = q >> 4, part = q & 15;
+            if (NV * NT == S * 16 || q < S * 16) {
+                const float* d = (part >= 8 ? im : re) + h * CLD + (part & 7) * 4;
+                f32x4 o = {d[0] * sc, d[1] * sc, d[2] * sc, d[3] * sc};
+                *reinterpret_cast<f32x4*>(dstg + (long long)q * 4) = o;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// rows back (c2r): a pair of image rows per step; out = y + add1 + add2.  With A = X_h, B = X_{h+1} (Hermitian, the imaginary
+// parts of columns 0 and S/2 ignored as torch's c2r does) the complex spectrum Z = A + iB transforms back to row h in the
+// real part and row h + 1 in the imaginary part.
+template <int S, int NT>
+__global__ __launch_bounds__(NT) void irfft_rows_any_kernel(const float* __restrict__ T, float* __restrict__ out, int out_ld,
                                                               const float* __restrict__ add1, int add1_ld,
-                                                              const float* __restrict__ add2, int add2_ld, int S, int logS) {
+                                                              const float* __restrict__ add2, int add2_ld, int units) {
+    constexpr int logS = Log2<S>::v, nkw = S / 2 + 1, NI = (nkw * 8 + NT - 1) / NT, NV = (S * 16 + NT - 1) / NT;
     extern __shared__ float lds[];
     float* re = lds;
     float* im = lds + S * 32;
     float* tw = lds + S * 64;
     fill_twiddles(tw, S);
-    const int hp = S >> 1;
-    const int b = blockIdx.x / hp, h = (blockIdx.x % hp) * 2;
-    const int nkw = S / 2 + 1;
-    for (int e = threadIdx.x; e < nkw * 32; e += blockDim.x) {
-        const int c = e & 31, kw = e >> 5;
-        const float* t = T + (((long long)(b * nkw + kw) * S + h) * 64) + c;
-        const bool edge = (kw == 0 || kw == S / 2);
-        const float ar = t[0], ai = edge ? 0.f : t[32];
-        const float br = t[64], bi = edge ? 0.f : t[64 + 32];
-        const int p0 = brev_n(kw, logS) * 32 + c;
-        re[p0] = ar - bi;
-        im[p0] = ai + br;
-        if (!edge) {
-            const int p1 = brev_n(S - kw, logS) * 32 + c;       // Z[S-k] = conj(A[k]) + i conj(B[k])
-            re[p1] = ar + bi;
-            im[p1] = br - ai;
+    const int tid = threadIdx.x;
+    f32x4 t0[NI], t1[NI], t2[NI], t3[NI];
+    auto issue = [&](int u) {
+        const int b = u / (S / 2), h = (u % (S / 2)) * 2;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int it = tid + NT * j, kw = it >> 3, c4 = it & 7;
+            if (it < nkw * 8) {
+                const float* t = T + (((long long)(b * nkw + kw) * S + h) * 64) + c4 * 4;
+                t0[j] = *reinterpret_cast<const f32x4*>(t);
+                t1[j] = *reinterpret_cast<const f32x4*>(t + 32);
+                t2[j] = *reinterpret_cast<const f32x4*>(t + 64);
+                t3[j] = *reinterpret_cast<const f32x4*>(t + 96);
+            }
         }
-    }
-    __syncthreads();
-    lds_fft<+1, false>(re, im, tw, S, logS);
+    };
+    int u = blockIdx.x;
+    if (u < units) issue(u);
     const float sc = rsqrtf((float)S);
-    const long long rowpix = (long long)(b * S + h) * S;
-    for (int e = threadIdx.x; e < S * 32; e += blockDim.x) {
-        const int c = e & 31, w = e >> 5;
-        float v0 = re[e] * sc, v1 = im[e] * sc;
-        if (add1) { v0 += add1[(rowpix + w) * add1_ld + c]; v1 += add1[(rowpix + S + w) * add1_ld + c]; }
-        if (add2) { v0 += add2[(rowpix + w) * add2_ld + c]; v1 += add2[(rowpix + S + w) * add2_ld + c]; }
-        out[(rowpix + w) * out_ld + c] = v0;
-        out[(rowpix + S + w) * out_ld + c] = v1;
+    for (; u < units; u += gridDim.x) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int it = tid + NT * j, kw = it >> 3, c4 = it & 7;
+            if (it < nkw * 8) {
+                const bool edge = (kw == 0 || kw == S / 2);
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 ar = t0[j], ai = edge ? zero : t1[j], br = t2[j], bi = edge ? zero : t3[j];
+                const int p0 = brev_n(kw, logS) * 32 + c4 * 4;
+                *reinterpret_cast<f32x4*>(re + p0) = ar - bi;
+                *reinterpret_cast<f32x4*>(im + p0) = ai + br;
+                if (!edge) {
+                    const int p1 = brev_n(S - kw, logS) * 32 + c4 * 4;       // Z[S-k] = conj(A[k]) + i conj(B[k])
+                    *reinterpret_cast<f32x4*>(re + p1) = ar + bi;
+                    *reinterpret_cast<f32x4*>(im + p1) = br - ai;
+                }
+            }
+        }
+        __syncthreads();
+        if (u + (int)gridDim.x < units) issue(u + gridDim.x);
+        lds_fft<+1, false, 32>(re, im, tw, S, logS);
+        const int b = u / (S / 2), h = (u % (S / 2)) * 2;
+        const long long rowpix = (long long)(b * S + h) * S;                  // rows h, h + 1: 2 S consecutive pixels
+        constexpr int CH = NV < 4 ? NV : 4;                                   // residual operands in chunks: 2 x CH vectors in flight
+#pragma nounroll
+        for (int j0 = 0; j0 < NV; j0 += CH) {
+            f32x4 a1[CH], a2[CH];
+#pragma unroll
+            for (int jj = 0; jj < CH; ++jj) {
+                const int q = tid + NT * (j0 + jj), p = q >> 3, c4 = q & 7;
+                if (NV * NT == S * 16 || q < S * 16) {
+                    if (add1) a1[jj] = *reinterpret_cast<const f32x4*>(add1 + (rowpix + p) * add1_ld + c4 * 4);
+                    if (add2) a2[jj] = *reinterpret_cast<const f32x4*>(add2 + (rowpix + p) * add2_ld + c4 * 4);
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < CH; ++jj) {
+                const int q = tid + NT * (j0 + jj), p = q >> 3, c4 = q & 7;
+                if (NV * NT == S * 16 || q < S * 16) {
+                    f32x4 o = *reinterpret_cast<const f32x4*>((p >= S ? im : re) + (p & (S - 1)) * 32 + c4 * 4) * sc;
+                    if (add1) o += a1[jj];
+                    if (add2) o += a2[jj];
+                    *reinterpret_cast<f32x4*>(out + (rowpix + p) * out_ld + c4 * 4) = o;
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -253,18 +362,71 @@ int set_lds(K kernel, size_t bytes) {
     return e == hipSuccess ? MTD_OK : (int)e;
 }
 
+// persistent grid: as many workgroups as fit the chip at this LDS footprint (160 KB per CU, 2048 threads per CU)
+inline int persistent_grid(int units, size_t lds_bytes) {
+    int per_cu = (int)((160 * 1024) / (lds_bytes + 1024));
+    if (per_cu > 2) per_cu = 2;
+    if (per_cu < 1) per_cu = 1;
+    const int g = NCU * per_cu;
+    return units < g ? units : g;
+}
+
+template <int S>
+int launch_rfft_rows(const float* x, int x_ld, float* R, int B, hipStream_t s) {
+    const size_t lds = (size_t)S * 256 + (size_t)S * 4;
+    constexpr int NT = 1024;
+    int rc = set_lds(rfft_rows_any_kernel<S, NT>, lds);
+    if (rc != MTD_OK) return rc;
+    const int units = B * S / 2;
+    const int prof = mtd_prof_begin(2, 0, 1, (long long)B * S * S, 32, 32, 0, s, 4.0 * B * S * 32.0 * (S + 2.0 * (S / 2 + 1)));
+    MTD_LAUNCH((rfft_rows_any_kernel<S, NT>), dim3(persistent_grid(units, lds)), dim3(NT), lds, s, x, x_ld, R, units);
+    mtd_prof_end(prof, s);
+    return MTD_OK;
+}
+
+template <int S>
+int launch_spec_mix(const float* R, const float* w2t, const float* b2, float* T, int B, hipStream_t s) {
+    const size_t lds = (size_t)2 * S * CLD * 4 + (size_t)S * 4 + (64 * 64 + 64) * 4;
+    constexpr int NT = 1024;
+    int rc = set_lds(spec_mix_any_kernel<S, NT>, lds);
+    if (rc != MTD_OK) return rc;
+    const int units = B * (S / 2 + 1);
+    const int prof = mtd_prof_begin(2, 1, 1, (long long)B * S * (S / 2 + 1), 64, 64, 0, s, 2.0 * 4.0 * B * S * 64.0 * (S / 2 + 1));
+    MTD_LAUNCH((spec_mix_any_kernel<S, NT>), dim3(persistent_grid(units, lds)), dim3(NT), lds, s, R, w2t, b2, T, units);
+    mtd_prof_end(prof, s);
+    return MTD_OK;
+}
+
+template <int S>
+int launch_irfft_rows(const float* T, float* out, int out_ld, const float* add1, int add1_ld, const float* add2, int add2_ld, int B,
+                      hipStream_t s) {
+    const size_t lds = (size_t)S * 256 + (size_t)S * 4;
+    constexpr int NT = 1024;
+    int rc = set_lds(irfft_rows_any_kernel<S, NT>, lds);
+    if (rc != MTD_OK) return rc;
+    const int units = B * S / 2;
+    const int prof = mtd_prof_begin(2, 2, 1, (long long)B * S * S, 32, 32, 0, s,
+                                    4.0 * B * S * 32.0 * (2.0 * (S / 2 + 1) + S * (1.0 + (add1 ? 1 : 0) + (add2 ? 1 : 0))));
+    MTD_LAUNCH((irfft_rows_any_kernel<S, NT>), dim3(persistent_grid(units, lds)), dim3(NT), lds, s, T, out, out_ld, add1, add1_ld, add2,
+               add2_ld, units);
+    mtd_prof_end(prof, s);
+    return MTD_OK;
+}
+
 }  // namespace
+
+// (16-byte accesses: pixel strides in multiples of 4 floats, 16-byte aligned bases -- what the generator's NHWC tensors are)
+#define MTD_BY_SIDE(S, CALL64, CALL128, CALL256, CALL512) \
+    ((S) == 64 ? (CALL64) : (S) == 128 ? (CALL128) : (S) == 256 ? (CALL256) : (CALL512))
 
 extern "C" int mtd_rfft_rows_any(const float* x, int x_ld, float* R, int B, int S, void* stream) {
     const int logS = log2_exact(S);
     if (!x || !R || B <= 0 || logS < 6 || S > 512 || x_ld < 32) return MTD_EINVAL;
-    const size_t lds = (size_t)S * 256 + (size_t)S * 4;
-    int rc = set_lds(rfft_rows_any_kernel, lds);
+    if ((x_ld % 4) || !aligned16(x) || !aligned16(R)) return MTD_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = MTD_BY_SIDE(S, launch_rfft_rows<64>(x, x_ld, R, B, s), launch_rfft_rows<128>(x, x_ld, R, B, s),
+                         launch_rfft_rows<256>(x, x_ld, R, B, s), launch_rfft_rows<512>(x, x_ld, R, B, s));
     if (rc != MTD_OK) return rc;
-    // (launch profiler, kernel class 2 = the HBM-bound spectral kernels: bytes = every operand element once, no flops)
-    const int prof = mtd_prof_begin(2, 0, 1, (long long)B * S * S, 32, 32, 0, (hipStream_t)stream, 4.0 * B * S * 32.0 * (S + 2.0 * (S / 2 + 1)));
-    MTD_LAUNCH(rfft_rows_any_kernel, dim3(B * S / 2), dim3(1024), lds, (hipStream_t)stream, x, x_ld, R, S, logS);
-    mtd_prof_end(prof, (hipStream_t)stream);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }
@@ -272,12 +434,11 @@ extern "C" int mtd_rfft_rows_any(const float* x, int x_ld, float* R, int B, int 
 extern "C" int mtd_spec_mix_any(const float* R, const float* w2t, const float* b2, float* T, int B, int S, void* stream) {
     const int logS = log2_exact(S);
     if (!R || !w2t || !b2 || !T || B <= 0 || logS < 6 || S > 512) return MTD_EINVAL;
-    const size_t lds = (size_t)S * 256 + (size_t)S * 4;
-    int rc = set_lds(spec_mix_any_kernel, lds);
+    if (!aligned16(R) || !aligned16(T)) return MTD_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = MTD_BY_SIDE(S, launch_spec_mix<64>(R, w2t, b2, T, B, s), launch_spec_mix<128>(R, w2t, b2, T, B, s),
+                         launch_spec_mix<256>(R, w2t, b2, T, B, s), launch_spec_mix<512>(R, w2t, b2, T, B, s));
     if (rc != MTD_OK) return rc;
-    const int prof = mtd_prof_begin(2, 1, 1, (long long)B * S * (S / 2 + 1), 64, 64, 0, (hipStream_t)stream, 2.0 * 4.0 * B * S * 64.0 * (S / 2 + 1));
-    MTD_LAUNCH(spec_mix_any_kernel, dim3(B * (S / 2 + 1)), dim3(1024), lds, (hipStream_t)stream, R, w2t, b2, T, S, logS);
-    mtd_prof_end(prof, (hipStream_t)stream);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }
@@ -287,14 +448,15 @@ extern "C" int mtd_irfft_rows_any(const float* T, float* out, int out_ld, const 
     const int logS = log2_exact(S);
     if (!T || !out || B <= 0 || logS < 6 || S > 512 || out_ld < 32) return MTD_EINVAL;
     if ((add1 && add1_ld < 32) || (add2 && add2_ld < 32)) return MTD_EINVAL;
-    const size_t lds = (size_t)S * 256 + (size_t)S * 4;
-    int rc = set_lds(irfft_rows_any_kernel, lds);
+    if ((out_ld % 4) || !aligned16(T) || !aligned16(out) || (add1 && ((add1_ld % 4) || !aligned16(add1))) ||
+        (add2 && ((add2_ld % 4) || !aligned16(add2))))
+        return MTD_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = MTD_BY_SIDE(S, launch_irfft_rows<64>(T, out, out_ld, add1, add1_ld, add2, add2_ld, B, s),
+                         launch_irfft_rows<128>(T, out, out_ld, add1, add1_ld, add2, add2_ld, B, s),
+                         launch_irfft_rows<256>(T, out, out_ld, add1, add1_ld, add2, add2_ld, B, s),
+                         launch_irfft_rows<512>(T, out, out_ld, add1, add1_ld, add2, add2_ld, B, s));
     if (rc != MTD_OK) return rc;
-    const int prof = mtd_prof_begin(2, 2, 1, (long long)B * S * S, 32, 32, 0, (hipStream_t)stream,
-                                    4.0 * B * S * 32.0 * (2.0 * (S / 2 + 1) + S * (1.0 + (add1 ? 1 : 0) + (add2 ? 1 : 0))));
-    MTD_LAUNCH(irfft_rows_any_kernel, dim3(B * S / 2), dim3(1024), lds, (hipStream_t)stream, T, out, out_ld, add1, add1_ld, add2,
-               add2_ld, S, logS);
-    mtd_prof_end(prof, (hipStream_t)stream);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }

@@ -58,31 +58,35 @@ class DataParallelSync:
             dist.broadcast(t, src=0)
         return t
 
-    def _on_side(self, collective, tensor):
-        """Enqueue `collective` on the RCCL side stream, ordered after everything enqueued on the current stream so far.
-        Stream order and the call itself go through kernels.order_streams / kernels.rec, so a kernels.LaunchList that is
-        recording the step records them too (a replay re-issues the collective on the same tensor)."""
+    def _on_side(self, collective, tensor, after=()):
+        """Enqueue `collective` on the RCCL side stream, ordered after everything enqueued so far on the current stream and on
+        the streams in `after`.  Stream order and the call itself go through kernels.order_streams / kernels.rec, so a
+        kernels.LaunchList that is recording the step records them too (a replay re-issues the collective on the same tensor)."""
         from . import kernels as K
         K.order_streams(self.side, torch.cuda.current_stream())
+        for st in after:
+            K.order_streams(self.side, st)
         tensor.record_stream(self.side)
         with torch.cuda.stream(self.side):
             K.rec(collective)
         self._pending = True
 
-    def all_reduce_avg(self, flat):
+    def all_reduce_avg(self, flat, after=()):
         """Average `flat` (a contiguous tensor) across ranks.  On GPUs the collective runs on a side stream
-        ordered after the kernels already enqueued on the current stream; wait() joins it back."""
+        ordered after the kernels already enqueued on the current stream and on the streams in `after` (the weight-gradient
+        side stream that fills a task vector: the collective waits for it, the main stream does not have to); wait() joins
+        the collectives back."""
         if self.world == 1 and not self.force:
             return
         if self.cuda:
             if self.has_avg:
                 # RCCL scales inside the collective: no extra pass over 114 MB
-                self._on_side(lambda: dist.all_reduce(flat, op=dist.ReduceOp.AVG), flat)
+                self._on_side(lambda: dist.all_reduce(flat, op=dist.ReduceOp.AVG), flat, after)
             else:
                 def sum_and_scale():
                     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
                     flat.mul_(1.0 / self.world)
-                self._on_side(sum_and_scale, flat)
+                self._on_side(sum_and_scale, flat, after)
             # consumers of `flat` are enqueued later on the current stream, after wait(): the overlap window is the backward
             # kernels issued before the next consumer (PCGrad's Gram kernel is the first, after all three tasks)
         else:

@@ -168,8 +168,7 @@ class DStepTape:
         consistency12(consistency34(), ship if dp is not None and EARLY_SHIP else None)  # task 2
         if shipped["tail"]:
             if dp is not None:
-                K.side_stream(dev).join()
-                dp.all_reduce_avg(S[2, :tail_ofs])
+                dp.all_reduce_avg(S[2, :tail_ofs], after=self._side_of(dev))
         else:
             self._sync_task(dp, S, 2)
         K.side_stream(dev).join()              # weight gradients / spectral-norm corrections ran on the side stream
@@ -218,10 +217,18 @@ class DStepTape:
         return sum(sizes[:first])
 
     @staticmethod
-    def _sync_task(dp, S, i):
+    def _side_of(dev):
+        sd = K.side_stream(dev)
+        return (sd.stream,) if sd.enabled else ()
+
+    @classmethod
+    def _sync_task(cls, dp, S, i):
+        # The task vector is complete once the side-stream weight gradients (and their spectral-norm correction) are: the
+        # COLLECTIVE waits for that stream.  The main stream does not -- it goes on with the next task's data-gradient chain
+        # while this task's last weight gradients run (round 3 joined the side stream here: +1.2 ms per iteration at N = 1
+        # with every collective live, profiles/r4_forced_dp_*.json).
         if dp is not None:
-            K.side_stream(S.device).join()     # the task vector is complete once the side-stream weight gradients are
-            dp.all_reduce_avg(S[i])            # overlaps with the next task's backward (separate stream)
+            dp.all_reduce_avg(S[i], after=cls._side_of(S.device))   # overlaps with the next task's backward (separate stream)
 
 
 _orders_slots = {}

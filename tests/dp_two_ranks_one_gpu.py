@@ -182,6 +182,48 @@ def child(rank, world):
     both = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(both, h)
     check(all(torch.equal(both[0], b) for b in both), f"ranks diverged: {[b.tolist() for b in both]}")
+    # ---- round 4: the RECORDED launch list under data parallelism.  Five more iterations per rank on fresh models, once with
+    # every iteration eager and once as engine.train_MTD_GAN_Ours runs them by default (two eager, one recorded, two replayed:
+    # the collectives, the broadcast of rank 0's projection order and the stream hand-offs are part of the list): the two
+    # must agree BIT FOR BIT on every rank (dropout on, drawn from torch's generator), and the ranks with each other.
+    from mtd_gan_amd import train_step as TS
+    finals = {}
+    for mode in ("eager", "list"):
+        mm = MTD_GAN_Method()
+        mm.load_state_dict(full)
+        mm.to(dev).train()
+        wm2 = WeightMethods("pcgrad", n_tasks=3, device=dev)
+        dp2 = parallel.DataParallelSync(dev)
+        dp2.broadcast_module(mm)
+        wm2.method.dp = dp2
+        oD2 = FusedAdamW(mm.Discriminator.parameters(), lr=z["lr"], **kw)
+        oG2 = FusedAdamW(mm.Generator.parameters(), lr=z["lr"], **kw)
+        random.seed(5 + 100 * rank)
+        torch.manual_seed(900 + rank)
+        TS.LIST_MODE = mode == "list"
+        loader = [dict(n_20=x[lo:hi].roll(i, 0), n_100=y[lo:hi].roll(i, 0)) for i in range(5)]
+        st5 = engine.train_MTD_GAN_Ours(mm, loader, oG2, oD2, dev, 0, 0, per, wm2)
+        torch.cuda.synchronize()
+        if mode == "list":
+            check(isinstance(getattr(mm, "_mtd_recorded", None), TS.RecordedTrainStep) and mm._mtd_recorded.iterations == 3,      # (the recorded iteration + two replays)
+                  f"list mode did not replay: {getattr(mm, '_mtd_recorded', None)}")
+        finals[mode] = ({k: v.clone() for k, v in mm.state_dict().items()}, st5)
+        del mm, oD2, oG2
+    TS.LIST_MODE = True
+    check(finals["eager"][1] == finals["list"][1], f"5-iteration stats differ: {finals['eager'][1]} vs {finals['list'][1]}")
+    ndiff = sum(0 if torch.equal(finals["eager"][0][k], finals["list"][0][k]) else 1 for k in finals["eager"][0])
+    check(ndiff == 0, f"{ndiff} tensors differ between eager and replayed iterations")
+    h5 = torch.zeros(2, dtype=torch.float64)
+    for k, v in finals["list"][0].items():
+        if v.is_floating_point():
+            vv = v.double().reshape(-1)
+            h5[0] += vv.sum().cpu()
+            h5[1] += (vv * vv).sum().cpu()
+    both5 = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(both5, h5)
+    check(all(torch.equal(both5[0], b) for b in both5), f"ranks diverged after replays: {[b.tolist() for b in both5]}")
+    print(f"[dp2 rank {rank}] recorded-list rehearsal: 5 iterations (2 eager + 1 recorded + 2 replayed) == 5 eager, {ndiff} tensors differ; "
+          f"ranks identical: {all(torch.equal(both5[0], b) for b in both5)}", flush=True)
     print(f"[dp2 rank {rank}] step {dt * 1e3:.0f} ms (first step, gloo through the host); gram err {gerr:.2e}, pcgrad-weight err {werr:.2e}, "
           f"worst stat err {serr:.2e}, post-step samples off {len(bad)}/{4 * len(z['post_samples'])}, PSNR {psnr:.4f} dB "
           f"(reference {z['post_metrics']['psnr']:.4f}); {'OK' if not fails else 'FAILED: ' + '; '.join(fails)}", flush=True)

@@ -27,7 +27,8 @@ if args.procs > 1:
     ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True) for _ in range(args.procs)]
     outs = [p.communicate()[0] for p in ps]
     for i, o in enumerate(outs):
-        print(f"[proc {i}] " + (o.strip().splitlines() or ["<no output>"])[-1])
+        for ln in [l for l in o.splitlines() if l.startswith(("list replay", "  replay into", "host enqueue"))] or ["<no output>"]:
+            print(f"[proc {i}] " + ln)
     sys.exit(max(p.returncode for p in ps))
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
