@@ -40,7 +40,9 @@ __device__ __forceinline__ void twiddle(const float* tw, int hS, int idx, float&
     sn = (SIGN < 0) ? -tw[hS + idx] : tw[hS + idx];
 }
 
-template <int SIGN, bool DIF, int LD>
+// (NT = threads per workgroup as a compile-time constant: the butterfly loops then have constant trip counts and are unrolled
+// by UNR, so that the LDS reads of UNR butterflies are in flight together)
+template <int SIGN, bool DIF, int LD, int NT = 1024, int UNR = 2>
 __device__ __forceinline__ void lds_fft(float* re, float* im, const float* tw, int S, int logS) {
     const int hS = S >> 1;
     int st = 0;
@@ -48,7 +50,8 @@ __device__ __forceinline__ void lds_fft(float* re, float* im, const float* tw, i
     if (logS & 1) {
         const int lh = DIF ? (logS - 1) : 0;
         const int half = 1 << lh, tshift = logS - 1 - lh;
-        for (int e = threadIdx.x; e < hS * 32; e += blockDim.x) {
+#pragma unroll UNR
+        for (int e = threadIdx.x; e < hS * 32; e += (NT > 0 ? NT : (int)blockDim.x)) {
             const int c = e & 31, pidx = e >> 5;
             const int grp = pidx >> lh, j = pidx & (half - 1);
             const int i0 = (((grp << 1) << lh) + j) * LD + c, i1 = i0 + half * LD;
@@ -75,7 +78,8 @@ __device__ __forceinline__ void lds_fft(float* re, float* im, const float* tw, i
             const int lH = logS - 1 - st;             // log2(H)
             const int H = 1 << lH, Q = H >> 1;
             const int ts1 = logS - 1 - lH, ts2 = ts1 + 1;
-            for (int e = threadIdx.x; e < nq; e += blockDim.x) {
+#pragma unroll UNR
+            for (int e = threadIdx.x; e < nq; e += (NT > 0 ? NT : (int)blockDim.x)) {
                 const int c = e & 31, q = e >> 5;
                 const int blk = q >> (lH - 1), j = q & (Q - 1);
                 const int ia = ((blk << (lH + 1)) + j) * LD + c, ib = ia + Q * LD, ic = ia + H * LD, id = ic + Q * LD;
@@ -98,7 +102,8 @@ __device__ __forceinline__ void lds_fft(float* re, float* im, const float* tw, i
             const int lh = st;
             const int h = 1 << lh;
             const int ts1 = logS - 1 - lh, ts2 = ts1 - 1;
-            for (int e = threadIdx.x; e < nq; e += blockDim.x) {
+#pragma unroll UNR
+            for (int e = threadIdx.x; e < nq; e += (NT > 0 ? NT : (int)blockDim.x)) {
                 const int c = e & 31, q = e >> 5;
                 const int blk = q >> lh, j = q & (h - 1);
                 const int ia = ((blk << (lh + 2)) + j) * LD + c, ib = ia + h * LD, ic = ib + h * LD, id = ic + h * LD;
@@ -123,6 +128,23 @@ __device__ __forceinline__ void lds_fft(float* re, float* im, const float* tw, i
     }
 }
 
+// Lab knobs (compile time; tools/any_variants.sh builds and times them on the GPU box).  Measured at S = 512, B = 8, ms per 21
+// blocks (rows / columns / rows back): default 2.50 / 6.69 / 4.52; butterfly loops with compile-time trip counts
+// (-DMTD_ANY_CT) 2.54 / 8.27 / 4.54 and unrolled by 2 (-DMTD_ANY_UNR=2) 2.54 / 8.08 / 4.52 -- the compiler then keeps more
+// butterflies in flight than a lane's 128 registers hold and spills; 512 threads per workgroup (-DMTD_ANY_NT512=512: 256
+// registers per lane, no spills) 2.63 / 6.82 / 4.82.
+#ifndef MTD_ANY_NT512
+#define MTD_ANY_NT512 1024
+#endif
+#ifndef MTD_ANY_UNR
+#define MTD_ANY_UNR 1
+#endif
+constexpr int FFT_UNR = MTD_ANY_UNR;
+#ifdef MTD_ANY_CT       // trip counts of the butterfly loops from the template constant instead of blockDim.x
+#define FFT_NT(NT) NT
+#else
+#define FFT_NT(NT) 0
+#endif
 constexpr int NCU = 256;       // MI355X: persistent grids are sized in workgroups per CU
 
 template <int S> struct Log2 { static constexpr int v = 1 + Log2<S / 2>::v; };
@@ -159,7 +181,7 @@ __global__ __launch_bounds__(NT) void rfft_rows_any_kernel(const float* __restri
         }
         __syncthreads();
         if (u + (int)gridDim.x < units) issue(u + gridDim.x);                  // lands under this pair's transform
-        lds_fft<-1, true, 32>(re, im, tw, S, logS);
+        lds_fft<-1, true, 32, FFT_NT(NT), FFT_UNR>(re, im, tw, S, logS);
         const int b = u / (S / 2), h = (u % (S / 2)) * 2;
         const float sc = 0.5f * rsqrtf((float)S);
         for (int it = tid; it < nkw * 8; it += NT) {
@@ -213,8 +235,7 @@ __global__ __launch_bounds__(NT) void spec_mix_any_kernel(const float* __restric
             }
         }
         __syncthreads();
-        if (u + (int)gridDim.x < units) issue(u + gridDim.x);
-        lds_fft<-1, true, CLD>(re, im, tw, S, logS);
+        lds_fft<-1, true, CLD, FFT_NT(NT), FFT_UNR>(re, im, tw, S, logS);
         // channel mix at every frequency on the matrix cores: D[o][n] = sum_k W[k][o] * Z[n][k], k = (re 0..31 | im 32..63).
         // A operand: lane (o = l & 31, k = l >> 5) of W from LDS; B operand: lane (n = l & 31, k = l >> 5) of the column.
         // work items = (32-row tile, output half): S / 32 * 2 over the 16 waves; results stay in registers until every
@@ -252,7 +273,10 @@ __global__ __launch_bounds__(NT) void spec_mix_any_kernel(const float* __restric
             }
         }
         __syncthreads();
-        lds_fft<+1, false, CLD>(re, im, tw, S, logS);
+        // the next column's loads: issued here, after the mix (their 32 registers are not live under its accumulators -- with
+        // 1024 threads a lane has 128), they land under the inverse transform
+        if (u + (int)gridDim.x < units) issue(u + gridDim.x);
+        lds_fft<+1, false, CLD, FFT_NT(NT), FFT_UNR>(re, im, tw, S, logS);
         float* dstg = T + (long long)u * S * 64;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -319,10 +343,10 @@ __global__ __launch_bounds__(NT) void irfft_rows_any_kernel(const float* __restr
         }
         __syncthreads();
         if (u + (int)gridDim.x < units) issue(u + gridDim.x);
-        lds_fft<+1, false, 32>(re, im, tw, S, logS);
+        lds_fft<+1, false, 32, FFT_NT(NT), FFT_UNR>(re, im, tw, S, logS);
         const int b = u / (S / 2), h = (u % (S / 2)) * 2;
         const long long rowpix = (long long)(b * S + h) * S;                  // rows h, h + 1: 2 S consecutive pixels
-        constexpr int CH = NV < 4 ? NV : 4;                                   // residual operands in chunks: 2 x CH vectors in flight
+        constexpr int CH = NV < 2 ? NV : 2;                                   // residual operands in chunks: 2 x CH vectors in flight
 #pragma nounroll
         for (int j0 = 0; j0 < NV; j0 += CH) {
             f32x4 a1[CH], a2[CH];
@@ -374,7 +398,7 @@ inline int persistent_grid(int units, size_t lds_bytes) {
 template <int S>
 int launch_rfft_rows(const float* x, int x_ld, float* R, int B, hipStream_t s) {
     const size_t lds = (size_t)S * 256 + (size_t)S * 4;
-    constexpr int NT = 1024;
+    constexpr int NT = S >= 512 ? MTD_ANY_NT512 : 1024;
     int rc = set_lds(rfft_rows_any_kernel<S, NT>, lds);
     if (rc != MTD_OK) return rc;
     const int units = B * S / 2;
@@ -387,7 +411,7 @@ int launch_rfft_rows(const float* x, int x_ld, float* R, int B, hipStream_t s) {
 template <int S>
 int launch_spec_mix(const float* R, const float* w2t, const float* b2, float* T, int B, hipStream_t s) {
     const size_t lds = (size_t)2 * S * CLD * 4 + (size_t)S * 4 + (64 * 64 + 64) * 4;
-    constexpr int NT = 1024;
+    constexpr int NT = S >= 512 ? MTD_ANY_NT512 : 1024;
     int rc = set_lds(spec_mix_any_kernel<S, NT>, lds);
     if (rc != MTD_OK) return rc;
     const int units = B * (S / 2 + 1);
@@ -401,7 +425,7 @@ template <int S>
 int launch_irfft_rows(const float* T, float* out, int out_ld, const float* add1, int add1_ld, const float* add2, int add2_ld, int B,
                       hipStream_t s) {
     const size_t lds = (size_t)S * 256 + (size_t)S * 4;
-    constexpr int NT = 1024;
+    constexpr int NT = S >= 512 ? MTD_ANY_NT512 : 1024;
     int rc = set_lds(irfft_rows_any_kernel<S, NT>, lds);
     if (rc != MTD_OK) return rc;
     const int units = B * S / 2;
