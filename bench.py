@@ -32,6 +32,14 @@ PER_GPU_BATCH = 32
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA peak (dense)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E
 WINOGRAD_EXECUTED = 4.0 / 9.0     # csrc/conv_winograd.hip: 16 multiplications per 2 x 2 output tile instead of 36
+WINOGRAD_F24_EXECUTED = 3.0 / 9.0     # ... and F(2x4, 3x3), wino_conv_kernel<.., 6>: 24 per 2 x 4 tile instead of 72
+
+
+def executed_fraction(kernel):
+    """Share of a layer's algorithmic multiplications (2 M N C 9) that the kernel's MFMAs execute."""
+    if "wino" not in kernel:
+        return 1.0
+    return WINOGRAD_F24_EXECUTED if kernel.endswith(", 6>") else WINOGRAD_EXECUTED
 
 
 def parse(argv=None):
@@ -286,7 +294,7 @@ def roofline_pass(wl, steps, pmc_tag):
             d["ms"] += r["ms"]
             d["flops"] += r["flops"]
             # the Winograd kernel executes 16 of the 36 multiplications per 2 x 2 output tile that the layer's definition counts
-            d["exec"] += r["flops"] * (WINOGRAD_EXECUTED if "wino" in r["kernel"] else 1.0)      # (wino_conv_kernel, wgrad_wino_kernel)
+            d["exec"] += r["flops"] * executed_fraction(r["kernel"])      # (wino_conv_kernel, wgrad_wino_kernel)
             d["bytes"] += r["bytes"]
             d["n"] += 1
             key = f"M{r['M']}_N{r['N']}_C{r['C']}_T{r['taps']}_S{r['splitk']}"
@@ -330,11 +338,13 @@ def roofline_pass(wl, steps, pmc_tag):
                            "nothing subtracted)" if attach == 1 else "HIP events recorded before / after the launch (includes the marker packets; nothing subtracted)"),
                 "flops_per_launch": round(d["exec"] / d["n"]), "algorithmic_flops_per_launch": round(d["flops"] / d["n"]),
                 "algorithmic_tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2),
-                "flop_model": ("Winograd F(2x2,3x3): executed MFMA flops = 2 M N C 4 per launch (`achieved`, `flops_per_launch`, `frac`); the layer's "
+                "flop_model": ("Winograd F(2x4,3x3): executed MFMA flops = 2 M N C 3 per launch (`achieved`, `flops_per_launch`, `frac`); the layer's "
+                               "algorithmic count is 2 M N C 9 (`algorithmic_*`)" if executed_fraction(name) == WINOGRAD_F24_EXECUTED else
+                               "Winograd F(2x2,3x3): executed MFMA flops = 2 M N C 4 per launch (`achieved`, `flops_per_launch`, `frac`); the layer's "
                                "algorithmic count is 2 M N C 9 (`algorithmic_*`)" if "wino" in name else "executed = algorithmic = 2 M N C taps"),
                 "measured": "second pass of the same steps, all kernels in one stream",
                 "share_of_step_gpu_ms": round(d["ms"] / steps, 3),
-                "top_shapes": {k: {"us": round(1e3 * v[0] / v[2], 2), "tflops": round(v[1] / v[0] / 1e9 * (WINOGRAD_EXECUTED if "wino" in name else 1.0), 2),
+                "top_shapes": {k: {"us": round(1e3 * v[0] / v[2], 2), "tflops": round(v[1] / v[0] / 1e9 * executed_fraction(name), 2),
                                    "launches_per_step": v[2] // steps} for k, v in top},
                 # (executed MFMA flops, like `achieved`: the two Winograd kernels at 4 / 9 of their layers' algorithmic count)
                 "other_mfma_kernels": {k: {"tflops": round(v["exec"] / v["ms"] / 1e9, 2), "ms_per_step": round(v["ms"] / steps, 3)}

@@ -98,10 +98,16 @@ int mtd_conv_igemm(const mtd_conv_args* a, void* stream);
  *                          kmap[a*3+b] = index in the kh x kw plane of the filter entry that multiplies input offset
  *                          (-1+a, -1+b) (mtd_winograd_kmap derives it from a geometry: a forward conv and the data
  *                          gradient of the same layer use different maps); table in device memory + the same on the host.
- *   mtd_conv_winograd      a->w = the transformed weights (w_sn / w_sc / w_st ignored).  Requires 3x3, stride 1, OH x OW ==
+ *   mtd_conv_winograd      a->w = the transformed weights (w_sn / w_sc ignored; w_st = 6 says they are the F(2x4, 3x3) form).  Requires 3x3, stride 1, OH x OW ==
  *                          IH x IW both even, C % 16 == 0, N % 64 == 0, no out2: mtd_conv_winograd_ok(). */
-typedef struct { const float* src; float* dst; long long sn, sc, st; int N, C; int kmap[9]; int pad_; } mtd_wino_weight_desc;
-size_t mtd_winograd_weight_floats(int N, int C);
+/* px: patch width of the transform along x -- 6: F(2x4, 3x3) (round 4: F(2,3) down the rows, F(4,3) along them, 24 positions,
+ * 3 multiplications per output pixel; dst holds 24 N C floats), 0 or 4: F(2x2, 3x3) (16 N C floats).  A conv launch says which
+ * weights it was given through a->w_st (6 or not); mtd_conv_winograd_patch_w tells the caller which form the library's plan
+ * wants for a layer (0: not in the Winograd domain at all). */
+typedef struct { const float* src; float* dst; long long sn, sc, st; int N, C; int kmap[9]; int px; } mtd_wino_weight_desc;
+size_t mtd_winograd_weight_floats(int N, int C);      /* 24 N C: enough for either form */
+int mtd_conv_winograd_patch_w(const mtd_conv_args* a);
+int mtd_conv_winograd_f4_min_w(int min_w);      /* tuning / test hook: narrowest map width that takes F(2x4, 3x3); 0 = never, < 0 = query; returns the previous value */
 int mtd_winograd_kmap(const mtd_geom* g, int* kmap9);
 int mtd_winograd_weights(const mtd_wino_weight_desc* table_dev, const mtd_wino_weight_desc* table_host, int count, void* stream);
 int mtd_conv_winograd_ok(const mtd_conv_args* a);

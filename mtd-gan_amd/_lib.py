@@ -50,7 +50,7 @@ class PackDesc(C.Structure):
 
 class WinoWeightDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("sn", C.c_longlong), ("sc", C.c_longlong), ("st", C.c_longlong),
-                ("N", C.c_int), ("C", C.c_int), ("kmap", C.c_int * 9), ("pad_", C.c_int)]
+                ("N", C.c_int), ("C", C.c_int), ("kmap", C.c_int * 9), ("px", C.c_int)]
 
 
 class SnLayer(C.Structure):
@@ -112,7 +112,7 @@ def _preload_torch_hip_runtime():
 
 
 RECORDER = None      # kernels.LaunchList: while a step is being recorded, the list every launch is appended to
-_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "mtd_prof_", "_override", "_bwd_ok", "_stamps", "_zmask_bytes", "_tail_ok", "_winograd_ok", "_weight_floats", "_kmap", "_plan_cfg", "_pair_ok", "_pair_mode")
+_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "mtd_prof_", "_override", "_bwd_ok", "_stamps", "_zmask_bytes", "_tail_ok", "_winograd_ok", "_weight_floats", "_kmap", "_plan_cfg", "_pair_ok", "_pair_mode", "_patch_w", "_f4_min_w")
 
 
 class _RecordingLib:
@@ -246,6 +246,8 @@ def lib():
     sig("mtd_winograd_kmap", ci, C.POINTER(Geom), C.POINTER(C.c_int))
     sig("mtd_winograd_weights", ci, vp, vp, ci, vp)
     sig("mtd_conv_winograd_ok", ci, C.POINTER(ConvArgs))
+    sig("mtd_conv_winograd_patch_w", ci, C.POINTER(ConvArgs))
+    sig("mtd_conv_winograd_f4_min_w", ci, ci)
     sig("mtd_conv_winograd_ws_bytes", sz, C.POINTER(ConvArgs))
     sig("mtd_conv_winograd", ci, C.POINTER(ConvArgs), vp)
     sig("mtd_pcgrad_coeff", ci, vp, vp, ci, vp, vp)
@@ -270,7 +272,7 @@ EXPORTS = [
     "mtd_spec_mix_zmask_bytes", "mtd_spec_mix_fwd4", "mtd_spec_mix_bwd4",
     "mtd_resfft_block_tail_ok", "mtd_resfft_block_tail", "mtd_conv_c32_bwd_irfft",
     "mtd_winograd_weight_floats", "mtd_winograd_kmap", "mtd_winograd_weights", "mtd_conv_winograd_ok", "mtd_conv_winograd_ws_bytes", "mtd_conv_winograd",
-    "mtd_conv_wgrad_plan_cfg", "mtd_dropout_mask", "mtd_scale_by", "mtd_scalar_sums", "mtd_zero_multi",
+    "mtd_conv_wgrad_plan_cfg", "mtd_conv_winograd_patch_w", "mtd_conv_winograd_f4_min_w", "mtd_dropout_mask", "mtd_scale_by", "mtd_scalar_sums", "mtd_zero_multi",
 ]
 
 

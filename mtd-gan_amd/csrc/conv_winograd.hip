@@ -28,6 +28,16 @@
 //     to slabs [split][M][N] and conv_igemm.hip's splitk_epilogue_kernel finishes them, as for the implicit GEMM.
 // Roofline: fp32 MFMA.  Algorithmic flops of the layer = 2 M N C 9 (what the caller asked for); executed MFMA flops =
 // 2 M N C 4; both are reported to the launch profiler's reader (bench.py).
+//
+// Round 4: F(2x4, 3x3) -- F(2,3) down the rows as before, F(4,3) ALONG them (template parameter PX = 6, the patch width): 2 x 4
+// output tiles from 4 x 6 patches, 24 positions = three per wave, 24 multiplications per 8 output pixels = 3 per pixel instead
+// of 4: a quarter of the MFMA work of the large layers gone (executed = 2 M N C 3).  Everything that made the F(2x2) kernel
+// fast carries over unchanged because the patch still has FOUR rows: a row per lane of a quad, the column transform by DPP,
+// the K loop's single path, the weight fragments straight from L2.  A thread loads six pixels of its row instead of four and
+// applies the 6-point B^T of F(4,3) (interpolation points 0, +-1, +-2, inf) in registers.  fp32 error against float64 on the
+// discriminator's layers 1.4e-6 .. 2.5e-6 of the output's max-abs (F(2x2): 3e-7 .. 6e-7, direct fp32: 3e-7; a full F(4x4, 3x3)
+// would be 6e-6 .. 1.3e-5 -- tools/winograd_f24_probe.py), far inside the 1e-3 parity bound.  Maps whose width is a multiple
+// of 4 (and at least wino_plan's threshold) take it; NB = 2 only (three positions x two n blocks = 96 accumulator registers).
 #define MTD_NO_API 1
 #include "conv_igemm.hip"
 
@@ -51,13 +61,14 @@ struct WinoWDesc {
     long long sn, sc, st;     // W(n, c, kidx) = src[n * sn + c * sc + kidx * st]
     int N, C;
     int kmap[9];
-    int pad_;
+    int px;                   // patch width of the transform along x: 6 = F(4,3), anything else = F(2,3) (4)
 };
 
 __global__ __launch_bounds__(256) void wino_weights_kernel(const WinoWDesc* __restrict__ tab, int count) {
     for (int d = blockIdx.y; d < count; d += gridDim.y) {
         const WinoWDesc w = tab[d];
         const long long total = (long long)w.N * w.C;
+        const int PXr = w.px == 6 ? 6 : 4;
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
             // destination order: c8 fastest within (n), so consecutive threads write consecutive floats
             const int c8 = (int)(i & 7);
@@ -71,7 +82,8 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const WinoWDesc* __re
             for (int a = 0; a < 3; ++a)
 #pragma unroll
                 for (int b = 0; b < 3; ++b) g[a][b] = s[(long long)w.kmap[a * 3 + b] * w.st];
-            // t = G g  (4 x 3), u = t G^T (4 x 4);  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+            // t = G g  (4 x 3), u = t Gx^T (4 x PX);  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1] down the rows,
+            // Gx = G (F(2,3)) or [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1] (F(4,3)) along them
             float t[4][3];
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
@@ -80,15 +92,26 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const WinoWDesc* __re
                 t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
                 t[3][b] = g[2][b];
             }
+            const long long xs = (long long)(w.C / 8) * w.N * 8;          // stride between positions xi = a * PX + b
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]), u3 = t[a][2];
-                float* o = w.dst + (((long long)(a * 4) * (w.C / 8) + ck) * w.N + n) * 8 + c8;
-                const long long xs = (long long)(w.C / 8) * w.N * 8;      // stride between positions xi
-                o[0] = u0;
-                o[xs] = u1;
-                o[2 * xs] = u2;
-                o[3 * xs] = u3;
+                float* o = w.dst + (((long long)(a * PXr) * (w.C / 8) + ck) * w.N + n) * 8 + c8;
+                const float t0 = t[a][0], t1 = t[a][1], t2 = t[a][2];
+                if (PXr == 6) {
+                    const float e = (t0 + t2) * (1.f / 6.f), f = t1 * (1.f / 6.f);           // (t0 + t2) / 6, t1 / 6
+                    const float h = t0 * (1.f / 24.f) + t2 * (1.f / 6.f), k = t1 * (1.f / 12.f);
+                    o[0] = 0.25f * t0;
+                    o[xs] = -e - f;
+                    o[2 * xs] = -e + f;
+                    o[3 * xs] = h + k;
+                    o[4 * xs] = h - k;
+                    o[5 * xs] = t2;
+                } else {
+                    o[0] = t0;
+                    o[xs] = 0.5f * (t0 + t1 + t2);
+                    o[2 * xs] = 0.5f * (t0 - t1 + t2);
+                    o[3 * xs] = t2;
+                }
             }
         }
     }
@@ -98,12 +121,17 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const WinoWDesc* __re
 // LEAN (NB = 2): at most 128 registers, so TWO workgroups share a CU (2 x 80 KB of LDS) and one's prologue / epilogue / waits run
 // under the other's MFMAs -- for the layers with few K steps (C <= 128) or N = 64, where a lone workgroup per CU spends as long
 // outside its K loop as inside.  One weight-fragment register set instead of two.
-template <int NB, bool LEAN = false>
+// PX: patch width.  4 = F(2x2, 3x3): 16 positions, two per wave; 6 = F(2x4, 3x3): 24 positions, three per wave (NB = 2, not LEAN).
+template <int NB, bool LEAN = false, int PX = 4>
 __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const WinoParams wp) {
-    // As: two buffers of 16 positions x 32 tiles x 16 channels (row stride WALD floats, 40 KB each); the exchange image of the
-    // epilogue (16 x 32 x WXLD floats = 72 KB) reuses the same memory after the K loop.
-    constexpr int AS_BUF = 16 * WT * WALD;
-    constexpr int X_SIZE = 16 * WT * WXLD;
+    constexpr int NP = 4 * PX;            // transform positions xi = PX * (patch row) + (patch column)
+    constexpr int PW = NP / 8;            // positions per wave
+    constexpr int TWX = PX - 2;           // output pixels per tile row
+    static_assert(PX == 4 || (PX == 6 && NB == 2 && !LEAN), "F(2x4, 3x3): NB = 2, one workgroup per CU");
+    // As: two buffers of NP positions x 32 tiles x 16 channels (row stride WALD floats, 40 / 60 KB each); the exchange image of
+    // the epilogue (NP x 32 x WXLD floats = 72 / 108 KB) reuses the same memory after the K loop.
+    constexpr int AS_BUF = NP * WT * WALD;
+    constexpr int X_SIZE = NP * WT * WXLD;
     __shared__ __attribute__((aligned(16))) float Ls[(2 * AS_BUF > X_SIZE) ? 2 * AS_BUF : X_SIZE];
     const IgemmParams& p = wp.p;
     const mtd_conv_args& a = p.a;
@@ -144,12 +172,12 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
     const int st_last = st_end - 1;
 
     // ---- transform role: thread (tile tt, channel quad tq, patch row ti) -- the four rows of a patch are the four lanes of a
-    // quad.  A thread loads its row as four 16-byte vectors (4 channels x 4 pixels: a quarter of the vector-memory and LDS
+    // quad.  A thread loads its row as PX 16-byte vectors (4 channels x PX pixels: a quarter of the vector-memory and LDS
     // instructions of a dword-per-lane form, which had the K loop waiting on instruction issue), applies B along the row in
-    // registers and B^T across the quad with DPP, and stores row ti of the 4 x 4 result as four 16-byte vectors.
+    // registers and B^T across the quad with DPP, and stores row ti of the 4 x PX result as PX 16-byte vectors.
     const int ti = tid & 3, tq = (tid >> 2) & 3, tt = tid >> 4;
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)p.in_bytes, 0x00020000);
-    unsigned pbase, pvalid = 0;            // offset of patch pixel (ti, 0), channels 4 tq ..; validity of the row's four pixels
+    unsigned pbase, pvalid = 0;            // offset of patch pixel (ti, 0), channels 4 tq ..; validity of the row's PX pixels
     {
         const int tg = tile0 + tt;
         const bool tv = tg < wp.ntiles;
@@ -157,73 +185,85 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
         const int r = tg - b * wp.tiles_per_image;
         const int ty = r / wp.tiles_x, tx = r - ty * wp.tiles_x;
         const int iy = 2 * ty - 1 + ti;
-        // (pixel (iy, 2 tx - 1) may lie outside the image: the offset is formed modulo 2^32, every VALID pixel's is in range)
-        pbase = (unsigned)(((((long long)b * g.IH + iy) * g.IW + (2 * tx - 1)) * a.in_ld + 4 * tq) * 4);
+        // (pixel (iy, TWX tx - 1) may lie outside the image: the offset is formed modulo 2^32, every VALID pixel's is in range)
+        pbase = (unsigned)(((((long long)b * g.IH + iy) * g.IW + (TWX * tx - 1)) * a.in_ld + 4 * tq) * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ix = 2 * tx - 1 + j;
+        for (int j = 0; j < PX; ++j) {
+            const int ix = TWX * tx - 1 + j;
             if (tv & ((unsigned)iy < (unsigned)g.IH) & ((unsigned)ix < (unsigned)g.IW)) pvalid |= 1u << j;
         }
     }
     const int px_b = a.in_ld * 4;          // byte displacement of one pixel
-    f32x4 d[4];
+    f32x4 d[PX];
     auto load_patch = [&](int st) {        // step st (absolute, clamped by the caller): channels 16 st + 4 tq .. + 3
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < PX; ++j) {
             const unsigned vo = ((pvalid >> j) & 1u) ? pbase + (unsigned)(j * px_b) : 0x80000000u;
             d[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, vo, st * 64, 0));
         }
     };
-    // B^T d B -> As[xi = 4 ti + j][tt][4 tq ..]: columns j0, j0 + 1 of the result (the K loop places the halves between MFMA groups)
+    // B^T d B -> As[xi = PX ti + j][tt][4 tq ..]: columns j0, j0 + 1 of the result (the K loop places the pairs between MFMA groups)
     const float qsign = ti == 1 ? 1.f : -1.f;
     auto quad_get = [&](float v, int ctrl) {
         const int x = __builtin_bit_cast(int, v);
         return __builtin_bit_cast(float, ctrl == 0 ? __builtin_amdgcn_update_dpp(0, x, 0x64, 0xf, 0xf, true)      // lanes [0, 1, 2, 1]
                                                   : __builtin_amdgcn_update_dpp(0, x, 0xDA, 0xf, 0xf, true));    // lanes [2, 2, 1, 3]
     };
+    auto row_value = [&](int j) -> f32x4 {        // (d B)[j] along the row
+        if constexpr (PX == 4) {
+            return j == 0 ? d[0] - d[2] : (j == 1 ? d[1] + d[2] : (j == 2 ? d[2] - d[1] : d[1] - d[3]));
+        } else {
+            // F(4,3):  B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+            if (j == 0) return 4.f * d[0] - 5.f * d[2] + d[4];
+            if (j == 1) return (d[4] - 4.f * d[2]) + (d[3] - 4.f * d[1]);
+            if (j == 2) return (d[4] - 4.f * d[2]) - (d[3] - 4.f * d[1]);
+            if (j == 3) return (d[4] - d[2]) + 2.f * (d[3] - d[1]);
+            if (j == 4) return (d[4] - d[2]) - 2.f * (d[3] - d[1]);
+            return 4.f * d[1] - 5.f * d[3] + d[5];
+        }
+    };
     auto transform_cols = [&](float* As, int j0) {
         float* o = As + tt * WALD + 4 * tq;
 #pragma unroll
         for (int j = j0; j < j0 + 2; ++j) {
-            // along the row: (d B)[j]
-            const f32x4 rj = j == 0 ? d[0] - d[2] : (j == 1 ? d[1] + d[2] : (j == 2 ? d[2] - d[1] : d[1] - d[3]));
+            const f32x4 rj = row_value(j);
             // across the quad: (B^T .)[ti] = r[0]-r[2] | r[1]+r[2] | r[2]-r[1] | r[1]-r[3]
             f32x4 u;
 #pragma unroll
             for (int c = 0; c < 4; ++c) u[c] = fmaf(qsign, quad_get(rj[c], 1), quad_get(rj[c], 0));
-            *reinterpret_cast<f32x4*>(o + (4 * ti + j) * (WT * WALD)) = u;
+            *reinterpret_cast<f32x4*>(o + (PX * ti + j) * (WT * WALD)) = u;
         }
     };
     auto transform_store = [&](float* As) {
-        transform_cols(As, 0);
-        transform_cols(As, 2);
+#pragma unroll
+        for (int j0 = 0; j0 < PX; j0 += 2) transform_cols(As, j0);
     };
 
-    // ---- MFMA role: positions 2 wave, 2 wave + 1; B fragments straight from the transformed weights
-    const float* wbase = a.w + ((long long)(2 * wave) * wp.nchunk * a.N + (n0 + l31)) * 8 + kh * 4;
+    // ---- MFMA role: positions PW wave .. PW wave + PW - 1; B fragments straight from the transformed weights
+    const float* wbase = a.w + ((long long)(PW * wave) * wp.nchunk * a.N + (n0 + l31)) * 8 + kh * 4;
     const long long xi_stride = (long long)wp.nchunk * a.N * 8;
-    auto load_b = [&](int ck, f32x4 (&bf)[2][NB]) {
+    auto load_b = [&](int ck, f32x4 (&bf)[PW][NB]) {
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+        for (int x = 0; x < PW; ++x)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
                 bf[x][nb] = *reinterpret_cast<const f32x4*>(wbase + x * xi_stride + ((long long)ck * a.N + nb * 32) * 8);
     };
-    f32x16 acc[2][NB];
+    f32x16 acc[PW][NB];
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+    for (int x = 0; x < PW; ++x)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[x][nb][e] = 0.f;
-    f32x4 af[2];                                                 // this sub-chunk's A fragments, one per position
+    f32x4 af[PW];                                                // this sub-chunk's A fragments, one per position
     auto load_af = [&](const float* Ac, int u) {
 #pragma unroll
-        for (int x = 0; x < 2; ++x) af[x] = *reinterpret_cast<const f32x4*>(Ac + ((2 * wave + x) * WT + l31) * WALD + u * 8 + kh * 4);
+        for (int x = 0; x < PW; ++x) af[x] = *reinterpret_cast<const f32x4*>(Ac + ((PW * wave + x) * WT + l31) * WALD + u * 8 + kh * 4);
     };
-    auto mfma_group = [&](int s, const f32x4 (&bf)[2][NB]) {      // k-step s of the sub-chunk in af: 2 NB MFMAs
+    auto mfma_group = [&](int s, const f32x4 (&bf)[PW][NB]) {     // k-step s of the sub-chunk in af: PW NB MFMAs
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+        for (int x = 0; x < PW; ++x)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[x][nb] = mfma32(af[x][s], bf[x][nb][s], acc[x][nb]);
     };
@@ -233,7 +273,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
     // the waits the compiler places count exactly the loads that are younger than the registers an MFMA needs.  (With the
     // loads under `if (k + 1 < n)` the path that skips them set the wait counts for all, and every chunk stood for a full
     // memory round trip of its own prefetches: half speed.)
-    f32x4 b0[2][NB], b1[2][NB];        // (LEAN never touches b1)
+    f32x4 b0[PW][NB], b1[PW][NB];      // (LEAN never touches b1)
     if (nst > 0) {
         load_patch(st_beg);
         load_b(2 * st_beg, b0);
@@ -261,25 +301,34 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
         if constexpr (LEAN) load_b(2 * st + 1, b0);            // one register set: requested right before its use, the other
         load_af(Ac, 1);                                        // workgroup of the CU has the matrix pipe meanwhile
         __builtin_amdgcn_sched_barrier(0);
-        // second half: its 8 NB MFMAs and the transform of step j + 1 (vector ALU, DPP, four LDS stores) in ONE scheduling region,
+        // second half: its 4 PW NB MFMAs and the transform of step j + 1 (vector ALU, DPP, PX LDS stores) in ONE scheduling region,
         // interleaved one MFMA : a few VALU operations -- in separate clusters both waves of a SIMD reach their VALU cluster
         // together (they run the same program between the same barriers) and the matrix pipe stands
         if constexpr (LEAN) {
             mfma_group(0, b0); mfma_group(1, b0); mfma_group(2, b0); mfma_group(3, b0);
-            transform_cols(An, 0);
-            transform_cols(An, 2);
+            transform_store(An);
         } else {
             load_b(2 * min(st + 1, st_last), b0);              // (the first half's MFMAs have read b0)
             __builtin_amdgcn_sched_barrier(0);
             mfma_group(0, b1); mfma_group(1, b1); mfma_group(2, b1); mfma_group(3, b1);
-            transform_cols(An, 0);
-            transform_cols(An, 2);
+            transform_store(An);
         }
+        if constexpr (PX == 4) {
 #pragma unroll
-        for (int i = 0; i < 8 * NB; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, NB == 4 ? 3 : 6, 0);     // a few VALU / DPP operations
-            if ((i & (NB == 4 ? 7 : 3)) == (NB == 4 ? 7 : 3)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // an LDS store
+            for (int i = 0; i < 8 * NB; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, NB == 4 ? 3 : 6, 0);     // a few VALU / DPP operations
+                if ((i & (NB == 4 ? 7 : 3)) == (NB == 4 ? 7 : 3)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // an LDS store
+            }
+        } else {
+            // 24 MFMAs over ~150 vector-ALU / DPP operations (six row values of 4 channels at 2-5 operations each, 24 x 3 across
+            // the quad) and six LDS stores
+#pragma unroll
+            for (int i = 0; i < 4 * PW * NB; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+                if ((i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (LEAN) load_b(2 * min(st + 1, st_last), b0);
@@ -287,7 +336,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
     }
 
     // ---- epilogue: one n block at a time through the exchange image X[xi][tile][n] (row stride WXLD: 16-byte aligned rows).
-    // Thread (tile tl, channel quad nq, output row ei) finishes 2 pixels x 4 channels: A^T m A on 16-byte vectors, then the conv
+    // Thread (tile tl, channel quad nq, output row ei) finishes TWX pixels x 4 channels: A^T m A on 16-byte vectors, then the conv
     // epilogue in epilogue_value()'s order.  Its operands -- up to three tensors -- are requested BEFORE the accumulators go to
     // LDS, so their way from memory is under the exchange; everything moves as 16-byte vectors (the dword form of this
     // epilogue cost the data gradients, with two adds and a mask, up to 60 us per launch).
@@ -299,17 +348,19 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
         const int bimg = tg / wp.tiles_per_image;
         const int r = tg - bimg * wp.tiles_per_image;
         const int ty = r / wp.tiles_x, tx = r - ty * wp.tiles_x;
-        epix = tg < wp.ntiles ? (bimg * g.OH + 2 * ty + ei) * g.OW + 2 * tx : -1;
+        epix = tg < wp.ntiles ? (bimg * g.OH + 2 * ty + ei) * g.OW + TWX * tx : -1;
     }
     const bool evalid = epix >= 0;
-    const float esc0 = pick_scale(sp, epix < 0 ? 0 : epix), esc1 = pick_scale(sp, epix < 0 ? 0 : epix + 1);
+    float esc[TWX];
+#pragma unroll
+    for (int q = 0; q < TWX; ++q) esc[q] = pick_scale(sp, epix < 0 ? 0 : epix + q);
     const bool vec = (p.wide & 1) != 0;                            // every epilogue operand row 16-byte aligned (wide_epilogue_ok)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {        // (unrolled: a run-time index into the accumulators would put them in scratch memory)
         const int n = n0 + nb * 32 + 4 * enq;
-        f32x4 e1[2], e2[2], em[2], bias4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 e1[TWX], e2[TWX], em[TWX], bias4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < TWX; ++q) {
             e1[q] = f32x4{-0.0f, -0.0f, -0.0f, -0.0f};
             e2[q] = e1[q];
             em[q] = f32x4{1.f, 1.f, 1.f, 1.f};
@@ -319,22 +370,22 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
                 if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n);
                 if (a.add1) {
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) e1[q] = *reinterpret_cast<const f32x4*>(a.add1 + (long long)(epix + q) * a.add1_ld + n);
+                    for (int q = 0; q < TWX; ++q) e1[q] = *reinterpret_cast<const f32x4*>(a.add1 + (long long)(epix + q) * a.add1_ld + n);
                 }
                 if (a.add2) {
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) e2[q] = *reinterpret_cast<const f32x4*>(a.add2 + (long long)(epix + q) * a.add2_ld + n);
+                    for (int q = 0; q < TWX; ++q) e2[q] = *reinterpret_cast<const f32x4*>(a.add2 + (long long)(epix + q) * a.add2_ld + n);
                 }
                 if (a.mask) {
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) em[q] = *reinterpret_cast<const f32x4*>(a.mask + (long long)(epix + q) * a.mask_ld + n);
+                    for (int q = 0; q < TWX; ++q) em[q] = *reinterpret_cast<const f32x4*>(a.mask + (long long)(epix + q) * a.mask_ld + n);
                 }
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     if (a.bias) bias4[c] = a.bias[n + c];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
+                    for (int q = 0; q < TWX; ++q) {
                         if (a.add1) e1[q][c] = a.add1[(long long)(epix + q) * a.add1_ld + n + c];
                         if (a.add2) e2[q][c] = a.add2[(long long)(epix + q) * a.add2_ld + n + c];
                         if (a.mask) em[q][c] = a.mask[(long long)(epix + q) * a.mask_ld + n + c];
@@ -344,31 +395,40 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            float* X = Ls + (2 * wave + x) * (WT * WXLD) + l31;
+        for (int x = 0; x < PW; ++x) {
+            float* X = Ls + (PW * wave + x) * (WT * WXLD) + l31;
 #pragma unroll
             for (int e = 0; e < 16; ++e) X[mfma32_row(e, lane) * WXLD] = acc[x][nb][e];
         }
         __syncthreads();
-        f32x4 y[2];
+        f32x4 y[TWX];
         {
-            f32x4 t[4];
+            f32x4 t[PX];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const float* col = Ls + (b * WT + etl) * WXLD + 4 * enq;              // position xi = 4 a + b at col + a * 4 * WT * WXLD
-                const f32x4 m1 = *reinterpret_cast<const f32x4*>(col + 1 * 4 * WT * WXLD);
-                const f32x4 m2 = *reinterpret_cast<const f32x4*>(col + 2 * 4 * WT * WXLD);
-                const f32x4 m03 = *reinterpret_cast<const f32x4*>(col + (ei ? 3 : 0) * 4 * WT * WXLD);
+            for (int b = 0; b < PX; ++b) {
+                const float* col = Ls + (b * WT + etl) * WXLD + 4 * enq;              // position xi = PX a + b at col + a * PX * WT * WXLD
+                const f32x4 m1 = *reinterpret_cast<const f32x4*>(col + 1 * PX * WT * WXLD);
+                const f32x4 m2 = *reinterpret_cast<const f32x4*>(col + 2 * PX * WT * WXLD);
+                const f32x4 m03 = *reinterpret_cast<const f32x4*>(col + (ei ? 3 : 0) * PX * WT * WXLD);
                 t[b] = ei ? m1 - m2 - m03 : m03 + m1 + m2;                             // row ei of A^T m
             }
-            y[0] = t[0] + t[1] + t[2];
-            y[1] = t[1] - t[2] - t[3];
+            if constexpr (PX == 4) {
+                y[0] = t[0] + t[1] + t[2];
+                y[1] = t[1] - t[2] - t[3];
+            } else {
+                // A^T of F(4,3) = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+                const f32x4 s12 = t[1] + t[2], d12 = t[1] - t[2], s34 = t[3] + t[4], d34 = t[3] - t[4];
+                y[0] = t[0] + s12 + s34;
+                y[1] = d12 + 2.f * d34;
+                y[2] = s12 + 4.f * s34;
+                y[3] = d12 + 8.f * d34 + t[5];
+            }
         }
         if (evalid) {
             if (p.splitk > 1) {
                 float* slab = a.ws + (long long)zk * ((long long)p.M * a.N) + n;
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
+                for (int q = 0; q < TWX; ++q) {
                     if (vec && (p.wide & 2)) *reinterpret_cast<f32x4*>(slab + (long long)(epix + q) * a.N) = y[q];
                     else
 #pragma unroll
@@ -376,8 +436,8 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
                 }
             } else {
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const float sc = q ? esc1 : esc0;
+                for (int q = 0; q < TWX; ++q) {
+                    const float sc = esc[q];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         float v = y[q][c] * sc + bias4[c];
@@ -388,24 +448,24 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
                 }
                 if (a.act == MTD_ACT_RELU) {
 #pragma unroll
-                    for (int q = 0; q < 2; ++q)
+                    for (int q = 0; q < TWX; ++q)
 #pragma unroll
                         for (int c = 0; c < 4; ++c) y[q][c] = y[q][c] > 0.f ? y[q][c] : 0.f;
                 } else if (a.act == MTD_ACT_LRELU) {
 #pragma unroll
-                    for (int q = 0; q < 2; ++q)
+                    for (int q = 0; q < TWX; ++q)
 #pragma unroll
                         for (int c = 0; c < 4; ++c) y[q][c] = y[q][c] > 0.f ? y[q][c] : 0.2f * y[q][c];
                 }
                 if (a.mask) {
                     const float slope = a.mask_slope;
 #pragma unroll
-                    for (int q = 0; q < 2; ++q)
+                    for (int q = 0; q < TWX; ++q)
 #pragma unroll
                         for (int c = 0; c < 4; ++c) y[q][c] *= (em[q][c] > 0.f) ? 1.f : slope;
                 }
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
+                for (int q = 0; q < TWX; ++q) {
                     float* o = a.out + (long long)(epix + q) * a.out_ld + n;
                     if (vec) *reinterpret_cast<f32x4*>(o) = y[q];
                     else
@@ -434,17 +494,32 @@ bool wino_eligible(const mtd_conv_args& a) {
     return true;
 }
 
-struct WinoPlan { int nb, lean, splitk, c_per_split; };
+struct WinoPlan { int nb, lean, splitk, c_per_split, px; };
 
-WinoPlan wino_plan(const mtd_conv_args& a) {
+// Which transform along x does this layer take?  4 = the patch width of F(2x2, 3x3), 6 = F(2x4, 3x3): maps whose width is a
+// multiple of 4 and at least MTD_WINO_F4_MIN_W (default 8: on the 4-pixel-wide maps a tile row is one tile and the transformed
+// weights -- 24 / 9 of the filter instead of 16 / 9 -- are what the launch streams).  MTD_WINO_F4=0 switches the form off.
+int g_f4_min_w = -1;          // -1: not yet read from the environment; 0: the form is off
+int wino_patch_w(const mtd_conv_args& a) {
+    if (g_f4_min_w < 0) {
+        const char* off = getenv("MTD_WINO_F4");
+        const char* mw = getenv("MTD_WINO_F4_MIN_W");
+        g_f4_min_w = (off && atoi(off) == 0) ? 0 : (mw ? atoi(mw) : 8);
+    }
+    return (g_f4_min_w > 0 && (a.g.OW % 4) == 0 && a.g.OW >= g_f4_min_w) ? 6 : 4;
+}
+
+WinoPlan wino_plan(const mtd_conv_args& a, int px) {
     WinoPlan pl{};
-    pl.nb = (a.N % 128 == 0) ? 4 : 2;
+    pl.px = px;
+    const int tile_px = 2 * (px - 2);                            // output pixels per tile
+    pl.nb = (a.N % 128 == 0 && px == 4) ? 4 : 2;
     // (lab, MTD_WINO_NB2_MAXC=64: the narrow form with its lean variant for layers with four K steps whatever their N -- 5 % less time
     // for those launches (123 -> 116 us, 226 -> 213 us), 0.08 ms per step, but the input is then read per 64 instead of per 128 output
     // channels: 62 -> 80 MB of fabric traffic per launch.  Off.)
     static const int env_nb2_c = [] { const char* e = getenv("MTD_WINO_NB2_MAXC"); return e ? atoi(e) : 0; }();
     if (a.C <= env_nb2_c) pl.nb = 2;
-    const long long tiles = geom_pixels(a.g) / 4;
+    const long long tiles = geom_pixels(a.g) / tile_px;
     long long blocks = ((tiles + WT - 1) / WT) * (a.N / (32 * pl.nb));
     if (blocks < 192 && pl.nb == 4 && a.N % 64 == 0) {          // more, narrower workgroups before splitting K
         pl.nb = 2;
@@ -464,9 +539,12 @@ WinoPlan wino_plan(const mtd_conv_args& a) {
     // 1 by this rule, 2 whenever NB = 2)
     static const int env_lean = [] { const char* e = getenv("MTD_WINO_LEAN"); return e ? atoi(e) : 1; }();
     const long long grid = ((tiles + WT - 1) / WT) * (a.N / (32 * pl.nb)) * pl.splitk;
-    pl.lean = pl.nb == 2 && env_lean && (env_lean == 2 || (cps <= 8 && grid >= 512));
+    pl.lean = px == 4 && pl.nb == 2 && env_lean && (env_lean == 2 || (cps <= 8 && grid >= 512));
     return pl;
 }
+
+// the patch width the transformed weights in a->w were built for travels in a->w_st (6: F(2x4, 3x3); anything else: 4)
+inline int wino_args_px(const mtd_conv_args& a) { return a.w_st == 6 ? 6 : 4; }
 
 }  // namespace
 
@@ -474,7 +552,7 @@ WinoPlan wino_plan(const mtd_conv_args& a) {
 // Transformed weights of `count` conv views in one launch.  desc[i]: the weight view W(n, c, kidx) = src[n sn + c sc + kidx st]
 // and the geometry it will be used with (its taps decide which filter entry sits at which correlation position: a forward
 // conv and the data gradient of the same layer need different transforms); dst: 16 * N * C floats, layout [xi][C/8][N][8].
-extern "C" size_t mtd_winograd_weight_floats(int N, int C) { return (N > 0 && C > 0) ? (size_t)16 * N * C : 0; }
+extern "C" size_t mtd_winograd_weight_floats(int N, int C) { return (N > 0 && C > 0) ? (size_t)24 * N * C : 0; }      /* enough for either form */
 
 extern "C" int mtd_winograd_weights(const mtd_wino_weight_desc* table_dev, const mtd_wino_weight_desc* table_host, int count, void* stream) {
     static_assert(sizeof(mtd_wino_weight_desc) == sizeof(WinoWDesc), "descriptor layouts must agree");
@@ -482,7 +560,7 @@ extern "C" int mtd_winograd_weights(const mtd_wino_weight_desc* table_dev, const
     long long most = 0;
     for (int i = 0; i < count; ++i) {
         const mtd_wino_weight_desc& d = table_host[i];
-        if (!d.src || !d.dst || d.N <= 0 || d.C <= 0 || (d.C % 8)) return MTD_EINVAL;
+        if (!d.src || !d.dst || d.N <= 0 || d.C <= 0 || (d.C % 8) || !(d.px == 0 || d.px == 4 || d.px == 6)) return MTD_EINVAL;
         for (int k = 0; k < 9; ++k)
             if (d.kmap[k] < 0 || d.kmap[k] > 15) return MTD_EINVAL;
         const long long t = (long long)d.N * d.C;
@@ -521,9 +599,26 @@ extern "C" int mtd_conv_winograd_ok(const mtd_conv_args* a) {
     return 1;
 }
 
+// The transform this layer's weights are to be built for (mtd_wino_weight_desc.px, and a->w_st of the conv launch): 6 =
+// F(2x4, 3x3), 4 = F(2x2, 3x3); 0 if the layer is not in the Winograd kernel's domain.
+extern "C" int mtd_conv_winograd_patch_w(const mtd_conv_args* a) {
+    if (!mtd_conv_winograd_ok(a)) return 0;
+    return wino_patch_w(*a);
+}
+
+// Tuning / test hook: narrowest map that takes F(2x4, 3x3) (0: never; the default is 8, or MTD_WINO_F4_MIN_W / MTD_WINO_F4=0 from
+// the environment).  Returns the previous value.  Callers that cache mtd_conv_winograd_patch_w's answers drop them.
+extern "C" int mtd_conv_winograd_f4_min_w(int min_w) {
+    mtd_conv_args probe{};
+    (void)wino_patch_w(probe);                       // (reads the environment once)
+    const int old = g_f4_min_w;
+    if (min_w >= 0) g_f4_min_w = min_w;
+    return old;
+}
+
 extern "C" size_t mtd_conv_winograd_ws_bytes(const mtd_conv_args* a) {
     if (!mtd_conv_winograd_ok(a)) return 0;
-    const WinoPlan pl = wino_plan(*a);
+    const WinoPlan pl = wino_plan(*a, wino_args_px(*a));
     return pl.splitk > 1 ? (size_t)pl.splitk * (size_t)geom_pixels(a->g) * a->N * sizeof(float) : 0;
 }
 
@@ -532,7 +627,9 @@ extern "C" size_t mtd_conv_winograd_ws_bytes(const mtd_conv_args* a) {
 extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
     if (!mtd_conv_winograd_ok(a)) return MTD_EINVAL;
     if (!aligned16(a->w)) return MTD_EALIGN;
-    const WinoPlan pl = wino_plan(*a);
+    const int px = wino_args_px(*a);
+    if (px == 6 && (a->g.OW % 4)) return MTD_EINVAL;
+    const WinoPlan pl = wino_plan(*a, px);
     WinoParams wp;
     IgemmParams& p = wp.p;
     p.a = *a;
@@ -551,13 +648,13 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
     p.nt_store = 0;
     p.fin = 0;
     p.wide = (wide_epilogue_ok(*a) ? 1 : 0) | ((pl.splitk > 1 && aligned16(a->ws) && (a->N % 4) == 0) ? 2 : 0);
-    wp.tiles_x = a->g.OW / 2;
+    wp.tiles_x = a->g.OW / (px - 2);
     wp.tiles_per_image = (a->g.OH / 2) * wp.tiles_x;
     wp.ntiles = a->g.B * wp.tiles_per_image;
     wp.nchunk = a->C / 8;
     {
         static const int env_xcd = [] { const char* e = getenv("MTD_WINO_XCD"); return e ? atoi(e) : -1; }();
-        const double wbytes = 16.0 * a->C * a->N * 4, ibytes = (double)p.M * a->C * 4;
+        const double wbytes = 4.0 * px * a->C * a->N * 4, ibytes = (double)p.M * a->C * 4;
         wp.xcd_order = env_xcd >= 0 ? env_xcd : (wbytes >= ibytes ? 1 : 2);
     }
     if (pl.splitk > 1) {
@@ -566,9 +663,11 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
     }
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((wp.ntiles + WT - 1) / WT, a->N / (32 * pl.nb), pl.splitk);
-    // (one profiler id per INSTANTIATION -- 14: <2, false>, 15: <4, false>, 22: <2, true> -- so that a record's name is one kernel symbol of a rocprofv3 table)
-    const int prof = mtd_prof_begin(0, pl.nb == 4 ? 15 : (pl.lean ? 22 : 14), pl.splitk, p.M, a->N, a->C, 9, s, algorithmic_bytes(a));
-    if (pl.nb == 4) MTD_LAUNCH((wino_conv_kernel<4>), grid, dim3(512), 0, s, wp);
+    // (one profiler id per INSTANTIATION -- 14: <2, false, 4>, 15: <4, false, 4>, 22: <2, true, 4>, 23: <2, false, 6> -- so that a record's name is
+    // one kernel symbol of a rocprofv3 table)
+    const int prof = mtd_prof_begin(0, px == 6 ? 23 : (pl.nb == 4 ? 15 : (pl.lean ? 22 : 14)), pl.splitk, p.M, a->N, a->C, 9, s, algorithmic_bytes(a));
+    if (px == 6) MTD_LAUNCH((wino_conv_kernel<2, false, 6>), grid, dim3(512), 0, s, wp);
+    else if (pl.nb == 4) MTD_LAUNCH((wino_conv_kernel<4>), grid, dim3(512), 0, s, wp);
     else if (pl.lean) MTD_LAUNCH((wino_conv_kernel<2, true>), grid, dim3(512), 0, s, wp);
     else MTD_LAUNCH((wino_conv_kernel<2>), grid, dim3(512), 0, s, wp);
     mtd_prof_end(prof, s);

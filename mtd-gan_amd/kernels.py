@@ -134,10 +134,36 @@ def winograd_takes(geom, N, Cc, kw):
     return len(_wino_kmap(geom)) == 9
 
 
-def _wino_desc(w, N, Cc, w_sn, w_sc, kmap, device):
-    dst = _view_buffer((w.data_ptr(), N, Cc, w_sn, w_sc, "wino", kmap), (16 * N * Cc,), device)
+_wino_px_cache = {}
+
+
+def winograd_patch_w(geom, N, Cc):
+    """The transform the library's plan wants along x for this layer (mtd_conv_winograd_patch_w): 6 = F(2x4, 3x3) -- 3 MFMA
+    multiplications per output pixel and channel pair -- or 4 = F(2x2, 3x3) -- 4 of them; the direct form has 9."""
+    key = (bytes(geom), N, Cc)
+    px = _wino_px_cache.get(key)
+    if px is None:
+        a = ConvArgs()
+        a.g = geom
+        a.inp = a.w = a.out = 16                   # (the query looks at shapes only; non-null placeholders)
+        a.in_ld, a.C, a.N, a.out_ld = Cc, Cc, N, N
+        px = _lib.lib().mtd_conv_winograd_patch_w(C.byref(a))
+        _wino_px_cache[key] = px
+    return px
+
+
+def winograd_f4_min_w(min_w):
+    """Tuning / test hook (mtd_conv_winograd_f4_min_w): narrowest map that takes F(2x4, 3x3); 0 = never.  Returns the old value."""
+    old = _lib.lib().mtd_conv_winograd_f4_min_w(int(min_w))
+    _wino_px_cache.clear()
+    _igemm_ws_cache.clear()
+    return old
+
+
+def _wino_desc(w, N, Cc, w_sn, w_sc, kmap, device, px):
+    dst = _view_buffer((w.data_ptr(), N, Cc, w_sn, w_sc, "wino", kmap, px), (4 * px * N * Cc,), device)
     d = _lib.WinoWeightDesc()
-    d.src, d.dst, d.sn, d.sc, d.st, d.N, d.C = w.data_ptr(), dst.data_ptr(), w_sn, w_sc, 1, N, Cc
+    d.src, d.dst, d.sn, d.sc, d.st, d.N, d.C, d.px = w.data_ptr(), dst.data_ptr(), w_sn, w_sc, 1, N, Cc, px
     for i, k in enumerate(kmap):
         d.kmap[i] = k
     return d, dst
@@ -152,13 +178,14 @@ def prepack_winograd(views):
         if not winograd_takes(geom, N, Cc, {}):
             continue
         kmap = _wino_kmap(geom)
-        key = (w.data_ptr(), w._version, _pack_epoch, N, Cc, w_sn, w_sc, "wino", kmap)
+        px = winograd_patch_w(geom, N, Cc)
+        key = (w.data_ptr(), w._version, _pack_epoch, N, Cc, w_sn, w_sc, "wino", kmap, px)
         if key in _pack_cache:
             continue
-        d, dst = _wino_desc(w, N, Cc, w_sn, w_sc, kmap, w.device)
+        d, dst = _wino_desc(w, N, Cc, w_sn, w_sc, kmap, w.device, px)
         todo.append(d)
         dev = w.device
-        _remember(_pack_cache, (w.data_ptr(), N, Cc, w_sn, w_sc, "wino", kmap), key, (dst, w))
+        _remember(_pack_cache, (w.data_ptr(), N, Cc, w_sn, w_sc, "wino", kmap, px), key, (dst, w))
     if todo:
         tab, host = device_table(todo, dev)
         check(_lib.lib().mtd_winograd_weights(tab.data_ptr(), C.cast(host, C.c_void_p), len(todo), stream_ptr()), "mtd_winograd_weights")
@@ -166,17 +193,19 @@ def prepack_winograd(views):
 
 def winograd_weight_view(w, N, Cc, w_sn, w_sc, geom):
     """The transformed weights [xi][C/8][N][8] of the view W(n,c,tap) = w[n*w_sn + c*w_sc + tap] for this geometry's tap
-    order.  Cached until the weights change (like the packed [tap][n][c] views)."""
+    order, and the patch width px (6: F(2x4, 3x3), 4: F(2x2, 3x3)) they were built for -- the library's choice per layer.
+    Cached until the weights change (like the packed [tap][n][c] views)."""
     kmap = _wino_kmap(geom)
-    key = (w.data_ptr(), w._version, _pack_epoch, N, Cc, w_sn, w_sc, "wino", kmap)
+    px = winograd_patch_w(geom, N, Cc)
+    key = (w.data_ptr(), w._version, _pack_epoch, N, Cc, w_sn, w_sc, "wino", kmap, px)
     hit = _pack_cache.get(key)
     if hit is None:
-        d, dst = _wino_desc(w, N, Cc, w_sn, w_sc, kmap, w.device)
+        d, dst = _wino_desc(w, N, Cc, w_sn, w_sc, kmap, w.device, px)
         tab, host = device_table([d], w.device)
         check(_lib.lib().mtd_winograd_weights(tab.data_ptr(), C.cast(host, C.c_void_p), 1, stream_ptr()), "mtd_winograd_weights")
         hit = (dst, w)
-        _remember(_pack_cache, (w.data_ptr(), N, Cc, w_sn, w_sc, "wino", kmap), key, hit)
-    return hit[0]
+        _remember(_pack_cache, (w.data_ptr(), N, Cc, w_sn, w_sc, "wino", kmap, px), key, hit)
+    return hit[0], px
 
 
 def regrouped_bias(b, groups):
@@ -225,10 +254,10 @@ CALL_LOG = None     # tools/tune_igemm.py: a list collects ("igemm" | "wgrad", b
 IGEMM_CONFIGS = ["igemm_kernel<2, 1, 4, 1>", "igemm_kernel<1, 1, 4, 1>", "igemm_kernel<2, 2, 4, 1>",
                  "igemm_kernel<1, 1, 2, 2>", "igemm_kernel<2, 2, 2, 2>", "igemm_kernel<1, 1, 1, 4>",
                  "igemm_tb_kernel<1>", "igemm_tb_kernel<2>", "igemm_v2_kernel<0>", "igemm_c32p_kernel", "igemm_c32t_kernel", "c32_bwd_kernel",
-                 "igemm_c32t_kernel<4, true, true, true>", "c32_bwd_kernel<1, true>", "wino_conv_kernel<2, false>", "wino_conv_kernel<4, false>",      # 12: Res-FFT block tail; 13: c32_bwd + irfft; 14, 15, 22: Winograd
+                 "igemm_c32t_kernel<4, true, true, true>", "c32_bwd_kernel<1, true>", "wino_conv_kernel<2, false, 4>", "wino_conv_kernel<4, false, 4>",      # 12: Res-FFT block tail; 13: c32_bwd + irfft; 14, 15, 22, 23: Winograd
                  "igemm_multi_kernel<2, 1, 4, 1>", "igemm_multi_kernel<1, 1, 4, 1>", "igemm_multi_kernel<2, 2, 4, 1>",      # 16 + cfg
                  "igemm_multi_kernel<1, 1, 2, 2>", "igemm_multi_kernel<2, 2, 2, 2>", "igemm_multi_kernel<1, 1, 1, 4>",
-                 "wino_conv_kernel<2, true>"]                                                                                 # 22
+                 "wino_conv_kernel<2, true, 4>", "wino_conv_kernel<2, false, 6>"]                                             # 22, 23 (6: F(2x4, 3x3))
 WGRAD_CONFIGS = ["wgrad_kernel<1, 1, 9>", "wgrad_kernel<1, 1, 4>", "wgrad_kernel<2, 2, 1>", "wgrad_kernel<1, 1, 8>",
                  "wgrad_kernel<1, 1, 3>", "wgrad_kernel<1, 1, 1>", "wgrad_kernel<2, 2, 3>",
                  "wgrad_row_kernel<3, 3, 1>", "wgrad_row_kernel<3, 3, -1>", "wgrad_row_kernel<1, 1, 1>",
@@ -407,7 +436,8 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, **kw):
     if winograd_takes(geom, N, Cc, kw):
         a = _conv_args(x, w, geom, N, Cc, w_sn, w_sc, out, pack=False, **kw)
         if L.mtd_conv_winograd_ok(C.byref(a)):
-            a.w = winograd_weight_view(w, N, Cc, w_sn, w_sc, geom).data_ptr()
+            wv, px = winograd_weight_view(w, N, Cc, w_sn, w_sc, geom)
+            a.w, a.w_st = wv.data_ptr(), px           # (w_st tells the library which form the weights are)
             wkey = ("wino", bytes(geom), N, Cc)
             need = _igemm_ws_cache.get(wkey)
             if need is None:
@@ -416,9 +446,10 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, **kw):
             if need:
                 ws = workspace(need, x.device)
                 a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
-            if FLOP_COUNT is not None:          # executed MFMA flops: 16 instead of 36 multiplications per 2 x 2 output tile
-                FLOP_COUNT["conv_mfma"] -= 2.0 * geom.B * geom.OH * geom.OW * N * Cc * 5
-                FLOP_COUNT["conv_winograd_saved"] = FLOP_COUNT.get("conv_winograd_saved", 0.0) + 2.0 * geom.B * geom.OH * geom.OW * N * Cc * 5
+            if FLOP_COUNT is not None:          # executed MFMA flops: 4 (F(2x2)) or 3 (F(2x4)) instead of 9 multiplications per output pixel
+                saved = 2.0 * geom.B * geom.OH * geom.OW * N * Cc * (6 if px == 6 else 5)
+                FLOP_COUNT["conv_mfma"] -= saved
+                FLOP_COUNT["conv_winograd_saved"] = FLOP_COUNT.get("conv_winograd_saved", 0.0) + saved
             check(L.mtd_conv_winograd(C.byref(a), stream_ptr()), "mtd_conv_winograd")
             return out
         if FLOP_COUNT is not None:
@@ -1010,7 +1041,13 @@ def device_table(structs, device):
     if hit is None:
         host, dev = arena(device).take(len(raw))
         host[:len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
-        check(_lib.lib().mtd_upload(host.data_ptr(), dev.data_ptr(), host.numel(), stream_ptr()), "mtd_upload")
+        # (a table's contents never change and the static arena is never recycled: the upload runs NOW and is not part of a
+        # recorded list -- 27 launches per replayed iteration otherwise)
+        rec_, _lib.RECORDER = _lib.RECORDER, None
+        try:
+            check(_lib.lib().mtd_upload(host.data_ptr(), dev.data_ptr(), host.numel(), stream_ptr()), "mtd_upload")
+        finally:
+            _lib.RECORDER = rec_
         hit = (dev, arr, host)
         _desc_cache[key] = hit
         if RECORDING is not None:

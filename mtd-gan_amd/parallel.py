@@ -80,8 +80,11 @@ class DataParallelSync:
             return
         if self.cuda:
             if self.has_avg:
-                # RCCL scales inside the collective: no extra pass over 114 MB
-                self._on_side(lambda: dist.all_reduce(flat, op=dist.ReduceOp.AVG), flat, after)
+                # RCCL scales inside the collective: no extra pass over 114 MB.  (A ONE-rank group -- MTD_FORCE_DP=1, the
+                # plumbing rehearsal -- asks for SUM, which equals AVG there: RCCL runs a one-rank AVG as a pre-multiply kernel
+                # that rewrites the whole buffer in place, 112 us per 114 MB, which no multi-rank run executes.)
+                op = dist.ReduceOp.AVG if self.world > 1 else dist.ReduceOp.SUM
+                self._on_side(lambda: dist.all_reduce(flat, op=op), flat, after)
             else:
                 def sum_and_scale():
                     dist.all_reduce(flat, op=dist.ReduceOp.SUM)

@@ -623,17 +623,31 @@ WINO_CASES = [
     (7, 512, 1024, 2, 2, "dgrad"),     # one tile per image
     (16, 64, 64, 64, 64, "dgrad"),     # 512 workgroups with four K steps: the lean form, two workgroups per CU
     (16, 64, 256, 32, 32, "fwd"),      # C = 64 with wide N: four K steps under BN = 128 (MTD_WINO_NB2_MAXC=64: the narrow lean form)
+    (3, 128, 128, 8, 8, "dgrad"),      # F(2x4): two tiles per tile row, 24 tiles -- one ragged workgroup
+    (1, 64, 64, 6, 20, "fwd"),         # F(2x4): width a multiple of 4 but not of 8, height not a multiple of 4
 ]
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["plan", "f2x2"])
 @pytest.mark.parametrize("case", WINO_CASES)
-def test_winograd_conv_vs_torch(hip_lib, case):
-    """csrc/conv_winograd.hip, F(2x2, 3x3): forward conv and data gradient with the full epilogue (two scales by batch half,
-    bias, two adds, LeakyReLU, mask) against torch on the CPU in float64 and against the implicit GEMM on the same inputs
-    (the two differ by fp32 rounding only: 1e-5)."""
+def test_winograd_conv_vs_torch(hip_lib, case, form):
+    """csrc/conv_winograd.hip: forward conv and data gradient with the full epilogue (two scales by batch half, bias, two adds,
+    LeakyReLU, mask) against torch on the CPU in float64 and against the implicit GEMM on the same inputs (the two differ by
+    fp32 rounding only: 2e-5).  form "plan": what the library picks per layer -- F(2x4, 3x3) on maps at least 8 wide whose width
+    is a multiple of 4, F(2x2, 3x3) elsewhere; "f2x2": F(2x2, 3x3) everywhere (mtd_conv_winograd_f4_min_w(0))."""
     from mtd_gan_amd import kernels as K
     B, Ci, Co, H, W, what = case
+    if form == "f2x2" and not (W % 4 == 0 and W >= 8):
+        pytest.skip("the plan takes F(2x2, 3x3) for this map anyway")
+    old_min_w = K.winograd_f4_min_w(0 if form == "f2x2" else 8)
+    try:
+        _winograd_conv_case(K, B, Ci, Co, H, W, what, form)
+    finally:
+        K.winograd_f4_min_w(old_min_w)
+
+
+def _winograd_conv_case(K, B, Ci, Co, H, W, what, form):
     gen = torch.Generator().manual_seed(17)
     r = lambda *s: torch.randn(*s, generator=gen)
     x = r(B, H, W, Ci if what == "fwd" else Co).cuda()
@@ -650,6 +664,7 @@ def test_winograd_conv_vs_torch(hip_lib, case):
     if split:
         kw.update(scale2=s2, scale_split=split)
     assert K.winograd_takes(geom, N, Cc, kw)
+    assert K.winograd_patch_w(geom, N, Cc) == (6 if (form == "plan" and W % 4 == 0 and W >= 8) else 4)
     outs = []
     for wino in (True, False):
         K.WINOGRAD = wino
@@ -660,7 +675,7 @@ def test_winograd_conv_vs_torch(hip_lib, case):
             outs.append(out)
         finally:
             K.WINOGRAD = True
-    assert relerr(outs[0].cpu(), outs[1].cpu()) < 1e-5
+    assert relerr(outs[0].cpu(), outs[1].cpu()) < 2e-5
     xc, wc = nchw(x).double(), w.cpu().double()
     y = F.conv2d(xc, wc, None, padding=1) if what == "fwd" else F.conv_transpose2d(xc, wc, None, padding=1)
     sc = torch.full((B, 1, 1, 1), 0.7, dtype=torch.double)
