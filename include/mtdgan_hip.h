@@ -34,6 +34,11 @@ extern "C" {
 #define MTD_ACT_NONE 0
 #define MTD_ACT_RELU 1
 #define MTD_ACT_LRELU 2   /* LeakyReLU(0.2) -- arch/Ours/networks.py:182 etc. */
+/* Round 4: relu(acc * scale + bias) + add1 + add2 -- the residual operands added AFTER the activation: x + relu(conv3x3(x) + b)
+ * of FFT_ConvBlock.forward (networks.py:31-35) in one launch for whole-slice inference, where the block's third term then
+ * needs one operand less.  Only where mtd_conv_relu_add_ok() says so (mtd_conv_igemm on the generator-shaped 32-channel 3x3
+ * layers whose plan is the persistent kernel; no mask, no out2); every other entry point answers MTD_EINVAL to it. */
+#define MTD_ACT_RELU_ADD 3
 
 /* Gather geometry shared by conv forward, data-gradient and weight-gradient kernels.
  * For launch-grid pixel (b, oy, ox), tap (ty, tx):
@@ -130,6 +135,7 @@ int mtd_pack_weights(const mtd_pack_desc* table_dev, const mtd_pack_desc* table_
  * of 32): generator encoder.0 / decoder.0 (networks.py:97,162), discriminator conv11, *_dconv61/62,
  * enc_out/dec_out/rec_out (networks.py:385,441-442,466-472). */
 int mtd_conv_direct(const mtd_conv_args* a, void* stream);
+int mtd_conv_relu_add_ok(const mtd_conv_args* a);      /* nonzero: mtd_conv_igemm takes these arguments with act = MTD_ACT_RELU_ADD */
 
 /* Weight gradient:  dW(n,c,kidx) (+)= sum_pix p[pix,n] * q[gather(pix,tap),c]
  * (autograd of the conv call sites above).  dw is addressed like W.

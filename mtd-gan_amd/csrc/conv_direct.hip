@@ -731,7 +731,7 @@ bool wide_plan(const mtd_wgrad_args& a, WideParams& p) {
 }  // namespace
 
 extern "C" int mtd_conv_direct(const mtd_conv_args* a, void* stream) {
-    if (!a || !a->in || !a->w || !a->out || a->out2) return MTD_EINVAL;
+    if (!a || !a->in || !a->w || !a->out || a->out2 || a->act == MTD_ACT_RELU_ADD) return MTD_EINVAL;
     const mtd_geom& g = a->g;
     if (a->C <= 0 || a->N <= 0 || g.B <= 0 || g.TH <= 0 || g.TW <= 0) return MTD_EINVAL;
     if (a->in_ld < a->C || a->out_ld < a->N) return MTD_EINVAL;

@@ -84,6 +84,12 @@ __device__ __forceinline__ long long out_pixel(const mtd_geom& g, int m, int ide
 __device__ __forceinline__ float epilogue_value(const mtd_conv_args& a, float acc, float sc, float bias_n,
                                                 long long pix, int n) {
     float v = acc * sc + bias_n;
+    if (a.act == MTD_ACT_RELU_ADD) {        // the residual operands AFTER the activation (whole-slice Res-FFT block)
+        v = v > 0.f ? v : 0.f;
+        if (a.add1) v += a.add1[pix * a.add1_ld + n];
+        if (a.add2) v += a.add2[pix * a.add2_ld + n];
+        return v;
+    }
     if (a.add1) v += a.add1[pix * a.add1_ld + n];
     if (a.add2) v += a.add2[pix * a.add2_ld + n];
     v = apply_act(v, a.act);
@@ -150,9 +156,11 @@ __device__ __forceinline__ void epi_store(const IgemmParams& p, const f32x16& ac
                                           float bias_n, const EpiOps<NE>& o) {
     const mtd_conv_args& a = p.a;
     float v[NE];
+    const bool post = a.act == MTD_ACT_RELU_ADD;       // the residual operands AFTER the activation (whole-slice Res-FFT block)
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         v[i] = acc[E0 + i] * pick_scale(sp, ad.mu + mfma32_row(E0 + i, ad.lane)) + bias_n;
+        if (post) v[i] = v[i] > 0.f ? v[i] : 0.f;
         v[i] += o.e1[i];
         v[i] += o.e2[i];
     }
@@ -287,6 +295,21 @@ __device__ __forceinline__ void epiw_store(const IgemmParams& p, const f32x16& a
                                            const EpiWideOps& o) {
     const mtd_conv_args& a = p.a;
     f32x4 v[4];
+    if (a.act == MTD_ACT_RELU_ADD) {        // the residual operands AFTER the activation (no mask, no second output)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = acc[4 * g + j] * ad.sc + bias4[g][j];
+                x = x > 0.f ? x : 0.f;
+                x += o.e1[g][j];
+                x += o.e2[g][j];
+                v[g][j] = x;
+            }
+            *reinterpret_cast<f32x4*>(a.out + ad.pix * a.out_ld + ad.ch + 8 * g) = v[g];
+        }
+        return;
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -1525,6 +1548,14 @@ extern "C" int mtd_conv_igemm_override(int cfg, int splitk) {
     return MTD_OK;
 }
 
+// Does mtd_conv_igemm take these arguments with act = MTD_ACT_RELU_ADD?  (The persistent kernel of the generator-shaped layers:
+// its two epilogue forms implement it; no split-K, no mask, no second output.)
+extern "C" int mtd_conv_relu_add_ok(const mtd_conv_args* a) {
+    if (!a || check_args(*a) != MTD_OK || a->out2 || a->mask) return 0;
+    const bool gen_shape = a->C == 32 && a->g.TH * a->g.TW == 9 && geom_pixels(a->g) >= 32768;
+    return (g_force_cfg == -1 || g_force_cfg == 9) && gen_shape ? 1 : 0;
+}
+
 extern "C" size_t mtd_conv_igemm_ws_bytes(const mtd_conv_args* a) {
     if (!a || check_args(*a) != MTD_OK) return 0;
     Plan pl = make_plan(*a);
@@ -1607,7 +1638,7 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const double alg_bytes = algorithmic_bytes(a);      // profiler record
     const bool gen_shape = a->C == 32 && a->g.TH * a->g.TW == 9 && p.M >= 32768;
-    if ((g_force_cfg == -1 || g_force_cfg == 10) && gen_shape && c32t_eligible(*a)) {
+    if ((g_force_cfg == -1 || g_force_cfg == 10) && gen_shape && c32t_eligible(*a) && a->act != MTD_ACT_RELU_ADD) {
         // generator-shaped layers on 64-pixel rows: halo tiles of four image rows, one persistent workgroup per CU
         const int prof = mtd_prof_begin(0, 10, 1, p.M, a->N, a->C, 9, s, alg_bytes);
         static const int env_variant = [] { const char* e = getenv("MTD_C32T_VARIANT"); return e ? atoi(e) : 0; }();
@@ -1628,6 +1659,7 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
         return MTD_OK;
     }
     if (a->out2) return MTD_EINVAL;               // second output: halo-tile kernel only
+    if (a->act == MTD_ACT_RELU_ADD && !((g_force_cfg == -1 || g_force_cfg == 9) && gen_shape && !a->mask)) return MTD_EINVAL;
     if ((g_force_cfg == -1 || g_force_cfg == 9) && gen_shape) {
         // generator-shaped layers: persistent kernel, two 32-pixel tiles per wave at M = 131072
         const int ntiles = (p.M + 31) / 32;
@@ -1722,6 +1754,8 @@ extern "C" size_t mtd_conv_igemm_multi_ws_bytes(const mtd_conv_args* a, int coun
 }
 
 extern "C" int mtd_conv_igemm_multi(const mtd_conv_args* a, int count, void* stream) {
+    for (int i = 0; a && i < count; ++i)
+        if (a[i].act == MTD_ACT_RELU_ADD) return MTD_EINVAL;
     if (!a || count < 1 || count > MULTI_MAX) return MTD_EINVAL;
     for (int i = 0; i < count; ++i) {
         int rc = check_args(a[i]);

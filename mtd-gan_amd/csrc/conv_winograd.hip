@@ -490,7 +490,7 @@ bool wino_eligible(const mtd_conv_args& a) {
         if (dy < -1 || dy > 1 || dx < -1 || dx > 1) return false;
     }
     if (g.tap_dy == 0 || g.tap_dx == 0) return false;
-    if ((a.C % 16) || (a.N % 64) || a.out2) return false;
+    if ((a.C % 16) || (a.N % 64) || a.out2 || a.act == MTD_ACT_RELU_ADD) return false;
     return true;
 }
 

@@ -42,8 +42,18 @@ __device__ __forceinline__ void twiddle(const float* tw, int hS, int idx, float&
 
 // (NT = threads per workgroup as a compile-time constant: the butterfly loops then have constant trip counts and are unrolled
 // by UNR, so that the LDS reads of UNR butterflies are in flight together)
-template <int SIGN, bool DIF, int LD, int NT = 1024, int UNR = 2>
+// V = channels per lane: 1 (lane = channel, 4-byte LDS accesses) or 2 (lane = channel pair, 8-byte accesses: half the LDS
+// instructions per butterfly -- the column kernel's transforms are bound by LDS instruction issue; LD must then be even).
+template <int V> struct FftVec { typedef float type; };
+template <> struct FftVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+
+template <int SIGN, bool DIF, int LD, int NT = 1024, int UNR = 2, int V = 1>
 __device__ __forceinline__ void lds_fft(float* re, float* im, const float* tw, int S, int logS) {
+    typedef typename FftVec<V>::type VT;
+    static_assert(V == 1 || (V == 2 && (LD % 2) == 0), "8-byte accesses need even row strides");
+    constexpr int CPL = 32 / V, CSH = V == 2 ? 4 : 5;          // lanes per point, log2 of it
+#define FLD(P, I) (*reinterpret_cast<const VT*>((P) + (I)))
+#define FST(P, I, X) (*reinterpret_cast<VT*>((P) + (I)) = (X))
     const int hS = S >> 1;
     int st = 0;
     // single radix-2 stage when log2(S) is odd: the first stage for DIF (half = S/2), the first for DIT (half = 1)
@@ -51,27 +61,27 @@ __device__ __forceinline__ void lds_fft(float* re, float* im, const float* tw, i
         const int lh = DIF ? (logS - 1) : 0;
         const int half = 1 << lh, tshift = logS - 1 - lh;
 #pragma unroll UNR
-        for (int e = threadIdx.x; e < hS * 32; e += (NT > 0 ? NT : (int)blockDim.x)) {
-            const int c = e & 31, pidx = e >> 5;
+        for (int e = threadIdx.x; e < hS * CPL; e += (NT > 0 ? NT : (int)blockDim.x)) {
+            const int c = (e & (CPL - 1)) * V, pidx = e >> CSH;
             const int grp = pidx >> lh, j = pidx & (half - 1);
             const int i0 = (((grp << 1) << lh) + j) * LD + c, i1 = i0 + half * LD;
             float cs, sn;
             twiddle<SIGN>(tw, hS, j << tshift, cs, sn);
-            const float ur = re[i0], ui = im[i0], vr = re[i1], vi = im[i1];
+            const VT ur = FLD(re, i0), ui = FLD(im, i0), vr = FLD(re, i1), vi = FLD(im, i1);
             if (DIF) {
-                const float dr = ur - vr, di = ui - vi;
-                re[i0] = ur + vr; im[i0] = ui + vi;
-                re[i1] = dr * cs - di * sn; im[i1] = dr * sn + di * cs;
+                const VT dr = ur - vr, di = ui - vi;
+                FST(re, i0, ur + vr); FST(im, i0, ui + vi);
+                FST(re, i1, dr * cs - di * sn); FST(im, i1, dr * sn + di * cs);
             } else {
-                const float wr = vr * cs - vi * sn, wi = vr * sn + vi * cs;
-                re[i0] = ur + wr; im[i0] = ui + wi;
-                re[i1] = ur - wr; im[i1] = ui - wi;
+                const VT wr = vr * cs - vi * sn, wi = vr * sn + vi * cs;
+                FST(re, i0, ur + wr); FST(im, i0, ui + wi);
+                FST(re, i1, ur - wr); FST(im, i1, ui - wi);
             }
         }
         __syncthreads();
         st = 1;
     }
-    const int nq = (S >> 2) * 32;                     // 4-point groups per fused pass (x channel)
+    const int nq = (S >> 2) * CPL;                    // 4-point groups per fused pass (x channel)
     for (; st < logS; st += 2) {
         if (DIF) {
             // stages with half = H and H/2;  points a, b = a + H/2, c = a + H, d = a + 3H/2 of a block of 2H
@@ -80,22 +90,22 @@ __device__ __forceinline__ void lds_fft(float* re, float* im, const float* tw, i
             const int ts1 = logS - 1 - lH, ts2 = ts1 + 1;
 #pragma unroll UNR
             for (int e = threadIdx.x; e < nq; e += (NT > 0 ? NT : (int)blockDim.x)) {
-                const int c = e & 31, q = e >> 5;
+                const int c = (e & (CPL - 1)) * V, q = e >> CSH;
                 const int blk = q >> (lH - 1), j = q & (Q - 1);
                 const int ia = ((blk << (lH + 1)) + j) * LD + c, ib = ia + Q * LD, ic = ia + H * LD, id = ic + Q * LD;
                 float c1, s1, c2, s2, c3, s3;
                 twiddle<SIGN>(tw, hS, j << ts1, c1, s1);
                 twiddle<SIGN>(tw, hS, (j + Q) << ts1, c2, s2);
                 twiddle<SIGN>(tw, hS, j << ts2, c3, s3);
-                const float ar = re[ia], ai = im[ia], br = re[ib], bi = im[ib], cr = re[ic], ci = im[ic], dr = re[id], di = im[id];
-                const float a1r = ar + cr, a1i = ai + ci, tr = ar - cr, ti = ai - ci;
-                const float c1r = tr * c1 - ti * s1, c1i = tr * s1 + ti * c1;
-                const float b1r = br + dr, b1i = bi + di, ur = br - dr, ui = bi - di;
-                const float d1r = ur * c2 - ui * s2, d1i = ur * s2 + ui * c2;
-                re[ia] = a1r + b1r; im[ia] = a1i + b1i;
-                { const float xr = a1r - b1r, xi = a1i - b1i; re[ib] = xr * c3 - xi * s3; im[ib] = xr * s3 + xi * c3; }
-                re[ic] = c1r + d1r; im[ic] = c1i + d1i;
-                { const float xr = c1r - d1r, xi = c1i - d1i; re[id] = xr * c3 - xi * s3; im[id] = xr * s3 + xi * c3; }
+                const VT ar = FLD(re, ia), ai = FLD(im, ia), br = FLD(re, ib), bi = FLD(im, ib), cr = FLD(re, ic), ci = FLD(im, ic), dr = FLD(re, id), di = FLD(im, id);
+                const VT a1r = ar + cr, a1i = ai + ci, tr = ar - cr, ti = ai - ci;
+                const VT c1r = tr * c1 - ti * s1, c1i = tr * s1 + ti * c1;
+                const VT b1r = br + dr, b1i = bi + di, ur = br - dr, ui = bi - di;
+                const VT d1r = ur * c2 - ui * s2, d1i = ur * s2 + ui * c2;
+                FST(re, ia, a1r + b1r); FST(im, ia, a1i + b1i);
+                { const VT xr = a1r - b1r, xi = a1i - b1i; FST(re, ib, xr * c3 - xi * s3); FST(im, ib, xr * s3 + xi * c3); }
+                FST(re, ic, c1r + d1r); FST(im, ic, c1i + d1i);
+                { const VT xr = c1r - d1r, xi = c1i - d1i; FST(re, id, xr * c3 - xi * s3); FST(im, id, xr * s3 + xi * c3); }
             }
         } else {
             // stages with half = h and 2h;  points a, b = a + h, c = a + 2h, d = a + 3h of a block of 4h
@@ -104,28 +114,30 @@ __device__ __forceinline__ void lds_fft(float* re, float* im, const float* tw, i
             const int ts1 = logS - 1 - lh, ts2 = ts1 - 1;
 #pragma unroll UNR
             for (int e = threadIdx.x; e < nq; e += (NT > 0 ? NT : (int)blockDim.x)) {
-                const int c = e & 31, q = e >> 5;
+                const int c = (e & (CPL - 1)) * V, q = e >> CSH;
                 const int blk = q >> lh, j = q & (h - 1);
                 const int ia = ((blk << (lh + 2)) + j) * LD + c, ib = ia + h * LD, ic = ib + h * LD, id = ic + h * LD;
                 float c1, s1, c2, s2, c3, s3;
                 twiddle<SIGN>(tw, hS, j << ts1, c1, s1);
                 twiddle<SIGN>(tw, hS, j << ts2, c2, s2);
                 twiddle<SIGN>(tw, hS, (j + h) << ts2, c3, s3);
-                const float ar = re[ia], ai = im[ia], br = re[ib], bi = im[ib], cr = re[ic], ci = im[ic], dr = re[id], di = im[id];
-                const float bwr = br * c1 - bi * s1, bwi = br * s1 + bi * c1;
-                const float dwr = dr * c1 - di * s1, dwi = dr * s1 + di * c1;
-                const float a1r = ar + bwr, a1i = ai + bwi, b1r = ar - bwr, b1i = ai - bwi;
-                const float c1r = cr + dwr, c1i = ci + dwi, d1r = cr - dwr, d1i = ci - dwi;
-                const float cwr = c1r * c2 - c1i * s2, cwi = c1r * s2 + c1i * c2;
-                const float ewr = d1r * c3 - d1i * s3, ewi = d1r * s3 + d1i * c3;
-                re[ia] = a1r + cwr; im[ia] = a1i + cwi;
-                re[ic] = a1r - cwr; im[ic] = a1i - cwi;
-                re[ib] = b1r + ewr; im[ib] = b1i + ewi;
-                re[id] = b1r - ewr; im[id] = b1i - ewi;
+                const VT ar = FLD(re, ia), ai = FLD(im, ia), br = FLD(re, ib), bi = FLD(im, ib), cr = FLD(re, ic), ci = FLD(im, ic), dr = FLD(re, id), di = FLD(im, id);
+                const VT bwr = br * c1 - bi * s1, bwi = br * s1 + bi * c1;
+                const VT dwr = dr * c1 - di * s1, dwi = dr * s1 + di * c1;
+                const VT a1r = ar + bwr, a1i = ai + bwi, b1r = ar - bwr, b1i = ai - bwi;
+                const VT c1r = cr + dwr, c1i = ci + dwi, d1r = cr - dwr, d1i = ci - dwi;
+                const VT cwr = c1r * c2 - c1i * s2, cwi = c1r * s2 + c1i * c2;
+                const VT ewr = d1r * c3 - d1i * s3, ewi = d1r * s3 + d1i * c3;
+                FST(re, ia, a1r + cwr); FST(im, ia, a1i + cwi);
+                FST(re, ic, a1r - cwr); FST(im, ic, a1i - cwi);
+                FST(re, ib, b1r + ewr); FST(im, ib, b1i + ewi);
+                FST(re, id, b1r - ewr); FST(im, id, b1i - ewi);
             }
         }
         __syncthreads();
     }
+#undef FLD
+#undef FST
 }
 
 // Lab knobs (compile time; tools/any_variants.sh builds and times them on the GPU box).  Measured at S = 512, B = 8, ms per 21
@@ -133,6 +145,12 @@ __device__ __forceinline__ void lds_fft(float* re, float* im, const float* tw, i
 // (-DMTD_ANY_CT) 2.54 / 8.27 / 4.54 and unrolled by 2 (-DMTD_ANY_UNR=2) 2.54 / 8.08 / 4.52 -- the compiler then keeps more
 // butterflies in flight than a lane's 128 registers hold and spills; 512 threads per workgroup (-DMTD_ANY_NT512=512: 256
 // registers per lane, no spills) 2.63 / 6.82 / 4.82.
+#ifndef MTD_ANY_SKIP      // lab (wrong results): bit 0 skips the forward column transform, bit 1 the mix's MFMAs, bit 2 the inverse transform
+#define MTD_ANY_SKIP 0
+#endif
+#ifndef MTD_ANY_FFTV      // channels per lane in the column kernel's transforms (1 or 2)
+#define MTD_ANY_FFTV 2
+#endif
 #ifndef MTD_ANY_NT512
 #define MTD_ANY_NT512 1024
 #endif
@@ -200,7 +218,7 @@ __global__ __launch_bounds__(NT) void rfft_rows_any_kernel(const float* __restri
 }
 
 // columns + channel mix + columns back: a column (b, kw) per step.  LDS rows are CLD = 33 floats apart (see the header).
-constexpr int CLD = 33;
+constexpr int CLD = 34;        // even (8-byte transform accesses), 2-way bank conflicts for the MFMA operand reads along the frequency index
 template <int S, int NT>
 __global__ __launch_bounds__(NT) void spec_mix_any_kernel(const float* __restrict__ R, const float* __restrict__ w2t,
                                                            const float* __restrict__ b2, float* __restrict__ T, int units) {
@@ -235,7 +253,7 @@ __global__ __launch_bounds__(NT) void spec_mix_any_kernel(const float* __restric
             }
         }
         __syncthreads();
-        lds_fft<-1, true, CLD, FFT_NT(NT), FFT_UNR>(re, im, tw, S, logS);
+        if (!(MTD_ANY_SKIP & 1)) lds_fft<-1, true, CLD, FFT_NT(NT), FFT_UNR, MTD_ANY_FFTV>(re, im, tw, S, logS);
         // channel mix at every frequency on the matrix cores: D[o][n] = sum_k W[k][o] * Z[n][k], k = (re 0..31 | im 32..63).
         // A operand: lane (o = l & 31, k = l >> 5) of W from LDS; B operand: lane (n = l & 31, k = l >> 5) of the column.
         // work items = (32-row tile, output half): S / 32 * 2 over the 16 waves; results stay in registers until every
@@ -247,7 +265,7 @@ __global__ __launch_bounds__(NT) void spec_mix_any_kernel(const float* __restric
             const int item = wv + NW * i;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-            if (item < ITEMS) {
+            if (item < ITEMS && !(MTD_ANY_SKIP & 2)) {
                 const int tile = item % (S / 32), ob = item / (S / 32);
                 const float* zr = re + (tile * 32 + (lane & 31)) * CLD + (lane >> 5);
                 const float* zi = im + (tile * 32 + (lane & 31)) * CLD + (lane >> 5);
@@ -276,7 +294,7 @@ __global__ __launch_bounds__(NT) void spec_mix_any_kernel(const float* __restric
         // the next column's loads: issued here, after the mix (their 32 registers are not live under its accumulators -- with
         // 1024 threads a lane has 128), they land under the inverse transform
         if (u + (int)gridDim.x < units) issue(u + gridDim.x);
-        lds_fft<+1, false, CLD, FFT_NT(NT), FFT_UNR>(re, im, tw, S, logS);
+        if (!(MTD_ANY_SKIP & 4)) lds_fft<+1, false, CLD, FFT_NT(NT), FFT_UNR, MTD_ANY_FFTV>(re, im, tw, S, logS);
         float* dstg = T + (long long)u * S * 64;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {

@@ -25,9 +25,14 @@ def block_forward(x, w_img, b_img, w_fft, b_fft, save, w2t=None):
             raise RuntimeError("FFT_ConvBlock: training is implemented for 64 x 64 patches; larger maps are inference-only")
         if H != W or H not in (128, 256, 512):
             raise RuntimeError(f"FFT_ConvBlock: unsupported map size {H} x {W} (64, 128, 256 or 512 square)")
-        K.conv(x, w_img, g, CH, CH, CH * 9, 9, img, bias=b_img, act=ACT_RELU)
         out = K.empty_nhwc(B, H, W, CH, x)
-        K.spectral_branch_any(x, K.transpose64(w_fft), b_fft, out, add1=x, add2=img)
+        if K.conv_relu_add_ok(x, w_img, g, CH, CH, CH * 9, 9, img, bias=b_img, add1=x):
+            # img = x + relu(conv3x3(x) + b) in one launch (MTD_ACT_RELU_ADD): the closing row transform then adds ONE operand
+            K.conv(x, w_img, g, CH, CH, CH * 9, 9, img, bias=b_img, add1=x, act=K.ACT_RELU_ADD)
+            K.spectral_branch_any(x, K.transpose64(w_fft), b_fft, out, add1=img)
+        else:
+            K.conv(x, w_img, g, CH, CH, CH * 9, 9, img, bias=b_img, act=ACT_RELU)
+            K.spectral_branch_any(x, K.transpose64(w_fft), b_fft, out, add1=x, add2=img)
         return out, None
     if w2t is None:
         w2t = K.transpose64(w_fft)

@@ -8,7 +8,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ConvArgs, Geom, WgradArgs, check  # noqa: F401
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_RELU_ADD, ConvArgs, Geom, WgradArgs, check  # noqa: F401
 
 _ws = {}
 _pack_cache = {}
@@ -475,6 +475,15 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, **kw):
             CALL_LOG.append(("direct", bytes(a)))
         check(L.mtd_conv_direct(C.byref(a), stream_ptr()), "mtd_conv_direct")
     return out
+
+
+def conv_relu_add_ok(x, w, geom, N, Cc, w_sn, w_sc, out, **kw):
+    """Would conv(..., act=ACT_RELU_ADD) -- relu(conv + bias) + add1 + add2, the adds AFTER the activation -- be taken for these
+    arguments (mtd_conv_relu_add_ok)?  Nothing is launched or counted."""
+    if os.environ.get("MTD_NO_RELU_ADD", "0") == "1" or (Cc % 32) or (N % 32):
+        return False
+    a = _conv_args(x, w, geom, N, Cc, w_sn, w_sc, out, act=ACT_RELU_ADD, count=False, **kw)
+    return bool(_lib.lib().mtd_conv_relu_add_ok(C.byref(a)))
 
 
 MULTI_CONV = os.environ.get("MTD_NO_MULTI_CONV", "0") != "1"

@@ -4,7 +4,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out; mkdir -p $O
 OBJS=$(ls mtd-gan_amd/csrc/build/*.o | grep -v resfft_any.o)
-for cfg in "" "-DMTD_ANY_UNR=2" "-DMTD_ANY_CT" "-DMTD_ANY_NT512=512 -DMTD_ANY_CT" "-DMTD_ANY_NT512=512 -DMTD_ANY_CT -DMTD_ANY_UNR=2" "-DMTD_ANY_NT512=512"; do
+for cfg in ${ANY_CFGS:-"" "-DMTD_ANY_FFTV=1" "-DMTD_ANY_SKIP=1" "-DMTD_ANY_SKIP=2" "-DMTD_ANY_SKIP=4" "-DMTD_ANY_SKIP=7"}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc $cfg -c mtd-gan_amd/csrc/resfft_any.hip -o mtd-gan_amd/csrc/build/resfft_any.o 2>/dev/null || { echo "compile failed: $cfg"; continue; }
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o mtd-gan_amd/libmtdgan_hip.so $OBJS mtd-gan_amd/csrc/build/resfft_any.o
   timeout -k 10 200 python bench.py --workload inference512 --no-cpu-baseline --steps 10 --warmup 2 > $O/any_var.json 2> $O/any_var.err || { echo "bench failed: $cfg"; tail -3 $O/any_var.err; continue; }

@@ -1,15 +1,16 @@
 #!/bin/bash
-# Copies the summaries of the last tools/r3_measure.sh run from gpurun_out/ (scratch) to profiles/ (tracked)
+# Copies the summaries of the last tools/r4_measure.sh run from gpurun_out/ (scratch) to profiles/ (tracked)
 # and rewrites profiles/pmc_manifest.json with the kernel-source hash the PMC passes were taken at.  Run after a gpurun call
-# of both scripts, with the same kernel sources checked out.
+# of the script, with the same kernel sources checked out.   usage: tools/install_profiles.sh r4 [nogit]
 set -e
 cd "$(dirname "$0")/.."
-R=${1:-r3}
+R=${1:-r4}
 O=gpurun_out
-cp $O/bench_full.json profiles/${R}_full_step_bench.json
+[ -f $O/bench_full.json ] && [ "$2" != "nogit" ] && cp $O/bench_full.json profiles/${R}_full_step_bench.json
 cp $O/prof_full/full_results_kernel_stats.csv profiles/${R}_full_step_kernel_stats_single_stream.csv
 cp $O/prof_gen/gen_results_kernel_stats.csv profiles/${R}_generator_kernel_stats_single_stream.csv
-for wl in full_step generator; do
+cp $O/prof_inf/inf_results_kernel_stats.csv profiles/${R}_inference512_kernel_stats.csv
+for wl in full_step generator inference512; do
   for k in fetch write mfma_util; do cp $O/pmc_${wl}_$k.csv profiles/${R}_pmc_${wl}_$k.csv; done
 done
 python - "$R" <<'PY'
@@ -24,9 +25,9 @@ try:
     commit = subprocess.check_output(["git", "rev-parse", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
 except Exception:
     commit = "unknown (no .git on the GPU box; the builder's install_profiles.sh run records it)"
-cmd = "tools/r3_measure.sh (rocprofv3 --pmc <counter(s)> --kernel-trace, one pass per counter set, eager single-stream launches)"
+cmd = f"tools/{R}_measure.sh (rocprofv3 --pmc <counter(s)> --kernel-trace, one pass per counter set, eager single-stream launches)"
 man = {wl: {"files": {"fetch": f"{R}_pmc_{wl}_fetch.csv", "write": f"{R}_pmc_{wl}_write.csv", "mfma": f"{R}_pmc_{wl}_mfma_util.csv"},
-            "commit": commit, "source_hash": h_now, "command": cmd} for wl in ("full_step", "generator")}
+            "commit": commit, "source_hash": h_now, "command": cmd} for wl in ("full_step", "generator", "inference512")}
 json.dump(man, open("profiles/pmc_manifest.json", "w"), indent=1)
 print("profiles/ updated at", commit[:10], h_now)
 PY
