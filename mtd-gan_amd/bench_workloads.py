@@ -28,12 +28,12 @@ class GeneratorWorkload:
         import os
         mode = os.environ.get("MTD_GRAPH", "1")
         if world == 1 and mode == "list":
-            # recorded launch list (kernels.LaunchList): the step's C-ABI calls and stream-order operations re-issued
-            # without the Python around them, side streams kept.  Measured (tools/list_probe.py, 284 launches, host enqueue
-            # 1.1-3.0 ms per step, so GPU-bound in every mode): all side streams 7.14 ms, weight gradients only 6.74 ms, one
-            # stream 6.56 ms -- against 6.43 ms for the captured single-stream graph, which therefore stays the default.
-            # The kernels of a block cannot share a CU (the halo-tile conv holds 136 KB of LDS, one workgroup per CU), so
-            # a second stream only adds event waits between them.
+            # recorded launch list (kernels.LaunchList): the step's C-ABI calls and stream-order operations re-issued without
+            # the Python around them, side streams kept.  For THIS workload the captured single-stream graph is the faster
+            # replay (round 2, docs/LAB_NOTES_r1_r2.md: the kernels of a Res-FFT block cannot share a CU -- the halo-tile conv
+            # holds 136 KB of LDS, one workgroup per CU -- so a second stream only adds event waits between them); the full
+            # training iteration, whose weight gradients do overlap its data-gradient chain, replays as a list by default
+            # (train_step.RecordedTrainStep).
             from . import kernels as K
             try:
                 for _ in range(2):
@@ -47,10 +47,10 @@ class GeneratorWorkload:
                 self.launch_list = None
                 torch.cuda.synchronize()
         if world == 1 and mode == "1":
-            # hipGraph replay of the forward + backward (static shapes, no host-side state): the Python enqueue of the 432
-            # launches takes 7.3 ms per step, as long as the GPU work.  Captured with every kernel in ONE stream: replay of a
-            # single-stream graph runs at the kernels' own pace (7.1 ms), a captured multi-stream section does not (7.9 ms,
-            # ROCm 7.2), and eager launches are host-bound (7.8 ms).  MTD_GRAPH=0 keeps the eager launches.
+            # hipGraph replay of the forward + backward (static shapes, no host-side state): eager launches of this workload
+            # are host-bound (the Python enqueue of its ~430 launches takes longer than the 5.4 ms of GPU work).  Captured
+            # with every kernel in ONE stream: a single-stream graph replays at the kernels' own pace, a captured multi-stream
+            # section does not (ROCm 7.2 serialises it with extra waits).  MTD_GRAPH=0 keeps the eager launches.
             from . import kernels as K
             try:
                 K.set_concurrency(False)
