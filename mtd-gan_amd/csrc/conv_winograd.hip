@@ -127,7 +127,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
     constexpr int NP = 4 * PX;            // transform positions xi = PX * (patch row) + (patch column)
     constexpr int PW = NP / 8;            // positions per wave
     constexpr int TWX = PX - 2;           // output pixels per tile row
-    static_assert(PX == 4 || (PX == 6 && NB == 2 && !LEAN), "F(2x4, 3x3): NB = 2, one workgroup per CU");
+    static_assert(PX == 4 || (PX == 6 && NB <= 2 && !LEAN), "F(2x4, 3x3): NB <= 2, one workgroup per CU");
     // As: two buffers of NP positions x 32 tiles x 16 channels (row stride WALD floats, 40 / 60 KB each); the exchange image of
     // the epilogue (NP x 32 x WXLD floats = 72 / 108 KB) reuses the same memory after the K loop.
     constexpr int AS_BUF = NP * WT * WALD;
@@ -326,8 +326,8 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
 #pragma unroll
             for (int i = 0; i < 4 * PW * NB; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
-                if ((i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, NB == 2 ? 7 : 14, 0);
+                if ((i & (NB == 2 ? 3 : 1)) == (NB == 2 ? 3 : 1)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -514,6 +514,13 @@ WinoPlan wino_plan(const mtd_conv_args& a, int px) {
     pl.px = px;
     const int tile_px = 2 * (px - 2);                            // output pixels per tile
     pl.nb = (a.N % 128 == 0 && px == 4) ? 4 : 2;
+    // F(2x4): a tile block is 256 pixels x 64 channels; where that leaves the grid short (the mid-size maps: 4096 .. 16384 pixels),
+    // 32-channel workgroups (NB = 1) before a split of K -- no slabs, no finishing launch (MTD_WINO_F4_NB1=0: always NB = 2)
+    static const int env_f4_nb1 = [] { const char* e = getenv("MTD_WINO_F4_NB1"); return e ? atoi(e) : 1; }();
+    if (px == 6 && env_f4_nb1) {
+        const long long t = geom_pixels(a.g) / tile_px;
+        if (((t + WT - 1) / WT) * (a.N / 64) <= 128 && a.C >= 128) pl.nb = 1;
+    }
     // (lab, MTD_WINO_NB2_MAXC=64: the narrow form with its lean variant for layers with four K steps whatever their N -- 5 % less time
     // for those launches (123 -> 116 us, 226 -> 213 us), 0.08 ms per step, but the input is then read per 64 instead of per 128 output
     // channels: 62 -> 80 MB of fabric traffic per launch.  Off.)
@@ -663,10 +670,11 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
     }
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((wp.ntiles + WT - 1) / WT, a->N / (32 * pl.nb), pl.splitk);
-    // (one profiler id per INSTANTIATION -- 14: <2, false, 4>, 15: <4, false, 4>, 22: <2, true, 4>, 23: <2, false, 6> -- so that a record's name is
+    // (one profiler id per INSTANTIATION -- 14: <2, false, 4>, 15: <4, false, 4>, 22: <2, true, 4>, 23: <2, false, 6>, 24: <1, false, 6> -- so that a record's name is
     // one kernel symbol of a rocprofv3 table)
-    const int prof = mtd_prof_begin(0, px == 6 ? 23 : (pl.nb == 4 ? 15 : (pl.lean ? 22 : 14)), pl.splitk, p.M, a->N, a->C, 9, s, algorithmic_bytes(a));
-    if (px == 6) MTD_LAUNCH((wino_conv_kernel<2, false, 6>), grid, dim3(512), 0, s, wp);
+    const int prof = mtd_prof_begin(0, px == 6 ? (pl.nb == 1 ? 24 : 23) : (pl.nb == 4 ? 15 : (pl.lean ? 22 : 14)), pl.splitk, p.M, a->N, a->C, 9, s, algorithmic_bytes(a));
+    if (px == 6 && pl.nb == 1) MTD_LAUNCH((wino_conv_kernel<1, false, 6>), grid, dim3(512), 0, s, wp);
+    else if (px == 6) MTD_LAUNCH((wino_conv_kernel<2, false, 6>), grid, dim3(512), 0, s, wp);
     else if (pl.nb == 4) MTD_LAUNCH((wino_conv_kernel<4>), grid, dim3(512), 0, s, wp);
     else if (pl.lean) MTD_LAUNCH((wino_conv_kernel<2, true>), grid, dim3(512), 0, s, wp);
     else MTD_LAUNCH((wino_conv_kernel<2>), grid, dim3(512), 0, s, wp);
