@@ -470,6 +470,7 @@ class GraphedTrainStep:
 
 # ================================================================================================ launch-list replay
 LIST_MODE = os.environ.get("MTD_LIST", "1") != "0"      # engine.train_MTD_GAN_Ours / bench: recorded launch list after two eager iterations
+LIST_UNDER_DP = os.environ.get("MTD_LIST_DP", "1") != "0"   # ... also in a multi-rank group (0: data-parallel iterations stay eager)
 
 
 class RecordedTrainStep:
@@ -510,10 +511,15 @@ class RecordedTrainStep:
     @staticmethod
     def _signature(model, oG, oD, wm, dp):
         D, G = model.Discriminator, model.Generator
+        # (version counters: an in-place torch update from outside -- load_state_dict, weight clipping, an EMA copy -- between two
+        # iterations moves them; the list's own launches and FusedAdamW write through raw pointers and do not.  The list reads
+        # derived weight views that only its own pack launches refresh, so such an update retires it: two eager iterations, then a
+        # new recording.)
         return (tuple(p.data_ptr() for p in D.parameters()), tuple(p.data_ptr() for p in G.parameters()),
                 tuple(b.data_ptr() for b in D.buffers()), D.training, G.training, D.c_drop.p,
                 tuple(p.requires_grad for p in model.parameters()), id(oG), id(oD), id(wm), id(dp),
-                tuple((g["betas"], g["eps"]) for g in oD.param_groups + oG.param_groups))
+                tuple((g["betas"], g["eps"]) for g in oD.param_groups + oG.param_groups),
+                tuple(t._version for t in model.parameters()), tuple(t._version for t in model.buffers()))
 
     @staticmethod
     def usable(model, optimizer_G, optimizer_D, method_D, x, y):
@@ -556,7 +562,7 @@ def recorded_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp=None)
     eagerly, the third is recorded while it runs, later ones replay.  The step object lives on the model (it is tied to the
     model's parameter storage).  Returns (names, device tensor of the logged values) like engine.train_iteration."""
     from . import engine
-    if not RecordedTrainStep.usable(model, optimizer_G, optimizer_D, method_D, x, y):
+    if not RecordedTrainStep.usable(model, optimizer_G, optimizer_D, method_D, x, y) or (dp is not None and not LIST_UNDER_DP):
         return engine.train_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp)
     st = getattr(model, "_mtd_recorded", None)
     if isinstance(st, RecordedTrainStep):

@@ -678,6 +678,29 @@ def test_launch_list_replay_equals_eager_bit_for_bit(hip_lib):
             TS.LIST_MODE = True
     assert stats["eager"] == stats["list"], (stats["eager"], stats["list"])
     assert torch.equal(stats["eager_pred"], stats["list_pred"])
+    # ---- an in-place update from OUTSIDE the loop (here: a checkpoint loaded into the live model) retires the list: the next
+    # iterations are eager on the new weights, a new list is recorded at the third, and all of it equals plain eager execution
+    ends = {}
+    for mode in ("eager", "list"):
+        m, wm, oD, oG = build()
+        TS.LIST_MODE = mode == "list"
+        try:
+            for x, y in batches[:4]:
+                TS.recorded_iteration(m, x, y, oG, oD, wm, None)
+            first = getattr(m, "_mtd_recorded", None)
+            with torch.no_grad():
+                for p in m.Discriminator.parameters():
+                    p.mul_(0.5)                         # (bumps the version counters, as load_state_dict's copy_ does)
+            for x, y in batches:
+                TS.recorded_iteration(m, x, y, oG, oD, wm, None)
+            if mode == "list":
+                assert isinstance(first, TS.RecordedTrainStep) and isinstance(m._mtd_recorded, TS.RecordedTrainStep) and m._mtd_recorded is not first
+            torch.cuda.synchronize()
+            ends[mode] = {k: v.clone() for k, v in m.state_dict().items()}
+        finally:
+            TS.LIST_MODE = True
+    for k in ends["eager"]:
+        assert torch.equal(ends["list"][k], ends["eager"][k]), k
 
 
 def test_checkpoint_resume_like_train_py(hip_lib, tmp_path):
