@@ -409,13 +409,16 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
                 s.sigma2 = tp.sig2.data_ptr() + 8 * i
             structs.append(s)
         del sn_touched[:]
-        dev_tab, host_arr = K.device_table(structs, dev)
-        need = L.mtd_sn_grad_ws_bytes(C.cast(host_arr, C.c_void_p), len(structs))
-
         def fix():
+            # (the descriptor table is built HERE, under the side stream: a new table's upload is then ordered before its reader
+            # by the stream itself)
+            dev_tab, host_arr = K.device_table(structs, dev)
+            need = L.mtd_sn_grad_ws_bytes(C.cast(host_arr, C.c_void_p), len(structs))
             ws = K.workspace(need, dev)
             K.check(L.mtd_sn_grad(dev_tab.data_ptr(), C.cast(host_arr, C.c_void_p), len(structs), ws.data_ptr(), K.stream_ptr()), "mtd_sn_grad")
-        side.run(fix)
+        # (its operands are the raw weight gradients the side stream itself produced, the layer's weights and the saved u / v / sigma of
+        # the forward pass: nothing the main stream has enqueued since the last fork -- no new hand-off)
+        side.run(fix, fork=False)
 
     def flush_point(stage):
         if flush is not None:

@@ -51,8 +51,11 @@ def _all_reduce_generator_grads(model, G, dp):
     flat = getattr(model, "_ggrad_flat", None)
     grads = [p.grad for p in G.parameters()]
     if flat is not None and all(g is not None and g.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for g in grads):
-        dp.all_reduce_avg(flat)
-        dp.wait()
+        if hasattr(dp, "all_reduce_avg_inline"):
+            dp.all_reduce_avg_inline(flat)          # on the current stream: the optimizer launch that follows needs it at once
+        else:
+            dp.all_reduce_avg(flat)
+            dp.wait()
     else:
         dp.all_reduce_avg_list(grads)
 

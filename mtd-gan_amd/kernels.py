@@ -1415,11 +1415,14 @@ class SideStream:
         if self.enabled:
             _order(self.stream, torch.cuda.current_stream())
 
-    def run(self, fn, *keep):
+    def run(self, fn, *keep, fork=True):
+        """fork=False: the work depends only on what this stream already holds (the spectral-norm correction of weight
+        gradients the stream itself computed, a collective on them): no event hand-off from the main stream."""
         if not self.enabled:
             fn()
             return
-        self.fork()
+        if fork:
+            self.fork()
         with torch.cuda.stream(self.stream):
             fn()
         self._keep.extend(keep)

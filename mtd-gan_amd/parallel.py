@@ -71,6 +71,24 @@ class DataParallelSync:
             K.rec(collective)
         self._pending = True
 
+    def all_reduce_avg_inline(self, flat):
+        """Average a SMALL tensor across ranks on the CURRENT stream (the generator's 1.9 MB of gradients, needed by the very
+        next launch): no side stream, no event hand-offs -- at this size the two cross-stream hops cost more than the collective."""
+        if self.world == 1 and not self.force:
+            return
+        if not self.cuda:
+            return self.all_reduce_avg(flat)
+        from . import kernels as K
+        self.wait()                                   # (collectives on the side stream that may touch the same communicator: keep issue order)
+        if self.has_avg:
+            op = dist.ReduceOp.AVG if self.world > 1 else dist.ReduceOp.SUM
+            K.rec(lambda: dist.all_reduce(flat, op=op))
+        else:
+            def sum_and_scale():
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                flat.mul_(1.0 / self.world)
+            K.rec(sum_and_scale)
+
     def all_reduce_avg(self, flat, after=()):
         """Average `flat` (a contiguous tensor) across ranks.  On GPUs the collective runs on a side stream
         ordered after the kernels already enqueued on the current stream and on the streams in `after` (the weight-gradient

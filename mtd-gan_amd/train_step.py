@@ -155,10 +155,10 @@ class DStepTape:
         def ship(stage):
             side = K.side_stream(dev)          # the weight gradients and their spectral-norm corrections are on this stream
             if stage == "heads" and ts_names:
-                side.run(lambda: dp.all_reduce_avg(TSflat))
+                side.run(lambda: dp.all_reduce_avg(TSflat), fork=False)       # (ordered after the side stream's own work: no fork)
                 shipped["ts"] = True
             elif stage == "trunk_low" and tail_ofs is not None:
-                side.run(lambda: dp.all_reduce_avg(S[2, tail_ofs:]))
+                side.run(lambda: dp.all_reduce_avg(S[2, tail_ofs:]), fork=False)
                 shipped["tail"] = True
 
         adversarial()                                                                    # task 0
