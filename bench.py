@@ -39,7 +39,7 @@ def executed_fraction(kernel):
     """Share of a layer's algorithmic multiplications (2 M N C 9) that the kernel's MFMAs execute."""
     if "wino" not in kernel:
         return 1.0
-    return WINOGRAD_F24_EXECUTED if kernel.endswith(", 6>") else WINOGRAD_EXECUTED
+    return WINOGRAD_F24_EXECUTED if (kernel.endswith(", 6>") or "wino24" in kernel) else WINOGRAD_EXECUTED
 
 
 def parse(argv=None):

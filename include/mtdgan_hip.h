@@ -155,7 +155,8 @@ int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream);
 /* The kernel the plan picks for these arguments: index into the weight-gradient name table of the launch profiler
  * (16 = wgrad_wino_kernel, Winograd F(2x2,3x3): 4/9 of the layer's multiplications), -1 = the vector-ALU kernels of
  * mtd_conv_direct's domain, MTD_EINVAL = invalid arguments.  Nothing is launched.  (Host-side flop accounting of bench.py.) */
-int mtd_conv_wgrad_plan_cfg(const mtd_wgrad_args* a);
+int mtd_conv_wgrad_plan_cfg(const mtd_wgrad_args* a);      /* (17 = the F(2x4, 3x3) form of the Winograd kernel: 3/9 of the multiplications) */
+int mtd_conv_wgrad_wino24_min_w(int min_w);      /* tuning / test hook: narrowest map that takes that form; 0 = never, < 0 = query */
 
 /* The two image ranges [0, b_first), [b_first, B) of one batch, a weight gradient each (a->dw and dw2; both bias
  * gradients into a->db, the second accumulated) from ONE launch of the slab-producing kernel: the paired discriminator

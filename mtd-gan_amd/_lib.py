@@ -112,7 +112,7 @@ def _preload_torch_hip_runtime():
 
 
 RECORDER = None      # kernels.LaunchList: while a step is being recorded, the list every launch is appended to
-_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "mtd_prof_", "_override", "_bwd_ok", "_stamps", "_zmask_bytes", "_tail_ok", "_winograd_ok", "_weight_floats", "_kmap", "_plan_cfg", "_pair_ok", "_pair_mode", "_patch_w", "_f4_min_w", "_relu_add_ok")
+_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "mtd_prof_", "_override", "_bwd_ok", "_stamps", "_zmask_bytes", "_tail_ok", "_winograd_ok", "_weight_floats", "_kmap", "_plan_cfg", "_pair_ok", "_pair_mode", "_patch_w", "_f4_min_w", "_relu_add_ok", "_wino24_min_w")
 
 
 class _RecordingLib:
@@ -173,6 +173,7 @@ def lib():
     sig("mtd_conv_wgrad_ws_bytes", sz, C.POINTER(WgradArgs))
     sig("mtd_conv_wgrad", ci, C.POINTER(WgradArgs), vp)
     sig("mtd_conv_wgrad_plan_cfg", ci, C.POINTER(WgradArgs))
+    sig("mtd_conv_wgrad_wino24_min_w", ci, ci)
     sig("mtd_conv_wgrad_pair_ok", ci, C.POINTER(WgradArgs), ci)
     sig("mtd_conv_wgrad_pair_mode", ci, ci)
     sig("mtd_conv_wgrad_pair_ws_bytes", sz, C.POINTER(WgradArgs), ci)
@@ -273,7 +274,7 @@ EXPORTS = [
     "mtd_spec_mix_zmask_bytes", "mtd_spec_mix_fwd4", "mtd_spec_mix_bwd4",
     "mtd_resfft_block_tail_ok", "mtd_resfft_block_tail", "mtd_conv_c32_bwd_irfft",
     "mtd_winograd_weight_floats", "mtd_winograd_kmap", "mtd_winograd_weights", "mtd_conv_winograd_ok", "mtd_conv_winograd_ws_bytes", "mtd_conv_winograd",
-    "mtd_conv_wgrad_plan_cfg", "mtd_conv_winograd_patch_w", "mtd_conv_winograd_f4_min_w", "mtd_conv_relu_add_ok", "mtd_dropout_mask", "mtd_scale_by", "mtd_scalar_sums", "mtd_zero_multi",
+    "mtd_conv_wgrad_plan_cfg", "mtd_conv_wgrad_wino24_min_w", "mtd_conv_winograd_patch_w", "mtd_conv_winograd_f4_min_w", "mtd_conv_relu_add_ok", "mtd_dropout_mask", "mtd_scale_by", "mtd_scalar_sums", "mtd_zero_multi",
 ]
 
 

@@ -1160,8 +1160,8 @@ WPlan make_wplan(const mtd_wgrad_args& a, const int g_wplan_div = 1) {
     if (((env_wino && g_wforce_cfg == -1) || g_wforce_cfg == 16) && wgrad_wino_ok(a) && a.g.OH >= env_wino_hw && a.g.OW >= env_wino_hw) {
         pl.cfg = 16;
         pl.WN = 2; pl.WC = 2; pl.TG = T; pl.ntg = 1; pl.nw = 8;
-        const long long blocks = (long long)(a.N / 64) * (a.C / 64);
-        const long long chunks = (M / 4 + WGW_T - 1) / WGW_T;
+        const long long blocks = wgrad_wino_blocks(a);            // 64 x 64 (F(2x2)) or 64 x 32 (F(2x4)) blocks of (n, c)
+        const long long chunks = (wgrad_wino_tiles(a, a.g.B) + WGW_T - 1) / WGW_T;
         long long ns = (256 + blocks - 1) / blocks;              // about one workgroup per CU
         if (g_wforce_split > 0) ns = g_wforce_split;
         if (ns > chunks / 4) ns = chunks / 4;                    // at least four chunks per slice
@@ -1279,7 +1279,18 @@ extern "C" size_t mtd_conv_wgrad_ws_bytes(const mtd_wgrad_args* a) {
 extern "C" int mtd_conv_wgrad_plan_cfg(const mtd_wgrad_args* a) {
     if (!a || check_wargs(*a) != MTD_OK) return MTD_EINVAL;
     if (is_direct(*a)) return -1;
-    return make_wplan(*a).cfg;
+    const int cfg = make_wplan(*a).cfg;
+    return (cfg == 16 && wgrad_wino_px(*a) == 6) ? 17 : cfg;      // 17: the F(2x4, 3x3) form of the Winograd kernel (3/9 of the multiplications)
+}
+
+// Tuning / test hook: narrowest map whose Winograd weight gradient takes the F(2x4, 3x3) form (0: never = the default, or
+// MTD_WGRAD_WINO24_MIN_W / MTD_WGRAD_WINO24=1 from the environment; the form is off by default); < 0 only queries.  Returns the previous value.
+extern "C" int mtd_conv_wgrad_wino24_min_w(int min_w) {
+    mtd_wgrad_args probe{};
+    (void)wgrad_wino_px(probe);                      // (reads the environment once)
+    const int old = g_wgw24_min_w;
+    if (min_w >= 0) g_wgw24_min_w = min_w;
+    return old;
 }
 
 // plans whose kernels implement the pair form (pair_select): wgrad_kernel<> (0-6), the block-window kernels (10-12), the all-taps
@@ -1345,7 +1356,7 @@ static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, 
         p.nCt = a->C / (32 * pl.WC);
         dim3 grid(pl.nsplit, (a->N / (32 * pl.WN)) * p.nCt, pl.ntg);
         const int np = pair ? 2 : 1;         // problems in this launch
-        const int prof = mtd_prof_begin(1, pl.cfg, pl.nsplit, np * geom_pixels(a->g), a->N, a->C, a->g.TH * a->g.TW, s,
+        const int prof = mtd_prof_begin(1, (pl.cfg == 16 && wgrad_wino_px(*a) == 6) ? 17 : pl.cfg, pl.nsplit, np * geom_pixels(a->g), a->N, a->C, a->g.TH * a->g.TW, s,
                                             4.0 * np * ((double)geom_pixels(a->g) * a->N + (double)a->g.B * a->g.IH * a->g.IW * a->C + (double)a->g.TH * a->g.TW * a->N * a->C));
         // Row-window kernel: 64 KB of dynamic LDS nobody uses caps it at ONE workgroup (one wave per SIMD) per CU.  Alone in
         // a stream that changes nothing (generator step: 31.7 us per launch either way); in the full step, where it runs on a
@@ -1355,13 +1366,15 @@ static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, 
         if (pl.cfg == 16) {
             WgradWinoParams wp;
             wp.w = p;
-            wp.tiles_x = a->g.OW / 2;
+            const bool f24 = wgrad_wino_px(*a) == 6;
+            wp.tiles_x = a->g.OW / (f24 ? 4 : 2);
             wp.tiles_per_image = (a->g.OH / 2) * wp.tiles_x;
             wp.ntiles = a->g.B * wp.tiles_per_image;
             wp.chunks_per_split = pl.ppw;
             wp.ns_first = wp.first_tiles = 0;
             wp.p_add = nullptr;
-            MTD_LAUNCH(wgrad_wino_kernel, dim3(pl.nsplit, (a->N / 64) * (a->C / 64)), dim3(512), 0, s, wp);
+            if (f24) MTD_LAUNCH(wgrad_wino24_kernel<false>, dim3(pl.nsplit, (unsigned)wgrad_wino_blocks(*a)), dim3(512), 0, s, wp);
+            else MTD_LAUNCH(wgrad_wino_kernel, dim3(pl.nsplit, (a->N / 64) * (a->C / 64)), dim3(512), 0, s, wp);
             mtd_prof_end(prof, s);
             MTD_LAUNCH_CHECK();
             return MTD_OK;
@@ -1525,8 +1538,8 @@ static bool wgrad_pair_plan(const mtd_wgrad_args& a, int b_first, int& ns_half, 
         ns_half = cps = 0;
         return wgrad_cfg_pairs(cfg);
     }
-    const long long blocks = (long long)(a.N / 64) * (a.C / 64);
-    const long long chunks = ((long long)b_first * (a.g.OH / 2) * (a.g.OW / 2) + WGW_T - 1) / WGW_T;
+    const long long blocks = wgrad_wino_blocks(a);
+    const long long chunks = (wgrad_wino_tiles(a, b_first) + WGW_T - 1) / WGW_T;
     long long ns = (128 + blocks - 1) / blocks;                  // the two ranges together: about one workgroup per CU
     if (ns > chunks / 4) ns = chunks / 4;
     if (ns < 1) ns = 1;
@@ -1603,7 +1616,8 @@ extern "C" int mtd_conv_wgrad_pair_sum(const mtd_wgrad_args* a, const float* p_a
     }
     p.ppw = cps;
     p.nCt = a->C / 64;
-    wp.tiles_x = a->g.OW / 2;
+    const bool f24 = wgrad_wino_px(*a) == 6;
+    wp.tiles_x = a->g.OW / (f24 ? 4 : 2);
     wp.tiles_per_image = (a->g.OH / 2) * wp.tiles_x;
     wp.ntiles = a->g.B * wp.tiles_per_image;
     wp.chunks_per_split = cps;
@@ -1611,9 +1625,11 @@ extern "C" int mtd_conv_wgrad_pair_sum(const mtd_wgrad_args* a, const float* p_a
     wp.first_tiles = b_first * wp.tiles_per_image;
     wp.p_add = p_add;
     hipStream_t s = (hipStream_t)stream;
-    const int prof = mtd_prof_begin(1, 16, nsplit, geom_pixels(a->g), a->N, a->C, 9, s,
+    const int prof = mtd_prof_begin(1, f24 ? 17 : 16, nsplit, geom_pixels(a->g), a->N, a->C, 9, s,
                                     4.0 * ((double)geom_pixels(a->g) * a->N + (double)a->g.B * a->g.IH * a->g.IW * a->C + 2.0 * 9 * a->N * a->C));
-    MTD_LAUNCH(wgrad_wino_kernel, dim3(nsplit, (a->N / 64) * (a->C / 64)), dim3(512), 0, s, wp);
+    if (f24 && p_add) MTD_LAUNCH(wgrad_wino24_kernel<true>, dim3(nsplit, (unsigned)wgrad_wino_blocks(*a)), dim3(512), 0, s, wp);
+    else if (f24) MTD_LAUNCH(wgrad_wino24_kernel<false>, dim3(nsplit, (unsigned)wgrad_wino_blocks(*a)), dim3(512), 0, s, wp);
+    else MTD_LAUNCH(wgrad_wino_kernel, dim3(nsplit, (a->N / 64) * (a->C / 64)), dim3(512), 0, s, wp);
     mtd_prof_end(prof, s);
     MTD_LAUNCH_CHECK();
     return wgrad_reduce_pair(p, a->ws, ns_half, a->ws + (long long)nsplit * p.slab_stride, dw2, a->accumulate, s);

@@ -152,6 +152,11 @@ def winograd_patch_w(geom, N, Cc):
     return px
 
 
+def wgrad_wino24_min_w(min_w):
+    """Tuning / test hook (mtd_conv_wgrad_wino24_min_w): narrowest map whose weight gradient takes F(2x4, 3x3); 0 = never."""
+    return _lib.lib().mtd_conv_wgrad_wino24_min_w(int(min_w))
+
+
 def winograd_f4_min_w(min_w):
     """Tuning / test hook (mtd_conv_winograd_f4_min_w): narrowest map that takes F(2x4, 3x3); 0 = never.  Returns the old value."""
     old = _lib.lib().mtd_conv_winograd_f4_min_w(int(min_w))
@@ -230,16 +235,18 @@ FLOP_COUNT = None
 _FFT_HALF_PLANE = 2.5 * 4096 * 12 / 2
 
 
-WGRAD_CFG_WINO = 16      # mtd_conv_wgrad_plan_cfg: wgrad_wino_kernel
+WGRAD_CFG_WINO, WGRAD_CFG_WINO24 = 16, 17      # mtd_conv_wgrad_plan_cfg: wgrad_wino_kernel (F(2x2, 3x3)), wgrad_wino24_kernel (F(2x4, 3x3))
 
 
-def _count_wgrad(geom, N, Cc, winograd):
+def _count_wgrad(geom, N, Cc, cfg):
     """Executed flops of one weight-gradient launch: 2 M N C taps on the matrix cores (or the vector ALU for the degenerate
-    channel counts); the Winograd kernel multiplies 16 instead of 36 times per 2 x 2 tile, the rest is `wgrad_winograd_saved`."""
+    channel counts); the Winograd kernels multiply 4 (F(2x2)) or 3 (F(2x4)) instead of 9 times per output pixel, the rest is
+    `wgrad_winograd_saved`."""
     full = 2.0 * geom.B * geom.OH * geom.OW * N * Cc * geom.TH * geom.TW
-    if winograd:
-        _count("wgrad_mfma", full * 4.0 / 9.0)
-        FLOP_COUNT["wgrad_winograd_saved"] = FLOP_COUNT.get("wgrad_winograd_saved", 0.0) + full * 5.0 / 9.0
+    if cfg in (WGRAD_CFG_WINO, WGRAD_CFG_WINO24):
+        share = 4.0 / 9.0 if cfg == WGRAD_CFG_WINO else 3.0 / 9.0
+        _count("wgrad_mfma", full * share)
+        FLOP_COUNT["wgrad_winograd_saved"] = FLOP_COUNT.get("wgrad_winograd_saved", 0.0) + full * (1.0 - share)
     else:
         _count("wgrad_mfma" if (Cc % 32 == 0 and N % 32 == 0) else "wgrad_valu", full)
 
@@ -262,7 +269,7 @@ WGRAD_CONFIGS = ["wgrad_kernel<1, 1, 9>", "wgrad_kernel<1, 1, 4>", "wgrad_kernel
                  "wgrad_kernel<1, 1, 3>", "wgrad_kernel<1, 1, 1>", "wgrad_kernel<2, 2, 3>",
                  "wgrad_row_kernel<3, 3, 1>", "wgrad_row_kernel<3, 3, -1>", "wgrad_row_kernel<1, 1, 1>",
                  "wgrad_blk_kernel<8>", "wgrad_blk_kernel<4>", "wgrad_blk_kernel<2>", "wgrad_taps_kernel", "?", "wgrad_s2_kernel",
-                 "wgrad_wino_kernel"]
+                 "wgrad_wino_kernel", "wgrad_wino24_kernel"]
 
 
 SPECTRAL_KERNELS = ["rfft_rows_any_kernel", "spec_mix_any_kernel", "irfft_rows_any_kernel"]      # profiler class 2 (HBM-bound)
@@ -594,7 +601,7 @@ def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumula
     a.accumulate = (1 if accumulate else 0) | (2 if accumulate_bias else 0)
     a.ws, a.ws_bytes = None, 0
     if FLOP_COUNT is not None:
-        _count_wgrad(geom, N, Cc, L.mtd_conv_wgrad_plan_cfg(C.byref(a)) == WGRAD_CFG_WINO)
+        _count_wgrad(geom, N, Cc, L.mtd_conv_wgrad_plan_cfg(C.byref(a)))
     need = L.mtd_conv_wgrad_ws_bytes(C.byref(a))
     if need == 0:
         raise RuntimeError(f"mtd_conv_wgrad: unsupported arguments N={N} C={Cc}")
@@ -655,7 +662,7 @@ def wgrad_pair(p, q, geom, b_first, N, Cc, dw1, dw2, w_sn, w_sc, db=None, accumu
         wgrad(p[b_first:], q[b_first:], gb, N, Cc, dw2, w_sn, w_sc, db=db, accumulate=False, accumulate_bias=True)
         return
     if FLOP_COUNT is not None:
-        _count_wgrad(geom, N, Cc, L.mtd_conv_wgrad_pair_ok(C.byref(a), b_first) == 2)      # (2: the Winograd kernel's pair form)
+        _count_wgrad(geom, N, Cc, L.mtd_conv_wgrad_plan_cfg(C.byref(a)) if L.mtd_conv_wgrad_pair_ok(C.byref(a), b_first) == 2 else -1)      # (2: the Winograd kernels' pair form)
     ws = workspace(need, p.device)
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     check(L.mtd_conv_wgrad_pair_sum(C.byref(a), _ptr(p_add), dw2.data_ptr(), b_first, stream_ptr()), "mtd_conv_wgrad_pair_sum")

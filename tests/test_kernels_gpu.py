@@ -687,14 +687,25 @@ def _winograd_conv_case(K, B, Ci, Co, H, W, what, form):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", [(2, 64, 64, 64, 64), (3, 128, 64, 16, 16), (5, 256, 512, 8, 8), (2, 64, 128, 10, 12), (32, 64, 64, 32, 32)])
-def test_winograd_weight_gradient_vs_torch(hip_lib, case):
-    """csrc/conv_wgrad_wino.h, F(2x2, 3x3) weight + bias gradient (both operands transformed, 16 multiplications per tile and
-    (n, c) pair) against torch's autograd on the CPU in float64 and against the row-window / block-window kernels on the same
-    inputs; with and without accumulation into an existing gradient.  (5, 256, 512, 8, 8): 80 tiles = 10 chunks, ragged
-    slices; (2, 64, 128, 10, 12): odd tile counts per row."""
-    from mtd_gan_amd import _lib
+@pytest.mark.parametrize("form", ["plan", "f2x2"])
+@pytest.mark.parametrize("case", [(2, 64, 64, 64, 64), (3, 128, 64, 16, 16), (5, 256, 512, 8, 8), (2, 64, 128, 10, 12), (32, 64, 64, 32, 32),
+                                  (3, 64, 64, 6, 20), (7, 128, 192, 8, 8)])
+def test_winograd_weight_gradient_vs_torch(hip_lib, case, form):
+    """csrc/conv_wgrad_wino.h: Winograd weight + bias gradient (both operands transformed) against torch's autograd on the CPU
+    in float64 and against the row-window / block-window kernels on the same inputs; with and without accumulation into an
+    existing gradient.  form "plan": F(2x4, 3x3) (24 positions, 64 x 32 blocks) on maps at least 8 wide whose width is a multiple
+    of 4, F(2x2, 3x3) elsewhere; "f2x2": F(2x2, 3x3) everywhere.  (5, 256, 512, 8, 8): ragged slices; (2, 64, 128, 10, 12),
+    (3, 64, 64, 6, 20): odd tile counts; (7, 128, 192, 8, 8): 14 tiles, C = 192 = six 32-channel blocks."""
     from mtd_gan_amd import kernels as K
+    old_min_w = K.wgrad_wino24_min_w(0 if form == "f2x2" else 8)
+    try:
+        _winograd_wgrad_case(K, case, form)
+    finally:
+        K.wgrad_wino24_min_w(old_min_w)
+
+
+def _winograd_wgrad_case(K, case, form):
+    from mtd_gan_amd import _lib
     B, Ci, Co, H, W = case
     gen = torch.Generator().manual_seed(23)
     x = torch.randn(B, H, W, Ci, generator=gen).cuda()
@@ -750,6 +761,13 @@ def test_weight_gradient_pair_equals_two_launches(hip_lib, case):
             _pair_case(K, _lib, B, Bh, Ci, Co, H, W, k, expect)
         finally:
             L.mtd_conv_wgrad_pair_mode(prev)
+    if default_rule and k == 3 and W % 4 == 0:
+        # the F(2x4, 3x3) form of the Winograd weight gradient (off by default, conv_wgrad_wino.h): pair launch and second cotangent
+        old_min_w = K.wgrad_wino24_min_w(8)
+        try:
+            _pair_case(K, _lib, B, Bh, Ci, Co, H, W, k, 1)
+        finally:
+            K.wgrad_wino24_min_w(old_min_w)
 
 
 def _pair_case(K, _lib, B, Bh, Ci, Co, H, W, k, pairs):
