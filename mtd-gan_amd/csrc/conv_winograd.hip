@@ -441,6 +441,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         float v = y[q][c] * sc + bias4[c];
+                        if (a.act == MTD_ACT_RELU_ADD) v = v > 0.f ? v : 0.f;      // the residual operands AFTER the activation
                         v += e1[q][c];
                         v += e2[q][c];
                         y[q][c] = v;
@@ -478,8 +479,10 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
     }
 }
 
+int wino_patch_w_of(const mtd_conv_args& a);
+
 // the kernel's domain: 3x3, stride 1, "same" size, even height and width, every tap within one pixel of the output position,
-// output pixel == launch pixel, C a multiple of 16, N a multiple of 64, the input view inside 32-bit byte offsets
+// output pixel == launch pixel, C a multiple of 16, N a multiple of 64 (32: F(2x4) form), the input view inside 32-bit byte offsets
 bool wino_eligible(const mtd_conv_args& a) {
     const mtd_geom& g = a.g;
     if (g.TH != 3 || g.TW != 3 || g.in_sy != 1 || g.in_sx != 1) return false;
@@ -490,7 +493,12 @@ bool wino_eligible(const mtd_conv_args& a) {
         if (dy < -1 || dy > 1 || dx < -1 || dx > 1) return false;
     }
     if (g.tap_dy == 0 || g.tap_dx == 0) return false;
-    if ((a.C % 16) || (a.N % 64) || a.out2 || a.act == MTD_ACT_RELU_ADD) return false;
+    if ((a.C % 16) || a.out2) return false;
+    // N a multiple of 64; a multiple of 32 in the F(2x4) form only, whose 32-channel workgroups (NB = 1) then take the layer: the
+    // generator's 32 -> 32 layers.  (Whether conv() sends them here is the host's threshold, kernels.WINO_C32_MIN_HW: whole-slice
+    // inference yes, the 64 x 64 training patches no -- DESIGN 3.2.)
+    if ((a.N % 64) && !((a.N % 32) == 0 && wino_patch_w_of(a) == 6)) return false;
+    if (a.act == MTD_ACT_RELU_ADD && !((a.N % 64) != 0 && !a.mask)) return false;      // residual after the activation: that form only
     return true;
 }
 
@@ -500,6 +508,8 @@ struct WinoPlan { int nb, lean, splitk, c_per_split, px; };
 // multiple of 4 and at least MTD_WINO_F4_MIN_W (default 8: on the 4-pixel-wide maps a tile row is one tile and the transformed
 // weights -- 24 / 9 of the filter instead of 16 / 9 -- are what the launch streams).  MTD_WINO_F4=0 switches the form off.
 int g_f4_min_w = -1;          // -1: not yet read from the environment; 0: the form is off
+int wino_patch_w(const mtd_conv_args& a);
+int wino_patch_w_of(const mtd_conv_args& a) { return wino_patch_w(a); }
 int wino_patch_w(const mtd_conv_args& a) {
     if (g_f4_min_w < 0) {
         const char* off = getenv("MTD_WINO_F4");
@@ -521,6 +531,7 @@ WinoPlan wino_plan(const mtd_conv_args& a, int px) {
         const long long t = geom_pixels(a.g) / tile_px;
         if (((t + WT - 1) / WT) * (a.N / 64) <= 128 && a.C >= 128) pl.nb = 1;
     }
+    if (a.N % 64) pl.nb = 1;                                     // (F(2x4) only: wino_eligible)
     // (lab, MTD_WINO_NB2_MAXC=64: the narrow form with its lean variant for layers with four K steps whatever their N -- 5 % less time
     // for those launches (123 -> 116 us, 226 -> 213 us), 0.08 ms per step, but the input is then read per 64 instead of per 128 output
     // channels: 62 -> 80 MB of fabric traffic per launch.  Off.)

@@ -107,6 +107,11 @@ WINOGRAD = os.environ.get("MTD_WINOGRAD", "1") != "0"
 WINO_MIN_HW = int(os.environ.get("MTD_WINOGRAD_MIN_HW", "2"))
 WINO_MIN_C = int(os.environ.get("MTD_WINOGRAD_MIN_C", "64"))
 WINO_MIN_N = int(os.environ.get("MTD_WINOGRAD_MIN_N", "64"))
+# The generator's 32 -> 32 layers on the F(2x4) kernel's 32-channel form (NB = 1, two K steps per launch tile): on maps of at
+# least this side.  Default 128 = whole-slice inference only (512 x 512: 29.36 -> 27.99 ms per slice); on the 64 x 64 training
+# patches the halo-tile kernel is as fast (generator leg 5.44 -> 5.39 ms with 64 here) and carries the fused epilogues
+# (out2, block tail) the Winograd kernel does not have.  0 switches the form off.
+WINO_C32_MIN_HW = int(os.environ.get("MTD_WINO_C32_MIN_HW", "128"))
 _kmap_cache = {}
 
 
@@ -129,7 +134,13 @@ def winograd_takes(geom, N, Cc, kw):
         return False
     if not (geom.out_sy == 1 and geom.out_sx == 1 and geom.out_oy == 0 and geom.out_ox == 0 and geom.OHF == geom.OH and geom.OWF == geom.OW):
         return False
-    if (Cc % 16) or Cc < WINO_MIN_C or (N % 64) or N < WINO_MIN_N or kw.get("out2") is not None:
+    if kw.get("out2") is not None or (Cc % 16):
+        return False
+    if Cc < WINO_MIN_C or (N % 64) or N < WINO_MIN_N:
+        # (the 32-channel form; the library checks that the layer's transform is F(2x4): mtd_conv_winograd_ok)
+        if not (WINO_C32_MIN_HW and Cc == 32 and N == 32 and min(geom.OH, geom.OW) >= WINO_C32_MIN_HW and geom.OW % 4 == 0):
+            return False
+    elif kw.get("act") == ACT_RELU_ADD:
         return False
     return len(_wino_kmap(geom)) == 9
 
@@ -489,7 +500,12 @@ def conv_relu_add_ok(x, w, geom, N, Cc, w_sn, w_sc, out, **kw):
     arguments (mtd_conv_relu_add_ok)?  Nothing is launched or counted."""
     if os.environ.get("MTD_NO_RELU_ADD", "0") == "1" or (Cc % 32) or (N % 32):
         return False
-    a = _conv_args(x, w, geom, N, Cc, w_sn, w_sc, out, act=ACT_RELU_ADD, count=False, **kw)
+    kw = dict(kw, act=ACT_RELU_ADD)
+    if winograd_takes(geom, N, Cc, kw):        # (the 32-channel F(2x4) form carries this epilogue: conv_winograd.hip)
+        a = _conv_args(x, w, geom, N, Cc, w_sn, w_sc, out, pack=False, count=False, **kw)
+        if _lib.lib().mtd_conv_winograd_ok(C.byref(a)):
+            return True
+    a = _conv_args(x, w, geom, N, Cc, w_sn, w_sc, out, count=False, **kw)
     return bool(_lib.lib().mtd_conv_relu_add_ok(C.byref(a)))
 
 

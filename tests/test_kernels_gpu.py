@@ -687,6 +687,61 @@ def _winograd_conv_case(K, B, Ci, Co, H, W, what, form):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 128, 128, "fwd", "relu_add"), (2, 128, 132, "dgrad", "relu"), (1, 256, 256, "fwd", "relu"),
+                                  (3, 128, 128, "dgrad", "lrelu_mask")])
+def test_winograd_32_channel_form(hip_lib, case):
+    """The generator's 32 -> 32 layers on whole-slice maps (side >= kernels.WINO_C32_MIN_HW = 128) run on the F(2x4, 3x3)
+    kernel's 32-channel workgroups (wino_conv_kernel<1, false, 6>): forward conv / ConvTranspose gather with the three
+    epilogues the inference schedule uses -- relu(conv + b) + x (MTD_ACT_RELU_ADD), relu(conv + b + skip), and the general one
+    -- against torch on the CPU in float64 and against the halo-tile implicit GEMM on the same inputs.  On a 64 x 64 map the
+    same layer stays on the implicit GEMM (the training path is unchanged)."""
+    from mtd_gan_amd import kernels as K
+    B, H, W, what, epi = case
+    gen = torch.Generator().manual_seed(29)
+    r = lambda *s: torch.randn(*s, generator=gen)
+    x = r(B, H, W, 32).cuda()
+    w = (r(32, 32, 3, 3) * (9 * 32) ** -0.5).cuda()
+    bias, add1, mask = (r(32) * 0.1).cuda(), r(B, H, W, 32).cuda(), r(B, H, W, 32).cuda()
+    if what == "fwd":
+        geom, wsn, wsc = K.geom_fwd(B, H, W, 3, 1, 1), 32 * 9, 9
+    else:
+        geom, wsn, wsc = K.geom_dgrad_s1(B, H, W, 3, 1), 9, 32 * 9
+    kw = {"relu_add": dict(bias=bias, add1=add1, act=K.ACT_RELU_ADD), "relu": dict(bias=bias, add1=add1, act=K.ACT_RELU),
+          "lrelu_mask": dict(bias=bias, add1=add1, act=K.ACT_LRELU, mask=mask, mask_slope=0.2)}[epi]
+    assert K.winograd_takes(geom, 32, 32, kw) and K.winograd_patch_w(geom, 32, 32) == 6
+    assert not K.winograd_takes(K.geom_fwd(B, 64, 64, 3, 1, 1), 32, 32, kw)
+    if epi == "relu_add":
+        assert K.conv_relu_add_ok(x, w, geom, 32, 32, wsn, wsc, torch.empty_like(x), bias=bias, add1=add1)
+    outs = []
+    for wino in (True, False):
+        K.WINOGRAD = wino
+        try:
+            out = torch.zeros(B, H, W, 32, device="cuda")
+            K.FLOP_COUNT = {}
+            try:
+                K.conv(x, w, geom, 32, 32, wsn, wsc, out, **kw)
+            finally:
+                fc, K.FLOP_COUNT = K.FLOP_COUNT, None
+            torch.cuda.synchronize()
+            assert (fc.get("conv_winograd_saved", 0.0) > 0) == wino      # (which kernel took the launch)
+            outs.append(out)
+        finally:
+            K.WINOGRAD = True
+    assert relerr(outs[0].cpu(), outs[1].cpu()) < 2e-5
+    xc, wc = nchw(x).double(), w.cpu().double()
+    y = F.conv2d(xc, wc, None, padding=1) if what == "fwd" else F.conv_transpose2d(xc, wc, None, padding=1)
+    y = y + bias.cpu().double().view(1, -1, 1, 1)
+    a1 = nchw(add1).double()
+    if epi == "relu_add":
+        v = F.relu(y) + a1
+    elif epi == "relu":
+        v = F.relu(y + a1)
+    else:
+        v = F.leaky_relu(y + a1, 0.2) * torch.where(nchw(mask) > 0, 1.0, 0.2)
+    assert relerr(nchw(outs[0]), v) < TOL
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("form", ["plan", "f2x2"])
 @pytest.mark.parametrize("case", [(2, 64, 64, 64, 64), (3, 128, 64, 16, 16), (5, 256, 512, 8, 8), (2, 64, 128, 10, 12), (32, 64, 64, 32, 32),
                                   (3, 64, 64, 6, 20), (7, 128, 192, 8, 8)])
