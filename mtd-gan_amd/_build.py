@@ -23,7 +23,7 @@ def build(force=False, verbose=True):
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "fft64.h"), os.path.join(os.path.dirname(HERE), "include", "mtdgan_hip.h"),
-               os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_wgrad.hip"), os.path.join(CSRC, "conv_wgrad_wino.h")]      # (conv_c32_bwd.hip includes the two kernel files)
+               os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_wgrad.hip"), os.path.join(CSRC, "conv_wgrad_wino.h"), os.path.join(CSRC, "conv_wino_c32.h")]      # (conv_c32_bwd.hip includes the two kernel files)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     objs = []
     procs = []

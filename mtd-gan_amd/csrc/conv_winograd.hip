@@ -479,6 +479,8 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
     }
 }
 
+#include "conv_wino_c32.h"
+
 int wino_patch_w_of(const mtd_conv_args& a);
 
 // the kernel's domain: 3x3, stride 1, "same" size, even height and width, every tap within one pixel of the output position,
@@ -559,6 +561,21 @@ WinoPlan wino_plan(const mtd_conv_args& a, int px) {
     const long long grid = ((tiles + WT - 1) / WT) * (a.N / (32 * pl.nb)) * pl.splitk;
     pl.lean = px == 4 && pl.nb == 2 && env_lean && (env_lean == 2 || (cps <= 8 && grid >= 512));
     return pl;
+}
+
+// The persistent 32 -> 32 channel kernel (conv_wino_c32.h) takes a layer of the F(2x4) form with one residual operand at most,
+// no scales, no mask, 16-byte aligned rows everywhere and buffers inside 31-bit byte offsets.  MTD_WINO_C32_KERNEL=0: the
+// general kernel's 32-channel workgroups instead (lab switch).
+bool wino_c32_takes(const mtd_conv_args& a, int px) {
+    static const int env_on = [] { const char* e = getenv("MTD_WINO_C32_KERNEL"); return e ? atoi(e) : 1; }();
+    if (!env_on || px != 6 || a.C != 32 || a.N != 32) return false;
+    if (a.scale || a.scale2 || a.add2 || a.mask || a.out2) return false;
+    if (!wide_epilogue_ok(a) || !aligned16(a.in) || (a.in_ld % 4)) return false;
+    const long long M = geom_pixels(a.g);
+    if (M / 8 >= (1ll << 23)) return false;
+    if (((M - 1) * a.out_ld + a.N) * 4 >= (1ll << 31)) return false;
+    if (a.add1 && ((M - 1) * a.add1_ld + a.N) * 4 >= (1ll << 31)) return false;
+    return true;
 }
 
 // the patch width the transformed weights in a->w were built for travels in a->w_st (6: F(2x4, 3x3); anything else: 4)
@@ -680,8 +697,25 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
         if (!a->ws || a->ws_bytes < need) return MTD_EWS;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (wino_c32_takes(*a, px)) {
+        C32Params cp;
+        cp.wp = wp;
+        cp.nblocks = (wp.ntiles + WT - 1) / WT;
+        cp.inv_tpi = 1.0f / (float)wp.tiles_per_image;
+        cp.inv_tx = 1.0f / (float)wp.tiles_x;
+        cp.out_bytes = (unsigned)((((long long)p.M - 1) * a->out_ld + a->N) * 4);
+        cp.add_bytes = a->add1 ? (unsigned)((((long long)p.M - 1) * a->add1_ld + a->N) * 4) : 0u;
+        const int per = (cp.nblocks + 7) / 8;                    // blocks per XCD; one workgroup per CU: 32 per XCD
+        const dim3 pgrid(8 * (per < 32 ? per : 32));
+        const int prof = mtd_prof_begin(0, a->add1 ? 26 : 25, 1, p.M, a->N, a->C, 9, s, algorithmic_bytes(a));
+        if (a->add1) MTD_LAUNCH((wino_c32_kernel<true>), pgrid, dim3(512), 0, s, cp);
+        else MTD_LAUNCH((wino_c32_kernel<false>), pgrid, dim3(512), 0, s, cp);
+        mtd_prof_end(prof, s);
+        MTD_LAUNCH_CHECK();
+        return MTD_OK;
+    }
     const dim3 grid((wp.ntiles + WT - 1) / WT, a->N / (32 * pl.nb), pl.splitk);
-    // (one profiler id per INSTANTIATION -- 14: <2, false, 4>, 15: <4, false, 4>, 22: <2, true, 4>, 23: <2, false, 6>, 24: <1, false, 6> -- so that a record's name is
+    // (one profiler id per INSTANTIATION -- 14: <2, false, 4>, 15: <4, false, 4>, 22: <2, true, 4>, 23: <2, false, 6>, 24: <1, false, 6>; 25, 26: wino_c32_kernel<false / true> -- so that a record's name is
     // one kernel symbol of a rocprofv3 table)
     const int prof = mtd_prof_begin(0, px == 6 ? (pl.nb == 1 ? 24 : 23) : (pl.nb == 4 ? 15 : (pl.lean ? 22 : 14)), pl.splitk, p.M, a->N, a->C, 9, s, algorithmic_bytes(a));
     if (px == 6 && pl.nb == 1) MTD_LAUNCH((wino_conv_kernel<1, false, 6>), grid, dim3(512), 0, s, wp);

@@ -688,12 +688,15 @@ def _winograd_conv_case(K, B, Ci, Co, H, W, what, form):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [(2, 128, 128, "fwd", "relu_add"), (2, 128, 132, "dgrad", "relu"), (1, 256, 256, "fwd", "relu"),
-                                  (3, 128, 128, "dgrad", "lrelu_mask")])
+                                  (3, 128, 128, "dgrad", "lrelu_mask"), (1, 256, 256, "dgrad", "relu_noadd"), (3, 136, 132, "fwd", "none"),
+                                  (5, 130, 140, "fwd", "lrelu"), (8, 512, 512, "fwd", "relu_add")])
 def test_winograd_32_channel_form(hip_lib, case):
     """The generator's 32 -> 32 layers on whole-slice maps (side >= kernels.WINO_C32_MIN_HW = 128) run on the F(2x4, 3x3)
-    kernel's 32-channel workgroups (wino_conv_kernel<1, false, 6>): forward conv / ConvTranspose gather with the three
-    epilogues the inference schedule uses -- relu(conv + b) + x (MTD_ACT_RELU_ADD), relu(conv + b + skip), and the general one
-    -- against torch on the CPU in float64 and against the halo-tile implicit GEMM on the same inputs.  On a 64 x 64 map the
+    form: the persistent kernel of csrc/conv_wino_c32.h (weights in registers, two half-steps per 256-pixel block; one residual
+    operand at most) or, with a mask, the general kernel's 32-channel workgroups (wino_conv_kernel<1, false, 6>).  Forward conv /
+    ConvTranspose gather with the epilogues the inference schedule uses -- relu(conv + b) + x (MTD_ACT_RELU_ADD),
+    relu(conv + b + skip), relu(conv + b) -- and the others, on whole blocks, ragged last blocks (136 x 132 x 3, 130 x 140 x 5) and
+    the bench's own size, against torch on the CPU in float64 and against the halo-tile implicit GEMM on the same inputs.  On a 64 x 64 map the
     same layer stays on the implicit GEMM (the training path is unchanged)."""
     from mtd_gan_amd import kernels as K
     B, H, W, what, epi = case
@@ -707,7 +710,8 @@ def test_winograd_32_channel_form(hip_lib, case):
     else:
         geom, wsn, wsc = K.geom_dgrad_s1(B, H, W, 3, 1), 9, 32 * 9
     kw = {"relu_add": dict(bias=bias, add1=add1, act=K.ACT_RELU_ADD), "relu": dict(bias=bias, add1=add1, act=K.ACT_RELU),
-          "lrelu_mask": dict(bias=bias, add1=add1, act=K.ACT_LRELU, mask=mask, mask_slope=0.2)}[epi]
+          "lrelu_mask": dict(bias=bias, add1=add1, act=K.ACT_LRELU, mask=mask, mask_slope=0.2),
+          "relu_noadd": dict(bias=bias, act=K.ACT_RELU), "none": dict(add1=add1), "lrelu": dict(bias=bias, act=K.ACT_LRELU)}[epi]
     assert K.winograd_takes(geom, 32, 32, kw) and K.winograd_patch_w(geom, 32, 32) == 6
     assert not K.winograd_takes(K.geom_fwd(B, 64, 64, 3, 1, 1), 32, 32, kw)
     if epi == "relu_add":
@@ -730,12 +734,19 @@ def test_winograd_32_channel_form(hip_lib, case):
     assert relerr(outs[0].cpu(), outs[1].cpu()) < 2e-5
     xc, wc = nchw(x).double(), w.cpu().double()
     y = F.conv2d(xc, wc, None, padding=1) if what == "fwd" else F.conv_transpose2d(xc, wc, None, padding=1)
-    y = y + bias.cpu().double().view(1, -1, 1, 1)
+    if "bias" in kw:
+        y = y + bias.cpu().double().view(1, -1, 1, 1)
     a1 = nchw(add1).double()
     if epi == "relu_add":
         v = F.relu(y) + a1
     elif epi == "relu":
         v = F.relu(y + a1)
+    elif epi == "relu_noadd":
+        v = F.relu(y)
+    elif epi == "none":
+        v = y + a1
+    elif epi == "lrelu":
+        v = F.leaky_relu(y, 0.2)
     else:
         v = F.leaky_relu(y + a1, 0.2) * torch.where(nchw(mask) > 0, 1.0, 0.2)
     assert relerr(nchw(outs[0]), v) < TOL
