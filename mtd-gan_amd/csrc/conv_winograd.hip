@@ -700,13 +700,17 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
     if (wino_c32_takes(*a, px)) {
         C32Params cp;
         cp.wp = wp;
-        cp.nblocks = (wp.ntiles + WT - 1) / WT;
-        cp.inv_tpi = 1.0f / (float)wp.tiles_per_image;
-        cp.inv_tx = 1.0f / (float)wp.tiles_x;
+        cp.tiles_y = a->g.OH / 2;
+        cp.nblocks = (wp.ntiles + C32_T - 1) / C32_T;
         cp.out_bytes = (unsigned)((((long long)p.M - 1) * a->out_ld + a->N) * 4);
         cp.add_bytes = a->add1 ? (unsigned)((((long long)p.M - 1) * a->add1_ld + a->N) * 4) : 0u;
         const int per = (cp.nblocks + 7) / 8;                    // blocks per XCD; one workgroup per CU: 32 per XCD
-        const dim3 pgrid(8 * (per < 32 ? per : 32));
+        const int slots = per < 32 ? per : 32;
+        const dim3 pgrid(8 * slots);
+        const int step = C32_T * slots;                          // tiles between two blocks of a workgroup's walk
+        cp.d_tx = step % wp.tiles_x;
+        cp.d_ty = (step / wp.tiles_x) % cp.tiles_y;
+        cp.d_img = step / wp.tiles_per_image;
         const int prof = mtd_prof_begin(0, a->add1 ? 26 : 25, 1, p.M, a->N, a->C, 9, s, algorithmic_bytes(a));
         if (a->add1) MTD_LAUNCH((wino_c32_kernel<true>), pgrid, dim3(512), 0, s, cp);
         else MTD_LAUNCH((wino_c32_kernel<false>), pgrid, dim3(512), 0, s, cp);
