@@ -39,7 +39,7 @@ def executed_fraction(kernel):
     """Share of a layer's algorithmic multiplications (2 M N C 9) that the kernel's MFMAs execute."""
     if "wino" not in kernel:
         return 1.0
-    return WINOGRAD_F24_EXECUTED if (kernel.endswith(", 6>") or "wino24" in kernel) else WINOGRAD_EXECUTED
+    return WINOGRAD_F24_EXECUTED if (kernel.endswith(", 6>") or "wino24" in kernel or "wino_c32" in kernel) else WINOGRAD_EXECUTED
 
 
 def parse(argv=None):
@@ -347,8 +347,18 @@ def roofline_pass(wl, steps, pmc_tag):
                 "top_shapes": {k: {"us": round(1e3 * v[0] / v[2], 2), "tflops": round(v[1] / v[0] / 1e9 * executed_fraction(name), 2),
                                    "launches_per_step": v[2] // steps} for k, v in top},
                 # (executed MFMA flops, like `achieved`: the two Winograd kernels at 4 / 9 of their layers' algorithmic count)
-                "other_mfma_kernels": {k: {"tflops": round(v["exec"] / v["ms"] / 1e9, 2), "ms_per_step": round(v["ms"] / steps, 3)}
-                                for k, v in by.items() if k != name}}
+                "other_mfma_kernels": {k: ({"gb_per_s": round(v["bytes"] / v["ms"] / 1e6, 1)} if k in K.SPECTRAL_KERNELS else
+                                           {"tflops": round(v["exec"] / v["ms"] / 1e9, 2)}) | {"ms_per_step": round(v["ms"] / steps, 3)}
+                                       for k, v in by.items() if k != name}}
+    # A launch whose algorithmic bytes need longer at the HBM peak than its executed flops at the MFMA peak is bounded by memory
+    # (the 32 -> 32 channel layers of whole-slice inference: 805 MB against 12.9 GFLOP per launch): quote that roofline, keep the
+    # matrix-pipe figures beside it.
+    t_hbm, t_mfma = d["bytes"] / d["n"] / (PEAK_HBM_GBS * 1e9), d["exec"] / d["n"] / (PEAK_F32_MFMA_TFLOPS * 1e12)
+    if t_hbm > t_mfma:
+        gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                         "mfma_tflops": round(ach, 2), "mfma_frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                         "bound_note": "algorithmic bytes / HBM peak = %.0f us > executed flops / fp32-MFMA peak = %.0f us per launch" % (t_hbm * 1e6, t_mfma * 1e6)})
     return roofline, extra
 
 
