@@ -164,3 +164,22 @@ def test_gradient_buffer_name_rules_cover_the_discriminator():
     assert tail is not None
     first_low = next(i for i, n in enumerate(shared) if n.startswith(f"conv{DP.FLUSH_LEVEL}1"))
     assert tail == sum(sizes[:first_low]) and (sum(sizes) - tail) / sum(sizes) > 0.9
+
+
+def test_which_layers_take_the_32_channel_winograd_kernel():
+    """kernels.winograd_takes is the host's mirror of mtd_conv_winograd_ok plus the size thresholds (no launch, no GPU): the
+    generator's 32 -> 32 channel 3x3 layers go to the Winograd kernels on whole-slice maps (side >= WINO_C32_MIN_HW = 128:
+    csrc/conv_wino_c32.h) and stay on the halo-tile kernels on the 64 x 64 training patches; the residual-after-activation
+    epilogue (MTD_ACT_RELU_ADD) is that form's only; 64-multiples of channels are unaffected by the threshold; a second output
+    (the fused masked cotangent) never goes there."""
+    from mtd_gan_amd import kernels as K
+    assert K.WINO_C32_MIN_HW == 128
+    fwd = lambda side: K.geom_fwd(2, side, side, 3, 1, 1)
+    for side, want in ((64, False), (128, True), (256, True), (512, True)):
+        assert K.winograd_takes(fwd(side), 32, 32, {}) is want, side
+        assert K.winograd_takes(K.geom_dgrad_s1(2, side, side, 3, 1), 32, 32, {"act": K.ACT_RELU_ADD}) is want, side
+    assert K.winograd_takes(fwd(64), 64, 64, {}) and not K.winograd_takes(fwd(64), 64, 64, {"act": K.ACT_RELU_ADD})
+    assert not K.winograd_takes(fwd(512), 32, 32, {"out2": object()})
+    assert not K.winograd_takes(fwd(512), 32, 64, {}) and not K.winograd_takes(fwd(512), 64, 32, {})       # (C, N) = (32, 32) only
+    assert not K.winograd_takes(K.geom_fwd(2, 130, 130, 3, 1, 1), 32, 32, {})                               # width not a multiple of 4
+    assert not K.winograd_takes(K.geom_fwd(2, 512, 512, 4, 2, 1), 32, 32, {})                               # 3x3 stride 1 only
