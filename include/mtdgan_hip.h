@@ -104,7 +104,7 @@ int mtd_conv_igemm(const mtd_conv_args* a, void* stream);
  *                          (-1+a, -1+b) (mtd_winograd_kmap derives it from a geometry: a forward conv and the data
  *                          gradient of the same layer use different maps); table in device memory + the same on the host.
  *   mtd_conv_winograd      a->w = the transformed weights (w_sn / w_sc ignored; w_st = 6 says they are the F(2x4, 3x3) form).  Requires 3x3, stride 1, OH x OW ==
- *                          IH x IW both even, C % 16 == 0, N % 64 == 0 (N % 32 == 0 in the F(2x4, 3x3) form), no out2:
+ *                          IH x IW both even, C % 16 == 0, N % 64 == 0 (or C = N = 32 in the F(2x4, 3x3) form), no out2:
  *                          mtd_conv_winograd_ok().  The generator's 32 -> 32 channel layers (arch/Ours/networks.py:95-164) with one
  *                          residual operand at most, no scales and no mask run on a persistent kernel of their own
  *                          (csrc/conv_wino_c32.h; what whole-slice inference spends its conv time in), which also implements

@@ -55,6 +55,53 @@ __device__ __forceinline__ float wgw_quad(float v, int ctrl) {
     return __builtin_bit_cast(float, r);
 }
 
+// The quad arithmetic written out with the permuted operand taken directly by the arithmetic instruction (v_mul_f32_dpp,
+// v_add_f32_dpp, v_fmac_f32_dpp) instead of a v_mov_b32_dpp per operand: beside fp32 MFMAs every vector instruction is paid in
+// full (tools/overlap_probe.hip).  The s_nop covers the two wait states between a vector write of the source and
+// its first DPP read.
+//   wgw_quad_rows:  r[perm0] + sign r[perm1]  per channel  (F(2,3) across the four lanes that hold a patch's rows)
+__device__ __forceinline__ f32x4 wgw_quad_rows(f32x4 r, float sign) {
+    float u0, u1, u2, u3, t0, t1, t2, t3;
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %4, %8, %12 quad_perm:[2,2,1,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mul_f32_dpp %5, %9, %12 quad_perm:[2,2,1,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mul_f32_dpp %6, %10, %12 quad_perm:[2,2,1,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mul_f32_dpp %7, %11, %12 quad_perm:[2,2,1,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %8, %4 quad_perm:[0,1,2,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %9, %5 quad_perm:[0,1,2,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %10, %6 quad_perm:[0,1,2,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %11, %7 quad_perm:[0,1,2,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(sign));
+    return f32x4{u0, u1, u2, u3};
+}
+//   wgw_quad_pair:  s0 = alpha y[lane 0] + beta y[lane 2],  s1 = alpha y[lane 1] + beta y[lane 3]  per channel (the 2 x 2
+//   cotangent tile of a quad, one pixel per lane, combined down its rows)
+__device__ __forceinline__ void wgw_quad_pair(f32x4 y, float alpha, float beta, f32x4& s0, f32x4& s1) {
+    float a0, a1, a2, a3, b0, b1, b2, b3;
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %8, %12 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mul_f32_dpp %1, %9, %12 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mul_f32_dpp %2, %10, %12 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mul_f32_dpp %3, %11, %12 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mul_f32_dpp %4, %8, %12 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mul_f32_dpp %5, %9, %12 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mul_f32_dpp %6, %10, %12 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mul_f32_dpp %7, %11, %12 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %0, %8, %13 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %1, %9, %13 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %2, %10, %13 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %3, %11, %13 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %4, %8, %13 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %5, %9, %13 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %6, %10, %13 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %7, %11, %13 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+        : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(alpha), "v"(beta));
+    s0 = f32x4{a0, a1, a2, a3};
+    s1 = f32x4{b0, b1, b2, b3};
+}
+
 __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgradWinoParams wp) {
     __shared__ __attribute__((aligned(16))) float Ls[2 * WGW_BUF];         // 2 x 66 KB; the exchange image of the epilogue reuses it
     const WgradParams& p = wp.w;
@@ -114,33 +161,27 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgradWinoParam
     // The transform of one chunk in six pieces (the K loop places them between groups of MFMAs): U columns 0 .. 3, then the
     // cotangent's quad gather, then its two store pairs.  `live` = 1 for a chunk of the slice, 0 for the clamped repeat past
     // its end (stored into a buffer nobody reads, not summed into the bias gradient).
-    f32x4 vr0[4], vr1[4];
+    f32x4 vs0, vs1;
     auto tr_u = [&](float* Lb, const Pre& r, int j) {
         const f32x4 rj = j == 0 ? r.d[0] - r.d[2] : (j == 1 ? r.d[1] + r.d[2] : (j == 2 ? r.d[2] - r.d[1] : r.d[1] - r.d[3]));
-        f32x4 u;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) u[c] = fmaf(usign, wgw_quad(rj[c], 1), wgw_quad(rj[c], 0));
-        *reinterpret_cast<f32x4*>(Lb + t8 * 64 + 4 * cq + (4 * qp + j) * WGW_PL) = u;
+        *reinterpret_cast<f32x4*>(Lb + t8 * 64 + 4 * cq + (4 * qp + j) * WGW_PL) = wgw_quad_rows(rj, usign);
     };
+    // row a = qp of A dY A^T = [s0, s0 + s1, s0 - s1, -s1]  with  s_b = alpha dY[0][b] + beta dY[1][b]  (A combined down the tile's
+    // rows first -- two DPP multiply-adds per value, no gather of the four pixels --, then along them)
     auto tr_v_gather = [&](const Pre& r, float live) {
-        f32x4 y00, y01, y10, y11;
         const f32x4 ys = r.y + r.y2;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            y00[c] = wgw_quad(ys[c], 2);
-            y01[c] = wgw_quad(ys[c], 3);
-            y10[c] = wgw_quad(ys[c], 4);
-            y11[c] = wgw_quad(ys[c], 5);
-        }
         dbacc += live * ys;
-        // R_i = [y_i0, y_i0 + y_i1, y_i0 - y_i1, -y_i1]
-        vr0[0] = y00; vr0[1] = y00 + y01; vr0[2] = y00 - y01; vr0[3] = -y01;
-        vr1[0] = y10; vr1[1] = y10 + y11; vr1[2] = y10 - y11; vr1[3] = -y11;
+        wgw_quad_pair(ys, valpha, vbeta, vs0, vs1);
     };
     auto tr_v_store = [&](float* Lb, int b0) {
         float* vo = Lb + 16 * WGW_PL + t8 * 64 + 4 * cq;
-#pragma unroll
-        for (int b = b0; b < b0 + 2; ++b) *reinterpret_cast<f32x4*>(vo + (4 * qp + b) * WGW_PL) = valpha * vr0[b] + vbeta * vr1[b];
+        if (b0 == 0) {
+            *reinterpret_cast<f32x4*>(vo + (4 * qp + 0) * WGW_PL) = vs0;
+            *reinterpret_cast<f32x4*>(vo + (4 * qp + 1) * WGW_PL) = vs0 + vs1;
+        } else {
+            *reinterpret_cast<f32x4*>(vo + (4 * qp + 2) * WGW_PL) = vs0 - vs1;
+            *reinterpret_cast<f32x4*>(vo + (4 * qp + 3) * WGW_PL) = -vs1;
+        }
     };
     auto transform_store = [&](float* Lb, const Pre& r, float live) {
         tr_u(Lb, r, 0); tr_u(Lb, r, 1); tr_u(Lb, r, 2); tr_u(Lb, r, 3);

@@ -61,17 +61,6 @@ struct C32Params {
     unsigned out_bytes, add_bytes;
 };
 
-// F(2,3) across the quad of lanes that hold the four rows of a patch: row ti of B^T r = r[0] - r[2] | r[1] + r[2] | r[2] - r[1] |
-// r[1] - r[3], as  r[perm0] + qsign r[perm1]  with qsign = +1 for ti = 1, else -1.  Mul and add stay apart (no contraction): each
-// takes its DPP operand directly, two instructions per value instead of two moves and an fma.
-__device__ __forceinline__ float c32_quad_row(float r, float qsign) {
-#pragma clang fp contract(off)
-    const int x = __builtin_bit_cast(int, r);
-    const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x64, 0xf, 0xf, true));      // lanes [0, 1, 2, 1]
-    const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0xDA, 0xf, 0xf, true));      // lanes [2, 2, 1, 3]
-    return p0 + qsign * p1;
-}
-
 template <bool HAS_ADD>
 __global__ __launch_bounds__(512) void wino_c32_kernel(const C32Params cp) {
     constexpr int PX = 6, TWX = 4;
@@ -172,10 +161,7 @@ __global__ __launch_bounds__(512) void wino_c32_kernel(const C32Params cp) {
         if constexpr ((MTD_C32_SKIP & 2) == 0) {
 #pragma unroll
             for (int j = j0; j < j1; ++j) {
-                f32x4 u;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) u[c] = c32_quad_row(r[j][c], qsign);
-                *reinterpret_cast<f32x4*>(As + t_off + j * C32_PS) = u;
+                *reinterpret_cast<f32x4*>(As + t_off + j * C32_PS) = wino_quad_rows(r[j], qsign);
             }
         } else {
 #pragma unroll

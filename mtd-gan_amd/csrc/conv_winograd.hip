@@ -52,6 +52,7 @@ struct WinoParams {
     int ntiles, tiles_x, tiles_per_image;
     int nchunk;               // C / 8
     int xcd_order;            // 0: workgroup = blockIdx; 1, 2: XCD-contiguous orders (see the kernel)
+    unsigned w_bytes;         // extent of the transformed weights (4 PX N C floats)
 };
 
 // ---- weight transform:  Uw[xi][C/8][N][8] = (G g G^T)[xi],  g[a][b] = W(n, c, kmap[a * 3 + b])  (a, b = correlation position
@@ -115,6 +116,27 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const WinoWDesc* __re
             }
         }
     }
+}
+
+// F(2,3) across the quad of lanes that hold the four rows of a patch, four channels at once: row ti of B^T r = r[0] - r[2] |
+// r[1] + r[2] | r[2] - r[1] | r[1] - r[3], as  r[perm0] + qsign r[perm1]  with qsign = +1 for ti = 1, else -1.  Written out as
+// v_mul_f32_dpp + v_add_f32_dpp -- each takes its permuted operand directly: two instructions per value where the compiler's
+// form is two v_mov_b32_dpp and an fma (a vector instruction is paid in full beside fp32 MFMAs: DESIGN 3.8: tools/overlap_probe.hip).  The s_nop covers
+// the two wait states between a vector write of r and its first DPP read.
+__device__ __forceinline__ f32x4 wino_quad_rows(f32x4 r, float qsign) {
+    float u0, u1, u2, u3, t0, t1, t2, t3;
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %4, %8, %12 quad_perm:[2,2,1,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mul_f32_dpp %5, %9, %12 quad_perm:[2,2,1,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mul_f32_dpp %6, %10, %12 quad_perm:[2,2,1,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mul_f32_dpp %7, %11, %12 quad_perm:[2,2,1,3] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %8, %4 quad_perm:[0,1,2,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %9, %5 quad_perm:[0,1,2,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %10, %6 quad_perm:[0,1,2,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %11, %7 quad_perm:[0,1,2,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(qsign));
+    return f32x4{u0, u1, u2, u3};
 }
 
 // ---- the convolution
@@ -204,22 +226,23 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
     };
     // B^T d B -> As[xi = PX ti + j][tt][4 tq ..]: columns j0, j0 + 1 of the result (the K loop places the pairs between MFMA groups)
     const float qsign = ti == 1 ? 1.f : -1.f;
-    auto quad_get = [&](float v, int ctrl) {
-        const int x = __builtin_bit_cast(int, v);
-        return __builtin_bit_cast(float, ctrl == 0 ? __builtin_amdgcn_update_dpp(0, x, 0x64, 0xf, 0xf, true)      // lanes [0, 1, 2, 1]
-                                                  : __builtin_amdgcn_update_dpp(0, x, 0xDA, 0xf, 0xf, true));    // lanes [2, 2, 1, 3]
-    };
     auto row_value = [&](int j) -> f32x4 {        // (d B)[j] along the row
         if constexpr (PX == 4) {
             return j == 0 ? d[0] - d[2] : (j == 1 ? d[1] + d[2] : (j == 2 ? d[2] - d[1] : d[1] - d[3]));
         } else {
             // F(4,3):  B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
-            if (j == 0) return 4.f * d[0] - 5.f * d[2] + d[4];
-            if (j == 1) return (d[4] - 4.f * d[2]) + (d[3] - 4.f * d[1]);
-            if (j == 2) return (d[4] - 4.f * d[2]) - (d[3] - 4.f * d[1]);
-            if (j == 3) return (d[4] - d[2]) + 2.f * (d[3] - d[1]);
-            if (j == 4) return (d[4] - d[2]) - 2.f * (d[3] - d[1]);
-            return 4.f * d[1] - 5.f * d[3] + d[5];
+            // (one fma or add per term: 12 instructions per channel for the six values; negations folded into the constants)
+            f32x4 r;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (j == 0) r[c] = fmaf(4.f, d[0][c], fmaf(-5.f, d[2][c], d[4][c]));
+                else if (j == 1) r[c] = fmaf(-4.f, d[2][c], d[4][c]) + fmaf(-4.f, d[1][c], d[3][c]);
+                else if (j == 2) r[c] = fmaf(-4.f, d[2][c], d[4][c]) - fmaf(-4.f, d[1][c], d[3][c]);
+                else if (j == 3) r[c] = fmaf(2.f, d[3][c] - d[1][c], d[4][c] - d[2][c]);
+                else if (j == 4) r[c] = fmaf(-2.f, d[3][c] - d[1][c], d[4][c] - d[2][c]);
+                else r[c] = fmaf(4.f, d[1][c], fmaf(-5.f, d[3][c], d[5][c]));
+            }
+            return r;
         }
     };
     auto transform_cols = [&](float* As, int j0) {
@@ -228,10 +251,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
         for (int j = j0; j < j0 + 2; ++j) {
             const f32x4 rj = row_value(j);
             // across the quad: (B^T .)[ti] = r[0]-r[2] | r[1]+r[2] | r[2]-r[1] | r[1]-r[3]
-            f32x4 u;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) u[c] = fmaf(qsign, quad_get(rj[c], 1), quad_get(rj[c], 0));
-            *reinterpret_cast<f32x4*>(o + (PX * ti + j) * (WT * WALD)) = u;
+            *reinterpret_cast<f32x4*>(o + (PX * ti + j) * (WT * WALD)) = wino_quad_rows(rj, qsign);
         }
     };
     auto transform_store = [&](float* As) {
@@ -240,14 +260,19 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
     };
 
     // ---- MFMA role: positions PW wave .. PW wave + PW - 1; B fragments straight from the transformed weights
-    const float* wbase = a.w + ((long long)(PW * wave) * wp.nchunk * a.N + (n0 + l31)) * 8 + kh * 4;
-    const long long xi_stride = (long long)wp.nchunk * a.N * 8;
+    // (buffer loads: the lane's part of the address is ONE register for the whole launch, position and chunk go through the scalar
+    // offset, the n block through the instruction's immediate -- no vector-ALU address arithmetic in the K loop, where every
+    // vector instruction is paid in full beside the fp32 MFMAs)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), (short)0, (int)wp.w_bytes, 0x00020000);
+    const unsigned w_lane = (unsigned)(((n0 + l31) * 8 + kh * 4) * 4);
+    const int xi_stride_b = wp.nchunk * a.N * 32;                  // bytes between positions
+    const int w_pos0 = PW * wave * xi_stride_b;
     auto load_b = [&](int ck, f32x4 (&bf)[PW][NB]) {
 #pragma unroll
         for (int x = 0; x < PW; ++x)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
-                bf[x][nb] = *reinterpret_cast<const f32x4*>(wbase + x * xi_stride + ((long long)ck * a.N + nb * 32) * 8);
+                bf[x][nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, w_lane + (unsigned)(nb * 1024), w_pos0 + x * xi_stride_b + ck * a.N * 32, 0));
     };
     f32x16 acc[PW][NB];
 #pragma unroll
@@ -484,7 +509,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
 int wino_patch_w_of(const mtd_conv_args& a);
 
 // the kernel's domain: 3x3, stride 1, "same" size, even height and width, every tap within one pixel of the output position,
-// output pixel == launch pixel, C a multiple of 16, N a multiple of 64 (32: F(2x4) form), the input view inside 32-bit byte offsets
+// output pixel == launch pixel, C a multiple of 16, N a multiple of 64 (or C = N = 32 in the F(2x4) form), the input view inside 32-bit byte offsets
 bool wino_eligible(const mtd_conv_args& a) {
     const mtd_geom& g = a.g;
     if (g.TH != 3 || g.TW != 3 || g.in_sy != 1 || g.in_sx != 1) return false;
@@ -496,10 +521,10 @@ bool wino_eligible(const mtd_conv_args& a) {
     }
     if (g.tap_dy == 0 || g.tap_dx == 0) return false;
     if ((a.C % 16) || a.out2) return false;
-    // N a multiple of 64; a multiple of 32 in the F(2x4) form only, whose 32-channel workgroups (NB = 1) then take the layer: the
-    // generator's 32 -> 32 layers.  (Whether conv() sends them here is the host's threshold, kernels.WINO_C32_MIN_HW: whole-slice
-    // inference yes, the 64 x 64 training patches no -- DESIGN 3.2.)
-    if ((a.N % 64) && !((a.N % 32) == 0 && wino_patch_w_of(a) == 6)) return false;
+    // N a multiple of 64; or the generator's 32 -> 32 channel layers in the F(2x4) form: the persistent kernel of conv_wino_c32.h
+    // (wino_c32_takes), else this kernel's 32-channel workgroups (NB = 1).  (Whether conv() sends them here is the host's
+    // threshold, kernels.WINO_C32_MIN_HW: whole-slice inference yes, the 64 x 64 training patches no -- DESIGN 3.8.)
+    if ((a.N % 64) && !(a.N == 32 && a.C == 32 && wino_patch_w_of(a) == 6)) return false;
     if (a.act == MTD_ACT_RELU_ADD && !((a.N % 64) != 0 && !a.mask)) return false;      // residual after the activation: that form only
     return true;
 }
@@ -631,6 +656,7 @@ extern "C" int mtd_conv_winograd_ok(const mtd_conv_args* a) {
     const long long npix = (long long)a->g.B * a->g.IH * a->g.IW;
     if (((npix - 1) * a->in_ld + a->C) * 4 >= (1ll << 31)) return 0;
     if (geom_pixels(a->g) * a->N >= (1ll << 31)) return 0;
+    if ((long long)96 * a->N * a->C >= (1ll << 31)) return 0;          // (the transformed weights inside 31-bit byte offsets)
     return 1;
 }
 
@@ -687,6 +713,7 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
     wp.tiles_per_image = (a->g.OH / 2) * wp.tiles_x;
     wp.ntiles = a->g.B * wp.tiles_per_image;
     wp.nchunk = a->C / 8;
+    wp.w_bytes = (unsigned)((long long)4 * px * a->N * a->C * 4);
     {
         static const int env_xcd = [] { const char* e = getenv("MTD_WINO_XCD"); return e ? atoi(e) : -1; }();
         const double wbytes = 4.0 * px * a->C * a->N * 4, ibytes = (double)p.M * a->C * 4;
