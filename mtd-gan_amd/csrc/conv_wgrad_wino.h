@@ -133,27 +133,51 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgradWinoParam
     const __amdgpu_buffer_rsrc_t p2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp.p_add ? wp.p_add : a.p), (short)0, (int)p.p_bytes, 0x00020000);
     const bool has_p2 = wp.p_add != nullptr;
     f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
-    auto load_chunk = [&](int ck, Pre& r) {
-        const int tg = tile_lo + ck * WGW_T + t8;
-        const bool tv = tg < tile_hi;
-        const int b = tg / wp.tiles_per_image;
-        const int rr = tg - b * wp.tiles_per_image;
-        const int ty = rr / wp.tiles_x, tx = rr - ty * wp.tiles_x;
-        // U: patch row qp = image row 2 ty - 1 + qp, pixels 2 tx - 1 .. 2 tx + 2, channels c0 + 4 cq ..
-        const int iy = 2 * ty - 1 + qp;
-        const unsigned ubase = (unsigned)(((((long long)b * g.IH + iy) * g.IW + (2 * tx - 1)) * a.q_ld + c0 + 4 * cq) * 4);
-        const bool rowok = tv & ((unsigned)iy < (unsigned)g.IH);
+    // The wave's tile (t8 == wave: a chunk is eight tiles, one per wave) walks the slice in steps of WGW_T tiles; its (image, tile
+    // row, tile column) live in scalar registers and a step adds (d_b, d_ty, d_tx) with carries -- no per-chunk divisions, and
+    // of the address arithmetic only the lane's own part is vector work (every vector instruction is paid in full beside the
+    // MFMAs: DESIGN 3.8).  load_next requests the operands of the cursor's chunk and moves the cursor on, until the slice's last
+    // chunk, which it then repeats (the clamped loads of the loop's tail).
+    const int tiles_y = wp.tiles_per_image / wp.tiles_x;
+    const int d_tx = WGW_T % wp.tiles_x, d_ty = (WGW_T / wp.tiles_x) % tiles_y, d_b = WGW_T / wp.tiles_per_image;
+    int cur_ck = ck_beg, cur_tg = tile_lo + ck_beg * WGW_T + wave;
+    int cur_b = cur_tg / wp.tiles_per_image, cur_ty, cur_tx;
+    {
+        const int rr = cur_tg - cur_b * wp.tiles_per_image;
+        cur_ty = rr / wp.tiles_x;
+        cur_tx = rr - cur_ty * wp.tiles_x;
+    }
+    const unsigned u_lane = (unsigned)((qp * g.IW * a.q_ld + c0 + 4 * cq) * 4);
+    const unsigned p_lane = (unsigned)((((qp >> 1) * g.OW + (qp & 1)) * a.p_ld + n0 + 4 * cq) * 4);
+    auto load_next = [&](Pre& r) {
+        const bool tv = cur_tg < tile_hi;
+        // U: patch row qp = image row 2 ty - 1 + qp, pixels 2 tx - 1 .. 2 tx + 2, channels c0 + 4 cq ..  (formed modulo 2^32 around
+        // pixel 2 tx, which is inside the image whenever the row is: every VALID pixel's offset is in range AS the vector offset --
+        // the range check does not see a scalar offset, so the column cannot travel there)
+        const unsigned u_s = (((unsigned)cur_b * (unsigned)g.IH + (unsigned)(2 * cur_ty - 1)) * (unsigned)g.IW + (unsigned)(2 * cur_tx)) * (unsigned)a.q_ld * 4u;
+        const unsigned uv = u_s + u_lane;
+        const bool rowok = tv & ((unsigned)(2 * cur_ty - 1 + qp) < (unsigned)g.IH);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int ix = 2 * tx - 1 + j;
-            const unsigned vo = (rowok & ((unsigned)ix < (unsigned)g.IW)) ? ubase + (unsigned)(j * qpx_b) : 0x80000000u;
-            r.d[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qrs, vo, 0, 0));
+            const bool colok = (unsigned)(2 * cur_tx - 1 + j) < (unsigned)g.IW;
+            r.d[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qrs, (rowok & colok) ? uv + (unsigned)((j - 1) * qpx_b) : 0x80000000u, 0, 0));
         }
         // V: cotangent pixel (2 ty + (qp >> 1), 2 tx + (qp & 1)), channels n0 + 4 cq ..
-        const long long pix = ((long long)b * g.OH + 2 * ty + (qp >> 1)) * g.OW + 2 * tx + (qp & 1);
-        const unsigned vo = tv ? (unsigned)((pix * a.p_ld + n0 + 4 * cq) * 4) : 0x80000000u;
-        r.y = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, vo, 0, 0));
-        r.y2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(p2rs, has_p2 ? vo : 0x80000000u, 0, 0));
+        const unsigned p_s = tv ? (((unsigned)cur_b * (unsigned)g.OH + (unsigned)(2 * cur_ty)) * (unsigned)g.OW + (unsigned)(2 * cur_tx)) * (unsigned)a.p_ld * 4u : 0x80000000u;
+        const unsigned pv = p_s + p_lane;
+        r.y = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, pv, 0, 0));
+        r.y2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(p2rs, has_p2 ? pv : 0x80000000u, 0, 0));
+        // (scalar selects, no branch: one path through the loop)
+        const int adv = cur_ck < ck_last ? 1 : 0;
+        cur_ck += adv;
+        cur_tg += adv ? WGW_T : 0;
+        cur_tx += adv ? d_tx : 0;
+        const int c1 = cur_tx >= wp.tiles_x ? 1 : 0;
+        cur_tx -= c1 ? wp.tiles_x : 0;
+        cur_ty += (adv ? d_ty : 0) + c1;
+        const int c2 = cur_ty >= tiles_y ? 1 : 0;
+        cur_ty -= c2 ? tiles_y : 0;
+        cur_b += (adv ? d_b : 0) + c2;
     };
     const float usign = qp == 1 ? 1.f : -1.f;
     // A = [1 0; 1 1; 1 -1; 0 -1]: row a = qp of A dY A^T is  alpha * R0 + beta * R1,  R_i[b] = (dY A^T)[i][b]
@@ -202,9 +226,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgradWinoParam
 
     Pre pa, pb;
     if (nck > 0) {
-        load_chunk(ck_beg, pa);
+        load_next(pa);
         transform_store(Ls, pa, 1.f);
-        load_chunk(min(ck_beg + 1, ck_last), pa);
+        load_next(pa);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
@@ -215,7 +239,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgradWinoParam
     auto one_chunk = [&](int k, const Pre& cur, Pre& nxt) {
         const float* Lc = Ls + (k & 1) * WGW_BUF;
         float* Ln = Ls + ((k + 1) & 1) * WGW_BUF;
-        load_chunk(min(ck_beg + k + 2, ck_last), nxt);
+        load_next(nxt);                                                    // (chunk k + 2, or the last one again)
         __builtin_amdgcn_sched_barrier(0);
         float fa[2][2], fb[2][2];                                      // [ping-pong][half]
         auto frag = [&](int gi, int pp) {                             // group gi = 2 s + x
