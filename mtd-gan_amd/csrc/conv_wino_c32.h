@@ -242,11 +242,11 @@ __global__ __launch_bounds__(512) void wino_c32_kernel(const C32Params cp) {
         for (int q = 0; q < TWX; ++q) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
+                // (slopes in [0, 1]: max(v, slope v) is v for v > 0 and slope v below -- two instructions per activation)
                 float v = y[q][c] + bias2[c];
-                v = v > 0.f ? v : v * slope_pre;                                       // MTD_ACT_RELU_ADD: the residual AFTER the activation
+                v = fmaxf(v, v * slope_pre);                                           // MTD_ACT_RELU_ADD: the residual AFTER the activation
                 v += e1[q][c];
-                v = v > 0.f ? v : v * slope_post;
-                y[q][c] = v;
+                y[q][c] = fmaxf(v, v * slope_post);
             }
             const unsigned vo = (((unsigned)(epix + q) * (unsigned)a.out_ld + 2u * (unsigned)ecp) * 4u) | ((unsigned)(epix >> 31) & 0x80000000u);
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(c32_u32x2, y[q]), ors, vo, 0, 0);

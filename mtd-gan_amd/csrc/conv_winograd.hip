@@ -551,9 +551,12 @@ WinoPlan wino_plan(const mtd_conv_args& a, int px) {
     pl.px = px;
     const int tile_px = 2 * (px - 2);                            // output pixels per tile
     pl.nb = (a.N % 128 == 0 && px == 4) ? 4 : 2;
-    // F(2x4): a tile block is 256 pixels x 64 channels; where that leaves the grid short (the mid-size maps: 4096 .. 16384 pixels),
-    // 32-channel workgroups (NB = 1) before a split of K -- no slabs, no finishing launch (MTD_WINO_F4_NB1=0: always NB = 2)
-    static const int env_f4_nb1 = [] { const char* e = getenv("MTD_WINO_F4_NB1"); return e ? atoi(e) : 1; }();
+    // F(2x4): a tile block is 256 pixels x 64 channels; where that leaves the grid short (the mid-size maps: 4096 .. 16384 pixels)
+    // 32-channel workgroups (NB = 1) can stand in for a split of K -- no slabs, no finishing launch, but every 32 output channels
+    // repeat the input transform, and a transform instruction is paid in full beside the fp32 MFMAs.  The form won
+    // 0.2 ms per step while the transform cost 170 vector instructions per K step; at 116 the split of K is ahead by 0.15 ms
+    // (29.15 against 29.31 ms), so it is off by default now (MTD_WINO_F4_NB1=1: on).
+    static const int env_f4_nb1 = [] { const char* e = getenv("MTD_WINO_F4_NB1"); return e ? atoi(e) : 0; }();
     if (px == 6 && env_f4_nb1) {
         const long long t = geom_pixels(a.g) / tile_px;
         if (((t + WT - 1) / WT) * (a.N / 64) <= 128 && a.C >= 128) pl.nb = 1;
