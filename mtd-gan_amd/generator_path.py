@@ -138,6 +138,13 @@ def generator_forward(x, P, save, out=None):
     w2ts = K.transpose64_all([blk[2] for blk in P.blk]) if (H == 64 and W == 64) else {}      # ... and one for the mix weights
     gf = K.geom_fwd(B, H, W, 3, 1, 1)
     gt = K.geom_dgrad_s1(B, H, W, 3, 1)                    # ConvTranspose2d(k3,s1,p1) gathers like a stride-1 dgrad
+    # The plain encoder / decoder layers run on the persistent F(2x4, 3x3) kernel of the 32-channel layers where conv() takes
+    # them (kernels.winograd_takes: whole slices always, the training patches in this forward pass): their transformed weights
+    # in one launch per weight update.
+    fwd32 = dict(wino32=True)
+    K.prepack_winograd([(P.enc_w[i], CH, CH, CH * 9, 9, gf, fwd32) for i in range(1, L + 1)]
+                       + [(P.dec_w[i], CH, CH, 9, CH * 9, gt, fwd32) for i in range(1, L + 1)]
+                       + [(blk[0], CH, CH, CH * 9, 9, gf) for blk in P.blk])          # (the blocks' convs: whole slices only)
     tape = {"t": [], "e": [], "blk": [], "d": [], "u": []}
     t = K.empty_nhwc(B, H, W, CH, x)
     K.conv(x, P.enc_w[0], gf, CH, 1, 9, 9, t, bias=P.enc_b[0], act=ACT_RELU)
@@ -152,12 +159,12 @@ def generator_forward(x, P, save, out=None):
             tape["e"].append(e)
         if i < L:
             t = K.empty_nhwc(B, H, W, CH, x)
-            K.conv(e, P.enc_w[i + 1], gf, CH, CH, CH * 9, 9, t, bias=P.enc_b[i + 1], act=ACT_RELU)
+            K.conv(e, P.enc_w[i + 1], gf, CH, CH, CH * 9, 9, t, bias=P.enc_b[i + 1], act=ACT_RELU, wino32=True)
     # e list: e1..e10, xb  (index 0..10)
     cur = e                                                # x_b
     for j in range(L, 0, -1):                              # decoder[j], j = 10..1
         d = K.empty_nhwc(B, H, W, CH, x)
-        K.conv(cur, P.dec_w[j], gt, CH, CH, 9, CH * 9, d, bias=P.dec_b[j], add1=tape["e"][j - 1], act=ACT_RELU)
+        K.conv(cur, P.dec_w[j], gt, CH, CH, 9, CH * 9, d, bias=P.dec_b[j], add1=tape["e"][j - 1], act=ACT_RELU, wino32=True)
         u, sv = block_forward(d, *P.blk[2 * L + 1 - j], save, w2t=w2ts.get(id(P.blk[2 * L + 1 - j][2])))   # enforce[11] after decoder[-1] ... enforce[20] after decoder[-10]
         if save:
             tape["u"].append(cur)                          # input of decoder[j]

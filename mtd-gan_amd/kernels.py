@@ -112,6 +112,9 @@ WINO_MIN_N = int(os.environ.get("MTD_WINOGRAD_MIN_N", "64"))
 # patches the halo-tile kernel is as fast (generator leg 5.44 -> 5.39 ms with 64 here) and carries the fused epilogues
 # (out2, block tail) the Winograd kernel does not have.  0 switches the form off.
 WINO_C32_MIN_HW = int(os.environ.get("MTD_WINO_C32_MIN_HW", "128"))
+# ... and the FORWARD pass of the generator's plain encoder / decoder layers on the training patches too (conv(..., wino32=True):
+# 23 us per layer against the halo-tile kernel's 28; generator leg 5.45 -> 5.33 ms).  The backward pass keeps its fused kernels.
+WINO_C32_FWD = os.environ.get("MTD_WINO_C32_FWD", "1") != "0"
 _kmap_cache = {}
 
 
@@ -138,8 +141,14 @@ def winograd_takes(geom, N, Cc, kw):
         return False
     if Cc < WINO_MIN_C or (N % 64) or N < WINO_MIN_N:
         # (the 32-channel form; the library checks that the layer's transform is F(2x4): mtd_conv_winograd_ok)
-        if not (WINO_C32_MIN_HW and Cc == 32 and N == 32 and min(geom.OH, geom.OW) >= WINO_C32_MIN_HW and geom.OW % 4 == 0):
+        if not (WINO_C32_MIN_HW and Cc == 32 and N == 32 and geom.OW % 4 == 0):
             return False
+        if min(geom.OH, geom.OW) < WINO_C32_MIN_HW:
+            # smaller maps: only where the caller asks for it (wino32=True: the generator's forward pass) and the persistent
+            # kernel itself takes the launch (mirror of wino_c32_takes: one residual operand at most, no scale, no mask)
+            if not (WINO_C32_FWD and kw.get("wino32") and min(geom.OH, geom.OW) >= 16 and kw.get("mask") is None and kw.get("add2") is None
+                    and kw.get("scale") is None and kw.get("scale2") is None):
+                return False
     elif kw.get("act") == ACT_RELU_ADD:
         return False
     return len(_wino_kmap(geom)) == 9
@@ -186,12 +195,13 @@ def _wino_desc(w, N, Cc, w_sn, w_sc, kmap, device, px):
 
 
 def prepack_winograd(views):
-    """Transform many weight views in ONE launch.  views: iterable of (w, N, C, w_sn, w_sc, geom) exactly as conv() will ask
-    for them; cached views and views conv() would not send to the Winograd kernel are skipped."""
+    """Transform many weight views in ONE launch.  views: iterable of (w, N, C, w_sn, w_sc, geom[, conv keywords]) exactly as
+    conv() will ask for them; cached views and views conv() would not send to the Winograd kernel are skipped."""
     todo = []
     dev = None
-    for (w, N, Cc, w_sn, w_sc, geom) in views:
-        if not winograd_takes(geom, N, Cc, {}):
+    for v in views:
+        w, N, Cc, w_sn, w_sc, geom = v[:6]
+        if not winograd_takes(geom, N, Cc, v[6] if len(v) > 6 else {}):       # (v[6]: the keywords conv() will be called with)
             continue
         kmap = _wino_kmap(geom)
         px = winograd_patch_w(geom, N, Cc)
@@ -452,7 +462,9 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, **kw):
     add2, act, mask, mask_slope, scale2, scale_split, out2 (see fuses_masked_cotangent: also store the value before the
     mask factor)."""
     L = _lib.lib()
-    if winograd_takes(geom, N, Cc, kw):
+    takes = winograd_takes(geom, N, Cc, kw)
+    kw.pop("wino32", None)
+    if takes:
         a = _conv_args(x, w, geom, N, Cc, w_sn, w_sc, out, pack=False, **kw)
         if L.mtd_conv_winograd_ok(C.byref(a)):
             wv, px = winograd_weight_view(w, N, Cc, w_sn, w_sc, geom)

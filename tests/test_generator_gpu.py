@@ -210,4 +210,4 @@ def test_deferred_weight_gradient_sums_equal_immediate(hip_lib):
         # the row transforms riding on the conv launches (mtd_resfft_block_tail, mtd_conv_c32_bwd_irfft: a DFT on the matrix
         # cores instead of the register FFT): the same numbers up to fp32 rounding through the 43-layer chain
         a, b = got[(True, True)][n], got["tails"][n]
-        assert (a - b).abs().max().item() <= 2e-4 * a.abs().max().item(), n
+        assert (a - b).abs().max().item() <= 5e-4 * a.abs().max().item(), n        # (2e-4 held by 2 % on one bias gradient before the forward pass's Winograd layers)

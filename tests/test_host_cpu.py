@@ -178,6 +178,12 @@ def test_which_layers_take_the_32_channel_winograd_kernel():
     for side, want in ((64, False), (128, True), (256, True), (512, True)):
         assert K.winograd_takes(fwd(side), 32, 32, {}) is want, side
         assert K.winograd_takes(K.geom_dgrad_s1(2, side, side, 3, 1), 32, 32, {"act": K.ACT_RELU_ADD}) is want, side
+    # ... except where the caller opts in (the generator's forward pass, conv(..., wino32=True)) and the persistent kernel itself
+    # takes the launch: one residual operand at most, no mask, no scale
+    assert K.WINO_C32_FWD and K.winograd_takes(fwd(64), 32, 32, {"wino32": True, "add1": object(), "act": K.ACT_RELU})
+    assert not K.winograd_takes(fwd(64), 32, 32, {"wino32": True, "mask": object()})
+    assert not K.winograd_takes(fwd(64), 32, 32, {"wino32": True, "add2": object()})
+    assert not K.winograd_takes(fwd(8), 32, 32, {"wino32": True})
     assert K.winograd_takes(fwd(64), 64, 64, {}) and not K.winograd_takes(fwd(64), 64, 64, {"act": K.ACT_RELU_ADD})
     assert not K.winograd_takes(fwd(512), 32, 32, {"out2": object()})
     assert not K.winograd_takes(fwd(512), 32, 64, {}) and not K.winograd_takes(fwd(512), 64, 32, {})       # (C, N) = (32, 32) only
