@@ -42,6 +42,23 @@ __device__ __forceinline__ ScalePair load_scale(const mtd_conv_args& a) {
 }
 __device__ __forceinline__ float pick_scale(const ScalePair& s, int m) { return m < s.split ? s.s0 : s.s1; }
 
+// Launch pixel m -> (image, row, column) of an OH x OW map: shifts and masks when both sides are powers of two (every map of this
+// model), the divisions otherwise.  An integer division expands to ~25 vector instructions, and beside fp32 MFMAs those are paid in
+// full; the branch is uniform.
+__device__ __forceinline__ void pix_decompose(int m, int OW, int OH, int& b, int& oy, int& ox) {
+    if (((OW & (OW - 1)) | (OH & (OH - 1))) == 0) {
+        const int t = m >> __builtin_ctz(OW);
+        ox = m & (OW - 1);
+        oy = t & (OH - 1);
+        b = t >> __builtin_ctz(OH);
+    } else {
+        ox = m % OW;
+        const int t = m / OW;
+        oy = t % OH;
+        b = t / OH;
+    }
+}
+
 // Consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2).  Position of workgroup b in an order
 // that gives every XCD one contiguous run of the nblk tiles: tiles that share operands then meet in the same L2.
 __device__ __forceinline__ int xcd_contiguous_block(int b, int nblk) {

@@ -240,10 +240,8 @@ __global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) 
 #pragma unroll
             for (int ty = 0; ty < TH; ++ty) rowoff[ty] = OOB;
             if (q < 2 * iters && m < p.M) {
-                const int ox = m % g.OW;
-                const int t2 = m / g.OW;
-                const int oy = t2 % g.OH;
-                const int b = t2 / g.OH;
+                int b, oy, ox;
+                pix_decompose(m, g.OW, g.OH, b, oy, ox);
                 pbase = (unsigned)(((long long)m * a.p_ld + l31) * 4);
                 xbase = ox + g.off_x + smin;
 #pragma unroll

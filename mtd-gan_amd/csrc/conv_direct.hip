@@ -15,10 +15,7 @@
 namespace {
 
 __device__ __forceinline__ void decompose(const mtd_geom& g, int m, int& b, int& oy, int& ox) {
-    ox = m % g.OW;
-    int t = m / g.OW;
-    oy = t % g.OH;
-    b = t / g.OH;
+    pix_decompose(m, g.OW, g.OH, b, oy, ox);
 }
 
 // one thread per (pixel, n)

@@ -74,10 +74,8 @@ __device__ __forceinline__ void tile_of(const IgemmParams& p, int& tm, int& tn) 
 
 __device__ __forceinline__ long long out_pixel(const mtd_geom& g, int m, int identity) {
     if (identity) return m;
-    int ox = m % g.OW;
-    int t = m / g.OW;
-    int oy = t % g.OH;
-    int b = t / g.OH;
+    int b, oy, ox;
+    pix_decompose(m, g.OW, g.OH, b, oy, ox);
     return ((long long)b * g.OHF + (oy * g.out_sy + g.out_oy)) * g.OWF + (ox * g.out_sx + g.out_ox);
 }
 
@@ -523,10 +521,8 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int zk) {
         okmask[i] = 0;
         boff[i] = 0;
         if (m < p.M) {
-            const int ox = m % g.OW;
-            const int t2 = m / g.OW;
-            const int oy = t2 % g.OH;
-            const int b = t2 / g.OH;
+            int b, oy, ox;
+            pix_decompose(m, g.OW, g.OH, b, oy, ox);
             const int py = oy * g.in_sy + g.off_y, px = ox * g.in_sx + g.off_x;
             boff[i] = (unsigned)(((((long long)b * g.IH + py) * g.IW + px) * a.in_ld + kh * 16) * 4);
             for (int t = 0; t < T; ++t) {
@@ -790,10 +786,8 @@ __global__ __launch_bounds__(256, 2) void igemm_tb_kernel(const IgemmParams p) {
         okmask[i] = 0;
         boff[i] = 0;
         if (m < p.M) {
-            const int ox = m % g.OW;
-            const int t2 = m / g.OW;
-            const int oy = t2 % g.OH;
-            const int b = t2 / g.OH;
+            int b, oy, ox;
+            pix_decompose(m, g.OW, g.OH, b, oy, ox);
             const int py = oy * g.in_sy + g.off_y, px = ox * g.in_sx + g.off_x;
             boff[i] = (unsigned)(((((long long)b * g.IH + py) * g.IW + px) * a.in_ld + kh * 16) * 4);
             for (int t = 0; t < T; ++t) {
@@ -981,10 +975,8 @@ __global__ __launch_bounds__(256, 2) void igemm_c32p_kernel(const IgemmParams p,
         bo = 0;
         ok = 0;
         if (tl < ntiles && m < p.M) {
-            const int ox = m % g.OW;
-            const int t2 = m / g.OW;
-            const int oy = t2 % g.OH;
-            const int b = t2 / g.OH;
+            int b, oy, ox;
+            pix_decompose(m, g.OW, g.OH, b, oy, ox);
             const int py = oy * g.in_sy + g.off_y, px = ox * g.in_sx + g.off_x;
             bo = (unsigned)(((((long long)b * g.IH + py) * g.IW + px) * a.in_ld + kh * 16) * 4);
 #pragma unroll
@@ -1315,10 +1307,8 @@ __global__ __launch_bounds__(256, 2) void igemm_v2_kernel(const IgemmParams p) {
         aoff[ii] = 0;
         okm[ii] = 0;
         if (m < p.M) {
-            const int ox = m % g.OW;
-            const int t2 = m / g.OW;
-            const int oy = t2 % g.OH;
-            const int b = t2 / g.OH;
+            int b, oy, ox;
+            pix_decompose(m, g.OW, g.OH, b, oy, ox);
             const int py = oy * g.in_sy + g.off_y, px = ox * g.in_sx + g.off_x;
             aoff[ii] = (unsigned)(((((long long)b * g.IH + py) * g.IW + px) * a.in_ld + piece * 4) * 4);
             for (int t = 0; t < T; ++t) {

@@ -96,10 +96,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
             qoff[i] = 0;
             qok[i] = 0;
             if (m < p.M) {
-                const int ox = m % g.OW;
-                const int t2 = m / g.OW;
-                const int oy = t2 % g.OH;
-                const int b = t2 / g.OH;
+                int b, oy, ox;
+                pix_decompose(m, g.OW, g.OH, b, oy, ox);
                 const int py = oy * g.in_sy + g.off_y, px = ox * g.in_sx + g.off_x;
                 qoff[i] = (unsigned)(((((long long)b * g.IH + py) * g.IW + px) * a.q_ld + c0 + 4 * quad) * 4);
                 for (int t = 0; t < ntap; ++t) {
@@ -347,10 +345,8 @@ __device__ __forceinline__ void wgrad_row_body(const WgradParams& p, const int b
 #pragma unroll
         for (int ty = 0; ty < TH; ++ty) rowoff[ty] = OOB;
         if (mc < p.ppw && m < p.M) {
-            const int ox = m % g.OW;
-            const int t2 = m / g.OW;
-            const int oy = t2 % g.OH;
-            const int b = t2 / g.OH;
+            int b, oy, ox;
+            pix_decompose(m, g.OW, g.OH, b, oy, ox);
             pbase = (unsigned)(((long long)m * a.p_ld + n0 + l31) * 4);
             xbase = ox + g.off_x + smin;
 #pragma unroll
@@ -559,10 +555,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_taps_kernel(const WgradParams p)
         Walk w;
         w.m = m0 + mc + kh * 16;
         w.live = mc < p.ppw;
-        w.ox = w.m % g.OW;
-        const int t2 = w.m / g.OW;
-        w.oy = t2 % g.OH;
-        w.b = t2 / g.OH;
+        pix_decompose(w.m, g.OW, g.OH, w.b, w.oy, w.ox);
         return w;
     };
     unsigned qbase = 0;
