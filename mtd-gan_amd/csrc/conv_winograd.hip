@@ -203,9 +203,8 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
     {
         const int tg = tile0 + tt;
         const bool tv = tg < wp.ntiles;
-        const int b = tg / wp.tiles_per_image;
-        const int r = tg - b * wp.tiles_per_image;
-        const int ty = r / wp.tiles_x, tx = r - ty * wp.tiles_x;
+        int b, ty, tx;
+        pix_decompose(tg, wp.tiles_x, g.OH >> 1, b, ty, tx);           // (image, tile row, tile column)
         const int iy = 2 * ty - 1 + ti;
         // (pixel (iy, TWX tx - 1) may lie outside the image: the offset is formed modulo 2^32, every VALID pixel's is in range)
         pbase = (unsigned)(((((long long)b * g.IH + iy) * g.IW + (TWX * tx - 1)) * a.in_ld + 4 * tq) * 4);
@@ -370,9 +369,8 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
     int epix;                                                      // left pixel of the thread's output row (-1: no such tile)
     {
         const int tg = tile0 + etl;
-        const int bimg = tg / wp.tiles_per_image;
-        const int r = tg - bimg * wp.tiles_per_image;
-        const int ty = r / wp.tiles_x, tx = r - ty * wp.tiles_x;
+        int bimg, ty, tx;
+        pix_decompose(tg, wp.tiles_x, g.OH >> 1, bimg, ty, tx);
         epix = tg < wp.ntiles ? (bimg * g.OH + 2 * ty + ei) * g.OW + TWX * tx : -1;
     }
     const bool evalid = epix >= 0;
