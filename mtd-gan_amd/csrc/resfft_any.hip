@@ -223,6 +223,16 @@ template <int S, int NT>
 __global__ __launch_bounds__(NT) void spec_mix_any_kernel(const float* __restrict__ R, const float* __restrict__ w2t,
                                                            const float* __restrict__ b2, float* __restrict__ T, int units) {
     constexpr int logS = Log2<S>::v, NV = (S * 16 + NT - 1) / NT;
+#ifdef MTD_ANY_EARLY      /* lab: how many of the next column's NV load vectors go out before the mix / before the forward transform */
+    constexpr int EARLY = MTD_ANY_EARLY < NV ? MTD_ANY_EARLY : NV;
+#else
+    constexpr int EARLY = NV / 2;
+#endif
+#ifdef MTD_ANY_EARLY_TOP
+    constexpr int EARLY_TOP = MTD_ANY_EARLY_TOP < EARLY ? MTD_ANY_EARLY_TOP : EARLY;
+#else
+    constexpr int EARLY_TOP = 0;
+#endif
     extern __shared__ float lds[];
     float* re = lds;
     float* im = lds + S * CLD;
@@ -232,16 +242,16 @@ __global__ __launch_bounds__(NT) void spec_mix_any_kernel(const float* __restric
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int i = tid; i < 64 * 64 + 64; i += NT) wl[i] = i < 4096 ? w2t[i] : b2[i - 4096];
     f32x4 v[NV];
-    auto issue = [&](int u) {
+    auto issue = [&](int u, int j0, int j1) {
         const float* src = R + (long long)u * S * 64;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
+        for (int j = j0; j < j1; ++j) {
             const int q = tid + NT * j;
             if (NV * NT == S * 16 || q < S * 16) v[j] = *reinterpret_cast<const f32x4*>(src + (long long)q * 4);
         }
     };
     int u = blockIdx.x;
-    if (u < units) issue(u);
+    if (u < units) issue(u, 0, NV);
     const float sc = rsqrtf((float)S);
     for (; u < units; u += gridDim.x) {
 #pragma unroll
@@ -253,11 +263,16 @@ __global__ __launch_bounds__(NT) void spec_mix_any_kernel(const float* __restric
             }
         }
         __syncthreads();
+        if (EARLY_TOP > 0 && u + (int)gridDim.x < units) issue(u + gridDim.x, 0, EARLY_TOP);
         if (!(MTD_ANY_SKIP & 1)) lds_fft<-1, true, CLD, FFT_NT(NT), FFT_UNR, MTD_ANY_FFTV>(re, im, tw, S, logS);
         // channel mix at every frequency on the matrix cores: D[o][n] = sum_k W[k][o] * Z[n][k], k = (re 0..31 | im 32..63).
         // A operand: lane (o = l & 31, k = l >> 5) of W from LDS; B operand: lane (n = l & 31, k = l >> 5) of the column.
         // work items = (32-row tile, output half): S / 32 * 2 over the 16 waves; results stay in registers until every
         // wave has read its operands (two waves may share a tile), then replace the column.
+        // the next column's loads in two halves: one requested here, before the mix (16 registers beside its accumulators: more do
+        // not fit a 1024-thread workgroup's 128), the other after it -- with all of them after the mix their way from memory had
+        // only the inverse transform to hide under, and 256 CUs asking for 33 MB at once need longer than that (6.28 -> 5.99 ms)
+        if (u + (int)gridDim.x < units) issue(u + gridDim.x, EARLY_TOP, EARLY);
         constexpr int NW = NT / 64, ITEMS = S / 32 * 2, PER = (ITEMS + NW - 1) / NW;
         f32x16 acc[PER];
 #pragma unroll
@@ -293,7 +308,7 @@ __global__ __launch_bounds__(NT) void spec_mix_any_kernel(const float* __restric
         __syncthreads();
         // the next column's loads: issued here, after the mix (their 32 registers are not live under its accumulators -- with
         // 1024 threads a lane has 128), they land under the inverse transform
-        if (u + (int)gridDim.x < units) issue(u + gridDim.x);
+        if (u + (int)gridDim.x < units) issue(u + gridDim.x, EARLY, NV);
         if (!(MTD_ANY_SKIP & 4)) lds_fft<+1, false, CLD, FFT_NT(NT), FFT_UNR, MTD_ANY_FFTV>(re, im, tw, S, logS);
         float* dstg = T + (long long)u * S * 64;
 #pragma unroll

@@ -11,7 +11,9 @@ for cfg in ${ANY_CFGS:-"" "-DMTD_ANY_FFTV=1" "-DMTD_ANY_SKIP=1" "-DMTD_ANY_SKIP=
   python - "$cfg" <<'PY'
 import json, sys
 z = json.load(open("gpurun_out/any_var.json"))
-o = z["roofline"]["other_mfma_kernels"]
+r = z["roofline"]
+o = dict(r.get("other_mfma_kernels") or r.get("other_kernels") or {})
+o[r["kernel"]] = {"ms_per_step": r["share_of_step_gpu_ms"]}
 print(f"{sys.argv[1]!r:50s} step {z['ms_per_step']:.2f} ms  rows {o['rfft_rows_any_kernel']['ms_per_step']:.2f}  mix {o['spec_mix_any_kernel']['ms_per_step']:.2f}  rows back {o['irfft_rows_any_kernel']['ms_per_step']:.2f}", flush=True)
 PY
 done
