@@ -33,7 +33,8 @@
 //     the tile and 32 extra floats per patch row a (rows 0 and 3, read by the two output rows of a tile, on opposite halves
 //     of the 64 banks).
 // Roofline: HBM at (in + out + residual) x 128 B per pixel; fp32 MFMA at 2 M 32 32 3 executed flops is the smaller bound on
-// these layers.  Measured on 8 x 512 x 512 (profiles/r4_c32_winograd_parts.txt): 235 - 260 us per layer against 360
+// these layers.  Measured on 8 x 512 x 512 (profiles/r4_c32_winograd_parts.txt): 235 - 260 us per layer (223 - 240 after the vector-ALU
+// trimming of DESIGN 9.2; 201 inside the inference step) against 360
 // (general kernel) and 400 - 440 (implicit GEMM); fabric traffic exactly the algorithmic bytes (FETCH_SIZE x 2 = in + residual),
 // no LDS bank conflicts, matrix pipe busy 41 %.  With parts switched off (MTD_C32_SKIP): everything but the patch loads 165 us,
 // loads + stores alone 135 - 160 us, MFMAs + barriers alone 140 us -- the vector-memory path (about 19 clocks per instruction
