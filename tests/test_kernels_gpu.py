@@ -753,6 +753,35 @@ def test_winograd_32_channel_form(hip_lib, case):
 
 
 @pytest.mark.gpu
+def test_winograd_32_channel_form_is_repeatable(hip_lib):
+    """The persistent kernel's pipeline hands three blocks' work between its waves through LDS (two input images, one exchange
+    image, two barriers per block): the same launch twice gives the same bits, on a whole-block shape, a ragged one and the
+    training patches' shape (where the generator's forward pass asks for it: conv(..., wino32=True)), every element written."""
+    from mtd_gan_amd import kernels as K
+    for (B, H, W) in ((32, 64, 64), (2, 128, 128), (3, 136, 132)):
+        gen = torch.Generator().manual_seed(5)
+        x = torch.randn(B, H, W, 32, generator=gen).cuda()
+        w = (torch.randn(32, 32, 3, 3, generator=gen) * 0.06).cuda()
+        bias, add1 = torch.randn(32, generator=gen).cuda(), torch.randn(B, H, W, 32, generator=gen).cuda()
+        geom = K.geom_fwd(B, H, W, 3, 1, 1)
+        ref = None
+        for _ in range(5):
+            out = torch.full_like(x, float("nan"))
+            K.FLOP_COUNT = {}
+            try:
+                K.conv(x, w, geom, 32, 32, 288, 9, out, bias=bias, add1=add1, act=K.ACT_RELU, wino32=True)
+            finally:
+                fc, K.FLOP_COUNT = K.FLOP_COUNT, None
+            torch.cuda.synchronize()
+            assert fc.get("conv_winograd_saved", 0.0) > 0
+            assert not torch.isnan(out).any()
+            if ref is None:
+                ref = out
+            else:
+                assert torch.equal(ref, out)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("form", ["plan", "f2x2"])
 @pytest.mark.parametrize("case", [(2, 64, 64, 64, 64), (3, 128, 64, 16, 16), (5, 256, 512, 8, 8), (2, 64, 128, 10, 12), (32, 64, 64, 32, 32),
                                   (3, 64, 64, 6, 20), (7, 128, 192, 8, 8)])
