@@ -29,10 +29,10 @@ def block_forward(x, w_img, b_img, w_fft, b_fft, save, w2t=None):
         if K.conv_relu_add_ok(x, w_img, g, CH, CH, CH * 9, 9, img, bias=b_img, add1=x):
             # img = x + relu(conv3x3(x) + b) in one launch (MTD_ACT_RELU_ADD): the closing row transform then adds ONE operand
             K.conv(x, w_img, g, CH, CH, CH * 9, 9, img, bias=b_img, add1=x, act=K.ACT_RELU_ADD)
-            K.spectral_branch_any(x, K.transpose64(w_fft), b_fft, out, add1=img)
+            K.spectral_branch_any(x, w2t if w2t is not None else K.transpose64(w_fft), b_fft, out, add1=img)
         else:
             K.conv(x, w_img, g, CH, CH, CH * 9, 9, img, bias=b_img, act=ACT_RELU)
-            K.spectral_branch_any(x, K.transpose64(w_fft), b_fft, out, add1=x, add2=img)
+            K.spectral_branch_any(x, w2t if w2t is not None else K.transpose64(w_fft), b_fft, out, add1=x, add2=img)
         return out, None
     if w2t is None:
         w2t = K.transpose64(w_fft)
@@ -135,7 +135,7 @@ def generator_forward(x, P, save, out=None):
         if save:
             views.append((w_img, CH, CH, 9, CH * 9))
     K.prepack(views)                                       # one launch for all [tap][n][c] weight views
-    w2ts = K.transpose64_all([blk[2] for blk in P.blk]) if (H == 64 and W == 64) else {}      # ... and one for the mix weights
+    w2ts = K.transpose64_all([blk[2] for blk in P.blk])      # ... and one for the mix weights (cached until they change)
     gf = K.geom_fwd(B, H, W, 3, 1, 1)
     gt = K.geom_dgrad_s1(B, H, W, 3, 1)                    # ConvTranspose2d(k3,s1,p1) gathers like a stride-1 dgrad
     # The plain encoder / decoder layers run on the persistent F(2x4, 3x3) kernel of the 32-channel layers where conv() takes
