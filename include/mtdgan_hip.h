@@ -281,6 +281,10 @@ typedef struct { const float* a; const float* b; int na, nb; } mtd_sum_desc;    
 int mtd_scalar_sums(const mtd_sum_desc* table_dev, int count, float* out, void* stream);
 typedef struct { float* p; long long n; } mtd_zero_desc;
 int mtd_zero_multi(const mtd_zero_desc* table_dev, const mtd_zero_desc* table_host, int count, void* stream);
+/* sums[t] = sum of the 32-bit patterns of tensor t modulo 2^64 (an order-independent integer checksum).  Data-parallel
+ * replicas must hold bit-identical parameters after every update (train.py:93-98 relies on nn.DataParallel for that; here the
+ * ranks compare these sums after the first replayed iterations: parallel.DataParallelSync.replicas_agree). */
+int mtd_checksum_multi(const mtd_zero_desc* table_dev, const mtd_zero_desc* table_host, int count, unsigned long long* sums, void* stream);
 /* dst[0..bytes) = src_pinned[0..bytes): src is page-locked host memory mapped into the device address space
  * (hipHostMalloc / torch pin_memory), read by a kernel on `stream`; bytes % 16 == 0, both 16-byte aligned.
  * Used for the descriptor tables (mtd_*_layer / mtd_loss_term / mtd_adamw_tensor arrays). */
@@ -447,6 +451,17 @@ int mtd_prof_collect(mtd_prof_record* out, int max_records);   /* returns the nu
 int mtd_prof_mode(int attach);
 
 const char* mtd_version(void);
+
+/* ---- run-time options.  The shipped library reads NO environment variable (round 5): the kernel-selection and tuning
+ * switches of earlier rounds exist only in a build with -DMTD_LAB (mtd_lab_build() == 1; tools/ probes).  What may be changed
+ * at run time goes through these two calls, by name; unknown names return MTD_EINVAL.
+ *   "c32f_safe_wait"  0 (default) | 1: the fused 32-channel backward launch waits for ALL outstanding vector-memory operations
+ *                     before it hands a halo buffer to the next DMA, instead of the counted wait (a checking mode:
+ *                     tests/test_kernels_gpu.py::test_fused_c32_backward_counted_waits_same_bits).
+ * Plan-level tuning hooks with their own entry points: mtd_conv_winograd_f4_min_w, mtd_conv_wgrad_plan_cfg, mtd_prof_mode. */
+int mtd_set_option(const char* name, int value);
+int mtd_get_option(const char* name, int* value);
+int mtd_lab_build(void);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,10 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libmtdgan_hip.so")
+# MTD_LAB_BUILD=1: the lab library (-DMTD_LAB: the kernel-selection environment switches of csrc/ are live), written beside
+# the shipped one as libmtdgan_hip_lab.so and loaded only under MTD_LAB=1 (_options.py).  Never built by __graft_entry__.build().
+LAB_BUILD = os.environ.get("MTD_LAB_BUILD", "0") == "1"
+LIB = os.path.join(HERE, "libmtdgan_hip_lab.so" if LAB_BUILD else "libmtdgan_hip.so")
 SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "conv_c32_bwd.hip", "conv_winograd.hip", "conv_direct.hip", "resfft.hip", "resfft4.hip", "resfft_any.hip", "elementwise.hip",
            "specnorm.hip", "losses.hip", "metrics.hip", "sampler.hip", "pcgrad.hip", "adamw.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
@@ -20,7 +23,8 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(CSRC, "build")
+    objdir = os.path.join(CSRC, "build_lab" if LAB_BUILD else "build")
+    flags = FLAGS + (["-DMTD_LAB"] if LAB_BUILD else [])
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "fft64.h"), os.path.join(os.path.dirname(HERE), "include", "mtdgan_hip.h"),
                os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_wgrad.hip"), os.path.join(CSRC, "conv_wgrad_wino.h"), os.path.join(CSRC, "conv_wino_c32.h")]      # (conv_c32_bwd.hip includes the two kernel files)
@@ -32,7 +36,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc] + flags + ["-c", src, "-o", obj]
             if verbose:
                 print("[mtdgan build]", " ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

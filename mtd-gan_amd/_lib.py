@@ -7,6 +7,8 @@ import torch  # noqa: F401  -- must come first: torch's bundled HIP runtime has 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmtdgan_hip.so")
+if os.environ.get("MTD_LAB", "0") == "1" and os.path.exists(os.path.join(_HERE, "libmtdgan_hip_lab.so")):
+    LIB_PATH = os.path.join(_HERE, "libmtdgan_hip_lab.so")       # the -DMTD_LAB build (_options.py, _build.py): lab sessions only
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_RELU_ADD = 0, 1, 2, 3
 
@@ -112,7 +114,7 @@ def _preload_torch_hip_runtime():
 
 
 RECORDER = None      # kernels.LaunchList: while a step is being recorded, the list every launch is appended to
-_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "mtd_prof_", "_override", "_bwd_ok", "_stamps", "_zmask_bytes", "_tail_ok", "_winograd_ok", "_weight_floats", "_kmap", "_plan_cfg", "_pair_ok", "_pair_mode", "_patch_w", "_f4_min_w", "_relu_add_ok", "_wino24_min_w")
+_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "_option", "mtd_lab_build", "mtd_prof_", "_override", "_bwd_ok", "_stamps", "_zmask_bytes", "_tail_ok", "_winograd_ok", "_weight_floats", "_kmap", "_plan_cfg", "_pair_ok", "_pair_mode", "_patch_w", "_f4_min_w", "_relu_add_ok", "_wino24_min_w")
 
 
 class _RecordingLib:
@@ -166,6 +168,9 @@ def lib():
         f.argtypes = list(args)
 
     sig("mtd_version", C.c_char_p)
+    sig("mtd_set_option", ci, C.c_char_p, ci)
+    sig("mtd_get_option", ci, C.c_char_p, vp)
+    sig("mtd_lab_build", ci)
     sig("mtd_conv_igemm_ws_bytes", sz, C.POINTER(ConvArgs))
     sig("mtd_conv_igemm", ci, C.POINTER(ConvArgs), vp)
     sig("mtd_conv_direct", ci, C.POINTER(ConvArgs), vp)
@@ -208,6 +213,7 @@ def lib():
     sig("mtd_scale_by", ci, vp, vp, vp, ll, vp)
     sig("mtd_scalar_sums", ci, vp, ci, vp, vp)
     sig("mtd_zero_multi", ci, vp, vp, ci, vp)
+    sig("mtd_checksum_multi", ci, vp, vp, ci, vp, vp)
     sig("mtd_pack_weights", ci, vp, vp, ci, vp)
     sig("mtd_upload", ci, vp, vp, sz, vp)
     sig("mtd_sn_ws_bytes", sz, vp, ci)
@@ -274,7 +280,8 @@ EXPORTS = [
     "mtd_spec_mix_zmask_bytes", "mtd_spec_mix_fwd4", "mtd_spec_mix_bwd4",
     "mtd_resfft_block_tail_ok", "mtd_resfft_block_tail", "mtd_conv_c32_bwd_irfft",
     "mtd_winograd_weight_floats", "mtd_winograd_kmap", "mtd_winograd_weights", "mtd_conv_winograd_ok", "mtd_conv_winograd_ws_bytes", "mtd_conv_winograd",
-    "mtd_conv_wgrad_plan_cfg", "mtd_conv_wgrad_wino24_min_w", "mtd_conv_winograd_patch_w", "mtd_conv_winograd_f4_min_w", "mtd_conv_relu_add_ok", "mtd_dropout_mask", "mtd_scale_by", "mtd_scalar_sums", "mtd_zero_multi",
+    "mtd_conv_wgrad_plan_cfg", "mtd_conv_wgrad_wino24_min_w", "mtd_conv_winograd_patch_w", "mtd_conv_winograd_f4_min_w", "mtd_conv_relu_add_ok", "mtd_dropout_mask", "mtd_scale_by", "mtd_scalar_sums", "mtd_zero_multi", "mtd_checksum_multi",
+    "mtd_set_option", "mtd_get_option", "mtd_lab_build",
 ]
 
 

@@ -1,5 +1,6 @@
 """Workloads timed by bench.py.  Each exposes step() (one pass of the hot path over one resident batch),
 config(), extra() and cpu_baseline_spec()."""
+from . import _options
 import torch
 import torch.distributed as dist
 
@@ -26,7 +27,7 @@ class GeneratorWorkload:
         self.graph_error = None
         self.launch_list = None
         import os
-        mode = os.environ.get("MTD_GRAPH", "1")
+        mode = _options.product("MTD_GRAPH", "1")
         if world == 1 and mode == "list":
             # recorded launch list (kernels.LaunchList): the step's C-ABI calls and stream-order operations re-issued without
             # the Python around them, side streams kept.  For THIS workload the captured single-stream graph is the faster

@@ -3,7 +3,41 @@
 #include <mutex>
 #include <vector>
 
+#include <string.h>
 extern "C" const char* mtd_version(void) { return "mtdgan_hip 0.1.0 (gfx950)"; }
+
+// ---- run-time options: the ONE documented way to change the library's behaviour at run time (include/mtdgan_hip.h lists the
+// names).  Everything else that used to be an environment variable is a lab switch of an -DMTD_LAB build (common.h).
+namespace {
+int g_options[MTD_OPT_COUNT] = {0};
+const char* const g_option_names[MTD_OPT_COUNT] = {"c32f_safe_wait"};
+int option_id(const char* name) {
+    if (!name) return -1;
+    for (int i = 0; i < MTD_OPT_COUNT; ++i)
+        if (!strcmp(name, g_option_names[i])) return i;
+    return -1;
+}
+}  // namespace
+int mtd_option(int id) { return g_options[id]; }
+extern "C" int mtd_set_option(const char* name, int value) {
+    const int id = option_id(name);
+    if (id < 0) return MTD_EINVAL;
+    g_options[id] = value;
+    return MTD_OK;
+}
+extern "C" int mtd_get_option(const char* name, int* value) {
+    const int id = option_id(name);
+    if (id < 0 || !value) return MTD_EINVAL;
+    *value = g_options[id];
+    return MTD_OK;
+}
+extern "C" int mtd_lab_build(void) {
+#ifdef MTD_LAB
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 namespace {
 struct ProfSlot {
@@ -70,7 +104,7 @@ extern "C" int mtd_prof_enable(int capacity) {
     g_prof.clear();
     g_prof_cap = capacity > 0 ? capacity : 0;
     if (g_prof_cap) g_prof.reserve(g_prof_cap);
-    static const bool env_bracket = [] { const char* e = getenv("MTD_PROF_MODE"); return e && e[0] == 'b'; }();
+    static const bool env_bracket = [] { const char* e = mtd_lab_env("MTD_PROF_MODE"); return e && e[0] == 'b'; }();
     if (env_bracket) g_prof_attach = 0;
     return MTD_OK;
 }

@@ -5,6 +5,20 @@
 #include <stdint.h>
 #include "../../include/mtdgan_hip.h"
 
+// Lab switches.  The kernel-selection / tuning environment variables of rounds 1-4 (MTD_WINO_*, MTD_WGRAD_*, MTD_IGEMM_*, ...)
+// exist only in a library built with -DMTD_LAB (tools/ probes: `MTD_LAB_BUILD=1 python mtd-gan_amd/_build.py --force`).  The
+// shipped library reads NO environment variable: a stray MTD_* in a user's shell cannot change which kernel runs.  The few
+// options that are meant to be flipped at run time go through mtd_set_option() (api.hip), each exercised by a test.
+#include <stdlib.h>
+#ifdef MTD_LAB
+static inline const char* mtd_lab_env(const char* name) { return getenv(name); }
+#else
+static inline const char* mtd_lab_env(const char*) { return nullptr; }
+#endif
+// run-time options (api.hip: mtd_set_option / mtd_get_option)
+enum { MTD_OPT_C32F_SAFE_WAIT = 0, MTD_OPT_COUNT };
+int mtd_option(int id);
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

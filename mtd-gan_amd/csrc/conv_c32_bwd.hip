@@ -424,10 +424,9 @@ int c32_bwd_launch(const mtd_conv_args* d, const mtd_wgrad_args* w, const float*
     const int grid = fp.ntiles < 256 ? fp.ntiles : 256;
     fp.iters = (fp.ntiles + grid - 1) / grid;
     p.nslab = grid;
-    static const int env_roles = [] { const char* e = getenv("MTD_C32F_ROLES"); return e ? atoi(e) : 3; }();
-    const char* safe = getenv("MTD_C32F_SAFE_WAIT");        // (read per call: the test flips it)
-    fp.roles = env_roles | ((safe && safe[0] == '1') ? 8 : 0);
-    static const bool want_stamps = getenv("MTD_C32F_STAMPS") != nullptr;
+    static const int env_roles = [] { const char* e = mtd_lab_env("MTD_C32F_ROLES"); return e ? atoi(e) : 3; }();
+    fp.roles = env_roles | (mtd_option(MTD_OPT_C32F_SAFE_WAIT) ? 8 : 0);      // (mtd_set_option("c32f_safe_wait", 1): the test flips it)
+    static const bool want_stamps = mtd_lab_env("MTD_C32F_STAMPS") != nullptr;
     if (want_stamps && !g_c32f_stamps && hipMalloc(&g_c32f_stamps, 256 * sizeof(unsigned long long)) != hipSuccess) g_c32f_stamps = nullptr;
     fp.stamps = g_c32f_stamps;
     fp.specT = specT;

@@ -702,7 +702,7 @@ bool wide_plan(const mtd_wgrad_args& a, WideParams& p) {
     // ~512 workgroups (tools/wide_probe.py, MTD_WIDE_WGS = 256 / 512 / 1024 / 2048: 25.4 / 22.9 / 23.1 / 31.5 us for conv11 at 32
     // images, main kernel + slab sum): with four wide loads in flight per lane a workgroup of four image rows amortises
     // its tile load and its cross-wave sum; the 2048 one-row workgroups of the first version were all prologue and epilogue
-    static const int env_wgs = [] { const char* e = getenv("MTD_WIDE_WGS"); return e ? atoi(e) : 512; }();
+    static const int env_wgs = [] { const char* e = mtd_lab_env("MTD_WIDE_WGS"); return e ? atoi(e) : 512; }();
     long long ppb = (p.Mw + env_wgs - 1) / env_wgs;
     const long long min_ppb = 4ll * (64 / p.CL) * 4;
     if (ppb < min_ppb) ppb = min_ppb;
@@ -769,12 +769,12 @@ extern "C" int mtd_conv_direct(const mtd_conv_args* a, void* stream) {
                 near = dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1 && !seen[(dy + 1) * 3 + dx + 1];
                 if (near) seen[(dy + 1) * 3 + dx + 1] = true;
             }
-            static const int env_tile = [] { const char* e = getenv("MTD_C1_TILE"); return e ? atoi(e) : 1; }();
+            static const int env_tile = [] { const char* e = mtd_lab_env("MTD_C1_TILE"); return e ? atoi(e) : 1; }();
             int R = 0;
             if (near && env_tile && g.OW % PL == 0 && (a->scale2 == nullptr || a->scale_split % (g.OH * g.OW) == 0)) {
                 // ~512 workgroups of 4 or 8 image rows: with one row each (2048 workgroups of four pixels per thread) the
                 // launch was ramp and tail (19 us for 16.8 MB of output)
-                static const int env_wgs = [] { const char* e = getenv("MTD_C1_WGS"); return e ? atoi(e) : 512; }();
+                static const int env_wgs = [] { const char* e = mtd_lab_env("MTD_C1_WGS"); return e ? atoi(e) : 512; }();
                 R = (int)(((Mpix + env_wgs - 1) / env_wgs) / g.OW);
                 if (R < 1) R = 1;
                 while (R > 1 && g.OH % R) --R;                                 // whole tiles per image
@@ -792,7 +792,7 @@ extern "C" int mtd_conv_direct(const mtd_conv_args* a, void* stream) {
             hipLaunchKernelGGL(fwd_c1_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
         } else if ([&] {
                        // tap planes on the matrix cores (fwd_n1_planes_kernel): 3x3 "same" geometry on 64-pixel rows, C = 32 / 64 / 128
-                       static const int env_planes = [] { const char* e = getenv("MTD_N1_PLANES"); return e ? atoi(e) : 1; }();
+                       static const int env_planes = [] { const char* e = mtd_lab_env("MTD_N1_PLANES"); return e ? atoi(e) : 1; }();
                        if (!env_planes || !(a->C == 32 || a->C == 64 || a->C == 128) || T > 9 || !identity) return false;
                        if (g.in_sy != 1 || g.in_sx != 1 || g.OH != g.IH || g.OW != g.IW || g.OW != 64 || (g.OH % 8)) return false;
                        if (a->w_sc <= 0 || (a->scale2 && a->scale_split % (g.OH * g.OW))) return false;
@@ -809,7 +809,7 @@ extern "C" int mtd_conv_direct(const mtd_conv_args* a, void* stream) {
             q.a = *a;
             q.M = (int)Mpix;
             q.T = T;
-            static const int env_r = [] { const char* e = getenv("MTD_N1_R"); return e ? atoi(e) : 8; }();
+            static const int env_r = [] { const char* e = mtd_lab_env("MTD_N1_R"); return e ? atoi(e) : 8; }();
             q.R = env_r;
             q.in_bytes = (unsigned)((((long long)g.B * g.IH * g.IW - 1) * a->in_ld + a->C) * 4);
             for (int t = 0; t < T; ++t) {

@@ -1476,7 +1476,7 @@ Plan make_plan(const mtd_conv_args& a, int sets = 1) {
     // move 7.0 ms of launches onto that tile and 1.6 ms onto the two-block tap-block kernel and the family's total does not
     // change (20.63 -> 20.58 ms in the one-stream trace, step 40.26 vs 40.40 ms): standalone timings on repeated launches
     // do not predict the in-step ranking at this margin.  Off by default.
-    static const int env_plan = [] { const char* e = getenv("MTD_IGEMM_PLAN"); return e ? atoi(e) : 1; }();
+    static const int env_plan = [] { const char* e = mtd_lab_env("MTD_IGEMM_PLAN"); return e ? atoi(e) : 1; }();
     const int T9 = a.g.TH * a.g.TW == TB_MAXT;
     if (env_plan >= 2 && sets == 1 && T9) {
         const long long MN = M * a.N;
@@ -1589,9 +1589,9 @@ int fill_params(const mtd_conv_args* a, const Plan& pl, IgemmParams& p) {
     const mtd_geom& g = a->g;
     p.out_identity = (g.out_sy == 1 && g.out_sx == 1 && g.out_oy == 0 && g.out_ox == 0 && g.OHF == g.OH && g.OWF == g.OW);
     p.out_linear = p.out_identity || (g.OW % 32 == 0);
-    static const int env_xcd = [] { const char* e = getenv("MTD_IGEMM_XCD"); return e ? atoi(e) : 1; }();
+    static const int env_xcd = [] { const char* e = mtd_lab_env("MTD_IGEMM_XCD"); return e ? atoi(e) : 1; }();
     p.xcd_map = env_xcd;
-    static const int env_nt = [] { const char* e = getenv("MTD_IGEMM_NT"); return e ? atoi(e) : 0; }();
+    static const int env_nt = [] { const char* e = mtd_lab_env("MTD_IGEMM_NT"); return e ? atoi(e) : 0; }();
     p.nt_store = env_nt;
     p.wide = (wide_epilogue_ok(*a) ? 1 : 0) | ((pl.splitk > 1 && aligned16(a->ws)) ? 2 : 0);
     p.fin = 0;
@@ -1600,9 +1600,9 @@ int fill_params(const mtd_conv_args* a, const Plan& pl, IgemmParams& p) {
         if (!a->ws || a->ws_bytes < need) return MTD_EWS;
         // finish inside the kernel when the caller brought arrival counters for every output tile (MTD_SPLITK_FIN=0: lab
         // switch back to the separate epilogue launch)
-        static const int env_fin = [] { const char* e = getenv("MTD_SPLITK_FIN"); return e ? atoi(e) : 1; }();
+        static const int env_fin = [] { const char* e = mtd_lab_env("MTD_SPLITK_FIN"); return e ? atoi(e) : 1; }();
         const long long tiles = (long long)((p.M + pl.BM - 1) / pl.BM) * (a->N / pl.BN);
-        static const int env_fin_max = [] { const char* e = getenv("MTD_SPLITK_FIN_MAX"); return e ? atoi(e) : 8; }();
+        static const int env_fin_max = [] { const char* e = mtd_lab_env("MTD_SPLITK_FIN_MAX"); return e ? atoi(e) : 8; }();
         p.fin = (env_fin && pl.cfg != 7 && a->tile_ctr && tiles <= (long long)a->tile_ctr_len && pl.splitk <= env_fin_max) ? (splitk_vec_ok(*a, p.M) ? 1 : 2) : 0;
     }
     return MTD_OK;
@@ -1631,14 +1631,14 @@ extern "C" int mtd_conv_igemm(const mtd_conv_args* a, void* stream) {
     if ((g_force_cfg == -1 || g_force_cfg == 10) && gen_shape && c32t_eligible(*a) && a->act != MTD_ACT_RELU_ADD) {
         // generator-shaped layers on 64-pixel rows: halo tiles of four image rows, one persistent workgroup per CU
         const int prof = mtd_prof_begin(0, 10, 1, p.M, a->N, a->C, 9, s, alg_bytes);
-        static const int env_variant = [] { const char* e = getenv("MTD_C32T_VARIANT"); return e ? atoi(e) : 0; }();
-        static const int env_stagger = [] { const char* e = getenv("MTD_C32T_STAGGER"); return e ? atoi(e) : 0; }();
+        static const int env_variant = [] { const char* e = mtd_lab_env("MTD_C32T_VARIANT"); return e ? atoi(e) : 0; }();
+        static const int env_stagger = [] { const char* e = mtd_lab_env("MTD_C32T_STAGGER"); return e ? atoi(e) : 0; }();
         if (env_variant == 1) {
             const int ntiles = p.M / (2 * C32T_W);
             MTD_LAUNCH((igemm_c32t_kernel<2, false>), dim3(ntiles < 512 ? ntiles : 512, a->N / 32), dim3(256), 0, s, p, ntiles, env_stagger, (const float*)nullptr);
         } else {
             const int ntiles = p.M / (C32T_R * C32T_W);
-            static const int env_wide = [] { const char* e = getenv("MTD_C32T_WIDE"); return e ? atoi(e) : 1; }();
+            static const int env_wide = [] { const char* e = mtd_lab_env("MTD_C32T_WIDE"); return e ? atoi(e) : 1; }();
             if (env_wide && wide_epilogue_ok(*a))
                 MTD_LAUNCH((igemm_c32t_kernel<C32T_R, true, true>), dim3(ntiles < 256 ? ntiles : 256, a->N / 32), dim3(512), 0, s, p, ntiles, 0, (const float*)nullptr);
             else
@@ -1714,7 +1714,7 @@ extern "C" int mtd_resfft_block_tail(const mtd_conv_args* a, const float* T, voi
     const int ntiles = p.M / (C32T_R * C32T_W);
     const int prof = mtd_prof_begin(0, 12, 1, p.M, a->N, a->C, 9, s, algorithmic_bytes(a) + 4.0 * a->g.B * NKW * 4096);
 #ifdef MTD_LAB       // lab builds only (stage switches that produce WRONG results); never read from the environment by the shipped library
-    static const int env_lab = [] { const char* e = getenv("MTD_TAIL_LAB"); return e ? atoi(e) : 0; }();
+    static const int env_lab = [] { const char* e = mtd_lab_env("MTD_TAIL_LAB"); return e ? atoi(e) : 0; }();
 #else
     const int env_lab = 0;
 #endif

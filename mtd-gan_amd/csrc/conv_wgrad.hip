@@ -1106,7 +1106,7 @@ WPlan make_wplan(const mtd_wgrad_args& a, const int g_wplan_div = 1) {
     else if (T <= 4) pl.cfg = 1;
     else if (T <= 9) pl.cfg = (M <= 2048) ? 4 : 0;              // few pixels, many tiles: 3 taps per wave, no pixel split
     else pl.cfg = (M >= 2048 && a.N % 64 == 0 && a.C % 64 == 0) ? 2 : 4;
-    static const int env_s2 = [] { const char* e = getenv("MTD_WGRAD_S2"); return e ? atoi(e) : 1; }();
+    static const int env_s2 = [] { const char* e = mtd_lab_env("MTD_WGRAD_S2"); return e ? atoi(e) : 1; }();
     if (a.g.TH == 4 && a.g.TW == 4 && a.g.in_sy == 2 && a.g.in_sx == 2 && a.g.off_y == -1 && a.g.off_x == -1 && a.g.tap_dy == 1 &&
         a.g.tap_dx == 1 && (a.g.OH % 8) == 0 && (a.g.OW % 8) == 0 && ((env_s2 && g_wforce_cfg == -1) || g_wforce_cfg == 15)) {
         // halo-window kernel: 8 x 8 pixel blocks; ~512 workgroups of the single-buffer form, two per CU (51 KB of LDS each), which take
@@ -1115,7 +1115,7 @@ WPlan make_wplan(const mtd_wgrad_args& a, const int g_wplan_div = 1) {
         pl.WN = 1; pl.WC = 1; pl.TG = T; pl.ntg = 1; pl.nw = 4;
         const long long tiles = (long long)(a.N / 32) * (a.C / 32);
         const long long NB = (long long)a.g.B * (a.g.OH / 8) * (a.g.OW / 8);
-        static const int env_s2wgs = [] { const char* e = getenv("MTD_WGRAD_S2_WGS"); return e ? atoi(e) : 512; }();
+        static const int env_s2wgs = [] { const char* e = mtd_lab_env("MTD_WGRAD_S2_WGS"); return e ? atoi(e) : 512; }();
         long long ns = (env_s2wgs / g_wplan_div + tiles - 1) / tiles;
         if (g_wforce_split > 0) ns = g_wforce_split;
         if (ns > NB) ns = NB;
@@ -1126,14 +1126,14 @@ WPlan make_wplan(const mtd_wgrad_args& a, const int g_wplan_div = 1) {
         pl.nsplit = (int)ns;
         return pl;
     }
-    static const int env_taps = [] { const char* e = getenv("MTD_WGRAD_TAPS"); return e ? atoi(e) : 1; }();
-    static const int env_taps_maxm = [] { const char* e = getenv("MTD_WGRAD_TAPS_MAXM"); return e ? atoi(e) : 128; }();
+    static const int env_taps = [] { const char* e = mtd_lab_env("MTD_WGRAD_TAPS"); return e ? atoi(e) : 1; }();
+    static const int env_taps_maxm = [] { const char* e = mtd_lab_env("MTD_WGRAD_TAPS_MAXM"); return e ? atoi(e) : 128; }();
     if (a.g.TH == 4 && a.g.TW == 4 && ((env_taps && g_wforce_cfg == -1 && M <= env_taps_maxm) || g_wforce_cfg == 13)) {
         // all-taps kernel: ~one workgroup per CU; pixels per workgroup a multiple of 32
         pl.cfg = 13;
         pl.WN = 1; pl.WC = 1; pl.TG = T; pl.ntg = 1; pl.nw = 4;
         const long long tiles = (long long)(a.N / 32) * (a.C / 32);
-        static const int env_wgs = [] { const char* e = getenv("MTD_WGRAD_TAPS_WGS"); return e ? atoi(e) : 256; }();
+        static const int env_wgs = [] { const char* e = mtd_lab_env("MTD_WGRAD_TAPS_WGS"); return e ? atoi(e) : 256; }();
         long long ns = (env_wgs / g_wplan_div + tiles - 1) / tiles;
         if (g_wforce_split > 0) ns = g_wforce_split;
         const long long max_splits = (M + 31) / 32;
@@ -1148,8 +1148,8 @@ WPlan make_wplan(const mtd_wgrad_args& a, const int g_wplan_div = 1) {
     }
     // Winograd F(2x2, 3x3) form (conv_wgrad_wino.h): 3x3 stride-1 layers with N, C multiples of 64 on maps of at least
     // MTD_WGRAD_WINO_MIN_HW pixels a side.  cfg 16; ppw = chunks of eight tiles per pixel split.
-    static const int env_wino = [] { const char* e = getenv("MTD_WGRAD_WINO"); return e ? atoi(e) : 1; }();
-    static const int env_wino_hw = [] { const char* e = getenv("MTD_WGRAD_WINO_MIN_HW"); return e ? atoi(e) : 8; }();
+    static const int env_wino = [] { const char* e = mtd_lab_env("MTD_WGRAD_WINO"); return e ? atoi(e) : 1; }();
+    static const int env_wino_hw = [] { const char* e = mtd_lab_env("MTD_WGRAD_WINO_MIN_HW"); return e ? atoi(e) : 8; }();
     if (((env_wino && g_wforce_cfg == -1) || g_wforce_cfg == 16) && wgrad_wino_ok(a) && a.g.OH >= env_wino_hw && a.g.OW >= env_wino_hw) {
         pl.cfg = 16;
         pl.WN = 2; pl.WC = 2; pl.TG = T; pl.ntg = 1; pl.nw = 8;
@@ -1297,7 +1297,7 @@ static bool wgrad_cfg_pairs(int cfg) { return (cfg >= 0 && cfg < NWCFG) || (cfg 
 static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, int& nsplit, bool& direct_out,
                          const RowsArgs* rows = nullptr, bool* rows_done = nullptr, bool pair = false) {
     if (!a) return MTD_EINVAL;
-    static const int env_nw = [] { const char* e = getenv("MTD_WGRAD_NW"); return e ? atoi(e) : 0; }();
+    static const int env_nw = [] { const char* e = mtd_lab_env("MTD_WGRAD_NW"); return e ? atoi(e) : 0; }();
     if (env_nw == 4 || env_nw == 8) g_wforce_nw = env_nw;
     int rc = check_wargs(*a);
     if (rc != MTD_OK) return rc;
@@ -1355,7 +1355,7 @@ static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, 
         // a stream that changes nothing (generator step: 31.7 us per launch either way); in the full step, where it runs on a
         // side stream beside the data-gradient chain, a second workgroup on a CU took the slots of the other stream's
         // kernel: 44.47 -> 44.03 ms per step (three A/B runs each, tools/wgrad_pad_full.sh).  MTD_WGRAD_LDS_PAD=0 is the old launch.
-        static const unsigned lds_pad = [] { const char* e = getenv("MTD_WGRAD_LDS_PAD"); return e ? (unsigned)atoi(e) : 65536u; }();
+        static const unsigned lds_pad = [] { const char* e = mtd_lab_env("MTD_WGRAD_LDS_PAD"); return e ? (unsigned)atoi(e) : 65536u; }();
         if (pl.cfg == 16) {
             WgradWinoParams wp;
             wp.w = p;
@@ -1404,7 +1404,7 @@ static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, 
                      break;
             case 13: MTD_LAUNCH(wgrad_taps_kernel, grid, dim3(256), 0, s, p); break;
             case 15: {
-                static const int env_db = [] { const char* e = getenv("MTD_WGRAD_S2_DB"); return e ? atoi(e) : 0; }();
+                static const int env_db = [] { const char* e = mtd_lab_env("MTD_WGRAD_S2_DB"); return e ? atoi(e) : 0; }();
                 if (env_db) MTD_LAUNCH((wgrad_s2_kernel<true>), grid, dim3(256), 0, s, p);
                 else MTD_LAUNCH((wgrad_s2_kernel<false>), grid, dim3(256), 0, s, p);
                 break;
@@ -1477,7 +1477,7 @@ extern "C" int mtd_conv_wgrad_reduce_multi(const mtd_wgrad_reduce_desc* table_de
 }
 
 static int wgrad_fused_reduce_enabled() {
-    static const int env_fused = [] { const char* e = getenv("MTD_WGRAD_FUSED_REDUCE"); return e ? atoi(e) : 1; }();
+    static const int env_fused = [] { const char* e = mtd_lab_env("MTD_WGRAD_FUSED_REDUCE"); return e ? atoi(e) : 1; }();
     return env_fused;
 }
 static int wgrad_reduce_slabs_impl(const WgradParams& p, const float* cur, int ns, float* next, bool direct, hipStream_t s, float* dw2);
@@ -1516,7 +1516,7 @@ static int g_wpair_mode = -1;            // -1: MTD_WGRAD_PAIR (default 1); set 
 static bool wgrad_pair_plan(const mtd_wgrad_args& a, int b_first, int& ns_half, int& cps) {
     if (check_wargs(a) != MTD_OK || is_direct(a)) return false;
     if (b_first <= 0 || 2 * b_first != a.g.B) return false;
-    static const int env_pair_default = [] { const char* e = getenv("MTD_WGRAD_PAIR"); return e ? atoi(e) : 1; }();
+    static const int env_pair_default = [] { const char* e = mtd_lab_env("MTD_WGRAD_PAIR"); return e ? atoi(e) : 1; }();
     const int env_pair = g_wpair_mode >= 0 ? g_wpair_mode : env_pair_default;
     if (!env_pair) return false;
     mtd_wgrad_args h = a;

@@ -625,8 +625,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino24_kernel(const WgradWinoPar
 int g_wgw24_min_w = -1;
 int wgrad_wino_px(const mtd_wgrad_args& a) {
     if (g_wgw24_min_w < 0) {
-        const char* on = getenv("MTD_WGRAD_WINO24");
-        const char* mw = getenv("MTD_WGRAD_WINO24_MIN_W");
+        const char* on = mtd_lab_env("MTD_WGRAD_WINO24");
+        const char* mw = mtd_lab_env("MTD_WGRAD_WINO24_MIN_W");
         g_wgw24_min_w = mw ? atoi(mw) : ((on && atoi(on) != 0) ? 8 : 0);
     }
     return (g_wgw24_min_w > 0 && (a.g.OW % 4) == 0 && a.g.OW >= g_wgw24_min_w) ? 6 : 4;

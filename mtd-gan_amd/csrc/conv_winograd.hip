@@ -537,8 +537,8 @@ int wino_patch_w(const mtd_conv_args& a);
 int wino_patch_w_of(const mtd_conv_args& a) { return wino_patch_w(a); }
 int wino_patch_w(const mtd_conv_args& a) {
     if (g_f4_min_w < 0) {
-        const char* off = getenv("MTD_WINO_F4");
-        const char* mw = getenv("MTD_WINO_F4_MIN_W");
+        const char* off = mtd_lab_env("MTD_WINO_F4");
+        const char* mw = mtd_lab_env("MTD_WINO_F4_MIN_W");
         g_f4_min_w = (off && atoi(off) == 0) ? 0 : (mw ? atoi(mw) : 8);
     }
     return (g_f4_min_w > 0 && (a.g.OW % 4) == 0 && a.g.OW >= g_f4_min_w) ? 6 : 4;
@@ -554,7 +554,7 @@ WinoPlan wino_plan(const mtd_conv_args& a, int px) {
     // repeat the input transform, and a transform instruction is paid in full beside the fp32 MFMAs.  The form won
     // 0.2 ms per step while the transform cost 170 vector instructions per K step; at 116 the split of K is ahead by 0.15 ms
     // (29.15 against 29.31 ms), so it is off by default now (MTD_WINO_F4_NB1=1: on).
-    static const int env_f4_nb1 = [] { const char* e = getenv("MTD_WINO_F4_NB1"); return e ? atoi(e) : 0; }();
+    static const int env_f4_nb1 = [] { const char* e = mtd_lab_env("MTD_WINO_F4_NB1"); return e ? atoi(e) : 0; }();
     if (px == 6 && env_f4_nb1) {
         const long long t = geom_pixels(a.g) / tile_px;
         if (((t + WT - 1) / WT) * (a.N / 64) <= 128 && a.C >= 128) pl.nb = 1;
@@ -563,7 +563,7 @@ WinoPlan wino_plan(const mtd_conv_args& a, int px) {
     // (lab, MTD_WINO_NB2_MAXC=64: the narrow form with its lean variant for layers with four K steps whatever their N -- 5 % less time
     // for those launches (123 -> 116 us, 226 -> 213 us), 0.08 ms per step, but the input is then read per 64 instead of per 128 output
     // channels: 62 -> 80 MB of fabric traffic per launch.  Off.)
-    static const int env_nb2_c = [] { const char* e = getenv("MTD_WINO_NB2_MAXC"); return e ? atoi(e) : 0; }();
+    static const int env_nb2_c = [] { const char* e = mtd_lab_env("MTD_WINO_NB2_MAXC"); return e ? atoi(e) : 0; }();
     if (a.C <= env_nb2_c) pl.nb = 2;
     const long long tiles = geom_pixels(a.g) / tile_px;
     long long blocks = ((tiles + WT - 1) / WT) * (a.N / (32 * pl.nb));
@@ -576,14 +576,14 @@ WinoPlan wino_plan(const mtd_conv_args& a, int px) {
     if (sk > chunks / 4) sk = chunks / 4;                        // at least four steps per slice
     if (sk > 16) sk = 16;
     if (sk < 1) sk = 1;
-    static const int env_sk = [] { const char* e = getenv("MTD_WINO_SPLITK"); return e ? atoi(e) : 0; }();
+    static const int env_sk = [] { const char* e = mtd_lab_env("MTD_WINO_SPLITK"); return e ? atoi(e) : 0; }();
     if (env_sk > 0) sk = env_sk < chunks ? env_sk : chunks;
     const int cps = (chunks + sk - 1) / sk;
     pl.splitk = (chunks + cps - 1) / cps;
     pl.c_per_split = cps * 16;
     // two lean workgroups per CU where a workgroup has few K steps and the grid has at least two per CU (MTD_WINO_LEAN: 0 never,
     // 1 by this rule, 2 whenever NB = 2)
-    static const int env_lean = [] { const char* e = getenv("MTD_WINO_LEAN"); return e ? atoi(e) : 1; }();
+    static const int env_lean = [] { const char* e = mtd_lab_env("MTD_WINO_LEAN"); return e ? atoi(e) : 1; }();
     const long long grid = ((tiles + WT - 1) / WT) * (a.N / (32 * pl.nb)) * pl.splitk;
     pl.lean = px == 4 && pl.nb == 2 && env_lean && (env_lean == 2 || (cps <= 8 && grid >= 512));
     return pl;
@@ -593,7 +593,7 @@ WinoPlan wino_plan(const mtd_conv_args& a, int px) {
 // no scales, no mask, 16-byte aligned rows everywhere and buffers inside 31-bit byte offsets.  MTD_WINO_C32_KERNEL=0: the
 // general kernel's 32-channel workgroups instead (lab switch).
 bool wino_c32_takes(const mtd_conv_args& a, int px) {
-    static const int env_on = [] { const char* e = getenv("MTD_WINO_C32_KERNEL"); return e ? atoi(e) : 1; }();
+    static const int env_on = [] { const char* e = mtd_lab_env("MTD_WINO_C32_KERNEL"); return e ? atoi(e) : 1; }();
     if (!env_on || px != 6 || a.C != 32 || a.N != 32) return false;
     if (a.scale || a.scale2 || a.add2 || a.mask || a.out2) return false;
     if (!wide_epilogue_ok(a) || !aligned16(a.in) || (a.in_ld % 4)) return false;
@@ -716,7 +716,7 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
     wp.nchunk = a->C / 8;
     wp.w_bytes = (unsigned)((long long)4 * px * a->N * a->C * 4);
     {
-        static const int env_xcd = [] { const char* e = getenv("MTD_WINO_XCD"); return e ? atoi(e) : -1; }();
+        static const int env_xcd = [] { const char* e = mtd_lab_env("MTD_WINO_XCD"); return e ? atoi(e) : -1; }();
         const double wbytes = 4.0 * px * a->C * a->N * 4, ibytes = (double)p.M * a->C * 4;
         wp.xcd_order = env_xcd >= 0 ? env_xcd : (wbytes >= ibytes ? 1 : 2);
     }

@@ -372,6 +372,29 @@ __global__ __launch_bounds__(256) void zero_multi_kernel(const mtd_zero_desc* __
         if (local + i < d.n) d.p[local + i] = 0.f;
 }
 
+// sums[t] = sum of the 32-bit patterns of tensor t (mod 2^64): an integer checksum, so the order of the atomic additions
+// does not matter -- equal tensors give equal sums on every rank, whatever the timing (replica agreement, parallel.py).
+// Block b takes floats [4096 b', 4096 b' + 4096) of its tensor (same block -> tensor walk as zero_multi_kernel).
+__global__ __launch_bounds__(256) void checksum_multi_kernel(const mtd_zero_desc* __restrict__ T, int count, unsigned long long* __restrict__ sums) {
+    long long first = (long long)blockIdx.x * 4096;
+    int t = 0;
+    long long base = 0;
+    while (t < count && first >= base + ((T[t].n + 4095) / 4096) * 4096) { base += ((T[t].n + 4095) / 4096) * 4096; ++t; }
+    if (t >= count) return;
+    const mtd_zero_desc d = T[t];
+    const long long local = first - base;
+    const unsigned* bits = reinterpret_cast<const unsigned*>(d.p);
+    unsigned long long acc = 0;
+    for (int i = threadIdx.x; i < 4096; i += 256)
+        if (local + i < d.n) acc += bits[local + i];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sums[t], acc);
+}
+__global__ void zero_u64_kernel(unsigned long long* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0ull;
+}
+
 inline unsigned grid_for(long long n) {
     long long b = (n + 255) / 256;
     if (b > 4096) b = 4096;
@@ -436,6 +459,20 @@ extern "C" int mtd_zero_multi(const mtd_zero_desc* table_dev, const mtd_zero_des
     }
     if (blocks >= (1ll << 31)) return MTD_EINVAL;
     hipLaunchKernelGGL(zero_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, table_dev, count);
+    MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+extern "C" int mtd_checksum_multi(const mtd_zero_desc* table_dev, const mtd_zero_desc* table_host, int count, unsigned long long* sums, void* stream) {
+    if (!table_dev || !table_host || !sums || count <= 0) return MTD_EINVAL;
+    long long blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!table_host[i].p || table_host[i].n <= 0) return MTD_EINVAL;
+        blocks += (table_host[i].n + 4095) / 4096;
+    }
+    if (blocks >= (1ll << 31)) return MTD_EINVAL;
+    hipLaunchKernelGGL(zero_u64_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count);
+    hipLaunchKernelGGL(checksum_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, table_dev, count, sums);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }

@@ -508,7 +508,7 @@ extern "C" int mtd_spec_mix_wgrad_reduce(const float* ws, int B, float* dw2, flo
     hipStream_t s = (hipStream_t)stream;
     int ns = B * 17;
     const float* cur = ws;
-    static const int env_fused = [] { const char* e = getenv("MTD_MIX_FUSED_REDUCE"); return e ? atoi(e) : 1; }();
+    static const int env_fused = [] { const char* e = mtd_lab_env("MTD_MIX_FUSED_REDUCE"); return e ? atoi(e) : 1; }();
     if (env_fused && ns <= 4096 && aligned16(ws) && aligned16(dw2)) {
         hipLaunchKernelGGL(mix_reduce_finish_kernel, dim3(65), dim3(1024), 0, s, cur, ns, dw2, db2, accumulate);
         MTD_LAUNCH_CHECK();

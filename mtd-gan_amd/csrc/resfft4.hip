@@ -336,7 +336,7 @@ extern "C" int mtd_spec_mix_fwd4(const float* R, const float* w2t, const float* 
     if (!R || !w2t || !b2 || !T || B <= 0) return MTD_EINVAL;
     if (!aligned16(R)) return MTD_EALIGN;
     // one column per workgroup (1056 + B units of 128 threads: four per CU in flight) or a pair (544 of 256); MTD_SPECMIX_COLS
-    static const int env_cols = [] { const char* e = getenv("MTD_SPECMIX_COLS"); return e ? atoi(e) : 1; }();
+    static const int env_cols = [] { const char* e = mtd_lab_env("MTD_SPECMIX_COLS"); return e ? atoi(e) : 1; }();
     if (env_cols == 2)
         hipLaunchKernelGGL((spec_mix_fwd4_kernel<2>), dim3(17, B), dim3(256), 0, (hipStream_t)stream, R, w2t, b2, T, S_save,
                            (unsigned long long*)zmask);

@@ -8,6 +8,7 @@ vector per task).  Spectral norm: sigma per pass comes from mtd_sn_power_iter; c
 weight_orig in place and scale their accumulators by 1/sigma; the weight gradient correction
  is one batched mtd_sn_grad per backward.  NHWC fp32 throughout.
 """
+from . import _options
 import ctypes as C
 import os
 
@@ -17,7 +18,7 @@ from . import _lib
 from . import kernels as K
 from .kernels import ACT_LRELU, ACT_NONE
 
-PS_FUSED = os.environ.get("MTD_NO_PS_FUSE", "0") != "1"     # r_up{l}: conv1x1 + PixelShuffle as four strided-output classes in one grid
+PS_FUSED = _options.lab("MTD_NO_PS_FUSE", "0") != "1"     # r_up{l}: conv1x1 + PixelShuffle as four strided-output classes in one grid
 CH = [64, 128, 256, 512, 512, 512]                    # trunk channels per level (out_channels = 64)
 DEC = [(1024, 512), (1024, 512), (1024, 256), (512, 128), (256, 64), (128, 1)]   # (cat channels, out) per decoder level
 RUP = [(512, 512), (512, 512), (512, 512), (256, 256), (128, 128), (64, 64)]      # r_up{l}: cin -> cout' (conv to 4*cout')

@@ -4,6 +4,7 @@ Same 9 positional arguments and the same returned dict {meter name: round(global
 of one iteration is `train_iteration` (D step with PCGrad, then G step); the reference performs ~25 host
 synchronisations per iteration (16 `.item()` in MetricLogger.update plus 9 `if dot < 0` in PCGrad), this
 one gathers the 17 logged scalars into one device vector and copies it to the host once per iteration."""
+from . import _options
 import os
 
 import torch
@@ -84,7 +85,7 @@ def freeze_long_lived_objects(force=False):
     This changes PROCESS-WIDE interpreter state, so a library entry point does it only when asked: `MTD_GC_FREEZE=1` in the
     environment (train_MTD_GAN_Ours then calls it before its first iteration) or an explicit call with force=True (bench.py's
     workloads do, and say so in their line).  Once per process."""
-    if _gc_frozen[0] or not (force or os.environ.get("MTD_GC_FREEZE", "0") == "1"):
+    if _gc_frozen[0] or not (force or _options.product("MTD_GC_FREEZE", "0") == "1"):
         return
     import gc
     gc.collect()

@@ -2,6 +2,7 @@
 the current HIP stream; every arithmetic op below runs in libmtdgan_hip.so.  NHWC activations are torch
 tensors of shape (B, H, W, C) whose last-dim stride is 1 and whose pixel stride (`ld`) may exceed C
 (channel slices of a concat buffer)."""
+from . import _options
 import ctypes as C
 import os
 
@@ -29,6 +30,22 @@ def _view_buffer(ident, shape, device):
         buf = torch.empty(shape, dtype=torch.float32, device=device)
         _view_bufs[ident] = buf
     return buf
+
+
+def release_views(params):
+    """Free the derived-view buffers (packed / Winograd-transformed / transposed weights) of these parameters -- for a caller
+    that drops a model and keeps the process: the buffers are keyed by the weights' addresses and would otherwise stay for
+    the life of the process.  Call it only when nothing will launch on the model again (a recorded launch list of that model
+    carries the buffers' addresses)."""
+    spans = []
+    for p in params:
+        st = p.untyped_storage()
+        spans.append((st.data_ptr(), st.data_ptr() + st.nbytes()))
+    dead = [i for i in _view_bufs if any(lo <= i[0] < hi for lo, hi in spans)]
+    for i in dead:
+        del _view_bufs[i]
+    weights_changed(None)
+    return len(dead)
 
 
 def _remember(cache, ident, key, value):
@@ -103,18 +120,18 @@ def packed_weight_view(w, N, Cc, w_sn, w_sc):
 # MTD_WINOGRAD_MIN_HW / _MIN_C / _MIN_N bound the layers that take it.  (Measured: even the 4 x 4 and 2 x 2 maps of the
 # deepest levels gain -- 942 against 926 img/s with them -- although the implicit GEMM's whole-tile tap skipping already drops
 # most of their padding taps: 512 x 512 on 4 x 4 maps 54 -> 35 us.)
-WINOGRAD = os.environ.get("MTD_WINOGRAD", "1") != "0"
-WINO_MIN_HW = int(os.environ.get("MTD_WINOGRAD_MIN_HW", "2"))
-WINO_MIN_C = int(os.environ.get("MTD_WINOGRAD_MIN_C", "64"))
-WINO_MIN_N = int(os.environ.get("MTD_WINOGRAD_MIN_N", "64"))
+WINOGRAD = _options.lab("MTD_WINOGRAD", "1") != "0"
+WINO_MIN_HW = int(_options.lab("MTD_WINOGRAD_MIN_HW", "2"))
+WINO_MIN_C = int(_options.lab("MTD_WINOGRAD_MIN_C", "64"))
+WINO_MIN_N = int(_options.lab("MTD_WINOGRAD_MIN_N", "64"))
 # The generator's 32 -> 32 layers on the F(2x4) kernel's 32-channel form (NB = 1, two K steps per launch tile): on maps of at
 # least this side.  Default 128 = whole-slice inference only (512 x 512: 29.36 -> 27.99 ms per slice); on the 64 x 64 training
 # patches the halo-tile kernel is as fast (generator leg 5.44 -> 5.39 ms with 64 here) and carries the fused epilogues
 # (out2, block tail) the Winograd kernel does not have.  0 switches the form off.
-WINO_C32_MIN_HW = int(os.environ.get("MTD_WINO_C32_MIN_HW", "128"))
+WINO_C32_MIN_HW = int(_options.lab("MTD_WINO_C32_MIN_HW", "128"))
 # ... and the FORWARD pass of the generator's plain encoder / decoder layers on the training patches too (conv(..., wino32=True):
 # 23 us per layer against the halo-tile kernel's 28; generator leg 5.45 -> 5.33 ms).  The backward pass keeps its fused kernels.
-WINO_C32_FWD = os.environ.get("MTD_WINO_C32_FWD", "1") != "0"
+WINO_C32_FWD = _options.lab("MTD_WINO_C32_FWD", "1") != "0"
 _kmap_cache = {}
 
 
@@ -331,8 +348,8 @@ def igemm_override(cfg, splitk=1):
     _igemm_ws_cache.clear()
 
 
-if os.environ.get("MTD_IGEMM_CFG"):        # diagnostic switch, e.g. MTD_IGEMM_CFG=9: persistent kernel for the 32-channel 3x3 layers
-    igemm_override(int(os.environ["MTD_IGEMM_CFG"]), 1)
+if _options.lab("MTD_IGEMM_CFG", ""):        # diagnostic switch, e.g. MTD_IGEMM_CFG=9: persistent kernel for the 32-channel 3x3 layers
+    igemm_override(int(_options.lab("MTD_IGEMM_CFG", "0")), 1)
 
 _raw_stream = torch._C._cuda_getCurrentRawStream       # (device index) -> hipStream_t as int; no Python Stream objects
 _cur_device = torch._C._cuda_getDevice
@@ -342,7 +359,7 @@ def stream_ptr():
     return C.c_void_p(_raw_stream(_cur_device()))
 
 
-DEFER_WGRADS = os.environ.get("MTD_NO_DEFERRED_WGRAD", "0") != "1"     # generator backward: slab sums of all layers in two launches
+DEFER_WGRADS = _options.lab("MTD_NO_DEFERRED_WGRAD", "0") != "1"     # generator backward: slab sums of all layers in two launches
 RECORDING = None    # the LaunchList being recorded, if any
 CAPTURE_TAG = 0     # bumped while a hipGraph is captured so that graph-pool scratch never mixes with eager scratch
 
@@ -360,7 +377,7 @@ def workspace(nbytes, device):
 
 # Split-K launches may finish inside the kernel (mtd_conv_args.tile_ctr: the last slice to arrive at a tile sums the slabs).
 # Same bits as the separate epilogue launch; measured neutral on the full step (42.54 vs 42.42 ms), so off unless asked for.
-SPLITK_FIN = os.environ.get("MTD_SPLITK_FIN", "0") == "1"
+SPLITK_FIN = _options.lab("MTD_SPLITK_FIN", "0") == "1"
 TILE_CTRS = 4096        # arrival counters per set of a split-K launch (mtd_conv_args.tile_ctr); four sets per buffer
 _tile_ctrs = {}
 
@@ -511,7 +528,7 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, **kw):
 def conv_relu_add_ok(x, w, geom, N, Cc, w_sn, w_sc, out, **kw):
     """Would conv(..., act=ACT_RELU_ADD) -- relu(conv + bias) + add1 + add2, the adds AFTER the activation -- be taken for these
     arguments (mtd_conv_relu_add_ok)?  Nothing is launched or counted."""
-    if os.environ.get("MTD_NO_RELU_ADD", "0") == "1" or (Cc % 32) or (N % 32):
+    if _options.lab("MTD_NO_RELU_ADD", "0") == "1" or (Cc % 32) or (N % 32):
         return False
     kw = dict(kw, act=ACT_RELU_ADD)
     if winograd_takes(geom, N, Cc, kw):        # (the 32-channel F(2x4) form carries this epilogue: conv_winograd.hip)
@@ -522,7 +539,7 @@ def conv_relu_add_ok(x, w, geom, N, Cc, w_sn, w_sc, out, **kw):
     return bool(_lib.lib().mtd_conv_relu_add_ok(C.byref(a)))
 
 
-MULTI_CONV = os.environ.get("MTD_NO_MULTI_CONV", "0") != "1"
+MULTI_CONV = _options.lab("MTD_NO_MULTI_CONV", "0") != "1"
 
 
 def conv_multi(calls):
@@ -549,7 +566,7 @@ def conv_multi(calls):
     check(L.mtd_conv_igemm_multi(arr, len(calls), stream_ptr()), "mtd_conv_igemm_multi")
 
 
-FUSE_ACT_GRAD = os.environ.get("MTD_NO_FUSED_ACT_GRAD", "0") != "1"
+FUSE_ACT_GRAD = _options.lab("MTD_NO_FUSED_ACT_GRAD", "0") != "1"
 
 
 def fuses_masked_cotangent(B, H, W, Cc, N):
@@ -609,7 +626,7 @@ def flush_wgrads(defer):
 # Lab switch, off: the block conv's weight-gradient launch carries the row transform of the same cotangent (workgroups of
 # both kinds in one grid, mtd_conv_wgrad_slabs_rfft).  Correct (bit-identical, tested) but slower: the fused launch takes
 # 54 us against 29.3 + 8.7 us for the two -- the row-transform waves share SIMDs with the MFMA waves on half of the CUs.
-FUSE_WGRAD_ROWS = os.environ.get("MTD_FUSED_WGRAD_ROWS", "0") == "1"
+FUSE_WGRAD_ROWS = _options.lab("MTD_FUSED_WGRAD_ROWS", "0") == "1"
 
 
 def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumulate_bias=None, defer=None, rows=None):
@@ -660,7 +677,7 @@ def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumula
     check(L.mtd_conv_wgrad(C.byref(a), stream_ptr()), "mtd_conv_wgrad")
 
 
-WGRAD_SUM = os.environ.get("MTD_WGRAD_SUM", "1") == "1"      # second cotangent added inside the pair launch (0: by kernels.add)
+WGRAD_SUM = _options.lab("MTD_WGRAD_SUM", "1") == "1"      # second cotangent added inside the pair launch (0: by kernels.add)
 
 
 def wgrad_pair(p, q, geom, b_first, N, Cc, dw1, dw2, w_sn, w_sc, db=None, accumulate_bias=True, p_add=None):
@@ -704,7 +721,7 @@ def mtd_geom_with_batch(geom, B):
     return g
 
 
-FUSE_C32_BWD = os.environ.get("MTD_NO_FUSED_C32_BWD", "0") != "1"
+FUSE_C32_BWD = _options.lab("MTD_NO_FUSED_C32_BWD", "0") != "1"
 
 
 def conv_wgrad_fusable(conv_call, wgrad_call):
@@ -780,7 +797,7 @@ def rfft_rows(x, col_weight):
     return R
 
 
-SPECMIX4 = os.environ.get("MTD_SPECMIX4", "1") != "0"      # four-wave column / mix kernels (csrc/resfft4.hip); 0 = the one-wave forms
+SPECMIX4 = _options.lab("MTD_SPECMIX4", "1") != "0"      # four-wave column / mix kernels (csrc/resfft4.hip); 0 = the one-wave forms
 
 
 def spec_mix_fwd(R, w2t, b2, save):
@@ -839,7 +856,7 @@ def irfft_rows(T, out, add1=None, add2=None, mask=None):
 
 
 CH32 = 32
-BLOCK_TAIL = os.environ.get("MTD_NO_BLOCK_TAIL", "0") != "1"      # conv3x3 + inverse row transform + residual in one launch
+BLOCK_TAIL = _options.lab("MTD_NO_BLOCK_TAIL", "0") != "1"      # conv3x3 + inverse row transform + residual in one launch
 
 
 def block_tail_ok(x, w, geom, img, bias):
@@ -1009,6 +1026,22 @@ def zero_multi(tensors):
     check(_lib.lib().mtd_zero_multi(tab.data_ptr(), C.cast(host, C.c_void_p), len(structs), stream_ptr()), "mtd_zero_multi")
 
 
+def checksum_multi(tensors):
+    """Order-independent integer checksums (sum of the 32-bit patterns modulo 2^64) of contiguous fp32 tensors, one launch;
+    returns an int64 device tensor with one entry per tensor."""
+    structs = []
+    for t in tensors:
+        if not t.is_contiguous() or t.dtype != torch.float32:
+            raise ValueError("checksum_multi: contiguous fp32 tensors only")
+        d = _lib.ZeroDesc()
+        d.p, d.n = t.data_ptr(), t.numel()
+        structs.append(d)
+    tab, host = device_table(structs, tensors[0].device)
+    out = torch.empty(len(structs), dtype=torch.int64, device=tensors[0].device)
+    check(_lib.lib().mtd_checksum_multi(tab.data_ptr(), C.cast(host, C.c_void_p), len(structs), out.data_ptr(), stream_ptr()), "mtd_checksum_multi")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- descriptor tables
 _desc_cache = {}
 
@@ -1024,22 +1057,25 @@ class _Arena:
         self.dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self.ofs = 0
         self.recycle = recycle
+        self.retired = []       # full chunks of a non-recycling arena: graphs / lists still read their tables
 
     def take(self, nbytes):
         n = (nbytes + 255) & ~255
         if self.ofs + n > self.host.numel():
             if not self.recycle:
-                # tables of captured graphs / recorded lists are never recycled: start a new chunk (the old one stays alive
-                # through the views its tables are, which the graphs' / lists' owners hold).  Not while a capture is running.
+                # tables of captured graphs / recorded lists are never recycled: start a new chunk; the full one is kept
+                # (self.retired) for the life of the process -- a hipGraph holds only addresses.  Not while a capture is running.
                 if torch.cuda.is_current_stream_capturing():
                     raise RuntimeError("descriptor arena of the captured graph exhausted")
                 size = max(self.host.numel(), 2 * n)
+                self.retired.append((self.host, self.dev))
                 self.host = torch.empty(size, dtype=torch.uint8).pin_memory()
                 self.dev = torch.empty(size, dtype=torch.uint8, device=self.dev.device)
                 self.ofs = 0
             else:
                 torch.cuda.synchronize()             # every kernel that reads an old table has finished
-                _desc_cache.clear()
+                for k in [k for k in _desc_cache if not k[1]]:      # (static tables live in the other arena and stay)
+                    del _desc_cache[k]
                 self.ofs = 0
         o = self.ofs
         self.ofs += n
@@ -1288,7 +1324,7 @@ def adamw_multi(params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps,
 
 
 # ---------------------------------------------------------------------------------------------- side stream
-SIDE_STREAMS = os.environ.get("MTD_NO_SIDE_STREAMS", "0") != "1"
+SIDE_STREAMS = _options.lab("MTD_NO_SIDE_STREAMS", "0") != "1"
 
 
 def set_concurrency(on):
@@ -1296,7 +1332,7 @@ def set_concurrency(on):
     launch's duration includes the time it shares the chip with other kernels).  Synchronises."""
     global SIDE_STREAMS
     torch.cuda.synchronize()
-    on = bool(on) and os.environ.get("MTD_NO_SIDE_STREAMS", "0") != "1"
+    on = bool(on) and _options.lab("MTD_NO_SIDE_STREAMS", "0") != "1"
     SIDE_STREAMS = on
     for s in _side.values():
         s.enabled = on
@@ -1351,6 +1387,7 @@ class LaunchList:
         self.main = None        # the stream that was current while recording: replay() must run under it
         self.slots = []         # HostScalars that recorded launches read (the PCGrad order, AdamW's step scalars)
         self.sites = {}         # id(slot) -> [(op index, argument index)] of the launches that take its address
+        self.result = None      # what the recorded function returned (set once it has run to completion)
 
     def add_call(self, fn, args):
         cur = torch.cuda.current_stream()
@@ -1392,6 +1429,7 @@ class LaunchList:
             _lib.RECORDER = None
             RECORDING = None
         torch.cuda.synchronize()
+        self.result = out             # fn ran to completion; what follows only inspects the list (RecordedTrainStep tells the two apart)
         self._find_slot_sites()
         return out
 

@@ -5,6 +5,7 @@ the gradients, so each per-task shared-gradient vector is averaged across ranks 
 three 114 MB all-reduces per iteration, each enqueued on a side stream as soon as that task's backward
 has been issued so that it overlaps the next task's backward kernels (the last task ships its finished
 slices while it still runs: train_step.DStepTape.run_pcgrad); rank 0's shuffle order is broadcast.  On CPU the same code runs on the gloo backend (tests)."""
+from . import _options
 import torch
 import torch.distributed as dist
 
@@ -16,7 +17,7 @@ class DataParallelSync:
         self.world = dist.get_world_size()
         # MTD_FORCE_DP=1: run every collective even in a one-rank group (single-GPU smoke test of the N > 1 code path)
         import os
-        self.force = os.environ.get("MTD_FORCE_DP", "0") == "1"
+        self.force = _options.product("MTD_FORCE_DP", "0") == "1"
         self.device = device
         self.cuda = device is not None and torch.device(device).type == "cuda"
         # RCCL averages inside the collective (ReduceOp.AVG); gloo -- CPU tests, and the two-ranks-on-one-GPU rehearsal of
@@ -120,6 +121,37 @@ class DataParallelSync:
             from . import kernels as K
             K.order_streams(torch.cuda.current_stream(), self.side)
         self._pending = False
+
+    def all_agree(self, ok):
+        """One MIN all-reduce of a flag: True only if EVERY rank passed True.  Ranks decide together whether the recorded launch
+        list of an iteration is used (train_step.recorded_iteration): a rank whose recording failed must not leave the others
+        replaying while it runs eagerly with a different schedule of stream hand-offs.  Synchronises the host once."""
+        if self.world == 1 and not self.force:
+            return bool(ok)
+        self.wait()
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if self.cuda else None)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def replicas_agree(self, tensors):
+        """Do all ranks hold bit-identical copies of `tensors` (contiguous fp32)?  The invariant of synchronous data
+        parallelism -- the reference gets it from nn.DataParallel's single set of weights (train.py:93-98) -- and what any
+        missed ordering edge around a collective would break first: a rank that reads a gradient buffer before its all-reduce
+        has landed updates with its own shard's gradient.  Integer checksums (mtd_checksum_multi) compared by a MIN and a MAX
+        all-reduce; synchronises the host once."""
+        if self.world == 1 and not self.force:
+            return True
+        tensors = [t.detach() for t in tensors]
+        if self.cuda:
+            from . import kernels as K
+            sums = K.checksum_multi(tensors)
+        else:
+            sums = torch.stack([t.reshape(-1).view(torch.int32).to(torch.int64).sum() for t in tensors])
+        self.wait()
+        lo, hi = sums.clone(), sums.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        return bool(torch.equal(lo, hi))
 
     def all_reduce_avg_list(self, tensors):
         """Bucket a list of tensors into one flat buffer, average, scatter back."""

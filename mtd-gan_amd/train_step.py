@@ -10,6 +10,7 @@ one autograd node: G forward, one D pass without the restoration decoder, loss k
 replays D for the input gradient only (the reference's D weight gradients in the G step are discarded by
 the next zero_grad) and then the generator.  Nothing here synchronises with the host.
 """
+from . import _options
 import os
 import random
 import re
@@ -22,16 +23,38 @@ from . import kernels as K
 
 NPIX = 64 * 64
 # the first pass into a task vector overwrites its spectral-norm weight gradients (MTD_FIRST_WRITE=0: zero fill + accumulate)
-FIRST_WRITE = os.environ.get("MTD_FIRST_WRITE", "1") == "1"
-POISON = os.environ.get("MTD_POISON_TASK_VECTORS", "0") == "1"
+FIRST_WRITE = _options.lab("MTD_FIRST_WRITE", "1") == "1"
+POISON = _options.lab("MTD_POISON_TASK_VECTORS", "0") == "1"
 _TRUNK_SN_WEIGHT = re.compile(r"(?:conv\d\d|down\d|bconv\d)\.weight_orig$")
 re_dec = {"s": re.compile(r"s_dconv\d\d\.weight_orig$"), "r": re.compile(r"r_dconv\d\d\.weight_orig$")}
 # data parallelism: ship finished gradient slices of the last task pass while it runs (MTD_DP_EARLY_SHIP=0: after the pass)
-EARLY_SHIP = os.environ.get("MTD_DP_EARLY_SHIP", "1") == "1"
+EARLY_SHIP = _options.lab("MTD_DP_EARLY_SHIP", "1") == "1"
 
 
 def _nhwc1(t):
     return t.contiguous().reshape(t.shape[0], 64, 64, 1)
+
+
+def _dp_avg(dp, flat, after=()):
+    """dp.all_reduce_avg(flat, after=streams) -- the hook contract since round 4 (parallel.DataParallelSync): the collective
+    waits for `after`, the main stream does not.  A hook object with the older one-argument form still works: the streams in
+    `after` are joined into the current stream first, which is what that form assumed."""
+    takes = getattr(dp, "_mtd_takes_after", None)
+    if takes is None:
+        import inspect
+        try:
+            takes = "after" in inspect.signature(dp.all_reduce_avg).parameters
+        except (TypeError, ValueError):
+            takes = False
+        try:
+            dp._mtd_takes_after = takes
+        except AttributeError:
+            pass
+    if takes:
+        return dp.all_reduce_avg(flat, after=after)
+    for st in after:
+        K.order_streams(torch.cuda.current_stream(), st)
+    return dp.all_reduce_avg(flat)
 
 
 # ================================================================================================ D step
@@ -168,7 +191,7 @@ class DStepTape:
         consistency12(consistency34(), ship if dp is not None and EARLY_SHIP else None)  # task 2
         if shipped["tail"]:
             if dp is not None:
-                dp.all_reduce_avg(S[2, :tail_ofs], after=self._side_of(dev))
+                _dp_avg(dp, S[2, :tail_ofs], after=self._side_of(dev))
         else:
             self._sync_task(dp, S, 2)
         K.side_stream(dev).join()              # weight gradients / spectral-norm corrections ran on the side stream
@@ -228,7 +251,7 @@ class DStepTape:
         # while this task's last weight gradients run (round 3 joined the side stream here: +1.2 ms per iteration at N = 1
         # with every collective live, profiles/r4_forced_dp_*.json).
         if dp is not None:
-            dp.all_reduce_avg(S[i], after=cls._side_of(S.device))   # overlaps with the next task's backward (separate stream)
+            _dp_avg(dp, S[i], after=cls._side_of(S.device))   # overlaps with the next task's backward (separate stream)
 
 
 _orders_slots = {}
@@ -469,8 +492,18 @@ class GraphedTrainStep:
 
 
 # ================================================================================================ launch-list replay
-LIST_MODE = os.environ.get("MTD_LIST", "1") != "0"      # engine.train_MTD_GAN_Ours / bench: recorded launch list after two eager iterations
-LIST_UNDER_DP = os.environ.get("MTD_LIST_DP", "1") != "0"   # ... also in a multi-rank group (0: data-parallel iterations stay eager)
+LIST_MODE = _options.product("MTD_LIST", "1") != "0"      # engine.train_MTD_GAN_Ours / bench: recorded launch list after two eager iterations
+LIST_UNDER_DP = _options.product("MTD_LIST_DP", "1") != "0"   # ... also in a multi-rank group (0: data-parallel iterations stay eager)
+
+
+class RecordingUnusable(RuntimeError):
+    """The recorded iteration RAN TO COMPLETION (both optimizer steps applied) but the list it left cannot be replayed.
+    Carries the iteration's (names, vals) so that the caller returns them and stays eager -- re-running the batch would
+    apply it twice."""
+
+    def __init__(self, why, names, vals):
+        super().__init__(why)
+        self.names, self.vals = names, vals
 
 
 class RecordedTrainStep:
@@ -499,11 +532,23 @@ class RecordedTrainStep:
         for _ in range(warmup):                                    # optimizer state, workspaces and derived weight views exist
             self.names, self.vals = engine.train_iteration(model, self.x, self.y, optimizer_G, optimizer_D, method_D, dp)
         self.list = K.LaunchList()
-        self.names, self.vals = self.list.record(
-            lambda: engine.train_iteration(model, self.x, self.y, optimizer_G, optimizer_D, method_D, dp), dev, repack=False)
-        self.slot = orders_slot(dev)
-        if all(self.slot is not sl for sl in self.list.slots):
-            raise RuntimeError("RecordedTrainStep: the recorded iteration did not read the PCGrad order slot")
+        try:
+            self.names, self.vals = self.list.record(
+                lambda: engine.train_iteration(model, self.x, self.y, optimizer_G, optimizer_D, method_D, dp), dev, repack=False)
+        except RuntimeError as e:
+            if self.list.result is None:       # the iteration itself failed: nothing to salvage
+                raise
+            raise RecordingUnusable(str(e), *self.list.result) from e
+        try:
+            self.slot = orders_slot(dev)
+            if all(self.slot is not sl for sl in self.list.slots):
+                raise RuntimeError("RecordedTrainStep: the recorded iteration did not read the PCGrad order slot")
+        except RuntimeError as e:              # the iteration itself is done: do not let the caller run the batch again
+            raise RecordingUnusable(str(e), self.names, self.vals) from e
+        # the recorded AdamW launches hold raw pointers into the optimizers' moment tensors: keep those tensors alive with the
+        # list, and let a replaced optimizer state (load_state_dict) retire it through the signature (advisor, round 4)
+        self.moments = [t for opt in (optimizer_D, optimizer_G) for st in opt.state.values() for t in (st.get("exp_avg"), st.get("exp_avg_sq"))
+                        if torch.is_tensor(t)]
         self.signature = self._signature(model, optimizer_G, optimizer_D, method_D, dp)
         self.grads = [(p, p.grad) for p in list(model.Discriminator.parameters()) + list(model.Generator.parameters())]
         self.iterations = warmup + 1
@@ -519,7 +564,9 @@ class RecordedTrainStep:
                 tuple(b.data_ptr() for b in D.buffers()), D.training, G.training, D.c_drop.p,
                 tuple(p.requires_grad for p in model.parameters()), id(oG), id(oD), id(wm), id(dp),
                 tuple((g["betas"], g["eps"]) for g in oD.param_groups + oG.param_groups),
-                tuple(t._version for t in model.parameters()), tuple(t._version for t in model.buffers()))
+                tuple(t._version for t in model.parameters()), tuple(t._version for t in model.buffers()),
+                tuple(t.data_ptr() for opt in (oD, oG) for st in opt.state.values() for t in (st.get("exp_avg"), st.get("exp_avg_sq"))
+                      if torch.is_tensor(t)))
 
     @staticmethod
     def usable(model, optimizer_G, optimizer_D, method_D, x, y):
@@ -557,17 +604,42 @@ class RecordedTrainStep:
         return self.names, self.vals
 
 
+REPLICA_CHECKS = 3      # data-parallel replays whose result is compared across ranks (parallel.replicas_agree) before the list is trusted
+
+
+def _retire_list(model, optimizer_G, optimizer_D, why):
+    """Stay eager for good with these objects, and say why once."""
+    import warnings
+    model._mtd_recorded = -(1 << 30)
+    model._mtd_list_error = why
+    optimizer_G.graph_mode = optimizer_D.graph_mode = False
+    warnings.warn("mtd-gan_amd: the recorded launch list is not used (iterations stay eager): " + why, RuntimeWarning, stacklevel=3)
+
+
 def recorded_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp=None):
     """engine.train_iteration through a RecordedTrainStep where one applies: the first two iterations of a configuration run
     eagerly, the third is recorded while it runs, later ones replay.  The step object lives on the model (it is tied to the
-    model's parameter storage).  Returns (names, device tensor of the logged values) like engine.train_iteration."""
+    model's parameter storage).  Returns (names, device tensor of the logged values) like engine.train_iteration.
+
+    A recording that cannot be replayed never costs an iteration or a restart: the recorded iteration has run, its values are
+    returned, and every later iteration is eager (`model._mtd_list_error` says why; bench.py reports it as `graph_error`).
+    Under data parallelism the ranks decide that TOGETHER (one all-reduce of a flag), and the first REPLICA_CHECKS replays are
+    followed by a comparison of the replicas' parameters across ranks: a list whose collectives were mis-ordered on real
+    RCCL would show there, and is retired with rank 0's weights re-broadcast -- loudly, not silently."""
     from . import engine
     if not RecordedTrainStep.usable(model, optimizer_G, optimizer_D, method_D, x, y) or (dp is not None and not LIST_UNDER_DP):
         return engine.train_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp)
     st = getattr(model, "_mtd_recorded", None)
     if isinstance(st, RecordedTrainStep):
         if st.matches(model, optimizer_G, optimizer_D, method_D, x, y, dp):
-            return st.step(x, y)
+            out = st.step(x, y)
+            if dp is not None and st.replica_checks_left > 0:
+                st.replica_checks_left -= 1
+                if not dp.replicas_agree(list(model.parameters()) + list(model.buffers())):
+                    dp.broadcast_module(model)
+                    _retire_list(model, optimizer_G, optimizer_D, "data-parallel replicas differed after a replayed iteration "
+                                 "(rank 0's weights were re-broadcast)")
+            return out
         if x.shape != st.x.shape:                                   # e.g. the last, smaller batch of an epoch: eager, keep the list
             return engine.train_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp)
         model._mtd_recorded = st = None                             # different objects / storage: start over
@@ -575,16 +647,27 @@ def recorded_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp=None)
     key = (tuple(x.shape), id(optimizer_G), id(optimizer_D))
     if getattr(model, "_mtd_recorded_key", None) != key:
         model._mtd_recorded_key, seen = key, 0
+    if seen < 0:                                                    # retired
+        return engine.train_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp)
     if seen < 2:
         model._mtd_recorded = seen + 1
         return engine.train_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp)
+    why = None
     try:
         st = RecordedTrainStep(model, optimizer_G, optimizer_D, method_D, x, y, dp, warmup=0)
-    except Exception:
-        model._mtd_recorded = -(1 << 30)                            # recording failed: stay eager for good, and say why once
-        raise
+        out = (st.names, st.vals)
+    except RecordingUnusable as e:                                  # the iteration ran; only the list is unusable
+        st, out, why = None, (e.names, e.vals), str(e)
+    # (an exception from the iteration itself propagates: nothing was completed that could be returned)
+    if dp is not None and not dp.all_agree(st is not None) and st is not None:
+        st, why = None, "another rank could not record its iteration"
+    if st is None:
+        _retire_list(model, optimizer_G, optimizer_D, why)
+        return out
+    st.replica_checks_left = REPLICA_CHECKS if dp is not None else 0
     model._mtd_recorded = st
-    return st.names, st.vals
+    model._mtd_list_error = None
+    return out
 
 
 # ================================================================================================ bench workload
@@ -613,7 +696,7 @@ class FullStepWorkload:
         self.oD = FusedAdamW(self.model.Discriminator.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
         self.oG = FusedAdamW(self.model.Generator.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
         import os
-        force_dp = os.environ.get("MTD_FORCE_DP", "0") == "1"
+        force_dp = _options.product("MTD_FORCE_DP", "0") == "1"
         self.dp = parallel.DataParallelSync(dev) if (world > 1 or force_dp) else None
         if self.dp is not None:
             self.dp.broadcast_module(self.model)
@@ -624,7 +707,7 @@ class FullStepWorkload:
         import os
         # hipGraph replay is opt-in (MTD_GRAPH=1): a captured step is slower than the launches it replaces, because ROCm 7.2
         # serialises the captured multi-stream sections; the default is the recorded launch list (MTD_LIST=0: eager)
-        if world == 1 and os.environ.get("MTD_GRAPH", "0") == "1":
+        if world == 1 and _options.product("MTD_GRAPH", "0") == "1":
             try:
                 self.graphed = GraphedTrainStep(self.model, self.oG, self.oD, self.wm, self.x, self.y)
             except Exception as e:                      # capture is an optimisation: report and run eagerly
@@ -686,4 +769,4 @@ class FullStepWorkload:
                 "launches_per_step": (sum(1 for f, _a in self.recorded.list.ops if getattr(f, "__name__", "").startswith("mtd_"))
                                       if isinstance(getattr(self, "recorded", None), RecordedTrainStep) else None),
                 "list_ops_per_step": len(self.recorded.list.ops) if isinstance(getattr(self, "recorded", None), RecordedTrainStep) else None,
-                "graph_error": getattr(self, "graph_error", None), "table_stats": dict(K.STATS)}
+                "graph_error": getattr(self, "graph_error", None) or getattr(self.model, "_mtd_list_error", None), "table_stats": dict(K.STATS)}

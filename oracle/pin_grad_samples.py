@@ -10,6 +10,11 @@ Writes
                                            the merged gradient it writes into .grad (:438-439) and the task-specific
                                            gradients (:443), PER TENSOR: 6 sampled elements, the tensor's max-abs, and the
                                            error of the reference's own fp32 arithmetic against float64 on that tensor;
+  tests/golden/g_grad_samples_b32.json     the G step of the same iteration (round 5): engine.train_MTD_GAN_Ours at 32 patches
+                                           (engine.py:26-55), the generator's .grad after g_loss.backward() (engine.py:50-52;
+                                           networks.py:1994-2009) PER PARAMETER -- 6 sampled elements, max-abs, the fp32-vs-
+                                           float64 error, the tensor's norm -- evaluated from the state the G step starts in
+                                           (the discriminator AFTER its AdamW update and four power iterations);
   tests/golden/ablation_grad_samples.json  the same per parameter for the ten Ablation_* wrappers' d_loss / g_loss gradients
                                            (the run of ablation.json: B = 2, seeded fill, mask seed 41).
 Values: `ref32` = the REFERENCE's fp32 CPU result at the sampled positions; `f64` = the float64 evaluation by the oracle
@@ -127,6 +132,68 @@ def d_step_b32():
         json.dump(out, f)
 
 
+def g_step_b32():
+    """The generator gradients of the B = 32 golden iteration (tests/golden/step_seeded_b32.json).  The reference runs its own
+    engine loop; the state its g_loss starts from is captured at the call, and the oracle restatement evaluates the same G step
+    from that state in fp32 (must equal the reference) and in float64 (the arbiter of the GPU test)."""
+    import engine as ref_engine
+    z2 = json.load(open(os.path.join(GOLD, "step_seeded.json")))
+    z = json.load(open(os.path.join(GOLD, "step_seeded_b32.json")))
+    B = z["batch"]
+    full = {"Generator." + k: v for k, v in orc.seeded_fill(orc.g_param_shapes(), seed=z2["gfill"]).items()}
+    full.update({"Discriminator." + k: v for k, v in orc.seeded_fill(orc.d_state_shapes(), seed=z2["dfill"]).items()})
+    x, y = orc.synthetic_ldct(B, seed=z["data_seed"])
+    masks = mask_seq(5, B, seed=z["mask_seed"])
+    model = MTD_GAN_Method()
+    model.load_state_dict(full)
+    model.Discriminator.c_drop = RecDrop(0.3, inject=[k.clone() for k in masks])
+    wm = WeightMethods("pcgrad", n_tasks=3, device=torch.device("cpu"))
+    kw = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+    oD = torch.optim.AdamW([dict(params=model.Discriminator.parameters(), lr=z["lr"], **kw), dict(params=wm.parameters(), lr=0.025, **kw)])
+    oG = torch.optim.AdamW(model.Generator.parameters(), lr=z["lr"], **kw)
+    snap = {}
+    real_g_loss = model.g_loss
+
+    def g_loss(a, b):
+        snap["state"] = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        return real_g_loss(a, b)
+    model.g_loss = g_loss
+    random.seed(77)
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        stats = ref_engine.train_MTD_GAN_Ours(model, [dict(n_20=x, n_100=y)], oG, oD, torch.device("cpu"), 0, 1, B, wm)
+    print(f"  reference iteration at B={B}: {time.time() - t0:.1f}s, g_loss {stats['g_loss']}")
+    assert abs(stats["g_loss"] - z["stats"]["g_loss"]) <= 1e-6 * abs(z["stats"]["g_loss"])       # the run of step_seeded_b32.json
+    gnames = [n for n, _ in model.Generator.named_parameters()]
+    gref = {n: p.grad.detach().clone() for n, p in model.Generator.named_parameters()}      # (optimizer.step() leaves .grad in place)
+
+    def oracle(dtype):
+        st = {k: v.to(dtype).clone() for k, v in snap["state"].items()}
+        for n in gnames:
+            st["Generator." + n] = st["Generator." + n].requires_grad_(True)
+        total, _, _ = orc.g_loss(st, x.to(dtype), y.to(dtype), masks[4].to(dtype))
+        return float(total.detach()), dict(zip(gnames, torch.autograd.grad(total, [st["Generator." + n] for n in gnames])))
+    t0 = time.time()
+    tot32, g32 = oracle(torch.float32)
+    worst = max((g32[n] - gref[n]).abs().max().item() / (gref[n].abs().max().item() + 1e-30) for n in gnames)
+    print(f"  oracle fp32 generator gradients vs reference: worst rel {worst:.2e}, g_loss {tot32} ({time.time() - t0:.1f}s)")
+    assert worst < 1e-5 and abs(tot32 - stats["g_loss"]) <= 1e-5 * abs(tot32)
+    t0 = time.time()
+    tot64, g64 = oracle(torch.float64)
+    print(f"  oracle float64: {time.time() - t0:.1f}s, g_loss {tot64}")
+    out = dict(batch=B, samples=K, g_loss_f64=tot64, g_loss_ref32=stats["g_loss"], grads={})
+    for n in gnames:
+        e = entry(gref[n], g64[n])
+        e["norm_ref32"] = float(gref[n].norm())
+        e["norm_f64"] = float(g64[n].norm())
+        out["grads"]["Generator." + n] = e
+        assert abs(e["norm_ref32"] - z["g_grad_norms"]["Generator." + n]) <= 1e-4 * e["norm_ref32"] + 1e-12, n      # the committed norms are these
+    e = [v["err32"] for v in out["grads"].values()]
+    print(f"  fp32-vs-float64 error of the reference per generator tensor: median {sorted(e)[len(e) // 2]:.1e}, max {max(e):.1e}")
+    with open(os.path.join(GOLD, "g_grad_samples_b32.json"), "w") as f:
+        json.dump(out, f)
+
+
 def ablations():
     xa, ya = orc.synthetic_ldct(2, seed=1234)
     gold = {}
@@ -187,8 +254,13 @@ def ablations():
 
 if __name__ == "__main__":
     t0 = time.time()
+    if "--g-only" in sys.argv:
+        g_step_b32()
+        sys.exit(0)
     print("gradient elements of the ablation family")
     ablations()
     print("gradient elements of the D step at B = 32")
     d_step_b32()
+    print("gradient elements of the G step at B = 32")
+    g_step_b32()
     print(f"done in {time.time() - t0:.1f}s")

@@ -189,3 +189,42 @@ def test_ablation_path_needs_and_uses_the_dp_hook():
     for rank, refused, same in res:
         assert refused, rank          # no hook in a two-rank group: refused
         assert same, rank             # with the hook: the replicas stay identical (gradients averaged before each update)
+
+
+def _agree_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mtd_gan_amd.parallel import DataParallelSync
+    dp = DataParallelSync(device=None)
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.randn(1000, generator=g), torch.randn(33, generator=g)
+    res = dict(same=dp.replicas_agree([a, b]))
+    b2 = b.clone()
+    if rank == 1:
+        b2.view(torch.int32)[7] ^= 1                 # one bit on one rank
+    res["one_bit"] = dp.replicas_agree([a, b2])
+    res["all_ok"] = dp.all_agree(True)
+    res["one_failed"] = dp.all_agree(rank != 1)      # rank 1's recording "failed": every rank must hear of it
+    out.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_ranks_decide_together_and_replica_divergence_is_seen():
+    """Round 5 (the first N > 1 run must be boring): the flag all-reduce by which ranks agree to use / drop the recorded launch
+    list, and the comparison of replicas that guards the first data-parallel replays, at world size 2 over gloo."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get() for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        assert got[r] == dict(same=True, one_bit=False, all_ok=True, one_failed=False), (r, got[r])

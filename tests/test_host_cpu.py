@@ -189,3 +189,40 @@ def test_which_layers_take_the_32_channel_winograd_kernel():
     assert not K.winograd_takes(fwd(512), 32, 64, {}) and not K.winograd_takes(fwd(512), 64, 32, {})       # (C, N) = (32, 32) only
     assert not K.winograd_takes(K.geom_fwd(2, 130, 130, 3, 1, 1), 32, 32, {})                               # width not a multiple of 4
     assert not K.winograd_takes(K.geom_fwd(2, 512, 512, 4, 2, 1), 32, 32, {})                               # 3x3 stride 1 only
+
+
+def test_the_switchboard_is_frozen(built_lib, monkeypatch):
+    """Round 5: the shipped library reads NO environment variable (its lab switches exist only in an -DMTD_LAB build), run-time
+    options go through mtd_set_option by name, and the Python package reads the environment in one place (_options.py: eight
+    product switches; everything else only under MTD_LAB=1)."""
+    import subprocess
+    from mtd_gan_amd import _lib, _options
+    und = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und, [ln for ln in und.splitlines() if "getenv" in ln]
+    built_lib.mtd_lab_build.restype = ctypes.c_int
+    assert built_lib.mtd_lab_build() == 0
+    built_lib.mtd_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    built_lib.mtd_get_option.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+    v = ctypes.c_int(-7)
+    assert built_lib.mtd_get_option(b"c32f_safe_wait", ctypes.byref(v)) == 0 and v.value == 0
+    assert built_lib.mtd_set_option(b"c32f_safe_wait", 1) == 0
+    assert built_lib.mtd_get_option(b"c32f_safe_wait", ctypes.byref(v)) == 0 and v.value == 1
+    assert built_lib.mtd_set_option(b"c32f_safe_wait", 0) == 0
+    assert built_lib.mtd_set_option(b"wino_splitk", 3) == -1 and built_lib.mtd_get_option(None, ctypes.byref(v)) == -1
+    # the sources: getenv only inside mtd_lab_env, os.environ only in _options.py / _lib.py (MTD_LAB) / _build.py (HIPCC, MTD_LAB_BUILD)
+    csrc = os.path.join(ROOT, "mtd-gan_amd", "csrc")
+    for fn in os.listdir(csrc):
+        if fn.endswith((".hip", ".h")):
+            for ln in open(os.path.join(csrc, fn)).read().splitlines():
+                if re.search(r"(?<![a-z_])getenv\(", ln):
+                    assert fn == "common.h" and "mtd_lab_env" in ln, (fn, ln)
+    pkg = os.path.join(ROOT, "mtd-gan_amd")
+    for dp_, _d, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(".py") and fn not in ("_options.py", "_lib.py", "_build.py"):
+                assert "os.environ" not in open(os.path.join(dp_, fn)).read(), fn
+    assert len(_options.PRODUCT) <= 10
+    monkeypatch.setenv("MTD_WINOGRAD", "0")
+    assert _options.lab("MTD_WINOGRAD", "1") == ("0" if _options.LAB else "1")
+    with pytest.raises(AssertionError):
+        _options.product("MTD_WINOGRAD", "1")

@@ -910,10 +910,10 @@ def _pair_case(K, _lib, B, Bh, Ci, Co, H, W, k, pairs):
 @pytest.mark.parametrize("B,second", [(4, False), (12, True), (20, True), (40, True)])
 def test_fused_c32_backward_counted_waits_same_bits(hip_lib, monkeypatch, B, second):
     """conv_c32_bwd.hip hands a 32-pixel block's halo buffer to the next DMA after `s_waitcnt vmcnt(4 | 8)` -- counts that assume
-    the epilogue issues exactly that many vector-memory instructions after the DMAs.  MTD_C32F_SAFE_WAIT=1 waits for everything
+    the epilogue issues exactly that many vector-memory instructions after the DMAs.  mtd_set_option("c32f_safe_wait", 1) waits for everything
     instead; both must give the same bits, with and without the second output, on grids below 256 workgroups (B = 4: 64 tiles),
     with one and two live tiles per workgroup (B = 20), and with several iterations per workgroup (B = 40: 640 tiles)."""
-    from mtd_gan_amd import kernels as K
+    from mtd_gan_amd import _lib, kernels as K
     H = W = 64
     gen = torch.Generator().manual_seed(29)
     r = lambda *s: torch.randn(*s, generator=gen).cuda()
@@ -922,7 +922,7 @@ def test_fused_c32_backward_counted_waits_same_bits(hip_lib, monkeypatch, B, sec
     gf, gt = K.geom_fwd(B, H, W, 3, 1, 1), K.geom_dgrad_s1(B, H, W, 3, 1)
     res = []
     for safe in ("0", "1"):
-        monkeypatch.setenv("MTD_C32F_SAFE_WAIT", safe)
+        assert _lib.lib().mtd_set_option(b"c32f_safe_wait", int(safe)) == 0
         out, out2 = torch.zeros(B, H, W, 32, device="cuda"), torch.zeros(B, H, W, 32, device="cuda")
         dw, db = torch.zeros(32, 32, 3, 3, device="cuda"), torch.zeros(32, device="cuda")
         defer = K.DeferredWgrads()
@@ -931,5 +931,10 @@ def test_fused_c32_backward_counted_waits_same_bits(hip_lib, monkeypatch, B, sec
         K.flush_wgrads(defer)
         torch.cuda.synchronize()
         res.append((out, out2, dw, db))
+    assert _lib.lib().mtd_set_option(b"c32f_safe_wait", 0) == 0
+    import ctypes
+    v = ctypes.c_int(-1)
+    assert _lib.lib().mtd_get_option(b"c32f_safe_wait", ctypes.byref(v)) == 0 and v.value == 0
+    assert _lib.lib().mtd_set_option(b"no_such_option", 1) != 0
     for a, b in zip(*res):
         assert torch.equal(a, b)

@@ -187,6 +187,13 @@ def test_full_step_b32_matches_reference_vectors():
         pred = orc.generator_forward(full, x, "Generator.")
     assert abs(float(orc.psnr(pred.clip(0, 1), y)) - z["post_metrics"]["psnr"]) < 1e-4
     assert rel(pred[:, 0, ::16, ::16], torch.tensor(z["post_pred_sample"])) < 1e-5
+    # the G step's gradients: the oracle's per-parameter norms against the REFERENCE's own .grad norms (round 5:
+    # g_grad_samples_b32.json holds what engine.py:50-52 left in the generator's .grad)
+    gs = json.load(open(os.path.join(GOLD, "g_grad_samples_b32.json")))
+    assert len(gs["grads"]) == 128 and set(gs["grads"]) == set(res["g_grad_norms"])
+    for n, e in gs["grads"].items():
+        assert abs(res["g_grad_norms"][n] - e["norm_ref32"]) <= 1e-4 * e["norm_ref32"] + 1e-12, n
+        assert abs(z["g_grad_norms"][n] - e["norm_ref32"]) <= 1e-4 * e["norm_ref32"] + 1e-12, n
 
 
 def test_ablation_family_matches_reference_vectors():

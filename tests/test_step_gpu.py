@@ -213,6 +213,52 @@ def test_full_step_b32_vs_golden(hip_lib):
     _post_step_psnr(m, x, y, z["post_metrics"], z["post_pred_sample"], 16)
 
 
+def test_g_step_gradients_b32_vs_reference_samples(hip_lib):
+    """The generator's gradients of the G step at BASELINE size (engine.py:50-52: g_loss.backward() after the discriminator's
+    update; networks.py:1994-2009) against the reference's own: per parameter 6 sampled ELEMENTS and the tensor's norm
+    (tests/golden/g_grad_samples_b32.json, written by oracle/pin_grad_samples.py from a run of the reference's engine loop),
+    and the norms committed with the golden step (step_seeded_b32.json `g_grad_norms`).  Bound per tensor: max(1e-3, 2 x the
+    reference's own fp32-vs-float64 error on that tensor) of its max-abs, float64 as the arbiter."""
+    from mtd_gan_amd import engine
+    from mtd_gan_amd.module.weight_methods import WeightMethods
+    from mtd_gan_amd.optimizers import FusedAdamW
+    z = json.load(open(os.path.join(GOLD, "step_seeded_b32.json")))
+    gs = json.load(open(os.path.join(GOLD, "g_grad_samples_b32.json")))
+    m, full, masks, _ = _model(32)
+    m.Discriminator._inject_masks = [k.clone() for k in masks]
+    x, y = orc.synthetic_ldct(32, seed=z["data_seed"])
+    wm = WeightMethods("pcgrad", n_tasks=3, device=torch.device("cuda"))
+    kw = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+    oD = FusedAdamW([dict(params=m.Discriminator.parameters(), lr=z["lr"], **kw), dict(params=wm.parameters(), lr=0.025, **kw)])
+    oG = FusedAdamW(m.Generator.parameters(), lr=z["lr"], **kw)
+    random.seed(77)
+    stats = engine.train_MTD_GAN_Ours(m, [dict(n_20=x, n_100=y)], oG, oD, torch.device("cuda"), 0, 0, 32, wm)
+    assert abs(stats["g_loss"] - gs["g_loss_ref32"]) <= TOL * abs(gs["g_loss_ref32"])
+    names = [n for n, _ in m.Generator.named_parameters()]
+    assert ["Generator." + n for n in names] == list(gs["grads"].keys()) and len(names) == 128
+    bad, worst, nel = [], 0.0, 0
+    for n, p in m.Generator.named_parameters():
+        e = gs["grads"]["Generator." + n]
+        assert p.grad is not None, n                                  # (optimizer.step() leaves .grad in place, as torch.optim does)
+        g = p.grad.detach().reshape(-1).double().cpu()
+        bound = max(TOL, 2 * e["err32"])
+        for i, want in enumerate(e["f64"]):
+            idx = (i * 2654435761 + 12345) % g.numel()
+            err = abs(g[idx].item() - want) / (e["maxabs"] + 1e-30)
+            worst = max(worst, err / bound)
+            nel += 1
+            if err > bound:
+                bad.append((n, i, g[idx].item(), want, err, bound))
+        # the tensor's norm: against the float64 value, and against the norm committed with the golden step (the reference's fp32)
+        nb = max(TOL, 2 * abs(e["norm_ref32"] - e["norm_f64"]) / (e["norm_f64"] + 1e-30))
+        got = g.norm().item()
+        if abs(got - e["norm_f64"]) > nb * e["norm_f64"] or abs(got - z["g_grad_norms"]["Generator." + n]) > 2 * nb * e["norm_f64"]:
+            bad.append((n, "norm", got, e["norm_f64"], z["g_grad_norms"]["Generator." + n]))
+    assert not bad, (len(bad), bad[:8])
+    assert nel == 6 * 128
+    print(f"G-step gradients at B = 32: {nel} elements + 128 norms, worst error / bound {worst:.3f}")
+
+
 def test_config1_anchor_on_the_hip_path(hip_lib):
     """BASELINE configs[0] (`MTD_GAN_Method`, --batch-size 2 => 16 patches, 1 train step; a CPU run in the reference): the
     same run on the HIP path.  The reference's default-init state (seeds 2024) is rebuilt from the recorded draw tape and
@@ -802,10 +848,13 @@ def test_torch_adamw_drives_the_same_step(hip_lib):
 def test_data_parallel_path_on_one_rank_equals_plain_step(hip_lib, monkeypatch):
     """The N > 1 code path (parallel.DataParallelSync: per-task all-reduce on a side stream before the PCGrad
     projection, task-specific and generator gradients bucketed) with every collective forced in a one-rank RCCL
-    group (MTD_FORCE_DP=1): the average over one rank is the identity, so three iterations must give the plain
-    step's parameters bit for bit -- the stream hand-offs around the collectives are what is being tested."""
+    group (MTD_FORCE_DP=1): the average over one rank is the identity, so the iterations must give the plain
+    step's parameters bit for bit -- the stream hand-offs around the collectives are what is being tested.
+    Round 5: also THROUGH THE RECORDED LIST (two eager iterations, one recorded, five replayed -- collectives, the broadcast of the
+    projection order and the hand-offs re-issued by the list on a real RCCL communicator), with the replica comparison of the
+    first replays live, and dropout on."""
     import torch.distributed as dist
-    from mtd_gan_amd import engine, parallel
+    from mtd_gan_amd import engine, parallel, train_step as TS
     from mtd_gan_amd.arch.Ours.networks import MTD_GAN_Method
     from mtd_gan_amd.module.weight_methods import WeightMethods
     from mtd_gan_amd.optimizers import FusedAdamW
@@ -817,31 +866,124 @@ def test_data_parallel_path_on_one_rank_equals_plain_step(hip_lib, monkeypatch):
     if created:
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
-        x, y = orc.synthetic_ldct(4, seed=78)
-        x, y = x.cuda(), y.cuda()
-        results = []
-        for mode in ("plain", "dp"):
+        batches = [tuple(t.cuda() for t in orc.synthetic_ldct(4, seed=78 + i)) for i in range(8)]
+        results = {}
+        for mode in ("plain", "dp", "dp_list"):
             torch.manual_seed(6)
             m = MTD_GAN_Method().cuda().train()
-            m.Discriminator.c_drop.p = 0.0
             wm = WeightMethods("pcgrad", n_tasks=3, device=dev)
             oD = FusedAdamW(m.Discriminator.parameters(), lr=1e-4, weight_decay=5e-4)
             oG = FusedAdamW(m.Generator.parameters(), lr=1e-4, weight_decay=5e-4)
             dp = None
-            if mode == "dp":
+            if mode != "plain":
                 dp = parallel.DataParallelSync(dev)
                 assert dp.force and dp.world == 1
                 dp.broadcast_module(m)
                 wm.method.dp = dp
             random.seed(321)
-            for _ in range(3):
-                names, vals = engine.train_iteration(m, x, y, oG, oD, wm, dp)
+            torch.manual_seed(77)                       # the dropout draws
+            logged = []
+            for x, y in batches:
+                if mode == "dp_list":
+                    names, vals = TS.recorded_iteration(m, x, y, oG, oD, wm, dp)
+                else:
+                    names, vals = engine.train_iteration(m, x, y, oG, oD, wm, dp)
+                logged.append(vals.clone())
             torch.cuda.synchronize()
-            results.append(({k: v.clone() for k, v in m.state_dict().items()}, vals.clone()))
-        (sd_p, v_p), (sd_d, v_d) = results
-        assert torch.equal(v_p, v_d)
-        for k in sd_p:
-            assert torch.equal(sd_p[k], sd_d[k]), k
+            if mode == "dp_list":
+                st = m._mtd_recorded
+                assert isinstance(st, TS.RecordedTrainStep) and st.iterations == 6, getattr(m, "_mtd_list_error", None)     # recorded + five replays
+                assert st.replica_checks_left == 0 and m._mtd_list_error is None
+                assert any(getattr(f, "__name__", "") == "<lambda>" or "all_reduce" in repr(f) for f, _a in st.list.ops)   # collectives are in the list
+            results[mode] = ({k: v.clone() for k, v in m.state_dict().items()}, logged)
+        sd_p, log_p = results["plain"]
+        for mode in ("dp", "dp_list"):
+            sd, log = results[mode]
+            for i in range(len(batches)):
+                assert torch.equal(log[i], log_p[i]), (mode, i)
+            for k in sd_p:
+                assert torch.equal(sd_p[k], sd[k]), (mode, k)
+        # replicas_agree on this communicator: True on equal tensors (one rank), and the checksums see a single flipped bit
+        from mtd_gan_amd import kernels as K
+        t = torch.randn(1 << 20, device=dev)
+        c0 = K.checksum_multi([t, t[:1000].contiguous()])
+        t2 = t.clone()
+        t2.view(torch.int32)[12345] ^= 1
+        c1 = K.checksum_multi([t2, t2[:1000].contiguous()])
+        want = t.view(torch.int32).to(torch.int64).bitwise_and(0xFFFFFFFF).sum()
+        assert c0[0].item() == want.item() and c0[0].item() != c1[0].item() and c0[1].item() == c1[1].item()
+        assert parallel.DataParallelSync(dev).replicas_agree([t, t2])
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_unusable_recording_falls_back_to_eager_without_losing_the_iteration(hip_lib, monkeypatch):
+    """A recording that cannot be replayed (here: made to look as if the recorded iteration never read the PCGrad order slot)
+    must not raise out of the training loop, must not run the batch twice, and must leave every later iteration eager: five
+    iterations equal five plain eager ones bit for bit, with a warning that says why (`model._mtd_list_error`).  An optimizer
+    state that is REPLACED while a list is live (optimizer.load_state_dict) retires the list instead of letting the replays
+    write the old moment tensors (advisor, round 4)."""
+    import warnings
+    from mtd_gan_amd import engine, kernels as K, train_step as TS
+    from mtd_gan_amd.arch.Ours.networks import MTD_GAN_Method
+    from mtd_gan_amd.module.weight_methods import WeightMethods
+    from mtd_gan_amd.optimizers import FusedAdamW
+    dev = torch.device("cuda")
+    batches = [tuple(t.cuda() for t in orc.synthetic_ldct(4, seed=170 + i)) for i in range(5)]
+
+    def build():
+        torch.manual_seed(15)
+        m = MTD_GAN_Method().cuda().train()
+        wm = WeightMethods("pcgrad", n_tasks=3, device=dev)
+        oD = FusedAdamW(m.Discriminator.parameters(), lr=1e-4, weight_decay=5e-4)
+        oG = FusedAdamW(m.Generator.parameters(), lr=1e-4, weight_decay=5e-4)
+        random.seed(9)
+        torch.manual_seed(19)
+        return m, wm, oD, oG
+
+    m, wm, oD, oG = build()
+    want = [engine.train_iteration(m, x, y, oG, oD, wm, None)[1].clone() for x, y in batches]
+    sd_want = {k: v.clone() for k, v in m.state_dict().items()}
+
+    m, wm, oD, oG = build()
+    real_slot = TS.orders_slot
+
+    def other_slot(d):          # the real slot while the iteration is being recorded, afterwards one the list has never seen
+        return real_slot(d) if K.RECORDING is not None else K.HostScalars(d, 16, torch.int32)
+    got = []
+    for i, (x, y) in enumerate(batches):
+        if i == 2:              # the recording iteration: RecordedTrainStep looks its slot up after the iteration has run
+            monkeypatch.setattr(TS, "orders_slot", other_slot)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got.append(TS.recorded_iteration(m, x, y, oG, oD, wm, None)[1].clone())
+        if i == 2:
+            monkeypatch.setattr(TS, "orders_slot", real_slot)
+            assert any("recorded launch list is not used" in str(x_.message) for x_ in w), [str(x_.message) for x_ in w]
+            assert "order slot" in m._mtd_list_error and not isinstance(m._mtd_recorded, TS.RecordedTrainStep)
+            assert oD.graph_mode is False and oG.graph_mode is False
+    for i in range(5):
+        assert torch.equal(got[i], want[i]), i
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd_want[k]), k
+    assert oD.state[m.Discriminator.enc_out.weight]["step"] == 5        # every batch applied exactly once
+
+    # ---- a replaced optimizer state retires a live list
+    m, wm, oD, oG = build()
+    for x, y in batches[:4]:
+        TS.recorded_iteration(m, x, y, oG, oD, wm, None)
+    first = m._mtd_recorded
+    assert isinstance(first, TS.RecordedTrainStep)
+    oD.load_state_dict(oD.state_dict())                                  # new moment tensors, same values
+    assert not first.matches(m, oG, oD, wm, batches[0][0], batches[0][1], None)
+    TS.recorded_iteration(m, *batches[4], oG, oD, wm, None)
+    assert m._mtd_recorded is not first
+    m2, wm2, oD2, oG2 = build()
+    for x, y in batches:
+        engine.train_iteration(m2, x, y, oG2, oD2, wm2, None)
+    torch.cuda.synchronize()
+    for (k, v), (_k, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(v, v2), k
+    # the derived-view buffers of a model can be released explicitly (kernels.release_views)
+    assert K.release_views(list(m2.parameters())) > 0
