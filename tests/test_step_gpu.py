@@ -975,7 +975,8 @@ def test_unusable_recording_falls_back_to_eager_without_losing_the_iteration(hip
         TS.recorded_iteration(m, x, y, oG, oD, wm, None)
     first = m._mtd_recorded
     assert isinstance(first, TS.RecordedTrainStep)
-    oD.load_state_dict(oD.state_dict())                                  # new moment tensors, same values
+    import copy
+    oD.load_state_dict(copy.deepcopy(oD.state_dict()))                   # new moment tensors, same values (a checkpoint resume)
     assert not first.matches(m, oG, oD, wm, batches[0][0], batches[0][1], None)
     TS.recorded_iteration(m, *batches[4], oG, oD, wm, None)
     assert m._mtd_recorded is not first
