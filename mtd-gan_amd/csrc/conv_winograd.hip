@@ -53,7 +53,6 @@ struct WinoParams {
     int nchunk;               // C / 8
     int xcd_order;            // 0: workgroup = blockIdx; 1, 2: XCD-contiguous orders (see the kernel)
     unsigned w_bytes;         // extent of the transformed weights (4 PX N C floats)
-    unsigned slab_stride_bytes;   // one split-K slab (M N floats)
 };
 
 // ---- weight transform:  Uw[xi][C/8][N][8] = (G g G^T)[xi],  g[a][b] = W(n, c, kmap[a * 3 + b])  (a, b = correlation position
@@ -379,27 +378,6 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
 #pragma unroll
     for (int q = 0; q < TWX; ++q) esc[q] = pick_scale(sp, epix < 0 ? 0 : epix + q);
     const bool vec = (p.wide & 1) != 0;                            // every epilogue operand row 16-byte aligned (wide_epilogue_ok)
-    // ---- split-K inside the launch (round 5; p.fin): no slab epilogue launch, and one slab less written and read.
-    // The K slices of an output tile ARRIVE at the tile's first counter when they reach this point.  Every slice but the last
-    // to arrive writes its partial output tile to its slab (device-scope 16-byte stores: the slabs cross XCDs, each with an L2
-    // of its own) and then bumps the second counter.  The LAST one keeps its partial tile in registers, waits until the second
-    // counter says the other slabs are complete -- their writers have arrived, i.e. they are resident and running, and need
-    // nobody to finish: the wait is bounded whatever else shares the chip -- and adds the slabs IN SLICE ORDER, its own
-    // registers in their place: the sum splitk_epilogue_kernel forms, bit for bit, whichever slice is last.  It leaves both
-    // counters zero for the next launch.  role: 0 = no split, 1 = partial slab, 2 = the finishing slice.
-    int role = p.splitk > 1 ? 1 : 0;
-    unsigned* const ctr = p.fin ? a.tile_ctr + 2 * (bx * (int)gridDim.y + by) : nullptr;
-    if (p.fin) {
-        // (the rank travels through the first word of Ls -- the K loop's last barrier is behind every read of the A images,
-        // and the LEAN form's 80 KB leave no room for a variable of its own beside a second workgroup on the CU)
-        unsigned* const s_rank = reinterpret_cast<unsigned*>(Ls);
-        if (tid == 0) *s_rank = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        role = __builtin_amdgcn_readfirstlane(*s_rank == (unsigned)p.splitk - 1u ? 2 : 1);
-        __syncthreads();
-    }
-    // (one slab's extent: the slice goes through the scalar offset, which the range check does not see)
-    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.ws, (short)0, p.splitk > 1 ? (int)wp.slab_stride_bytes : 0, 0x00020000);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {        // (unrolled: a run-time index into the accumulators would put them in scratch memory)
         const int n = n0 + nb * 32 + 4 * enq;
@@ -410,7 +388,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
             e2[q] = e1[q];
             em[q] = f32x4{1.f, 1.f, 1.f, 1.f};
         }
-        if (role != 1 && evalid) {
+        if (p.splitk == 1 && evalid) {
             if (vec) {
                 if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n);
                 if (a.add1) {
@@ -469,51 +447,8 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
                 y[3] = d12 + 8.f * d34 + t[5];
             }
         }
-        if (role == 2) {
-            if (nb == 0) {
-                // the other slices' slabs are complete once the second counter has reached splitk - 1
-                if (tid == 0) {
-                    while (__hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.splitk - 1u) __builtin_amdgcn_s_sleep(2);
-                    __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __syncthreads();
-            }
-            // slabs in slice order from +0.0f, this slice's own partial tile (registers) in its place; device-scope loads
-            f32x4 sum[TWX];
-#pragma unroll
-            for (int q = 0; q < TWX; ++q) sum[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const unsigned so = evalid ? (unsigned)(((long long)epix * a.N + n) * 4) : 0x80000000u;
-            for (int k0 = 0; k0 < p.splitk; k0 += 2) {
-                f32x4 v[2][TWX];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const bool ld = k0 + j < p.splitk && k0 + j != zk;
-#pragma unroll
-                    for (int q = 0; q < TWX; ++q)
-                        v[j][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                            srs, ld ? so + (unsigned)(q * a.N * 4) : 0x80000000u, (k0 + j) * (int)wp.slab_stride_bytes, 16));
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (k0 + j < p.splitk) {
-#pragma unroll
-                        for (int q = 0; q < TWX; ++q) sum[q] += (k0 + j == zk) ? y[q] : v[j][q];
-                    }
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < TWX; ++q) y[q] = sum[q];
-        }
         if (evalid) {
-            if (role == 1) {
-                if (p.fin) {      // device-scope 16-byte stores (p.fin implies the 16-byte slab form)
-                    const unsigned so = (unsigned)(((long long)epix * a.N + n) * 4);
-#pragma unroll
-                    for (int q = 0; q < TWX; ++q)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, y[q]), srs,
-                                                               so + (unsigned)(q * a.N * 4), zk * (int)wp.slab_stride_bytes, 16);
-                } else {
+            if (p.splitk > 1) {
                 float* slab = a.ws + (long long)zk * ((long long)p.M * a.N) + n;
 #pragma unroll
                 for (int q = 0; q < TWX; ++q) {
@@ -521,7 +456,6 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
                     else
 #pragma unroll
                         for (int c = 0; c < 4; ++c) slab[(long long)(epix + q) * a.N + c] = y[q][c];
-                }
                 }
             } else {
 #pragma unroll
@@ -565,12 +499,6 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
             }
         }
         __syncthreads();
-    }
-    if (p.fin && role == 1) {
-        // this slice's slab is complete (vmcnt: the device-scope stores have been acknowledged) before the counter moves
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -780,15 +708,8 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
     p.out_linear = 1;
     p.xcd_map = 0;
     p.nt_store = 0;
+    p.fin = 0;
     p.wide = (wide_epilogue_ok(*a) ? 1 : 0) | ((pl.splitk > 1 && aligned16(a->ws) && (a->N % 4) == 0) ? 2 : 0);
-    wp.slab_stride_bytes = (unsigned)((long long)p.M * a->N * 4);
-    {
-        // finish inside the launch when the caller brought two zeroed counters per output tile (a->tile_ctr) and everything moves
-        // as 16-byte vectors inside 31-bit byte offsets; otherwise splitk_epilogue_kernel does, as before.  Same bits either way.
-        const long long otiles = (long long)((a->g.B * (a->g.OH / 2) * (a->g.OW / (px - 2)) + WT - 1) / WT) * (a->N / (32 * pl.nb));
-        p.fin = (pl.splitk > 1 && p.wide == 3 && a->tile_ctr && 2 * otiles <= (long long)a->tile_ctr_len &&
-                 (long long)pl.splitk * p.M * a->N * 4 < (1ll << 31) && !wino_c32_takes(*a, px)) ? 1 : 0;
-    }
     wp.tiles_x = a->g.OW / (px - 2);
     wp.tiles_per_image = (a->g.OH / 2) * wp.tiles_x;
     wp.ntiles = a->g.B * wp.tiles_per_image;
@@ -836,7 +757,7 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
     else MTD_LAUNCH((wino_conv_kernel<2>), grid, dim3(512), 0, s, wp);
     mtd_prof_end(prof, s);
     MTD_LAUNCH_CHECK();
-    if (pl.splitk > 1 && !p.fin) {
+    if (pl.splitk > 1) {
         const long long total = (long long)p.M * a->N;
         const bool vec = splitk_vec_ok(*a, p.M);
         int blocks = (int)(((vec ? total / 4 : total) + 255) / 256);

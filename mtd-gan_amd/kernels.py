@@ -375,11 +375,9 @@ def workspace(nbytes, device):
     return buf
 
 
-# Split-K launches may finish inside the kernel (mtd_conv_args.tile_ctr: the last slice to arrive at a tile sums the slabs): same
-# bits as the separate epilogue launch.  Round 5: the Winograd kernel does by default -- it keeps the finishing slice's partial
-# tile in registers and moves the slabs as device-scope 16-byte vectors; the implicit GEMM's form is a switch of its own.
+# Split-K launches may finish inside the kernel (mtd_conv_args.tile_ctr: the last slice to arrive at a tile sums the slabs).
+# Same bits as the separate epilogue launch; measured neutral on the full step (42.54 vs 42.42 ms), so off unless asked for.
 SPLITK_FIN = _options.lab("MTD_SPLITK_FIN", "0") == "1"
-SPLITK_FIN_WINO = _options.lab("MTD_SPLITK_FIN_WINO", "1") == "1"
 TILE_CTRS = 4096        # arrival counters per set of a split-K launch (mtd_conv_args.tile_ctr); four sets per buffer
 _tile_ctrs = {}
 
@@ -496,8 +494,6 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, **kw):
             if need:
                 ws = workspace(need, x.device)
                 a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
-                if SPLITK_FIN_WINO:
-                    a.tile_ctr, a.tile_ctr_len = tile_counters(x.device).data_ptr(), 4 * TILE_CTRS
             if FLOP_COUNT is not None:          # executed MFMA flops: 4 (F(2x2)) or 3 (F(2x4)) instead of 9 multiplications per output pixel
                 saved = 2.0 * geom.B * geom.OH * geom.OW * N * Cc * (6 if px == 6 else 5)
                 FLOP_COUNT["conv_mfma"] -= saved

@@ -687,61 +687,6 @@ def _winograd_conv_case(K, B, Ci, Co, H, W, what, form):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", [(64, 512, 512, 8, 8, "fwd"),       # F(2x4), split 2: the trunk's 8 x 8 maps of a paired pass
-                                  (64, 256, 256, 8, 8, "dgrad"),     # F(2x4), split 4
-                                  (64, 512, 512, 4, 4, "fwd"),       # F(2x2), split 4
-                                  (64, 512, 512, 2, 2, "dgrad"),     # F(2x2), split 8
-                                  (16, 128, 128, 16, 16, "fwd"),     # F(2x4), split 2 or 4, 32 tile blocks
-                                  (3, 1024, 512, 4, 4, "fwd"),       # split 16: more slices than one chunk of the finishing loop, a ragged tile block
-                                  (5, 256, 128, 8, 12, "dgrad")])    # ragged last tile block with split K
-def test_winograd_splitk_finish_in_launch_same_bits(hip_lib, case):
-    """Round 5: the Winograd kernel's split-K launches finish inside the launch (two arrival counters per output tile: the last
-    K slice to arrive keeps its partial tile in registers, waits for the other slices' slabs and adds them in slice order) --
-    against the separate slab epilogue launch they replace: the same bits, with the whole epilogue, on every shape class of the
-    step that splits K, repeated so that different slices come last, with the counters back at zero afterwards."""
-    from mtd_gan_amd import kernels as K
-    B, Ci, Co, H, W, what = case
-    gen = torch.Generator().manual_seed(31)
-    r = lambda *s: torch.randn(*s, generator=gen)
-    x = r(B, H, W, Ci if what == "fwd" else Co).cuda()
-    w = (r(Co, Ci, 3, 3) * (9 * Ci) ** -0.5).cuda()
-    N, Cc = (Co, Ci) if what == "fwd" else (Ci, Co)
-    bias, add1, add2, mask = (r(N) * 0.1).cuda(), r(B, H, W, N).cuda(), r(B, H, W, N).cuda(), r(B, H, W, N).cuda()
-    s1, s2 = torch.tensor([0.7], device="cuda"), torch.tensor([1.3], device="cuda")
-    if what == "fwd":
-        geom, wsn, wsc = K.geom_fwd(B, H, W, 3, 1, 1), Ci * 9, 9
-    else:
-        geom, wsn, wsc = K.geom_dgrad_s1(B, H, W, 3, 1), 9, Ci * 9
-    kw = dict(scale=s1, bias=bias, add1=add1, add2=add2, act=K.ACT_LRELU, mask=mask, mask_slope=0.2, scale2=s2, scale_split=(B // 2) * H * W)
-    assert K.winograd_takes(geom, N, Cc, kw)
-    ctr = K.tile_counters(torch.device("cuda", 0))
-    fin_default = K.SPLITK_FIN_WINO
-    outs = {}
-    try:
-        for fin in (False, True):
-            K.SPLITK_FIN_WINO = fin
-            for rep in range(6 if fin else 1):
-                out = torch.full((B, H, W, N), float("nan"), device="cuda")
-                K.conv(x, w, geom, N, Cc, wsn, wsc, out, **kw)
-                torch.cuda.synchronize()
-                outs.setdefault(fin, []).append(out)
-            assert int(ctr.abs().sum()) == 0, "arrival counters must be left at zero"
-    finally:
-        K.SPLITK_FIN_WINO = fin_default
-    need = K._igemm_ws_cache[("wino", bytes(geom), N, Cc)]
-    assert need > 0, "this shape was meant to split K"
-    for o in outs[True]:
-        assert torch.equal(o, outs[False][0])
-    xc, wc = nchw(x).double(), w.cpu().double()
-    y = F.conv2d(xc, wc, None, padding=1) if what == "fwd" else F.conv_transpose2d(xc, wc, None, padding=1)
-    sc = torch.full((B, 1, 1, 1), 0.7, dtype=torch.double)
-    sc[B // 2:] = 1.3
-    v = y * sc + bias.cpu().double().view(1, -1, 1, 1) + nchw(add1).double() + nchw(add2).double()
-    v = F.leaky_relu(v, 0.2) * torch.where(nchw(mask) > 0, 1.0, 0.2)
-    assert relerr(nchw(outs[True][0]), v) < TOL
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("case", [(2, 128, 128, "fwd", "relu_add"), (2, 128, 132, "dgrad", "relu"), (1, 256, 256, "fwd", "relu"),
                                   (3, 128, 128, "dgrad", "lrelu_mask"), (1, 256, 256, "dgrad", "relu_noadd"), (3, 136, 132, "fwd", "none"),
                                   (5, 130, 140, "fwd", "lrelu"), (8, 512, 512, "fwd", "relu_add")])
