@@ -112,9 +112,13 @@ int mtd_conv_igemm(const mtd_conv_args* a, void* stream);
 /* px: patch width of the transform along x -- 6: F(2x4, 3x3) (round 4: F(2,3) down the rows, F(4,3) along them, 24 positions,
  * 3 multiplications per output pixel; dst holds 24 N C floats), 0 or 4: F(2x2, 3x3) (16 N C floats).  A conv launch says which
  * weights it was given through a->w_st (6 or not); mtd_conv_winograd_patch_w tells the caller which form the library's plan
- * wants for a layer (0: not in the Winograd domain at all). */
+ * wants for a layer (0: not in the Winograd domain at all).
+ * Round 5: px + 16 (20, 22) = the SPLIT-BF16 form of the same transform -- every transformed weight as three bf16 pieces whose sum
+ * is the fp32 value exactly, dst = [xi][C/16][plane 0..2][N][16 c] bf16 (4 px N C x 6 bytes; C % 16 == 0): the operand of
+ * csrc/conv_winograd_split.h, which forms each fp32 product from six bf16 MFMA products at fp32 accuracy.  The plan asks for it
+ * on every layer with N % 64 == 0 unless mtd_set_option("wino_split", 0). */
 typedef struct { const float* src; float* dst; long long sn, sc, st; int N, C; int kmap[9]; int px; } mtd_wino_weight_desc;
-size_t mtd_winograd_weight_floats(int N, int C);      /* 24 N C: enough for either form */
+size_t mtd_winograd_weight_floats(int N, int C);      /* 36 N C: enough for every form */
 int mtd_conv_winograd_patch_w(const mtd_conv_args* a);
 int mtd_conv_winograd_f4_min_w(int min_w);      /* tuning / test hook: narrowest map width that takes F(2x4, 3x3); 0 = never, < 0 = query; returns the previous value */
 int mtd_winograd_kmap(const mtd_geom* g, int* kmap9);
@@ -458,6 +462,11 @@ const char* mtd_version(void);
  *   "c32f_safe_wait"  0 (default) | 1: the fused 32-channel backward launch waits for ALL outstanding vector-memory operations
  *                     before it hands a halo buffer to the next DMA, instead of the counted wait (a checking mode:
  *                     tests/test_kernels_gpu.py::test_fused_c32_backward_counted_waits_same_bits).
+ *   "wino_split"      1 (default) | 0: the 3x3 stride-1 layers with N % 64 == 0 run their Winograd products on the bf16 matrix
+ *                     pipe from exact three-way bf16 splits of both operands (six products per fp32 product, fp32
+ *                     accumulation: fp32 accuracy at 2.7x the fp32 MFMA rate; csrc/conv_winograd_split.h) | on the fp32 MFMA
+ *                     (wino_conv_kernel).  Callers that cache mtd_conv_winograd_patch_w's answers drop them after a change
+ *                     (tests/test_kernels_gpu.py::test_winograd_conv_vs_torch runs both).
  * Plan-level tuning hooks with their own entry points: mtd_conv_winograd_f4_min_w, mtd_conv_wgrad_plan_cfg, mtd_prof_mode. */
 int mtd_set_option(const char* name, int value);
 int mtd_get_option(const char* name, int* value);

@@ -16,7 +16,7 @@ static inline const char* mtd_lab_env(const char* name) { return getenv(name); }
 static inline const char* mtd_lab_env(const char*) { return nullptr; }
 #endif
 // run-time options (api.hip: mtd_set_option / mtd_get_option)
-enum { MTD_OPT_C32F_SAFE_WAIT = 0, MTD_OPT_COUNT };
+enum { MTD_OPT_C32F_SAFE_WAIT = 0, MTD_OPT_WINO_SPLIT, MTD_OPT_COUNT };
 int mtd_option(int id);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

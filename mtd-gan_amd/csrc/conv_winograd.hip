@@ -47,6 +47,18 @@ constexpr int WT = 32;        // tiles per workgroup
 constexpr int WALD = 20;      // LDS row stride (floats) of As[xi][tile][16 c]: 16-byte aligned, b128 reads of 16 rows hit 16 x 4 distinct banks
 constexpr int WXLD = 36;      // LDS row stride (floats) of the exchange image X[xi][tile][32 n]: 16-byte aligned rows
 
+// x -> three bf16 pieces (the upper halves of h, m, l) with x = hi + mid + lo EXACTLY: bit masks and exact subtractions
+// (conv_winograd_split.h says what for)
+__device__ __forceinline__ void w3_split(float x, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned xb = __builtin_bit_cast(unsigned, x);
+    const float r = x - __builtin_bit_cast(float, xb & 0xffff0000u);
+    const unsigned rb = __builtin_bit_cast(unsigned, r);
+    const float q = r - __builtin_bit_cast(float, rb & 0xffff0000u);
+    h = xb;
+    m = rb;
+    l = __builtin_bit_cast(unsigned, q);
+}
+
 struct WinoParams {
     IgemmParams p;            // args, M, split-K (c_per_split in channels), buffer extents, out_identity
     int ntiles, tiles_x, tiles_per_image;
@@ -62,21 +74,23 @@ struct WinoWDesc {
     long long sn, sc, st;     // W(n, c, kidx) = src[n * sn + c * sc + kidx * st]
     int N, C;
     int kmap[9];
-    int px;                   // patch width of the transform along x: 6 = F(4,3), anything else = F(2,3) (4)
+    int px;                   // low four bits: patch width of the transform along x: 6 = F(4,3), anything else = F(2,3) (4);
+                              // bit 4: the split-bf16 form  Uw3[xi][C/16][plane 0..2][N][16 c]  (conv_winograd_split.h)
 };
 
 __global__ __launch_bounds__(256) void wino_weights_kernel(const WinoWDesc* __restrict__ tab, int count) {
     for (int d = blockIdx.y; d < count; d += gridDim.y) {
         const WinoWDesc w = tab[d];
         const long long total = (long long)w.N * w.C;
-        const int PXr = w.px == 6 ? 6 : 4;
+        const int PXr = (w.px & 15) == 6 ? 6 : 4;
+        const bool split = (w.px & 16) != 0;
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-            // destination order: c8 fastest within (n), so consecutive threads write consecutive floats
-            const int c8 = (int)(i & 7);
-            const long long r = i >> 3;
+            // destination order: c8 (split form: c16) fastest within (n), so consecutive threads write consecutive elements
+            const int c8 = split ? (int)(i & 15) : (int)(i & 7);
+            const long long r = split ? i >> 4 : i >> 3;
             const int n = (int)(r % w.N);
             const int ck = (int)(r / w.N);
-            const int c = ck * 8 + c8;
+            const int c = split ? ck * 16 + c8 : ck * 8 + c8;
             const float* s = w.src + (long long)n * w.sn + (long long)c * w.sc;
             float g[3][3];
 #pragma unroll
@@ -92,6 +106,34 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const WinoWDesc* __re
                 t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
                 t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
                 t[3][b] = g[2][b];
+            }
+            if (split) {
+                // the transformed value, split exactly into three bf16 pieces (conv_winograd_split.h), plane p at
+                // ((xi (C/16) + ck) 3 + p) N 16 + n 16 + c16  (in bf16 elements)
+                unsigned short* d16 = reinterpret_cast<unsigned short*>(w.dst);
+                const long long plane = (long long)w.N * 16;
+                const long long xs16 = (long long)(w.C / 16) * 3 * plane;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const float t0 = t[a][0], t1 = t[a][1], t2 = t[a][2];
+                    float u[6];
+                    if (PXr == 6) {
+                        const float e = (t0 + t2) * (1.f / 6.f), f = t1 * (1.f / 6.f);
+                        const float h = t0 * (1.f / 24.f) + t2 * (1.f / 6.f), k = t1 * (1.f / 12.f);
+                        u[0] = 0.25f * t0; u[1] = -e - f; u[2] = -e + f; u[3] = h + k; u[4] = h - k; u[5] = t2;
+                    } else {
+                        u[0] = t0; u[1] = 0.5f * (t0 + t1 + t2); u[2] = 0.5f * (t0 - t1 + t2); u[3] = t2; u[4] = u[5] = 0.f;
+                    }
+                    for (int b = 0; b < PXr; ++b) {
+                        unsigned hh, mm, ll;
+                        w3_split(u[b], hh, mm, ll);
+                        unsigned short* o = d16 + (long long)(a * PXr + b) * xs16 + (long long)ck * 3 * plane + (long long)n * 16 + c8;
+                        o[0] = (unsigned short)(hh >> 16);
+                        o[plane] = (unsigned short)(mm >> 16);
+                        o[2 * plane] = (unsigned short)(ll >> 16);
+                    }
+                }
+                continue;
             }
             const long long xs = (long long)(w.C / 8) * w.N * 8;          // stride between positions xi = a * PX + b
 #pragma unroll
@@ -503,6 +545,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
 }
 
 #include "conv_wino_c32.h"
+#include "conv_winograd_split.h"
 
 int wino_patch_w_of(const mtd_conv_args& a);
 
@@ -541,11 +584,16 @@ int wino_patch_w(const mtd_conv_args& a) {
         const char* mw = mtd_lab_env("MTD_WINO_F4_MIN_W");
         g_f4_min_w = (off && atoi(off) == 0) ? 0 : (mw ? atoi(mw) : 8);
     }
-    return (g_f4_min_w > 0 && (a.g.OW % 4) == 0 && a.g.OW >= g_f4_min_w) ? 6 : 4;
+    const int pxw = (g_f4_min_w > 0 && (a.g.OW % 4) == 0 && a.g.OW >= g_f4_min_w) ? 6 : 4;
+    // the split-bf16 kernel (conv_winograd_split.h) takes every layer whose N is a multiple of 64 (bit 4 of the code); the
+    // generator's 32 -> 32 layers keep the fp32 forms (the persistent kernel of conv_wino_c32.h)
+    return pxw | ((mtd_option(MTD_OPT_WINO_SPLIT) && (a.N % 64) == 0) ? 16 : 0);
 }
 
-WinoPlan wino_plan(const mtd_conv_args& a, int px) {
+WinoPlan wino_plan(const mtd_conv_args& a, int pxcode) {
     WinoPlan pl{};
+    const int px = pxcode & 15;
+    const bool split3 = (pxcode & 16) != 0;
     pl.px = px;
     const int tile_px = 2 * (px - 2);                            // output pixels per tile
     pl.nb = (a.N % 128 == 0 && px == 4) ? 4 : 2;
@@ -560,6 +608,7 @@ WinoPlan wino_plan(const mtd_conv_args& a, int px) {
         if (((t + WT - 1) / WT) * (a.N / 64) <= 128 && a.C >= 128) pl.nb = 1;
     }
     if (a.N % 64) pl.nb = 1;                                     // (F(2x4) only: wino_eligible)
+    if (split3) pl.nb = 2;                                       // the split-bf16 kernel: 64-channel workgroups only
     // (lab, MTD_WINO_NB2_MAXC=64: the narrow form with its lean variant for layers with four K steps whatever their N -- 5 % less time
     // for those launches (123 -> 116 us, 226 -> 213 us), 0.08 ms per step, but the input is then read per 64 instead of per 128 output
     // channels: 62 -> 80 MB of fabric traffic per launch.  Off.)
@@ -567,7 +616,7 @@ WinoPlan wino_plan(const mtd_conv_args& a, int px) {
     if (a.C <= env_nb2_c) pl.nb = 2;
     const long long tiles = geom_pixels(a.g) / tile_px;
     long long blocks = ((tiles + WT - 1) / WT) * (a.N / (32 * pl.nb));
-    if (blocks < 192 && pl.nb == 4 && a.N % 64 == 0) {          // more, narrower workgroups before splitting K
+    if (blocks < 192 && pl.nb == 4 && a.N % 64 == 0 && !split3) {          // more, narrower workgroups before splitting K
         pl.nb = 2;
         blocks = ((tiles + WT - 1) / WT) * (a.N / 64);
     }
@@ -585,14 +634,15 @@ WinoPlan wino_plan(const mtd_conv_args& a, int px) {
     // 1 by this rule, 2 whenever NB = 2)
     static const int env_lean = [] { const char* e = mtd_lab_env("MTD_WINO_LEAN"); return e ? atoi(e) : 1; }();
     const long long grid = ((tiles + WT - 1) / WT) * (a.N / (32 * pl.nb)) * pl.splitk;
-    pl.lean = px == 4 && pl.nb == 2 && env_lean && (env_lean == 2 || (cps <= 8 && grid >= 512));
+    pl.lean = px == 4 && pl.nb == 2 && env_lean && (env_lean == 2 || (cps <= 8 && grid >= 512)) && !split3;
     return pl;
 }
 
 // The persistent 32 -> 32 channel kernel (conv_wino_c32.h) takes a layer of the F(2x4) form with one residual operand at most,
 // no scales, no mask, 16-byte aligned rows everywhere and buffers inside 31-bit byte offsets.  MTD_WINO_C32_KERNEL=0: the
 // general kernel's 32-channel workgroups instead (lab switch).
-bool wino_c32_takes(const mtd_conv_args& a, int px) {
+bool wino_c32_takes(const mtd_conv_args& a, int pxcode) {
+    const int px = pxcode;       // (a split code, 20 / 22, never matches 6: N % 64 == 0 there)
     static const int env_on = [] { const char* e = mtd_lab_env("MTD_WINO_C32_KERNEL"); return e ? atoi(e) : 1; }();
     if (!env_on || px != 6 || a.C != 32 || a.N != 32) return false;
     if (a.scale || a.scale2 || a.add2 || a.mask || a.out2) return false;
@@ -605,7 +655,8 @@ bool wino_c32_takes(const mtd_conv_args& a, int px) {
 }
 
 // the patch width the transformed weights in a->w were built for travels in a->w_st (6: F(2x4, 3x3); anything else: 4)
-inline int wino_args_px(const mtd_conv_args& a) { return a.w_st == 6 ? 6 : 4; }
+// (bit 4: the split-bf16 form)
+inline int wino_args_px(const mtd_conv_args& a) { return ((a.w_st & 15) == 6 ? 6 : 4) | ((a.w_st & 16) && a.w_st < 32 ? 16 : 0); }
 
 }  // namespace
 
@@ -613,7 +664,7 @@ inline int wino_args_px(const mtd_conv_args& a) { return a.w_st == 6 ? 6 : 4; }
 // Transformed weights of `count` conv views in one launch.  desc[i]: the weight view W(n, c, kidx) = src[n sn + c sc + kidx st]
 // and the geometry it will be used with (its taps decide which filter entry sits at which correlation position: a forward
 // conv and the data gradient of the same layer need different transforms); dst: 16 * N * C floats, layout [xi][C/8][N][8].
-extern "C" size_t mtd_winograd_weight_floats(int N, int C) { return (N > 0 && C > 0) ? (size_t)24 * N * C : 0; }      /* enough for either form */
+extern "C" size_t mtd_winograd_weight_floats(int N, int C) { return (N > 0 && C > 0) ? (size_t)36 * N * C : 0; }      /* enough for every form (split: 24 N C x 3 bf16) */
 
 extern "C" int mtd_winograd_weights(const mtd_wino_weight_desc* table_dev, const mtd_wino_weight_desc* table_host, int count, void* stream) {
     static_assert(sizeof(mtd_wino_weight_desc) == sizeof(WinoWDesc), "descriptor layouts must agree");
@@ -621,7 +672,8 @@ extern "C" int mtd_winograd_weights(const mtd_wino_weight_desc* table_dev, const
     long long most = 0;
     for (int i = 0; i < count; ++i) {
         const mtd_wino_weight_desc& d = table_host[i];
-        if (!d.src || !d.dst || d.N <= 0 || d.C <= 0 || (d.C % 8) || !(d.px == 0 || d.px == 4 || d.px == 6)) return MTD_EINVAL;
+        if (!d.src || !d.dst || d.N <= 0 || d.C <= 0 || (d.C % 8) || !(d.px == 0 || d.px == 4 || d.px == 6 || d.px == 20 || d.px == 22)) return MTD_EINVAL;
+        if ((d.px & 16) && (d.C % 16)) return MTD_EINVAL;
         for (int k = 0; k < 9; ++k)
             if (d.kmap[k] < 0 || d.kmap[k] > 15) return MTD_EINVAL;
         const long long t = (long long)d.N * d.C;
@@ -657,7 +709,7 @@ extern "C" int mtd_conv_winograd_ok(const mtd_conv_args* a) {
     const long long npix = (long long)a->g.B * a->g.IH * a->g.IW;
     if (((npix - 1) * a->in_ld + a->C) * 4 >= (1ll << 31)) return 0;
     if (geom_pixels(a->g) * a->N >= (1ll << 31)) return 0;
-    if ((long long)96 * a->N * a->C >= (1ll << 31)) return 0;          // (the transformed weights inside 31-bit byte offsets)
+    if ((long long)144 * a->N * a->C >= (1ll << 31)) return 0;          // (the transformed weights inside 31-bit byte offsets, split form included)
     return 1;
 }
 
@@ -689,9 +741,12 @@ extern "C" size_t mtd_conv_winograd_ws_bytes(const mtd_conv_args* a) {
 extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
     if (!mtd_conv_winograd_ok(a)) return MTD_EINVAL;
     if (!aligned16(a->w)) return MTD_EALIGN;
-    const int px = wino_args_px(*a);
+    const int pxcode = wino_args_px(*a);
+    const int px = pxcode & 15;
+    const bool split3 = (pxcode & 16) != 0;
     if (px == 6 && (a->g.OW % 4)) return MTD_EINVAL;
-    const WinoPlan pl = wino_plan(*a, px);
+    if (split3 && (a->N % 64)) return MTD_EINVAL;
+    const WinoPlan pl = wino_plan(*a, pxcode);
     WinoParams wp;
     IgemmParams& p = wp.p;
     p.a = *a;
@@ -714,7 +769,7 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
     wp.tiles_per_image = (a->g.OH / 2) * wp.tiles_x;
     wp.ntiles = a->g.B * wp.tiles_per_image;
     wp.nchunk = a->C / 8;
-    wp.w_bytes = (unsigned)((long long)4 * px * a->N * a->C * 4);
+    wp.w_bytes = (unsigned)((long long)4 * px * a->N * a->C * (split3 ? 6 : 4));
     {
         static const int env_xcd = [] { const char* e = mtd_lab_env("MTD_WINO_XCD"); return e ? atoi(e) : -1; }();
         const double wbytes = 4.0 * px * a->C * a->N * 4, ibytes = (double)p.M * a->C * 4;
@@ -725,7 +780,7 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
         if (!a->ws || a->ws_bytes < need) return MTD_EWS;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (wino_c32_takes(*a, px)) {
+    if (wino_c32_takes(*a, pxcode)) {
         C32Params cp;
         cp.wp = wp;
         cp.tiles_y = a->g.OH / 2;
@@ -749,8 +804,11 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
     const dim3 grid((wp.ntiles + WT - 1) / WT, a->N / (32 * pl.nb), pl.splitk);
     // (one profiler id per INSTANTIATION -- 14: <2, false, 4>, 15: <4, false, 4>, 22: <2, true, 4>, 23: <2, false, 6>, 24: <1, false, 6>; 25, 26: wino_c32_kernel<false / true> -- so that a record's name is
     // one kernel symbol of a rocprofv3 table)
-    const int prof = mtd_prof_begin(0, px == 6 ? (pl.nb == 1 ? 24 : 23) : (pl.nb == 4 ? 15 : (pl.lean ? 22 : 14)), pl.splitk, p.M, a->N, a->C, 9, s, algorithmic_bytes(a));
-    if (px == 6 && pl.nb == 1) MTD_LAUNCH((wino_conv_kernel<1, false, 6>), grid, dim3(512), 0, s, wp);
+    // (27, 28: wino_conv3_kernel<6 / 4>, the split-bf16 forms)
+    const int prof = mtd_prof_begin(0, split3 ? (px == 6 ? 27 : 28) : px == 6 ? (pl.nb == 1 ? 24 : 23) : (pl.nb == 4 ? 15 : (pl.lean ? 22 : 14)), pl.splitk, p.M, a->N, a->C, 9, s, algorithmic_bytes(a));
+    if (split3 && px == 6) MTD_LAUNCH((wino_conv3_kernel<6>), grid, dim3(512), 0, s, wp);
+    else if (split3) MTD_LAUNCH((wino_conv3_kernel<4>), grid, dim3(512), 0, s, wp);
+    else if (px == 6 && pl.nb == 1) MTD_LAUNCH((wino_conv_kernel<1, false, 6>), grid, dim3(512), 0, s, wp);
     else if (px == 6) MTD_LAUNCH((wino_conv_kernel<2, false, 6>), grid, dim3(512), 0, s, wp);
     else if (pl.nb == 4) MTD_LAUNCH((wino_conv_kernel<4>), grid, dim3(512), 0, s, wp);
     else if (pl.lean) MTD_LAUNCH((wino_conv_kernel<2, true>), grid, dim3(512), 0, s, wp);

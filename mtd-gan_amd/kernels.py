@@ -176,7 +176,8 @@ _wino_px_cache = {}
 
 def winograd_patch_w(geom, N, Cc):
     """The transform the library's plan wants along x for this layer (mtd_conv_winograd_patch_w): 6 = F(2x4, 3x3) -- 3 MFMA
-    multiplications per output pixel and channel pair -- or 4 = F(2x2, 3x3) -- 4 of them; the direct form has 9."""
+    multiplications per output pixel and channel pair -- or 4 = F(2x2, 3x3) -- 4 of them; the direct form has 9.  Plus 16 when the
+    layer runs on the split-bf16 kernel (csrc/conv_winograd_split.h: its weights are three bf16 planes)."""
     key = (bytes(geom), N, Cc)
     px = _wino_px_cache.get(key)
     if px is None:
@@ -203,7 +204,8 @@ def winograd_f4_min_w(min_w):
 
 
 def _wino_desc(w, N, Cc, w_sn, w_sc, kmap, device, px):
-    dst = _view_buffer((w.data_ptr(), N, Cc, w_sn, w_sc, "wino", kmap, px), (4 * px * N * Cc,), device)
+    # (px: patch width 4 / 6, + 16 for the split-bf16 form -- three bf16 planes, 6 bytes per transformed weight)
+    dst = _view_buffer((w.data_ptr(), N, Cc, w_sn, w_sc, "wino", kmap, px), ((6 if px & 16 else 4) * (px & 15) * N * Cc,), device)
     d = _lib.WinoWeightDesc()
     d.src, d.dst, d.sn, d.sc, d.st, d.N, d.C, d.px = w.data_ptr(), dst.data_ptr(), w_sn, w_sc, 1, N, Cc, px
     for i, k in enumerate(kmap):
@@ -495,7 +497,7 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, **kw):
                 ws = workspace(need, x.device)
                 a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
             if FLOP_COUNT is not None:          # executed MFMA flops: 4 (F(2x2)) or 3 (F(2x4)) instead of 9 multiplications per output pixel
-                saved = 2.0 * geom.B * geom.OH * geom.OW * N * Cc * (6 if px == 6 else 5)
+                saved = 2.0 * geom.B * geom.OH * geom.OW * N * Cc * (6 if (px & 15) == 6 else 5)
                 FLOP_COUNT["conv_mfma"] -= saved
                 FLOP_COUNT["conv_winograd_saved"] = FLOP_COUNT.get("conv_winograd_saved", 0.0) + saved
             check(L.mtd_conv_winograd(C.byref(a), stream_ptr()), "mtd_conv_winograd")

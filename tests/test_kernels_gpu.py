@@ -628,26 +628,41 @@ WINO_CASES = [
 ]
 
 
+def _set_wino_split(K, on):
+    """mtd_set_option("wino_split", on): the split-bf16 Winograd kernel (csrc/conv_winograd_split.h) or the fp32 MFMA one."""
+    from mtd_gan_amd import _lib
+    assert _lib.lib().mtd_set_option(b"wino_split", int(on)) == 0
+    K._wino_px_cache.clear()
+    K._igemm_ws_cache.clear()
+    K.weights_changed(None)
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("pipe", ["bf16x3", "fp32"])
 @pytest.mark.parametrize("form", ["plan", "f2x2"])
 @pytest.mark.parametrize("case", WINO_CASES)
-def test_winograd_conv_vs_torch(hip_lib, case, form):
+def test_winograd_conv_vs_torch(hip_lib, case, form, pipe):
     """csrc/conv_winograd.hip: forward conv and data gradient with the full epilogue (two scales by batch half, bias, two adds,
     LeakyReLU, mask) against torch on the CPU in float64 and against the implicit GEMM on the same inputs (the two differ by
     fp32 rounding only: 2e-5).  form "plan": what the library picks per layer -- F(2x4, 3x3) on maps at least 8 wide whose width
-    is a multiple of 4, F(2x2, 3x3) elsewhere; "f2x2": F(2x2, 3x3) everywhere (mtd_conv_winograd_f4_min_w(0))."""
+    is a multiple of 4, F(2x2, 3x3) elsewhere; "f2x2": F(2x2, 3x3) everywhere (mtd_conv_winograd_f4_min_w(0)).
+    pipe "bf16x3" (round 5, the default): the products on the bf16 matrix pipe from exact three-way splits of both operands, six
+    per fp32 product (csrc/conv_winograd_split.h) -- held to the SAME bounds as the fp32 MFMA kernel ("fp32":
+    mtd_set_option("wino_split", 0)), and its error against float64 may not exceed twice the fp32 kernel's."""
     from mtd_gan_amd import kernels as K
     B, Ci, Co, H, W, what = case
     if form == "f2x2" and not (W % 4 == 0 and W >= 8):
         pytest.skip("the plan takes F(2x2, 3x3) for this map anyway")
     old_min_w = K.winograd_f4_min_w(0 if form == "f2x2" else 8)
+    _set_wino_split(K, pipe == "bf16x3")
     try:
-        _winograd_conv_case(K, B, Ci, Co, H, W, what, form)
+        _winograd_conv_case(K, B, Ci, Co, H, W, what, form, pipe)
     finally:
         K.winograd_f4_min_w(old_min_w)
+        _set_wino_split(K, True)
 
 
-def _winograd_conv_case(K, B, Ci, Co, H, W, what, form):
+def _winograd_conv_case(K, B, Ci, Co, H, W, what, form, pipe="bf16x3"):
     gen = torch.Generator().manual_seed(17)
     r = lambda *s: torch.randn(*s, generator=gen)
     x = r(B, H, W, Ci if what == "fwd" else Co).cuda()
@@ -664,7 +679,7 @@ def _winograd_conv_case(K, B, Ci, Co, H, W, what, form):
     if split:
         kw.update(scale2=s2, scale_split=split)
     assert K.winograd_takes(geom, N, Cc, kw)
-    assert K.winograd_patch_w(geom, N, Cc) == (6 if (form == "plan" and W % 4 == 0 and W >= 8) else 4)
+    assert K.winograd_patch_w(geom, N, Cc) == (6 if (form == "plan" and W % 4 == 0 and W >= 8) else 4) + (16 if pipe == "bf16x3" else 0)
     outs = []
     for wino in (True, False):
         K.WINOGRAD = wino
@@ -684,6 +699,16 @@ def _winograd_conv_case(K, B, Ci, Co, H, W, what, form):
     v = y * sc + bias.cpu().double().view(1, -1, 1, 1) + nchw(add1).double() + nchw(add2).double()
     v = F.leaky_relu(v, 0.2) * torch.where(nchw(mask) > 0, 1.0, 0.2)
     assert relerr(nchw(outs[0]), v) < TOL
+    if pipe == "bf16x3":
+        # fp32 accuracy, not merely parity: against float64 no worse than twice the fp32 MFMA kernel on the same inputs
+        _set_wino_split(K, False)
+        out32 = torch.zeros(B, H, W, N, device="cuda")
+        K.conv(x, w, geom, N, Cc, wsn, wsc, out32, **kw)
+        torch.cuda.synchronize()
+        _set_wino_split(K, True)
+        e3 = (nchw(outs[0]).double() - v).abs().max().item() / v.abs().max().item()
+        e32 = (nchw(out32).double() - v).abs().max().item() / v.abs().max().item()
+        assert e3 <= 2 * e32 + 2e-7, (e3, e32)
 
 
 @pytest.mark.gpu
