@@ -24,7 +24,7 @@ def _stale(target, deps):
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(CSRC, "build_lab" if LAB_BUILD else "build")
-    flags = FLAGS + (["-DMTD_LAB"] if LAB_BUILD else [])
+    flags = FLAGS + (["-DMTD_LAB"] + os.environ.get("MTD_LAB_FLAGS", "").split() if LAB_BUILD else [])      # (MTD_LAB_FLAGS: e.g. -DW3_SKIP=1, lab probes)
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "fft64.h"), os.path.join(os.path.dirname(HERE), "include", "mtdgan_hip.h"),
                os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_wgrad.hip"), os.path.join(CSRC, "conv_wgrad_wino.h"), os.path.join(CSRC, "conv_wino_c32.h")]      # (conv_c32_bwd.hip includes the two kernel files)

@@ -33,6 +33,9 @@ typedef __bf16 w3_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned w3_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned w3_u32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef W3_SKIP
+#define W3_SKIP 0        // lab (tools/wino3_variants.sh): 1 no MFMAs, 2 no transform / split arithmetic, 4 no weight loads, 8 no patch loads, 16 no LDS stores
+#endif
 constexpr int W3_XB = 1024 + 32;      // bytes between positions of one plane of As: 32 tiles x 16 bf16, + 32 (the four patch rows of a quad on different banks)
 
 // upper halves of two words -> one word (first value in the low half): v_perm_b32
@@ -103,6 +106,11 @@ __global__ __launch_bounds__(512, 1) void wino_conv3_kernel(const WinoParams wp)
     const int px_b = a.in_ld * 4;
     f32x4 d[PX];
     auto load_patch = [&](int st) {
+        if (W3_SKIP & 8) {
+#pragma unroll
+            for (int j = 0; j < PX; ++j) d[j] = f32x4{(float)st, 1.f, 2.f, (float)j};
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
             const unsigned vo = ((pvalid >> j) & 1u) ? pbase + (unsigned)(j * px_b) : 0x80000000u;
@@ -111,6 +119,7 @@ __global__ __launch_bounds__(512, 1) void wino_conv3_kernel(const WinoParams wp)
     };
     const float qsign = ti == 1 ? 1.f : -1.f;
     auto row_value = [&](int j) -> f32x4 {
+        if (W3_SKIP & 2) return d[j];
         if constexpr (PX == 4) {
             return j == 0 ? d[0] - d[2] : (j == 1 ? d[1] + d[2] : (j == 2 ? d[2] - d[1] : d[1] - d[3]));
         } else {
@@ -132,11 +141,15 @@ __global__ __launch_bounds__(512, 1) void wino_conv3_kernel(const WinoParams wp)
         unsigned char* o = As + tt * 32 + tq * 8;
 #pragma unroll
         for (int j = j0; j < j0 + 2; ++j) {
-            const f32x4 u = wino_quad_rows(row_value(j), qsign);
+            const f32x4 u = (W3_SKIP & 2) ? row_value(j) : wino_quad_rows(row_value(j), qsign);
             unsigned h[4], m[4], l[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) w3_split(u[c], h[c], m[c], l[c]);
+            for (int c = 0; c < 4; ++c) {
+                if (W3_SKIP & 2) h[c] = m[c] = l[c] = __builtin_bit_cast(unsigned, u[c]);
+                else w3_split(u[c], h[c], m[c], l[c]);
+            }
             const int xi = PX * ti + j;
+            if (W3_SKIP & 16) { asm volatile("" :: "v"(h[0]), "v"(m[1]), "v"(l[2]), "v"(h[3])); continue; }
             *reinterpret_cast<w3_u32x2*>(o + (0 * NP + xi) * W3_XB) = w3_u32x2{w3_pack(h[0], h[1]), w3_pack(h[2], h[3])};
             *reinterpret_cast<w3_u32x2*>(o + (1 * NP + xi) * W3_XB) = w3_u32x2{w3_pack(m[0], m[1]), w3_pack(m[2], m[3])};
             *reinterpret_cast<w3_u32x2*>(o + (2 * NP + xi) * W3_XB) = w3_u32x2{w3_pack(l[0], l[1]), w3_pack(l[2], l[3])};
@@ -156,6 +169,11 @@ __global__ __launch_bounds__(512, 1) void wino_conv3_kernel(const WinoParams wp)
     const int w_pos0 = PW * wave * xi_stride_b;
     auto load_b = [&](int st, int u, w3_u32x4 (&bf)[3]) {      // step st (absolute), unit u
         const int x = u / NB, nb = u % NB;
+        if (W3_SKIP & 4) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bf[pl] = w3_u32x4{(unsigned)st, (unsigned)u, 0x3f803f80u, (unsigned)pl};
+            return;
+        }
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
             bf[pl] = __builtin_bit_cast(w3_u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, w_lane + (unsigned)(nb * 1024), w_pos0 + x * xi_stride_b + st * chunk_b + pl * plane_b, 0));
@@ -174,6 +192,12 @@ __global__ __launch_bounds__(512, 1) void wino_conv3_kernel(const WinoParams wp)
     };
     auto mfma_unit = [&](int u, const w3_u32x4 (&bf)[3]) {     // the six products of one (position, n block), smallest first
         f32x16 c = acc[u / NB][u % NB];
+        if (W3_SKIP & 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c[e] += __builtin_bit_cast(float, af[0][e] ^ bf[0][e] ^ af[1][e] ^ bf[1][e] ^ af[2][e] ^ bf[2][e]);
+            acc[u / NB][u % NB] = c;
+            return;
+        }
         c = w3_mfma(af[0], bf[2], c);
         c = w3_mfma(af[2], bf[0], c);
         c = w3_mfma(af[1], bf[1], c);
@@ -183,29 +207,34 @@ __global__ __launch_bounds__(512, 1) void wino_conv3_kernel(const WinoParams wp)
         acc[u / NB][u % NB] = c;
     };
 
-    // ---- prologue: step 0 in buffer 0, the first units' weights in the ring.  Every load is unconditional (clamped indices):
-    // ONE path through the loop, so the compiler's vmcnt waits count exactly the younger requests (wino_conv_kernel).
-    // Ring of B fragments: PX = 6 (six units per step) three register sets, unit u in set u % 3, refilled for unit u + 3 right
-    // after its MFMAs; PX = 4 (four units) four sets, refilled for the same unit of the next step.
+    // ---- K loop, two half-steps per step of 16 channels ("ping-pong").  The four SIMDs of the CU each hold one wave of 0 .. 3
+    // and one of 4 .. 7.  In the first half-step of step j waves 0 .. 3 run the MFMAs of step j (segment M: 6 NU MFMAs, the A
+    // fragments from LDS, the weight ring) while waves 4 .. 7 transform and split THEIR part of step j + 1's input (segment T:
+    // ~250 vector instructions, 3 PX LDS stores, the patch loads of the step after); in the second half-step the roles swap.
+    // One wave's matrix work thus always runs beside the other wave's vector work on a SIMD -- the two pipes are separate
+    // (measured: the SAME work as one M-then-T stream per wave, everything in lockstep, took the SUM of its parts,
+    // profiles/r5_wino3_parts.txt) -- and a barrier closes each half-step.  Images: M_j reads buffer j & 1 (complete since the
+    // end of step j - 1: both halves of T_j are behind a barrier), T_{j+1} writes buffer (j + 1) & 1 (last read by M_{j-1}).
+    // Every load is unconditional (clamped indices), so each path through the loop is ONE path and the compiler's vmcnt waits
+    // count exactly the younger requests (wino_conv_kernel).  Ring of B fragments: PX = 6 (six units per step) three register
+    // sets, unit u in set u % 3, refilled for unit u + 3 right after its MFMAs; PX = 4 (four units) four sets, refilled for the
+    // same unit of the next step.
     constexpr int RING = NU == 6 ? 3 : NU;
     static_assert(NU == 6 || NU == 4, "units per step");
     w3_u32x4 br[RING][3];
+    const bool m_first = wave < 4;
     if (nst > 0) {
         load_patch(st_beg);
 #pragma unroll
         for (int u = 0; u < RING; ++u) load_b(st_beg, u, br[u]);
         transform_store(Lb);
+        load_patch(min(st_beg + 1, st_last));
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
-#pragma unroll 1
-    for (int j = 0; j < nst; ++j) {
+    auto seg_m = [&](int j) {                                       // the MFMAs of step j
         const int st = st_beg + j;
         const int stn = min(st + 1, st_last);
         const unsigned char* Ac = Lb + (j & 1) * AS_BUF;
-        unsigned char* An = Lb + ((j + 1) & 1) * AS_BUF;
-        load_patch(stn);                                            // the next step's patch: a step of MFMAs covers its way
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             if (u % NB == 0) load_af(Ac, u / NB);
@@ -214,9 +243,27 @@ __global__ __launch_bounds__(512, 1) void wino_conv3_kernel(const WinoParams wp)
             else load_b(stn, u + RING - NU, br[u % RING]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        transform_store(An);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+    };
+    auto seg_t = [&](int j) {                                       // the input of step j + 1 -> the other image; the patch of step j + 2 requested
+        transform_store(Lb + ((j + 1) & 1) * AS_BUF);
+        load_patch(min(st_beg + j + 2, st_last));
+    };
+    if (m_first) {
+#pragma unroll 1
+        for (int j = 0; j < nst; ++j) {
+            seg_m(j);
+            __syncthreads();
+            seg_t(j);
+            __syncthreads();
+        }
+    } else {
+#pragma unroll 1
+        for (int j = 0; j < nst; ++j) {
+            seg_t(j);
+            __syncthreads();
+            seg_m(j);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: wino_conv_kernel's, on the same accumulator layout

@@ -305,7 +305,8 @@ IGEMM_CONFIGS = ["igemm_kernel<2, 1, 4, 1>", "igemm_kernel<1, 1, 4, 1>", "igemm_
                  "igemm_multi_kernel<2, 1, 4, 1>", "igemm_multi_kernel<1, 1, 4, 1>", "igemm_multi_kernel<2, 2, 4, 1>",      # 16 + cfg
                  "igemm_multi_kernel<1, 1, 2, 2>", "igemm_multi_kernel<2, 2, 2, 2>", "igemm_multi_kernel<1, 1, 1, 4>",
                  "wino_conv_kernel<2, true, 4>", "wino_conv_kernel<2, false, 6>", "wino_conv_kernel<1, false, 6>",             # 22, 23, 24 (6: F(2x4, 3x3))
-                 "wino_c32_kernel<false>", "wino_c32_kernel<true>"]                                                             # 25, 26: the persistent 32 -> 32 channel form
+                 "wino_c32_kernel<false>", "wino_c32_kernel<true>",                                                             # 25, 26: the persistent 32 -> 32 channel form
+                 "wino_conv3_kernel<6>", "wino_conv3_kernel<4>"]                                                                # 27, 28: the split-bf16 forms (conv_winograd_split.h)
 WGRAD_CONFIGS = ["wgrad_kernel<1, 1, 9>", "wgrad_kernel<1, 1, 4>", "wgrad_kernel<2, 2, 1>", "wgrad_kernel<1, 1, 8>",
                  "wgrad_kernel<1, 1, 3>", "wgrad_kernel<1, 1, 1>", "wgrad_kernel<2, 2, 3>",
                  "wgrad_row_kernel<3, 3, 1>", "wgrad_row_kernel<3, 3, -1>", "wgrad_row_kernel<1, 1, 1>",

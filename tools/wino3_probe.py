@@ -1,0 +1,31 @@
+"""Times single Winograd conv launches of the step's shapes on the split-bf16 kernel and on the fp32 MFMA kernel (us per launch,
+hot inputs).  `MTD_LAB=1` picks up libmtdgan_hip_lab.so when it exists (tools/wino3_variants.sh builds W3_SKIP variants)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mtd_gan_amd import _lib, kernels as K
+L = _lib.lib()
+SHAPES = [(64, 64, 64, 64, 64), (64, 128, 128, 32, 32), (64, 256, 256, 16, 16), (64, 512, 512, 8, 8), (64, 1024, 256, 8, 8), (64, 512, 512, 4, 4), (64, 512, 512, 2, 2)]
+pipes = [1] if os.environ.get("W3_ONLY") else [1, 0]
+print("lab build" if L.mtd_lab_build() else "shipped build", _lib.LIB_PATH)
+for (B, Ci, Co, H, W) in SHAPES:
+    x = torch.randn(B, H, W, Ci, device="cuda")
+    w = torch.randn(Co, Ci, 3, 3, device="cuda") * (9 * Ci) ** -0.5
+    out = torch.empty(B, H, W, Co, device="cuda")
+    geom = K.geom_fwd(B, H, W, 3, 1, 1)
+    row = f"M{B * H * W:7d} N{Co:5d} C{Ci:5d}"
+    for split in pipes:
+        L.mtd_set_option(b"wino_split", split)
+        K._wino_px_cache.clear(); K._igemm_ws_cache.clear(); K.weights_changed(None)
+        for _ in range(3):
+            K.conv(x, w, geom, Co, Ci, Ci * 9, 9, out, act=K.ACT_LRELU)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 20
+        e0.record()
+        for _ in range(n):
+            K.conv(x, w, geom, Co, Ci, Ci * 9, 9, out, act=K.ACT_LRELU)
+        e1.record()
+        torch.cuda.synchronize()
+        row += f"   {'bf16x3' if split else 'fp32  '} {1e3 * e0.elapsed_time(e1) / n:7.1f} us"
+    print(row, flush=True)
