@@ -116,7 +116,7 @@ int mtd_conv_igemm(const mtd_conv_args* a, void* stream);
  * Round 5: px + 16 (20, 22) = the SPLIT-BF16 form of the same transform -- every transformed weight as three bf16 pieces whose sum
  * is the fp32 value exactly, dst = [xi][C/16][plane 0..2][N][16 c] bf16 (4 px N C x 6 bytes; C % 16 == 0): the operand of
  * csrc/conv_winograd_split.h, which forms each fp32 product from six bf16 MFMA products at fp32 accuracy.  The plan asks for it
- * on every layer with N % 64 == 0 unless mtd_set_option("wino_split", 0). */
+ * on every layer with N % 64 == 0 after mtd_set_option("wino_split", 1) (off by default: see the option). */
 typedef struct { const float* src; float* dst; long long sn, sc, st; int N, C; int kmap[9]; int px; } mtd_wino_weight_desc;
 size_t mtd_winograd_weight_floats(int N, int C);      /* 36 N C: enough for every form */
 int mtd_conv_winograd_patch_w(const mtd_conv_args* a);
@@ -462,11 +462,13 @@ const char* mtd_version(void);
  *   "c32f_safe_wait"  0 (default) | 1: the fused 32-channel backward launch waits for ALL outstanding vector-memory operations
  *                     before it hands a halo buffer to the next DMA, instead of the counted wait (a checking mode:
  *                     tests/test_kernels_gpu.py::test_fused_c32_backward_counted_waits_same_bits).
- *   "wino_split"      1 (default) | 0: the 3x3 stride-1 layers with N % 64 == 0 run their Winograd products on the bf16 matrix
- *                     pipe from exact three-way bf16 splits of both operands (six products per fp32 product, fp32
- *                     accumulation: fp32 accuracy at 2.7x the fp32 MFMA rate; csrc/conv_winograd_split.h) | on the fp32 MFMA
- *                     (wino_conv_kernel).  Callers that cache mtd_conv_winograd_patch_w's answers drop them after a change
- *                     (tests/test_kernels_gpu.py::test_winograd_conv_vs_torch runs both).
+ *   "wino_split"      0 (default) | 1: the 3x3 stride-1 layers with N % 64 == 0 run their Winograd products on the fp32 MFMA
+ *                     (wino_conv_kernel) | on the bf16 matrix pipe from exact three-way bf16 splits of both operands (six
+ *                     products per fp32 product, fp32 accumulation: fp32 accuracy at 2.7x the fp32 MFMA rate;
+ *                     csrc/conv_winograd_split.h).  Measured (profiles/r5_wino3_parts.txt): the launches are bound by the
+ *                     vector-memory path, not the matrix pipe -- 5-20 % per launch on hot inputs, nothing in the step -- so
+ *                     the fp32 kernel stays the default.  Callers that cache mtd_conv_winograd_patch_w's answers drop them
+ *                     after a change (tests/test_kernels_gpu.py::test_winograd_conv_vs_torch runs both).
  * Plan-level tuning hooks with their own entry points: mtd_conv_winograd_f4_min_w, mtd_conv_wgrad_plan_cfg, mtd_prof_mode. */
 int mtd_set_option(const char* name, int value);
 int mtd_get_option(const char* name, int* value);

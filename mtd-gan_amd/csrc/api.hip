@@ -9,7 +9,7 @@ extern "C" const char* mtd_version(void) { return "mtdgan_hip 0.1.0 (gfx950)"; }
 // ---- run-time options: the ONE documented way to change the library's behaviour at run time (include/mtdgan_hip.h lists the
 // names).  Everything else that used to be an environment variable is a lab switch of an -DMTD_LAB build (common.h).
 namespace {
-int g_options[MTD_OPT_COUNT] = {0, 1};
+int g_options[MTD_OPT_COUNT] = {0, 0};
 const char* const g_option_names[MTD_OPT_COUNT] = {"c32f_safe_wait", "wino_split"};
 int option_id(const char* name) {
     if (!name) return -1;

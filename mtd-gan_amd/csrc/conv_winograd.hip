@@ -41,6 +41,9 @@
 #define MTD_NO_API 1
 #include "conv_igemm.hip"
 
+#ifndef W_AUX
+#define W_AUX 0      // cache policy of the weight-fragment loads (lab: 2 = nt, streaming: the weights of a workgroup are read once)
+#endif
 namespace {
 
 constexpr int WT = 32;        // tiles per workgroup
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
         for (int x = 0; x < PW; ++x)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
-                bf[x][nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, w_lane + (unsigned)(nb * 1024), w_pos0 + x * xi_stride_b + ck * a.N * 32, 0));
+                bf[x][nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, w_lane + (unsigned)(nb * 1024), w_pos0 + x * xi_stride_b + ck * a.N * 32, W_AUX));
     };
     f32x16 acc[PW][NB];
 #pragma unroll

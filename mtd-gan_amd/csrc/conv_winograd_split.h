@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512, 1) void wino_conv3_kernel(const WinoParams wp)
         }
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-            bf[pl] = __builtin_bit_cast(w3_u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, w_lane + (unsigned)(nb * 1024), w_pos0 + x * xi_stride_b + st * chunk_b + pl * plane_b, 0));
+            bf[pl] = __builtin_bit_cast(w3_u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, w_lane + (unsigned)(nb * 1024), w_pos0 + x * xi_stride_b + st * chunk_b + pl * plane_b, W_AUX));
     };
     f32x16 acc[PW][NB];
 #pragma unroll

@@ -646,9 +646,9 @@ def test_winograd_conv_vs_torch(hip_lib, case, form, pipe):
     LeakyReLU, mask) against torch on the CPU in float64 and against the implicit GEMM on the same inputs (the two differ by
     fp32 rounding only: 2e-5).  form "plan": what the library picks per layer -- F(2x4, 3x3) on maps at least 8 wide whose width
     is a multiple of 4, F(2x2, 3x3) elsewhere; "f2x2": F(2x2, 3x3) everywhere (mtd_conv_winograd_f4_min_w(0)).
-    pipe "bf16x3" (round 5, the default): the products on the bf16 matrix pipe from exact three-way splits of both operands, six
-    per fp32 product (csrc/conv_winograd_split.h) -- held to the SAME bounds as the fp32 MFMA kernel ("fp32":
-    mtd_set_option("wino_split", 0)), and its error against float64 may not exceed twice the fp32 kernel's."""
+    pipe "bf16x3" (round 5; mtd_set_option("wino_split", 1)): the products on the bf16 matrix pipe from exact three-way splits of both operands, six
+    per fp32 product (csrc/conv_winograd_split.h) -- held to the SAME bounds as the fp32 MFMA kernel ("fp32", the default),
+    and its error against float64 may not exceed twice the fp32 kernel's."""
     from mtd_gan_amd import kernels as K
     B, Ci, Co, H, W, what = case
     if form == "f2x2" and not (W % 4 == 0 and W >= 8):
@@ -659,7 +659,7 @@ def test_winograd_conv_vs_torch(hip_lib, case, form, pipe):
         _winograd_conv_case(K, B, Ci, Co, H, W, what, form, pipe)
     finally:
         K.winograd_f4_min_w(old_min_w)
-        _set_wino_split(K, True)
+        _set_wino_split(K, False)
 
 
 def _winograd_conv_case(K, B, Ci, Co, H, W, what, form, pipe="bf16x3"):
