@@ -25,10 +25,16 @@
 //     16-byte LDS load per lane;
 //   * K loop: per step of 16 channels and wave, PW positions x 2 n blocks x 6 MFMAs (PX = 6: 36 MFMAs = 1152 matrix-pipe clocks
 //     where the fp32 kernel has 48 = 3072); the split costs ~5.5 vector instructions per transformed value (132 per thread and
-//     step beside the transform's 116);
+//     step beside the transform's 116); with the matrix segment that short, every request is further ahead of its use than in
+//     the fp32 kernel: the patch rows two steps (two register sets);
 //   * accumulators, exchange image and epilogue are the fp32 kernel's (the bf16 MFMA has the same 32 x 32 result layout).
-// Domain: everything wino_conv_kernel takes with N a multiple of 64 (the library's plan sends those layers here; their weights
-// are built in the split form: mtd_wino_weight_desc.px = 16 + PX, and a conv launch says so through a->w_st).
+// Domain: everything wino_conv_kernel takes with N a multiple of 64 (after mtd_set_option("wino_split", 1) the library's plan
+// sends those layers here; their weights are built in the split form: mtd_wino_weight_desc.px = 16 + PX, and a conv launch says
+// so through a->w_st).
+// Measured (profiles/r5_wino3_parts.txt): 62 against 76 us per launch on hot inputs (M 16384, N = C = 256), 49.5 against 53.1 us
+// on the average launch of the training step, -0.27 ms per step: with two thirds of the matrix-pipe time gone a launch is bound
+// by what a CU can take in per K step -- 147 KB of weight fragments and 98 KB of patch-row lines against 64 B / clock -- and that
+// bound lies just under the fp32 MFMA one.  OFF by default.
 typedef __bf16 w3_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned w3_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned w3_u32x2 __attribute__((ext_vector_type(2)));
@@ -104,8 +110,8 @@ __global__ __launch_bounds__(512, 1) void wino_conv3_kernel(const WinoParams wp)
         }
     }
     const int px_b = a.in_ld * 4;
-    f32x4 d[PX];
-    auto load_patch = [&](int st) {
+    f32x4 d0[PX], d1[PX];                  // two patch register sets: a step's patch is requested TWO steps ahead
+    auto load_patch = [&](f32x4 (&d)[PX], int st) {
         if (W3_SKIP & 8) {
 #pragma unroll
             for (int j = 0; j < PX; ++j) d[j] = f32x4{(float)st, 1.f, 2.f, (float)j};
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(512, 1) void wino_conv3_kernel(const WinoParams wp)
         }
     };
     const float qsign = ti == 1 ? 1.f : -1.f;
-    auto row_value = [&](int j) -> f32x4 {
+    auto row_value = [&](const f32x4 (&d)[PX], int j) -> f32x4 {
         if (W3_SKIP & 2) return d[j];
         if constexpr (PX == 4) {
             return j == 0 ? d[0] - d[2] : (j == 1 ? d[1] + d[2] : (j == 2 ? d[2] - d[1] : d[1] - d[3]));
@@ -137,11 +143,11 @@ __global__ __launch_bounds__(512, 1) void wino_conv3_kernel(const WinoParams wp)
         }
     };
     // B^T d B, split, -> As[plane][xi = PX ti + j][tt][channels 4 tq .. 4 tq + 3] (8 bytes per plane)
-    auto transform_cols = [&](unsigned char* As, int j0) {
+    auto transform_cols = [&](const f32x4 (&d)[PX], unsigned char* As, int j0) {
         unsigned char* o = As + tt * 32 + tq * 8;
 #pragma unroll
         for (int j = j0; j < j0 + 2; ++j) {
-            const f32x4 u = (W3_SKIP & 2) ? row_value(j) : wino_quad_rows(row_value(j), qsign);
+            const f32x4 u = (W3_SKIP & 2) ? row_value(d, j) : wino_quad_rows(row_value(d, j), qsign);
             unsigned h[4], m[4], l[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -155,9 +161,9 @@ __global__ __launch_bounds__(512, 1) void wino_conv3_kernel(const WinoParams wp)
             *reinterpret_cast<w3_u32x2*>(o + (2 * NP + xi) * W3_XB) = w3_u32x2{w3_pack(l[0], l[1]), w3_pack(l[2], l[3])};
         }
     };
-    auto transform_store = [&](unsigned char* As) {
+    auto transform_store = [&](const f32x4 (&d)[PX], unsigned char* As) {
 #pragma unroll
-        for (int j0 = 0; j0 < PX; j0 += 2) transform_cols(As, j0);
+        for (int j0 = 0; j0 < PX; j0 += 2) transform_cols(d, As, j0);
     };
 
     // ---- MFMA role: positions PW wave .. PW wave + PW - 1.  B fragments of unit u = (x = u / NB, nb = u % NB): three planes
@@ -207,31 +213,25 @@ __global__ __launch_bounds__(512, 1) void wino_conv3_kernel(const WinoParams wp)
         acc[u / NB][u % NB] = c;
     };
 
-    // ---- K loop, two half-steps per step of 16 channels ("ping-pong").  The four SIMDs of the CU each hold one wave of 0 .. 3
-    // and one of 4 .. 7.  In the first half-step of step j waves 0 .. 3 run the MFMAs of step j (segment M: 6 NU MFMAs, the A
-    // fragments from LDS, the weight ring) while waves 4 .. 7 transform and split THEIR part of step j + 1's input (segment T:
-    // ~250 vector instructions, 3 PX LDS stores, the patch loads of the step after); in the second half-step the roles swap.
-    // One wave's matrix work thus always runs beside the other wave's vector work on a SIMD -- the two pipes are separate
-    // (measured: the SAME work as one M-then-T stream per wave, everything in lockstep, took the SUM of its parts,
-    // profiles/r5_wino3_parts.txt) -- and a barrier closes each half-step.  Images: M_j reads buffer j & 1 (complete since the
-    // end of step j - 1: both halves of T_j are behind a barrier), T_{j+1} writes buffer (j + 1) & 1 (last read by M_{j-1}).
-    // Every load is unconditional (clamped indices), so each path through the loop is ONE path and the compiler's vmcnt waits
-    // count exactly the younger requests (wino_conv_kernel).  Ring of B fragments: PX = 6 (six units per step) three register
-    // sets, unit u in set u % 3, refilled for unit u + 3 right after its MFMAs; PX = 4 (four units) four sets, refilled for the
-    // same unit of the next step.
+    // ---- K loop: one stream per wave -- the MFMAs of step j, then the transform + split of step j + 1 into the other image, one
+    // barrier per step.  With the matrix segment down to 1 152 clocks nothing of a step covers a memory round trip any more
+    // (profiles/r5_wino3_parts.txt: the parts of a step ADD UP), so every request is far ahead of its use: the patch rows TWO steps
+    // (two register sets, the loop runs two steps per trip), the weight fragments three units in a ring of three register sets
+    // (PX = 4: four sets, a whole step).  Every load is unconditional (clamped indices): ONE path through the loop, so the
+    // compiler's vmcnt waits count exactly the younger requests (wino_conv_kernel).
     constexpr int RING = NU == 6 ? 3 : NU;
     static_assert(NU == 6 || NU == 4, "units per step");
     w3_u32x4 br[RING][3];
-    const bool m_first = wave < 4;
     if (nst > 0) {
-        load_patch(st_beg);
+        load_patch(d0, st_beg);
 #pragma unroll
         for (int u = 0; u < RING; ++u) load_b(st_beg, u, br[u]);
-        transform_store(Lb);
-        load_patch(min(st_beg + 1, st_last));
+        load_patch(d1, min(st_beg + 1, st_last));
+        transform_store(d0, Lb);
+        load_patch(d0, min(st_beg + 2, st_last));
     }
     __syncthreads();
-    auto seg_m = [&](int j) {                                       // the MFMAs of step j
+    auto step = [&](int j, f32x4 (&d)[PX]) {          // d: the patch of step j + 1 (requested two steps ago); refilled for step j + 3
         const int st = st_beg + j;
         const int stn = min(st + 1, st_last);
         const unsigned char* Ac = Lb + (j & 1) * AS_BUF;
@@ -243,27 +243,15 @@ __global__ __launch_bounds__(512, 1) void wino_conv3_kernel(const WinoParams wp)
             else load_b(stn, u + RING - NU, br[u % RING]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        transform_store(d, Lb + ((j + 1) & 1) * AS_BUF);
+        load_patch(d, min(st + 3, st_last));
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
     };
-    auto seg_t = [&](int j) {                                       // the input of step j + 1 -> the other image; the patch of step j + 2 requested
-        transform_store(Lb + ((j + 1) & 1) * AS_BUF);
-        load_patch(min(st_beg + j + 2, st_last));
-    };
-    if (m_first) {
 #pragma unroll 1
-        for (int j = 0; j < nst; ++j) {
-            seg_m(j);
-            __syncthreads();
-            seg_t(j);
-            __syncthreads();
-        }
-    } else {
-#pragma unroll 1
-        for (int j = 0; j < nst; ++j) {
-            seg_t(j);
-            __syncthreads();
-            seg_m(j);
-            __syncthreads();
-        }
+    for (int j = 0; j < nst; j += 2) {
+        step(j, d1);
+        if (j + 1 < nst) step(j + 1, d0);
     }
 
     // ---- epilogue: wino_conv_kernel's, on the same accumulator layout

@@ -120,6 +120,8 @@ def packed_weight_view(w, N, Cc, w_sn, w_sc):
 # MTD_WINOGRAD_MIN_HW / _MIN_C / _MIN_N bound the layers that take it.  (Measured: even the 4 x 4 and 2 x 2 maps of the
 # deepest levels gain -- 942 against 926 img/s with them -- although the implicit GEMM's whole-tile tap skipping already drops
 # most of their padding taps: 512 x 512 on 4 x 4 maps 54 -> 35 us.)
+if _options.lab("MTD_WINO_SPLIT", "") != "":       # lab: the split-bf16 Winograd kernel for a whole run (mtd_set_option("wino_split", ...))
+    _lib.lib().mtd_set_option(b"wino_split", int(_options.lab("MTD_WINO_SPLIT", "0")))
 WINOGRAD = _options.lab("MTD_WINOGRAD", "1") != "0"
 WINO_MIN_HW = int(_options.lab("MTD_WINOGRAD_MIN_HW", "2"))
 WINO_MIN_C = int(_options.lab("MTD_WINOGRAD_MIN_C", "64"))
