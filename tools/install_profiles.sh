@@ -1,10 +1,10 @@
 #!/bin/bash
-# Copies the summaries of the last tools/r4_measure.sh run from gpurun_out/ (scratch) to profiles/ (tracked)
+# Copies the summaries of the last tools/r5_measure.sh run from gpurun_out/ (scratch) to profiles/ (tracked)
 # and rewrites profiles/pmc_manifest.json with the kernel-source hash the PMC passes were taken at.  Run after a gpurun call
-# of the script, with the same kernel sources checked out.   usage: tools/install_profiles.sh r4 [nogit]
+# of the script, with the same kernel sources checked out.   usage: tools/install_profiles.sh r5 [nogit]
 set -e
 cd "$(dirname "$0")/.."
-R=${1:-r4}
+R=${1:-r5}
 O=gpurun_out
 [ -f $O/bench_full.json ] && [ "$2" != "nogit" ] && cp $O/bench_full.json profiles/${R}_full_step_bench.json
 cp $O/prof_full/full_results_kernel_stats.csv profiles/${R}_full_step_kernel_stats_single_stream.csv
