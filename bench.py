@@ -54,6 +54,7 @@ def parse(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-generator", action="store_true", help="skip the configs[1] generator object of the default workload")
     ap.add_argument("--no-inference", action="store_true", help="skip the configs[4] whole-slice inference object of the default workload")
+    ap.add_argument("--no-wino-split", action="store_true", help="skip the information-only leg that re-times the step on the split-bf16 Winograd kernel")
     ap.add_argument("--no-engine-api", action="store_true", help="skip the engine.train_MTD_GAN_Ours leg (profiling runs: only the timed steps)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / collective plumbing only: gloo on the CPU, a trivial step (no GPU, no HIP library)")
@@ -535,6 +536,32 @@ def main(argv=None):
         inf["pixel_metrics_last_batch"] = iw.last
         del iw
 
+    # ---- information only (round 5): the SAME step with the 3x3 stride-1 trunk layers on the split-bf16 Winograd kernel
+    # (mtd_set_option("wino_split", 1); csrc/conv_winograd_split.h: fp32-accurate products from six bf16 MFMAs each).  A second
+    # model instance in this process, same box, after everything that feeds the headline has been measured; the option is put back.
+    split_leg = None
+    if wl.name == "full_step" and world == 1 and rank == 0 and not args.no_wino_split:
+        from mtd_gan_amd import _lib as _L
+        from mtd_gan_amd import kernels as _K
+
+        def _set_split(on):
+            _L.lib().mtd_set_option(b"wino_split", int(on))
+            _K._wino_px_cache.clear()
+            _K._igemm_ws_cache.clear()
+            _K.weights_changed(None)
+        _set_split(1)
+        try:
+            sw = BW.make("full_step", dev, rank, world, PER_GPU_BATCH)
+            sdt = timed(sw, args.steps, args.warmup, barrier)
+            split_leg = {"ms_per_step": round(1e3 * sdt / args.steps, 3), "value": round(PER_GPU_BATCH * args.steps / sdt, 2), "unit": "img/s",
+                         "what": "the same full step with mtd_set_option('wino_split', 1): the Winograd products of the 3x3 stride-1 layers with "
+                                 "N % 64 == 0 as six bf16 MFMA products of exact three-way bf16 splits, fp32 accumulation (error against "
+                                 "float64 <= 2 x the fp32 MFMA kernel's: tests/test_kernels_gpu.py::test_winograd_conv_vs_torch[*bf16x3*]); "
+                                 "NOT the headline configuration"}
+            del sw
+        finally:
+            _set_split(0)
+
     # the same iterations through the kept API (engine.train_MTD_GAN_Ours, reference engine.py:26-76): the timed step above is that
     # loop's body, this is the loop itself.  (Before the CPU baseline: run after it -- 32 host threads that have just been busy --
     # this leg sporadically read 1 ms per iteration slower than the timed step, 31.2 against 30.2-30.4.)
@@ -571,6 +598,8 @@ def main(argv=None):
             line["generator_fwd_bwd"] = gen
         if inf is not None:
             line["inference512"] = inf
+        if split_leg is not None:
+            line["full_step_wino_split"] = split_leg
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

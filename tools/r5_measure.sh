@@ -8,7 +8,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O
-NOX="--no-roofline --no-cpu-baseline --no-generator --no-inference --no-engine-api"
+NOX="--no-roofline --no-cpu-baseline --no-generator --no-inference --no-engine-api --no-wino-split"
 rm -rf $O/prof_full $O/prof_gen $O/prof_inf
 MTD_LAB=1 MTD_LIST=0 MTD_NO_SIDE_STREAMS=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/prof_full -o full -- python3 bench.py --steps 5 --warmup 2 $NOX > $O/prof_full.log 2>&1 || { echo "rocprof full failed"; tail -5 $O/prof_full.log; exit 1; }
 MTD_LAB=1 MTD_NO_SIDE_STREAMS=1 MTD_GRAPH=0 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/prof_gen -o gen -- python3 bench.py --workload generator --steps 10 --warmup 3 --no-roofline --no-cpu-baseline > $O/prof_gen.log 2>&1 || { echo "rocprof gen failed"; exit 1; }
