@@ -161,14 +161,32 @@ def _post_step_psnr(m, x, y, want, pred_sample, stride):
     assert rel(pred[:, 0, ::stride, ::stride], torch.tensor(pred_sample)) < TOL
 
 
-def test_full_step_b32_vs_golden(hip_lib):
-    """BASELINE configs[2] at its full size: one iteration on 32 patches from the seeded-fill state (O(1) activations, all
+@pytest.mark.parametrize("pipe", ["fp32", "bf16x3"])
+def test_full_step_b32_vs_golden(hip_lib, pipe):
+    """(pipe "bf16x3", round 5: the same iteration with mtd_set_option("wino_split", 1) -- the 3x3 stride-1 trunk layers' Winograd
+    products as six bf16 MFMA products of exact three-way splits -- held to the SAME golden values and bounds.)
+    BASELINE configs[2] at its full size: one iteration on 32 patches from the seeded-fill state (O(1) activations, all
     three task gradients non-degenerate) against the step the reference itself ran -- 17 logged scalars, sampled
     post-step parameters and spectral-norm vectors, the Gram matrix of the task gradients, the generator's PSNR after
     the step.  The D optimizer has the reference's two-group layout (train.py:122-124: second group empty, lr 0.025)."""
     from mtd_gan_amd import engine
     from mtd_gan_amd.module.weight_methods import WeightMethods
     from mtd_gan_amd.optimizers import FusedAdamW
+    from mtd_gan_amd import _lib, kernels as K
+
+    def set_split(on):
+        assert _lib.lib().mtd_set_option(b"wino_split", int(on)) == 0
+        K._wino_px_cache.clear()
+        K._igemm_ws_cache.clear()
+        K.weights_changed(None)
+    set_split(pipe == "bf16x3")
+    try:
+        _full_step_b32(engine, WeightMethods, FusedAdamW)
+    finally:
+        set_split(False)
+
+
+def _full_step_b32(engine, WeightMethods, FusedAdamW):
     z = json.load(open(os.path.join(GOLD, "step_seeded_b32.json")))
     m, full, masks, _ = _model(32)
     m.Discriminator._inject_masks = [k.clone() for k in masks]
@@ -213,8 +231,11 @@ def test_full_step_b32_vs_golden(hip_lib):
     _post_step_psnr(m, x, y, z["post_metrics"], z["post_pred_sample"], 16)
 
 
-def test_g_step_gradients_b32_vs_reference_samples(hip_lib):
-    """The generator's gradients of the G step at BASELINE size (engine.py:50-52: g_loss.backward() after the discriminator's
+@pytest.mark.parametrize("pipe", ["fp32", "bf16x3"])
+def test_g_step_gradients_b32_vs_reference_samples(hip_lib, pipe):
+    """(pipe "bf16x3": with mtd_set_option("wino_split", 1) -- the discriminator's 3x3 stride-1 layers on the split-bf16 Winograd
+    kernel, through which the G step's data gradient flows -- under the same per-tensor bounds.)
+    The generator's gradients of the G step at BASELINE size (engine.py:50-52: g_loss.backward() after the discriminator's
     update; networks.py:1994-2009) against the reference's own: per parameter 6 sampled ELEMENTS and the tensor's norm
     (tests/golden/g_grad_samples_b32.json, written by oracle/pin_grad_samples.py from a run of the reference's engine loop),
     and the norms committed with the golden step (step_seeded_b32.json `g_grad_norms`).  Bound per tensor: max(1e-3, 2 x the
@@ -222,6 +243,21 @@ def test_g_step_gradients_b32_vs_reference_samples(hip_lib):
     from mtd_gan_amd import engine
     from mtd_gan_amd.module.weight_methods import WeightMethods
     from mtd_gan_amd.optimizers import FusedAdamW
+    from mtd_gan_amd import _lib, kernels as K
+
+    def set_split(on):
+        assert _lib.lib().mtd_set_option(b"wino_split", int(on)) == 0
+        K._wino_px_cache.clear()
+        K._igemm_ws_cache.clear()
+        K.weights_changed(None)
+    set_split(pipe == "bf16x3")
+    try:
+        _g_step_gradients_b32(engine, WeightMethods, FusedAdamW)
+    finally:
+        set_split(False)
+
+
+def _g_step_gradients_b32(engine, WeightMethods, FusedAdamW):
     z = json.load(open(os.path.join(GOLD, "step_seeded_b32.json")))
     gs = json.load(open(os.path.join(GOLD, "g_grad_samples_b32.json")))
     m, full, masks, _ = _model(32)

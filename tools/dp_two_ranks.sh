@@ -1,6 +1,6 @@
 #!/bin/bash
 # The data-parallel schedule at world size 2 on the one GPU of a gpurun box (tests/dp_two_ranks_one_gpu.py), then a short
-# 2-rank bench rehearsal (MTD_DP_SHARE_GPU=1).  Log -> profiles/r4_dp_two_ranks_one_gpu.log
+# 2-rank bench rehearsal (MTD_DP_SHARE_GPU=1).  Log -> profiles/r5_dp_two_ranks_one_gpu.log
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out; mkdir -p $O
 timeout -k 10 700 python tests/dp_two_ranks_one_gpu.py > $O/dp2.log 2>&1; rc=$?
