@@ -86,7 +86,8 @@ typedef struct {
                                                     A data-gradient launch then also hands the next layer's activation-masked
                                                     cotangent over.  Halo-tile kernel only (C == 32, 3x3, 64-pixel rows,
                                                     >= 32768 pixels); MTD_EINVAL on every other path */
-    unsigned* tile_ctr; int tile_ctr_len;        /* optional arrival counters of split-K launches: tile_ctr_len zero-initialised
+    unsigned* tile_ctr; int tile_ctr_len;        /* LAB BUILDS ONLY since round 5 (ignored by the shipped library: the variant lost twice).
+                                                    Optional arrival counters of split-K launches: tile_ctr_len zero-initialised
                                                     words that only these launches touch (they leave them zero).  With one word
                                                     per output tile the last slice to arrive at a tile sums the slabs, in slice
                                                     order, and runs the epilogue in the same kernel; NULL / too few = a second

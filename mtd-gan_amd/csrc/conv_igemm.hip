@@ -17,6 +17,11 @@
 //
 // Roofline: fp32 MFMA, 64 FLOP/clk/SIMD (157.3 TFLOP/s chip).  Algorithmic flops = 2*M*N*K.
 #include "common.h"
+#ifdef MTD_LAB
+#define MTD_IGEMM_FIN 1
+#else
+#define MTD_IGEMM_FIN 0      // the in-kernel split-K finish exists in lab builds only (see "split-K finish inside the kernel")
+#endif
 #include "fft64.h"
 
 // In-kernel phase stamps for the diagnostic build only (tools/igemm_stamp.hip defines MTD_STAMPS and includes this
@@ -56,7 +61,7 @@ struct IgemmParams {
     int out_linear;    // 32 consecutive launch-grid pixels (from a multiple of 32) map to output pixels pix0 + r * out_sx
     int xcd_map;       // tiles in XCD-contiguous, n-fastest order (tile_of below)
     int nt_store;      // lab switch MTD_IGEMM_NT=1: non-temporal output stores in the block epilogue
-    int fin;           // split-K: the last workgroup to arrive at a tile sums the slabs and runs the epilogue (a.tile_ctr)
+    int fin;           // split-K: the last workgroup to arrive at a tile sums the slabs and runs the epilogue (a.tile_ctr; lab builds)
     int wide;          // igemm_body: bit 0 = every epilogue operand row is 16-byte aligned (EpiWide), bit 1 = the slabs are
 };
 
@@ -377,7 +382,9 @@ __device__ __forceinline__ void epiw_bias(const mtd_conv_args& a, int ch, f32x4 
     for (int g = 0; g < 4; ++g) bias4[g] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + ch + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// ---- split-K finish inside the kernel ------------------------------------------------------------------------------
+// ---- split-K finish inside the kernel (LAB BUILDS ONLY since round 5: the variant lost twice -- neutral in round 2, +0.2 ms in
+// round 4 -- and the Winograd kernel's form of it lost in round 5, profiles/r5_winograd_in_launch_splitk_finish.txt; in the shipped
+// library MTD_IGEMM_FIN is 0, p.fin is never set and the branches below are compiled out) ------------------------------------------
 // Every slice stores its partial tile to its slab as before, then arrives at the tile's counter (a.tile_ctr, zero on
 // entry).  The workgroup that completes the count re-reads ALL slabs of the tile in slice order 0 .. splitk-1 -- the
 // sum is the one splitk_epilogue_kernel forms, bit for bit, whichever slice arrives last -- and runs the ordinary
@@ -682,7 +689,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int zk) {
                 const int m = m0 + (wm * WM + i) * 32 + l31;
                 if (m < p.M) {
                     float* row = slab + (long long)m * a.N + (n0 + (wn * WN + j) * 32 + 4 * kh);
-                    const bool through = p.fin != 0;
+                    const bool through = MTD_IGEMM_FIN && p.fin != 0;
                     if ((p.wide & 2) && !through) {
 #pragma unroll
                         for (int g4 = 0; g4 < 4; ++g4)
@@ -694,7 +701,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int zk) {
                 }
             }
         if constexpr (FIN) {
-            if (p.fin && splitk_last_arrival(p, tile_m * (int)gridDim.y + tile_n)) splitk_finish_tile<BM, BN>(p, m0, n0);
+            if (MTD_IGEMM_FIN && p.fin && splitk_last_arrival(p, tile_m * (int)gridDim.y + tile_n)) splitk_finish_tile<BM, BN>(p, m0, n0);
         }
         return;
     }
@@ -898,7 +905,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tb_kernel(const IgemmParams p) {
             const int m = m0 + (wave * WM + i) * 32 + l31;
             if (m < p.M) {
                 float* row = slab + (long long)m * a.N + (n0 + 4 * kh);
-                const bool through = p.fin != 0;
+                const bool through = MTD_IGEMM_FIN && p.fin != 0;
                 if ((p.wide & 2) && !through) {
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4)
@@ -910,7 +917,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tb_kernel(const IgemmParams p) {
             }
         }
         if constexpr (WM == 1) {      // (the two-block form has no registers to spare: fill_params keeps fin off for it)
-            if (p.fin && splitk_last_arrival(p, tile_m * (int)gridDim.y + tile_n)) splitk_finish_tile<BM, 32>(p, m0, n0);
+            if (MTD_IGEMM_FIN && p.fin && splitk_last_arrival(p, tile_m * (int)gridDim.y + tile_n)) splitk_finish_tile<BM, 32>(p, m0, n0);
         }
         return;
     }
@@ -1386,10 +1393,10 @@ __global__ __launch_bounds__(256, 2) void igemm_v2_kernel(const IgemmParams p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int m = m0 + wm * 64 + i * 32 + mfma32_row(e, lane);
-                    if (m < p.M) slab_store(&slab[(long long)m * a.N + n], acc[i][j][e], p.fin != 0);
+                    if (m < p.M) slab_store(&slab[(long long)m * a.N + n], acc[i][j][e], MTD_IGEMM_FIN && p.fin != 0);
                 }
             }
-        if (p.fin && splitk_last_arrival(p, (int)(blockIdx.x * gridDim.y + blockIdx.y))) splitk_finish_tile<128, 128>(p, m0, n0);
+        if (MTD_IGEMM_FIN && p.fin && splitk_last_arrival(p, (int)(blockIdx.x * gridDim.y + blockIdx.y))) splitk_finish_tile<128, 128>(p, m0, n0);
         return;
     }
     const ScalePair sp = load_scale(a);
@@ -1603,7 +1610,7 @@ int fill_params(const mtd_conv_args* a, const Plan& pl, IgemmParams& p) {
         static const int env_fin = [] { const char* e = mtd_lab_env("MTD_SPLITK_FIN"); return e ? atoi(e) : 1; }();
         const long long tiles = (long long)((p.M + pl.BM - 1) / pl.BM) * (a->N / pl.BN);
         static const int env_fin_max = [] { const char* e = mtd_lab_env("MTD_SPLITK_FIN_MAX"); return e ? atoi(e) : 8; }();
-        p.fin = (env_fin && pl.cfg != 7 && a->tile_ctr && tiles <= (long long)a->tile_ctr_len && pl.splitk <= env_fin_max) ? (splitk_vec_ok(*a, p.M) ? 1 : 2) : 0;
+        p.fin = (MTD_IGEMM_FIN && env_fin && pl.cfg != 7 && a->tile_ctr && tiles <= (long long)a->tile_ctr_len && pl.splitk <= env_fin_max) ? (splitk_vec_ok(*a, p.M) ? 1 : 2) : 0;
     }
     return MTD_OK;
 }

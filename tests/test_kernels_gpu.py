@@ -393,6 +393,9 @@ def test_igemm_every_tile_config(hip_lib, cfg):
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 8])
 def test_splitk_finish_in_kernel_same_bits(hip_lib, cfg):
+    from mtd_gan_amd import _lib as _L
+    if not _L.lib().mtd_lab_build():
+        pytest.skip("the in-kernel split-K finish of the implicit GEMM exists in lab builds only since round 5 (it lost twice)")
     """Split-K launches that finish inside the kernel (arrival counters, mtd_conv_args.tile_ctr: the last slice to reach a
     tile sums the slabs in slice order and runs the epilogue) against the separate epilogue launch: the same bits, with
     the whole epilogue (1/sigma pair, bias, adds, LeakyReLU mask), ragged last tiles, unaligned output views (scalar form),
