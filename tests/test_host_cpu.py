@@ -226,3 +226,33 @@ def test_the_switchboard_is_frozen(built_lib, monkeypatch):
     assert _options.lab("MTD_WINOGRAD", "1") == ("0" if _options.LAB else "1")
     with pytest.raises(AssertionError):
         _options.product("MTD_WINOGRAD", "1")
+
+
+def test_product_switches_are_read_from_the_environment():
+    """The eight product variables of mtd-gan_amd/_options.py, each through the code that reads it (fresh interpreters: most are read
+    at import).  MTD_FORCE_DP and MTD_GRAPH have GPU tests of their own (tests/test_step_gpu.py, tests/test_generator_gpu.py)."""
+    import subprocess
+    import sys
+
+    def run(code, **env):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("MTD_")}
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\n" % ROOT + code], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stdout.strip().splitlines()[-1]
+    probe = ("from mtd_gan_amd import train_step as TS, _options as O\n"
+             "print(TS.LIST_MODE, TS.LIST_UNDER_DP, O.LAB, O.lab('MTD_WINOGRAD', '1'))")
+    assert run(probe) == "True True False 1"
+    assert run(probe, MTD_LIST="0", MTD_WINOGRAD="0") == "False True False 1"               # a lab variable without MTD_LAB changes nothing
+    assert run(probe, MTD_LIST_DP="0", MTD_LAB="1", MTD_WINOGRAD="0") == "True False True 0"
+    gc_probe = ("import gc\nfrom mtd_gan_amd import engine\nengine.freeze_long_lived_objects()\nprint(engine._gc_frozen[0], gc.get_freeze_count() > 0)")
+    assert run(gc_probe) == "False False"
+    assert run(gc_probe, MTD_GC_FREEZE="1") == "True True"
+    wl_probe = "import bench\nprint(bench.parse([]).workload)"
+    assert run(wl_probe) == "auto" and run(wl_probe, MTD_BENCH_WORKLOAD="generator") == "generator"
+    # MTD_DP_SHARE_GPU: read by bench.py's ranks; the launcher passes it through (two dry-run ranks come up with it set)
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    e["MTD_DP_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"],
+                       env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and '"n_gpus": 2' in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
