@@ -41,6 +41,16 @@
 #define MTD_NO_API 1
 #include "conv_igemm.hip"
 
+#ifndef W_SPREAD
+// How the K step's load instructions are issued.  0 (rounds 3-4): in bursts -- PX patch loads + PW NB weight loads at the top of the
+// step, PW NB more in the middle.  1: the first burst spread over the first half's MFMAs (two MFMAs per load).  2 (round 5, the
+// default): the second burst too, one load per four MFMAs of the second half.  An in-order wave whose load the address unit cannot
+// accept issues nothing else meanwhile, and all eight waves of the workgroup burst together after the barrier: the matrix pipe
+// stood while the queue drained (MFMA busy 51.5 % + TA busy 47.2 % = 99 % of wino_conv_kernel<2, false, 6>'s time:
+// profiles/r5_full_step_pipes_per_kernel.txt).  Measured (profiles/r5_load_spreading.txt): 53.3 -> 49.75 us on the step's average
+// launch, full step 29.05 -> 28.47 ms.
+#define W_SPREAD 2
+#endif
 #ifndef W_AUX
 #define W_AUX 0      // cache policy of the weight-fragment loads (lab: 2 = nt, streaming: the weights of a workgroup are read once)
 #endif
@@ -364,8 +374,19 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
         load_af(Ac, 0);
         load_patch(min(st + 1, st_last));
         if constexpr (!LEAN) load_b(2 * st + 1, b1);
-        __builtin_amdgcn_sched_barrier(0);
+        if (!(W_SPREAD) || LEAN) __builtin_amdgcn_sched_barrier(0);
         mfma_group(0, b0); mfma_group(1, b0); mfma_group(2, b0); mfma_group(3, b0);
+        if constexpr (W_SPREAD && !LEAN) {
+            // the step's PX + PW NB load instructions spread over the first half's MFMAs, two MFMAs per load, instead of one
+            // burst at the top (W_SPREAD above)
+            __builtin_amdgcn_sched_group_barrier(0x100, PW, 0);
+#pragma unroll
+            for (int i = 0; i < PX + PW * NB; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * PW * NB - 2 * (PX + PW * NB), 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (LEAN) load_b(2 * st + 1, b0);            // one register set: requested right before its use, the other
         load_af(Ac, 1);                                        // workgroup of the CU has the matrix pipe meanwhile
@@ -378,7 +399,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
             transform_store(An);
         } else {
             load_b(2 * min(st + 1, st_last), b0);              // (the first half's MFMAs have read b0)
-            __builtin_amdgcn_sched_barrier(0);
+            if (W_SPREAD < 2) __builtin_amdgcn_sched_barrier(0);
             mfma_group(0, b1); mfma_group(1, b1); mfma_group(2, b1); mfma_group(3, b1);
             transform_store(An);
         }
@@ -387,6 +408,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
             for (int i = 0; i < 8 * NB; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA
                 __builtin_amdgcn_sched_group_barrier(0x002, NB == 4 ? 3 : 6, 0);     // a few VALU / DPP operations
+                if (W_SPREAD >= 2 && !LEAN && (i & 3) == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              // one of the next step's weight loads
                 if ((i & (NB == 4 ? 7 : 3)) == (NB == 4 ? 7 : 3)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // an LDS store
             }
         } else {
@@ -396,6 +418,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
             for (int i = 0; i < 4 * PW * NB; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, NB == 2 ? 7 : 14, 0);
+                if (W_SPREAD >= 2 && (i & 3) == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 if ((i & (NB == 2 ? 3 : 1)) == (NB == 2 ? 3 : 1)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
         }
