@@ -102,6 +102,9 @@ __device__ __forceinline__ void wgw_quad_pair(f32x4 y, float alpha, float beta, 
     s1 = f32x4{b0, b1, b2, b3};
 }
 
+#ifndef WGW_SPREAD
+#define WGW_SPREAD 1      // 1 (round 5): a chunk's six requests one per MFMA group; 0: all at the top of the chunk
+#endif
 __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgradWinoParams wp) {
     __shared__ __attribute__((aligned(16))) float Ls[2 * WGW_BUF];         // 2 x 66 KB; the exchange image of the epilogue reuses it
     const WgradParams& p = wp.w;
@@ -149,24 +152,25 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgradWinoParam
     }
     const unsigned u_lane = (unsigned)((qp * g.IW * a.q_ld + c0 + 4 * cq) * 4);
     const unsigned p_lane = (unsigned)((((qp >> 1) * g.OW + (qp & 1)) * a.p_ld + n0 + 4 * cq) * 4);
-    auto load_next = [&](Pre& r) {
+    // (round 5) the six requests of a chunk are issued ONE PER MFMA GROUP instead of as a burst at the top of the chunk: an in-order
+    // wave whose load the address unit cannot accept yet issues no MFMA either, and all eight waves burst together after the
+    // barrier (profiles/r5_load_spreading.txt).  prep_next computes the chunk's addresses and moves the cursor on; issue_next(j)
+    // sends request j (0 .. 3: the patch row's pixels, 4: the cotangent, 5: the second cotangent).
+    unsigned nx_uv = 0, nx_pv = 0x80000000u;
+    bool nx_rowok = false;
+    int nx_tx = 0;
+    auto prep_next = [&]() {
         const bool tv = cur_tg < tile_hi;
         // U: patch row qp = image row 2 ty - 1 + qp, pixels 2 tx - 1 .. 2 tx + 2, channels c0 + 4 cq ..  (formed modulo 2^32 around
         // pixel 2 tx, which is inside the image whenever the row is: every VALID pixel's offset is in range AS the vector offset --
         // the range check does not see a scalar offset, so the column cannot travel there)
         const unsigned u_s = (((unsigned)cur_b * (unsigned)g.IH + (unsigned)(2 * cur_ty - 1)) * (unsigned)g.IW + (unsigned)(2 * cur_tx)) * (unsigned)a.q_ld * 4u;
-        const unsigned uv = u_s + u_lane;
-        const bool rowok = tv & ((unsigned)(2 * cur_ty - 1 + qp) < (unsigned)g.IH);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool colok = (unsigned)(2 * cur_tx - 1 + j) < (unsigned)g.IW;
-            r.d[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qrs, (rowok & colok) ? uv + (unsigned)((j - 1) * qpx_b) : 0x80000000u, 0, 0));
-        }
+        nx_uv = u_s + u_lane;
+        nx_rowok = tv & ((unsigned)(2 * cur_ty - 1 + qp) < (unsigned)g.IH);
+        nx_tx = cur_tx;
         // V: cotangent pixel (2 ty + (qp >> 1), 2 tx + (qp & 1)), channels n0 + 4 cq ..
         const unsigned p_s = tv ? (((unsigned)cur_b * (unsigned)g.OH + (unsigned)(2 * cur_ty)) * (unsigned)g.OW + (unsigned)(2 * cur_tx)) * (unsigned)a.p_ld * 4u : 0x80000000u;
-        const unsigned pv = p_s + p_lane;
-        r.y = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, pv, 0, 0));
-        r.y2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(p2rs, has_p2 ? pv : 0x80000000u, 0, 0));
+        nx_pv = p_s + p_lane;
         // (scalar selects, no branch: one path through the loop)
         const int adv = cur_ck < ck_last ? 1 : 0;
         cur_ck += adv;
@@ -178,6 +182,21 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgradWinoParam
         const int c2 = cur_ty >= tiles_y ? 1 : 0;
         cur_ty -= c2 ? tiles_y : 0;
         cur_b += (adv ? d_b : 0) + c2;
+    };
+    auto issue_next = [&](Pre& r, int j) {
+        if (j < 4) {
+            const bool colok = (unsigned)(2 * nx_tx - 1 + j) < (unsigned)g.IW;
+            r.d[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qrs, (nx_rowok & colok) ? nx_uv + (unsigned)((j - 1) * qpx_b) : 0x80000000u, 0, 0));
+        } else if (j == 4) {
+            r.y = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, nx_pv, 0, 0));
+        } else {
+            r.y2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(p2rs, has_p2 ? nx_pv : 0x80000000u, 0, 0));
+        }
+    };
+    auto load_next = [&](Pre& r) {
+        prep_next();
+#pragma unroll
+        for (int j = 0; j < 6; ++j) issue_next(r, j);
     };
     const float usign = qp == 1 ? 1.f : -1.f;
     // A = [1 0; 1 1; 1 -1; 0 -1]: row a = qp of A dY A^T is  alpha * R0 + beta * R1,  R_i[b] = (dY A^T)[i][b]
@@ -239,7 +258,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgradWinoParam
     auto one_chunk = [&](int k, const Pre& cur, Pre& nxt) {
         const float* Lc = Ls + (k & 1) * WGW_BUF;
         float* Ln = Ls + ((k + 1) & 1) * WGW_BUF;
-        load_next(nxt);                                                    // (chunk k + 2, or the last one again)
+        if (WGW_SPREAD) prep_next();                                       // (chunk k + 2, or the last one again)
+        else load_next(nxt);
         __builtin_amdgcn_sched_barrier(0);
         float fa[2][2], fb[2][2];                                      // [ping-pong][half]
         auto frag = [&](int gi, int pp) {                             // group gi = 2 s + x
@@ -260,6 +280,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgradWinoParam
             acc[x][0][1] = mfma32(fa[pp][0], fb[pp][1], acc[x][0][1]);
             acc[x][1][0] = mfma32(fa[pp][1], fb[pp][0], acc[x][1][0]);
             acc[x][1][1] = mfma32(fa[pp][1], fb[pp][1], acc[x][1][1]);
+            if (WGW_SPREAD && gi < 6) issue_next(nxt, gi);               // one request per MFMA group
             __builtin_amdgcn_sched_barrier(0);
             // the transform of chunk k + 1, a piece per group from the second group on (its operands were requested a chunk ago)
             if (gi >= 1 && gi <= 4) tr_u(Ln, cur, gi - 1);
