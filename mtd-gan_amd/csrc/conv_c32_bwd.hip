@@ -23,6 +23,9 @@
 #include "conv_igemm.hip"
 #include "conv_wgrad.hip"
 
+#ifndef C32F_SPREAD
+#define C32F_SPREAD 1      // weight-gradient role: a row's requests one per MFMA (0: in a burst before the row's MFMAs)
+#endif
 namespace {
 
 struct C32BwdParams {
@@ -292,12 +295,29 @@ __global__ __launch_bounds__(512, 1) void c32_bwd_kernel(const C32BwdParams fp) 
                     load_p(an);
                     load_row(0, nxt);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if (!(C32F_SPREAD)) __builtin_amdgcn_sched_barrier(0);
                 if (ty == 0) {
 #pragma unroll
                     for (int kk = 0; kk < 16; ++kk) bsum += af[kk];
                 }
                 mfma_row(ty, cur);
+                if constexpr (C32F_SPREAD) {
+                    // (round 5) this row's WIN (last row: 16 + WIN) dword requests one per MFMA instead of a burst in front of the
+                    // row's 16 TW MFMAs (profiles/r5_load_spreading.txt)
+                    if (ty + 1 < TH) {
+#pragma unroll
+                        for (int i = 0; i < WIN; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 16 + WIN; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        }
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
