@@ -238,9 +238,40 @@ __global__ __launch_bounds__(512, 1) void wino_conv3_kernel(const WinoParams wp)
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             if (u % NB == 0) load_af(Ac, u / NB);
-            mfma_unit(u, br[u % RING]);
-            if (u + RING < NU) load_b(st, u + RING, br[u % RING]);
-            else load_b(stn, u + RING - NU, br[u % RING]);
+            // the unit's six MFMAs with the three weight requests of the unit RING units ahead BETWEEN them, two MFMAs per request (the
+            // requests refill the ring slot this unit reads: each plane's request follows the last MFMA that reads that plane) --
+            // not as a burst behind the unit (profiles/r5_load_spreading.txt)
+            f32x16 c = acc[u / NB][u % NB];
+            const w3_u32x4 (&bf)[3] = br[u % RING];
+            const int lst = (u + RING < NU) ? st : stn, lu = (u + RING < NU) ? u + RING : u + RING - NU;
+            const int x = lu / NB, nb = lu % NB;
+            auto ld = [&](int pl) {
+                return __builtin_bit_cast(w3_u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, w_lane + (unsigned)(nb * 1024), w_pos0 + x * xi_stride_b + lst * chunk_b + pl * plane_b, W_AUX));
+            };
+            if (W3_SKIP & 1) {
+                mfma_unit(u, br[u % RING]);
+                load_b(lst, lu, br[u % RING]);
+            } else {
+                c = w3_mfma(af[0], bf[2], c);
+                c = w3_mfma(af[2], bf[0], c);
+                const w3_u32x4 n2 = (W3_SKIP & 4) ? bf[2] : ld(2);          // plane 2 was read by the first MFMA only
+                c = w3_mfma(af[1], bf[1], c);
+                c = w3_mfma(af[0], bf[1], c);
+                const w3_u32x4 n1 = (W3_SKIP & 4) ? bf[1] : ld(1);
+                c = w3_mfma(af[1], bf[0], c);
+                c = w3_mfma(af[0], bf[0], c);
+                const w3_u32x4 n0 = (W3_SKIP & 4) ? bf[0] : ld(0);
+                acc[u / NB][u % NB] = c;
+                br[u % RING][2] = n2;
+                br[u % RING][1] = n1;
+                br[u % RING][0] = n0;
+                if (u % NB == 0) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         transform_store(d, Lb + ((j + 1) & 1) * AS_BUF);
