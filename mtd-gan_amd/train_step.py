@@ -604,7 +604,8 @@ class RecordedTrainStep:
         return self.names, self.vals
 
 
-REPLICA_CHECKS = 3      # data-parallel replays whose result is compared across ranks (parallel.replicas_agree) before the list is trusted
+REPLICA_CHECKS = 2      # data-parallel replays whose result is compared across ranks (parallel.replicas_agree) before the list is trusted
+# (each is a host synchronisation; two fall inside the five warm-up iterations of bench.py and of a training run's first seconds)
 
 
 def _retire_list(model, optimizer_G, optimizer_D, why):
