@@ -51,6 +51,9 @@
 // launch, full step 29.05 -> 28.47 ms.
 #define W_SPREAD 2
 #endif
+#ifndef W_TRANSPOSED
+#define W_TRANSPOSED 1      // accumulator blocks transposed: the epilogue's exchange image is written as 16-byte vectors
+#endif
 #ifndef W_AUX
 #define W_AUX 0      // cache policy of the weight-fragment loads (lab: 2 = nt, streaming: the weights of a workgroup are read once)
 #endif
@@ -344,7 +347,8 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
 #pragma unroll
         for (int x = 0; x < PW; ++x)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[x][nb] = mfma32(af[x][s], bf[x][nb][s], acc[x][nb]);
+            for (int nb = 0; nb < NB; ++nb)      // (W_TRANSPOSED: the block transposed -- rows = channels, columns = tiles; same products, same sums)
+                acc[x][nb] = W_TRANSPOSED ? mfma32(bf[x][nb][s], af[x][s], acc[x][nb]) : mfma32(af[x][s], bf[x][nb][s], acc[x][nb]);
     };
 
     // ---- prologue: step 0 transformed into buffer 0, step 1's patch in flight, step 0's first weights in registers.
@@ -487,9 +491,19 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int x = 0; x < PW; ++x) {
-            float* X = Ls + (PW * wave + x) * (WT * WXLD) + l31;
+            if constexpr (W_TRANSPOSED) {
+                // round 5: the accumulator blocks are computed TRANSPOSED (mfma(b, a): a lane holds, for ITS tile l31, channels
+                // 8 g + 4 kh .. + 3 in registers 4 g .. 4 g + 3), so the exchange image is written as four 16-byte vectors per
+                // block instead of sixteen dwords: 12 / 8 LDS stores per n block and wave instead of 48 / 32
+                float* X = Ls + ((PW * wave + x) * WT + l31) * WXLD + 4 * kh;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) X[mfma32_row(e, lane) * WXLD] = acc[x][nb][e];
+                for (int gq = 0; gq < 4; ++gq)
+                    *reinterpret_cast<f32x4*>(X + 8 * gq) = f32x4{acc[x][nb][4 * gq], acc[x][nb][4 * gq + 1], acc[x][nb][4 * gq + 2], acc[x][nb][4 * gq + 3]};
+            } else {
+                float* X = Ls + (PW * wave + x) * (WT * WXLD) + l31;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) X[mfma32_row(e, lane) * WXLD] = acc[x][nb][e];
+            }
         }
         __syncthreads();
         f32x4 y[TWX];
