@@ -17,6 +17,9 @@
 //
 // Roofline: fp32 MFMA, 64 FLOP/clk/SIMD (157.3 TFLOP/s chip).  Algorithmic flops = 2*M*N*K.
 #include "common.h"
+#ifndef S2DG_PLAN
+#define S2DG_PLAN 1      // round-5 tile rules for the four-class stride-2 data gradients (make_plan)
+#endif
 #ifdef MTD_LAB
 #define MTD_IGEMM_FIN 1
 #else
@@ -1493,6 +1496,22 @@ Plan make_plan(const mtd_conv_args& a, int sets = 1) {
             pl.cfg = 7;         // tap-block kernel with two blocks per wave: 16384 x 128, 32768 x 64, 8192 x 256
         }
     }
+    // Round 5: the four-class stride-2 data gradients (sets == 4, 2 x 2 taps) had kept round 2's tiles; re-timed on the step's shapes
+    // (tools/s2_dgrad_probe.py, us per launch, plan -> new): 65536 x 4 pixels, 64 channels 119 -> 108 (256 x 64 tile); 16384 x 4, 128:
+    // 90 -> 87; 4096 x 4, 256: 95 -> 79 (256 x 32); the G step's unpaired passes 32768 x 4, 64: 61 -> 57; 8192 x 4, 128: 58 -> 48;
+    // 2048 x 4, 256: 60 -> 44 (128 x 32 WITHOUT the split of K).  The 512-channel levels keep the plan.
+    bool unsplit = false;
+    if (S2DG_PLAN && sets == 4 && a.g.TH * a.g.TW == 4) {
+        if ((a.N == 64 && M >= 131072) || (a.N == 128 && M >= 32768)) { pl.cfg = 2; unsplit = true; }
+        else if (a.N == 256 && M >= 16384) { pl.cfg = 0; unsplit = true; }
+        else if (a.N == 256 && M >= 8192) { pl.cfg = 1; unsplit = true; }
+    }
+    // ... and the first 4 x 4 stride-2 forward conv (down1: 64 -> 64 channels; tools/s2_fwd_probe.py): 65536 pixels 99 -> 82 us on the
+    // 256 x 64 tile, the G step's 32768 pixels 64 -> 45 on the 64 x 64 tile, both unsplit; the deeper levels keep the plan (it is the best there)
+    if (S2DG_PLAN && sets == 1 && a.g.TH * a.g.TW == 16 && a.N == 64 && a.C == 64) {
+        if (M >= 65536) { pl.cfg = 2; unsplit = true; }
+        else if (M >= 32768) { pl.cfg = 3; unsplit = true; }
+    }
     pl.BM = kCfgBM[pl.cfg];
     pl.BN = kCfgBN[pl.cfg];
     const long long Mset = geom_pixels(a.g);
@@ -1506,6 +1525,7 @@ Plan make_plan(const mtd_conv_args& a, int sets = 1) {
         if (pl.cfg == 2 || pl.cfg == 7) sk = 1;
         else if (pl.cfg == 6 && (long long)a.C * 9 < 4096) sk = 1;
     }
+    if (unsplit) sk = 1;
     if (sk > chunks) sk = chunks;
     if (sk > 32) sk = 32;
     if (sk < 1) sk = 1;
