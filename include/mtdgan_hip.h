@@ -128,6 +128,26 @@ int mtd_conv_winograd_ok(const mtd_conv_args* a);
 size_t mtd_conv_winograd_ws_bytes(const mtd_conv_args* a);
 int mtd_conv_winograd(const mtd_conv_args* a, void* stream);
 
+/* ---- Winograd F(3x3, 2x2) for the 4x4 / stride-2 / padding-1 layers (csrc/conv_wino_s2.h; arch/Ours/networks.py:185-215 down1..3:
+ * Conv2d(k4, s2, p1) forward and its four-parity data gradient): the forward conv is a 2x2 stride-1 conv over the 4 C channels of
+ * the space-to-depth image of the padded input (never formed: each phase is read at pixel stride 2), each parity class of the
+ * data gradient a 2x2 stride-1 conv over the cotangent; 16 multiplications per 3x3 output tile instead of 36.
+ *   mtd_winograd_s2_kmap     for a forward geometry (TH = TW = 4, in_s = 2, tap_d = 1): groups = 4 and, per phase (py, px) = group
+ *                            2 py + px, the filter entries at correlation positions (jy, jx): kmap16[4 group + 2 jy + jx];
+ *                            for a class geometry (TH = TW = 2, in_s = 1, tap_d = +-1): groups = 1, kmap16[0..3].
+ *   mtd_winograd_s2_weights  dst = [xi 0..15][groups C / 8][N][8] floats (16 groups N C), once per optimizer step.
+ *   mtd_conv_winograd_s2     a[0 .. count) as for mtd_conv_igemm_multi (count = 1: a plain launch), a[i].w = set i's transformed
+ *                            weights.  Requires C % 16 == 0, N % 64 == 0, no out2, not MTD_ACT_RELU_ADD; the sets share every operand
+ *                            but w, ws and the geometry's offsets: mtd_conv_winograd_s2_ok() (0: no; 1: in the domain; 2: and the
+ *                            plan expects it to beat mtd_conv_igemm / _multi on this shape).  Same epilogue, and with split-K the
+ *                            same workspace contract: mtd_conv_winograd_s2_ws_bytes() bytes for EACH set. */
+typedef struct { const float* src; float* dst; long long sn, sc, st; int N, C, groups; int kmap[16]; } mtd_wino_s2_weight_desc;
+int mtd_winograd_s2_kmap(const mtd_geom* g, int* groups, int* kmap16);
+int mtd_winograd_s2_weights(const mtd_wino_s2_weight_desc* table_dev, const mtd_wino_s2_weight_desc* table_host, int count, void* stream);
+int mtd_conv_winograd_s2_ok(const mtd_conv_args* a, int count);
+size_t mtd_conv_winograd_s2_ws_bytes(const mtd_conv_args* a, int count);
+int mtd_conv_winograd_s2(const mtd_conv_args* a, int count, void* stream);
+
 /* Up to four launches of ONE shape (same pixels, N, C, taps) as one grid -- the four input-parity classes of a stride-2
  * data gradient (arch/Ours/networks.py down{l}: Conv2d(k4, s2, p1) backward w.r.t. its input), each a 2x2-tap stride-1
  * gather that writes every other pixel of the same output.  a[0..count) are complete argument sets; with split-K each

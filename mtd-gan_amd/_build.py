@@ -26,8 +26,9 @@ def build(force=False, verbose=True):
     objdir = os.path.join(CSRC, "build_lab" if LAB_BUILD else "build")
     flags = FLAGS + (["-DMTD_LAB"] + os.environ.get("MTD_LAB_FLAGS", "").split() if LAB_BUILD else [])      # (MTD_LAB_FLAGS: e.g. -DW3_SKIP=1, lab probes)
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "fft64.h"), os.path.join(os.path.dirname(HERE), "include", "mtdgan_hip.h"),
-               os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_wgrad.hip"), os.path.join(CSRC, "conv_wgrad_wino.h"), os.path.join(CSRC, "conv_wino_c32.h")]      # (conv_c32_bwd.hip includes the two kernel files)
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [
+        os.path.join(os.path.dirname(HERE), "include", "mtdgan_hip.h"),
+        os.path.join(CSRC, "conv_igemm.hip"), os.path.join(CSRC, "conv_wgrad.hip")]      # (conv_c32_bwd.hip / conv_winograd.hip include the two kernel files)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     objs = []
     procs = []

@@ -45,6 +45,11 @@ class WgradArgs(C.Structure):
                 ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
 
 
+class WinoS2WeightDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("sn", C.c_longlong), ("sc", C.c_longlong), ("st", C.c_longlong),
+                ("N", C.c_int), ("C", C.c_int), ("groups", C.c_int), ("kmap", C.c_int * 16)]
+
+
 class PackDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("N", C.c_int), ("C", C.c_int), ("T", C.c_int),
                 ("sn", C.c_longlong), ("sc", C.c_longlong)]
@@ -114,7 +119,7 @@ def _preload_torch_hip_runtime():
 
 
 RECORDER = None      # kernels.LaunchList: while a step is being recorded, the list every launch is appended to
-_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "_option", "mtd_lab_build", "mtd_prof_", "_override", "_bwd_ok", "_stamps", "_zmask_bytes", "_tail_ok", "_winograd_ok", "_weight_floats", "_kmap", "_plan_cfg", "_pair_ok", "_pair_mode", "_patch_w", "_f4_min_w", "_relu_add_ok", "_wino24_min_w")
+_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "_option", "mtd_lab_build", "mtd_prof_", "_override", "_bwd_ok", "_stamps", "_zmask_bytes", "_tail_ok", "_winograd_ok", "_winograd_s2_ok", "_weight_floats", "_kmap", "_plan_cfg", "_pair_ok", "_pair_mode", "_patch_w", "_f4_min_w", "_relu_add_ok", "_wino24_min_w")
 
 
 class _RecordingLib:
@@ -258,6 +263,11 @@ def lib():
     sig("mtd_conv_winograd_f4_min_w", ci, ci)
     sig("mtd_conv_winograd_ws_bytes", sz, C.POINTER(ConvArgs))
     sig("mtd_conv_winograd", ci, C.POINTER(ConvArgs), vp)
+    sig("mtd_winograd_s2_kmap", ci, C.POINTER(Geom), C.POINTER(C.c_int), C.POINTER(C.c_int))
+    sig("mtd_winograd_s2_weights", ci, vp, vp, ci, vp)
+    sig("mtd_conv_winograd_s2_ok", ci, C.POINTER(ConvArgs), ci)
+    sig("mtd_conv_winograd_s2_ws_bytes", sz, C.POINTER(ConvArgs), ci)
+    sig("mtd_conv_winograd_s2", ci, C.POINTER(ConvArgs), ci, vp)
     sig("mtd_pcgrad_coeff", ci, vp, vp, ci, vp, vp)
     sig("mtd_pcgrad_axpy", ci, vp, vp, vp, vp, ci, ll, vp, cf, vp, vp)
     _lib = L
@@ -282,6 +292,7 @@ EXPORTS = [
     "mtd_winograd_weight_floats", "mtd_winograd_kmap", "mtd_winograd_weights", "mtd_conv_winograd_ok", "mtd_conv_winograd_ws_bytes", "mtd_conv_winograd",
     "mtd_conv_wgrad_plan_cfg", "mtd_conv_wgrad_wino24_min_w", "mtd_conv_winograd_patch_w", "mtd_conv_winograd_f4_min_w", "mtd_conv_relu_add_ok", "mtd_dropout_mask", "mtd_scale_by", "mtd_scalar_sums", "mtd_zero_multi", "mtd_checksum_multi",
     "mtd_set_option", "mtd_get_option", "mtd_lab_build",
+    "mtd_winograd_s2_kmap", "mtd_winograd_s2_weights", "mtd_conv_winograd_s2_ok", "mtd_conv_winograd_s2_ws_bytes", "mtd_conv_winograd_s2",
 ]
 
 

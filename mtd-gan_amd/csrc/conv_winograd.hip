@@ -866,3 +866,5 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
     }
     return MTD_OK;
 }
+
+#include "conv_wino_s2.h"

@@ -255,6 +255,95 @@ def winograd_weight_view(w, N, Cc, w_sn, w_sc, geom):
     return hit[0], px
 
 
+# ---- F(3x3, 2x2) for the 4x4 / stride-2 layers (csrc/conv_wino_s2.h): the forward conv and the parity classes of its data gradient
+WINO_S2 = int(_options.lab("MTD_WINO_S2", "1"))      # 0: never; 1: where the library's plan expects it to pay (mtd_conv_winograd_s2_ok == 2); 2: wherever it can
+WINO_S2_MIN_HW = int(_options.lab("MTD_WINO_S2_MIN_HW", "8"))      # smallest output map (of a set) that takes it
+_wino_s2_kmap_cache = {}
+
+
+def _wino_s2_kmap(geom):
+    key = bytes(geom)
+    hit = _wino_s2_kmap_cache.get(key)
+    if hit is None:
+        groups = C.c_int(0)
+        km = (C.c_int * 16)()
+        rc = _lib.lib().mtd_winograd_s2_kmap(C.byref(geom), C.byref(groups), km)
+        hit = (groups.value, tuple(km)) if rc == 0 else (0, ())
+        _wino_s2_kmap_cache[key] = hit
+    return hit
+
+
+def winograd_s2_takes(geom, N, Cc, kw):
+    """Host-side mirror of mtd_conv_winograd_s2_ok plus the size threshold."""
+    if not WINO_S2 or (N % 64) or (Cc % 16) or kw.get("out2") is not None or kw.get("act") == ACT_RELU_ADD:
+        return False
+    if not ((geom.TH == 4 and geom.TW == 4 and geom.in_sy == 2 and geom.in_sx == 2) or (geom.TH == 2 and geom.TW == 2 and geom.in_sy == 1 and geom.in_sx == 1)):
+        return False
+    if min(geom.OH, geom.OW) < WINO_S2_MIN_HW:
+        return False
+    return _wino_s2_kmap(geom)[0] > 0
+
+
+def winograd_s2_weight_view(w, N, Cc, w_sn, w_sc, geom):
+    """The transformed weights [xi][groups C / 8][N][8] of the view W(n, c, tap) for this geometry (mtd_winograd_s2_weights);
+    cached until the weights change."""
+    groups, kmap = _wino_s2_kmap(geom)
+    key = (w.data_ptr(), w._version, _pack_epoch, N, Cc, w_sn, w_sc, "wino_s2", kmap, groups)
+    hit = _pack_cache.get(key)
+    if hit is None:
+        skey = (w.data_ptr(), N, Cc, w_sn, w_sc, "wino_s2", kmap, groups)
+        dst = _view_buffer(skey, (16 * groups * N * Cc,), w.device)
+        d = _lib.WinoS2WeightDesc()
+        d.src, d.dst, d.sn, d.sc, d.st, d.N, d.C, d.groups = w.data_ptr(), dst.data_ptr(), w_sn, w_sc, 1, N, Cc, groups
+        for i, k in enumerate(kmap):
+            d.kmap[i] = k
+        tab, host = device_table([d], w.device)
+        check(_lib.lib().mtd_winograd_s2_weights(tab.data_ptr(), C.cast(host, C.c_void_p), 1, stream_ptr()), "mtd_winograd_s2_weights")
+        hit = (dst, w)
+        _remember(_pack_cache, skey, key, hit)
+    return hit[0]
+
+
+def _conv_winograd_s2(calls):
+    """calls: [(conv() argument tuple, keywords)] of one shape (one forward conv, or the parity classes of a data gradient).
+    True if the launch was made."""
+    L = _lib.lib()
+    arr = (ConvArgs * len(calls))(*[_conv_args(*args, pack=False, **kw) for args, kw in calls])
+    if L.mtd_conv_winograd_s2_ok(arr, len(calls)) < (1 if WINO_S2 >= 2 else 2):
+        if FLOP_COUNT is not None:
+            for args, _ in calls:
+                g = args[2]
+                FLOP_COUNT["conv_mfma"] -= 2.0 * g.B * g.OH * g.OW * args[3] * args[4] * g.TH * g.TW
+                FLOP_COUNT["launches"] -= 1
+        return False
+    for i, (args, _) in enumerate(calls):
+        x, w, geom, N, Cc, w_sn, w_sc = args[:7]
+        arr[i].w = winograd_s2_weight_view(w, N, Cc, w_sn, w_sc, geom).data_ptr()
+    x, _, geom, N, Cc = calls[0][0][:5]
+    key = ("wino_s2", bytes(geom), N, Cc, len(calls))
+    need = _igemm_ws_cache.get(key)
+    if need is None:
+        need = L.mtd_conv_winograd_s2_ws_bytes(arr, len(calls))
+        _igemm_ws_cache[key] = need
+    if need:
+        need = (need + 255) & ~255
+        ws = workspace(need * len(calls), x.device)
+        for i in range(len(calls)):
+            arr[i].ws, arr[i].ws_bytes = ws.data_ptr() + i * need, need
+    if FLOP_COUNT is not None:      # executed: 16 multiplications per 3 x 3 tile (ragged tiles in full) instead of taps per pixel
+        for args, _ in calls:
+            g = args[2]
+            full = 2.0 * g.B * g.OH * g.OW * args[3] * args[4] * g.TH * g.TW
+            groups = 4 if g.TH == 4 else 1
+            done = 2.0 * g.B * ((g.OH + 2) // 3) * ((g.OW + 2) // 3) * 16 * args[3] * args[4] * groups
+            FLOP_COUNT["conv_mfma"] -= full - done
+            FLOP_COUNT["conv_winograd_saved"] = FLOP_COUNT.get("conv_winograd_saved", 0.0) + full - done
+            if args is not calls[0][0]:
+                FLOP_COUNT["launches"] -= 1
+    check(L.mtd_conv_winograd_s2(arr, len(calls), stream_ptr()), "mtd_conv_winograd_s2")
+    return True
+
+
 def regrouped_bias(b, groups):
     """out[q * n + c] = b[c * groups + q]: the bias of a conv whose output channels are taken group by group (PixelShuffle
     classes, geom_pixel_shuffle2).  Cached like the packed weight views (dropped by weights_changed)."""
@@ -308,7 +397,8 @@ IGEMM_CONFIGS = ["igemm_kernel<2, 1, 4, 1>", "igemm_kernel<1, 1, 4, 1>", "igemm_
                  "igemm_multi_kernel<1, 1, 2, 2>", "igemm_multi_kernel<2, 2, 2, 2>", "igemm_multi_kernel<1, 1, 1, 4>",
                  "wino_conv_kernel<2, true, 4>", "wino_conv_kernel<2, false, 6>", "wino_conv_kernel<1, false, 6>",             # 22, 23, 24 (6: F(2x4, 3x3))
                  "wino_c32_kernel<false>", "wino_c32_kernel<true>",                                                             # 25, 26: the persistent 32 -> 32 channel form
-                 "wino_conv3_kernel<6>", "wino_conv3_kernel<4>"]                                                                # 27, 28: the split-bf16 forms (conv_winograd_split.h)
+                 "wino_conv3_kernel<6>", "wino_conv3_kernel<4>",                                                                # 27, 28: the split-bf16 forms (conv_winograd_split.h)
+                 "wino32_conv_kernel<2, false>", "wino32_conv_kernel<2, true>"]                                                                                       # 29: F(3x3, 2x2) for the 4x4 / stride-2 layers (conv_wino_s2.h)
 WGRAD_CONFIGS = ["wgrad_kernel<1, 1, 9>", "wgrad_kernel<1, 1, 4>", "wgrad_kernel<2, 2, 1>", "wgrad_kernel<1, 1, 8>",
                  "wgrad_kernel<1, 1, 3>", "wgrad_kernel<1, 1, 1>", "wgrad_kernel<2, 2, 3>",
                  "wgrad_row_kernel<3, 3, 1>", "wgrad_row_kernel<3, 3, -1>", "wgrad_row_kernel<1, 1, 1>",
@@ -484,6 +574,8 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, **kw):
     add2, act, mask, mask_slope, scale2, scale_split, out2 (see fuses_masked_cotangent: also store the value before the
     mask factor)."""
     L = _lib.lib()
+    if winograd_s2_takes(geom, N, Cc, kw) and _conv_winograd_s2([((x, w, geom, N, Cc, w_sn, w_sc, out), kw)]):
+        return out
     takes = winograd_takes(geom, N, Cc, kw)
     kw.pop("wino32", None)
     if takes:
@@ -557,6 +649,8 @@ def conv_multi(calls):
             conv(*args, **kw)
         return
     L = _lib.lib()
+    if all(winograd_s2_takes(args[2], N, Cc, kw) for args, kw in calls) and _conv_winograd_s2(calls):
+        return
     arr = (ConvArgs * len(calls))(*[_conv_args(*args, **kw) for args, kw in calls])
     key = ("multi", bytes(calls[0][0][2]), N, Cc, len(calls))
     need = _igemm_ws_cache.get(key)

@@ -966,3 +966,50 @@ def test_fused_c32_backward_counted_waits_same_bits(hip_lib, monkeypatch, B, sec
     assert _lib.lib().mtd_set_option(b"no_such_option", 1) != 0
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case", [(3, 64, 64, 32, 32), (2, 64, 128, 64, 64), (5, 128, 64, 16, 16), (2, 256, 256, 16, 16), (3, 64, 64, 20, 28),
+                                  (2, 512, 64, 16, 16), (2, 64, 64, 18, 18), (40, 64, 64, 32, 32)])
+def test_stride2_winograd_f33_22_vs_float64(hip_lib, case):
+    """F(3x3, 2x2) form of the 4x4 / stride-2 / padding-1 layers (csrc/conv_wino_s2.h; networks.py:185-215 down1..3): the forward
+    conv (four phases of the padded input in the K sum, ragged last tiles, full epilogue, split-K on the small grids) and the four-parity data gradient
+    as one grid (with a residual operand and the activation mask), against float64; the error may not exceed twice the implicit
+    GEMM's on the same operands (and 1e-3 in any case)."""
+    from mtd_gan_amd import kernels as K
+    B, Ci, Co, H, W = case
+    x = rnd(B, Ci, H, W, seed=31)
+    w = rnd(Co, Ci, 4, 4, seed=32, scale=0.05)
+    b = rnd(Co, seed=33)
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), None, stride=2, padding=1) * 0.7 + b.double().view(1, -1, 1, 1), 0.2)
+    OH, OW = H // 2, W // 2
+    xd, wd, bd = nhwc(x), w.cuda(), b.cuda()
+    scale = torch.tensor([0.7], device="cuda")
+    geom = K.geom_fwd(B, H, W, 4, 2, 1)
+    assert K.winograd_s2_takes(geom, Co, Ci, {})
+    outs = {}
+    for form in ("igemm", "wino"):
+        K.WINO_S2 = 2 if form == "wino" else 0
+        out = torch.full((B, OH, OW, Co), float("nan"), device="cuda")
+        K.conv(xd, wd, geom, Co, Ci, Ci * 16, 16, out, scale=scale, bias=bd, act=K.ACT_LRELU)
+        outs[form] = relerr(nchw(out).double(), ref)
+    K.WINO_S2 = 1
+    assert outs["wino"] < max(TOL * 1e-2, 2 * outs["igemm"]), outs
+    # data gradient: dx = add1 + conv_transpose(cot, w), masked by (mask > 0 ? 1 : 0.2), four classes in one grid
+    cot = rnd(B, Co, OH, OW, seed=34)
+    add = rnd(B, Ci, H, W, seed=35)
+    msk = rnd(B, Ci, H, W, seed=36)
+    want = (F.conv_transpose2d(cot.double(), w.double(), None, stride=2, padding=1) * 0.7 + add.double()) * torch.where(msk > 0, 1.0, 0.2).double()
+    cd, addd, mskd = nhwc(cot), nhwc(add), nhwc(msk)
+    errs = {}
+    for form in ("igemm", "wino"):
+        K.WINO_S2 = 2 if form == "wino" else 0
+        dx = torch.full((B, H, W, Ci), float("nan"), device="cuda")
+        calls = []
+        for py in range(2):
+            for px in range(2):
+                gp = K.geom_dgrad_s2(B, H, W, py, px)
+                calls.append(((cd, wd, gp, Ci, Co, 16, Ci * 16, dx), dict(scale=scale, add1=addd, mask=mskd, mask_slope=0.2)))
+        K.conv_multi(calls)
+        errs[form] = relerr(nchw(dx).double(), want)
+    K.WINO_S2 = 1
+    assert errs["wino"] < max(TOL * 1e-2, 2 * errs["igemm"]), errs
