@@ -280,6 +280,51 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino32_conv_kernel(const W3
                 *reinterpret_cast<f32x4*>(X + 8 * gq) = f32x4{acc[x][nb][4 * gq], acc[x][nb][4 * gq + 1], acc[x][nb][4 * gq + 2], acc[x][nb][4 * gq + 3]};
         }
         __syncthreads();
+        // the epilogue operands of the thread's (up to) six pixels are requested in ONE batch before the exchange image is read
+        // (requested pixel by pixel behind the stores, every pixel stood for a memory round trip of its own: the output may
+        // alias them as far as the compiler knows)
+        constexpr int RB = LEAN ? 1 : 2;          // rows per batch (LEAN: 128 registers)
+        int opix[2][3];          // (inside 31 bits with the channel stride applied: wino32_eligible)
+        bool pok[2][3];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int oy = 3 * ety + (rr == 0 ? ei : 2);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int ox = 3 * etx + q;
+                pok[rr][q] = etv && (rr == 0 || ei == 0) && oy < g.OH && ox < g.OW;
+                opix[rr][q] = (eb * g.OHF + oy * g.out_sy + S.out_oy) * g.OWF + ox * g.out_sx + S.out_ox;
+            }
+        }
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 e1[RB][3], e2[RB][3], em[RB][3];
+        auto load_ops = [&](int rr, int slot) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                e1[slot][q] = f32x4{-0.0f, -0.0f, -0.0f, -0.0f};
+                e2[slot][q] = e1[slot][q];
+                em[slot][q] = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (p.splitk > 1 || !pok[rr][q]) continue;
+                const long long op = opix[rr][q];
+                if (vec) {
+                    if (a.add1) e1[slot][q] = *reinterpret_cast<const f32x4*>(a.add1 + op * a.add1_ld + n);
+                    if (!LEAN && a.add2) e2[slot][q] = *reinterpret_cast<const f32x4*>(a.add2 + op * a.add2_ld + n);
+                    if (a.mask) em[slot][q] = *reinterpret_cast<const f32x4*>(a.mask + op * a.mask_ld + n);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (a.add1) e1[slot][q][c] = a.add1[op * a.add1_ld + n + c];
+                        if (!LEAN && a.add2) e2[slot][q][c] = a.add2[op * a.add2_ld + n + c];
+                        if (a.mask) em[slot][q][c] = a.mask[op * a.mask_ld + n + c];
+                    }
+                }
+            }
+        };
+        if (p.splitk == 1 && a.bias) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bias4[c] = a.bias[n + c];
+        }
+        if constexpr (!LEAN) { load_ops(0, 0); load_ops(1, 1); }
         f32x4 ta[PX], tb[PX];      // rows ei (ta) and, for ei = 0, 2 (tb) of A^T m, per patch column
 #pragma unroll
         for (int b = 0; b < PX; ++b) {
@@ -299,19 +344,26 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino32_conv_kernel(const W3
         }
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
-            const int r = rr == 0 ? ei : 2;
-            const int oy = 3 * ety + r;
-            if (!(etv && (rr == 0 || ei == 0) && oy < g.OH)) continue;
-            const f32x4* t = rr == 0 ? ta : tb;
+            const int slot = LEAN ? 0 : rr;
+            if constexpr (LEAN) {            // (one row's operands at a time, after the exchange image has been read: 128 registers)
+                __builtin_amdgcn_sched_barrier(0);
+                load_ops(rr, 0);
+            }
+            const int oy = 3 * ety + (rr == 0 ? ei : 2);
             f32x4 y[3];
-            y[0] = t[0] + t[1] + t[2];
-            y[1] = t[1] - t[2];
-            y[2] = t[1] + t[2] - t[3];
+            if (rr == 0) {
+                y[0] = ta[0] + ta[1] + ta[2];
+                y[1] = ta[1] - ta[2];
+                y[2] = ta[1] + ta[2] - ta[3];
+            } else {
+                y[0] = tb[0] + tb[1] + tb[2];
+                y[1] = tb[1] - tb[2];
+                y[2] = tb[1] + tb[2] - tb[3];
+            }
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                const int ox = 3 * etx + q;
-                if (ox >= g.OW) continue;
-                const int m = (eb * g.OH + oy) * g.OW + ox;                       // launch-grid pixel
+                if (!pok[rr][q]) continue;
+                const int m = (eb * g.OH + oy) * g.OW + 3 * etx + q;              // launch-grid pixel
                 if (p.splitk > 1) {
                     float* slab = S.ws + (long long)zk * ((long long)p.M * a.N) + (long long)m * a.N + n;
                     if (vec && (p.wide & 2)) *reinterpret_cast<f32x4*>(slab) = y[q];
@@ -320,35 +372,20 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino32_conv_kernel(const W3
                         for (int c = 0; c < 4; ++c) slab[c] = y[q][c];
                     continue;
                 }
-                const long long opix = ((long long)eb * g.OHF + oy * g.out_sy + S.out_oy) * g.OWF + ox * g.out_sx + S.out_ox;
                 const float sc = pick_scale(sp, m);
                 f32x4 v = y[q];
-                f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, e1 = {-0.0f, -0.0f, -0.0f, -0.0f}, e2 = e1, em = {1.f, 1.f, 1.f, 1.f};
-                if (vec) {
-                    if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n);
-                    if (a.add1) e1 = *reinterpret_cast<const f32x4*>(a.add1 + opix * a.add1_ld + n);
-                    if (a.add2) e2 = *reinterpret_cast<const f32x4*>(a.add2 + opix * a.add2_ld + n);
-                    if (a.mask) em = *reinterpret_cast<const f32x4*>(a.mask + opix * a.mask_ld + n);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if (a.bias) bias4[c] = a.bias[n + c];
-                        if (a.add1) e1[c] = a.add1[opix * a.add1_ld + n + c];
-                        if (a.add2) e2[c] = a.add2[opix * a.add2_ld + n + c];
-                        if (a.mask) em[c] = a.mask[opix * a.mask_ld + n + c];
-                    }
-                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float u = v[c] * sc + bias4[c];
-                    u += e1[c];
-                    u += e2[c];
+                    u += e1[slot][q][c];
+                    if constexpr (LEAN) { if (a.add2) u += a.add2[(long long)opix[rr][q] * a.add2_ld + n + c]; }      // (a rare second operand: at its use)
+                    else u += e2[slot][q][c];
                     if (a.act == MTD_ACT_RELU) u = u > 0.f ? u : 0.f;
                     else if (a.act == MTD_ACT_LRELU) u = u > 0.f ? u : 0.2f * u;
-                    if (a.mask) u *= (em[c] > 0.f) ? 1.f : a.mask_slope;
+                    if (a.mask) u *= (em[slot][q][c] > 0.f) ? 1.f : a.mask_slope;
                     v[c] = u;
                 }
-                float* o = a.out + opix * a.out_ld + n;
+                float* o = a.out + (long long)opix[rr][q] * a.out_ld + n;
                 if (vec) *reinterpret_cast<f32x4*>(o) = v;
                 else
 #pragma unroll
@@ -418,14 +455,15 @@ bool wino32_eligible(const mtd_conv_args* a, int count) {
     return true;
 }
 
-struct W32Plan { int splitk, c_per_split, tiles_x, tiles_y, ntiles, lean, pays; };
+struct W32Plan { int splitk, c_per_split, tiles_x, tiles_y, ntiles, lean, pays, nb; };
 
-W32Plan wino32_plan(const mtd_conv_args& a, int count, int groups) {
+W32Plan wino32_plan_nb(const mtd_conv_args& a, int count, int groups, int nb) {
     W32Plan pl{};
     pl.tiles_x = (a.g.OW + 2) / 3;
     pl.tiles_y = (a.g.OH + 2) / 3;
     pl.ntiles = a.g.B * pl.tiles_x * pl.tiles_y;
-    const long long blocks = (long long)((pl.ntiles + WT - 1) / WT) * (a.N / 64) * count;
+    pl.nb = nb;
+    const long long blocks = (long long)((pl.ntiles + WT - 1) / WT) * (a.N / (32 * pl.nb)) * count;
     const int chunks = groups * a.C / 16;
     int sk = blocks <= 128 ? (int)(256 / blocks) : 1;
     if (sk > chunks / 4) sk = chunks / 4;
@@ -438,13 +476,26 @@ W32Plan wino32_plan(const mtd_conv_args& a, int count, int groups) {
     pl.c_per_split = cps * 16;
     static const int env_lean = [] { const char* e = mtd_lab_env("MTD_WINO_S2_LEAN"); return e ? atoi(e) : 1; }();
     const long long grid = blocks * pl.splitk;
-    pl.lean = env_lean && (env_lean == 2 || (cps <= 8 && grid >= 384));
+    pl.lean = pl.nb == 2 && env_lean && (env_lean == 2 || (cps <= 8 && grid >= 384));
     // Does the form pay against the implicit GEMM (tools/wino_s2_probe.py, profiles/r5_wino_s2_probe.txt)?  A workgroup is 32 tiles x 64
-    // channels with a fixed cost outside its K loop, so: forward -- where the grid fills the 256 CUs' rounds to 80 % (1.2 .. 1.4x on
-    // down1 / down3 at both batch sizes and down2 at 32 images; down2 at 64 images is 144 workgroups: 0.93x); data gradient -- K is the
-    // layer's output channels, only down1's four steps in the two-per-CU form come out ahead (1.27 .. 1.34x).
+    // (or 128) channels with a fixed cost outside its K loop, so: forward -- where the grid fills the 256 CUs' rounds to 80 % (1.2 .. 1.5x
+    // on down1 / down3 at both batch sizes and down2 at 32 images); data gradient -- K is the layer's output channels, only down1's four
+    // steps in the two-per-CU form come out ahead (1.36 .. 1.42x; down2: 1.09x at 64 images, 0.72x at 32).
     const double fill = (double)grid / (double)(((grid + 255) / 256) * 256);
     pl.pays = groups == 4 ? (fill >= 0.8) : (pl.lean && chunks <= 4);
+    return pl;
+}
+
+W32Plan wino32_plan(const mtd_conv_args& a, int count, int groups) {
+    static const int env_nb = [] { const char* e = mtd_lab_env("MTD_WINO_S2_NB"); return e ? atoi(e) : 0; }();
+    if (env_nb == 4 && a.N % 128 == 0) return wino32_plan_nb(a, count, groups, 4);
+    W32Plan pl = wino32_plan_nb(a, count, groups, 2);
+    // forward grids the 64-channel workgroups leave short (down2 at 64 images: 144 of them, 0.93x): 128-channel workgroups and the
+    // split of K that goes with them (72 x 3: 1.19x)
+    if (!pl.pays && groups == 4 && a.N % 128 == 0 && env_nb != 2) {
+        const W32Plan p4 = wino32_plan_nb(a, count, groups, 4);
+        if (p4.pays) pl = p4;
+    }
     return pl;
 }
 
@@ -547,11 +598,12 @@ extern "C" int mtd_conv_winograd_s2(const mtd_conv_args* a, int count, void* str
         wp.set[i] = W32Set{s.w, s.ws, f.base_y, f.base_x, s.g.out_oy, s.g.out_ox};
     }
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((wp.ntiles + WT - 1) / WT, a[0].N / 64, pl.splitk * count);
+    const dim3 grid((wp.ntiles + WT - 1) / WT, a[0].N / (32 * pl.nb), pl.splitk * count);
     double bytes = 0.0;
     for (int i = 0; i < count; ++i) bytes += algorithmic_bytes(&a[i]);
-    const int prof = mtd_prof_begin(0, pl.lean ? 30 : 29, pl.splitk, (long long)p.M * count, a[0].N, a[0].C, a[0].g.TH * a[0].g.TW, s, bytes);
-    if (pl.lean) MTD_LAUNCH((wino32_conv_kernel<2, true>), grid, dim3(512), 0, s, wp);
+    const int prof = mtd_prof_begin(0, pl.nb == 4 ? 31 : pl.lean ? 30 : 29, pl.splitk, (long long)p.M * count, a[0].N, a[0].C, a[0].g.TH * a[0].g.TW, s, bytes);
+    if (pl.nb == 4) MTD_LAUNCH((wino32_conv_kernel<4>), grid, dim3(512), 0, s, wp);
+    else if (pl.lean) MTD_LAUNCH((wino32_conv_kernel<2, true>), grid, dim3(512), 0, s, wp);
     else MTD_LAUNCH((wino32_conv_kernel<2>), grid, dim3(512), 0, s, wp);
     mtd_prof_end(prof, s);
     MTD_LAUNCH_CHECK();

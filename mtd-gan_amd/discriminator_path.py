@@ -123,6 +123,24 @@ def winograd_views(P, backward):
     return v
 
 
+def winograd_s2_views(P, backward):
+    """The 4x4 / stride-2 `down` layers in the views kernels.conv() (forward) and kernels.conv_multi() (the four parity classes of
+    the data gradient) ask the F(3x3, 2x2) kernel's weights in, for kernels.prepack_winograd_s2 (which prepares the ones the
+    step really uses).  The geometry only selects the filter entries, so batch 1 stands in for the real batch."""
+    v = []
+    r = 64
+    for l, co in enumerate(CH, start=1):
+        w = P.get(f"down{l}.weight_orig")
+        if w is not None and r // 2 >= K.WINO_S2_MIN_HW:
+            v.append((w, co, co, co * 16, 16, K.geom_fwd(1, r, r, 4, 2, 1)))
+            if backward:
+                for py in range(2):
+                    for px in range(2):
+                        v.append((w, co, co, 16, co * 16, K.geom_dgrad_s2(1, r, r, py, px)))
+        r //= 2
+    return v
+
+
 class DiscRuntime:
     """Per-module scratch: the raw weight-gradient temp (one flat buffer shared by all SN layers)."""
 
@@ -206,6 +224,7 @@ def disc_forward(P, x, train, drop_mask, need_rec, save, sn=None, sn2=None, pair
     tp = Tape()
     K.prepack(conv_views(P, save))
     K.prepack_winograd(winograd_views(P, save))
+    K.prepack_winograd_s2(winograd_s2_views(P, save))
     tp.sig, tp.u_save, tp.v_save = sn if sn is not None else _sn_forward(P, train, dev)
     tp.pair = int(pair)
     if tp.pair:

@@ -284,6 +284,19 @@ def winograd_s2_takes(geom, N, Cc, kw):
     return _wino_s2_kmap(geom)[0] > 0
 
 
+_wino_s2_demand = set()      # the views conv() / conv_multi() have asked for (prepack_winograd_s2 transforms these, and only these, ahead)
+
+
+def _wino_s2_desc(w, N, Cc, w_sn, w_sc, groups, kmap):
+    skey = (w.data_ptr(), N, Cc, w_sn, w_sc, "wino_s2", kmap, groups)
+    dst = _view_buffer(skey, (16 * groups * N * Cc,), w.device)
+    d = _lib.WinoS2WeightDesc()
+    d.src, d.dst, d.sn, d.sc, d.st, d.N, d.C, d.groups = w.data_ptr(), dst.data_ptr(), w_sn, w_sc, 1, N, Cc, groups
+    for i, k in enumerate(kmap):
+        d.kmap[i] = k
+    return skey, d, dst
+
+
 def winograd_s2_weight_view(w, N, Cc, w_sn, w_sc, geom):
     """The transformed weights [xi][groups C / 8][N][8] of the view W(n, c, tap) for this geometry (mtd_winograd_s2_weights);
     cached until the weights change."""
@@ -291,17 +304,35 @@ def winograd_s2_weight_view(w, N, Cc, w_sn, w_sc, geom):
     key = (w.data_ptr(), w._version, _pack_epoch, N, Cc, w_sn, w_sc, "wino_s2", kmap, groups)
     hit = _pack_cache.get(key)
     if hit is None:
-        skey = (w.data_ptr(), N, Cc, w_sn, w_sc, "wino_s2", kmap, groups)
-        dst = _view_buffer(skey, (16 * groups * N * Cc,), w.device)
-        d = _lib.WinoS2WeightDesc()
-        d.src, d.dst, d.sn, d.sc, d.st, d.N, d.C, d.groups = w.data_ptr(), dst.data_ptr(), w_sn, w_sc, 1, N, Cc, groups
-        for i, k in enumerate(kmap):
-            d.kmap[i] = k
+        skey, d, dst = _wino_s2_desc(w, N, Cc, w_sn, w_sc, groups, kmap)
+        _wino_s2_demand.add(skey)
         tab, host = device_table([d], w.device)
         check(_lib.lib().mtd_winograd_s2_weights(tab.data_ptr(), C.cast(host, C.c_void_p), 1, stream_ptr()), "mtd_winograd_s2_weights")
         hit = (dst, w)
         _remember(_pack_cache, skey, key, hit)
     return hit[0]
+
+
+def prepack_winograd_s2(views):
+    """Transform, in ONE launch, those of `views` -- (w, N, C, w_sn, w_sc, geom) as conv() / conv_multi() will ask for them -- that
+    an earlier step did ask for (whether a 4x4 stride-2 launch takes the F(3x3, 2x2) form is the library's plan for its batch and
+    shape, so the first step finds out and the later ones prepare exactly those) and whose weights have changed since."""
+    todo = []
+    dev = None
+    for (w, N, Cc, w_sn, w_sc, geom) in views:
+        groups, kmap = _wino_s2_kmap(geom)
+        if not groups or (w.data_ptr(), N, Cc, w_sn, w_sc, "wino_s2", kmap, groups) not in _wino_s2_demand:
+            continue
+        key = (w.data_ptr(), w._version, _pack_epoch, N, Cc, w_sn, w_sc, "wino_s2", kmap, groups)
+        if key in _pack_cache:
+            continue
+        skey, d, dst = _wino_s2_desc(w, N, Cc, w_sn, w_sc, groups, kmap)
+        todo.append(d)
+        dev = w.device
+        _remember(_pack_cache, skey, key, (dst, w))
+    if todo:
+        tab, host = device_table(todo, dev)
+        check(_lib.lib().mtd_winograd_s2_weights(tab.data_ptr(), C.cast(host, C.c_void_p), len(todo), stream_ptr()), "mtd_winograd_s2_weights")
 
 
 def _conv_winograd_s2(calls):
@@ -398,7 +429,7 @@ IGEMM_CONFIGS = ["igemm_kernel<2, 1, 4, 1>", "igemm_kernel<1, 1, 4, 1>", "igemm_
                  "wino_conv_kernel<2, true, 4>", "wino_conv_kernel<2, false, 6>", "wino_conv_kernel<1, false, 6>",             # 22, 23, 24 (6: F(2x4, 3x3))
                  "wino_c32_kernel<false>", "wino_c32_kernel<true>",                                                             # 25, 26: the persistent 32 -> 32 channel form
                  "wino_conv3_kernel<6>", "wino_conv3_kernel<4>",                                                                # 27, 28: the split-bf16 forms (conv_winograd_split.h)
-                 "wino32_conv_kernel<2, false>", "wino32_conv_kernel<2, true>"]                                                                                       # 29: F(3x3, 2x2) for the 4x4 / stride-2 layers (conv_wino_s2.h)
+                 "wino32_conv_kernel<2, false>", "wino32_conv_kernel<2, true>", "wino32_conv_kernel<4, false>"]                                                                                       # 29: F(3x3, 2x2) for the 4x4 / stride-2 layers (conv_wino_s2.h)
 WGRAD_CONFIGS = ["wgrad_kernel<1, 1, 9>", "wgrad_kernel<1, 1, 4>", "wgrad_kernel<2, 2, 1>", "wgrad_kernel<1, 1, 8>",
                  "wgrad_kernel<1, 1, 3>", "wgrad_kernel<1, 1, 1>", "wgrad_kernel<2, 2, 3>",
                  "wgrad_row_kernel<3, 3, 1>", "wgrad_row_kernel<3, 3, -1>", "wgrad_row_kernel<1, 1, 1>",

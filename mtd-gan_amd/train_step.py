@@ -323,6 +323,7 @@ def d_loss(method, x, y):
     # scale_split).  Same arithmetic per image; half the launches, twice the pixels per launch on the deep 4x4 .. 1x1 layers.
     K.prepack(DP.conv_views(P, True))
     K.prepack_winograd(DP.winograd_views(P, True))
+    K.prepack_winograd_s2(DP.winograd_s2_views(P, True))
     sn = [DP._sn_forward(P, train, dev) for _ in range(4)]
     masks = D._next_masks(B, dev, 4)          # the four passes' dropout multipliers, stacked: (4B, 512) or None
     m12, m34 = (None, None) if masks is None else (masks[:2 * B], masks[2 * B:])
