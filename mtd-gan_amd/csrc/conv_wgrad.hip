@@ -1067,6 +1067,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(const mtd_wgra
 }
 
 #include "conv_wgrad_wino.h"
+#include "conv_wgrad_wino_s2.h"
 
 struct WPlan { int cfg, WN, WC, TG, ppw, nsplit, ntg, nw; };
 
@@ -1106,6 +1107,30 @@ WPlan make_wplan(const mtd_wgrad_args& a, const int g_wplan_div = 1) {
     else if (T <= 4) pl.cfg = 1;
     else if (T <= 9) pl.cfg = (M <= 2048) ? 4 : 0;              // few pixels, many tiles: 3 taps per wave, no pixel split
     else pl.cfg = (M >= 2048 && a.N % 64 == 0 && a.C % 64 == 0) ? 2 : 4;
+    // Winograd F(3x3, 2x2) form of the 4x4 / stride-2 layers (conv_wgrad_wino_s2.h): output maps of at least MTD_WGRAD_WINO_S2_MIN_HW
+    // pixels a side.  cfg 18; planned like cfg 16 (ppw = chunks of eight tiles per pixel split, always through slabs).
+    static const int env_ws2 = [] { const char* e = mtd_lab_env("MTD_WGRAD_WINO_S2"); return e ? atoi(e) : 1; }();
+    static const int env_ws2_hw = [] { const char* e = mtd_lab_env("MTD_WGRAD_WINO_S2_MIN_HW"); return e ? atoi(e) : 8; }();
+    if (((env_ws2 && g_wforce_cfg == -1) || g_wforce_cfg == 18) && wgrad_wino_s2_ok(a) && a.g.OH >= env_ws2_hw && a.g.OW >= env_ws2_hw) {
+        pl.cfg = 18;
+        pl.WN = 2; pl.WC = 2; pl.TG = T; pl.ntg = 1; pl.nw = 8;
+        const long long blocks = wgrad_wino_s2_blocks(a);
+        const long long chunks = (wgrad_wino_s2_tiles(a, a.g.B) + WGW_T - 1) / WGW_T;
+        long long ns = (256 + blocks - 1) / blocks;
+        if (g_wforce_split > 0) ns = g_wforce_split;
+        if (ns > chunks / 4) ns = chunks / 4;
+        if (ns < 2) ns = 2;
+        if (ns > chunks) ns = chunks;
+        const long long cps = (chunks + ns - 1) / ns;
+        ns = (chunks + cps - 1) / cps;
+        if (ns >= 2) {
+            pl.ppw = (int)cps;
+            pl.nsplit = (int)ns;
+            return pl;
+        }
+        pl = WPlan{};
+        pl.cfg = (M >= 2048 && a.N % 64 == 0 && a.C % 64 == 0) ? 2 : 4;
+    }
     static const int env_s2 = [] { const char* e = mtd_lab_env("MTD_WGRAD_S2"); return e ? atoi(e) : 1; }();
     if (a.g.TH == 4 && a.g.TW == 4 && a.g.in_sy == 2 && a.g.in_sx == 2 && a.g.off_y == -1 && a.g.off_x == -1 && a.g.tap_dy == 1 &&
         a.g.tap_dx == 1 && (a.g.OH % 8) == 0 && (a.g.OW % 8) == 0 && ((env_s2 && g_wforce_cfg == -1) || g_wforce_cfg == 15)) {
@@ -1372,6 +1397,20 @@ static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, 
             MTD_LAUNCH_CHECK();
             return MTD_OK;
         }
+        if (pl.cfg == 18) {
+            WgradWinoParams wp;
+            wp.w = p;
+            wp.tiles_x = (a->g.OW + 2) / 3;
+            wp.tiles_per_image = ((a->g.OH + 2) / 3) * wp.tiles_x;
+            wp.ntiles = a->g.B * wp.tiles_per_image;
+            wp.chunks_per_split = pl.ppw;
+            wp.ns_first = wp.first_tiles = 0;
+            wp.p_add = nullptr;
+            MTD_LAUNCH(wgrad_wino_s2_kernel, dim3(pl.nsplit, (unsigned)wgrad_wino_s2_blocks(*a)), dim3(512), 0, s, wp);
+            mtd_prof_end(prof, s);
+            MTD_LAUNCH_CHECK();
+            return MTD_OK;
+        }
         switch (pl.cfg) {
             case 0: MTD_LAUNCH((wgrad_kernel<1, 1, 9>), grid, dim3(256), 0, s, p); break;
             case 1: MTD_LAUNCH((wgrad_kernel<1, 1, 4>), grid, dim3(256), 0, s, p); break;
@@ -1522,6 +1561,18 @@ static bool wgrad_pair_plan(const mtd_wgrad_args& a, int b_first, int& ns_half, 
     mtd_wgrad_args h = a;
     h.g.B = b_first;
     const int cfg = make_wplan(h).cfg;
+    if (cfg == 18) {                       // the stride-2 Winograd kernel: the pair form of cfg 16 (slices aligned to the image ranges)
+        const long long blocks = wgrad_wino_s2_blocks(a);
+        const long long chunks = (wgrad_wino_s2_tiles(a, b_first) + WGW_T - 1) / WGW_T;
+        long long ns = (128 + blocks - 1) / blocks;
+        if (ns > chunks / 4) ns = chunks / 4;
+        if (ns < 1) ns = 1;
+        const long long c = (chunks + ns - 1) / ns;
+        ns = (chunks + c - 1) / c;
+        ns_half = -(int)ns;                // (negative: cfg 18)
+        cps = (int)c;
+        return true;
+    }
     if (cfg != 16) {                       // the general kernels: planned inside wgrad_partial
         // By default only the stride-2 halo-window kernel (cfg 15: `down` layers with output maps of at least 8x8: 14-21 us less
         // per pair).  The small-map kernels lose: their single launches have one pixel split and write the gradient themselves,
@@ -1555,7 +1606,7 @@ extern "C" int mtd_conv_wgrad_pair_mode(int mode) {
 extern "C" int mtd_conv_wgrad_pair_ok(const mtd_wgrad_args* a, int b_first) {
     int ns, cps;
     if (!a || !wgrad_pair_plan(*a, b_first, ns, cps)) return 0;
-    return ns > 0 ? 2 : 1;
+    return ns > 0 ? 2 : 1;                 // (the stride-2 Winograd kernel, ns < 0, has no second cotangent)
 }
 
 extern "C" size_t mtd_conv_wgrad_pair_ws_bytes(const mtd_wgrad_args* a, int b_first) {
@@ -1566,6 +1617,7 @@ extern "C" size_t mtd_conv_wgrad_pair_ws_bytes(const mtd_wgrad_args* a, int b_fi
         h.g.B = b_first;
         ns = make_wplan(h, 2).nsplit;
     }
+    if (ns < 0) ns = -ns;
     return wgrad_ws_floats(*a, 2 * ns) * sizeof(float);
 }
 
@@ -1579,7 +1631,9 @@ extern "C" int mtd_conv_wgrad_pair(const mtd_wgrad_args* a, float* dw2, int b_fi
 extern "C" int mtd_conv_wgrad_pair_sum(const mtd_wgrad_args* a, const float* p_add, float* dw2, int b_first, void* stream) {
     int ns_half = 0, cps = 0;
     if (!a || !dw2 || !wgrad_pair_plan(*a, b_first, ns_half, cps)) return MTD_EINVAL;
-    if (p_add && (ns_half == 0 || !aligned16(p_add))) return MTD_EINVAL;
+    if (p_add && (ns_half <= 0 || !aligned16(p_add))) return MTD_EINVAL;
+    const bool s2w = ns_half < 0;          // the stride-2 Winograd kernel (cfg 18)
+    if (s2w) ns_half = -ns_half;
     if (ns_half == 0) {                    // one of the general kernels over both problems
         mtd_wgrad_args h = *a;
         h.g.B = b_first;
@@ -1596,7 +1650,7 @@ extern "C" int mtd_conv_wgrad_pair_sum(const mtd_wgrad_args* a, const float* p_a
     WgradParams& p = wp.w;
     p.a = *a;
     p.M = (int)geom_pixels(a->g);
-    p.T = 9;
+    p.T = s2w ? 16 : 9;
     p.nslab = nsplit;
     p.slab_stride = (long long)p.T * a->N * a->C + a->N;
     for (int t = 0; t < 16; ++t) p.tap_dy[t] = p.tap_dx[t] = p.tap_delta[t] = 0;
@@ -1609,18 +1663,19 @@ extern "C" int mtd_conv_wgrad_pair_sum(const mtd_wgrad_args* a, const float* p_a
     }
     p.ppw = cps;
     p.nCt = a->C / 64;
-    const bool f24 = wgrad_wino_px(*a) == 6;
-    wp.tiles_x = a->g.OW / (f24 ? 4 : 2);
-    wp.tiles_per_image = (a->g.OH / 2) * wp.tiles_x;
+    const bool f24 = !s2w && wgrad_wino_px(*a) == 6;
+    wp.tiles_x = s2w ? (a->g.OW + 2) / 3 : a->g.OW / (f24 ? 4 : 2);
+    wp.tiles_per_image = (s2w ? (a->g.OH + 2) / 3 : a->g.OH / 2) * wp.tiles_x;
     wp.ntiles = a->g.B * wp.tiles_per_image;
     wp.chunks_per_split = cps;
     wp.ns_first = ns_half;
     wp.first_tiles = b_first * wp.tiles_per_image;
     wp.p_add = p_add;
     hipStream_t s = (hipStream_t)stream;
-    const int prof = mtd_prof_begin(1, f24 ? 17 : 16, nsplit, geom_pixels(a->g), a->N, a->C, 9, s,
-                                    4.0 * ((double)geom_pixels(a->g) * a->N + (double)a->g.B * a->g.IH * a->g.IW * a->C + 2.0 * 9 * a->N * a->C));
-    if (f24 && p_add) MTD_LAUNCH(wgrad_wino24_kernel<true>, dim3(nsplit, (unsigned)wgrad_wino_blocks(*a)), dim3(512), 0, s, wp);
+    const int prof = mtd_prof_begin(1, s2w ? 18 : f24 ? 17 : 16, nsplit, geom_pixels(a->g), a->N, a->C, p.T, s,
+                                    4.0 * ((double)geom_pixels(a->g) * a->N + (double)a->g.B * a->g.IH * a->g.IW * a->C + 2.0 * p.T * a->N * a->C));
+    if (s2w) MTD_LAUNCH(wgrad_wino_s2_kernel, dim3(nsplit, (unsigned)wgrad_wino_s2_blocks(*a)), dim3(512), 0, s, wp);
+    else if (f24 && p_add) MTD_LAUNCH(wgrad_wino24_kernel<true>, dim3(nsplit, (unsigned)wgrad_wino_blocks(*a)), dim3(512), 0, s, wp);
     else if (f24) MTD_LAUNCH(wgrad_wino24_kernel<false>, dim3(nsplit, (unsigned)wgrad_wino_blocks(*a)), dim3(512), 0, s, wp);
     else MTD_LAUNCH(wgrad_wino_kernel, dim3(nsplit, (a->N / 64) * (a->C / 64)), dim3(512), 0, s, wp);
     mtd_prof_end(prof, s);

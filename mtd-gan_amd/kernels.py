@@ -398,6 +398,7 @@ _FFT_HALF_PLANE = 2.5 * 4096 * 12 / 2
 
 
 WGRAD_CFG_WINO, WGRAD_CFG_WINO24 = 16, 17      # mtd_conv_wgrad_plan_cfg: wgrad_wino_kernel (F(2x2, 3x3)), wgrad_wino24_kernel (F(2x4, 3x3))
+WGRAD_CFG_WINO_S2 = 18                         # wgrad_wino_s2_kernel: F(3x3, 2x2) over the four phases of a 4x4 / stride-2 layer
 
 
 def _count_wgrad(geom, N, Cc, cfg):
@@ -405,8 +406,10 @@ def _count_wgrad(geom, N, Cc, cfg):
     channel counts); the Winograd kernels multiply 4 (F(2x2)) or 3 (F(2x4)) instead of 9 times per output pixel, the rest is
     `wgrad_winograd_saved`."""
     full = 2.0 * geom.B * geom.OH * geom.OW * N * Cc * geom.TH * geom.TW
-    if cfg in (WGRAD_CFG_WINO, WGRAD_CFG_WINO24):
+    if cfg in (WGRAD_CFG_WINO, WGRAD_CFG_WINO24, WGRAD_CFG_WINO_S2):
         share = 4.0 / 9.0 if cfg == WGRAD_CFG_WINO else 3.0 / 9.0
+        if cfg == WGRAD_CFG_WINO_S2:      # 16 multiplications per 3 x 3 tile (ragged tiles in full) and phase instead of 16 per pixel
+            share = ((geom.OH + 2) // 3) * ((geom.OW + 2) // 3) * 16 * 4 / (geom.OH * geom.OW * 16.0)
         _count("wgrad_mfma", full * share)
         FLOP_COUNT["wgrad_winograd_saved"] = FLOP_COUNT.get("wgrad_winograd_saved", 0.0) + full * (1.0 - share)
     else:
@@ -434,7 +437,7 @@ WGRAD_CONFIGS = ["wgrad_kernel<1, 1, 9>", "wgrad_kernel<1, 1, 4>", "wgrad_kernel
                  "wgrad_kernel<1, 1, 3>", "wgrad_kernel<1, 1, 1>", "wgrad_kernel<2, 2, 3>",
                  "wgrad_row_kernel<3, 3, 1>", "wgrad_row_kernel<3, 3, -1>", "wgrad_row_kernel<1, 1, 1>",
                  "wgrad_blk_kernel<8>", "wgrad_blk_kernel<4>", "wgrad_blk_kernel<2>", "wgrad_taps_kernel", "?", "wgrad_s2_kernel",
-                 "wgrad_wino_kernel", "wgrad_wino24_kernel"]
+                 "wgrad_wino_kernel", "wgrad_wino24_kernel", "wgrad_wino_s2_kernel"]
 
 
 SPECTRAL_KERNELS = ["rfft_rows_any_kernel", "spec_mix_any_kernel", "irfft_rows_any_kernel"]      # profiler class 2 (HBM-bound)

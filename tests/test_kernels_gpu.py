@@ -1013,3 +1013,42 @@ def test_stride2_winograd_f33_22_vs_float64(hip_lib, case):
         errs[form] = relerr(nchw(dx).double(), want)
     K.WINO_S2 = 1
     assert errs["wino"] < max(TOL * 1e-2, 2 * errs["igemm"]), errs
+
+
+@pytest.mark.parametrize("case", [(3, 64, 64, 32, 32), (2, 64, 128, 16, 16), (5, 128, 64, 8, 8), (3, 64, 64, 10, 14), (2, 128, 128, 17, 9), (16, 64, 64, 32, 32)])
+def test_stride2_winograd_weight_gradient_vs_float64(hip_lib, case):
+    """F(3x3, 2x2) weight gradient of the 4x4 / stride-2 / padding-1 layers (csrc/conv_wgrad_wino_s2.h; networks.py:185-215): the four
+    phases as 4 C channels, ragged last tiles, the bias gradient, accumulation -- against autograd in float64, with the error of
+    the halo-window / LDS-staged kernels on the same operands as the yardstick (at most twice theirs, and 1e-3 in any case).
+    case = (B, Cin, Cout, OH, OW)."""
+    from mtd_gan_amd import _lib
+    from mtd_gan_amd import kernels as K
+    B, Ci, Co, OH, OW = case
+    H, W = 2 * OH, 2 * OW
+    x = rnd(B, Ci, H, W, seed=41)
+    gy = rnd(B, Co, OH, OW, seed=42)
+    wc = torch.zeros(Co, Ci, 4, 4, dtype=torch.double, requires_grad=True)
+    bc = torch.zeros(Co, dtype=torch.double, requires_grad=True)
+    (F.conv2d(x.double(), wc, bc, stride=2, padding=1) * gy.double()).sum().backward()
+    xd, gd = nhwc(x), nhwc(gy)
+    geom = K.geom_fwd(B, H, W, 4, 2, 1)
+    L = _lib.lib()
+    errs = {}
+    for name, cfg in (("wino_s2", 18), ("other", -2)):
+        L.mtd_conv_wgrad_override(cfg, -1)
+        try:
+            dw = torch.full((Co, Ci, 4, 4), float("nan"), device="cuda")
+            db = torch.full((Co,), float("nan"), device="cuda")
+            K.wgrad(gd, xd, geom, Co, Ci, dw, Ci * 16, 16, db=db)
+            if name == "wino_s2":
+                a = K.WgradArgs()
+                a.g = geom
+                a.p, a.p_ld, a.N, a.q, a.q_ld, a.C = gd.data_ptr(), Co, Co, xd.data_ptr(), Ci, Ci
+                a.dw, a.w_sn, a.w_sc = dw.data_ptr(), Ci * 16, 16
+                assert L.mtd_conv_wgrad_plan_cfg(_lib.C.byref(a)) == 18
+                K.wgrad(gd, xd, geom, Co, Ci, dw, Ci * 16, 16, db=db, accumulate=True, accumulate_bias=True)      # twice the gradient
+                dw, db = dw * 0.5, db * 0.5
+            errs[name] = (relerr(dw.cpu().double(), wc.grad), relerr(db.cpu().double(), bc.grad))
+        finally:
+            L.mtd_conv_wgrad_override(-1, -1)
+    assert errs["wino_s2"][0] < max(TOL * 1e-2, 2 * errs["other"][0]) and errs["wino_s2"][1] < max(TOL * 1e-2, 2 * errs["other"][1]), errs
