@@ -39,6 +39,10 @@ def executed_fraction(kernel):
     """Share of a layer's algorithmic multiplications (2 M N C 9) that the kernel's MFMAs execute."""
     if "wino" not in kernel:
         return 1.0
+    if "wino32" in kernel or "wino_s2" in kernel:
+        # F(3x3, 2x2) over the 4x4 / stride-2 layers: 16 of 36 multiplications per tile -- the ragged last tiles of a 32- / 16- / 8-pixel
+        # row (6 / 27 / 27 % more) are NOT counted here, so these kernels' achieved figures are understated by that much
+        return 16.0 / 36.0
     if "wino_conv3" in kernel:      # the split-bf16 kernel (opt-in): the same multiplications, each as six bf16 MFMA products -- counted
         return WINOGRAD_F24_EXECUTED if kernel.endswith("<6>") else WINOGRAD_EXECUTED      # here in fp32-equivalent flops
     return WINOGRAD_F24_EXECUTED if (kernel.endswith(", 6>") or "wino24" in kernel or "wino_c32" in kernel) else WINOGRAD_EXECUTED
