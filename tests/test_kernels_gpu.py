@@ -969,12 +969,14 @@ def test_fused_c32_backward_counted_waits_same_bits(hip_lib, monkeypatch, B, sec
 
 
 @pytest.mark.parametrize("case", [(3, 64, 64, 32, 32), (2, 64, 128, 64, 64), (5, 128, 64, 16, 16), (2, 256, 256, 16, 16), (3, 64, 64, 20, 28),
-                                  (2, 512, 64, 16, 16), (2, 64, 64, 18, 18), (40, 64, 64, 32, 32)])
+                                  (2, 512, 64, 16, 16), (2, 64, 64, 18, 18), (26, 64, 64, 64, 64), (64, 128, 128, 32, 32)])
 def test_stride2_winograd_f33_22_vs_float64(hip_lib, case):
     """F(3x3, 2x2) form of the 4x4 / stride-2 / padding-1 layers (csrc/conv_wino_s2.h; networks.py:185-215 down1..3): the forward
     conv (four phases of the padded input in the K sum, ragged last tiles, full epilogue, split-K on the small grids) and the four-parity data gradient
     as one grid (with a residual operand and the activation mask), against float64; the error may not exceed twice the implicit
-    GEMM's on the same operands (and 1e-3 in any case)."""
+    GEMM's on the same operands (and 1e-3 in any case).  (64, 128, 128, 32, 32) = down2 at the D step's 64 images: the plan's
+    128-channel workgroups with a three-way split of K; (26, 64, 64, 64, 64): 392 workgroups of four K steps = the two-workgroups-per-CU
+    form of the data gradient."""
     from mtd_gan_amd import kernels as K
     B, Ci, Co, H, W = case
     x = rnd(B, Ci, H, W, seed=31)
