@@ -1068,6 +1068,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(const mtd_wgra
 
 #include "conv_wgrad_wino.h"
 #include "conv_wgrad_wino_s2.h"
+#include "conv_wgrad_wino32.h"
 
 struct WPlan { int cfg, WN, WC, TG, ppw, nsplit, ntg, nw; };
 
@@ -1107,6 +1108,29 @@ WPlan make_wplan(const mtd_wgrad_args& a, const int g_wplan_div = 1) {
     else if (T <= 4) pl.cfg = 1;
     else if (T <= 9) pl.cfg = (M <= 2048) ? 4 : 0;              // few pixels, many tiles: 3 taps per wave, no pixel split
     else pl.cfg = (M >= 2048 && a.N % 64 == 0 && a.C % 64 == 0) ? 2 : 4;
+    // Winograd F(2x2, 3x3) on ONE 32 x 32 block (conv_wgrad_wino32.h): the generator's 32 -> 32 layers on maps of at least
+    // MTD_WGRAD_WINO32_MIN_HW pixels a side (where the row-window kernel is the plan otherwise).  cfg 19; ppw = chunks of 16 tiles per slice.
+    static const int env_w32 = [] { const char* e = mtd_lab_env("MTD_WGRAD_WINO32"); return e ? atoi(e) : 1; }();
+    static const int env_w32_hw = [] { const char* e = mtd_lab_env("MTD_WGRAD_WINO32_MIN_HW"); return e ? atoi(e) : 32; }();
+    if (((env_w32 && g_wforce_cfg == -1) || g_wforce_cfg == 19) && wgrad_wino32_ok(a) && a.g.OH >= env_w32_hw && a.g.OW >= env_w32_hw) {
+        const long long tiles = (long long)a.g.B * (a.g.OH / 2) * (a.g.OW / 2);
+        const long long chunks = (tiles + W32_T - 1) / W32_T;
+        long long ns = 256 / g_wplan_div;
+        if (g_wforce_split > 0) ns = g_wforce_split;
+        if (ns > chunks / 4) ns = chunks / 4;
+        if (ns > chunks) ns = chunks;
+        if (ns >= 2) {
+            const long long cps = (chunks + ns - 1) / ns;
+            ns = (chunks + cps - 1) / cps;
+            if (ns >= 2) {
+                pl.cfg = 19;
+                pl.WN = 1; pl.WC = 1; pl.TG = T; pl.ntg = 1; pl.nw = 8;
+                pl.ppw = (int)cps;
+                pl.nsplit = (int)ns;
+                return pl;
+            }
+        }
+    }
     // Winograd F(3x3, 2x2) form of the 4x4 / stride-2 layers (conv_wgrad_wino_s2.h): output maps of at least MTD_WGRAD_WINO_S2_MIN_HW
     // pixels a side.  cfg 18; planned like cfg 16 (ppw = chunks of eight tiles per pixel split, always through slabs).
     static const int env_ws2 = [] { const char* e = mtd_lab_env("MTD_WGRAD_WINO_S2"); return e ? atoi(e) : 1; }();
@@ -1393,6 +1417,20 @@ static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, 
             wp.p_add = nullptr;
             if (f24) MTD_LAUNCH(wgrad_wino24_kernel<false>, dim3(pl.nsplit, (unsigned)wgrad_wino_blocks(*a)), dim3(512), 0, s, wp);
             else MTD_LAUNCH(wgrad_wino_kernel, dim3(pl.nsplit, (a->N / 64) * (a->C / 64)), dim3(512), 0, s, wp);
+            mtd_prof_end(prof, s);
+            MTD_LAUNCH_CHECK();
+            return MTD_OK;
+        }
+        if (pl.cfg == 19) {
+            WgradWinoParams wp;
+            wp.w = p;
+            wp.tiles_x = a->g.OW / 2;
+            wp.tiles_per_image = (a->g.OH / 2) * wp.tiles_x;
+            wp.ntiles = a->g.B * wp.tiles_per_image;
+            wp.chunks_per_split = pl.ppw;
+            wp.ns_first = wp.first_tiles = 0;
+            wp.p_add = nullptr;
+            MTD_LAUNCH(wgrad_wino32_kernel, dim3(pl.nsplit), dim3(512), 0, s, wp, a->g.tap_dy < 0 ? 1 : 0);
             mtd_prof_end(prof, s);
             MTD_LAUNCH_CHECK();
             return MTD_OK;

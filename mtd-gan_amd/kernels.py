@@ -399,6 +399,7 @@ _FFT_HALF_PLANE = 2.5 * 4096 * 12 / 2
 
 WGRAD_CFG_WINO, WGRAD_CFG_WINO24 = 16, 17      # mtd_conv_wgrad_plan_cfg: wgrad_wino_kernel (F(2x2, 3x3)), wgrad_wino24_kernel (F(2x4, 3x3))
 WGRAD_CFG_WINO_S2 = 18                         # wgrad_wino_s2_kernel: F(3x3, 2x2) over the four phases of a 4x4 / stride-2 layer
+WGRAD_CFG_WINO32 = 19                          # wgrad_wino32_kernel: F(2x2, 3x3) on the generator's 32 x 32 block
 
 
 def _count_wgrad(geom, N, Cc, cfg):
@@ -406,8 +407,8 @@ def _count_wgrad(geom, N, Cc, cfg):
     channel counts); the Winograd kernels multiply 4 (F(2x2)) or 3 (F(2x4)) instead of 9 times per output pixel, the rest is
     `wgrad_winograd_saved`."""
     full = 2.0 * geom.B * geom.OH * geom.OW * N * Cc * geom.TH * geom.TW
-    if cfg in (WGRAD_CFG_WINO, WGRAD_CFG_WINO24, WGRAD_CFG_WINO_S2):
-        share = 4.0 / 9.0 if cfg == WGRAD_CFG_WINO else 3.0 / 9.0
+    if cfg in (WGRAD_CFG_WINO, WGRAD_CFG_WINO24, WGRAD_CFG_WINO_S2, WGRAD_CFG_WINO32):
+        share = 4.0 / 9.0 if cfg in (WGRAD_CFG_WINO, WGRAD_CFG_WINO32) else 3.0 / 9.0
         if cfg == WGRAD_CFG_WINO_S2:      # 16 multiplications per 3 x 3 tile (ragged tiles in full) and phase instead of 16 per pixel
             share = ((geom.OH + 2) // 3) * ((geom.OW + 2) // 3) * 16 * 4 / (geom.OH * geom.OW * 16.0)
         _count("wgrad_mfma", full * share)
@@ -437,7 +438,7 @@ WGRAD_CONFIGS = ["wgrad_kernel<1, 1, 9>", "wgrad_kernel<1, 1, 4>", "wgrad_kernel
                  "wgrad_kernel<1, 1, 3>", "wgrad_kernel<1, 1, 1>", "wgrad_kernel<2, 2, 3>",
                  "wgrad_row_kernel<3, 3, 1>", "wgrad_row_kernel<3, 3, -1>", "wgrad_row_kernel<1, 1, 1>",
                  "wgrad_blk_kernel<8>", "wgrad_blk_kernel<4>", "wgrad_blk_kernel<2>", "wgrad_taps_kernel", "?", "wgrad_s2_kernel",
-                 "wgrad_wino_kernel", "wgrad_wino24_kernel", "wgrad_wino_s2_kernel"]
+                 "wgrad_wino_kernel", "wgrad_wino24_kernel", "wgrad_wino_s2_kernel", "wgrad_wino32_kernel"]
 
 
 SPECTRAL_KERNELS = ["rfft_rows_any_kernel", "spec_mix_any_kernel", "irfft_rows_any_kernel"]      # profiler class 2 (HBM-bound)
@@ -855,6 +856,7 @@ def mtd_geom_with_batch(geom, B):
 
 
 FUSE_C32_BWD = _options.lab("MTD_NO_FUSED_C32_BWD", "0") != "1"
+UNFUSE_PLAIN_C32_BWD = _options.lab("MTD_UNFUSE_PLAIN_C32_BWD", "1") == "1"
 
 
 def conv_wgrad_fusable(conv_call, wgrad_call):
@@ -893,7 +895,17 @@ def conv_wgrad_fused(conv_call, wgrad_call, defer, spec=None):
     a.db = _ptr(db)
     a.accumulate = 0
     a.ws, a.ws_bytes = None, 0
-    if not L.mtd_conv_c32_bwd_ok(C.byref(d), C.byref(a)):
+    # Round 5: a layer WITHOUT a spectral tail whose weight gradient the library plans on the Winograd 32 x 32 kernel (plan 19,
+    # csrc/conv_wgrad_wino32.h: 26 instead of 35 us) goes as two launches -- the halo-tile data gradient with all eight waves + that
+    # kernel on the side stream: generator leg 5.33 -> 5.21 ms, step -0.04 ... -0.09 ms (profiles/r5_wgrad32_probe.txt)
+    unfuse = False
+    if spec is None and UNFUSE_PLAIN_C32_BWD:
+        ukey = ("c32 unfuse", bytes(geom))
+        unfuse = _igemm_ws_cache.get(ukey)
+        if unfuse is None:
+            unfuse = L.mtd_conv_wgrad_plan_cfg(C.byref(a)) == WGRAD_CFG_WINO32
+            _igemm_ws_cache[ukey] = unfuse
+    if unfuse or not L.mtd_conv_c32_bwd_ok(C.byref(d), C.byref(a)):
         if FLOP_COUNT is not None:
             FLOP_COUNT["conv_mfma"] -= 2.0 * geom.B * geom.OH * geom.OW * N * Cc * 9      # (_conv_args counted it; conv() will again)
             FLOP_COUNT["launches"] -= 1

@@ -1054,3 +1054,48 @@ def test_stride2_winograd_weight_gradient_vs_float64(hip_lib, case):
         finally:
             L.mtd_conv_wgrad_override(-1, -1)
     assert errs["wino_s2"][0] < max(TOL * 1e-2, 2 * errs["other"][0]) and errs["wino_s2"][1] < max(TOL * 1e-2, 2 * errs["other"][1]), errs
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, False), (3, 32, 64, True), (5, 64, 32, False), (32, 64, 64, True), (3, 34, 40, False), (1, 38, 36, True)])
+def test_winograd_weight_gradient_32x32_block_vs_float64(hip_lib, case):
+    """F(2x2, 3x3) weight gradient of the generator's 32 -> 32 channel layers on one 32 x 32 block (csrc/conv_wgrad_wino32.h, plan 19;
+    networks.py:95-164): forward (Conv2d) and transposed (ConvTranspose2d: flipped taps, IOHW view) tap order, bias gradient,
+    accumulation; (3, 34, 40) / (1, 38, 36): 20 / 18 tiles per tile row -- chunks of 16 tiles that straddle rows and images, a ragged last chunk --
+    against autograd in float64, with the row-window kernel's error on the same operands as the
+    yardstick (at most twice its error, and 1e-3 in any case).  case = (B, H, W, transposed)."""
+    from mtd_gan_amd import _lib
+    from mtd_gan_amd import kernels as K
+    B, H, W, transposed = case
+    x = rnd(B, 32, H, W, seed=51)
+    gy = rnd(B, 32, H, W, seed=52)
+    if transposed:
+        wc = torch.zeros(32, 32, 3, 3, dtype=torch.double, requires_grad=True)           # ConvTranspose2d weight: [in][out][kh][kw]
+        bc = torch.zeros(32, dtype=torch.double, requires_grad=True)
+        (F.conv_transpose2d(x.double(), wc, bc, stride=1, padding=1) * gy.double()).sum().backward()
+        geom, sn, sc = K.geom_dgrad_s1(B, H, W, 3, 1), 9, 288
+    else:
+        wc = torch.zeros(32, 32, 3, 3, dtype=torch.double, requires_grad=True)
+        bc = torch.zeros(32, dtype=torch.double, requires_grad=True)
+        (F.conv2d(x.double(), wc, bc, padding=1) * gy.double()).sum().backward()
+        geom, sn, sc = K.geom_fwd(B, H, W, 3, 1, 1), 288, 9
+    xd, gd = nhwc(x), nhwc(gy)
+    L = _lib.lib()
+    errs = {}
+    for name, cfg in (("wino32", 19), ("row", 8 if transposed else 7)):
+        L.mtd_conv_wgrad_override(cfg, -1)
+        try:
+            dw = torch.full((32, 32, 3, 3), float("nan"), device="cuda")
+            db = torch.full((32,), float("nan"), device="cuda")
+            K.wgrad(gd, xd, geom, 32, 32, dw, sn, sc, db=db)
+            if name == "wino32":
+                a = K.WgradArgs()
+                a.g = geom
+                a.p, a.p_ld, a.N, a.q, a.q_ld, a.C = gd.data_ptr(), 32, 32, xd.data_ptr(), 32, 32
+                a.dw, a.w_sn, a.w_sc = dw.data_ptr(), sn, sc
+                assert L.mtd_conv_wgrad_plan_cfg(_lib.C.byref(a)) == 19
+                K.wgrad(gd, xd, geom, 32, 32, dw, sn, sc, db=db, accumulate=True, accumulate_bias=True)
+                dw, db = dw * 0.5, db * 0.5
+            errs[name] = (relerr(dw.cpu().double(), wc.grad), relerr(db.cpu().double(), bc.grad))
+        finally:
+            L.mtd_conv_wgrad_override(-1, -1)
+    assert errs["wino32"][0] < max(TOL * 1e-2, 2 * errs["row"][0]) and errs["wino32"][1] < max(TOL * 1e-2, 2 * errs["row"][1]), errs
