@@ -44,6 +44,15 @@ __device__ __forceinline__ void store_rows32(const float* lds_rows, int ld, floa
     }
 }
 
+// Lab (MTD_SPECMIX_STAGGER = d, MTD_SPECMIX_STAGGER_MOD = m): workgroups that share a CU start their compute phases d half-microseconds
+// apart (group = (linear workgroup id / 256) % m), after their input request is out -- de-phases the all-resident lock step.
+__device__ __forceinline__ void stagger_wait(int lin, int d, int m) {
+    if (d > 0) {
+        const int n = ((lin >> 8) % m) * d;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+}
+
 // position of element (row kh of a 64-row column, channel o) in the sign masks: word, bit
 __device__ __forceinline__ int mask_word(int k2, int kh, int o) {
     const int i = kh >> 5, r32 = kh & 31;
@@ -56,7 +65,8 @@ __device__ __forceinline__ int mask_bit(int kh, int o) { return (o & 31) + 32 * 
 template <int COLS>
 __global__ __launch_bounds__(128 * COLS, 3) void spec_mix_fwd4_kernel(const float* __restrict__ R, const float* __restrict__ w2t,
                                                                const float* __restrict__ b2, float* __restrict__ T,
-                                                               float* __restrict__ S_save, unsigned long long* __restrict__ zmask) {
+                                                               float* __restrict__ S_save, unsigned long long* __restrict__ zmask,
+                                                               int stg_d, int stg_m) {
     // ONE LDS image, used in turn as the DMA target (rows of 64 floats), the MFMA operand image (rows of XLD4) and the
     // staging area of the result rows (64 again): 33 KB per workgroup, so THREE workgroups per CU = 768 slots for the 544
     // units of a 32-patch launch.  With an input and an operand buffer (66 KB, two per CU, 512 slots) the last 32 units
@@ -76,6 +86,7 @@ __global__ __launch_bounds__(128 * COLS, 3) void spec_mix_fwd4_kernel(const floa
         for (int i = wave; i < n; i += 2 * COLS)
             __builtin_amdgcn_global_load_lds(R + cb0 + i * 256 + lane * 4, (lds_float4k*)(Xin + i * 256), 16, 0, 0);
     }
+    stagger_wait(blockIdx.y * gridDim.x + blockIdx.x, stg_d, stg_m);
     // transform lanes: f = transform (column kwl, channel c), j = position in the quad
     const int f = tid >> 2, j = tid & 3, kwl = f >> 5, c = f & 31;
     const bool valid = kwl == 0 || two;
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(128 * COLS, 3) void spec_mix_fwd4_kernel(const floa
 __global__ __launch_bounds__(256, 3) void spec_mix_bwd4_kernel(const float* __restrict__ gR, const float* __restrict__ w2,
                                                                const float* __restrict__ S_save,
                                                                const unsigned long long* __restrict__ zmask, float* __restrict__ gT,
-                                                               float* __restrict__ ws) {
+                                                               float* __restrict__ ws, int stg_d, int stg_m) {
     // One LDS image as in the forward kernel (DMA target -> operand image of gZ -> operand image of gS -> staging of the
     // result rows): three workgroups per CU.  The saved spectrum S, the second operand of the weight-gradient product, is
     // read straight into registers in MFMA fragment order (lane = channel, k-step = frequency pair: one dword per lane and
@@ -191,6 +202,7 @@ __global__ __launch_bounds__(256, 3) void spec_mix_bwd4_kernel(const float* __re
     float* slab = ws + (long long)unit * MIX_SLAB4;
     dma_columns(gR + cb0, Xin, wave, lane, two);
     if (tid < 128) Zm[tid] = zmask[(long long)unit * 128 + tid];
+    stagger_wait(unit, stg_d, stg_m);
     const int f = tid >> 2, j = tid & 3, kwl = f >> 5, c = f & 31;
     const bool valid = kwl == 0 || two;
     const int l31 = lane & 31, kh2 = lane >> 5;
@@ -337,12 +349,14 @@ extern "C" int mtd_spec_mix_fwd4(const float* R, const float* w2t, const float* 
     if (!aligned16(R)) return MTD_EALIGN;
     // one column per workgroup (1056 + B units of 128 threads: four per CU in flight) or a pair (544 of 256); MTD_SPECMIX_COLS
     static const int env_cols = [] { const char* e = mtd_lab_env("MTD_SPECMIX_COLS"); return e ? atoi(e) : 1; }();
+    static const int stg_d = [] { const char* e = mtd_lab_env("MTD_SPECMIX_STAGGER"); return e ? atoi(e) : 0; }();
+    static const int stg_m = [] { const char* e = mtd_lab_env("MTD_SPECMIX_STAGGER_MOD"); return e ? atoi(e) : 2; }();
     if (env_cols == 2)
         hipLaunchKernelGGL((spec_mix_fwd4_kernel<2>), dim3(17, B), dim3(256), 0, (hipStream_t)stream, R, w2t, b2, T, S_save,
-                           (unsigned long long*)zmask);
+                           (unsigned long long*)zmask, stg_d, stg_m);
     else
         hipLaunchKernelGGL((spec_mix_fwd4_kernel<1>), dim3(NKW, B), dim3(128), 0, (hipStream_t)stream, R, w2t, b2, T, S_save,
-                           (unsigned long long*)zmask);
+                           (unsigned long long*)zmask, stg_d, stg_m);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }
@@ -351,8 +365,10 @@ extern "C" int mtd_spec_mix_bwd4(const float* gR, const float* w2, const float* 
                                  void* stream) {
     if (!gR || !w2 || !S_save || !zmask || !gT || !ws || B <= 0) return MTD_EINVAL;
     if (!aligned16(gR) || !aligned16(S_save)) return MTD_EALIGN;
+    static const int stg_d = [] { const char* e = mtd_lab_env("MTD_SPECMIX_STAGGER_BWD"); return e ? atoi(e) : 0; }();
+    static const int stg_m = [] { const char* e = mtd_lab_env("MTD_SPECMIX_STAGGER_MOD"); return e ? atoi(e) : 2; }();
     hipLaunchKernelGGL(spec_mix_bwd4_kernel, dim3(17, B), dim3(256), 0, (hipStream_t)stream, gR, w2, S_save,
-                       (const unsigned long long*)zmask, gT, ws);
+                       (const unsigned long long*)zmask, gT, ws, stg_d, stg_m);
     MTD_LAUNCH_CHECK();
     return MTD_OK;
 }

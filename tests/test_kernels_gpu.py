@@ -335,6 +335,26 @@ def _spectral_path_case(K, B, four_wave):
     assert relerr(db2.cpu(), b2.grad) < 1e-4
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def plain_layer_fused(hip_lib, plan):
+    """Since plan 19 (the Winograd 32 x 32 weight gradient, csrc/conv_wgrad_wino32.h) a generator layer WITHOUT a spectral tail goes
+    as two launches (kernels.conv_wgrad_fused: `unfuse`); the fused launch stays the product path of the 21 layers that close a
+    Res-FFT-Conv block, and its weight-gradient role is the row-window kernel's arithmetic.  Tests of the fused launch on a plain
+    layer pin that plan (7: forward taps, 8: mirrored) -- and drop the routing decisions cached under the override afterwards."""
+    from mtd_gan_amd import kernels as K
+    hip_lib.mtd_conv_wgrad_override(plan, -1)
+    try:
+        yield
+    finally:
+        hip_lib.mtd_conv_wgrad_override(-1, -1)
+        for k in [k for k in K._igemm_ws_cache if isinstance(k, tuple) and k and k[0] == "c32 unfuse"]:
+            del K._igemm_ws_cache[k]
+
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", list(range(9)))
 def test_igemm_every_tile_config(hip_lib, cfg):
@@ -500,20 +520,21 @@ def test_fused_c32_backward_launch(hip_lib, B):
             dg = lambda out, out2: ((p_, w, gf, 32, 32, 32 * 9, 9, out), dict(add1=add1, mask=mask, mask_slope=0.0, out2=out2 if second else None))
             wgeo, wsn, wsc = gt, 9, 32 * 9
         res = []
-        for fused in (False, True):
-            out, out2 = torch.zeros(B, H, W, 32, device="cuda"), torch.zeros(B, H, W, 32, device="cuda")
-            dw, db = torch.zeros(32, 32, 3, 3, device="cuda"), torch.zeros(32, device="cuda")
-            defer = K.DeferredWgrads()
-            wg = ((p_, q_, wgeo, 32, 32, dw, wsn, wsc), dict(db=db))
-            call = dg(out, out2)
-            if fused:
-                assert K.conv_wgrad_fused(call, wg, defer)
-            else:
-                K.wgrad(*wg[0], db=db, defer=defer)
-                K.conv(*call[0], **call[1])
-            K.flush_wgrads(defer)
-            torch.cuda.synchronize()
-            res.append((out, out2, dw, db))
+        with plain_layer_fused(hip_lib, 7 if kind == "conv" else 8):
+            for fused in (False, True):
+                out, out2 = torch.zeros(B, H, W, 32, device="cuda"), torch.zeros(B, H, W, 32, device="cuda")
+                dw, db = torch.zeros(32, 32, 3, 3, device="cuda"), torch.zeros(32, device="cuda")
+                defer = K.DeferredWgrads()
+                wg = ((p_, q_, wgeo, 32, 32, dw, wsn, wsc), dict(db=db))
+                call = dg(out, out2)
+                if fused:
+                    assert K.conv_wgrad_fused(call, wg, defer)
+                else:
+                    K.wgrad(*wg[0], db=db, defer=defer)
+                    K.conv(*call[0], **call[1])
+                K.flush_wgrads(defer)
+                torch.cuda.synchronize()
+                res.append((out, out2, dw, db))
         (o_a, o2_a, dw_a, db_a), (o_b, o2_b, dw_b, db_b) = res
         assert torch.equal(o_a, o_b) and torch.equal(o2_a, o2_b), kind            # the halo-tile kernel's arithmetic
         if B == 32:
@@ -597,7 +618,8 @@ def test_fused_c32_backward_launch_with_row_transform(hip_lib, B):
             assert K.conv_wgrad_fused(dg, wg, defer, spec=gT)
         else:
             d1 = torch.zeros(B, H, W, 32, device="cuda")
-            assert K.conv_wgrad_fused(((gm, w, gd, 32, 32, 9, 32 * 9, d1), dict(add1=g)), wg, defer)
+            with plain_layer_fused(hip_lib, 7):
+                assert K.conv_wgrad_fused(((gm, w, gd, 32, 32, 9, 32 * 9, d1), dict(add1=g)), wg, defer)
             K.irfft_rows(gT, gx, add1=d1, mask=x)
         K.flush_wgrads(defer)
         torch.cuda.synchronize()
@@ -955,7 +977,8 @@ def test_fused_c32_backward_counted_waits_same_bits(hip_lib, monkeypatch, B, sec
         dw, db = torch.zeros(32, 32, 3, 3, device="cuda"), torch.zeros(32, device="cuda")
         defer = K.DeferredWgrads()
         call = ((p_, w, gt, 32, 32, 9, 32 * 9, out), dict(add1=add1, mask=mask, mask_slope=0.0, out2=out2 if second else None))
-        assert K.conv_wgrad_fused(call, ((p_, q_, gf, 32, 32, dw, 32 * 9, 9), dict(db=db)), defer)
+        with plain_layer_fused(hip_lib, 7):
+            assert K.conv_wgrad_fused(call, ((p_, q_, gf, 32, 32, dw, 32 * 9, 9), dict(db=db)), defer)
         K.flush_wgrads(defer)
         torch.cuda.synchronize()
         res.append((out, out2, dw, db))

@@ -847,8 +847,8 @@ def test_checkpoint_resume_like_train_py(hip_lib, tmp_path):
 def test_torch_adamw_drives_the_same_step(hip_lib):
     """The reference's own optimizer (torch.optim.AdamW, train.py:122-126) instead of FusedAdamW: gradients are ordinary
     .grad tensors and the caches of derived weight views (packed conv weights, transposed mix weights, the generator tape)
-    follow the tensors' version counters.  (a) one iteration lands where FusedAdamW lands (same gradients, the update's
-    fp32 rounding aside); (b) two iterations are bit-identical to two iterations with every cache dropped in between."""
+    follow the tensors' version counters.  (a) one iteration lands where FusedAdamW lands (same gradients -- see the note at the
+    comparison -- the update's fp32 rounding aside); (b) two iterations are bit-identical to two iterations with every cache dropped in between."""
     import random
     from mtd_gan_amd import engine, kernels as K
     from mtd_gan_amd.arch.Ours.networks import MTD_GAN_Method
@@ -874,8 +874,15 @@ def test_torch_adamw_drives_the_same_step(hip_lib):
         return {k: v.detach().clone() for k, v in m.state_dict().items()}
 
     f1, t1 = run("fused", 1), run("torch", 1)
-    for k in f1:                                  # a first AdamW step moves every weight by ~lr = 1e-4
-        assert (f1[k].double() - t1[k].double()).abs().max().item() <= 2e-7, k
+    # A first AdamW step moves every weight by ~lr = 1e-4 whatever its gradient's size: lr * g / (|g| + eps).  The two routes take the
+    # SAME gradients from the same kernels except the generator's 32 -> 32 channel 3x3 layers -- there the one-launch backward of the
+    # deferred route multiplies directly where the plain-.grad route's weight gradient is the Winograd 32 x 32 kernel (plan 19), and the
+    # two accumulate differently: 1e-6 of the tensor's largest element apart, which only an element with a vanishing gradient can see.  So: (almost) every element within the update's own
+    # fp32 rounding, at most one in a thousand beyond it, none by more than a whole step.
+    for k in f1:
+        d = (f1[k].double() - t1[k].double()).abs()
+        assert d.max().item() <= 2.1e-4, k
+        assert (d > 2e-7).double().mean().item() <= (1e-3 if k.startswith("Generator.") and tuple(f1[k].shape) == (32, 32, 3, 3) else 0.0), (k, d.max().item())
     t2, t2_fresh = run("torch", 2), run("torch", 2, drop_caches=True)
     for k in t2:
         assert torch.equal(t2[k], t2_fresh[k]), k
