@@ -60,6 +60,8 @@ def parse(argv=None):
     ap.add_argument("--no-inference", action="store_true", help="skip the configs[4] whole-slice inference object of the default workload")
     ap.add_argument("--no-wino-split", action="store_true", help="skip the information-only leg that re-times the step on the split-bf16 Winograd kernel")
     ap.add_argument("--no-engine-api", action="store_true", help="skip the engine.train_MTD_GAN_Ours leg (profiling runs: only the timed steps)")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not collect the roofline object's PMC counters in rocprofv3 child processes (the line then quotes the committed passes of profiles/)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / collective plumbing only: gloo on the CPU, a trivial step (no GPU, no HIP library)")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # launcher test: this rank exits with 3
@@ -273,6 +275,102 @@ def pmc_summary(kernel, tag):
     return traffic, u, prov
 
 
+def live_pmc_collect(workload):
+    """PMC passes of this workload taken NOW, on this box, by this run -- BEFORE this process touches the GPU (so the children are
+    ordinary child processes of a process without GPU state): three times `rocprofv3 --pmc <counter set> --kernel-trace --
+    python3 bench.py --workload ... --steps 2` (FETCH_SIZE, WRITE_SIZE and the MFMA busy pair each in a pass of its own, eager
+    single-stream launches so that every dispatch is attributed: what tools/r5_measure.sh does).  Rank 0 at N = 1 only.  Any
+    failure (no rocprofv3, a pass that fails or times out, this process itself running under a profiler) returns None and the
+    line keeps the committed, hash-gated figures of profiles/.  Returns {"sums": {pass: {(kernel, counter): [total, dispatches]}},
+    "seconds": s}."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None                       # this run is being profiled itself: no nested profiler
+    env = dict(os.environ, MTD_LAB="1", MTD_LIST="0", MTD_GRAPH="0", MTD_NO_SIDE_STREAMS="1", TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MTD_FORCE_DP"):
+        env.pop(k, None)
+    got, t0 = {}, time.time()
+    top = tempfile.mkdtemp(prefix="mtd_live_pmc_", dir="/tmp")
+    try:
+        for name, ctrs in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("mfma", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES"])):
+            out = os.path.join(top, name)
+            cmd = [exe, "--pmc"] + ctrs + ["--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "2", "--warmup", "1", "--no-roofline",
+                   "--no-cpu-baseline", "--no-generator", "--no-inference", "--no-engine-api", "--no-wino-split", "--no-live-pmc"]
+            proc = subprocess.Popen(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, 9)      # the child's own process group (start_new_session): nothing else is in it
+                except OSError:
+                    pass
+                proc.wait()
+                return None
+            if rc != 0:
+                return None
+            sums = {}
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    c = sums.setdefault((row.get("Kernel_Name", ""), row.get("Counter_Name", "?")), [0.0, 0])
+                    c[0] += float(row.get("Counter_Value", 0) or 0)
+                    c[1] += 1
+            if not sums:
+                return None
+            got[name] = sums
+        return {"sums": got, "seconds": round(time.time() - t0, 1), "workload": workload}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(top, ignore_errors=True)
+
+
+def live_pmc_lookup(data, kernel):
+    """(traffic bytes per launch, MFMA utilisation, provenance) of `kernel` from live_pmc_collect's passes, or None.  FETCH_SIZE /
+    WRITE_SIZE are KiB per dispatch; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 -- the same rule as pmc_summary()."""
+    if data is None:
+        return None
+
+    def fam(pass_name, counter):
+        tot, n = 0.0, 0
+        for (kn, cn), (t, d) in data["sums"].get(pass_name, {}).items():
+            if cn == counter and _kernel_base(kn, "<" in kernel) == kernel:
+                tot += t
+                n += d
+        return tot, n
+    (f, nf), (w, nw) = fam("fetch", "FETCH_SIZE"), fam("write", "WRITE_SIZE")
+    (mb, nm), (sb, _n) = fam("mfma", "SQ_VALU_MFMA_BUSY_CYCLES"), fam("mfma", "SQ_BUSY_CYCLES")
+    if not nf or not nw:
+        return None
+    traffic = round(2.0 * (f / nf) * 1024.0 + (w / nw) * 1024.0)
+    util = round(mb / (32.0 * sb), 4) if sb else None
+    prov = {"live": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES: one child process each, "
+                    "--kernel-trace only) of `bench.py --workload %s --steps 2 --warmup 1`, eager single-stream launches, started by THIS run "
+                    "on THIS box before its timed legs" % data["workload"],
+            "source_hash": _kernel_source_hash(), "dispatches": {"fetch": nf, "write": nw, "mfma": nm}, "seconds": data["seconds"]}
+    return traffic, util, prov
+
+
+def apply_live_pmc(roof, data):
+    """This run's own counters into a roofline object; the committed (builder-supplied, hash-gated) passes stay beside them."""
+    if not roof or data is None:
+        return
+    lp = live_pmc_lookup(data, roof["kernel"])
+    if lp is None:
+        return
+    roof["committed_pmc"] = {"traffic": roof.get("traffic"), "mfma_util_pmc": roof.get("mfma_util_pmc"), "pmc_provenance": roof.get("pmc_provenance")}
+    roof["traffic"], roof["pmc_provenance"] = lp[0], lp[2]
+    if lp[1] is not None:
+        roof["mfma_util_pmc"] = lp[1]
+
+
 # ====================================================================================================== roofline pass
 def roofline_pass(wl, steps, pmc_tag):
     """Second pass of the same K steps, every kernel in one stream, the library's launch profiler on."""
@@ -436,6 +534,16 @@ def main(argv=None):
         raise SystemExit(f"bench.py: WORLD_SIZE={world} in the environment but --gpus {args.gpus}")
     if args.dry_run:
         return dry_run(args, rank, world)
+    # (before anything here touches the GPU) the default line's PMC passes, live: see live_pmc_collect
+    live = {}
+    if world == 1 and args.gpus == 1 and not args.no_roofline and not args.no_live_pmc and args.workload in ("auto", "full_step") \
+            and os.environ.get("MTD_FORCE_DP", "0") != "1":
+        live["full_step"] = live_pmc_collect("full_step")
+        if live["full_step"] is not None:            # (a box where the first pass fails is not asked twice more)
+            if not args.no_generator:
+                live["generator"] = live_pmc_collect("generator")
+            if not args.no_inference:
+                live["inference512"] = live_pmc_collect("inference512")
     import torch
     import torch.distributed as dist
     # MTD_DP_SHARE_GPU=1: rehearsal of the N > 1 schedule on a one-GPU box -- every rank on device 0, gloo instead of RCCL
@@ -577,6 +685,10 @@ def main(argv=None):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(wl)
 
+    if rank == 0 and wl.name == "full_step":
+        apply_live_pmc(roofline, live.get("full_step"))
+        apply_live_pmc(gen.get("roofline") if gen else None, live.get("generator"))
+        apply_live_pmc(inf.get("roofline") if inf else None, live.get("inference512"))
     if rank == 0:
         line = {"metric": "GAN train-step imgs/sec (G+D fwd+bwd) @ 64x64 patch", "value": round(value, 2), "unit": "img/s",
                 "n_gpus": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),

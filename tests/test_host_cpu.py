@@ -256,3 +256,42 @@ def test_product_switches_are_read_from_the_environment():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"],
                        env=e, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and '"n_gpus": 2' in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_live_pmc_lookup_and_refusals(monkeypatch):
+    """bench.py's own PMC passes (round 5): the per-kernel arithmetic -- dispatch-weighted over every instantiation of a family,
+    one symbol for a name with template arguments, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, MFMA
+    utilisation = busy cycles / (32 x SQ busy cycles) -- and the cases in which no child process is started at all."""
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    k6 = "void (anonymous namespace)::wino_conv_kernel<2, false, 6>((anonymous namespace)::WinoParams)"
+    k4 = "void (anonymous namespace)::wino_conv_kernel<2, false, 4>((anonymous namespace)::WinoParams)"
+    data = {"workload": "full_step", "seconds": 1.0, "sums": {
+        "fetch": {(k6, "FETCH_SIZE"): [3000.0, 3], (k4, "FETCH_SIZE"): [100.0, 1]},
+        "write": {(k6, "WRITE_SIZE"): [600.0, 3], (k4, "WRITE_SIZE"): [50.0, 1]},
+        "mfma": {(k6, "SQ_VALU_MFMA_BUSY_CYCLES"): [1600.0, 3], (k6, "SQ_BUSY_CYCLES"): [100.0, 3]}}}
+    traffic, util, prov = bench.live_pmc_lookup(data, "wino_conv_kernel<2, false, 6>")
+    assert traffic == round((2 * 1000.0 + 200.0) * 1024) and util == 0.5 and prov["dispatches"] == {"fetch": 3, "write": 3, "mfma": 3}
+    assert "live" in prov and prov["source_hash"] == bench._kernel_source_hash()
+    t_family, _u, p_family = bench.live_pmc_lookup(data, "wino_conv_kernel")           # the family: both instantiations, launch-weighted
+    assert t_family == round((2 * 3100.0 / 4 + 650.0 / 4) * 1024) and p_family["dispatches"]["fetch"] == 4
+    assert bench.live_pmc_lookup(data, "igemm_kernel<1, 1, 4, 1>") is None and bench.live_pmc_lookup(None, "x") is None
+    roof = {"kernel": "wino_conv_kernel<2, false, 6>", "traffic": 7, "mfma_util_pmc": 0.1, "pmc_provenance": {"files": {}}}
+    bench.apply_live_pmc(roof, data)
+    assert roof["traffic"] == traffic and roof["mfma_util_pmc"] == 0.5 and roof["committed_pmc"]["traffic"] == 7
+    untouched = {"kernel": "igemm_kernel<1, 1, 4, 1>", "traffic": 7}
+    bench.apply_live_pmc(untouched, data)
+    assert untouched == {"kernel": "igemm_kernel<1, 1, 4, 1>", "traffic": 7}
+    # no rocprofv3 on the path / this process under a profiler: nothing is started
+    started = []
+    monkeypatch.setattr(subprocess, "Popen", lambda *a, **k: started.append(a) or (_ for _ in ()).throw(AssertionError("child started")))
+    monkeypatch.setenv("ROCPROFILER_REGISTER_ROOT", "/x")
+    assert bench.live_pmc_collect("full_step") is None and not started
+    monkeypatch.delenv("ROCPROFILER_REGISTER_ROOT")
+    import shutil
+    monkeypatch.setattr(shutil, "which", lambda _n: None)
+    monkeypatch.setattr(os.path, "exists", lambda p_, _e=os.path.exists: False if p_ == "/opt/rocm/bin/rocprofv3" else _e(p_))
+    assert bench.live_pmc_collect("full_step") is None and not started
+    assert bench.parse(["--no-live-pmc"]).no_live_pmc and not bench.parse([]).no_live_pmc
