@@ -161,6 +161,9 @@ class Tape:
     pass
 
 
+SKIP_IN_CAT = _options.lab("MTD_SKIP_IN_CAT", "1") != "0"      # trunk outputs written into the pixel-level decoder's concatenated buffers
+
+
 def _sn_forward(P, train, device):
     """Power iteration + sigma for all 45 layers (4 launches).  Returns (sig[45,2], u_save, v_save)."""
     L = _lib.lib()
@@ -234,11 +237,20 @@ def disc_forward(P, x, train, drop_mask, need_rec, save, sn=None, sn2=None, pair
     tp.x_in, tp.B, tp.drop_mask, tp.need_rec = x, B, drop_mask, need_rec
     tp.tin, tp.a, tp.xs = {}, {}, {}
     t, h, cin = x, 64, 1
+    # A trunk level's output is the skip operand of BOTH decoders' level 7 - l (networks.py:420-467: torch.cat([up, skip], 1)).  It is
+    # written straight into the channel slice [ccat - co, ccat) of the pixel-level decoder's concatenated buffer (every kernel takes a
+    # pixel stride): one copy of the skip per level and pass instead of two (18 launches of 3-25 us per iteration less).
+    seg_cat = {}
     for l, co in enumerate(CH, start=1):
         g3 = K.geom_fwd(B, h, h, 3, 1, 1)
         a = K.empty_nhwc(B, h, h, co, x)
         _sn_conv(P, tp, f"conv{l}1", t, a, g3, co, cin, 3, ACT_LRELU)
-        xl = K.empty_nhwc(B, h, h, co, x)
+        if SKIP_IN_CAT and "seg" in heads:
+            ccat = DEC[6 - l][0]
+            seg_cat[7 - l] = K.empty_nhwc(B, h, h, ccat, x)
+            xl = seg_cat[7 - l][..., ccat - co:]
+        else:
+            xl = K.empty_nhwc(B, h, h, co, x)
         _sn_conv(P, tp, f"conv{l}2", a, xl, g3, co, co, 3, ACT_LRELU)
         d = K.empty_nhwc(B, h // 2, h // 2, co, x)
         _sn_conv(P, tp, f"down{l}", xl, d, K.geom_fwd(B, h, h, 4, 2, 1), co, co, 4, ACT_NONE)
@@ -266,9 +278,11 @@ def disc_forward(P, x, train, drop_mask, need_rec, save, sn=None, sn2=None, pair
         cprev = t.shape[3]
         skip = tp.xs[7 - lvl]
         ccat, co = DEC[lvl - 1]
-        cat = K.empty_nhwc(B, r, r, ccat, x)
+        cat = seg_cat.get(lvl)
+        if cat is None:
+            cat = K.empty_nhwc(B, r, r, ccat, x)
+            K.copy_channels(skip, cat[..., cprev:])
         K.upsample2x_fwd(t, cat[..., :cprev])
-        K.copy_channels(skip, cat[..., cprev:])
         g3 = K.geom_fwd(B, r, r, 3, 1, 1)
         o1 = K.empty_nhwc(B, r, r, co, x)
         _sn_conv(P, tp, f"s_dconv{lvl}1", cat, o1, g3, co, ccat, 3, ACT_LRELU)
