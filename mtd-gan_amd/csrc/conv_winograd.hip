@@ -661,8 +661,12 @@ WinoPlan wino_plan(const mtd_conv_args& a, int pxcode) {
         blocks = ((tiles + WT - 1) / WT) * (a.N / 64);
     }
     const int chunks = a.C / 16;                                 // K steps of 16 channels
+    // K steps per slice at least: 2 since the end of round 5 (rounds 3-5: 4).  In the concurrent step the layers this frees -- C = 64 ... 128 on
+    // grids of 64 ... 128 workgroups -- gain more from the second half of the chip than the extra slab costs: 27.45 -> 27.33 ms in four A/B
+    // pairs (1: 27.37 / 27.44, 3: 27.42 / 27.40; a cap on the split or a target of 384 / 512 workgroups loses 0.4 ... 1.8 ms)
+    static const int env_sk_steps = [] { const char* e = mtd_lab_env("MTD_WINO_SPLITK_MINSTEPS"); return e ? atoi(e) : 2; }();
     int sk = blocks <= 128 ? (int)(256 / blocks) : 1;
-    if (sk > chunks / 4) sk = chunks / 4;                        // at least four steps per slice
+    if (sk > chunks / env_sk_steps) sk = chunks / env_sk_steps;
     if (sk > 16) sk = 16;
     if (sk < 1) sk = 1;
     static const int env_sk = [] { const char* e = mtd_lab_env("MTD_WINO_SPLITK"); return e ? atoi(e) : 0; }();
