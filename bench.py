@@ -293,7 +293,7 @@ def live_pmc_collect(workload):
         return None
     if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None                       # this run is being profiled itself: no nested profiler
-    env = dict(os.environ, MTD_LAB="1", MTD_LIST="0", MTD_GRAPH="0", MTD_NO_SIDE_STREAMS="1", TMPDIR="/tmp")
+    env = dict(os.environ, MTD_LAB="1", MTD_LAB_LIB="0", MTD_LIST="0", MTD_GRAPH="0", MTD_NO_SIDE_STREAMS="1", TMPDIR="/tmp")      # (the SHIPPED library)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MTD_FORCE_DP"):
         env.pop(k, None)
     got, t0 = {}, time.time()

@@ -7,8 +7,19 @@ import torch  # noqa: F401  -- must come first: torch's bundled HIP runtime has 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmtdgan_hip.so")
-if os.environ.get("MTD_LAB", "0") == "1" and os.path.exists(os.path.join(_HERE, "libmtdgan_hip_lab.so")):
-    LIB_PATH = os.path.join(_HERE, "libmtdgan_hip_lab.so")       # the -DMTD_LAB build (_options.py, _build.py): lab sessions only
+def _lab_library():
+    """The -DMTD_LAB build (_options.py, _build.py) for lab sessions: taken under MTD_LAB=1 when it exists, is not older than any
+    kernel source (a stale lab build would silently measure yesterday's kernels) and MTD_LAB_LIB=0 does not ask for the shipped
+    library with the Python-level lab switches only (bench.py's PMC child processes)."""
+    lab = os.path.join(_HERE, "libmtdgan_hip_lab.so")
+    if os.environ.get("MTD_LAB", "0") != "1" or os.environ.get("MTD_LAB_LIB", "1") == "0" or not os.path.exists(lab):
+        return None
+    csrc = os.path.join(_HERE, "csrc")
+    newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
+    return lab if os.path.getmtime(lab) >= newest else None
+
+
+LIB_PATH = _lab_library() or LIB_PATH
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_RELU_ADD = 0, 1, 2, 3
 

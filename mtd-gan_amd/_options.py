@@ -17,7 +17,9 @@ PRODUCT switches -- read from the environment by a shipped installation, each ex
 LAB switches -- the kernel-selection / ablation variables of rounds 1-4 (MTD_NO_*, MTD_WINOGRAD*, MTD_FIRST_WRITE, ...) are read
 ONLY when MTD_LAB=1 is set; without it a stray variable in a user's shell changes nothing.  The native library's own
 switches need a lab build on top (`MTD_LAB_BUILD=1 python mtd-gan_amd/_build.py`, which writes libmtdgan_hip_lab.so; it is
-loaded instead of the shipped library when MTD_LAB=1 and it exists).  Tests flip module attributes, not the environment."""
+loaded instead of the shipped library when MTD_LAB=1, it exists, it is not older than the kernel sources, and MTD_LAB_LIB=0 does
+not ask for the shipped library with the Python-level lab switches only -- bench.py's PMC child processes do).  Tests flip module
+attributes, not the environment."""
 import os
 
 LAB = os.environ.get("MTD_LAB", "0") == "1"
