@@ -279,7 +279,7 @@ def live_pmc_collect(workload):
     """PMC passes of this workload taken NOW, on this box, by this run -- BEFORE this process touches the GPU (so the children are
     ordinary child processes of a process without GPU state): three times `rocprofv3 --pmc <counter set> --kernel-trace --
     python3 bench.py --workload ... --steps 2` (FETCH_SIZE, WRITE_SIZE and the MFMA busy pair each in a pass of its own, eager
-    single-stream launches so that every dispatch is attributed: what tools/r5_measure.sh does).  Rank 0 at N = 1 only.  Any
+    single-stream launches so that every dispatch is attributed: what tools/measure.sh does).  Rank 0 at N = 1 only.  Any
     failure (no rocprofv3, a pass that fails or times out, this process itself running under a profiler) returns None and the
     line keeps the committed, hash-gated figures of profiles/.  Returns {"sums": {pass: {(kernel, counter): [total, dispatches]}},
     "seconds": s}."""
@@ -293,8 +293,13 @@ def live_pmc_collect(workload):
         return None
     if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None                       # this run is being profiled itself: no nested profiler
-    env = dict(os.environ, MTD_LAB="1", MTD_LAB_LIB="0", MTD_LIST="0", MTD_GRAPH="0", MTD_NO_SIDE_STREAMS="1", TMPDIR="/tmp")      # (the SHIPPED library)
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MTD_FORCE_DP"):
+    if os.environ.get("MTD_LAB", "0") == "1" and os.environ.get("MTD_LAB_LIB", "1") != "0":
+        return None                       # this run may be timed on the lab library: children on the shipped one would measure another build
+    # the children run the SHIPPED library with exactly the five switches below: every other MTD_* variable of the caller's shell
+    # (a stray MTD_WINOGRAD=0 ...) is dropped, because MTD_LAB=1 would make it live in the children while the timed parent ignores it
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MTD_")}
+    env.update(MTD_LAB="1", MTD_LAB_LIB="0", MTD_LIST="0", MTD_GRAPH="0", MTD_NO_SIDE_STREAMS="1", TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     got, t0 = {}, time.time()
     top = tempfile.mkdtemp(prefix="mtd_live_pmc_", dir="/tmp")
@@ -478,6 +483,67 @@ def timed(wl, steps, warmup, barrier):
     return time.perf_counter() - t0
 
 
+# ====================================================================================================== N > 1 diagnostics
+def comm_diagnostics(wl, dev, world, steps, barrier, ms_step, avg_max):
+    """What a reader of the N > 1 line needs beside `value` ("achieved all-reduce bus GB/s vs 7 x 153 GB/s"):
+      allreduce_payload_mb   bytes one iteration all-reduces (three per-task shared-gradient vectors + the task-specific bucket of the
+                             discriminator step + the generator's flat gradient)
+      allreduce_alg_gbs /    a stand-alone all-reduce of four buffers of exactly those sizes (the three task vectors + the bucket),
+      allreduce_bus_gbs      nothing else on the GPU, timed over `reps` rounds: bytes / time, and x 2 (N - 1) / N (RCCL's bus bandwidth:
+                             what each rank's links carry; null at N = 1), against xGMI's 7 x 153 GB/s per GPU
+      comm_exposed_ms        (timed step) - (the same step, same ranks, same launch list, with every data-path collective a no-op:
+                             parallel.DataParallelSync.stub) -- the part of the collectives the backward kernels do NOT hide.
+                             Measured LAST: the replicas drift apart while the collectives are stubbed
+      launch_mode_per_rank   every rank's launch mode (a rank that fell back to eager launches would pace the others)
+    Runs after the timed region; `avg_max(seconds)` -> max over ranks."""
+    import torch
+    import torch.distributed as dist
+    dp = getattr(wl, "dp", None)
+    if dp is None or not dist.is_initialized():
+        return {}
+    D, G = wl.model.Discriminator, wl.model.Generator
+    n_shared = sum(p.numel() for p in D.shared_parameters())
+    n_spec = sum(p.numel() for p in D.task_specific_parameters())
+    n_gen = sum(p.numel() for p in G.parameters())
+    out = {"allreduce_payload_mb": round(4 * (3 * n_shared + n_spec + n_gen) / 1e6, 2),
+           "allreduce_messages_mb": [round(4 * n / 1e6, 2) for n in (n_shared, n_shared, n_shared, n_spec, n_gen)]}
+    on_gpu = dist.get_backend() == "nccl"
+    bufs = [torch.zeros(n, device=dev if on_gpu else None) for n in (n_shared, n_shared, n_shared, n_spec)]
+    nbytes = 4 * (3 * n_shared + n_spec)
+
+    def rounds(k):
+        for _ in range(k):
+            for b in bufs:
+                dist.all_reduce(b, op=dist.ReduceOp.SUM)
+    rounds(2)
+    reps = 5
+    barrier()
+    t0 = time.perf_counter()
+    rounds(reps)
+    barrier()
+    t = avg_max(time.perf_counter() - t0) / reps
+    alg = nbytes / t / 1e9
+    out["allreduce_standalone_ms"] = round(1e3 * t, 3)
+    out["allreduce_alg_gbs"] = round(alg, 1)
+    out["allreduce_bus_gbs"] = round(alg * 2.0 * (world - 1) / world, 1) if world > 1 else None
+    out["xgmi_peak_gbs_per_gpu"] = 7 * 153
+    out["allreduce_backend"] = dist.get_backend() + (" (RCCL)" if on_gpu else " (through the host: rehearsal)")
+    del bufs
+    modes = [None] * world
+    dist.all_gather_object(modes, wl.extra().get("launch_mode"))
+    out["launch_mode_per_rank"] = modes
+    # last: the same step with the collectives stubbed
+    dp.stub = True
+    try:
+        sdt = avg_max(timed(wl, steps, 2, barrier))
+    finally:
+        dp.stub = False
+    ms_stub = 1e3 * sdt / steps
+    out["ms_per_step_collectives_stubbed"] = round(ms_stub, 3)
+    out["comm_exposed_ms"] = round(ms_step - ms_stub, 3)
+    return out
+
+
 # ====================================================================================================== dry run
 def dry_run(args, rank, world):
     """Launcher / rendezvous / max-over-ranks plumbing on the CPU (gloo): what tests/test_bench_launcher.py drives."""
@@ -507,15 +573,49 @@ def dry_run(args, rank, world):
     for _ in range(args.steps):
         step()
     barrier()
-    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    def avg_max(sec):
+        t = torch.tensor([sec], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    dt = avg_max(time.perf_counter() - t0)
+    comm = {}
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+        # the N > 1 line's diagnostics through the same code as the GPU run (comm_diagnostics), on a stand-in workload whose
+        # "model" has the partition methods it sizes the payload from and whose step all-reduces through a DataParallelSync
+        from mtd_gan_amd import parallel
+
+        class _Part(torch.nn.Module):
+            def __init__(self, n_shared, n_spec):
+                super().__init__()
+                self.a, self.b = torch.nn.Parameter(torch.zeros(n_shared)), torch.nn.Parameter(torch.zeros(n_spec))
+
+            def shared_parameters(self):
+                return [self.a]
+
+            def task_specific_parameters(self):
+                return [self.b]
+
+        class _Model:
+            Discriminator, Generator = _Part(4096, 2048), _Part(512, 0)
+
+        class _Wl:
+            model, dp = _Model(), parallel.DataParallelSync(None)
+
+            def step(self):
+                w = v * 2.0
+                self.dp.all_reduce_avg(w)
+
+            def extra(self):
+                return {"launch_mode": "dry run (rank %d)" % rank}
+        comm = comm_diagnostics(_Wl(), None, world, args.steps, barrier, 1e3 * dt / args.steps, avg_max)
     if rank == 0:
-        print(json.dumps({"metric": "dry run (launcher plumbing, gloo on the CPU)", "value": round(PER_GPU_BATCH * seen * args.steps / dt, 2),
-                          "unit": "img/s", "n_gpus": seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "dry-run"}, "roofline": None, "cpu_baseline": None}), flush=True)
+        line = {"metric": "dry run (launcher plumbing, gloo on the CPU)", "value": round(PER_GPU_BATCH * seen * args.steps / dt, 2),
+                "unit": "img/s", "n_gpus": seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "dry-run"}, "roofline": None, "cpu_baseline": None, "ranks_seen": seen}
+        line.update(comm)
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
     return 0
@@ -590,11 +690,14 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize()
 
-    dt = timed(wl, args.steps, args.warmup, barrier)
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    def avg_max(sec):
+        if world == 1:
+            return sec
+        t = torch.tensor([sec], device=None if share_gpu else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
+
+    dt = avg_max(timed(wl, args.steps, args.warmup, barrier))
     ms = 1e3 * dt / args.steps
     value = per_gpu_units * ranks_seen * args.steps / dt
 
@@ -613,11 +716,7 @@ def main(argv=None):
     gen = None
     if wl.name == "full_step" and not args.no_generator:
         gw = BW.make("generator", dev, rank, world, PER_GPU_BATCH)
-        gdt = timed(gw, args.steps, args.warmup, barrier)
-        if world > 1:
-            t = torch.tensor([gdt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            gdt = float(t.item())
+        gdt = avg_max(timed(gw, args.steps, args.warmup, barrier))
         gms = 1e3 * gdt / args.steps
         gtf = gw.gflop_per_patch * PER_GPU_BATCH / (gms * 1e-3) / 1e3
         gen = {"config": gw.config(ranks_seen), "value": round(PER_GPU_BATCH * ranks_seen * args.steps / gdt, 2), "unit": "img/s",
@@ -685,6 +784,12 @@ def main(argv=None):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(wl)
 
+    # ---- the N > 1 line's diagnostics (also under MTD_FORCE_DP=1 on one rank): after everything that feeds the line, since the
+    # last of them runs the step with its collectives stubbed
+    comm = {}
+    if wl.name == "full_step" and dist.is_initialized():
+        comm = comm_diagnostics(wl, dev, world, args.steps, barrier, ms, avg_max)
+
     if rank == 0 and wl.name == "full_step":
         apply_live_pmc(roofline, live.get("full_step"))
         apply_live_pmc(gen.get("roofline") if gen else None, live.get("generator"))
@@ -698,6 +803,8 @@ def main(argv=None):
             line["config"]["parallelism"] += " (rehearsal: all ranks on ONE GPU, gloo through the host -- not a scaling figure)"
         line.update(wl.extra())
         line.update(extra)
+        line["ranks_seen"] = ranks_seen
+        line.update(comm)
         if api_ms is not None:
             ams = api_ms
             line["engine_api"] = {"ms_per_step": round(ams, 3), "value": round(per_gpu_units * 1e3 / ams, 2), "unit": "img/s",

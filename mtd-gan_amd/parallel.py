@@ -25,6 +25,17 @@ class DataParallelSync:
         self.has_avg = dist.get_backend() == "nccl"
         self.side = torch.cuda.Stream(device=device) if self.cuda else None
         self._pending = False
+        # stub = True: every data-path collective (all-reduce of gradients, broadcast of the projection order) becomes a no-op AT CALL
+        # TIME -- the stream hand-offs around it stay, and so does a recorded launch list (its entries are these closures).  A
+        # measurement switch: bench.py's `comm_exposed_ms` is (step) - (step with stub).  The replicas drift apart while it is on.
+        self.stub = False
+
+    def _coll(self, fn):
+        """A data-path collective as a closure that honours `stub` when it RUNS (also when a launch list replays it)."""
+        def run():
+            if not self.stub:
+                fn()
+        return run
 
     def broadcast_module(self, module):
         """Rank 0's parameters and buffers to every rank.  The weights change under every cache of derived quantities
@@ -37,6 +48,22 @@ class DataParallelSync:
                 dist.broadcast(t.detach(), src=0)          # shares the version counter with t (unlike t.data)
         K.weights_changed(params)
         K.weights_changed(None)
+
+    def broadcast_optimizer_state(self, optimizers):
+        """Rank 0's AdamW moment tensors (exp_avg, exp_avg_sq) and step counters to every rank, in place: the companion of
+        broadcast_module when replicas have drifted (train_step.recorded_iteration) -- moments that were updated from diverged
+        gradients would pull the re-broadcast weights apart again on the next step."""
+        with torch.no_grad():
+            for opt in optimizers:
+                for group in opt.param_groups:
+                    for p in group["params"]:
+                        st = opt.state.get(p)
+                        if not st:
+                            continue
+                        for key in ("exp_avg", "exp_avg_sq", "step"):
+                            t = st.get(key)
+                            if torch.is_tensor(t):
+                                dist.broadcast(t, src=0)
 
     def broadcast_orders(self, orders, device=None, upload=None):
         """The PCGrad projection order of this step as ONE collective decision: rank 0's draw wins.  Every rank still
@@ -52,10 +79,10 @@ class DataParallelSync:
         if self.cuda:
             t = upload(flat) if upload is not None else torch.tensor(flat, dtype=torch.int32).to(device or self.device)
             if self.world > 1 or self.force:
-                self._on_side(lambda: dist.broadcast(t, src=0), t)
+                self._on_side(self._coll(lambda: dist.broadcast(t, src=0)), t)
             return t
         t = torch.tensor(flat, dtype=torch.int32)
-        if self.world > 1:
+        if self.world > 1 and not self.stub:
             dist.broadcast(t, src=0)
         return t
 
@@ -83,12 +110,12 @@ class DataParallelSync:
         self.wait()                                   # (collectives on the side stream that may touch the same communicator: keep issue order)
         if self.has_avg:
             op = dist.ReduceOp.AVG if self.world > 1 else dist.ReduceOp.SUM
-            K.rec(lambda: dist.all_reduce(flat, op=op))
+            K.rec(self._coll(lambda: dist.all_reduce(flat, op=op)))
         else:
             def sum_and_scale():
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM)
                 flat.mul_(1.0 / self.world)
-            K.rec(sum_and_scale)
+            K.rec(self._coll(sum_and_scale))
 
     def all_reduce_avg(self, flat, after=()):
         """Average `flat` (a contiguous tensor) across ranks.  On GPUs the collective runs on a side stream
@@ -103,15 +130,15 @@ class DataParallelSync:
                 # plumbing rehearsal -- asks for SUM, which equals AVG there: RCCL runs a one-rank AVG as a pre-multiply kernel
                 # that rewrites the whole buffer in place, 112 us per 114 MB, which no multi-rank run executes.)
                 op = dist.ReduceOp.AVG if self.world > 1 else dist.ReduceOp.SUM
-                self._on_side(lambda: dist.all_reduce(flat, op=op), flat, after)
+                self._on_side(self._coll(lambda: dist.all_reduce(flat, op=op)), flat, after)
             else:
                 def sum_and_scale():
                     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
                     flat.mul_(1.0 / self.world)
-                self._on_side(sum_and_scale, flat, after)
+                self._on_side(self._coll(sum_and_scale), flat, after)
             # consumers of `flat` are enqueued later on the current stream, after wait(): the overlap window is the backward
             # kernels issued before the next consumer (PCGrad's Gram kernel is the first, after all three tasks)
-        else:
+        elif not self.stub:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             flat.mul_(1.0 / self.world)
 
@@ -155,7 +182,7 @@ class DataParallelSync:
 
     def all_reduce_avg_list(self, tensors):
         """Bucket a list of tensors into one flat buffer, average, scatter back."""
-        if self.world == 1 and not self.force:
+        if (self.world == 1 and not self.force) or self.stub:
             return
         self.wait()
         flat = torch.cat([t.reshape(-1) for t in tensors])

@@ -628,8 +628,11 @@ def recorded_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp=None)
     Under data parallelism the ranks decide that TOGETHER (one all-reduce of a flag), and the first REPLICA_CHECKS replays are
     followed by a comparison of the replicas' parameters across ranks: a list whose collectives were mis-ordered on real
     RCCL would show there, and is retired with rank 0's weights re-broadcast -- loudly, not silently."""
-    from . import engine
-    if not RecordedTrainStep.usable(model, optimizer_G, optimizer_D, method_D, x, y) or (dp is not None and not LIST_UNDER_DP):
+    from . import engine, parallel
+    # (the list path needs the whole DataParallelSync protocol -- all_agree / replicas_agree / broadcast_* and collectives that go
+    # through kernels.rec; a legacy hook object that only offers all_reduce_avg(flat) keeps its iterations eager)
+    if (not RecordedTrainStep.usable(model, optimizer_G, optimizer_D, method_D, x, y)
+            or (dp is not None and not (LIST_UNDER_DP and isinstance(dp, parallel.DataParallelSync)))):
         return engine.train_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp)
     st = getattr(model, "_mtd_recorded", None)
     if isinstance(st, RecordedTrainStep):
@@ -638,9 +641,12 @@ def recorded_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp=None)
             if dp is not None and st.replica_checks_left > 0:
                 st.replica_checks_left -= 1
                 if not dp.replicas_agree(list(model.parameters()) + list(model.buffers())):
+                    # the moments were updated from the same diverged gradients: rank 0's optimizer state goes with its weights
                     dp.broadcast_module(model)
+                    dp.broadcast_optimizer_state((optimizer_D, optimizer_G))
                     _retire_list(model, optimizer_G, optimizer_D, "data-parallel replicas differed after a replayed iteration "
-                                 "(rank 0's weights were re-broadcast)")
+                                 "(rank 0's weights and AdamW moments were re-broadcast)")
+                    model._mtd_eager_replica_checks = REPLICA_CHECKS      # ... and the eager iterations that follow are checked too
             return out
         if x.shape != st.x.shape:                                   # e.g. the last, smaller batch of an epoch: eager, keep the list
             return engine.train_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp)
@@ -650,7 +656,14 @@ def recorded_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp=None)
     if getattr(model, "_mtd_recorded_key", None) != key:
         model._mtd_recorded_key, seen = key, 0
     if seen < 0:                                                    # retired
-        return engine.train_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp)
+        out = engine.train_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp)
+        left = getattr(model, "_mtd_eager_replica_checks", 0)
+        if dp is not None and left > 0:                             # a list was retired because the replicas had drifted: the repair is checked
+            model._mtd_eager_replica_checks = left - 1
+            if not dp.replicas_agree(list(model.parameters()) + list(model.buffers())):
+                raise RuntimeError("mtd-gan_amd: data-parallel replicas differ after an EAGER iteration that followed a re-broadcast of rank 0's "
+                                   "weights and optimizer state: the collectives of this process group do not deliver (not a launch-list problem)")
+        return out
     if seen < 2:
         model._mtd_recorded = seen + 1
         return engine.train_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp)
@@ -660,7 +673,17 @@ def recorded_iteration(model, x, y, optimizer_G, optimizer_D, method_D, dp=None)
         out = (st.names, st.vals)
     except RecordingUnusable as e:                                  # the iteration ran; only the list is unusable
         st, out, why = None, (e.names, e.vals), str(e)
-    # (an exception from the iteration itself propagates: nothing was completed that could be returned)
+    except BaseException as e:
+        # the iteration itself failed (or something other than a RuntimeError escaped the recording): nothing was completed that could be
+        # returned, so the exception propagates -- but a caller that catches it must not re-record on every call with graph_mode left on,
+        # and under data parallelism the peers are waiting in all_agree() below: tell them before leaving
+        _retire_list(model, optimizer_G, optimizer_D, "the recorded iteration raised " + type(e).__name__)
+        if dp is not None:
+            try:
+                dp.all_agree(False)
+            except Exception:
+                pass
+        raise
     if dp is not None and not dp.all_agree(st is not None) and st is not None:
         st, why = None, "another rank could not record its iteration"
     if st is None:

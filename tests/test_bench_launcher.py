@@ -29,6 +29,14 @@ def test_gpus_2_launches_two_ranks_unwrapped():
     for key in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
                 "roofline", "cpu_baseline"):
         assert key in line, key
+    # the N > 1 line's diagnostics (bench.comm_diagnostics, the same code the RCCL run goes through): payload, a stand-alone
+    # all-reduce's algorithm / bus bandwidth, the step with its collectives stubbed, every rank's launch mode
+    assert line["ranks_seen"] == 2
+    assert line["allreduce_payload_mb"] == round(4 * (3 * 4096 + 2048 + 512) / 1e6, 2) and len(line["allreduce_messages_mb"]) == 5
+    assert line["allreduce_standalone_ms"] > 0 and line["allreduce_bus_gbs"] == pytest.approx(line["allreduce_alg_gbs"], abs=0.11)   # 2 (N - 1) / N = 1
+    assert line["launch_mode_per_rank"] == ["dry run (rank 0)", "dry run (rank 1)"]
+    assert line["ms_per_step_collectives_stubbed"] > 0
+    assert line["comm_exposed_ms"] == pytest.approx(line["ms_per_step"] - line["ms_per_step_collectives_stubbed"], abs=2e-3)
 
 
 @pytest.mark.timeout(600)

@@ -207,6 +207,23 @@ def _agree_worker(rank, world, port, out):
     res["one_bit"] = dp.replicas_agree([a, b2])
     res["all_ok"] = dp.all_agree(True)
     res["one_failed"] = dp.all_agree(rank != 1)      # rank 1's recording "failed": every rank must hear of it
+    # the repair of drifted replicas carries rank 0's AdamW moments with its weights (advisor, round 5): broadcast_optimizer_state
+    p = torch.nn.Parameter(a.clone())
+    p.grad = torch.full_like(p, 1.0 + rank)          # diverged gradients -> diverged moments
+    opt = torch.optim.AdamW([p], lr=1e-3)
+    opt.step()
+    m = opt.state[p]["exp_avg"]
+    res["moments_differ"] = not dp.replicas_agree([m])
+    dp.broadcast_optimizer_state([opt])
+    res["moments_repaired"] = dp.replicas_agree([m, opt.state[p]["exp_avg_sq"]])
+    # stub: a measurement switch (bench.py comm_exposed_ms) -- the data-path collectives become no-ops when they run
+    v = torch.full((4,), float(rank))
+    dp.stub = True
+    dp.all_reduce_avg(v)
+    res["stub_is_a_no_op"] = bool((v == float(rank)).all())
+    dp.stub = False
+    dp.all_reduce_avg(v)
+    res["live_again"] = bool((v == 0.5).all())
     out.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
@@ -227,4 +244,5 @@ def test_ranks_decide_together_and_replica_divergence_is_seen():
         p.join(120)
         assert p.exitcode == 0
     for r in (0, 1):
-        assert got[r] == dict(same=True, one_bit=False, all_ok=True, one_failed=False), (r, got[r])
+        assert got[r] == dict(same=True, one_bit=False, all_ok=True, one_failed=False, moments_differ=True, moments_repaired=True,
+                              stub_is_a_no_op=True, live_again=True), (r, got[r])

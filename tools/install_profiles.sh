@@ -1,10 +1,10 @@
 #!/bin/bash
-# Copies the summaries of the last tools/r5_measure.sh run from gpurun_out/ (scratch) to profiles/ (tracked)
+# Copies the summaries of the last tools/measure.sh run from gpurun_out/ (scratch) to profiles/ (tracked)
 # and rewrites profiles/pmc_manifest.json with the kernel-source hash the PMC passes were taken at.  Run after a gpurun call
-# of the script, with the same kernel sources checked out.   usage: tools/install_profiles.sh r5 [nogit]
+# of the script, with the same kernel sources checked out.   usage: tools/install_profiles.sh r6 [nogit]
 set -e
 cd "$(dirname "$0")/.."
-R=${1:-r5}
+R=${1:-r6}
 O=gpurun_out
 [ -f $O/bench_full.json ] && [ "$2" != "nogit" ] && cp $O/bench_full.json profiles/${R}_full_step_bench.json
 cp $O/prof_full/full_results_kernel_stats.csv profiles/${R}_full_step_kernel_stats_single_stream.csv
@@ -25,9 +25,14 @@ try:
     commit = subprocess.check_output(["git", "rev-parse", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
 except Exception:
     commit = "unknown (no .git on the GPU box; the builder's install_profiles.sh run records it)"
-cmd = f"tools/{R}_measure.sh (rocprofv3 --pmc <counter(s)> --kernel-trace, one pass per counter set, eager single-stream launches)"
+try:
+    lab = open("gpurun_out/pmc_lab_build.txt").read().strip()      # "<mtd_lab_build()> <path of the library the passes ran on>"
+except OSError:
+    lab = "unrecorded"
+assert lab == "unrecorded" or lab.startswith("0 "), f"PMC passes ran on a lab build: {lab}"
+cmd = f"tools/measure.sh {R} (rocprofv3 --pmc <counter(s)> --kernel-trace, one pass per counter set, eager single-stream launches)"
 man = {wl: {"files": {"fetch": f"{R}_pmc_{wl}_fetch.csv", "write": f"{R}_pmc_{wl}_write.csv", "mfma": f"{R}_pmc_{wl}_mfma_util.csv"},
-            "commit": commit, "source_hash": h_now, "command": cmd} for wl in ("full_step", "generator", "inference512")}
+            "commit": commit, "source_hash": h_now, "command": cmd, "library": lab} for wl in ("full_step", "generator", "inference512")}
 json.dump(man, open("profiles/pmc_manifest.json", "w"), indent=1)
 print("profiles/ updated at", commit[:10], h_now)
 PY
