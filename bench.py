@@ -45,7 +45,7 @@ def executed_fraction(kernel):
         return 16.0 / 36.0
     if "wino_conv3" in kernel:      # the split-bf16 kernel (opt-in): the same multiplications, each as six bf16 MFMA products -- counted
         return WINOGRAD_F24_EXECUTED if kernel.endswith("<6>") else WINOGRAD_EXECUTED      # here in fp32-equivalent flops
-    return WINOGRAD_F24_EXECUTED if (kernel.endswith(", 6>") or "wino24" in kernel or "wino_c32" in kernel) else WINOGRAD_EXECUTED
+    return WINOGRAD_F24_EXECUTED if (kernel.endswith(", 6>") or "wino_c32" in kernel) else WINOGRAD_EXECUTED
 
 
 def parse(argv=None):

@@ -184,8 +184,7 @@ int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream);
 /* The kernel the plan picks for these arguments: index into the weight-gradient name table of the launch profiler
  * (16 = wgrad_wino_kernel, Winograd F(2x2,3x3): 4/9 of the layer's multiplications), -1 = the vector-ALU kernels of
  * mtd_conv_direct's domain, MTD_EINVAL = invalid arguments.  Nothing is launched.  (Host-side flop accounting of bench.py.) */
-int mtd_conv_wgrad_plan_cfg(const mtd_wgrad_args* a);      /* (17 = the F(2x4, 3x3) form of the Winograd kernel: 3/9 of the multiplications) */
-int mtd_conv_wgrad_wino24_min_w(int min_w);      /* tuning / test hook: narrowest map that takes that form; 0 = never, < 0 = query */
+int mtd_conv_wgrad_plan_cfg(const mtd_wgrad_args* a);
 
 /* The two image ranges [0, b_first), [b_first, B) of one batch, a weight gradient each (a->dw and dw2; both bias
  * gradients into a->db, the second accumulated) from ONE launch of the slab-producing kernel: the paired discriminator
@@ -348,6 +347,15 @@ typedef struct {
     /* optional second pass over the same weight (a batch-paired discriminator pass has one sigma, u, v per half):
      * g_out (+)= corr(G, u, v, sigma) and then += corr(G2, u2, v2, sigma2), in that order; G2 == NULL: single pass */
     const float* G2; const float* u2; const float* v2; const float* sigma2;
+    /* optional (round 6): <G, W> WITHOUT reading G or W.  With y = conv(x, W)/sigma + b and gy the cotangent of y,
+     *   <G, W> = sum_pix gy . (W * x) = sigma * sum_{pix,n} gy[pix,n] (y[pix,n] - b[n]),
+     * and y comes back from the saved activation a = LeakyReLU(y): y = a > 0 ? a : a * act_inv_slope.  act_gy != NULL selects this
+     * form for the layer: a reduction over two [M][N] activation-sized tensors -- on the 4x4 ... 1x1 maps a few hundred KB where the
+     * weight-side dot reads G, G2 and W (3 x 9.4 MB for a 512 -> 512 3x3 layer).  The caller picks it where M < cols.
+     * act_gy2: a second cotangent added on load (NULL: none).  Pixels [0, act_M_first) belong to the first pass (sigma), the rest to
+     * the second (sigma2); act_M_first == act_M for a single pass.  Needs rows % 4 == 0, 16-byte aligned bases and strides. */
+    const float* act_gy; const float* act_gy2; const float* act_a; const float* act_bias;
+    int act_gy_ld, act_gy2_ld, act_a_ld, act_M, act_M_first; float act_inv_slope;
 } mtd_sn_grad_layer;
 size_t mtd_sn_grad_ws_bytes(const mtd_sn_grad_layer* layers_host, int n_layers);
 int mtd_sn_grad(const mtd_sn_grad_layer* layers_dev, const mtd_sn_grad_layer* layers_host, int n_layers,

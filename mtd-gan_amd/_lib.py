@@ -79,7 +79,10 @@ class SnLayer(C.Structure):
 class SnGradLayer(C.Structure):
     _fields_ = [("G", C.c_void_p), ("w", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("sigma", C.c_void_p),
                 ("g_out", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("accumulate", C.c_int),
-                ("G2", C.c_void_p), ("u2", C.c_void_p), ("v2", C.c_void_p), ("sigma2", C.c_void_p)]
+                ("G2", C.c_void_p), ("u2", C.c_void_p), ("v2", C.c_void_p), ("sigma2", C.c_void_p),
+                ("act_gy", C.c_void_p), ("act_gy2", C.c_void_p), ("act_a", C.c_void_p), ("act_bias", C.c_void_p),
+                ("act_gy_ld", C.c_int), ("act_gy2_ld", C.c_int), ("act_a_ld", C.c_int), ("act_M", C.c_int), ("act_M_first", C.c_int),
+                ("act_inv_slope", C.c_float)]
 
 
 class WgradReduceDesc(C.Structure):
@@ -130,7 +133,7 @@ def _preload_torch_hip_runtime():
 
 
 RECORDER = None      # kernels.LaunchList: while a step is being recorded, the list every launch is appended to
-_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "_option", "mtd_lab_build", "mtd_prof_", "_override", "_bwd_ok", "_stamps", "_zmask_bytes", "_tail_ok", "_winograd_ok", "_winograd_s2_ok", "_weight_floats", "_kmap", "_plan_cfg", "_pair_ok", "_pair_mode", "_patch_w", "_f4_min_w", "_relu_add_ok", "_wino24_min_w")
+_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "_option", "mtd_lab_build", "mtd_prof_", "_override", "_bwd_ok", "_stamps", "_zmask_bytes", "_tail_ok", "_winograd_ok", "_winograd_s2_ok", "_weight_floats", "_kmap", "_plan_cfg", "_pair_ok", "_pair_mode", "_patch_w", "_f4_min_w", "_relu_add_ok")
 
 
 class _RecordingLib:
@@ -194,7 +197,6 @@ def lib():
     sig("mtd_conv_wgrad_ws_bytes", sz, C.POINTER(WgradArgs))
     sig("mtd_conv_wgrad", ci, C.POINTER(WgradArgs), vp)
     sig("mtd_conv_wgrad_plan_cfg", ci, C.POINTER(WgradArgs))
-    sig("mtd_conv_wgrad_wino24_min_w", ci, ci)
     sig("mtd_conv_wgrad_pair_ok", ci, C.POINTER(WgradArgs), ci)
     sig("mtd_conv_wgrad_pair_mode", ci, ci)
     sig("mtd_conv_wgrad_pair_ws_bytes", sz, C.POINTER(WgradArgs), ci)
@@ -301,7 +303,7 @@ EXPORTS = [
     "mtd_spec_mix_zmask_bytes", "mtd_spec_mix_fwd4", "mtd_spec_mix_bwd4",
     "mtd_resfft_block_tail_ok", "mtd_resfft_block_tail", "mtd_conv_c32_bwd_irfft",
     "mtd_winograd_weight_floats", "mtd_winograd_kmap", "mtd_winograd_weights", "mtd_conv_winograd_ok", "mtd_conv_winograd_ws_bytes", "mtd_conv_winograd",
-    "mtd_conv_wgrad_plan_cfg", "mtd_conv_wgrad_wino24_min_w", "mtd_conv_winograd_patch_w", "mtd_conv_winograd_f4_min_w", "mtd_conv_relu_add_ok", "mtd_dropout_mask", "mtd_scale_by", "mtd_scalar_sums", "mtd_zero_multi", "mtd_checksum_multi",
+    "mtd_conv_wgrad_plan_cfg", "mtd_conv_winograd_patch_w", "mtd_conv_winograd_f4_min_w", "mtd_conv_relu_add_ok", "mtd_dropout_mask", "mtd_scale_by", "mtd_scalar_sums", "mtd_zero_multi", "mtd_checksum_multi",
     "mtd_set_option", "mtd_get_option", "mtd_lab_build",
     "mtd_winograd_s2_kmap", "mtd_winograd_s2_weights", "mtd_conv_winograd_s2_ok", "mtd_conv_winograd_s2_ws_bytes", "mtd_conv_winograd_s2",
 ]

@@ -1321,18 +1321,7 @@ extern "C" size_t mtd_conv_wgrad_ws_bytes(const mtd_wgrad_args* a) {
 extern "C" int mtd_conv_wgrad_plan_cfg(const mtd_wgrad_args* a) {
     if (!a || check_wargs(*a) != MTD_OK) return MTD_EINVAL;
     if (is_direct(*a)) return -1;
-    const int cfg = make_wplan(*a).cfg;
-    return (cfg == 16 && wgrad_wino_px(*a) == 6) ? 17 : cfg;      // 17: the F(2x4, 3x3) form of the Winograd kernel (3/9 of the multiplications)
-}
-
-// Tuning / test hook: narrowest map whose Winograd weight gradient takes the F(2x4, 3x3) form (0: never = the default, or
-// MTD_WGRAD_WINO24_MIN_W / MTD_WGRAD_WINO24=1 from the environment; the form is off by default); < 0 only queries.  Returns the previous value.
-extern "C" int mtd_conv_wgrad_wino24_min_w(int min_w) {
-    mtd_wgrad_args probe{};
-    (void)wgrad_wino_px(probe);                      // (reads the environment once)
-    const int old = g_wgw24_min_w;
-    if (min_w >= 0) g_wgw24_min_w = min_w;
-    return old;
+    return make_wplan(*a).cfg;
 }
 
 // plans whose kernels implement the pair form (pair_select): wgrad_kernel<> (0-6), the block-window kernels (10-12), the all-taps
@@ -1398,7 +1387,7 @@ static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, 
         p.nCt = a->C / (32 * pl.WC);
         dim3 grid(pl.nsplit, (a->N / (32 * pl.WN)) * p.nCt, pl.ntg);
         const int np = pair ? 2 : 1;         // problems in this launch
-        const int prof = mtd_prof_begin(1, (pl.cfg == 16 && wgrad_wino_px(*a) == 6) ? 17 : pl.cfg, pl.nsplit, np * geom_pixels(a->g), a->N, a->C, a->g.TH * a->g.TW, s,
+        const int prof = mtd_prof_begin(1, pl.cfg, pl.nsplit, np * geom_pixels(a->g), a->N, a->C, a->g.TH * a->g.TW, s,
                                             4.0 * np * ((double)geom_pixels(a->g) * a->N + (double)a->g.B * a->g.IH * a->g.IW * a->C + (double)a->g.TH * a->g.TW * a->N * a->C));
         // Row-window kernel: 64 KB of dynamic LDS nobody uses caps it at ONE workgroup (one wave per SIMD) per CU.  Alone in
         // a stream that changes nothing (generator step: 31.7 us per launch either way); in the full step, where it runs on a
@@ -1408,15 +1397,13 @@ static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, 
         if (pl.cfg == 16) {
             WgradWinoParams wp;
             wp.w = p;
-            const bool f24 = wgrad_wino_px(*a) == 6;
-            wp.tiles_x = a->g.OW / (f24 ? 4 : 2);
+            wp.tiles_x = a->g.OW / 2;
             wp.tiles_per_image = (a->g.OH / 2) * wp.tiles_x;
             wp.ntiles = a->g.B * wp.tiles_per_image;
             wp.chunks_per_split = pl.ppw;
             wp.ns_first = wp.first_tiles = 0;
             wp.p_add = nullptr;
-            if (f24) MTD_LAUNCH(wgrad_wino24_kernel<false>, dim3(pl.nsplit, (unsigned)wgrad_wino_blocks(*a)), dim3(512), 0, s, wp);
-            else MTD_LAUNCH(wgrad_wino_kernel, dim3(pl.nsplit, (a->N / 64) * (a->C / 64)), dim3(512), 0, s, wp);
+            MTD_LAUNCH(wgrad_wino_kernel, dim3(pl.nsplit, (a->N / 64) * (a->C / 64)), dim3(512), 0, s, wp);
             mtd_prof_end(prof, s);
             MTD_LAUNCH_CHECK();
             return MTD_OK;
@@ -1701,8 +1688,7 @@ extern "C" int mtd_conv_wgrad_pair_sum(const mtd_wgrad_args* a, const float* p_a
     }
     p.ppw = cps;
     p.nCt = a->C / 64;
-    const bool f24 = !s2w && wgrad_wino_px(*a) == 6;
-    wp.tiles_x = s2w ? (a->g.OW + 2) / 3 : a->g.OW / (f24 ? 4 : 2);
+    wp.tiles_x = s2w ? (a->g.OW + 2) / 3 : a->g.OW / 2;
     wp.tiles_per_image = (s2w ? (a->g.OH + 2) / 3 : a->g.OH / 2) * wp.tiles_x;
     wp.ntiles = a->g.B * wp.tiles_per_image;
     wp.chunks_per_split = cps;
@@ -1710,11 +1696,9 @@ extern "C" int mtd_conv_wgrad_pair_sum(const mtd_wgrad_args* a, const float* p_a
     wp.first_tiles = b_first * wp.tiles_per_image;
     wp.p_add = p_add;
     hipStream_t s = (hipStream_t)stream;
-    const int prof = mtd_prof_begin(1, s2w ? 18 : f24 ? 17 : 16, nsplit, geom_pixels(a->g), a->N, a->C, p.T, s,
+    const int prof = mtd_prof_begin(1, s2w ? 18 : 16, nsplit, geom_pixels(a->g), a->N, a->C, p.T, s,
                                     4.0 * ((double)geom_pixels(a->g) * a->N + (double)a->g.B * a->g.IH * a->g.IW * a->C + 2.0 * p.T * a->N * a->C));
     if (s2w) MTD_LAUNCH(wgrad_wino_s2_kernel, dim3(nsplit, (unsigned)wgrad_wino_s2_blocks(*a)), dim3(512), 0, s, wp);
-    else if (f24 && p_add) MTD_LAUNCH(wgrad_wino24_kernel<true>, dim3(nsplit, (unsigned)wgrad_wino_blocks(*a)), dim3(512), 0, s, wp);
-    else if (f24) MTD_LAUNCH(wgrad_wino24_kernel<false>, dim3(nsplit, (unsigned)wgrad_wino_blocks(*a)), dim3(512), 0, s, wp);
     else MTD_LAUNCH(wgrad_wino_kernel, dim3(nsplit, (a->N / 64) * (a->C / 64)), dim3(512), 0, s, wp);
     mtd_prof_end(prof, s);
     MTD_LAUNCH_CHECK();

@@ -364,296 +364,13 @@ bool wgrad_wino_ok(const mtd_wgrad_args& a) {
     return true;
 }
 
-// =====================================================================================================================
-// Round 4: Winograd F(2x4, 3x3) weight gradient -- the transpose of conv_winograd.hip's wino_conv_kernel<., ., 6>:
-//   dW = Gy^T [ sum over 2x4 output tiles  (Ay dY Ax^T) (.) (By^T d Bx) ] Gx       F(2,3) down the rows, F(4,3) along them
-// 24 positions, 24 multiplications per 8 output pixels: 3 per pixel instead of F(2x2)'s 4 (executed flops 2 M N C 3).  A
-// 512-thread workgroup owns a 64 (n) x 32 (c) block for all 24 positions -- wave w holds positions 3w .. 3w+2 as 3 x 2
-// accumulator blocks of 32 x 32 (96 registers; a 64 x 64 block would be 192 beside two prefetch sets) -- so the grid has twice
-// the (n, c) blocks of the F(2x2) kernel and needs half the pixel slices: half the slabs per launch.  K runs in chunks of 8
-// tiles (64 output pixels).  Transform roles:
-//   * U = By^T d Bx: every thread, (tile = wave, channel quad of the 32, column half, patch row): five 16-byte loads of the row
-//     (the pixels its three columns of d Bx need), the 6-point B^T of F(4,3) in registers, B^T of F(2,3) across the quad by
-//     DPP, three 16-byte stores;
-//   * V = Ay dY Ax^T: all 512 threads, (tile, channel quad of the 64, quad lane = (tile row i, column pair jp)): two pixels
-//     loaded, the row's other two from the neighbour lane by DPP, R_i[b] = sum_j dY[i][j] Ax[b][j] for the lane's three b
-//     (jp = 0: b = 0..2, jp = 1: b = 3..5), the other row's R from lane ^ 2, rows a = 2i, 2i+1 of V stored: six 16-byte stores.
-// Slab layout, pair form, second cotangent and the bias row are the F(2x2) kernel's.
-constexpr int W24_UPL = WGW_T * 32 + 4;          // plane stride (floats) of one position of U (8 tiles x 32 c, 16 bytes of skew)
-constexpr int W24_VPL = WGW_T * 64 + 4;          // ... of V (8 tiles x 64 n)
-constexpr int W24_BUF = 24 * (W24_UPL + W24_VPL);   // one chunk buffer: 24 U planes, then 24 V planes (74.5 KB)
-
-__device__ __forceinline__ float w24_quad(float v, int ctrl) {
-    const int x = __builtin_bit_cast(int, v);
-    int r;
-    switch (ctrl) {
-        case 0: r = __builtin_amdgcn_update_dpp(0, x, 0x64, 0xf, 0xf, true); break;      // lanes [0, 1, 2, 1]
-        case 1: r = __builtin_amdgcn_update_dpp(0, x, 0xDA, 0xf, 0xf, true); break;      // lanes [2, 2, 1, 3]
-        case 2: r = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true); break;      // lanes [1, 0, 3, 2]: the row's other column pair
-        case 3: r = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true); break;      // lanes [2, 3, 0, 1]: the other tile row
-        case 4: r = __builtin_amdgcn_update_dpp(0, x, 0x00, 0xf, 0xf, true); break;      // lane 0
-        case 5: r = __builtin_amdgcn_update_dpp(0, x, 0x55, 0xf, 0xf, true); break;      // lane 1
-        case 6: r = __builtin_amdgcn_update_dpp(0, x, 0xAA, 0xf, 0xf, true); break;      // lane 2
-        default: r = __builtin_amdgcn_update_dpp(0, x, 0xFF, 0xf, 0xf, true); break;     // lane 3
-    }
-    return __builtin_bit_cast(float, r);
-}
-
-// P2: a second cotangent is added as the operands are loaded (mtd_conv_wgrad_pair_sum); without it its two registers per
-// prefetch set are not there (the kernel sits at the 256-register limit).
-template <bool P2>
-__global__ __launch_bounds__(512, 1) void wgrad_wino24_kernel(const WgradWinoParams wp) {
-    __shared__ __attribute__((aligned(16))) float Ls[2 * W24_BUF];         // 2 x 74.5 KB; the exchange image of the epilogue (99 KB) reuses it
-    const WgradParams& p = wp.w;
-    const mtd_wgrad_args& a = p.a;
-    const mtd_geom& g = a.g;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, kh = lane >> 5;
-    const int ncb = a.C / 32;
-    const int nblk = blockIdx.y / ncb, cblk = blockIdx.y - nblk * ncb;
-    const int n0 = nblk * 64, c0 = cblk * 32;
-    const int second = (wp.ns_first > 0 && (int)blockIdx.x >= wp.ns_first) ? 1 : 0;
-    const int zk = blockIdx.x - second * wp.ns_first;                       // slice within its image range
-    const int tile_lo = second ? wp.first_tiles : 0;
-    const int tile_hi = (wp.ns_first > 0 && !second) ? wp.first_tiles : wp.ntiles;
-    const int ck_beg = zk * wp.chunks_per_split;
-    const int nchunks_all = (tile_hi - tile_lo + WGW_T - 1) / WGW_T;
-    const int ck_end = min(nchunks_all, ck_beg + wp.chunks_per_split);
-    const int nck = ck_end - ck_beg;
-    const int ck_last = ck_end - 1;
-
-    // Every thread has both roles for tile t8 = its wave:
-    //   U: (channel quad ucq of the 32, column half uh, patch row qp): five pixels of the row (uh .. uh + 4), three of the six columns
-    //   V: (channel quad vnq of the 64, tile row vi, column pair vjp)
-    const int qp = tid & 3, t8 = tid >> 6;
-    const int uh = (tid >> 2) & 1, ucq = (tid >> 3) & 7;
-    const int vnq = (tid >> 2) & 15, vi = qp >> 1, vjp = qp & 1;
-    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.q), (short)0, (int)p.q_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p), (short)0, (int)p.p_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t p2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P2 ? wp.p_add : a.p), (short)0, (int)p.p_bytes, 0x00020000);
-    const int qpx_b = a.q_ld * 4, ppx_b = a.p_ld * 4;
-    struct Pre { f32x4 d[5]; f32x4 y0, y1; f32x4 z[P2 ? 2 : 1]; };         // one chunk's operands of this thread, on their way from memory
-    f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
-    auto load_chunk = [&](int ck, Pre& r) {
-        const int tg = tile_lo + ck * WGW_T + t8;
-        const bool tv = tg < tile_hi;
-        const int b = tg / wp.tiles_per_image;
-        const int rr = tg - b * wp.tiles_per_image;
-        const int ty = rr / wp.tiles_x, tx = rr - ty * wp.tiles_x;
-        {   // U: patch row qp = image row 2 ty - 1 + qp, pixels 4 tx - 1 + uh .. + 4, channels c0 + 4 ucq ..
-            const int iy = 2 * ty - 1 + qp;
-            const int ix0 = 4 * tx - 1 + uh;
-            const unsigned ubase = (unsigned)(((((long long)b * g.IH + iy) * g.IW + ix0) * a.q_ld + c0 + 4 * ucq) * 4);
-            const bool rowok = tv & ((unsigned)iy < (unsigned)g.IH);
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const unsigned vo = (rowok & ((unsigned)(ix0 + j) < (unsigned)g.IW)) ? ubase + (unsigned)(j * qpx_b) : 0x80000000u;
-                r.d[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qrs, vo, 0, 0));
-            }
-        }
-        {   // V: cotangent pixels (2 ty + vi, 4 tx + 2 vjp + {0, 1}), channels n0 + 4 vnq ..
-            const long long pix = ((long long)b * g.OH + 2 * ty + vi) * g.OW + 4 * tx + 2 * vjp;
-            const unsigned vo = tv ? (unsigned)((pix * a.p_ld + n0 + 4 * vnq) * 4) : 0x80000000u;
-            const unsigned vo1 = tv ? vo + (unsigned)ppx_b : 0x80000000u;
-            r.y0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, vo, 0, 0));
-            r.y1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, vo1, 0, 0));
-            if constexpr (P2) {
-                r.z[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(p2rs, vo, 0, 0));
-                r.z[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(p2rs, vo1, 0, 0));
-            }
-        }
-    };
-    const float usign = qp == 1 ? 1.f : -1.f;
-    // U: with x_k = pixel uh + k of the row, s = 4 x0 - 5 x2 + x4 is column 0 (uh = 0) or 5 (uh = 1) of d Bx, and
-    //    uh = 0: A = x4 - 4 x2, B = x3 - 4 x1 -> columns 1, 2 = A + B, A - B;   uh = 1: A = x3 - x1, B = 2 (x2 - x0) -> columns 3, 4
-    // piece q (0, 1, 2) = the thread's q-th column in ascending order
-    auto tr_u = [&](float* Lb, const Pre& r, int q) {
-        const f32x4 sv = 4.f * r.d[0] - 5.f * r.d[2] + r.d[4];
-        const f32x4 A = uh ? r.d[3] - r.d[1] : r.d[4] - 4.f * r.d[2];
-        const f32x4 Bv = uh ? 2.f * (r.d[2] - r.d[0]) : r.d[3] - 4.f * r.d[1];
-        // uh = 0: columns (0, 1, 2) = (s, A + B, A - B);  uh = 1: columns (3, 4, 5) = (A + B, A - B, s)
-        const f32x4 rj = q == 0 ? (uh ? A + Bv : sv) : (q == 1 ? (uh ? A - Bv : A + Bv) : (uh ? sv : A - Bv));
-        f32x4 u;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) u[c] = fmaf(usign, w24_quad(rj[c], 1), w24_quad(rj[c], 0));
-        *reinterpret_cast<f32x4*>(Lb + t8 * 32 + 4 * ucq + (6 * qp + 3 * uh + q) * W24_UPL) = u;
-    };
-    // V: R = this lane's three columns b of (dY Ax^T)[vi], then rows a = 2 vi, 2 vi + 1 of Ay R
-    f32x4 vR[3];
-    auto tr_v_rows = [&](const Pre& r, float live) {
-        f32x4 s0 = r.y0, s1 = r.y1;                                         // this lane's pixels: columns 2 vjp, 2 vjp + 1
-        if constexpr (P2) { s0 += r.z[0]; s1 += r.z[1]; }
-        dbacc += live * (s0 + s1);
-        f32x4 o0, o1;                                                       // the row's other two pixels
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            o0[c] = w24_quad(s0[c], 2);
-            o1[c] = w24_quad(s1[c], 2);
-        }
-        const f32x4 e0 = vjp ? o0 : s0, e1 = vjp ? o1 : s1, e2 = vjp ? s0 : o0, e3 = vjp ? s1 : o1;
-        // Ax^T columns b: (1,0,0,0) (1,1,1,1) (1,-1,1,-1) (1,2,4,8) (1,-2,4,-8) (0,0,0,1)
-        const f32x4 ev = e0 + e2, od = e1 + e3, ev4 = e0 + 4.f * e2, od4 = 2.f * e1 + 8.f * e3;
-        vR[0] = vjp ? ev4 + od4 : e0;
-        vR[1] = vjp ? ev4 - od4 : ev + od;
-        vR[2] = vjp ? e3 : ev - od;
-    };
-    auto tr_v_store = [&](float* Lb, int k) {
-        float* vo = Lb + 24 * W24_UPL + t8 * 64 + 4 * vnq;
-        f32x4 ot;                                                           // the other tile row's R[k]
-#pragma unroll
-        for (int c = 0; c < 4; ++c) ot[c] = w24_quad(vR[k][c], 3);
-        const f32x4 r0 = vi ? ot : vR[k], r1 = vi ? vR[k] : ot;
-        // Ay = [1 0; 1 1; 1 -1; 0 -1]: rows a = 0, 1 (vi = 0) or 2, 3 (vi = 1)
-        const f32x4 va = vi ? r0 - r1 : r0, vb = vi ? -r1 : r0 + r1;
-        const int b = 3 * vjp + k;
-        *reinterpret_cast<f32x4*>(vo + (6 * (2 * vi) + b) * W24_VPL) = va;
-        *reinterpret_cast<f32x4*>(vo + (6 * (2 * vi + 1) + b) * W24_VPL) = vb;
-    };
-    auto transform_store = [&](float* Lb, const Pre& r, float live) {
-        tr_u(Lb, r, 0); tr_u(Lb, r, 1); tr_u(Lb, r, 2);
-        tr_v_rows(r, live);
-        tr_v_store(Lb, 0); tr_v_store(Lb, 1); tr_v_store(Lb, 2);
-    };
-
-    f32x16 acc[3][2];                          // [position][n half]
-#pragma unroll
-    for (int x = 0; x < 3; ++x)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[x][h][e] = 0.f;
-
-    Pre pa, pb;
-    if (nck > 0) {
-        load_chunk(ck_beg, pa);
-        transform_store(Ls, pa, 1.f);
-        load_chunk(min(ck_beg + 1, ck_last), pa);
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-    // One chunk (as in the F(2x2) kernel): the operands of chunk k + 2 requested at the top, the 24 MFMAs of chunk k in six groups
-    // of four (two (k-step, position) pairs) with their fragments read from LDS one group ahead, the transform of chunk k + 1 in
-    // six pieces between the groups.
-    auto one_chunk = [&](int k, const Pre& cur, Pre& nxt) {
-        const float* Lc = Ls + (k & 1) * W24_BUF;
-        float* Ln = Ls + ((k + 1) & 1) * W24_BUF;
-        load_chunk(min(ck_beg + k + 2, ck_last), nxt);
-        __builtin_amdgcn_sched_barrier(0);
-        float fa[2][2][2], fb[2][2];                                   // [ping-pong][pair of the group][n half], [ping-pong][pair]
-        auto frag = [&](int gi, int pp) {                             // group gi: pairs q = 2 gi, 2 gi + 1;  pair q = 3 s + x
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int q = 2 * gi + e, sst = q / 3, x = q - 3 * sst;
-                const float* up = Lc + (3 * wave + x) * W24_UPL + (2 * sst + kh) * 32 + l31;
-                const float* vp = Lc + 24 * W24_UPL + (3 * wave + x) * W24_VPL + (2 * sst + kh) * 64 + l31;
-                fa[pp][e][0] = vp[0]; fa[pp][e][1] = vp[32];
-                fb[pp][e] = up[0];
-            }
-        };
-        frag(0, 0);
-        const float live = (k + 1 < nck) ? 1.f : 0.f;
-#pragma unroll
-        for (int gi = 0; gi < 6; ++gi) {
-            const int pp = gi & 1;
-            __builtin_amdgcn_sched_barrier(0);
-            if (gi + 1 < 6) frag(gi + 1, pp ^ 1);                      // the next group's fragments, under this group's MFMAs
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int x = (2 * gi + e) % 3;
-                acc[x][0] = mfma32(fa[pp][e][0], fb[pp][e], acc[x][0]);
-                acc[x][1] = mfma32(fa[pp][e][1], fb[pp][e], acc[x][1]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // the transform of chunk k + 1, a piece per group (its operands were requested a chunk ago)
-            if (gi == 0) { tr_u(Ln, cur, 0); tr_u(Ln, cur, 1); }
-            else if (gi == 1) tr_u(Ln, cur, 2);
-            else if (gi == 2) tr_v_rows(cur, live);
-            else if (gi == 3) tr_v_store(Ln, 0);
-            else if (gi == 4) tr_v_store(Ln, 1);
-            else tr_v_store(Ln, 2);
-        }
-        __syncthreads();
-    };
-#pragma unroll 1
-    for (int k = 0; k < nck; k += 2) {
-        one_chunk(k, pa, pb);
-        if (k + 1 < nck) one_chunk(k + 1, pb, pa);
-    }
-
-    // ---- epilogue: Gy^T dU Gx per (n, c), one 32 x 32 sub-block at a time through X[xi][n][c]; the bias gradient
-    float* slab = a.ws + (long long)blockIdx.x * p.slab_stride;
-    const int en_c = tid & 31, en_n = tid >> 5;                        // this thread's c and n (+16) inside the sub-block
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int x = 0; x < 3; ++x) {
-            float* X = Ls + (3 * wave + x) * (32 * WGW_XLD) + l31;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) X[mfma32_row(e, lane) * WGW_XLD] = acc[x][h][e];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int nl = en_n + 16 * r;
-            float t[3][6];
-            // t = Gy^T m (3 x 6);  Gy^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]
-#pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                const float m0 = Ls[((0 * 6 + b) * 32 + nl) * WGW_XLD + en_c], m1 = Ls[((1 * 6 + b) * 32 + nl) * WGW_XLD + en_c];
-                const float m2 = Ls[((2 * 6 + b) * 32 + nl) * WGW_XLD + en_c], m3 = Ls[((3 * 6 + b) * 32 + nl) * WGW_XLD + en_c];
-                const float hs = 0.5f * (m1 + m2), hd = 0.5f * (m1 - m2);
-                t[0][b] = m0 + hs;
-                t[1][b] = hd;
-                t[2][b] = hs + m3;
-            }
-            float* o = slab + ((long long)(n0 + 32 * h + nl)) * a.C + c0 + en_c;
-            const long long tap_stride = (long long)a.N * a.C;
-            // out = t Gx (3 x 3);  Gx = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
-#pragma unroll
-            for (int pr = 0; pr < 3; ++pr) {
-                const float s12 = t[pr][1] + t[pr][2], d12 = t[pr][1] - t[pr][2], s34 = t[pr][3] + t[pr][4], d34 = t[pr][3] - t[pr][4];
-                o[(pr * 3 + 0) * tap_stride] = 0.25f * t[pr][0] - s12 * (1.f / 6.f) + s34 * (1.f / 24.f);
-                o[(pr * 3 + 1) * tap_stride] = -d12 * (1.f / 6.f) + d34 * (1.f / 12.f);
-                o[(pr * 3 + 2) * tap_stride] = -s12 * (1.f / 6.f) + s34 * (1.f / 6.f) + t[pr][5];
-            }
-        }
-        __syncthreads();
-    }
-    if (a.db && cblk == 0) {
-        // bias gradient of the slice: the quad's eight pixels, then the chunk's eight tiles (= the eight waves: t8 == wave)
-        f32x4 s;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) s[c] = ((w24_quad(dbacc[c], 4) + w24_quad(dbacc[c], 5)) + w24_quad(dbacc[c], 6)) + w24_quad(dbacc[c], 7);
-        if (qp == 0) *reinterpret_cast<f32x4*>(Ls + t8 * 64 + 4 * vnq) = s;
-        __syncthreads();
-        if (tid < 64) {
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) v += Ls[w * 64 + tid];
-            slab[(long long)p.T * a.N * a.C + n0 + tid] = v;
-        }
-    }
-}
-
-// which Winograd form does a layer's weight gradient take: 6 = F(2x4, 3x3) (map width a multiple of 4 and at least
-// MTD_WGRAD_WINO24_MIN_W), 4 = F(2x2, 3x3).  The F(2x4) form is OFF by default (MTD_WGRAD_WINO24=1 or a MIN_W switch it on; the
-// tests run it through mtd_conv_wgrad_wino24_min_w): correct, but slower -- 132-138 us per launch against 102 for the F(2x2)
-// kernel on the 4 096 x 512 x 512 ... 262 144 x 64 x 64 layers, full step 31.08 against 29.94 ms.  Both kernels spend ~7-8 000
-// clocks per chunk outside their MFMAs (two workgroup-wide LDS round trips, the DPP chains of two transforms); F(2x4) has 24
-// MFMAs per chunk and 32 channels to F(2x2)'s 32 per chunk and 64 channels, and a heavier cotangent transform per MFMA, so a
-// quarter fewer multiplications does not pay here as it does for the forward form (one operand transformed, weights from L2).
-int g_wgw24_min_w = -1;
-int wgrad_wino_px(const mtd_wgrad_args& a) {
-    if (g_wgw24_min_w < 0) {
-        const char* on = mtd_lab_env("MTD_WGRAD_WINO24");
-        const char* mw = mtd_lab_env("MTD_WGRAD_WINO24_MIN_W");
-        g_wgw24_min_w = mw ? atoi(mw) : ((on && atoi(on) != 0) ? 8 : 0);
-    }
-    return (g_wgw24_min_w > 0 && (a.g.OW % 4) == 0 && a.g.OW >= g_wgw24_min_w) ? 6 : 4;
-}
+// (A Winograd F(2x4, 3x3) form of this kernel -- the transpose of wino_conv_kernel<., ., 6>, 24 positions on a 64 x 32 block --
+// was built in round 4, measured slower twice (132-138 against 102 us per launch on the large layers, step 31.08 against 29.94 ms:
+// 24 MFMAs per chunk and 32 channels to this kernel's 32 and 64, a heavier cotangent transform per MFMA) and removed in round 6;
+// docs/LAB_NOTES_r3_r5.md has the numbers, the history has the kernel.)
+constexpr int wgrad_wino_px(const mtd_wgrad_args&) { return 4; }
 // (n, c) blocks and tiles of a layer in the form it takes
-inline long long wgrad_wino_blocks(const mtd_wgrad_args& a) { return (long long)(a.N / 64) * (a.C / (wgrad_wino_px(a) == 6 ? 32 : 64)); }
+inline long long wgrad_wino_blocks(const mtd_wgrad_args& a) { return (long long)(a.N / 64) * (a.C / 64); }
 inline long long wgrad_wino_tiles(const mtd_wgrad_args& a, long long images) {
-    return images * (a.g.OH / 2) * (a.g.OW / (wgrad_wino_px(a) == 6 ? 4 : 2));
+    return images * (a.g.OH / 2) * (a.g.OW / 2);
 }

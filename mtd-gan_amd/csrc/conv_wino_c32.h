@@ -60,9 +60,13 @@ struct C32Params {
     int tiles_y;              // tile rows per image
     int d_img, d_ty, d_tx;    // one step of a workgroup's walk (C32_T * slots tiles) as (images, tile rows, tile columns)
     unsigned out_bytes, add_bytes;
+    unsigned out2_bytes, mask_bytes;      // MASKED2 form: extents of the second output (0: none) and of the mask operand
 };
 
-template <bool HAS_ADD>
+// MASKED2 (round 6: the data-gradient role of the generator's plain 32 -> 32 layers, generator_path.generator_backward): the epilogue's value
+// v goes to a.out2 (where given) and v * (mask > 0 ? 1 : mask_slope) to a.out -- the cotangent and its masked form for the block
+// that consumes it, as the halo-tile kernel writes them (conv_igemm.hip).  Four more 8-byte loads and stores per thread and block.
+template <bool HAS_ADD, bool MASKED2 = false>
 __global__ __launch_bounds__(512) void wino_c32_kernel(const C32Params cp) {
     constexpr int PX = 6, TWX = 4;
     __shared__ __attribute__((aligned(16))) float Ls[2 * C32_AS + C32_X];
@@ -93,6 +97,9 @@ __global__ __launch_bounds__(512) void wino_c32_kernel(const C32Params cp) {
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), (short)0, (int)wp.p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, (int)cp.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t e1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(HAS_ADD ? a.add1 : a.in), (short)0, (int)(HAS_ADD ? cp.add_bytes : 0u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(MASKED2 ? a.mask : a.in), (short)0, (int)(MASKED2 ? cp.mask_bytes : 0u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t o2rs = __builtin_amdgcn_make_buffer_rsrc((MASKED2 && a.out2) ? a.out2 : a.out, (short)0, (int)((MASKED2 && a.out2) ? cp.out2_bytes : 0u), 0x00020000);
+    const float mslope = a.mask_slope;
     const unsigned px_b = (unsigned)a.in_ld * 4u;
 
     // a thread's tile as (image, tile row, tile column); one step of the walk adds (d_img, d_ty, d_tx) with carries
@@ -215,6 +222,17 @@ __global__ __launch_bounds__(512) void wino_c32_kernel(const C32Params cp) {
             }
         }
     };
+    auto load_mask = [&](f32x2 (&m)[TWX], int epix) {
+#pragma unroll
+        for (int q = 0; q < TWX; ++q) {
+            if constexpr (MASKED2) {
+                const unsigned vo = (((unsigned)(epix + q) * (unsigned)a.mask_ld + 2u * (unsigned)ecp) * 4u) | ((unsigned)(epix >> 31) & 0x80000000u);
+                m[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(mrs, vo, 0, 0));
+            } else {
+                m[q] = f32x2{1.f, 1.f};
+            }
+        }
+    };
     // output transform of the block in X (epi_read: the 18 LDS loads and row ei of A^T m per column), then A along the row, the
     // epilogue and the stores at pixel epix .. epix + 3 (epi_finish; epix < 0: nothing is stored)
     auto epi_read = [&](f32x2 (&t)[PX]) {
@@ -231,7 +249,7 @@ __global__ __launch_bounds__(512) void wino_c32_kernel(const C32Params cp) {
             }
         }
     };
-    auto epi_finish = [&](const f32x2 (&t)[PX], const f32x2 (&e1)[TWX], int epix) {
+    auto epi_finish = [&](const f32x2 (&t)[PX], const f32x2 (&e1)[TWX], const f32x2 (&mk)[TWX], int epix) {
         // A^T of F(4,3) = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
         f32x2 y[TWX];
         const f32x2 s12 = t[1] + t[2], d12 = t[1] - t[2], s34 = t[3] + t[4], d34 = t[3] - t[4];
@@ -249,6 +267,12 @@ __global__ __launch_bounds__(512) void wino_c32_kernel(const C32Params cp) {
                 v += e1[q][c];
                 y[q][c] = fmaxf(v, v * slope_post);
             }
+            if constexpr (MASKED2) {
+                const unsigned vo2 = (((unsigned)(epix + q) * (unsigned)a.out2_ld + 2u * (unsigned)ecp) * 4u) | ((unsigned)(epix >> 31) & 0x80000000u);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(c32_u32x2, y[q]), o2rs, vo2, 0, 0);      // (no second output: extent 0)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) y[q][c] *= mk[q][c] > 0.f ? 1.f : mslope;
+            }
             const unsigned vo = (((unsigned)(epix + q) * (unsigned)a.out_ld + 2u * (unsigned)ecp) * 4u) | ((unsigned)(epix >> 31) & 0x80000000u);
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(c32_u32x2, y[q]), ors, vo, 0, 0);
         }
@@ -259,6 +283,7 @@ __global__ __launch_bounds__(512) void wino_c32_kernel(const C32Params cp) {
     int ld_it = 0;                                       // walk index of the next patch request
     f32x4 D0[PX], D1[PX];
     f32x2 E0[TWX], E1[TWX];
+    f32x2 M0[TWX], M1[TWX];
     load_patch(D0, curT, ld_it < nit, 0, PX); cur_step(curT); ++ld_it;
     load_patch(D1, curT, ld_it < nit, 0, PX); cur_step(curT); ++ld_it;
     {
@@ -269,12 +294,13 @@ __global__ __launch_bounds__(512) void wino_c32_kernel(const C32Params cp) {
     __builtin_amdgcn_sched_barrier(0);
     load_patch(D0, curT, ld_it < nit, 0, PX); cur_step(curT); ++ld_it;
     load_residual(E1, -1);
+    load_mask(M1, -1);
     int epix_prev = -1;
     __syncthreads();
 
     // One iteration (parity P = it & 1): see the header.  Dn = the patch rows of block it + 1 (then re-requested for it + 3);
     // Ec receives this block's residual operand, Ep holds the previous block's.
-    auto body = [&](auto pc, int it, f32x4 (&Dn)[PX], f32x2 (&Ec)[TWX], const f32x2 (&Ep)[TWX]) {
+    auto body = [&](auto pc, int it, f32x4 (&Dn)[PX], f32x2 (&Ec)[TWX], const f32x2 (&Ep)[TWX], f32x2 (&Mc)[TWX], const f32x2 (&Mp)[TWX]) {
         constexpr int P = decltype(pc)::value;
         const float* Ac = Ls + P * C32_AS;
         float* An = Ls + (P ^ 1) * C32_AS;
@@ -334,12 +360,14 @@ __global__ __launch_bounds__(512) void wino_c32_kernel(const C32Params cp) {
         const int epix_cur = out_pixel_of(curE, it < nit);
         cur_step(curE);
         load_residual(Ec, epix_cur);
+        load_mask(Mc, epix_cur);
         f32x2 et_[PX];
         epi_read(et_);
-        interleave(I6{}, I1{}, I3{});
+        using IVM = std::integral_constant<int, MASKED2 ? 1 : 3>;      // eight instead of four memory instructions in each of the last two regions
+        interleave(I6{}, I1{}, IVM{});
         mfmas(std::integral_constant<int, 1>{}, 2);
-        epi_finish(et_, Ep, epix_prev);
-        interleave(I6{}, I0{}, I3{});
+        epi_finish(et_, Ep, Mp, epix_prev);
+        interleave(I6{}, I0{}, IVM{});
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         // the accumulators of this block -> X (read by the next iteration's epilogue)
@@ -357,10 +385,10 @@ __global__ __launch_bounds__(512) void wino_c32_kernel(const C32Params cp) {
     // (an odd count runs one more iteration on a block past the end: its loads and stores are out of range)
 #pragma unroll 1
     for (int it = 0; it < nit; it += 2) {
-        body(std::integral_constant<int, 0>{}, it, D1, E0, E1);
-        body(std::integral_constant<int, 1>{}, it + 1, D0, E1, E0);
+        body(std::integral_constant<int, 0>{}, it, D1, E0, E1, M0, M1);
+        body(std::integral_constant<int, 1>{}, it + 1, D0, E1, E0, M1, M0);
     }
     f32x2 et_[PX];
     epi_read(et_);
-    epi_finish(et_, E1, epix_prev);
+    epi_finish(et_, E1, M1, epix_prev);
 }

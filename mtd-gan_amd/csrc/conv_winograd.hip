@@ -601,7 +601,8 @@ bool wino_eligible(const mtd_conv_args& a) {
         if (dy < -1 || dy > 1 || dx < -1 || dx > 1) return false;
     }
     if (g.tap_dy == 0 || g.tap_dx == 0) return false;
-    if ((a.C % 16) || a.out2) return false;
+    if (a.C % 16) return false;
+    if (a.out2 && !(a.N == 32 && a.C == 32 && a.mask)) return false;      // (a second output: the persistent 32 -> 32 kernel's MASKED2 form only; mtd_conv_winograd_ok checks that it takes the launch)
     // N a multiple of 64; or the generator's 32 -> 32 channel layers in the F(2x4) form: the persistent kernel of conv_wino_c32.h
     // (wino_c32_takes), else this kernel's 32-channel workgroups (NB = 1).  (Whether conv() sends them here is the host's
     // threshold, kernels.WINO_C32_MIN_HW: whole-slice inference yes, the 64 x 64 training patches no -- DESIGN 3.8.)
@@ -689,12 +690,16 @@ bool wino_c32_takes(const mtd_conv_args& a, int pxcode) {
     const int px = pxcode;       // (a split code, 20 / 22, never matches 6: N % 64 == 0 there)
     static const int env_on = [] { const char* e = mtd_lab_env("MTD_WINO_C32_KERNEL"); return e ? atoi(e) : 1; }();
     if (!env_on || px != 6 || a.C != 32 || a.N != 32) return false;
-    if (a.scale || a.scale2 || a.add2 || a.mask || a.out2) return false;
+    if (a.scale || a.scale2 || a.add2 || (a.out2 && !a.mask)) return false;
+    if (a.mask && (a.act == MTD_ACT_RELU_ADD || !aligned16(a.mask) || (a.mask_ld % 4))) return false;
+    if (a.out2 && (!aligned16(a.out2) || (a.out2_ld % 4))) return false;
     if (!wide_epilogue_ok(a) || !aligned16(a.in) || (a.in_ld % 4)) return false;
     const long long M = geom_pixels(a.g);
     if (M / 8 >= (1ll << 23)) return false;
     if (((M - 1) * a.out_ld + a.N) * 4 >= (1ll << 31)) return false;
     if (a.add1 && ((M - 1) * a.add1_ld + a.N) * 4 >= (1ll << 31)) return false;
+    if (a.mask && ((M - 1) * a.mask_ld + a.N) * 4 >= (1ll << 31)) return false;
+    if (a.out2 && ((M - 1) * a.out2_ld + a.N) * 4 >= (1ll << 31)) return false;
     return true;
 }
 
@@ -754,6 +759,9 @@ extern "C" int mtd_conv_winograd_ok(const mtd_conv_args* a) {
     if (((npix - 1) * a->in_ld + a->C) * 4 >= (1ll << 31)) return 0;
     if (geom_pixels(a->g) * a->N >= (1ll << 31)) return 0;
     if ((long long)144 * a->N * a->C >= (1ll << 31)) return 0;          // (the transformed weights inside 31-bit byte offsets, split form included)
+    // a mask on a 32 -> 32 layer / a second output: only the persistent kernel carries them in this form (the general kernel's
+    // 32-channel workgroups take a mask, never a second output -- and the caller's MASKED2 launches must not end up there)
+    if (a->out2 && !wino_c32_takes(*a, wino_patch_w(*a))) return 0;
     return 1;
 }
 
@@ -831,6 +839,8 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
         cp.nblocks = (wp.ntiles + C32_T - 1) / C32_T;
         cp.out_bytes = (unsigned)((((long long)p.M - 1) * a->out_ld + a->N) * 4);
         cp.add_bytes = a->add1 ? (unsigned)((((long long)p.M - 1) * a->add1_ld + a->N) * 4) : 0u;
+        cp.mask_bytes = a->mask ? (unsigned)((((long long)p.M - 1) * a->mask_ld + a->N) * 4) : 0u;
+        cp.out2_bytes = a->out2 ? (unsigned)((((long long)p.M - 1) * a->out2_ld + a->N) * 4) : 0u;
         const int per = (cp.nblocks + 7) / 8;                    // blocks per XCD; one workgroup per CU: 32 per XCD
         const int slots = per < 32 ? per : 32;
         const dim3 pgrid(8 * slots);
@@ -838,15 +848,17 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
         cp.d_tx = step % wp.tiles_x;
         cp.d_ty = (step / wp.tiles_x) % cp.tiles_y;
         cp.d_img = step / wp.tiles_per_image;
-        const int prof = mtd_prof_begin(0, a->add1 ? 26 : 25, 1, p.M, a->N, a->C, 9, s, algorithmic_bytes(a));
-        if (a->add1) MTD_LAUNCH((wino_c32_kernel<true>), pgrid, dim3(512), 0, s, cp);
+        const int prof = mtd_prof_begin(0, a->mask ? (a->add1 ? 33 : 32) : (a->add1 ? 26 : 25), 1, p.M, a->N, a->C, 9, s, algorithmic_bytes(a));
+        if (a->mask && a->add1) MTD_LAUNCH((wino_c32_kernel<true, true>), pgrid, dim3(512), 0, s, cp);
+        else if (a->mask) MTD_LAUNCH((wino_c32_kernel<false, true>), pgrid, dim3(512), 0, s, cp);
+        else if (a->add1) MTD_LAUNCH((wino_c32_kernel<true>), pgrid, dim3(512), 0, s, cp);
         else MTD_LAUNCH((wino_c32_kernel<false>), pgrid, dim3(512), 0, s, cp);
         mtd_prof_end(prof, s);
         MTD_LAUNCH_CHECK();
         return MTD_OK;
     }
     const dim3 grid((wp.ntiles + WT - 1) / WT, a->N / (32 * pl.nb), pl.splitk);
-    // (one profiler id per INSTANTIATION -- 14: <2, false, 4>, 15: <4, false, 4>, 22: <2, true, 4>, 23: <2, false, 6>, 24: <1, false, 6>; 25, 26: wino_c32_kernel<false / true> -- so that a record's name is
+    // (one profiler id per INSTANTIATION -- 14: <2, false, 4>, 15: <4, false, 4>, 22: <2, true, 4>, 23: <2, false, 6>, 24: <1, false, 6>; 25, 26: wino_c32_kernel<false / true, false>; 32, 33: wino_c32_kernel<false / true, true> -- so that a record's name is
     // one kernel symbol of a rocprofv3 table)
     // (27, 28: wino_conv3_kernel<6 / 4>, the split-bf16 forms)
     const int prof = mtd_prof_begin(0, split3 ? (px == 6 ? 27 : 28) : px == 6 ? (pl.nb == 1 ? 24 : 23) : (pl.nb == 4 ? 15 : (pl.lean ? 22 : 14)), pl.splitk, p.M, a->N, a->C, 9, s, algorithmic_bytes(a));

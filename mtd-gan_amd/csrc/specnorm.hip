@@ -226,7 +226,36 @@ __global__ __launch_bounds__(256) void sn_grad_dot_kernel(const mtd_sn_grad_laye
     const unsigned base = (unsigned)local * GRAD_ELEMS_PER_BLOCK;
     const bool two = ly.G2 != nullptr;
     float p = 0.f, p2 = 0.f;
-    if (grad_vec_ok(ly)) {
+    if (ly.act_gy) {
+        // activation-side form (mtd_sn_grad_layer.act_*): sigma_s * sum over the pass's pixels of gy (y - b), y from the saved activation.
+        // The layer keeps its grad_blocks() blocks (the sum kernel's layout); act_M * rows <= rows * cols elements are spread over them in
+        // the same fixed order, blocks past the end contribute zeros.
+        const unsigned N = (unsigned)ly.rows, atotal = (unsigned)ly.act_M * N;
+        const float islope = ly.act_inv_slope;
+#pragma unroll 2
+        for (int i = threadIdx.x * 4; i < GRAD_ELEMS_PER_BLOCK; i += 1024) {
+            const unsigned e = base + i;
+            if (e < atotal) {
+                const unsigned pix = e / N, n = e - pix * N;                 // N % 4 == 0: the four elements share a pixel
+                float4 g = *reinterpret_cast<const float4*>(ly.act_gy + (size_t)pix * ly.act_gy_ld + n);
+                if (ly.act_gy2) {
+                    const float4 h = *reinterpret_cast<const float4*>(ly.act_gy2 + (size_t)pix * ly.act_gy2_ld + n);
+                    g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w;
+                }
+                const float4 av = *reinterpret_cast<const float4*>(ly.act_a + (size_t)pix * ly.act_a_ld + n);
+                const float4 b = *reinterpret_cast<const float4*>(ly.act_bias + n);
+                float t = 0.f;
+                t = fmaf(g.x, (av.x > 0.f ? av.x : av.x * islope) - b.x, t);
+                t = fmaf(g.y, (av.y > 0.f ? av.y : av.y * islope) - b.y, t);
+                t = fmaf(g.z, (av.z > 0.f ? av.z : av.z * islope) - b.z, t);
+                t = fmaf(g.w, (av.w > 0.f ? av.w : av.w * islope) - b.w, t);
+                if ((int)pix < ly.act_M_first) p += t;
+                else p2 += t;
+            }
+        }
+        p *= ly.sigma[0];
+        if (two) p2 *= ly.sigma2[0];
+    } else if (grad_vec_ok(ly)) {
         // fixed association: lane-local sums over its float4s in index order, then the block tree
 #pragma unroll 4
         for (int i = threadIdx.x * 4; i < GRAD_ELEMS_PER_BLOCK; i += 1024) {
@@ -391,6 +420,16 @@ extern "C" size_t mtd_sn_grad_ws_bytes(const mtd_sn_grad_layer* layers_host, int
 extern "C" int mtd_sn_grad(const mtd_sn_grad_layer* layers_dev, const mtd_sn_grad_layer* layers_host, int n_layers, float* ws,
                            void* stream) {
     if (!layers_dev || !layers_host || n_layers <= 0 || !ws) return MTD_EINVAL;
+    for (int i = 0; i < n_layers; ++i) {
+        const mtd_sn_grad_layer& l = layers_host[i];
+        if (!l.act_gy) continue;
+        // the activation-side dot: its elements fit the layer's blocks, float4 accesses everywhere, a second pass only with a second sigma
+        if (!l.act_a || !l.act_bias || l.act_M <= 0 || l.act_M_first < 0 || l.act_M_first > l.act_M) return MTD_EINVAL;
+        if ((long long)l.act_M * l.rows > (long long)l.rows * l.cols || (long long)l.act_M * l.rows >= (1ll << 31)) return MTD_EINVAL;
+        if ((l.rows % 4) || (l.act_gy_ld % 4) || (l.act_a_ld % 4) || (l.act_gy2 && (l.act_gy2_ld % 4))) return MTD_EALIGN;
+        if (!aligned16(l.act_gy) || !aligned16(l.act_a) || !aligned16(l.act_bias) || (l.act_gy2 && !aligned16(l.act_gy2))) return MTD_EALIGN;
+        if (l.act_M_first < l.act_M && !l.G2) return MTD_EINVAL;
+    }
     const long long nb = sn_grad_blocks_host(layers_host, n_layers);
     SnGradWs w;
     w.partial = ws;

@@ -161,6 +161,7 @@ class Tape:
     pass
 
 
+SN_ACT_DOT = _options.lab("MTD_SN_ACT_DOT", "1") != "0"        # the spectral-norm correction's <G, W> from (cotangent, saved output) on the small maps (round 6)
 SKIP_IN_CAT = _options.lab("MTD_SKIP_IN_CAT", "1") != "0"      # trunk outputs written into the pixel-level decoder's concatenated buffers
 
 
@@ -364,6 +365,7 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
     x = tp.x_in
     dev = x.device
     sn_touched = []
+    sn_act = {}                 # layer -> (cotangent, second cotangent or None, saved output, 1 / slope): see wgrad_sn
     side = K.side_stream(dev)   # weight gradients run beside the data-gradient chain
 
     def want(name):
@@ -387,15 +389,21 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
             return f
         return lambda: p
 
-    def wgrad_sn(name, p, q, gspec, N, Cc, k):
+    def wgrad_sn(name, p, q, gspec, N, Cc, k, yout=None, slope=0.2):
         """Raw weight gradient of an SN layer into the pass's temp (corrected and accumulated by mtd_sn_grad below).
         gspec = (h, k, stride, pad) of the forward conv.  A paired tape needs the two passes' gradients separately (each
-        has its own sigma, u, v), so its batch halves go through two launches."""
+        has its own sigma, u, v), so its batch halves go through two launches.
+        yout: the layer's saved output (after its activation of negative slope `slope`; 1.0: none) -- where the layer has fewer
+        output pixels than weight columns, the correction's <G, W> is taken from (p, yout) instead of from the gradient and the
+        weights (mtd_sn_grad_layer.act_*)."""
         wn, bn = name + ".weight_orig", name + ".bias"
         if want(wn):
             src = cot(name, p)
             if src is None:
                 return
+            if SN_ACT_DOT and yout is not None and p.shape[0] * p.shape[1] * p.shape[2] < Cc * k * k and N % 4 == 0:
+                pe, pe2 = getattr(src, "parts", None) or (p, None)
+                sn_act[name] = (pe, pe2, yout, 1.0 / slope)      # (references: the cotangents stay allocated until sn_fix has read them)
             hh, kk, ss, pp = gspec
             if Bh:
                 gfull = K.geom_fwd(B, hh, hh, kk, ss, pp)
@@ -425,7 +433,7 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
         if not sn_touched:
             return
         L = _lib.lib()
-        structs = []
+        structs, held = [], []
         for name in sn_touched:
             i = SN_INDEX[name]
             s = _lib.SnGradLayer()
@@ -441,6 +449,19 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
                 s.u2 = tp.u_save2.data_ptr() + 4 * SN_ROW_OFF[i]
                 s.v2 = tp.v_save2.data_ptr() + 4 * SN_COL_OFF[i]
                 s.sigma2 = tp.sig2.data_ptr() + 8 * i
+            act = sn_act.pop(name, None)
+            if act is not None:
+                pe, pe2, yout, inv_slope = act
+                ok = all(t is None or (t.data_ptr() % 16 == 0 and K.ld_of(t) % 4 == 0) for t in (pe, pe2, yout)) and P[name + ".bias"].data_ptr() % 16 == 0
+                if ok:
+                    npix = pe.shape[0] * pe.shape[1] * pe.shape[2]
+                    s.act_gy, s.act_gy_ld = pe.data_ptr(), K.ld_of(pe)
+                    if pe2 is not None:
+                        s.act_gy2, s.act_gy2_ld = pe2.data_ptr(), K.ld_of(pe2)
+                    s.act_a, s.act_a_ld = yout.data_ptr(), K.ld_of(yout)
+                    s.act_bias = P[name + ".bias"].data_ptr()
+                    s.act_M, s.act_M_first, s.act_inv_slope = npix, (Bh * (npix // B) if Bh else npix), inv_slope
+                    held.extend(t for t in (pe, pe2, yout) if t is not None)
             structs.append(s)
         del sn_touched[:]
         def fix():
@@ -450,6 +471,7 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
             need = L.mtd_sn_grad_ws_bytes(C.cast(host_arr, C.c_void_p), len(structs))
             ws = K.workspace(need, dev)
             K.check(L.mtd_sn_grad(dev_tab.data_ptr(), C.cast(host_arr, C.c_void_p), len(structs), ws.data_ptr(), K.stream_ptr()), "mtd_sn_grad")
+            K.crosses_streams(*held)             # (cotangents / activations of the main stream read here, on the side stream)
         # (its operands are the raw weight gradients the side stream itself produced, the layer's weights and the saved u / v / sigma of
         # the forward pass: nothing the main stream has enqueued since the last fork -- no new hand-off)
         side.run(fix, fork=False)
@@ -483,10 +505,10 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
             g3 = K.geom_fwd(B, r, r, 3, 1, 1)
             gpre2 = g                                      # already times (o2 > 0 ? 1 : 0.2)
             below = o2s[lvl - 1] if lvl > 1 else None      # output of the level below (None: the bottleneck, masked by the caller)
-            wgrad_sn(f"{pre}_dconv{lvl}2", gpre2, o1, (r, 3, 1, 1), co, co, 3)
+            wgrad_sn(f"{pre}_dconv{lvl}2", gpre2, o1, (r, 3, 1, 1), co, co, 3, yout=o2)
             gpre1 = K.empty_nhwc(B, r, r, co, x)
             dgrad_s1(f"{pre}_dconv{lvl}2", gpre2, r, co, co, gpre1, mask=o1)
-            wgrad_sn(f"{pre}_dconv{lvl}1", gpre1, cat, (r, 3, 1, 1), co, ccat, 3)
+            wgrad_sn(f"{pre}_dconv{lvl}1", gpre1, cat, (r, 3, 1, 1), co, ccat, 3, yout=o1)
             gcat = K.empty_nhwc(B, r, r, ccat, x)
             dgrad_s1(f"{pre}_dconv{lvl}1", gpre1, r, ccat, co, gcat)
             cprev = tin.shape[3] if pre == "s" else RUP[lvl - 1][1]
@@ -523,7 +545,7 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
         gpre = K.act_grad(gc, tp.c, 0.2)
         wn = "c_fc.weight_orig"
         if want(wn):
-            wgrad_sn("c_fc", gpre, tp.bot, (1, 1, 1, 0), 512, 512, 1)
+            wgrad_sn("c_fc", gpre, tp.bot, (1, 1, 1, 0), 512, 512, 1, yout=tp.c)
         gb = K.empty_nhwc(B, 1, 1, 512, x)
         K.conv(gpre, P[wn], g1, 512, 512, 1, 512, gb, **_scales(tp, "c_fc", g1))
         g_bot_parts.append(gb)
@@ -535,10 +557,10 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
     for extra in g_bot_parts[1:]:
         K.copy_channels(extra, gbot, accumulate=True)
     gpre = K.act_grad(gbot, tp.bot, 0.2)
-    wgrad_sn("bconv2", gpre, tp.b1, (1, 1, 1, 0), 512, 512, 1)
+    wgrad_sn("bconv2", gpre, tp.b1, (1, 1, 1, 0), 512, 512, 1, yout=tp.bot)
     gpre1 = K.empty_nhwc(B, 1, 1, 512, x)
     K.conv(gpre, P["bconv2.weight_orig"], g1, 512, 512, 1, 512, gpre1, mask=tp.b1, mask_slope=0.2, **_scales(tp, "bconv2", g1))
-    wgrad_sn("bconv1", gpre1, tp.d6, (1, 1, 1, 0), 512, 512, 1)
+    wgrad_sn("bconv1", gpre1, tp.d6, (1, 1, 1, 0), 512, 512, 1, yout=tp.b1)
     g = K.empty_nhwc(B, 1, 1, 512, x)
     K.conv(gpre1, P["bconv1.weight_orig"], g1, 512, 512, 1, 512, g, **_scales(tp, "bconv1", g1))
 
@@ -549,7 +571,7 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
         co = CH[l - 1]
         ci = 1 if l == 1 else CH[l - 2]
         xl, a, tin = tp.xs[l], tp.a[l], tp.tin[l]
-        wgrad_sn(f"down{l}", g, xl, (h, 4, 2, 1), co, co, 4)
+        wgrad_sn(f"down{l}", g, xl, (h, 4, 2, 1), co, co, 4, yout=(tp.tin[l + 1] if l < 6 else tp.d6), slope=1.0)
         gpre2 = K.empty_nhwc(B, h, h, co, x)
         adds = g_skip[l]
         add1 = adds[0] if len(adds) > 0 else None
@@ -564,10 +586,10 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
                               dict(add1=add1, add2=add2, mask=xl, mask_slope=0.2, **_scales(tp, f"down{l}", gp))))
         K.conv_multi(calls)
         g3 = K.geom_fwd(B, h, h, 3, 1, 1)
-        wgrad_sn(f"conv{l}2", gpre2, a, (h, 3, 1, 1), co, co, 3)
+        wgrad_sn(f"conv{l}2", gpre2, a, (h, 3, 1, 1), co, co, 3, yout=xl)
         gpre1 = K.empty_nhwc(B, h, h, co, x)
         dgrad_s1(f"conv{l}2", gpre2, h, co, co, gpre1, mask=a)
-        wgrad_sn(f"conv{l}1", gpre1, tin, (h, 3, 1, 1), co, ci, 3)
+        wgrad_sn(f"conv{l}1", gpre1, tin, (h, 3, 1, 1), co, ci, 3, yout=a)
         if l == FLUSH_LEVEL:
             flush_point("trunk_low")
         if l > 1:

@@ -36,6 +36,17 @@ def block_forward(x, w_img, b_img, w_fft, b_fft, save, w2t=None):
         return out, None
     if w2t is None:
         w2t = K.transpose64(w_fft)
+    if K.BLOCK_FWD_WINO:
+        # lab (round 6): the spatial branch on the persistent F(2x4, 3x3) kernel (conv_wino_c32.h, side stream) + the closing row
+        # transform as a launch of its own, instead of the halo-tile kernel with the transform in its tail
+        side = K.side_stream(x.device, 1)
+        side.run(lambda: K.conv(x, w_img, g, CH, CH, CH * 9, 9, img, bias=b_img, act=ACT_RELU, wino32=True), x)
+        R = K.rfft_rows(x, 0)
+        T, S, Z = K.spec_mix_fwd(R, w2t, b_fft, save)
+        out = K.empty_nhwc(B, H, W, CH, x)
+        side.join()
+        K.irfft_rows(T, out, add1=x, add2=img)
+        return out, ((x, img, S, Z) if save else None)
     if K.BLOCK_TAIL and K.block_tail_ok(x, w_img, g, img, b_img):
         # spectral branch first; the spatial branch's launch then carries the inverse row transform and the residual:
         # img = relu(conv3x3(x) + b), out = x + img + irfft_rows(T) (mtd_resfft_block_tail)
@@ -65,7 +76,7 @@ def block_backward(g, saved, w_img, w_fft, grads, premask, defer=None, gm=None):
     side = K.side_stream(x.device)
     if gm is None:
         gm = K.act_grad(g, img, 0.0)                                                # g * (img > 0)
-    if K.BLOCK_TAIL and defer is not None and K.DEFER_WGRADS and not K.FUSE_WGRAD_ROWS:
+    if K.BLOCK_TAIL and defer is not None and K.DEFER_WGRADS and not K.FUSE_WGRAD_ROWS and not K.BLOCK_BWD_WINO:
         # spectral chain first; the block conv's fused data + weight gradient launch then also takes the closing row
         # transform: gx = (dgrad(gm) + g + irfft_rows(gT)) * (x > 0)  (mtd_conv_c32_bwd_irfft)
         gx = K.empty_nhwc(B, H, W, CH, x)
@@ -83,7 +94,7 @@ def block_backward(g, saved, w_img, w_fft, grads, premask, defer=None, gm=None):
     fused_rows = defer is not None and K.DEFER_WGRADS and K.FUSE_WGRAD_ROWS
     # data gradient + weight gradient of the block's 3x3 conv in ONE launch (csrc/conv_c32_bwd.hip) where the pair is eligible
     d1 = K.empty_nhwc(B, H, W, CH, x)
-    dgrad_call = ((gm, w_img, K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, d1), dict(add1=g))
+    dgrad_call = ((gm, w_img, K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, d1), dict(add1=g, wino32=True) if K.BLOCK_BWD_WINO else dict(add1=g))
     wgrad_args = (gm, x, K.geom_fwd(B, H, W, 3, 1, 1), CH, CH, grads["dw_img"], CH * 9, 9)
     fused_bwd = (not fused_rows) and K.conv_wgrad_fused(dgrad_call, (wgrad_args, dict(db=grads["db_img"])), defer)
     if not fused_rows and not fused_bwd:
@@ -142,9 +153,18 @@ def generator_forward(x, P, save, out=None):
     # them (kernels.winograd_takes: whole slices always, the training patches in this forward pass): their transformed weights
     # in one launch per weight update.
     fwd32 = dict(wino32=True)
-    K.prepack_winograd([(P.enc_w[i], CH, CH, CH * 9, 9, gf, fwd32) for i in range(1, L + 1)]
-                       + [(P.dec_w[i], CH, CH, 9, CH * 9, gt, fwd32) for i in range(1, L + 1)]
-                       + [(blk[0], CH, CH, CH * 9, 9, gf) for blk in P.blk])          # (the blocks' convs: whole slices only)
+    wviews = ([(P.enc_w[i], CH, CH, CH * 9, 9, gf, fwd32) for i in range(1, L + 1)]
+              + [(P.dec_w[i], CH, CH, 9, CH * 9, gt, fwd32) for i in range(1, L + 1)]
+              + [(blk[0], CH, CH, CH * 9, 9, gf, fwd32 if K.BLOCK_FWD_WINO else {}) for blk in P.blk])      # (the blocks' convs: whole slices; training patches under BLOCK_FWD_WINO)
+    if save:
+        # ... and the views the backward pass will ask for (generator_backward / block_backward), in the same launch
+        m32 = dict(wino32=True, mask=x)                    # (the keywords decide the routing, not the values)
+        if K.WINO_C32_BWD:
+            wviews += [(P.dec_w[i], CH, CH, CH * 9, 9, gf, m32) for i in range(1, L + 1)]
+            wviews += [(P.enc_w[i], CH, CH, 9, CH * 9, gt, m32) for i in range(1, L + 1)]
+        if K.BLOCK_BWD_WINO:
+            wviews += [(blk[0], CH, CH, 9, CH * 9, gt, fwd32) for blk in P.blk]
+    K.prepack_winograd(wviews)
     tape = {"t": [], "e": [], "blk": [], "d": [], "u": []}
     t = K.empty_nhwc(B, H, W, CH, x)
     K.conv(x, P.enc_w[0], gf, CH, 1, 9, 9, t, bias=P.enc_b[0], act=ACT_RELU)
@@ -202,6 +222,7 @@ def generator_backward(g_out, tape, P, G):
     # A data-gradient launch also writes its result times (img > 0) of the block that consumes it -- that block's
     # masked cotangent, otherwise a pass of its own (21 x 10 us per step) -- where the halo-tile kernel runs it.
     fuse = K.fuses_masked_cotangent(B, H, W, CH, CH)
+    w32 = dict(wino32=True) if K.WINO_C32_BWD else {}      # (the plain layers' data gradients on the persistent F(2x4) kernel's MASKED2 form)
     gm = None
     # blocks 20..11 and decoders 1..10 (tape order: d/u/blk appended for j = 10..1)
     for j in range(1, L + 1):
@@ -213,7 +234,7 @@ def generator_backward(g_out, tape, P, G):
         wg = ((gpre_d, uj, gt, CH, CH, G.dec_w[j], 9, CH * 9), dict(db=G.dec_b[j]))
         if fuse:                                            # consumer: block 2L - j (tape position L + k), or block L after the loop
             gm = K.empty_nhwc(B, H, W, CH, x)
-            dg = ((gpre_d, P.dec_w[j], gf, CH, CH, CH * 9, 9, gm), dict(mask=tape["blk"][L + k][1], mask_slope=0.0, out2=gu))
+            dg = ((gpre_d, P.dec_w[j], gf, CH, CH, CH * 9, 9, gm), dict(mask=tape["blk"][L + k][1], mask_slope=0.0, out2=gu, **w32))
         else:
             dg = ((gpre_d, P.dec_w[j], gf, CH, CH, CH * 9, 9, gu), {})
         if not K.conv_wgrad_fused(dg, wg, defer):           # one launch for the layer's two gradients, else two
@@ -230,7 +251,7 @@ def generator_backward(g_out, tape, P, G):
             if fuse:
                 gm = K.empty_nhwc(B, H, W, CH, x)
                 dg = ((gpre_t, P.enc_w[i], K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, gm),
-                      dict(add1=skip[i], mask=tape["blk"][i - 1][1], mask_slope=0.0, out2=g_e))
+                      dict(add1=skip[i], mask=tape["blk"][i - 1][1], mask_slope=0.0, out2=g_e, **w32))
             else:
                 dg = ((gpre_t, P.enc_w[i], K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, g_e), dict(add1=skip[i]))
             if not K.conv_wgrad_fused(dg, wg, defer):

@@ -134,6 +134,9 @@ WINO_C32_MIN_HW = int(_options.lab("MTD_WINO_C32_MIN_HW", "128"))
 # ... and the FORWARD pass of the generator's plain encoder / decoder layers on the training patches too (conv(..., wino32=True):
 # 23 us per layer against the halo-tile kernel's 28; generator leg 5.45 -> 5.33 ms).  The backward pass keeps its fused kernels.
 WINO_C32_FWD = _options.lab("MTD_WINO_C32_FWD", "1") != "0"
+# ... and (round 6) their DATA GRADIENTS: the kernel's MASKED2 form writes the cotangent and its masked form for the consuming block
+# (conv(..., wino32=True, mask=..., out2=...)); the weight gradient goes to wgrad_wino32_kernel on the side stream
+WINO_C32_BWD = _options.lab("MTD_WINO_C32_BWD", "0") != "0"
 _kmap_cache = {}
 
 
@@ -156,7 +159,7 @@ def winograd_takes(geom, N, Cc, kw):
         return False
     if not (geom.out_sy == 1 and geom.out_sx == 1 and geom.out_oy == 0 and geom.out_ox == 0 and geom.OHF == geom.OH and geom.OWF == geom.OW):
         return False
-    if kw.get("out2") is not None or (Cc % 16):
+    if (Cc % 16) or (kw.get("out2") is not None and not (WINO_C32_BWD and kw.get("wino32") and Cc == 32 and N == 32 and kw.get("mask") is not None)):
         return False
     if Cc < WINO_MIN_C or (N % 64) or N < WINO_MIN_N:
         # (the 32-channel form; the library checks that the layer's transform is F(2x4): mtd_conv_winograd_ok)
@@ -165,8 +168,8 @@ def winograd_takes(geom, N, Cc, kw):
         if min(geom.OH, geom.OW) < WINO_C32_MIN_HW:
             # smaller maps: only where the caller asks for it (wino32=True: the generator's forward pass) and the persistent
             # kernel itself takes the launch (mirror of wino_c32_takes: one residual operand at most, no scale, no mask)
-            if not (WINO_C32_FWD and kw.get("wino32") and min(geom.OH, geom.OW) >= 16 and kw.get("mask") is None and kw.get("add2") is None
-                    and kw.get("scale") is None and kw.get("scale2") is None):
+            if not (WINO_C32_FWD and kw.get("wino32") and min(geom.OH, geom.OW) >= 16 and (kw.get("mask") is None or WINO_C32_BWD)
+                    and kw.get("add2") is None and kw.get("scale") is None and kw.get("scale2") is None):
                 return False
     elif kw.get("act") == ACT_RELU_ADD:
         return False
@@ -190,11 +193,6 @@ def winograd_patch_w(geom, N, Cc):
         px = _lib.lib().mtd_conv_winograd_patch_w(C.byref(a))
         _wino_px_cache[key] = px
     return px
-
-
-def wgrad_wino24_min_w(min_w):
-    """Tuning / test hook (mtd_conv_wgrad_wino24_min_w): narrowest map whose weight gradient takes F(2x4, 3x3); 0 = never."""
-    return _lib.lib().mtd_conv_wgrad_wino24_min_w(int(min_w))
 
 
 def winograd_f4_min_w(min_w):
@@ -397,18 +395,18 @@ FLOP_COUNT = None
 _FFT_HALF_PLANE = 2.5 * 4096 * 12 / 2
 
 
-WGRAD_CFG_WINO, WGRAD_CFG_WINO24 = 16, 17      # mtd_conv_wgrad_plan_cfg: wgrad_wino_kernel (F(2x2, 3x3)), wgrad_wino24_kernel (F(2x4, 3x3))
+WGRAD_CFG_WINO = 16                            # mtd_conv_wgrad_plan_cfg: wgrad_wino_kernel (F(2x2, 3x3); 17 was its F(2x4) form, removed in round 6)
 WGRAD_CFG_WINO_S2 = 18                         # wgrad_wino_s2_kernel: F(3x3, 2x2) over the four phases of a 4x4 / stride-2 layer
 WGRAD_CFG_WINO32 = 19                          # wgrad_wino32_kernel: F(2x2, 3x3) on the generator's 32 x 32 block
 
 
 def _count_wgrad(geom, N, Cc, cfg):
     """Executed flops of one weight-gradient launch: 2 M N C taps on the matrix cores (or the vector ALU for the degenerate
-    channel counts); the Winograd kernels multiply 4 (F(2x2)) or 3 (F(2x4)) instead of 9 times per output pixel, the rest is
+    channel counts); the Winograd kernels multiply 4 (F(2x2)) instead of 9 times per output pixel, the rest is
     `wgrad_winograd_saved`."""
     full = 2.0 * geom.B * geom.OH * geom.OW * N * Cc * geom.TH * geom.TW
-    if cfg in (WGRAD_CFG_WINO, WGRAD_CFG_WINO24, WGRAD_CFG_WINO_S2, WGRAD_CFG_WINO32):
-        share = 4.0 / 9.0 if cfg in (WGRAD_CFG_WINO, WGRAD_CFG_WINO32) else 3.0 / 9.0
+    if cfg in (WGRAD_CFG_WINO, WGRAD_CFG_WINO_S2, WGRAD_CFG_WINO32):
+        share = 4.0 / 9.0
         if cfg == WGRAD_CFG_WINO_S2:      # 16 multiplications per 3 x 3 tile (ragged tiles in full) and phase instead of 16 per pixel
             share = ((geom.OH + 2) // 3) * ((geom.OW + 2) // 3) * 16 * 4 / (geom.OH * geom.OW * 16.0)
         _count("wgrad_mfma", full * share)
@@ -431,14 +429,15 @@ IGEMM_CONFIGS = ["igemm_kernel<2, 1, 4, 1>", "igemm_kernel<1, 1, 4, 1>", "igemm_
                  "igemm_multi_kernel<2, 1, 4, 1>", "igemm_multi_kernel<1, 1, 4, 1>", "igemm_multi_kernel<2, 2, 4, 1>",      # 16 + cfg
                  "igemm_multi_kernel<1, 1, 2, 2>", "igemm_multi_kernel<2, 2, 2, 2>", "igemm_multi_kernel<1, 1, 1, 4>",
                  "wino_conv_kernel<2, true, 4>", "wino_conv_kernel<2, false, 6>", "wino_conv_kernel<1, false, 6>",             # 22, 23, 24 (6: F(2x4, 3x3))
-                 "wino_c32_kernel<false>", "wino_c32_kernel<true>",                                                             # 25, 26: the persistent 32 -> 32 channel form
+                 "wino_c32_kernel<false, false>", "wino_c32_kernel<true, false>",                                               # 25, 26: the persistent 32 -> 32 channel form
                  "wino_conv3_kernel<6>", "wino_conv3_kernel<4>",                                                                # 27, 28: the split-bf16 forms (conv_winograd_split.h)
-                 "wino32_conv_kernel<2, false>", "wino32_conv_kernel<2, true>", "wino32_conv_kernel<4, false>"]                                                                                       # 29: F(3x3, 2x2) for the 4x4 / stride-2 layers (conv_wino_s2.h)
+                 "wino32_conv_kernel<2, false>", "wino32_conv_kernel<2, true>", "wino32_conv_kernel<4, false>",
+                 "wino_c32_kernel<false, true>", "wino_c32_kernel<true, true>"]      # 32, 33: ... with a mask operand and a second output (round 6)                                                                                       # 29: F(3x3, 2x2) for the 4x4 / stride-2 layers (conv_wino_s2.h)
 WGRAD_CONFIGS = ["wgrad_kernel<1, 1, 9>", "wgrad_kernel<1, 1, 4>", "wgrad_kernel<2, 2, 1>", "wgrad_kernel<1, 1, 8>",
                  "wgrad_kernel<1, 1, 3>", "wgrad_kernel<1, 1, 1>", "wgrad_kernel<2, 2, 3>",
                  "wgrad_row_kernel<3, 3, 1>", "wgrad_row_kernel<3, 3, -1>", "wgrad_row_kernel<1, 1, 1>",
                  "wgrad_blk_kernel<8>", "wgrad_blk_kernel<4>", "wgrad_blk_kernel<2>", "wgrad_taps_kernel", "?", "wgrad_s2_kernel",
-                 "wgrad_wino_kernel", "wgrad_wino24_kernel", "wgrad_wino_s2_kernel", "wgrad_wino32_kernel"]
+                 "wgrad_wino_kernel", "?", "wgrad_wino_s2_kernel", "wgrad_wino32_kernel"]
 
 
 SPECTRAL_KERNELS = ["rfft_rows_any_kernel", "spec_mix_any_kernel", "irfft_rows_any_kernel"]      # profiler class 2 (HBM-bound)
@@ -864,7 +863,7 @@ def conv_wgrad_fusable(conv_call, wgrad_call):
     (p_, q_, geom, N, Cc, dw, w_sn, w_sc), wkw = wgrad_call
     if not (FUSE_C32_BWD and DEFER_WGRADS and N == 32 and Cc == 32 and not wkw.get("accumulate")):
         return False
-    d = _conv_args(*conv_call[0], count=False, **conv_call[1])
+    d = _conv_args(*conv_call[0], count=False, **{k: v for k, v in conv_call[1].items() if k != "wino32"})
     a = WgradArgs()
     a.g = geom
     a.p, a.p_ld, a.N = p_.data_ptr(), ld_of(p_), N
@@ -885,7 +884,7 @@ def conv_wgrad_fused(conv_call, wgrad_call, defer, spec=None):
     if not (FUSE_C32_BWD and defer is not None and DEFER_WGRADS and N == 32 and Cc == 32 and not wkw.get("accumulate")):
         return False
     L = _lib.lib()
-    d = _conv_args(*conv_call[0], **conv_call[1])
+    d = _conv_args(*conv_call[0], **{k: v for k, v in conv_call[1].items() if k != "wino32"})
     a = WgradArgs()
     a.g = geom
     a.p, a.p_ld, a.N = p_.data_ptr(), ld_of(p_), N
@@ -1002,6 +1001,13 @@ def irfft_rows(T, out, add1=None, add2=None, mask=None):
 
 CH32 = 32
 BLOCK_TAIL = _options.lab("MTD_NO_BLOCK_TAIL", "0") != "1"      # conv3x3 + inverse row transform + residual in one launch
+
+
+# lab (round 6): a Res-FFT-Conv block's 3x3 conv on the persistent F(2x4, 3x3) kernel in the forward pass (BLOCK_FWD_WINO)
+# and as its data gradient (BLOCK_BWD_WINO: three launches -- that kernel, the Winograd 32 x 32 weight gradient on the side stream, the
+# closing row transform -- instead of the fused c32_bwd launch)
+BLOCK_FWD_WINO = _options.lab("MTD_BLOCK_FWD_WINO", "0") == "1"
+BLOCK_BWD_WINO = _options.lab("MTD_BLOCK_BWD_WINO", "0") == "1"
 
 
 def block_tail_ok(x, w, geom, img, bias):

@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 import mtdgan_oracle as orc
 
@@ -158,6 +159,75 @@ def test_sn_grad_kernel_vs_formula(hip_lib, paired):
     for t, ref, shp in zip(keep, want, shapes):
         err = rel(t["out"], ref)       # fp32 rounding of <G, W> over up to 4 Mi products, relative to the largest entry
         assert err < 2e-5, (shp, err)
+
+
+@pytest.mark.parametrize("case", [(6, 4, 64, 128, 3, 1, 0.2, True, False), (5, 2, 32, 64, 3, 1, 0.2, False, True), (8, 2, 64, 64, 4, 2, 1.0, True, True),
+                                  (16, 1, 128, 256, 1, 1, 0.2, True, False), (4, 4, 512, 512, 3, 1, 0.2, True, True)])
+def test_sn_grad_activation_side_dot_vs_weight_side(hip_lib, case):
+    """mtd_sn_grad_layer.act_* (round 6): the correction's <G, W> taken from the cotangent of the layer's output and the saved
+    activation -- sigma * sum gy (y - b), y = a > 0 ? a : a / slope -- instead of from G and W.  A real layer (torch, float64):
+    y = conv(x, W) / sigma + b, a = LeakyReLU(y), G = the weight gradient of <gy, conv(x, W)>; both forms of mtd_sn_grad on the same
+    G against the formula.  case = (B, map side of the OUTPUT, Cin, Cout, k, stride, slope, paired, second cotangent)."""
+    import ctypes as C
+    from mtd_gan_amd import _lib, kernels as K
+    B, h, ci, co, k, st, slope, paired, second = case
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(1234 + B)
+    pad = (k - 1) // 2 if st == 1 else 1
+    x = torch.randn(B, ci, h * st, h * st, generator=g, dtype=torch.double)
+    W = (torch.randn(co, ci, k, k, generator=g, dtype=torch.double) / (ci * k * k) ** 0.5).requires_grad_(True)
+    b = torch.randn(co, generator=g, dtype=torch.double) * 0.3
+    Bh = B // 2 if paired else B
+    sig = [1.7, 0.6]
+    lin = F.conv2d(x, W, None, st, pad)
+    scale = torch.cat([torch.full((Bh,), 1.0 / sig[0]), torch.full((B - Bh,), 1.0 / sig[1])]).double().view(B, 1, 1, 1)
+    y = lin * scale + b.view(1, co, 1, 1)
+    a = F.leaky_relu(y, slope) if slope != 1.0 else y
+    gy1 = torch.randn(y.shape, generator=g, dtype=torch.double)
+    gy2 = torch.randn(y.shape, generator=g, dtype=torch.double) if second else None
+    gy = gy1 + (gy2 if second else 0.0)
+    Gs = []
+    for lo, hi in ((0, Bh), (Bh, B)) if paired else ((0, B),):
+        Gs.append(torch.autograd.grad((gy[lo:hi] * lin[lo:hi]).sum(), W, retain_graph=True)[0].detach())
+    rows, cols = co, ci * k * k
+    Wm = W.detach().reshape(rows, cols)
+    u = [torch.randn(rows, generator=g, dtype=torch.double) for _ in range(2)]
+    v = [torch.randn(cols, generator=g, dtype=torch.double) for _ in range(2)]
+    out0 = torch.randn(rows, cols, generator=g, dtype=torch.double)
+    ref = out0.clone()
+    for i, Gm in enumerate(Gs):
+        Gm = Gm.reshape(rows, cols)
+        ref += Gm / sig[i] - (Gm * Wm).sum() / sig[i] ** 2 * torch.outer(u[i], v[i])
+    f32 = lambda t: t.float().to(dev).contiguous()
+    nhwc = lambda t: t.permute(0, 2, 3, 1).float().contiguous().to(dev)
+    t = dict(W=f32(Wm), G1=f32(Gs[0].reshape(rows, cols)), G2=f32(Gs[-1].reshape(rows, cols)), u1=f32(u[0]), v1=f32(v[0]), u2=f32(u[1]), v2=f32(v[1]),
+             b=f32(b), gy=nhwc(gy1), a=nhwc(a), s1=torch.tensor([sig[0], 1 / sig[0]], device=dev), s2=torch.tensor([sig[1], 1 / sig[1]], device=dev))
+    if second:
+        t["gy2"] = nhwc(gy2)
+    L = _lib.lib()
+    got = {}
+    for form in ("weights", "activations"):
+        out = f32(out0)
+        s = _lib.SnGradLayer()
+        s.G, s.w, s.u, s.v, s.sigma = (t[n].data_ptr() for n in ("G1", "W", "u1", "v1", "s1"))
+        s.g_out, s.rows, s.cols, s.accumulate = out.data_ptr(), rows, cols, 1
+        if paired:
+            s.G2, s.u2, s.v2, s.sigma2 = (t[n].data_ptr() for n in ("G2", "u2", "v2", "s2"))
+        if form == "activations":
+            M = B * h * h
+            assert M < cols
+            s.act_gy, s.act_gy_ld, s.act_a, s.act_a_ld, s.act_bias = t["gy"].data_ptr(), co, t["a"].data_ptr(), co, t["b"].data_ptr()
+            if second:
+                s.act_gy2, s.act_gy2_ld = t["gy2"].data_ptr(), co
+            s.act_M, s.act_M_first, s.act_inv_slope = M, Bh * h * h, 1.0 / slope
+        tab, host = K.device_table([s], dev)
+        ws = torch.empty(L.mtd_sn_grad_ws_bytes(C.cast(host, C.c_void_p), 1), dtype=torch.uint8, device=dev)
+        K.check(L.mtd_sn_grad(tab.data_ptr(), C.cast(host, C.c_void_p), 1, ws.data_ptr(), K.stream_ptr()), "mtd_sn_grad")
+        torch.cuda.synchronize()
+        got[form] = out
+        assert rel(out, ref) < 2e-5, (form, rel(out, ref))
+    # the two forms agree far inside the bound of either (the only difference is the rounding of one scalar per pass)
+    assert rel(got["activations"], got["weights"].double()) < 5e-6
 
 
 @pytest.mark.parametrize("shape", [(512, 512, 3, 2), (64, 64, 2, 32), (256, 256, 2, 8), (128, 32, 2, 16)])

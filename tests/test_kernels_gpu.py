@@ -803,6 +803,58 @@ def test_winograd_32_channel_form(hip_lib, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [(32, 64, 64, "fwd", True, True), (32, 64, 64, "dgrad", False, True), (3, 64, 64, "dgrad", True, False),
+                                  (2, 32, 48, "fwd", False, True), (5, 40, 36, "dgrad", True, True)])
+def test_winograd_32_channel_masked_two_output_form(hip_lib, monkeypatch, case):
+    """csrc/conv_wino_c32.h, MASKED2 (round 6): the persistent F(2x4, 3x3) kernel in the data-gradient role of the generator's plain
+    32 -> 32 layers -- out2 = conv (+ add1), out = out2 * (mask > 0 ? 1 : slope) -- against the halo-tile / implicit-GEMM launch of
+    the same arguments and against float64; both tap orders (a decoder's data gradient gathers like a forward conv, an encoder's
+    like a transposed one), with and without the residual operand and the second output; ragged block counts; repeatable."""
+    from mtd_gan_amd import kernels as K
+    B, H, W, what, has_add, has_out2 = case
+    monkeypatch.setattr(K, "WINO_C32_BWD", True)
+    gen = torch.Generator().manual_seed(41)
+    x = torch.randn(B, H, W, 32, generator=gen).cuda()
+    w = (torch.randn(32, 32, 3, 3, generator=gen) * 0.06).cuda()
+    add1 = torch.randn(B, H, W, 32, generator=gen).cuda() if has_add else None
+    mask = torch.randn(B, H, W, 32, generator=gen).cuda()
+    mask[0, 0, :4] = 0.0                                          # exact zeros take the slope side
+    if what == "fwd":
+        geom, wsn, wsc = K.geom_fwd(B, H, W, 3, 1, 1), 288, 9
+    else:
+        geom, wsn, wsc = K.geom_dgrad_s1(B, H, W, 3, 1), 9, 288
+    res = {}
+    for form in ("wino", "wino_again", "igemm"):
+        out = torch.full_like(x, float("nan"))
+        # (the halo-tile kernel writes a second output on the generator's own shape only: kernels.fuses_masked_cotangent)
+        out2 = torch.full_like(x, float("nan")) if has_out2 and (form != "igemm" or K.fuses_masked_cotangent(B, H, W, 32, 32)) else None
+        kw = dict(add1=add1, mask=mask, mask_slope=0.0, out2=out2)
+        if form != "igemm":
+            kw["wino32"] = True
+        K.FLOP_COUNT = {}
+        try:
+            K.conv(x, w, geom, 32, 32, wsn, wsc, out, **kw)
+        finally:
+            fc, K.FLOP_COUNT = K.FLOP_COUNT, None
+        torch.cuda.synchronize()
+        assert (fc.get("conv_winograd_saved", 0.0) > 0) == (form != "igemm")
+        assert not torch.isnan(out).any() and (out2 is None or not torch.isnan(out2).any())
+        res[form] = (out, out2)
+    assert torch.equal(res["wino"][0], res["wino_again"][0])
+    xc, wc = nchw(x).double(), w.cpu().double()
+    y = F.conv2d(xc, wc, None, padding=1) if what == "fwd" else F.conv_transpose2d(xc, wc, None, padding=1)
+    if has_add:
+        y = y + nchw(add1).double()
+    ym = y * (nchw(mask) > 0).double()
+    assert relerr(nchw(res["wino"][0]), ym) < TOL and relerr(res["wino"][0].cpu(), res["igemm"][0].cpu()) < 2e-5
+    if has_out2:
+        assert torch.equal(res["wino"][1], res["wino_again"][1])
+        assert relerr(nchw(res["wino"][1]), y) < TOL
+        if res["igemm"][1] is not None:
+            assert relerr(res["wino"][1].cpu(), res["igemm"][1].cpu()) < 2e-5
+
+
+@pytest.mark.gpu
 def test_winograd_32_channel_form_is_repeatable(hip_lib):
     """The persistent kernel's pipeline hands three blocks' work between its waves through LDS (two input images, one exchange
     image, two barriers per block): the same launch twice gives the same bits, on a whole-block shape, a ragged one and the
@@ -832,21 +884,15 @@ def test_winograd_32_channel_form_is_repeatable(hip_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["plan", "f2x2"])
 @pytest.mark.parametrize("case", [(2, 64, 64, 64, 64), (3, 128, 64, 16, 16), (5, 256, 512, 8, 8), (2, 64, 128, 10, 12), (32, 64, 64, 32, 32),
                                   (3, 64, 64, 6, 20), (7, 128, 192, 8, 8)])
-def test_winograd_weight_gradient_vs_torch(hip_lib, case, form):
-    """csrc/conv_wgrad_wino.h: Winograd weight + bias gradient (both operands transformed) against torch's autograd on the CPU
-    in float64 and against the row-window / block-window kernels on the same inputs; with and without accumulation into an
-    existing gradient.  form "plan": F(2x4, 3x3) (24 positions, 64 x 32 blocks) on maps at least 8 wide whose width is a multiple
-    of 4, F(2x2, 3x3) elsewhere; "f2x2": F(2x2, 3x3) everywhere.  (5, 256, 512, 8, 8): ragged slices; (2, 64, 128, 10, 12),
-    (3, 64, 64, 6, 20): odd tile counts; (7, 128, 192, 8, 8): 14 tiles, C = 192 = six 32-channel blocks."""
+def test_winograd_weight_gradient_vs_torch(hip_lib, case):
+    """csrc/conv_wgrad_wino.h: Winograd F(2x2, 3x3) weight + bias gradient (both operands transformed) against torch's autograd on
+    the CPU in float64 and against the row-window / block-window kernels on the same inputs; with and without accumulation into an
+    existing gradient.  (5, 256, 512, 8, 8): ragged slices; (2, 64, 128, 10, 12), (3, 64, 64, 6, 20): odd tile counts;
+    (7, 128, 192, 8, 8): 14 tiles, C = 192.  (The F(2x4, 3x3) form this test also covered in rounds 4-5 was removed in round 6.)"""
     from mtd_gan_amd import kernels as K
-    old_min_w = K.wgrad_wino24_min_w(0 if form == "f2x2" else 8)
-    try:
-        _winograd_wgrad_case(K, case, form)
-    finally:
-        K.wgrad_wino24_min_w(old_min_w)
+    _winograd_wgrad_case(K, case, "f2x2")
 
 
 def _winograd_wgrad_case(K, case, form):
@@ -906,13 +952,6 @@ def test_weight_gradient_pair_equals_two_launches(hip_lib, case):
             _pair_case(K, _lib, B, Bh, Ci, Co, H, W, k, expect)
         finally:
             L.mtd_conv_wgrad_pair_mode(prev)
-    if default_rule and k == 3 and W % 4 == 0:
-        # the F(2x4, 3x3) form of the Winograd weight gradient (off by default, conv_wgrad_wino.h): pair launch and second cotangent
-        old_min_w = K.wgrad_wino24_min_w(8)
-        try:
-            _pair_case(K, _lib, B, Bh, Ci, Co, H, W, k, 1)
-        finally:
-            K.wgrad_wino24_min_w(old_min_w)
 
 
 def _pair_case(K, _lib, B, Bh, Ci, Co, H, W, k, pairs):
