@@ -340,6 +340,13 @@ typedef struct {
 size_t mtd_sn_ws_bytes(const mtd_sn_layer* layers_host, int n_layers);
 int mtd_sn_power_iter(const mtd_sn_layer* layers_dev, const mtd_sn_layer* layers_host, int n_layers,
                       int train, float* ws, void* stream);
+/* nit train-mode power iterations on the same weights back to back (the discriminator step's four passes, networks.py:1957-1992 calls
+ * D four times before any weight changes): the tables hold nit * n_layers entries, iteration-major; entry [i * n_layers + l] says where
+ * iteration i leaves layer l's sigma / u_save / v_save (w, u, v, rows, cols as in entry l).  nit + 1 passes over the weights instead
+ * of 2 nit: W v of one iteration and W^T (W v) of the next share a pass.  Same workspace as mtd_sn_power_iter; results differ from nit
+ * calls of it by rounding (~1e-7). */
+int mtd_sn_power_iter_multi(const mtd_sn_layer* layers_dev, const mtd_sn_layer* layers_host, int n_layers, int nit,
+                            float* ws, void* stream);
 /* g_orig (+)= G/sigma - <G,W>/sigma^2 * u v^T       */
 typedef struct {
     const float* G; const float* w; const float* u; const float* v; const float* sigma;

@@ -236,6 +236,7 @@ def lib():
     sig("mtd_upload", ci, vp, vp, sz, vp)
     sig("mtd_sn_ws_bytes", sz, vp, ci)
     sig("mtd_sn_power_iter", ci, vp, vp, ci, ci, vp, vp)
+    sig("mtd_sn_power_iter_multi", ci, vp, vp, ci, ci, vp, vp)
     sig("mtd_sn_grad_ws_bytes", sz, vp, ci)
     sig("mtd_sn_grad", ci, vp, vp, ci, vp, vp)
     sig("mtd_pcgrad_ws_bytes", sz, ll, ci)
@@ -292,7 +293,7 @@ EXPORTS = [
     "mtd_conv_wgrad", "mtd_conv_wgrad_pair_ok", "mtd_conv_wgrad_pair_mode", "mtd_conv_wgrad_pair_ws_bytes", "mtd_conv_wgrad_pair", "mtd_conv_wgrad_pair_sum", "mtd_rfft_rows", "mtd_spec_mix_fwd", "mtd_spec_mix_bwd_ws_bytes", "mtd_spec_mix_bwd",
     "mtd_spec_mix_wgrad_reduce", "mtd_irfft_rows", "mtd_transpose64", "mtd_act_grad", "mtd_copy_channels",
     "mtd_upsample2x_fwd", "mtd_upsample2x_bwd", "mtd_pixel_shuffle2_fwd", "mtd_pixel_shuffle2_bwd", "mtd_mul", "mtd_pack_weights",
-    "mtd_sn_ws_bytes", "mtd_sn_power_iter", "mtd_sn_grad_ws_bytes", "mtd_sn_grad", "mtd_pcgrad_ws_bytes",
+    "mtd_sn_ws_bytes", "mtd_sn_power_iter", "mtd_sn_power_iter_multi", "mtd_sn_grad_ws_bytes", "mtd_sn_grad", "mtd_pcgrad_ws_bytes",
     "mtd_pcgrad_gram", "mtd_pcgrad_combine", "mtd_adamw_multi", "mtd_adamw_multi_dyn", "mtd_adamw_multi_pre", "mtd_loss_terms_ws_bytes", "mtd_loss_terms",
     "mtd_loss_term_grads", "mtd_clip01", "mtd_clip01_bwd", "mtd_edge_loss_ws_bytes", "mtd_edge_loss",
     "mtd_prof_enable", "mtd_prof_collect", "mtd_conv_igemm_override", "mtd_conv_wgrad_override", "mtd_upload", "mtd_image_metrics_ws_bytes", "mtd_image_metrics", "mtd_rfft_rows_any", "mtd_spec_mix_any", "mtd_irfft_rows_any",

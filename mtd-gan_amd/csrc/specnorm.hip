@@ -91,17 +91,27 @@ __global__ __launch_bounds__(256) void sn_wtu_kernel(const mtd_sn_layer* __restr
 }
 
 // t[k] = sum of the row-chunk partials (fixed order), and the per-column-chunk partial of |t|^2
-__global__ __launch_bounds__(256) void sn_tsum_kernel(const mtd_sn_layer* __restrict__ L, int n_layers, SnWs ws) {
+// rows_per_chunk: the rows one partial covers (ROWS_PER_BLOCK: sn_wtu_kernel's; FUSE_ROWS: sn_wv_wtu_kernel's).  from_s: the partials are
+// W^T s of the previous iteration's UNNORMALISED s = W v (sn_wv_wtu_kernel; s is in ws.wv): t = (sum) / max(|s|, eps) = W^T u.
+__global__ __launch_bounds__(256) void sn_tsum_kernel(const mtd_sn_layer* __restrict__ L, int n_layers, SnWs ws, int rows_per_chunk, int from_s) {
     __shared__ float red[256];
     int layer, chunk;
     if (!locate(n_layers, blockIdx.x, [&](int l) { return (L[l].cols + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK; }, layer, chunk)) return;
     const mtd_sn_layer ly = L[layer];
     const int k = chunk * COLS_PER_BLOCK + threadIdx.x;
-    const int nrc = (ly.rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    const int nrc = (ly.rows + rows_per_chunk - 1) / rows_per_chunk;
+    float inv_s = 1.f;
+    if (from_s) {
+        const float* wv = ws.wv + row_offset(L, layer);
+        float q = 0.f;
+        for (int r = threadIdx.x; r < ly.rows; r += 256) q += wv[r] * wv[r];      // (the association of sn_finish_kernel's |s|^2)
+        inv_s = 1.f / fmaxf(sqrtf(block_sum(q, red)), SN_EPS);
+    }
     float t = 0.f;
     if (k < ly.cols) {
         const float* src = ws.tp + col_offset(L, layer) * MAX_ROW_CHUNKS + k;
         for (int rc = 0; rc < nrc; ++rc) t += src[(long long)rc * ly.cols];
+        t *= inv_s;
         ws.t[col_offset(L, layer) + k] = t;
     }
     float s = block_sum(t * t, red);
@@ -163,6 +173,121 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(const mtd_sn_layer* __restri
     }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0) ws.wv[row_offset(L, layer) + r] = s;
+}
+
+// Round 6 -- one pass over W for TWO products: s = W v (this iteration) and the partials of W^T s (the NEXT iteration's W^T u up to
+// the scalar 1 / |s|, applied by sn_tsum_kernel).  The discriminator step runs its four power iterations back to back on the same
+// weights (train_step.d_loss): 5 instead of 8 passes over the 260 MB.  A workgroup owns FUSE_ROWS rows; a thread holds its columns
+// (float4 k4 = tid + 256 j) of four rows at a time in registers, the four dot products meet through shuffles + LDS in a fixed order,
+// and the rows are used a second time from the registers for the column sums.
+constexpr int FUSE_ROWS = 32;
+#ifndef MTD_SN_FUSE_NT
+#define MTD_SN_FUSE_NT 512
+#endif
+constexpr int FUSE_NT = MTD_SN_FUSE_NT;                  // threads per workgroup
+constexpr int FUSE_NJ = (2304 + FUSE_NT - 1) / FUSE_NT;  // float4 columns per thread: cols <= 9216 (1024 -> 512 channels, 3x3) on the vector path
+#ifndef MTD_SN_FUSE_GR
+#define MTD_SN_FUSE_GR 1
+#endif
+constexpr int FUSE_GR = MTD_SN_FUSE_GR;   // rows a thread holds at a time (registers: (GR + 2) * 4 * NJ; measured in the step with 256-thread
+                                          // workgroups: 4 rows / one wave per SIMD +0.37 ms, 2 rows +0.24 ms, 1 row / three waves -0.10 ms)
+
+__global__ __launch_bounds__(FUSE_NT) void sn_wv_wtu_kernel(const mtd_sn_layer* __restrict__ L, int n_layers, SnWs ws) {
+    constexpr int NWV = FUSE_NT / 64;
+    __shared__ float red[NWV][FUSE_GR];
+    __shared__ float srow[FUSE_ROWS];
+    int layer, rb;
+    if (!locate(n_layers, blockIdx.x, [&](int l) { return (L[l].rows + FUSE_ROWS - 1) / FUSE_ROWS; }, layer, rb)) return;
+    const mtd_sn_layer ly = L[layer];
+    const int r0 = rb * FUSE_ROWS, r1 = min(ly.rows, r0 + FUSE_ROWS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* wv = ws.wv + row_offset(L, layer);
+    float* tp = ws.tp + col_offset(L, layer) * MAX_ROW_CHUNKS + (long long)rb * ly.cols;
+    if ((ly.cols & 3) == 0 && ly.cols <= 4 * FUSE_NT * FUSE_NJ && aligned16_dev(ly.w) && aligned16_dev(ly.v)) {
+        const int n4 = ly.cols >> 2;
+        const f32x4* v4 = reinterpret_cast<const f32x4*>(ly.v);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 vv[FUSE_NJ], tacc[FUSE_NJ];
+#pragma unroll
+        for (int j = 0; j < FUSE_NJ; ++j) {
+            const int k4 = tid + FUSE_NT * j;
+            vv[j] = k4 < n4 ? v4[k4] : zero;
+            tacc[j] = zero;
+        }
+        for (int r = r0; r < r1; r += FUSE_GR) {
+            f32x4 wr[FUSE_GR][FUSE_NJ];
+#pragma unroll
+            for (int i = 0; i < FUSE_GR; ++i) {
+                const f32x4* w4 = reinterpret_cast<const f32x4*>(ly.w + (long long)(r + i) * ly.cols);
+#pragma unroll
+                for (int j = 0; j < FUSE_NJ; ++j) {
+                    const int k4 = tid + FUSE_NT * j;
+                    wr[i][j] = (r + i < r1 && k4 < n4) ? w4[k4] : zero;
+                }
+            }
+            float d[FUSE_GR];
+#pragma unroll
+            for (int i = 0; i < FUSE_GR; ++i) {
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < FUSE_NJ; ++j) {
+                    a = fmaf(wr[i][j][0], vv[j][0], a); a = fmaf(wr[i][j][1], vv[j][1], a);
+                    a = fmaf(wr[i][j][2], vv[j][2], a); a = fmaf(wr[i][j][3], vv[j][3], a);
+                }
+                for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+                d[i] = a;
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < FUSE_GR; ++i) red[wave][i] = d[i];
+            }
+            __syncthreads();
+            float sr[FUSE_GR];
+#pragma unroll
+            for (int i = 0; i < FUSE_GR; ++i) {          // the waves' sums in a fixed order
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWV; ++w) t += red[w][i];
+                sr[i] = t;
+            }
+            if (tid < FUSE_GR && r + tid < r1) wv[r + tid] = sr[tid];
+#pragma unroll
+            for (int j = 0; j < FUSE_NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < FUSE_GR; ++i) {          // (rows past the block's end hold zeros)
+                    tacc[j][0] = fmaf(wr[i][j][0], sr[i], tacc[j][0]); tacc[j][1] = fmaf(wr[i][j][1], sr[i], tacc[j][1]);
+                    tacc[j][2] = fmaf(wr[i][j][2], sr[i], tacc[j][2]); tacc[j][3] = fmaf(wr[i][j][3], sr[i], tacc[j][3]);
+                }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < FUSE_NJ; ++j) {
+            const int k4 = tid + FUSE_NT * j;
+            // (the partials' base is 4-byte aligned only: the column offsets of the layers before this one include conv11's 9)
+            if (k4 < n4) { tp[4 * k4] = tacc[j][0]; tp[4 * k4 + 1] = tacc[j][1]; tp[4 * k4 + 2] = tacc[j][2]; tp[4 * k4 + 3] = tacc[j][3]; }
+        }
+    } else {
+        // narrow or unaligned layers (conv11: 64 x 9): the rows once for s, once more (from L1 / L2) for the column sums
+        __shared__ float redb[FUSE_NT];
+        for (int r = r0; r < r1; ++r) {
+            const float* w = ly.w + (long long)r * ly.cols;
+            float a = 0.f;
+            for (int k = tid; k < ly.cols; k += FUSE_NT) a = fmaf(w[k], ly.v[k], a);
+            redb[tid] = a;
+            __syncthreads();
+            for (int st = FUSE_NT / 2; st > 0; st >>= 1) {
+                if (tid < st) redb[tid] += redb[tid + st];
+                __syncthreads();
+            }
+            if (tid == 0) { srow[r - r0] = redb[0]; wv[r] = redb[0]; }
+            __syncthreads();
+        }
+        for (int k = tid; k < ly.cols; k += FUSE_NT) {
+            float t = 0.f;
+            for (int r = r0; r < r1; ++r) t = fmaf(ly.w[(long long)r * ly.cols + k], srow[r - r0], t);
+            tp[k] = t;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void sn_finish_kernel(const mtd_sn_layer* __restrict__ L, int n_layers, SnWs ws, int train) {
@@ -391,7 +516,7 @@ extern "C" int mtd_sn_power_iter(const mtd_sn_layer* layers_dev, const mtd_sn_la
     if (train) {
         hipLaunchKernelGGL(sn_wtu_kernel, dim3(wtu_blocks), dim3(256), 0, s, layers_dev, n_layers, w);
         MTD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(sn_tsum_kernel, dim3(col_blocks), dim3(256), 0, s, layers_dev, n_layers, w);
+        hipLaunchKernelGGL(sn_tsum_kernel, dim3(col_blocks), dim3(256), 0, s, layers_dev, n_layers, w, ROWS_PER_BLOCK, 0);
         MTD_LAUNCH_CHECK();
         hipLaunchKernelGGL(sn_norm_v_kernel, dim3(col_blocks), dim3(256), 0, s, layers_dev, n_layers, w);
         MTD_LAUNCH_CHECK();
@@ -403,6 +528,55 @@ extern "C" int mtd_sn_power_iter(const mtd_sn_layer* layers_dev, const mtd_sn_la
     MTD_LAUNCH_CHECK();
     hipLaunchKernelGGL(sn_finish_kernel, dim3(n_layers), dim3(256), 0, s, layers_dev, n_layers, w, train);
     MTD_LAUNCH_CHECK();
+    return MTD_OK;
+}
+
+// nit power iterations on the same weights, back to back (the discriminator step's four passes, train mode): iteration i reads and
+// writes the layers' u, v in place like mtd_sn_power_iter and leaves its sigma / u_save / v_save where entry [i * n_layers + l] of the
+// tables points (entries of one layer share w, u, v, rows, cols).  nit + 1 passes over the weights instead of 2 nit (sn_wv_wtu_kernel).
+// Same ws as mtd_sn_power_iter.  The results differ from nit calls of mtd_sn_power_iter by rounding only (t = (W^T s) / |s| instead of
+// W^T (s / |s|), and the row dot products of the fused pass in another fixed association).
+extern "C" int mtd_sn_power_iter_multi(const mtd_sn_layer* layers_dev, const mtd_sn_layer* layers_host, int n_layers, int nit, float* ws,
+                                       void* stream) {
+    if (!layers_dev || !layers_host || n_layers <= 0 || nit <= 0 || !ws) return MTD_EINVAL;
+    long long ctot = 0, rtot = 0;
+    sn_ws_floats(layers_host, n_layers, &ctot, &rtot);
+    int col_blocks = 0, row_blocks = 0, wtu_blocks = 0, fuse_blocks = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        const mtd_sn_layer& h = layers_host[i];
+        if (h.cols > COLS_PER_BLOCK * MAX_CHUNKS || h.rows <= 0 || h.cols <= 0) return MTD_EINVAL;
+        if (h.rows > FUSE_ROWS * MAX_ROW_CHUNKS) return MTD_EINVAL;                 // (the fused pass writes one partial per FUSE_ROWS rows)
+        for (int it = 1; it < nit; ++it) {
+            const mtd_sn_layer& o = layers_host[(long long)it * n_layers + i];
+            if (o.w != h.w || o.u != h.u || o.v != h.v || o.rows != h.rows || o.cols != h.cols) return MTD_EINVAL;
+        }
+        col_blocks += (h.cols + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK;
+        wtu_blocks += ((h.cols + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK) * ((h.rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+        row_blocks += (h.rows + 3) / 4;
+        fuse_blocks += (h.rows + FUSE_ROWS - 1) / FUSE_ROWS;
+    }
+    SnWs w;
+    w.t = ws;
+    w.partial = ws + ctot;
+    w.wv = w.partial + (long long)n_layers * MAX_CHUNKS;
+    w.tp = w.wv + rtot;
+    hipStream_t s = (hipStream_t)stream;
+    for (int it = 0; it < nit; ++it) {
+        const mtd_sn_layer* tab = layers_dev + (long long)it * n_layers;
+        if (it == 0) {
+            hipLaunchKernelGGL(sn_wtu_kernel, dim3(wtu_blocks), dim3(256), 0, s, tab, n_layers, w);
+            MTD_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(sn_tsum_kernel, dim3(col_blocks), dim3(256), 0, s, tab, n_layers, w, it == 0 ? ROWS_PER_BLOCK : FUSE_ROWS, it == 0 ? 0 : 1);
+        MTD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(sn_norm_v_kernel, dim3(col_blocks), dim3(256), 0, s, tab, n_layers, w);
+        MTD_LAUNCH_CHECK();
+        if (it + 1 < nit) hipLaunchKernelGGL(sn_wv_wtu_kernel, dim3(fuse_blocks), dim3(FUSE_NT), 0, s, tab, n_layers, w);
+        else hipLaunchKernelGGL(sn_wv_kernel, dim3(row_blocks), dim3(256), 0, s, tab, n_layers, w);
+        MTD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(sn_finish_kernel, dim3(n_layers), dim3(256), 0, s, tab, n_layers, w, 1);
+        MTD_LAUNCH_CHECK();
+    }
     return MTD_OK;
 }
 

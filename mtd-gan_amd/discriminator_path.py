@@ -192,6 +192,44 @@ def _sn_forward(P, train, device):
     return sig, u_save, v_save
 
 
+SN_FUSED_ITERS = _options.lab("MTD_SN_FUSED_ITERS", "1") != "0"      # d_loss: its four power iterations share passes over the weights (round 6)
+
+
+def _sn_forward_multi(P, train, device, nit):
+    """`nit` consecutive power iterations on the same weights -- the discriminator step's four passes, which the reference runs before
+    any weight changes (networks.py:1957-1992).  Returns [(sig, u_save, v_save)] * nit like nit calls of _sn_forward; in train mode
+    they go through mtd_sn_power_iter_multi: W v of one iteration and W^T (W v) of the next share one pass over the 260 MB of
+    weights (nit + 1 passes instead of 2 nit)."""
+    if not (train and SN_FUSED_ITERS and nit > 1):
+        return [_sn_forward(P, train, device) for _ in range(nit)]
+    L = _lib.lib()
+    outs, structs = [], []
+    for _it in range(nit):
+        sig = torch.empty((len(SN_SPECS), 2), dtype=torch.float32, device=device)
+        u_save = torch.empty(SN_ROWS_TOTAL, dtype=torch.float32, device=device)
+        v_save = torch.empty(SN_COLS_TOTAL, dtype=torch.float32, device=device)
+        outs.append((sig, u_save, v_save))
+        for i, (n, rows, cols) in enumerate(SN_SPECS):
+            if n + ".weight_orig" not in P:
+                continue
+            s = _lib.SnLayer()
+            s.w = P[n + ".weight_orig"].data_ptr()
+            s.u = P[n + ".weight_u"].data_ptr()
+            s.v = P[n + ".weight_v"].data_ptr()
+            s.sigma = sig.data_ptr() + 8 * i
+            s.u_save = u_save.data_ptr() + 4 * SN_ROW_OFF[i]
+            s.v_save = v_save.data_ptr() + 4 * SN_COL_OFF[i]
+            s.rows, s.cols = rows, cols
+            structs.append(s)
+    n_layers = len(structs) // nit
+    dev_tab, host_arr = K.device_table(structs, device)
+    need = L.mtd_sn_ws_bytes(C.cast(host_arr, C.c_void_p), n_layers)
+    ws = K.workspace(need, device)
+    K.check(L.mtd_sn_power_iter_multi(dev_tab.data_ptr(), C.cast(host_arr, C.c_void_p), n_layers, nit, ws.data_ptr(), K.stream_ptr()),
+            "mtd_sn_power_iter_multi")
+    return outs
+
+
 def _inv_sigma(tape, name):
     i = SN_INDEX[name]
     return tape.sig[i, 1:2]

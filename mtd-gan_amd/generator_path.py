@@ -236,7 +236,7 @@ def generator_backward(g_out, tape, P, G):
             gm = K.empty_nhwc(B, H, W, CH, x)
             dg = ((gpre_d, P.dec_w[j], gf, CH, CH, CH * 9, 9, gm), dict(mask=tape["blk"][L + k][1], mask_slope=0.0, out2=gu, **w32))
         else:
-            dg = ((gpre_d, P.dec_w[j], gf, CH, CH, CH * 9, 9, gu), {})
+            dg = ((gpre_d, P.dec_w[j], gf, CH, CH, CH * 9, 9, gu), dict(w32))
         if not K.conv_wgrad_fused(dg, wg, defer):           # one launch for the layer's two gradients, else two
             side.run(lambda: K.wgrad(*wg[0], db=G.dec_b[j], defer=defer), gpre_d)
             K.conv(*dg[0], **dg[1])
@@ -253,7 +253,7 @@ def generator_backward(g_out, tape, P, G):
                 dg = ((gpre_t, P.enc_w[i], K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, gm),
                       dict(add1=skip[i], mask=tape["blk"][i - 1][1], mask_slope=0.0, out2=g_e, **w32))
             else:
-                dg = ((gpre_t, P.enc_w[i], K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, g_e), dict(add1=skip[i]))
+                dg = ((gpre_t, P.enc_w[i], K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, g_e), dict(add1=skip[i], **w32))
             if not K.conv_wgrad_fused(dg, wg, defer):
                 side.run(lambda: K.wgrad(*wg[0], db=G.enc_b[i], defer=defer), gpre_t)
                 K.conv(*dg[0], **dg[1])

@@ -136,7 +136,7 @@ WINO_C32_MIN_HW = int(_options.lab("MTD_WINO_C32_MIN_HW", "128"))
 WINO_C32_FWD = _options.lab("MTD_WINO_C32_FWD", "1") != "0"
 # ... and (round 6) their DATA GRADIENTS: the kernel's MASKED2 form writes the cotangent and its masked form for the consuming block
 # (conv(..., wino32=True, mask=..., out2=...)); the weight gradient goes to wgrad_wino32_kernel on the side stream
-WINO_C32_BWD = _options.lab("MTD_WINO_C32_BWD", "0") != "0"
+WINO_C32_BWD = _options.lab("MTD_WINO_C32_BWD", "1") != "0"
 _kmap_cache = {}
 
 

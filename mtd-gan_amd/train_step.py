@@ -324,7 +324,7 @@ def d_loss(method, x, y):
     K.prepack(DP.conv_views(P, True))
     K.prepack_winograd(DP.winograd_views(P, True))
     K.prepack_winograd_s2(DP.winograd_s2_views(P, True))
-    sn = [DP._sn_forward(P, train, dev) for _ in range(4)]
+    sn = DP._sn_forward_multi(P, train, dev, 4)
     masks = D._next_masks(B, dev, 4)          # the four passes' dropout multipliers, stacked: (4B, 512) or None
     m12, m34 = (None, None) if masks is None else (masks[:2 * B], masks[2 * B:])
     (e12, d12, r12), t12 = DP.disc_forward(P, pair12, train, m12, True, True, sn=sn[0], sn2=sn[1], pair=B)

@@ -117,6 +117,40 @@ def test_spectral_norm_kernels_vs_torch(hip_lib):
         assert rel(us[DP.SN_ROW_OFF[i]:DP.SN_ROW_OFF[i] + rows], u) < 1e-4
 
 
+def test_fused_power_iterations_vs_torch(hip_lib):
+    """mtd_sn_power_iter_multi (round 6): the discriminator step's four power iterations with W v of one iteration and W^T (W v) of the
+    next in one pass over the weights -- every iteration's saved u, v, sigma and the final in-place state against four sequential
+    iterations in float64 (torch.nn.utils.spectral_norm's update, eps 1e-12), and against four calls of mtd_sn_power_iter (same
+    values up to rounding: the fused pass normalises after the column sums and adds its row products in another order)."""
+    from mtd_gan_amd import discriminator_path as DP
+    dev = torch.device("cuda")
+    D, dstate = _disc(seed=5)
+    P = D._param_dict()
+    multi = DP._sn_forward_multi(P, True, dev, 4)
+    torch.cuda.synchronize()
+    state_multi = {n: (P[n + ".weight_u"].clone(), P[n + ".weight_v"].clone()) for n, _r, _c in DP.SN_SPECS}
+    D2, _ = _disc(seed=5)
+    P2 = D2._param_dict()
+    single = [DP._sn_forward(P2, True, dev) for _ in range(4)]
+    torch.cuda.synchronize()
+    for i, (n, rows, cols) in enumerate(DP.SN_SPECS):
+        w = dstate[n + ".weight_orig"].reshape(rows, cols).double()
+        u = dstate[n + ".weight_u"].double()
+        ro, co = DP.SN_ROW_OFF[i], DP.SN_COL_OFF[i]
+        for it in range(4):
+            v = torch.nn.functional.normalize(w.t() @ u, dim=0, eps=1e-12)
+            u = torch.nn.functional.normalize(w @ v, dim=0, eps=1e-12)
+            sigma = torch.dot(u, w @ v).item()
+            sig, us, vs = multi[it]
+            assert rel(us[ro:ro + rows], u) < 1e-4 and rel(vs[co:co + cols], v) < 1e-4, (n, it)
+            assert abs(sig[i, 0].item() - sigma) < 1e-4 * abs(sigma) and abs(sig[i, 1].item() * sigma - 1.0) < 1e-4, (n, it)
+            sig1, us1, vs1 = single[it]
+            assert rel(us[ro:ro + rows], us1[ro:ro + rows]) < 2e-5 and rel(vs[co:co + cols], vs1[co:co + cols]) < 2e-5, (n, it)
+            assert abs(sig[i, 0].item() - sig1[i, 0].item()) < 1e-5 * abs(sigma), (n, it)
+        assert rel(state_multi[n][0], u) < 1e-4 and rel(state_multi[n][1], v) < 1e-4, n
+        assert torch.equal(state_multi[n][0], multi[3][1][ro:ro + rows]) and torch.equal(state_multi[n][1], multi[3][2][co:co + cols]), n
+
+
 @pytest.mark.parametrize("paired", [False, True])
 def test_sn_grad_kernel_vs_formula(hip_lib, paired):
     """mtd_sn_grad alone: g_out += G/sigma - <G, W>/sigma^2 u v^T (torch.nn.utils.spectral_norm's backward with u, v
