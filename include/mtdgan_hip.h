@@ -177,10 +177,17 @@ typedef struct {
     float* db;
     int accumulate;
     float* ws; size_t ws_bytes;
+    /* optional (round 6): the two halves of a paired discriminator pass in ONE launch of the small-map kernels.  half_scale != NULL:
+     * the cotangent is multiplied, as it is used, by *half_scale for pixels [0, m_first) and by *half_scale2 for the rest -- dw then
+     * holds G_1 / sigma_1 + G_2 / sigma_2 (each half's raw gradient scaled by its own 1 / sigma: what the spectral-norm correction
+     * adds up anyway, mtd_sn_grad_layer.prescaled).  db stays the unscaled sum.  m_first must be a multiple of 32 (a chunk of the K
+     * loop never straddles the halves); only the register-operand kernels take it (mtd_conv_wgrad_half_scale_ok). */
+    const float* half_scale; const float* half_scale2; int m_first;
 } mtd_wgrad_args;
 
 size_t mtd_conv_wgrad_ws_bytes(const mtd_wgrad_args* a);
 int mtd_conv_wgrad(const mtd_wgrad_args* a, void* stream);
+int mtd_conv_wgrad_half_scale_ok(const mtd_wgrad_args* a);      /* nonzero: mtd_conv_wgrad takes these arguments with half_scale set */
 /* The kernel the plan picks for these arguments: index into the weight-gradient name table of the launch profiler
  * (16 = wgrad_wino_kernel, Winograd F(2x2,3x3): 4/9 of the layer's multiplications), -1 = the vector-ALU kernels of
  * mtd_conv_direct's domain, MTD_EINVAL = invalid arguments.  Nothing is launched.  (Host-side flop accounting of bench.py.) */
@@ -354,6 +361,10 @@ typedef struct {
     /* optional second pass over the same weight (a batch-paired discriminator pass has one sigma, u, v per half):
      * g_out (+)= corr(G, u, v, sigma) and then += corr(G2, u2, v2, sigma2), in that order; G2 == NULL: single pass */
     const float* G2; const float* u2; const float* v2; const float* sigma2;
+    /* prescaled != 0 (round 6): G already holds G_1 / sigma_1 + G_2 / sigma_2 (mtd_wgrad_args.half_scale) and G2 is NULL:
+     * g_out (+)= G - <G_1,W>/sigma_1^2 u v^T - <G_2,W>/sigma_2^2 u2 v2^T; the two dot products must come from the activation-side
+     * form below (the raw gradients no longer exist apart); u2 / v2 / sigma2 non-NULL says that there are two passes. */
+    int prescaled;
     /* optional (round 6): <G, W> WITHOUT reading G or W.  With y = conv(x, W)/sigma + b and gy the cotangent of y,
      *   <G, W> = sum_pix gy . (W * x) = sigma * sum_{pix,n} gy[pix,n] (y[pix,n] - b[n]),
      * and y comes back from the saved activation a = LeakyReLU(y): y = a > 0 ? a : a * act_inv_slope.  act_gy != NULL selects this

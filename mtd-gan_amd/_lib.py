@@ -53,7 +53,8 @@ class WgradArgs(C.Structure):
                 ("q", C.c_void_p), ("q_ld", C.c_int), ("C", C.c_int),
                 ("dw", C.c_void_p), ("w_sn", C.c_longlong), ("w_sc", C.c_longlong),
                 ("db", C.c_void_p), ("accumulate", C.c_int),
-                ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
+                ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+                ("half_scale", C.c_void_p), ("half_scale2", C.c_void_p), ("m_first", C.c_int)]
 
 
 class WinoS2WeightDesc(C.Structure):
@@ -79,7 +80,7 @@ class SnLayer(C.Structure):
 class SnGradLayer(C.Structure):
     _fields_ = [("G", C.c_void_p), ("w", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("sigma", C.c_void_p),
                 ("g_out", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("accumulate", C.c_int),
-                ("G2", C.c_void_p), ("u2", C.c_void_p), ("v2", C.c_void_p), ("sigma2", C.c_void_p),
+                ("G2", C.c_void_p), ("u2", C.c_void_p), ("v2", C.c_void_p), ("sigma2", C.c_void_p), ("prescaled", C.c_int),
                 ("act_gy", C.c_void_p), ("act_gy2", C.c_void_p), ("act_a", C.c_void_p), ("act_bias", C.c_void_p),
                 ("act_gy_ld", C.c_int), ("act_gy2_ld", C.c_int), ("act_a_ld", C.c_int), ("act_M", C.c_int), ("act_M_first", C.c_int),
                 ("act_inv_slope", C.c_float)]
@@ -133,7 +134,7 @@ def _preload_torch_hip_runtime():
 
 
 RECORDER = None      # kernels.LaunchList: while a step is being recorded, the list every launch is appended to
-_NOT_LAUNCHES = ("_ws_bytes", "_blocks", "mtd_version", "_option", "mtd_lab_build", "mtd_prof_", "_override", "_bwd_ok", "_stamps", "_zmask_bytes", "_tail_ok", "_winograd_ok", "_winograd_s2_ok", "_weight_floats", "_kmap", "_plan_cfg", "_pair_ok", "_pair_mode", "_patch_w", "_f4_min_w", "_relu_add_ok")
+_NOT_LAUNCHES = ("_half_scale_ok", "_ws_bytes", "_blocks", "mtd_version", "_option", "mtd_lab_build", "mtd_prof_", "_override", "_bwd_ok", "_stamps", "_zmask_bytes", "_tail_ok", "_winograd_ok", "_winograd_s2_ok", "_weight_floats", "_kmap", "_plan_cfg", "_pair_ok", "_pair_mode", "_patch_w", "_f4_min_w", "_relu_add_ok")
 
 
 class _RecordingLib:
@@ -196,6 +197,7 @@ def lib():
     sig("mtd_conv_relu_add_ok", ci, C.POINTER(ConvArgs))
     sig("mtd_conv_wgrad_ws_bytes", sz, C.POINTER(WgradArgs))
     sig("mtd_conv_wgrad", ci, C.POINTER(WgradArgs), vp)
+    sig("mtd_conv_wgrad_half_scale_ok", ci, C.POINTER(WgradArgs))
     sig("mtd_conv_wgrad_plan_cfg", ci, C.POINTER(WgradArgs))
     sig("mtd_conv_wgrad_pair_ok", ci, C.POINTER(WgradArgs), ci)
     sig("mtd_conv_wgrad_pair_mode", ci, ci)
@@ -290,7 +292,7 @@ def lib():
 
 EXPORTS = [
     "mtd_version", "mtd_conv_igemm_ws_bytes", "mtd_conv_igemm", "mtd_conv_direct", "mtd_conv_wgrad_ws_bytes",
-    "mtd_conv_wgrad", "mtd_conv_wgrad_pair_ok", "mtd_conv_wgrad_pair_mode", "mtd_conv_wgrad_pair_ws_bytes", "mtd_conv_wgrad_pair", "mtd_conv_wgrad_pair_sum", "mtd_rfft_rows", "mtd_spec_mix_fwd", "mtd_spec_mix_bwd_ws_bytes", "mtd_spec_mix_bwd",
+    "mtd_conv_wgrad", "mtd_conv_wgrad_half_scale_ok", "mtd_conv_wgrad_pair_ok", "mtd_conv_wgrad_pair_mode", "mtd_conv_wgrad_pair_ws_bytes", "mtd_conv_wgrad_pair", "mtd_conv_wgrad_pair_sum", "mtd_rfft_rows", "mtd_spec_mix_fwd", "mtd_spec_mix_bwd_ws_bytes", "mtd_spec_mix_bwd",
     "mtd_spec_mix_wgrad_reduce", "mtd_irfft_rows", "mtd_transpose64", "mtd_act_grad", "mtd_copy_channels",
     "mtd_upsample2x_fwd", "mtd_upsample2x_bwd", "mtd_pixel_shuffle2_fwd", "mtd_pixel_shuffle2_bwd", "mtd_mul", "mtd_pack_weights",
     "mtd_sn_ws_bytes", "mtd_sn_power_iter", "mtd_sn_power_iter_multi", "mtd_sn_grad_ws_bytes", "mtd_sn_grad", "mtd_pcgrad_ws_bytes",

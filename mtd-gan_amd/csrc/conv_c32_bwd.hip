@@ -373,7 +373,7 @@ unsigned long long* g_c32f_stamps = nullptr;     // lab: MTD_C32F_STAMPS=1
 // Eligibility: d is a launch the halo-tile kernel takes (32 input and output channels, 3x3, stride 1, 64-pixel rows, whole
 // four-row tiles), w a 32 x 32 channel 3x3 weight gradient over the same pixel grid with the row-window geometry.
 extern "C" int mtd_conv_c32_bwd_ok(const mtd_conv_args* d, const mtd_wgrad_args* w) {
-    if (!d || !w || check_args(*d) != MTD_OK || check_wargs(*w) != MTD_OK) return 0;
+    if (!d || !w || w->half_scale || check_args(*d) != MTD_OK || check_wargs(*w) != MTD_OK) return 0;
     if (d->N != 32 || d->C != 32 || w->N != 32 || w->C != 32 || !c32t_eligible(*d) || !wide_epilogue_ok(*d)) return 0;
     if (geom_pixels(d->g) != geom_pixels(w->g) || geom_pixels(d->g) % (C32T_R * C32T_W)) return 0;
     const mtd_geom& g = w->g;

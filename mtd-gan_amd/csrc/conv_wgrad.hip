@@ -34,6 +34,16 @@ struct WgradParams {
     long long pair_p_off = 0, pair_q_off = 0;
 };
 
+// mtd_wgrad_args.half_scale: the factor of the 32-pixel chunk that starts at pixel m (1 without it).  m_first is a multiple of 32 and
+// every chunk starts at a multiple of 32, so a chunk lies in one half; the two scales are read once per kernel.
+struct HalfScale { float s1, s2; int m_first; };
+__device__ __forceinline__ HalfScale half_scale_load(const mtd_wgrad_args& a) {
+    HalfScale h{1.f, 1.f, 0x7fffffff};
+    if (a.half_scale) { h.s1 = *a.half_scale; h.s2 = *a.half_scale2; h.m_first = a.m_first; }
+    return h;
+}
+__device__ __forceinline__ float half_scale_of(const HalfScale& h, int m) { return m < h.m_first ? h.s1 : h.s2; }
+
 struct PairSel { int bx; const float* P; const float* Q; };
 __device__ __forceinline__ PairSel pair_select(const WgradParams& p) {
     PairSel r{(int)blockIdx.x, p.a.p, p.a.q};
@@ -64,6 +74,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     float* Qs = Ps + 32 * PLD;
     const PairSel ps = pair_select(p);
     const int mwave0 = (ps.bx * 4 + wave) * p.ppw;
+    const HalfScale hs = half_scale_load(a);
     const bool do_bias = (a.db != nullptr) && ctile == 0 && blockIdx.z == 0;
     // Both operands are read with buffer loads: 32-bit byte offsets, an out-of-range offset returns 0 (zero
     // padding and the pixel tail without branches, so the compiler's vmcnt bookkeeping stays exact).
@@ -168,6 +179,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
                     for (int kk = 0; kk < 16; ++kk)
 #pragma unroll
                         for (int j = 0; j < WN; ++j) bsum[j] += af[kk][j];
+                }
+                if (a.half_scale) {                 // (uniform; the bias sum above took the unscaled cotangent)
+                    const float hsc = half_scale_of(hs, mwave0 + mc);
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) af[kk][j] *= hsc;
                 }
 #pragma unroll
                 for (int kk = 0; kk < 16; ++kk)
@@ -592,13 +610,16 @@ __global__ __launch_bounds__(256, 1) void wgrad_taps_kernel(const WgradParams p)
 #pragma unroll
             for (int tx = 0; tx < TW; ++tx) piece(w, kk, tx);
     }
+    const HalfScale hs = half_scale_load(a);
     for (int mc = 0; mc < p.ppw; mc += 32) {
+        const float hsc = half_scale_of(hs, m0 + mc);
         Walk w = walk_init(mc + 32);            // past the workgroup's range: every offset out of range, zeros
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
+            const float pk = pa[kk] * hsc;          // (mtd_wgrad_args.half_scale: 1 without it)
 #pragma unroll
             for (int tx = 0; tx < TW; ++tx) {
-                acc[tx] = mfma32(pa[kk], qa[tx][kk], acc[tx]);
+                acc[tx] = mfma32(pk, qa[tx][kk], acc[tx]);
                 // (the bias sum takes each P value where it is in a register anyway; summed at the top of the chunk it made
                 // wave 0 wait for ALL of the chunk's loads before its first MFMA)
                 if (tx == TW - 1) bsum += bias_wave ? pa[kk] : 0.f;
@@ -781,6 +802,7 @@ __global__ __launch_bounds__(NW * 64, (W == 8 || NW == 8) ? 1 : 2) void wgrad_bl
     const int n0 = ntile * 32, c0 = ctile * 32;
     const PairSel ps = pair_select(p);
     const int mwave0 = (ps.bx * NW + wave) * p.ppw;
+    const HalfScale hs = half_scale_load(a);
     const bool do_bias = (a.db != nullptr) && ctile == 0;
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ps.P), (short)0, (int)p.p_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ps.Q), (short)0, (int)p.q_bytes, 0x00020000);
@@ -852,6 +874,11 @@ __global__ __launch_bounds__(NW * 64, (W == 8 || NW == 8) ? 1 : 2) void wgrad_bl
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) bsum += af[kk];
+        if (a.half_scale) {                      // (uniform; the bias sum took the unscaled cotangent)
+            const float hsc = half_scale_of(hs, mwave0 + mc);
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) af[kk] *= hsc;
+        }
         mfma_taprow(0);
         __builtin_amdgcn_sched_barrier(0);
         if (W == 8) load_q(qf, 0, 8);            // window row 0 is dead after filter row 0
@@ -1279,6 +1306,7 @@ int check_wargs(const mtd_wgrad_args& a) {
     if (geom_pixels(g) > (1ll << 30)) return MTD_EINVAL;
     if (a.p_ld < a.N || a.q_ld < a.C || (a.p_ld % 4) || (a.q_ld % 4)) return MTD_EINVAL;
     if (!aligned16(a.p) || !aligned16(a.q)) return MTD_EALIGN;
+    if (a.half_scale && (!a.half_scale2 || a.m_first <= 0 || (a.m_first % 32) || a.m_first >= geom_pixels(g))) return MTD_EINVAL;
     return MTD_OK;
 }
 
@@ -1332,6 +1360,14 @@ static bool wgrad_cfg_pairs(int cfg) { return (cfg >= 0 && cfg < NWCFG) || (cfg 
 // (rows != nullptr: also run the forward row transform `rows` describes, inside the same launch if the plan is the row-window
 // kernel on one (n, c) tile -- *rows_done says whether it was)
 // (pair: a describes ONE of two equal problems laid out back to back in p / q; the launch covers both, see WgradParams::pair_ns)
+// plans whose kernels apply mtd_wgrad_args.half_scale: wgrad_kernel<> (0-6), the block-window kernels (10-12), the all-taps kernel (13)
+static bool wgrad_cfg_half_scale(int cfg) { return (cfg >= 0 && cfg < NWCFG) || (cfg >= 10 && cfg <= 13); }
+
+extern "C" int mtd_conv_wgrad_half_scale_ok(const mtd_wgrad_args* a) {
+    if (!a || !a->half_scale || check_wargs(*a) != MTD_OK || is_direct(*a)) return 0;
+    return wgrad_cfg_half_scale(make_wplan(*a).cfg) ? 1 : 0;
+}
+
 static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, int& nsplit, bool& direct_out,
                          const RowsArgs* rows = nullptr, bool* rows_done = nullptr, bool pair = false) {
     if (!a) return MTD_EINVAL;
@@ -1344,6 +1380,8 @@ static int wgrad_partial(const mtd_wgrad_args* a, void* stream, WgradParams& p, 
     WPlan pl{};
     if (direct) nsplit = mtd_direct_wgrad_nslab(a);
     else if (!pair) { pl = make_wplan(*a); nsplit = pl.nsplit; }
+    // mtd_wgrad_args.half_scale: the register-operand kernels only (their K loops walk whole 32-pixel chunks of one half)
+    if (a->half_scale && (direct || pair || rows || !wgrad_cfg_half_scale(pl.cfg))) return MTD_EINVAL;
     if (pair) {
         if (direct) return MTD_EINVAL;
         pl = make_wplan(*a, 2);
@@ -1655,7 +1693,7 @@ extern "C" int mtd_conv_wgrad_pair(const mtd_wgrad_args* a, float* dw2, int b_fi
 // none).  Only where mtd_conv_wgrad_pair_ok says 2.
 extern "C" int mtd_conv_wgrad_pair_sum(const mtd_wgrad_args* a, const float* p_add, float* dw2, int b_first, void* stream) {
     int ns_half = 0, cps = 0;
-    if (!a || !dw2 || !wgrad_pair_plan(*a, b_first, ns_half, cps)) return MTD_EINVAL;
+    if (!a || !dw2 || a->half_scale || !wgrad_pair_plan(*a, b_first, ns_half, cps)) return MTD_EINVAL;
     if (p_add && (ns_half <= 0 || !aligned16(p_add))) return MTD_EINVAL;
     const bool s2w = ns_half < 0;          // the stride-2 Winograd kernel (cfg 18)
     if (s2w) ns_half = -ns_half;

@@ -15,10 +15,6 @@
 // different banks) instead of 64 broadcast-read FMAs per lane and frequency.
 #include "common.h"
 
-#ifndef MTD_ANY_R8        // radix-8 passes in lds_fft (0: the round-4 radix-4 form)
-#define MTD_ANY_R8 1
-#endif
-
 namespace {
 
 __device__ __forceinline__ int brev_n(int k, int logS) { return (int)(__brev((unsigned)k) >> (32 - logS)); }
@@ -60,13 +56,11 @@ __device__ __forceinline__ void lds_fft(float* re, float* im, const float* tw, i
 #define FST(P, I, X) (*reinterpret_cast<VT*>((P) + (I)) = (X))
     const int hS = S >> 1;
     int st = 0;
-    // Round 6 (MTD_ANY_R8, default on): THREE radix-2 stages per pass over LDS (eight points in registers) wherever three are left --
-    // S = 512: three passes instead of five, a third fewer LDS instructions and barriers; the stages left over go first: one
-    // single stage (log2(S) = 7) or one fused pair (log2(S) = 8).  Without it: a single stage when log2(S) is odd, then pairs.
-    const int rem = MTD_ANY_R8 ? logS % 3 : (logS & 1);
-    const int st4_end = MTD_ANY_R8 ? (rem == 2 ? 2 : (rem == 1 ? 1 : 0)) : logS;
-    // single radix-2 stage: the first stage for DIF (half = S/2), the first for DIT (half = 1)
-    if (rem == 1) {
+    // single radix-2 stage when log2(S) is odd: the first stage for DIF (half = S/2), the first for DIT (half = 1)
+    // (Round 6: a radix-8 form -- three stages per pass, S = 512 in three passes instead of five -- was built, passed the whole-slice tests
+    // and measured level with this one on one box, 20.76-21.01 against 20.80-21.55 ms per 8 slices (profiles/r6_whole_slice_radix8.txt): the
+    // column kernel is not bound by its LDS passes.  Removed; the history has it.)
+    if (logS & 1) {
         const int lh = DIF ? (logS - 1) : 0;
         const int half = 1 << lh, tshift = logS - 1 - lh;
 #pragma unroll UNR
@@ -91,7 +85,7 @@ __device__ __forceinline__ void lds_fft(float* re, float* im, const float* tw, i
         st = 1;
     }
     const int nq = (S >> 2) * CPL;                    // 4-point groups per fused pass (x channel)
-    for (; st < st4_end; st += 2) {
+    for (; st < logS; st += 2) {
         if (DIF) {
             // stages with half = H and H/2;  points a, b = a + H/2, c = a + H, d = a + 3H/2 of a block of 2H
             const int lH = logS - 1 - st;             // log2(H)
@@ -141,95 +135,6 @@ __device__ __forceinline__ void lds_fft(float* re, float* im, const float* tw, i
                 FST(re, ic, a1r - cwr); FST(im, ic, a1i - cwi);
                 FST(re, ib, b1r + ewr); FST(im, ib, b1i + ewi);
                 FST(re, id, b1r - ewr); FST(im, id, b1i - ewi);
-            }
-        }
-        __syncthreads();
-    }
-    // ---- three stages per pass: points a + m * stride, m = 0 .. 7, of a block of eight strides
-    const int nq8 = (S >> 3) * CPL;
-    for (; st < logS; st += 3) {
-#pragma unroll UNR
-        for (int e = threadIdx.x; e < nq8; e += (NT > 0 ? NT : (int)blockDim.x)) {
-            const int c = (e & (CPL - 1)) * V, q = e >> CSH;
-            VT xr[8], xi[8];
-            if (DIF) {
-                // stages with halves H, H/2, H/4 (H = S >> (st + 1)); stride Q = H / 4
-                const int lH = logS - 1 - st, lQ = lH - 2, Q = 1 << lQ;
-                const int blk = q >> lQ, j = q & (Q - 1);
-                const int ia = ((blk << (lH + 1)) + j) * LD + c, sd = Q * LD;
-                const int ts1 = logS - 1 - lH;
-#pragma unroll
-                for (int m = 0; m < 8; ++m) { xr[m] = FLD(re, ia + m * sd); xi[m] = FLD(im, ia + m * sd); }
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {              // half H: (m, m + 4), twiddle exp(-i pi (j + m Q) / H)
-                    float cs, sn;
-                    twiddle<SIGN>(tw, hS, (j + m * Q) << ts1, cs, sn);
-                    const VT dr = xr[m] - xr[m + 4], di = xi[m] - xi[m + 4];
-                    xr[m] += xr[m + 4]; xi[m] += xi[m + 4];
-                    xr[m + 4] = dr * cs - di * sn; xi[m + 4] = dr * sn + di * cs;
-                }
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {              // half H/2: (m, m + 2) and (m + 4, m + 6), twiddle exp(-i pi (j + m Q) / (H/2))
-                    float cs, sn;
-                    twiddle<SIGN>(tw, hS, (j + m * Q) << (ts1 + 1), cs, sn);
-#pragma unroll
-                    for (int b = 0; b < 8; b += 4) {
-                        const VT dr = xr[b + m] - xr[b + m + 2], di = xi[b + m] - xi[b + m + 2];
-                        xr[b + m] += xr[b + m + 2]; xi[b + m] += xi[b + m + 2];
-                        xr[b + m + 2] = dr * cs - di * sn; xi[b + m + 2] = dr * sn + di * cs;
-                    }
-                }
-                {                                          // half H/4: (m, m + 1), m even, twiddle exp(-i pi j / (H/4))
-                    float cs, sn;
-                    twiddle<SIGN>(tw, hS, j << (ts1 + 2), cs, sn);
-#pragma unroll
-                    for (int m = 0; m < 8; m += 2) {
-                        const VT dr = xr[m] - xr[m + 1], di = xi[m] - xi[m + 1];
-                        xr[m] += xr[m + 1]; xi[m] += xi[m + 1];
-                        xr[m + 1] = dr * cs - di * sn; xi[m + 1] = dr * sn + di * cs;
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < 8; ++m) { FST(re, ia + m * sd, xr[m]); FST(im, ia + m * sd, xi[m]); }
-            } else {
-                // stages with halves h, 2h, 4h (h = 1 << st); stride h
-                const int lh = st, h = 1 << lh;
-                const int blk = q >> lh, j = q & (h - 1);
-                const int ia = ((blk << (lh + 3)) + j) * LD + c, sd = h * LD;
-                const int ts1 = logS - 1 - lh;
-#pragma unroll
-                for (int m = 0; m < 8; ++m) { xr[m] = FLD(re, ia + m * sd); xi[m] = FLD(im, ia + m * sd); }
-                {                                          // half h: (m, m + 1), m even, twiddle exp(+i pi j / h)
-                    float cs, sn;
-                    twiddle<SIGN>(tw, hS, j << ts1, cs, sn);
-#pragma unroll
-                    for (int m = 0; m < 8; m += 2) {
-                        const VT wr = xr[m + 1] * cs - xi[m + 1] * sn, wi = xr[m + 1] * sn + xi[m + 1] * cs;
-                        xr[m + 1] = xr[m] - wr; xi[m + 1] = xi[m] - wi;
-                        xr[m] += wr; xi[m] += wi;
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {              // half 2h: (m, m + 2) and (m + 4, m + 6), twiddle exp(+i pi (j + m h) / 2h)
-                    float cs, sn;
-                    twiddle<SIGN>(tw, hS, (j + m * h) << (ts1 - 1), cs, sn);
-#pragma unroll
-                    for (int b = 0; b < 8; b += 4) {
-                        const VT wr = xr[b + m + 2] * cs - xi[b + m + 2] * sn, wi = xr[b + m + 2] * sn + xi[b + m + 2] * cs;
-                        xr[b + m + 2] = xr[b + m] - wr; xi[b + m + 2] = xi[b + m] - wi;
-                        xr[b + m] += wr; xi[b + m] += wi;
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {              // half 4h: (m, m + 4), twiddle exp(+i pi (j + m h) / 4h)
-                    float cs, sn;
-                    twiddle<SIGN>(tw, hS, (j + m * h) << (ts1 - 2), cs, sn);
-                    const VT wr = xr[m + 4] * cs - xi[m + 4] * sn, wi = xr[m + 4] * sn + xi[m + 4] * cs;
-                    xr[m + 4] = xr[m] - wr; xi[m + 4] = xi[m] - wi;
-                    xr[m] += wr; xi[m] += wi;
-                }
-#pragma unroll
-                for (int m = 0; m < 8; ++m) { FST(re, ia + m * sd, xr[m]); FST(im, ia + m * sd, xi[m]); }
             }
         }
         __syncthreads();

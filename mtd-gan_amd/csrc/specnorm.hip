@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void sn_grad_dot_kernel(const mtd_sn_grad_laye
     const mtd_sn_grad_layer ly = L[layer];
     const unsigned total = (unsigned)ly.rows * (unsigned)ly.cols;
     const unsigned base = (unsigned)local * GRAD_ELEMS_PER_BLOCK;
-    const bool two = ly.G2 != nullptr;
+    const bool two = ly.sigma2 != nullptr;              // a second pass (with G2, or folded into a prescaled G)
     float p = 0.f, p2 = 0.f;
     if (ly.act_gy) {
         // activation-side form (mtd_sn_grad_layer.act_*): sigma_s * sum over the pass's pixels of gy (y - b), y from the saved activation.
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void sn_grad_dot_kernel(const mtd_sn_grad_laye
             if (e < total) {
                 const float4 w = *reinterpret_cast<const float4*>(ly.w + e);
                 p = dot4(*reinterpret_cast<const float4*>(ly.G + e), w, p);
-                if (two) p2 = dot4(*reinterpret_cast<const float4*>(ly.G2 + e), w, p2);
+                if (ly.G2) p2 = dot4(*reinterpret_cast<const float4*>(ly.G2 + e), w, p2);
             }
         }
     } else {
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void sn_grad_dot_kernel(const mtd_sn_grad_laye
             if (e < total) {
                 const float w = ly.w[e];
                 p = fmaf(ly.G[e], w, p);
-                if (two) p2 = fmaf(ly.G2[e], w, p2);
+                if (ly.G2) p2 = fmaf(ly.G2[e], w, p2);
             }
         }
     }
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void sn_grad_dot_kernel(const mtd_sn_grad_laye
 __global__ __launch_bounds__(256) void sn_grad_sum_kernel(const mtd_sn_grad_layer* __restrict__ L, int n_layers, SnGradWs ws) {
     __shared__ float red[256];
     const int layer = blockIdx.x >> 1, s = blockIdx.x & 1;
-    if (layer >= n_layers || (s && !L[layer].G2)) return;
+    if (layer >= n_layers || (s && !L[layer].sigma2)) return;
     const int nb = grad_blocks(L[layer]);
     long long first = 0;
     for (int l = 0; l < layer; ++l) first += grad_blocks(L[l]);
@@ -431,11 +431,13 @@ __global__ __launch_bounds__(256) void sn_grad_apply_kernel(const mtd_sn_grad_la
     const unsigned total = (unsigned)ly.rows * (unsigned)ly.cols;
     const unsigned base = (unsigned)local * GRAD_ELEMS_PER_BLOCK;
     const unsigned cols = (unsigned)ly.cols;
-    const bool two = ly.G2 != nullptr;
+    const bool two = ly.sigma2 != nullptr;              // two passes: a second rank-one term, and a second gradient unless G is prescaled
+    const bool two_g = ly.G2 != nullptr;
     const float inv = ly.sigma[1];
     const float coef = ws.dot[2 * layer] * inv * inv;
     const float inv2 = two ? ly.sigma2[1] : 0.f;
     const float coef2 = two ? ws.dot[2 * layer + 1] * inv2 * inv2 : 0.f;
+    const float ginv = ly.prescaled ? 1.f : inv;        // (prescaled: G = G_1 / sigma_1 + G_2 / sigma_2 already)
     if (grad_vec_ok(ly)) {
 #pragma unroll 4
         for (int i = threadIdx.x * 4; i < GRAD_ELEMS_PER_BLOCK; i += 1024) {
@@ -445,22 +447,28 @@ __global__ __launch_bounds__(256) void sn_grad_apply_kernel(const mtd_sn_grad_la
                 const float cu = coef * ly.u[r];
                 const float4 G = *reinterpret_cast<const float4*>(ly.G + e);
                 float4 o;
-                o.x = G.x * inv - cu * ly.v[k];
-                o.y = G.y * inv - cu * ly.v[k + 1];
-                o.z = G.z * inv - cu * ly.v[k + 2];
-                o.w = G.w * inv - cu * ly.v[k + 3];
+                o.x = G.x * ginv - cu * ly.v[k];
+                o.y = G.y * ginv - cu * ly.v[k + 1];
+                o.z = G.z * ginv - cu * ly.v[k + 2];
+                o.w = G.w * ginv - cu * ly.v[k + 3];
                 float4* dst = reinterpret_cast<float4*>(ly.g_out + e);
                 if (ly.accumulate) {
                     const float4 a = *dst;
                     o.x = a.x + o.x; o.y = a.y + o.y; o.z = a.z + o.z; o.w = a.w + o.w;
                 }
-                if (two) {                                               // second pass added after the first, as two launches would
+                if (two_g) {                                             // second pass added after the first, as two launches would
                     const float cu2 = coef2 * ly.u2[r];
                     const float4 H = *reinterpret_cast<const float4*>(ly.G2 + e);
                     o.x += H.x * inv2 - cu2 * ly.v2[k];
                     o.y += H.y * inv2 - cu2 * ly.v2[k + 1];
                     o.z += H.z * inv2 - cu2 * ly.v2[k + 2];
                     o.w += H.w * inv2 - cu2 * ly.v2[k + 3];
+                } else if (two) {                                        // prescaled: the second pass's rank-one term only
+                    const float cu2 = coef2 * ly.u2[r];
+                    o.x -= cu2 * ly.v2[k];
+                    o.y -= cu2 * ly.v2[k + 1];
+                    o.z -= cu2 * ly.v2[k + 2];
+                    o.w -= cu2 * ly.v2[k + 3];
                 }
                 *dst = o;
             }
@@ -470,9 +478,10 @@ __global__ __launch_bounds__(256) void sn_grad_apply_kernel(const mtd_sn_grad_la
             const unsigned e = base + i;
             if (e < total) {
                 const unsigned r = e / cols, k = e - r * cols;
-                float g = ly.G[e] * inv - coef * ly.u[r] * ly.v[k];
+                float g = ly.G[e] * ginv - coef * ly.u[r] * ly.v[k];
                 if (ly.accumulate) g = ly.g_out[e] + g;
-                if (two) g += ly.G2[e] * inv2 - coef2 * ly.u2[r] * ly.v2[k];
+                if (two_g) g += ly.G2[e] * inv2 - coef2 * ly.u2[r] * ly.v2[k];
+                else if (two) g -= coef2 * ly.u2[r] * ly.v2[k];
                 ly.g_out[e] = g;
             }
         }
@@ -596,13 +605,15 @@ extern "C" int mtd_sn_grad(const mtd_sn_grad_layer* layers_dev, const mtd_sn_gra
     if (!layers_dev || !layers_host || n_layers <= 0 || !ws) return MTD_EINVAL;
     for (int i = 0; i < n_layers; ++i) {
         const mtd_sn_grad_layer& l = layers_host[i];
+        if (l.prescaled && (!l.act_gy || l.G2)) return MTD_EINVAL;      // the dot products of a prescaled gradient come from the activation side
+        if (l.G2 && !(l.u2 && l.v2 && l.sigma2)) return MTD_EINVAL;
         if (!l.act_gy) continue;
         // the activation-side dot: its elements fit the layer's blocks, float4 accesses everywhere, a second pass only with a second sigma
         if (!l.act_a || !l.act_bias || l.act_M <= 0 || l.act_M_first < 0 || l.act_M_first > l.act_M) return MTD_EINVAL;
         if ((long long)l.act_M * l.rows > (long long)l.rows * l.cols || (long long)l.act_M * l.rows >= (1ll << 31)) return MTD_EINVAL;
         if ((l.rows % 4) || (l.act_gy_ld % 4) || (l.act_a_ld % 4) || (l.act_gy2 && (l.act_gy2_ld % 4))) return MTD_EALIGN;
         if (!aligned16(l.act_gy) || !aligned16(l.act_a) || !aligned16(l.act_bias) || (l.act_gy2 && !aligned16(l.act_gy2))) return MTD_EALIGN;
-        if (l.act_M_first < l.act_M && !l.G2) return MTD_EINVAL;
+        if (l.act_M_first < l.act_M && !l.sigma2) return MTD_EINVAL;
     }
     const long long nb = sn_grad_blocks_host(layers_host, n_layers);
     SnGradWs w;

@@ -161,6 +161,7 @@ class Tape:
     pass
 
 
+SN_MERGE_HALVES = _options.lab("MTD_SN_MERGE_HALVES", "1") != "0"      # ... and both halves of a paired pass in one small-map weight-gradient launch
 SN_ACT_DOT = _options.lab("MTD_SN_ACT_DOT", "1") != "0"        # the spectral-norm correction's <G, W> from (cotangent, saved output) on the small maps (round 6)
 SKIP_IN_CAT = _options.lab("MTD_SKIP_IN_CAT", "1") != "0"      # trunk outputs written into the pixel-level decoder's concatenated buffers
 
@@ -404,6 +405,7 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
     dev = x.device
     sn_touched = []
     sn_act = {}                 # layer -> (cotangent, second cotangent or None, saved output, 1 / slope): see wgrad_sn
+    sn_pre = set()              # layers whose two halves went through one launch (the temp holds the gradient over both sigmas)
     side = K.side_stream(dev)   # weight gradients run beside the data-gradient chain
 
     def want(name):
@@ -441,10 +443,24 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
                 return
             if SN_ACT_DOT and yout is not None and p.shape[0] * p.shape[1] * p.shape[2] < Cc * k * k and N % 4 == 0:
                 pe, pe2 = getattr(src, "parts", None) or (p, None)
-                sn_act[name] = (pe, pe2, yout, 1.0 / slope)      # (references: the cotangents stay allocated until sn_fix has read them)
+                if (all(t is None or (t.data_ptr() % 16 == 0 and K.ld_of(t) % 4 == 0) for t in (pe, pe2, yout))
+                        and P[name + ".bias"].data_ptr() % 16 == 0):
+                    sn_act[name] = (pe, pe2, yout, 1.0 / slope)      # (references: the cotangents stay allocated until sn_fix has read them)
             hh, kk, ss, pp = gspec
             if Bh:
                 gfull = K.geom_fwd(B, hh, hh, kk, ss, pp)
+                m_first = Bh * p.shape[1] * p.shape[2]
+                if SN_MERGE_HALVES and name in sn_act and m_first % 32 == 0 and K.wgrad_half_ok(gfull, N, Cc, m_first):
+                    # both halves in ONE launch of the small-map kernels: each half's cotangent times its own 1 / sigma as it is used, so
+                    # the temp holds G_1 / sigma_1 + G_2 / sigma_2 and the correction adds two rank-one terms (its dot products come from
+                    # the activation side: the raw gradients do not exist apart any more)
+                    i = SN_INDEX[name]
+                    half = (tp.sig[i, 1:2], tp.sig2[i, 1:2], m_first)
+                    side.run(lambda: K.wgrad(src(), q, gfull, N, Cc, rt.gtemp(name, dev, 0), Cc * k * k, k * k, db=sink.get(bn),
+                                             accumulate=False, accumulate_bias=True, half=half), p, q)
+                    sn_pre.add(name)
+                    sn_touched.append(name)
+                    return
 
                 def both():         # (one launch for both halves where the library's plan allows it)
                     pe, pe2 = getattr(src, "parts", None) or (src(), None)
@@ -483,15 +499,17 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
             s.g_out = sink.get(name + ".weight_orig").data_ptr()
             s.rows, s.cols, s.accumulate = SN_SPECS[i][1], SN_SPECS[i][2], 0 if name in overwrite else 1
             if Bh:      # the second half's own sigma, u, v: corrected and added in the same launch, after the first
-                s.G2 = rt.gtemp(name, dev, 1).data_ptr()
+                if name in sn_pre:
+                    s.prescaled = 1                  # (one gradient, already over both sigmas: wgrad_sn)
+                else:
+                    s.G2 = rt.gtemp(name, dev, 1).data_ptr()
                 s.u2 = tp.u_save2.data_ptr() + 4 * SN_ROW_OFF[i]
                 s.v2 = tp.v_save2.data_ptr() + 4 * SN_COL_OFF[i]
                 s.sigma2 = tp.sig2.data_ptr() + 8 * i
             act = sn_act.pop(name, None)
             if act is not None:
                 pe, pe2, yout, inv_slope = act
-                ok = all(t is None or (t.data_ptr() % 16 == 0 and K.ld_of(t) % 4 == 0) for t in (pe, pe2, yout)) and P[name + ".bias"].data_ptr() % 16 == 0
-                if ok:
+                if True:
                     npix = pe.shape[0] * pe.shape[1] * pe.shape[2]
                     s.act_gy, s.act_gy_ld = pe.data_ptr(), K.ld_of(pe)
                     if pe2 is not None:
@@ -502,6 +520,7 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
                     held.extend(t for t in (pe, pe2, yout) if t is not None)
             structs.append(s)
         del sn_touched[:]
+        sn_pre.clear()
         def fix():
             # (the descriptor table is built HERE, under the side stream: a new table's upload is then ordered before its reader
             # by the stream itself)

@@ -39,12 +39,18 @@ def block_forward(x, w_img, b_img, w_fft, b_fft, save, w2t=None):
     if K.BLOCK_FWD_WINO:
         # lab (round 6): the spatial branch on the persistent F(2x4, 3x3) kernel (conv_wino_c32.h, side stream) + the closing row
         # transform as a launch of its own, instead of the halo-tile kernel with the transform in its tail
-        side = K.side_stream(x.device, 1)
-        side.run(lambda: K.conv(x, w_img, g, CH, CH, CH * 9, 9, img, bias=b_img, act=ACT_RELU, wino32=True), x)
-        R = K.rfft_rows(x, 0)
-        T, S, Z = K.spec_mix_fwd(R, w2t, b_fft, save)
-        out = K.empty_nhwc(B, H, W, CH, x)
-        side.join()
+        if K.BLOCK_FWD_WINO == 2:      # ... all on one stream (a persistent one-workgroup-per-CU kernel beside another stream's work waits for CUs)
+            K.conv(x, w_img, g, CH, CH, CH * 9, 9, img, bias=b_img, act=ACT_RELU, wino32=True)
+            R = K.rfft_rows(x, 0)
+            T, S, Z = K.spec_mix_fwd(R, w2t, b_fft, save)
+            out = K.empty_nhwc(B, H, W, CH, x)
+        else:
+            side = K.side_stream(x.device, 1)
+            side.run(lambda: K.conv(x, w_img, g, CH, CH, CH * 9, 9, img, bias=b_img, act=ACT_RELU, wino32=True), x)
+            R = K.rfft_rows(x, 0)
+            T, S, Z = K.spec_mix_fwd(R, w2t, b_fft, save)
+            out = K.empty_nhwc(B, H, W, CH, x)
+            side.join()
         K.irfft_rows(T, out, add1=x, add2=img)
         return out, ((x, img, S, Z) if save else None)
     if K.BLOCK_TAIL and K.block_tail_ok(x, w_img, g, img, b_img):
@@ -89,6 +95,19 @@ def block_backward(g, saved, w_img, w_fft, grads, premask, defer=None, gm=None):
             if not K.conv_wgrad_fused(dg, wg, defer, spec=gT):      # (a launch: never inside an assert, python -O strips those)
                 raise RuntimeError("block_backward: mtd_conv_c32_bwd_irfft refused a layer that mtd_conv_c32_bwd_ok accepted")
             return gx
+    if K.BLOCK_BWD_WINO >= 2 and defer is not None and K.DEFER_WGRADS:
+        # lab: the three-launch form with the spectral chain and the data gradient on ONE stream, the weight gradient beside them
+        gR = K.rfft_rows(g, 1)
+        gT = K.spec_mix_bwd(gR, w_fft, S, Z, grads["dw_fft"], grads["db_fft"], defer=defer)
+        if K.BLOCK_BWD_WINO == 3:      # (3: the weight gradient on the same stream too)
+            K.wgrad(gm, x, K.geom_fwd(B, H, W, 3, 1, 1), CH, CH, grads["dw_img"], CH * 9, 9, db=grads["db_img"], defer=defer)
+        else:
+            side.run(lambda: K.wgrad(gm, x, K.geom_fwd(B, H, W, 3, 1, 1), CH, CH, grads["dw_img"], CH * 9, 9, db=grads["db_img"], defer=defer), gm, g)
+        d1 = K.empty_nhwc(B, H, W, CH, x)
+        K.conv(gm, w_img, K.geom_dgrad_s1(B, H, W, 3, 1), CH, CH, 9, CH * 9, d1, add1=g, wino32=True)
+        gx = K.empty_nhwc(B, H, W, CH, x)
+        K.irfft_rows(gT, gx, add1=d1, mask=x if premask else None)
+        return gx
     # the block conv's weight gradient and the row transform that opens the spectral backward chain read the same
     # cotangent: one launch when the slab sums are deferred (kernels.wgrad rows=...), at the head of the spectral stream
     fused_rows = defer is not None and K.DEFER_WGRADS and K.FUSE_WGRAD_ROWS

@@ -762,9 +762,29 @@ def flush_wgrads(defer):
 FUSE_WGRAD_ROWS = _options.lab("MTD_FUSED_WGRAD_ROWS", "0") == "1"
 
 
-def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumulate_bias=None, defer=None, rows=None):
+_half_ok_cache = {}
+
+
+def wgrad_half_ok(geom, N, Cc, m_first):
+    """Would wgrad(..., half=...) be taken for a layer of this shape (mtd_conv_wgrad_half_scale_ok: the register-operand small-map
+    kernels, m_first a multiple of 32)?  Shapes only; nothing is launched."""
+    key = (bytes(geom), N, Cc, m_first)
+    ok = _half_ok_cache.get(key)
+    if ok is None:
+        a = WgradArgs()
+        a.g = geom
+        a.p = a.q = a.dw = a.half_scale = a.half_scale2 = 16            # (non-null, aligned placeholders: the query looks at shapes)
+        a.p_ld, a.N, a.q_ld, a.C, a.w_sn, a.w_sc, a.m_first = N, N, Cc, Cc, Cc * geom.TH * geom.TW, geom.TH * geom.TW, int(m_first)
+        ok = bool(_lib.lib().mtd_conv_wgrad_half_scale_ok(C.byref(a)))
+        _half_ok_cache[key] = ok
+    return ok
+
+
+def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumulate_bias=None, defer=None, rows=None, half=None):
     """rows = (x, col_weight): also return rfft_rows(x, col_weight) -- carried by the weight-gradient launch itself when
-    the slab sums are deferred (mtd_conv_wgrad_slabs_rfft), a launch of its own otherwise."""
+    the slab sums are deferred (mtd_conv_wgrad_slabs_rfft), a launch of its own otherwise.
+    half = (scale1, scale2, m_first): device scalars by which the cotangent of pixels [0, m_first) / the rest is multiplied as it
+    is used (mtd_wgrad_args.half_scale: both halves of a paired pass, each over its own sigma, in one launch); db stays unscaled."""
     if rows is not None and not (defer is not None and DEFER_WGRADS and FUSE_WGRAD_ROWS and N % 32 == 0 and Cc % 32 == 0):
         wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=db, accumulate=accumulate, accumulate_bias=accumulate_bias, defer=defer)
         return rfft_rows(rows[0], rows[1])
@@ -779,6 +799,8 @@ def wgrad(p, q, geom, N, Cc, dw, w_sn, w_sc, db=None, accumulate=False, accumula
         accumulate_bias = accumulate
     a.accumulate = (1 if accumulate else 0) | (2 if accumulate_bias else 0)
     a.ws, a.ws_bytes = None, 0
+    if half is not None:
+        a.half_scale, a.half_scale2, a.m_first = half[0].data_ptr(), half[1].data_ptr(), int(half[2])
     if FLOP_COUNT is not None:
         _count_wgrad(geom, N, Cc, L.mtd_conv_wgrad_plan_cfg(C.byref(a)))
     need = L.mtd_conv_wgrad_ws_bytes(C.byref(a))
@@ -1003,11 +1025,15 @@ CH32 = 32
 BLOCK_TAIL = _options.lab("MTD_NO_BLOCK_TAIL", "0") != "1"      # conv3x3 + inverse row transform + residual in one launch
 
 
-# lab (round 6): a Res-FFT-Conv block's 3x3 conv on the persistent F(2x4, 3x3) kernel in the forward pass (BLOCK_FWD_WINO)
-# and as its data gradient (BLOCK_BWD_WINO: three launches -- that kernel, the Winograd 32 x 32 weight gradient on the side stream, the
-# closing row transform -- instead of the fused c32_bwd launch)
-BLOCK_FWD_WINO = _options.lab("MTD_BLOCK_FWD_WINO", "0") == "1"
-BLOCK_BWD_WINO = _options.lab("MTD_BLOCK_BWD_WINO", "0") == "1"
+# Round 6: a Res-FFT-Conv block's 3x3 conv on the persistent F(2x4, 3x3) kernel too -- in the forward pass (BLOCK_FWD_WINO: that kernel +
+# the closing row transform as a launch of its own, instead of the halo-tile kernel with the transform in its tail) and as its data
+# gradient (BLOCK_BWD_WINO: that kernel, the Winograd 32 x 32 weight gradient and the closing row transform instead of the fused c32_bwd
+# launch).  The persistent kernel wants the chip to itself: beside another stream's kernels its workgroups wait for CUs, and the forms
+# with side streams (1) win 0.11 ms in the generator leg and LOSE 0.2-0.45 ms in the full step; on ONE stream (forward 2, backward 3:
+# the weight gradient on the same stream too) the leg gains 0.12 ms (5.09 -> 4.98 ms) and the step 0.01-0.08 ms (four A/B pairs).
+# 0: the fused launches of rounds 3-5.
+BLOCK_FWD_WINO = int(_options.lab("MTD_BLOCK_FWD_WINO", "2"))      # 1: the conv on a side stream beside the spectral branch; 2: one stream
+BLOCK_BWD_WINO = int(_options.lab("MTD_BLOCK_BWD_WINO", "3"))      # 1: spectral chain on a side stream; 2: main stream, weight gradient beside it; 3: one stream
 
 
 def block_tail_ok(x, w, geom, img, bias):

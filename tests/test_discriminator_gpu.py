@@ -240,14 +240,20 @@ def test_sn_grad_activation_side_dot_vs_weight_side(hip_lib, case):
         t["gy2"] = nhwc(gy2)
     L = _lib.lib()
     got = {}
-    for form in ("weights", "activations"):
+    if paired:      # (mtd_wgrad_args.half_scale leaves this in ONE buffer: mtd_sn_grad_layer.prescaled)
+        t["Gpre"] = f32(Gs[0].reshape(rows, cols) / sig[0] + Gs[1].reshape(rows, cols) / sig[1])
+    for form in ("weights", "activations") + (("prescaled",) if paired else ()):
         out = f32(out0)
         s = _lib.SnGradLayer()
-        s.G, s.w, s.u, s.v, s.sigma = (t[n].data_ptr() for n in ("G1", "W", "u1", "v1", "s1"))
+        s.G, s.w, s.u, s.v, s.sigma = (t[n].data_ptr() for n in ("Gpre" if form == "prescaled" else "G1", "W", "u1", "v1", "s1"))
         s.g_out, s.rows, s.cols, s.accumulate = out.data_ptr(), rows, cols, 1
         if paired:
-            s.G2, s.u2, s.v2, s.sigma2 = (t[n].data_ptr() for n in ("G2", "u2", "v2", "s2"))
-        if form == "activations":
+            s.u2, s.v2, s.sigma2 = (t[n].data_ptr() for n in ("u2", "v2", "s2"))
+            if form == "prescaled":
+                s.prescaled = 1
+            else:
+                s.G2 = t["G2"].data_ptr()
+        if form != "weights":
             M = B * h * h
             assert M < cols
             s.act_gy, s.act_gy_ld, s.act_a, s.act_a_ld, s.act_bias = t["gy"].data_ptr(), co, t["a"].data_ptr(), co, t["b"].data_ptr()

@@ -171,17 +171,21 @@ def test_which_layers_take_the_32_channel_winograd_kernel():
     generator's 32 -> 32 channel 3x3 layers go to the Winograd kernels on whole-slice maps (side >= WINO_C32_MIN_HW = 128:
     csrc/conv_wino_c32.h) and stay on the halo-tile kernels on the 64 x 64 training patches; the residual-after-activation
     epilogue (MTD_ACT_RELU_ADD) is that form's only; 64-multiples of channels are unaffected by the threshold; a second output
-    (the fused masked cotangent) never goes there."""
+    (the fused masked cotangent) goes there only in the persistent kernel's masked two-output form."""
     from mtd_gan_amd import kernels as K
     assert K.WINO_C32_MIN_HW == 128
     fwd = lambda side: K.geom_fwd(2, side, side, 3, 1, 1)
     for side, want in ((64, False), (128, True), (256, True), (512, True)):
         assert K.winograd_takes(fwd(side), 32, 32, {}) is want, side
         assert K.winograd_takes(K.geom_dgrad_s1(2, side, side, 3, 1), 32, 32, {"act": K.ACT_RELU_ADD}) is want, side
-    # ... except where the caller opts in (the generator's forward pass, conv(..., wino32=True)) and the persistent kernel itself
-    # takes the launch: one residual operand at most, no mask, no scale
+    # ... except where the caller opts in (the generator's forward pass and, since round 6, the data gradients of its plain layers:
+    # conv(..., wino32=True)) and the persistent kernel itself takes the launch: one residual operand at most, no scale; a mask and a
+    # second output only in its masked two-output form (WINO_C32_BWD), a second output never without a mask
     assert K.WINO_C32_FWD and K.winograd_takes(fwd(64), 32, 32, {"wino32": True, "add1": object(), "act": K.ACT_RELU})
-    assert not K.winograd_takes(fwd(64), 32, 32, {"wino32": True, "mask": object()})
+    assert K.WINO_C32_BWD and K.winograd_takes(fwd(64), 32, 32, {"wino32": True, "mask": object()})
+    assert K.winograd_takes(fwd(64), 32, 32, {"wino32": True, "mask": object(), "out2": object(), "add1": object()})
+    assert not K.winograd_takes(fwd(64), 32, 32, {"wino32": True, "out2": object()})
+    assert not K.winograd_takes(fwd(64), 32, 32, {"mask": object(), "out2": object()})                      # (not without the caller's opt-in)
     assert not K.winograd_takes(fwd(64), 32, 32, {"wino32": True, "add2": object()})
     assert not K.winograd_takes(fwd(8), 32, 32, {"wino32": True})
     assert K.winograd_takes(fwd(64), 64, 64, {}) and not K.winograd_takes(fwd(64), 64, 64, {"act": K.ACT_RELU_ADD})

@@ -954,6 +954,55 @@ def test_weight_gradient_pair_equals_two_launches(hip_lib, case):
             L.mtd_conv_wgrad_pair_mode(prev)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(64, 512, 512, 4, 3), (64, 512, 512, 2, 3), (64, 1024, 512, 2, 3), (64, 512, 512, 2, 4), (64, 512, 512, 1, 4),
+                                  (64, 512, 512, 1, 1), (64, 256, 512, 4, 4), (8, 128, 96, 4, 3), (64, 64, 64, 16, 3)])
+def test_weight_gradient_half_scale_equals_two_scaled_launches(hip_lib, case):
+    """mtd_wgrad_args.half_scale (round 6): both halves of a paired discriminator pass in ONE launch of the small-map kernels, the
+    cotangent of each half multiplied by that half's own factor as it is used -- against s1 * dw(first half) + s2 * dw(second half) from
+    two launches, and the bias gradient against the unscaled sum.  case = (B, Cin, Cout, OUTPUT map side, k): k = 3 the block-window
+    kernels (4x4, 2x2 maps), k = 4 the stride-2 layers (all-taps kernel, wgrad_kernel<1, 1, 3>), k = 1 the bottleneck; the last case is
+    a large map, whose plan (Winograd) does not take the form: refused, nothing launched."""
+    from mtd_gan_amd import kernels as K
+    B, Ci, Co, H, k = case
+    Bh = B // 2
+    stride, pad = (2, 1) if k == 4 else (1, (k - 1) // 2)
+    gen = torch.Generator().manual_seed(31)
+    x = torch.randn(B, H * stride, H * stride, Ci, generator=gen).cuda()
+    gy = torch.randn(B, H, H, Co, generator=gen).cuda()
+    geom = K.geom_fwd(B, H * stride, H * stride, k, stride, pad)
+    m_first = Bh * H * H
+    ok = K.wgrad_half_ok(geom, Co, Ci, m_first)
+    if H == 16:
+        assert not ok
+        return
+    assert ok == (m_first % 32 == 0)
+    if not ok:
+        return
+    s1, s2 = torch.tensor([1.7], device="cuda"), torch.tensor([0.45], device="cuda")
+    dw = torch.full((Co, Ci, k, k), float("nan"), device="cuda")
+    db = torch.zeros(Co, device="cuda")
+    K.wgrad(gy, x, geom, Co, Ci, dw, Ci * k * k, k * k, db=db, accumulate=False, accumulate_bias=True, half=(s1, s2, m_first))
+    parts, dbs = [], []
+    for lo, hi in ((0, Bh), (Bh, B)):
+        d = torch.empty(Co, Ci, k, k, device="cuda")
+        b = torch.empty(Co, device="cuda")
+        K.wgrad(gy[lo:hi], x[lo:hi], K.mtd_geom_with_batch(geom, hi - lo), Co, Ci, d, Ci * k * k, k * k, db=b)
+        parts.append(d)
+        dbs.append(b)
+    torch.cuda.synchronize()
+    ref = 1.7 * parts[0].double() + 0.45 * parts[1].double()
+    assert relerr(dw.cpu(), ref.cpu()) < 2e-5
+    assert relerr(db.cpu(), (dbs[0].double() + dbs[1].double()).cpu()) < 2e-5
+    # accumulation into an existing gradient, and repeatability
+    dw2 = torch.full_like(dw, 0.25)
+    K.wgrad(gy, x, geom, Co, Ci, dw2, Ci * k * k, k * k, db=None, accumulate=True, half=(s1, s2, m_first))
+    dw3 = torch.full_like(dw, float("nan"))
+    K.wgrad(gy, x, geom, Co, Ci, dw3, Ci * k * k, k * k, db=None, accumulate=False, half=(s1, s2, m_first))
+    torch.cuda.synchronize()
+    assert torch.equal(dw3, dw) and relerr((dw2 - 0.25).cpu(), ref.cpu()) < 2e-5
+
+
 def _pair_case(K, _lib, B, Bh, Ci, Co, H, W, k, pairs):
     gen = torch.Generator().manual_seed(29)
     stride, pad = (2, 1) if k == 4 else (1, (k - 1) // 2)

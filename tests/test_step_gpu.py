@@ -879,11 +879,14 @@ def test_torch_adamw_drives_the_same_step(hip_lib):
     # deferred route multiplies directly where the plain-.grad route's weight gradient is the Winograd 32 x 32 kernel (plan 19), and the
     # two accumulate differently: 1e-6 of the tensor's largest element apart, which only an element whose gradient is down at AdamW's eps
     # (1e-8: these layers' gradients are ~1e-7 at this initialisation) can see.  So: (almost) every element within the update's own
-    # fp32 rounding, at most one in a hundred beyond it (measured 0.3 %, by up to 0.9 % of a step), none by more than a whole step.
+    # fp32 rounding, at most three in a hundred beyond it, none by more than a whole step.  (Measured 0.3 % in round 5; 1.6 % on the last
+    # block's conv in round 6, with the block convs on the Winograd kernels as well -- tools/r6_probe_routes.py: 126 of the 128 gradient
+    # tensors differ between the routes by 1e-6 of their largest element under either set of kernels, each route by itself is repeatable
+    # bit for bit, and these layers' gradients are 1e-15 ... 1e-9 at this initialisation, around and below AdamW's eps.)
     for k in f1:
         d = (f1[k].double() - t1[k].double()).abs()
         assert d.max().item() <= 2.1e-4, k
-        assert (d > 2e-7).double().mean().item() <= (1e-2 if k.startswith("Generator.") and tuple(f1[k].shape) == (32, 32, 3, 3) else 0.0), (k, d.max().item())
+        assert (d > 2e-7).double().mean().item() <= (3e-2 if k.startswith("Generator.") and tuple(f1[k].shape) == (32, 32, 3, 3) else 0.0), (k, d.max().item())
     t2, t2_fresh = run("torch", 2), run("torch", 2, drop_caches=True)
     for k in t2:
         assert torch.equal(t2[k], t2_fresh[k]), k
