@@ -202,8 +202,10 @@ __device__ __forceinline__ f32x4 wino_quad_rows(f32x4 r, float qsign) {
 // under the other's MFMAs -- for the layers with few K steps (C <= 128) or N = 64, where a lone workgroup per CU spends as long
 // outside its K loop as inside.  One weight-fragment register set instead of two.
 // PX: patch width.  4 = F(2x2, 3x3): 16 positions, two per wave; 6 = F(2x4, 3x3): 24 positions, three per wave (NB = 2, not LEAN).
-template <int NB, bool LEAN = false, int PX = 4>
-__global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const WinoParams wp) {
+// (the kernel's body as a function of the workgroup's place (bx, by, bz) in a grid (gx, gy, gz): wino_conv_kernel runs it on its own
+// grid, wino_conv_multi_kernel -- round 6 -- on either half of a grid that holds TWO problems of one shape)
+template <int NB, bool LEAN, int PX>
+__device__ __forceinline__ void wino_conv_body(const WinoParams& wp, int bx, int by, int bz, const int gx, const int gy, const int gz) {
     constexpr int NP = 4 * PX;            // transform positions xi = PX * (patch row) + (patch column)
     constexpr int PW = NP / 8;            // positions per wave
     constexpr int TWX = PX - 2;           // output pixels per tile row
@@ -226,9 +228,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
     //     (n block, K slice) weight slices, each fetched by ONE L2 and used by all its tile blocks;
     //   2 (input > weights: the large maps) = tile block slowest, n block fastest -- an XCD holds a contiguous run of image rows
     //     (the halo rows of neighbouring tile blocks meet in its L2) and each input slice is fetched once for all its n blocks.
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (wp.xcd_order) {
-        const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
         const int v = xcd_contiguous_block(bx + gx * (by + gy * bz), gx * gy * gz);
         if (wp.xcd_order == 1) {
             bz = v / (gx * gy);
@@ -584,6 +584,27 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
     }
 }
 
+template <int NB, bool LEAN = false, int PX = 4>
+__global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const WinoParams wp) {
+    wino_conv_body<NB, LEAN, PX>(wp, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y, (int)gridDim.z);
+}
+
+// Round 6: TWO convs of one shape in one grid -- the mirror layers of the discriminator's pixel-level and restoration decoders
+// (networks.py:420-467: s_dconv{l}k and r_dconv{l}k have the same channels on the same map; their inputs, weights and epilogue operands
+// differ).  On the 2x2 ... 8x8 maps a single layer fills a fraction of the chip even with its split of K; two of them in one launch are
+// twice the workgroups for one launch latency (and one slab-sum launch for both).  grid.z = 2 x the split of K: the first half of it
+// is problem 0.  (A branch per problem, not an index: a dynamic index into the kernel arguments would put them in scratch.)
+struct WinoMulti { WinoParams p[2]; };
+
+template <int NB, bool LEAN = false, int PX = 4>
+__global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_multi_kernel(const WinoMulti mp) {
+    const int gz = (int)gridDim.z >> 1;
+    const int set = __builtin_amdgcn_readfirstlane((int)blockIdx.z >= gz ? 1 : 0);
+    const int bz = (int)blockIdx.z - set * gz;
+    if (set == 0) wino_conv_body<NB, LEAN, PX>(mp.p[0], (int)blockIdx.x, (int)blockIdx.y, bz, (int)gridDim.x, (int)gridDim.y, gz);
+    else wino_conv_body<NB, LEAN, PX>(mp.p[1], (int)blockIdx.x, (int)blockIdx.y, bz, (int)gridDim.x, (int)gridDim.y, gz);
+}
+
 #include "conv_wino_c32.h"
 #include "conv_winograd_split.h"
 
@@ -788,18 +809,10 @@ extern "C" size_t mtd_conv_winograd_ws_bytes(const mtd_conv_args* a) {
     return pl.splitk > 1 ? (size_t)pl.splitk * (size_t)geom_pixels(a->g) * a->N * sizeof(float) : 0;
 }
 
-// a: as for mtd_conv_igemm, except that a->w points to the TRANSFORMED weights of this view and geometry
-// (mtd_winograd_weights; a->w_sn / w_sc / w_st are ignored).  Same epilogue, same split-K workspace contract.
-extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
-    if (!mtd_conv_winograd_ok(a)) return MTD_EINVAL;
-    if (!aligned16(a->w)) return MTD_EALIGN;
-    const int pxcode = wino_args_px(*a);
+// the launch parameters of one problem (shared by mtd_conv_winograd and mtd_conv_winograd_pair)
+static int wino_fill(const mtd_conv_args* a, const WinoPlan& pl, int pxcode, WinoParams& wp) {
     const int px = pxcode & 15;
     const bool split3 = (pxcode & 16) != 0;
-    if (px == 6 && (a->g.OW % 4)) return MTD_EINVAL;
-    if (split3 && (a->N % 64)) return MTD_EINVAL;
-    const WinoPlan pl = wino_plan(*a, pxcode);
-    WinoParams wp;
     IgemmParams& p = wp.p;
     p.a = *a;
     p.M = (int)geom_pixels(a->g);
@@ -831,6 +844,26 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
         const size_t need = (size_t)pl.splitk * (size_t)p.M * a->N * sizeof(float);
         if (!a->ws || a->ws_bytes < need) return MTD_EWS;
     }
+    return MTD_OK;
+}
+
+// a: as for mtd_conv_igemm, except that a->w points to the TRANSFORMED weights of this view and geometry
+// (mtd_winograd_weights; a->w_sn / w_sc / w_st are ignored).  Same epilogue, same split-K workspace contract.
+extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
+    if (!mtd_conv_winograd_ok(a)) return MTD_EINVAL;
+    if (!aligned16(a->w)) return MTD_EALIGN;
+    const int pxcode = wino_args_px(*a);
+    const int px = pxcode & 15;
+    const bool split3 = (pxcode & 16) != 0;
+    if (px == 6 && (a->g.OW % 4)) return MTD_EINVAL;
+    if (split3 && (a->N % 64)) return MTD_EINVAL;
+    const WinoPlan pl = wino_plan(*a, pxcode);
+    WinoParams wp;
+    {
+        const int rc = wino_fill(a, pl, pxcode, wp);
+        if (rc != MTD_OK) return rc;
+    }
+    IgemmParams& p = wp.p;
     hipStream_t s = (hipStream_t)stream;
     if (wino_c32_takes(*a, pxcode)) {
         C32Params cp;
@@ -878,6 +911,60 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
         if (blocks > 2048) blocks = 2048;
         if (vec) hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, p);
         else hipLaunchKernelGGL(splitk_epilogue_scalar_kernel, dim3(blocks), dim3(256), 0, s, p);
+        MTD_LAUNCH_CHECK();
+    }
+    return MTD_OK;
+}
+
+// ---- two convs of one shape in ONE launch (wino_conv_multi_kernel): a[0], a[1] as for mtd_conv_winograd, same geometry, N, C,
+// pixel strides of the weights' form; inputs, weights, outputs, epilogue operands and workspaces their own.  The general fp32 kernels
+// only (not the persistent 32-channel kernel, not the split-bf16 form): mtd_conv_winograd_pair_ok says whether a pair qualifies.
+extern "C" int mtd_conv_winograd_pair_ok(const mtd_conv_args* a, const mtd_conv_args* b) {
+    if (!mtd_conv_winograd_ok(a) || !mtd_conv_winograd_ok(b)) return 0;
+    if (__builtin_memcmp(&a->g, &b->g, sizeof(mtd_geom)) != 0 || a->N != b->N || a->C != b->C) return 0;
+    const int pxa = wino_args_px(*a), pxb = wino_args_px(*b);
+    if (pxa != pxb || (pxa & 16) || (a->N % 64)) return 0;
+    if (wino_c32_takes(*a, pxa) || wino_c32_takes(*b, pxb)) return 0;
+    if (!aligned16(a->w) || !aligned16(b->w)) return 0;
+    if ((pxa & 15) == 6 && (a->g.OW % 4)) return 0;
+    // the two problems' slab sums go through ONE launch of the 16-byte epilogue: both need it (else: two single launches)
+    const long long M = geom_pixels(a->g);
+    if (wino_plan(*a, pxa).splitk > 1 && !(splitk_vec_ok(*a, M) && splitk_vec_ok(*b, M))) return 0;
+    return 1;
+}
+
+extern "C" int mtd_conv_winograd_pair(const mtd_conv_args* a, const mtd_conv_args* b, void* stream) {
+    if (!mtd_conv_winograd_pair_ok(a, b)) return MTD_EINVAL;
+    const int pxcode = wino_args_px(*a);
+    const int px = pxcode & 15;
+    const WinoPlan pl = wino_plan(*a, pxcode);
+    WinoMulti mp;
+    int rc = wino_fill(a, pl, pxcode, mp.p[0]);
+    if (rc == MTD_OK) rc = wino_fill(b, pl, pxcode, mp.p[1]);
+    if (rc != MTD_OK) return rc;
+    mp.p[1].xcd_order = mp.p[0].xcd_order;
+    const IgemmParams& p = mp.p[0].p;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((mp.p[0].ntiles + WT - 1) / WT, a->N / (32 * pl.nb), 2 * pl.splitk);
+    // (profiler ids 34-37: wino_conv_multi_kernel<2, false, 6>, <2, false, 4>, <4, false, 4>, <2, true, 4>)
+    const int prof = mtd_prof_begin(0, px == 6 ? 34 : (pl.nb == 4 ? 36 : (pl.lean ? 37 : 35)), pl.splitk, 2ll * p.M, a->N, a->C, 9, s,
+                                    algorithmic_bytes(a) + algorithmic_bytes(b));
+    if (px == 6 && pl.nb == 2) MTD_LAUNCH((wino_conv_multi_kernel<2, false, 6>), grid, dim3(512), 0, s, mp);
+    else if (px == 6) { mtd_prof_end(prof, s); return MTD_EINVAL; }
+    else if (pl.nb == 4) MTD_LAUNCH((wino_conv_multi_kernel<4>), grid, dim3(512), 0, s, mp);
+    else if (pl.lean) MTD_LAUNCH((wino_conv_multi_kernel<2, true>), grid, dim3(512), 0, s, mp);
+    else MTD_LAUNCH((wino_conv_multi_kernel<2>), grid, dim3(512), 0, s, mp);
+    mtd_prof_end(prof, s);
+    MTD_LAUNCH_CHECK();
+    if (pl.splitk > 1) {
+        IgemmMulti em;
+        em.p[0] = mp.p[0].p;
+        em.p[1] = mp.p[1].p;
+        em.p[2] = em.p[3] = mp.p[0].p;                           // (unused rows of the grid: blockIdx.y < 2)
+        const long long total = (long long)p.M * a->N;
+        int blocks = (int)((total / 4 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_epilogue_multi_kernel, dim3(blocks, 2), dim3(256), 0, s, em);
         MTD_LAUNCH_CHECK();
     }
     return MTD_OK;

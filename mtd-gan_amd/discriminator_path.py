@@ -247,9 +247,20 @@ def _scales(tape, name, geom):
     return kw
 
 
+def _sn_call(P, tape, name, x, out, geom, N, Cc, k, act):
+    """The (args, keywords) of an SN layer's forward conv as kernels.conv / conv_pair take them."""
+    return ((x, P[name + ".weight_orig"], geom, N, Cc, Cc * k * k, k * k, out), dict(bias=P[name + ".bias"], act=act, **_scales(tape, name, geom)))
+
+
 def _sn_conv(P, tape, name, x, out, geom, N, Cc, k, act):
-    return K.conv(x, P[name + ".weight_orig"], geom, N, Cc, Cc * k * k, k * k, out, bias=P[name + ".bias"], act=act,
-                  **_scales(tape, name, geom))
+    args, kw = _sn_call(P, tape, name, x, out, geom, N, Cc, k, act)
+    return K.conv(*args, **kw)
+
+
+# Round 6: the pixel-level and the restoration decoder are mirrors (networks.py:420-467: s_dconv{l}k and r_dconv{l}k have the same
+# channels on the same maps) -- where a pass runs both, level by level, each pair of mirror convs is ONE launch (kernels.conv_pair:
+# two problems in one grid of the Winograd kernel, one slab-sum launch for both) in the forward pass and for the data gradients.
+PAIR_DECODERS = _options.lab("MTD_PAIR_DECODERS", "1") != "0"
 
 
 def disc_forward(P, x, train, drop_mask, need_rec, save, sn=None, sn2=None, pair=0, heads=("cls", "seg", "rec")):
@@ -310,6 +321,51 @@ def disc_forward(P, x, train, drop_mask, need_rec, save, sn=None, sn2=None, pair
         tp.cm = K.mul(tp.c, drop_mask.reshape(B, 1, 1, 512)) if drop_mask is not None else tp.c
         enc = K.empty_nhwc(B, 1, 1, 1, x)
         K.conv(tp.cm, P["enc_out.weight"], g1, 1, 512, 512, 1, enc, bias=P["enc_out.bias"])
+    # ---- both decoders level by level, their mirror convs in pairs (PAIR_DECODERS)
+    both = PAIR_DECODERS and "seg" in heads and need_rec and "rec" in heads
+    g64 = K.geom_fwd(B, 64, 64, 1, 1, 0)
+    if both:
+        tp.s_cat, tp.s_o1, tp.s_o2, tp.s_in = {}, {}, {}, {}
+        tp.r_cat, tp.r_o1, tp.r_o2, tp.r_in = {}, {}, {}, {}
+        ts, tr, r = tp.bot, tp.bot, 1
+        for lvl in range(1, 7):
+            skip = tp.xs[7 - lvl]
+            ccat, co = DEC[lvl - 1]
+            cprev = ts.shape[3]
+            cat_s = seg_cat.get(lvl)
+            if cat_s is None:
+                cat_s = K.empty_nhwc(B, 2 * r, 2 * r, ccat, x)
+                K.copy_channels(skip, cat_s[..., cprev:])
+            K.upsample2x_fwd(ts, cat_s[..., :cprev])
+            cin_up, cup = RUP[lvl - 1]
+            cat_r = K.empty_nhwc(B, 2 * r, 2 * r, ccat, x)
+            wu = P[f"r_up{lvl}.upsample.0.weight"]
+            if PS_FUSED:
+                bu = K.regrouped_bias(P[f"r_up{lvl}.upsample.0.bias"], 4)
+                wq = wu.detach().view(cup, 4, cin_up)
+                K.conv_multi([((tr, wq[:, q], K.geom_pixel_shuffle2(B, r, r, q >> 1, q & 1), cup, cin_up, 4 * cin_up, 1, cat_r[..., :cup]),
+                               dict(bias=bu[q * cup:(q + 1) * cup])) for q in range(4)])
+            else:
+                up = K.empty_nhwc(B, r, r, 4 * cup, x)
+                K.conv(tr, wu, K.geom_fwd(B, r, r, 1, 1, 0), 4 * cup, cin_up, cin_up, 1, up, bias=P[f"r_up{lvl}.upsample.0.bias"])
+                K.pixel_shuffle2_fwd(up, cat_r[..., :cup])
+            K.copy_channels(skip, cat_r[..., cup:])
+            r *= 2
+            g3 = K.geom_fwd(B, r, r, 3, 1, 1)
+            o1s, o1r = K.empty_nhwc(B, r, r, co, x), K.empty_nhwc(B, r, r, co, x)
+            K.conv_pair(_sn_call(P, tp, f"s_dconv{lvl}1", cat_s, o1s, g3, co, ccat, 3, ACT_LRELU),
+                        _sn_call(P, tp, f"r_dconv{lvl}1", cat_r, o1r, g3, co, ccat, 3, ACT_LRELU))
+            o2s, o2r = K.empty_nhwc(B, r, r, co, x), K.empty_nhwc(B, r, r, co, x)
+            K.conv_pair(_sn_call(P, tp, f"s_dconv{lvl}2", o1s, o2s, g3, co, co, 3, ACT_LRELU),
+                        _sn_call(P, tp, f"r_dconv{lvl}2", o1r, o2r, g3, co, co, 3, ACT_LRELU))
+            tp.s_in[lvl], tp.s_cat[lvl], tp.s_o1[lvl], tp.s_o2[lvl] = ts, cat_s, o1s, o2s
+            tp.r_in[lvl], tp.r_cat[lvl], tp.r_o1[lvl], tp.r_o2[lvl] = tr, cat_r, o1r, o2r
+            ts, tr = o2s, o2r
+        dec = K.empty_nhwc(B, 64, 64, 1, x)
+        K.conv(ts, P["dec_out.weight"], g64, 1, 1, 1, 1, dec, bias=P["dec_out.bias"])
+        rec = K.empty_nhwc(B, 64, 64, 1, x)
+        K.conv(tr, P["rec_out.weight"], g64, 1, 1, 1, 1, rec, bias=P["rec_out.bias"])
+        return (enc, dec, rec), (tp if save else None)
     # ---- SEG decoder (networks.py:420-442)
     tp.s_cat, tp.s_o1, tp.s_o2, tp.s_in = {}, {}, {}, {}
     t, r = tp.bot, 1
@@ -330,7 +386,6 @@ def disc_forward(P, x, train, drop_mask, need_rec, save, sn=None, sn2=None, pair
         _sn_conv(P, tp, f"s_dconv{lvl}2", o1, o2, g3, co, co, 3, ACT_LRELU)
         tp.s_in[lvl], tp.s_cat[lvl], tp.s_o1[lvl], tp.s_o2[lvl] = t, cat, o1, o2
         t = o2
-    g64 = K.geom_fwd(B, 64, 64, 1, 1, 0)
     dec = None
     if "seg" in heads:
         dec = K.empty_nhwc(B, 64, 64, 1, x)
@@ -475,11 +530,15 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
         elif want(bn):
             raise NotImplementedError("bias-only gradient request")
 
-    def dgrad_s1(name, gpre, r, N, Cc, out, k=3, mask=None, add1=None):
-        # data gradient of a stride-1 SN conv with N input channels (outputs of this launch), Cc output channels
+    def dgrad_s1_call(name, gpre, r, N, Cc, out, k=3, mask=None, add1=None):
+        # data gradient of a stride-1 SN conv with N input channels (outputs of this launch), Cc output channels: (args, keywords)
         gd = K.geom_dgrad_s1(B, r, r, k, (k - 1) // 2)
-        return K.conv(gpre, P[name + ".weight_orig"], gd, N, Cc, k * k, N * k * k, out, add1=add1, mask=mask, mask_slope=0.2,
-                      **_scales(tp, name, gd))
+        return ((gpre, P[name + ".weight_orig"], gd, N, Cc, k * k, N * k * k, out),
+                dict(add1=add1, mask=mask, mask_slope=0.2, **_scales(tp, name, gd)))
+
+    def dgrad_s1(name, gpre, r, N, Cc, out, k=3, mask=None, add1=None):
+        args, kw = dgrad_s1_call(name, gpre, r, N, Cc, out, k, mask, add1)
+        return K.conv(*args, **kw)
 
     def sn_fix():
         """Corrects and accumulates the raw weight gradients taken since the last call (one launch, on the side stream:
@@ -589,10 +648,66 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
         in_decoder[0] = False
         return g
 
-    if g_rec is not None:
-        g_bot_parts.append(decoder_backward("r", g_rec, tp.r_cat, tp.r_o1, tp.r_o2, tp.r_in, "rec_out"))
-    if g_dec is not None:
-        g_bot_parts.append(decoder_backward("s", g_dec, tp.s_cat, tp.s_o1, tp.s_o2, tp.s_in, "dec_out"))
+    def decoders_backward_both():
+        """decoder_backward for the restoration and the pixel-level decoder level by level, the data gradients of their mirror convs in
+        pairs (kernels.conv_pair).  Every launch and every append happens in the order of two decoder_backward calls, "r" first."""
+        in_decoder[0] = True
+        D2 = {"r": (g_rec, tp.r_cat, tp.r_o1, tp.r_o2, tp.r_in, "rec_out"), "s": (g_dec, tp.s_cat, tp.s_o1, tp.s_o2, tp.s_in, "dec_out")}
+        g = {}
+        for pre in "rs":
+            g_out, _cats, _o1s, o2s, _ins, head = D2[pre]
+            t6 = o2s[6]
+            if want(head + ".weight"):
+                src_h = cot(head, g_out)
+                if src_h is not None:
+                    side.run(lambda src_h=src_h, t6=t6, head=head: K.wgrad(src_h(), t6, g64, 1, 1, sink.get(head + ".weight"), 1, 1,
+                                                                          db=sink.get(head + ".bias"), accumulate=True), g_out, t6)
+            g[pre] = K.empty_nhwc(B, 64, 64, 1, x)
+            K.conv(g_out, P[head + ".weight"], g64, 1, 1, 1, 1, g[pre], mask=o2s[6], mask_slope=0.2)
+        for lvl in range(6, 0, -1):
+            r = 2 ** lvl
+            ccat, co = DEC[lvl - 1]
+            gpre1, gcat = {}, {}
+            for pre in "rs":
+                wgrad_sn(f"{pre}_dconv{lvl}2", g[pre], D2[pre][2][lvl], (r, 3, 1, 1), co, co, 3, yout=D2[pre][3][lvl])
+                gpre1[pre] = K.empty_nhwc(B, r, r, co, x)
+            K.conv_pair(*[dgrad_s1_call(f"{pre}_dconv{lvl}2", g[pre], r, co, co, gpre1[pre], mask=D2[pre][2][lvl]) for pre in "rs"])
+            for pre in "rs":
+                wgrad_sn(f"{pre}_dconv{lvl}1", gpre1[pre], D2[pre][1][lvl], (r, 3, 1, 1), co, ccat, 3, yout=D2[pre][2][lvl])
+                gcat[pre] = K.empty_nhwc(B, r, r, ccat, x)
+            K.conv_pair(*[dgrad_s1_call(f"{pre}_dconv{lvl}1", gpre1[pre], r, ccat, co, gcat[pre]) for pre in "rs"])
+            for pre in "rs":
+                _g_out, _cats, _o1s, o2s, ins, _head = D2[pre]
+                tin = ins[lvl]
+                below = o2s[lvl - 1] if lvl > 1 else None
+                cprev = tin.shape[3] if pre == "s" else RUP[lvl - 1][1]
+                g_skip[7 - lvl].append(gcat[pre][..., cprev:])
+                if pre == "s":
+                    g[pre] = K.empty_nhwc(B, r // 2, r // 2, cprev, x)
+                    K.upsample2x_bwd(gcat[pre][..., :cprev], g[pre], mask=below, slope=0.2)
+                else:
+                    cin_up, cup = RUP[lvl - 1]
+                    gr = K.empty_nhwc(B, r // 2, r // 2, 4 * cup, x)
+                    K.pixel_shuffle2_bwd(gcat[pre][..., :cup], gr)
+                    gq = K.geom_fwd(B, r // 2, r // 2, 1, 1, 0)
+                    wn = f"r_up{lvl}.upsample.0.weight"
+                    if want(wn):
+                        src_u = cot(f"r_up{lvl}", gr)
+                        if src_u is not None:
+                            side.run(lambda src_u=src_u, tin=tin, gq=gq, wn=wn, cup=cup, cin_up=cin_up, lvl=lvl: K.wgrad(
+                                src_u(), tin, gq, 4 * cup, cin_up, sink.get(wn), cin_up, 1, db=sink.get(f"r_up{lvl}.upsample.0.bias"), accumulate=True), gr, tin)
+                    g[pre] = K.empty_nhwc(B, r // 2, r // 2, cin_up, x)
+                    K.conv(gr, P[wn], gq, cin_up, 4 * cup, 1, cin_up, g[pre], mask=below, mask_slope=0.2)
+        in_decoder[0] = False
+        return g["r"], g["s"]
+
+    if PAIR_DECODERS and g_rec is not None and g_dec is not None:
+        g_bot_parts.extend(decoders_backward_both())
+    else:
+        if g_rec is not None:
+            g_bot_parts.append(decoder_backward("r", g_rec, tp.r_cat, tp.r_o1, tp.r_o2, tp.r_in, "rec_out"))
+        if g_dec is not None:
+            g_bot_parts.append(decoder_backward("s", g_dec, tp.s_cat, tp.s_o1, tp.s_o2, tp.s_in, "dec_out"))
     if g_enc is not None:
         if want("enc_out.weight"):
             side.run(lambda: K.wgrad(g_enc, tp.cm, g1, 1, 512, sink.get("enc_out.weight"), 512, 1, db=sink.get("enc_out.bias"), accumulate=True), g_enc)

@@ -432,7 +432,9 @@ IGEMM_CONFIGS = ["igemm_kernel<2, 1, 4, 1>", "igemm_kernel<1, 1, 4, 1>", "igemm_
                  "wino_c32_kernel<false, false>", "wino_c32_kernel<true, false>",                                               # 25, 26: the persistent 32 -> 32 channel form
                  "wino_conv3_kernel<6>", "wino_conv3_kernel<4>",                                                                # 27, 28: the split-bf16 forms (conv_winograd_split.h)
                  "wino32_conv_kernel<2, false>", "wino32_conv_kernel<2, true>", "wino32_conv_kernel<4, false>",
-                 "wino_c32_kernel<false, true>", "wino_c32_kernel<true, true>"]      # 32, 33: ... with a mask operand and a second output (round 6)                                                                                       # 29: F(3x3, 2x2) for the 4x4 / stride-2 layers (conv_wino_s2.h)
+                 "wino_c32_kernel<false, true>", "wino_c32_kernel<true, true>",      # 32, 33: ... with a mask operand and a second output (round 6)
+                 "wino_conv_multi_kernel<2, false, 6>", "wino_conv_multi_kernel<2, false, 4>", "wino_conv_multi_kernel<4, false, 4>",      # 34-37: two problems of
+                 "wino_conv_multi_kernel<2, true, 4>"]                                                                                         # one shape per launch (round 6)                                                                                       # 29: F(3x3, 2x2) for the 4x4 / stride-2 layers (conv_wino_s2.h)
 WGRAD_CONFIGS = ["wgrad_kernel<1, 1, 9>", "wgrad_kernel<1, 1, 4>", "wgrad_kernel<2, 2, 1>", "wgrad_kernel<1, 1, 8>",
                  "wgrad_kernel<1, 1, 3>", "wgrad_kernel<1, 1, 1>", "wgrad_kernel<2, 2, 3>",
                  "wgrad_row_kernel<3, 3, 1>", "wgrad_row_kernel<3, 3, -1>", "wgrad_row_kernel<1, 1, 1>",
@@ -654,6 +656,48 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, **kw):
             CALL_LOG.append(("direct", bytes(a)))
         check(L.mtd_conv_direct(C.byref(a), stream_ptr()), "mtd_conv_direct")
     return out
+
+
+PAIR_CONV = _options.lab("MTD_NO_PAIR_CONV", "0") != "1"
+
+
+def conv_pair(call_a, call_b):
+    """Two conv() calls of ONE shape -- the mirror layers of the discriminator's two decoders -- as one launch where both go to
+    the general Winograd kernels (mtd_conv_winograd_pair); two launches otherwise.  call = (args tuple, keyword dict) as conv()
+    takes them.  Same results as two conv() calls, bit for bit."""
+    (xa, wa, geom, N, Cc, wsn, wsc, outa), kwa = call_a
+    (xb, wb, geom_b, Nb, Ccb, wsnb, wscb, outb), kwb = call_b
+    L = _lib.lib()
+    if (PAIR_CONV and bytes(geom) == bytes(geom_b) and (N, Cc) == (Nb, Ccb) and N % 64 == 0
+            and winograd_takes(geom, N, Cc, kwa) and winograd_takes(geom, N, Cc, kwb)):
+        a = _conv_args(xa, wa, geom, N, Cc, wsn, wsc, outa, pack=False, **kwa)
+        b = _conv_args(xb, wb, geom, N, Cc, wsnb, wscb, outb, pack=False, **kwb)
+        if L.mtd_conv_winograd_ok(C.byref(a)) and L.mtd_conv_winograd_ok(C.byref(b)):
+            wva, px = winograd_weight_view(wa, N, Cc, wsn, wsc, geom)
+            wvb, pxb = winograd_weight_view(wb, N, Cc, wsnb, wscb, geom)
+            a.w, a.w_st, b.w, b.w_st = wva.data_ptr(), px, wvb.data_ptr(), pxb
+            wkey = ("wino", bytes(geom), N, Cc)
+            need = _igemm_ws_cache.get(wkey)
+            if need is None:
+                need = L.mtd_conv_winograd_ws_bytes(C.byref(a))
+                _igemm_ws_cache[wkey] = need
+            if need:
+                need = (need + 255) & ~255
+                ws = workspace(2 * need, xa.device)
+                a.ws, a.ws_bytes, b.ws, b.ws_bytes = ws.data_ptr(), need, ws.data_ptr() + need, need
+            if L.mtd_conv_winograd_pair_ok(C.byref(a), C.byref(b)):
+                if FLOP_COUNT is not None:      # (both _conv_args calls counted the direct form)
+                    saved = 2 * 2.0 * geom.B * geom.OH * geom.OW * N * Cc * (6 if (px & 15) == 6 else 5)
+                    FLOP_COUNT["conv_mfma"] -= saved
+                    FLOP_COUNT["conv_winograd_saved"] = FLOP_COUNT.get("conv_winograd_saved", 0.0) + saved
+                    FLOP_COUNT["launches"] -= 1
+                check(L.mtd_conv_winograd_pair(C.byref(a), C.byref(b), stream_ptr()), "mtd_conv_winograd_pair")
+                return
+        if FLOP_COUNT is not None:              # (conv() below counts again)
+            FLOP_COUNT["conv_mfma"] -= 2 * 2.0 * geom.B * geom.OH * geom.OW * N * Cc * 9
+            FLOP_COUNT["launches"] -= 2
+    conv(*call_a[0], **kwa)
+    conv(*call_b[0], **kwb)
 
 
 def conv_relu_add_ok(x, w, geom, N, Cc, w_sn, w_sc, out, **kw):
