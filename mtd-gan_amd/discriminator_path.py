@@ -441,9 +441,58 @@ class GradSink:
 FLUSH_LEVEL = 4      # trunk levels 6 .. FLUSH_LEVEL + both bottleneck convs: 91 % of the shared parameters, done 60 % into the trunk
 
 
-def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_export=None, dec_import=None, flush=None,
-                  overwrite=frozenset()):
-    """Replay one recorded pass.  g_enc (B,1,1,1) / g_dec (B,64,64,1) / g_rec (B,64,64,1): output
+def disc_backward(*args, **kw):
+    """One backward pass over a recorded tape: _disc_backward_gen run by itself (every launch it hands out is issued at once)."""
+    gen = _disc_backward_gen(*args, **kw)
+    try:
+        call = next(gen)
+        while True:
+            K.conv(*call[0], **call[1])
+            call = next(gen)
+    except StopIteration as e:
+        return e.value
+
+
+LOCKSTEP = _options.lab("MTD_LOCKSTEP_PASSES", "1") != "0"
+
+
+def disc_backward_lockstep(pass_a, pass_b):
+    """TWO independent backward passes of one structure (the adversarial pass over tape 1+2 and the consistency pass over tape 3+4:
+    the same heads, decoder and trunk, different tapes and cotangents) advanced together: where both are about to issue the data
+    gradient of the same layer, the two go out as ONE launch (kernels.conv_pair: same weights, two problems in one grid) -- on the
+    4x4 ... 1x1 levels a single pass's launches fill a fraction of the chip.  Everything else each pass issues is issued in that pass's
+    own order, pass a's first; every result equals the two passes run one after the other, bit for bit (their raw weight gradients
+    go to separate temps: lane).  pass_x = (args, keywords) of disc_backward.  Returns both input gradients."""
+    ga = _disc_backward_gen(*pass_a[0], **dict(pass_a[1], lane=0))
+    gb = _disc_backward_gen(*pass_b[0], **dict(pass_b[1], lane=1))
+    res = [None, None]
+
+    def step(i, g):
+        try:
+            return next(g)
+        except StopIteration as e:
+            res[i] = e.value
+            return None
+    a, b = step(0, ga), step(1, gb)
+    while a is not None or b is not None:
+        if a is not None and b is not None:
+            K.conv_pair(a, b)            # (two launches where the pair does not qualify)
+            a, b = step(0, ga), step(1, gb)
+        elif a is not None:
+            K.conv(*a[0], **a[1])
+            a = step(0, ga)
+        else:
+            K.conv(*b[0], **b[1])
+            b = step(1, gb)
+    return res[0], res[1]
+
+
+def _disc_backward_gen(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_export=None, dec_import=None, flush=None,
+                       overwrite=frozenset(), lane=0):
+    """A generator: it YIELDS the data-gradient launches of the 3x3 layers as (args, keywords) of kernels.conv instead of issuing them
+    (disc_backward issues each at once; disc_backward_lockstep pairs them with another pass's) and issues everything else itself.
+    lane: which set of raw weight-gradient temps the pass uses (two passes advanced together must not share them).
+    Replay one recorded pass.  g_enc (B,1,1,1) / g_dec (B,64,64,1) / g_rec (B,64,64,1): output
     cotangents (any may be None).  sink: GradSink or None.  All parameter gradients are ACCUMULATED.
     The decoders are task-specific: their parameter gradient is the SUM over the tasks that reach them through this tape,
     and a weight gradient is linear in the cotangent -- so a pass may hand its decoder cotangents over instead of computing
@@ -511,7 +560,7 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
                     # the activation side: the raw gradients do not exist apart any more)
                     i = SN_INDEX[name]
                     half = (tp.sig[i, 1:2], tp.sig2[i, 1:2], m_first)
-                    side.run(lambda: K.wgrad(src(), q, gfull, N, Cc, rt.gtemp(name, dev, 0), Cc * k * k, k * k, db=sink.get(bn),
+                    side.run(lambda: K.wgrad(src(), q, gfull, N, Cc, rt.gtemp(name, dev, 2 * lane), Cc * k * k, k * k, db=sink.get(bn),
                                              accumulate=False, accumulate_bias=True, half=half), p, q)
                     sn_pre.add(name)
                     sn_touched.append(name)
@@ -519,12 +568,12 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
 
                 def both():         # (one launch for both halves where the library's plan allows it)
                     pe, pe2 = getattr(src, "parts", None) or (src(), None)
-                    K.wgrad_pair(pe, q, gfull, Bh, N, Cc, rt.gtemp(name, dev, 0), rt.gtemp(name, dev, 1), Cc * k * k, k * k,
+                    K.wgrad_pair(pe, q, gfull, Bh, N, Cc, rt.gtemp(name, dev, 2 * lane), rt.gtemp(name, dev, 2 * lane + 1), Cc * k * k, k * k,
                                  db=sink.get(bn), accumulate_bias=True, p_add=pe2)
                 side.run(both, p, q)
             else:
                 geom = K.geom_fwd(B, hh, hh, kk, ss, pp)
-                side.run(lambda: K.wgrad(src(), q, geom, N, Cc, rt.gtemp(name, dev, 0), Cc * k * k, k * k, db=sink.get(bn), accumulate=False,
+                side.run(lambda: K.wgrad(src(), q, geom, N, Cc, rt.gtemp(name, dev, 2 * lane), Cc * k * k, k * k, db=sink.get(bn), accumulate=False,
                                          accumulate_bias=True), p, q)
             sn_touched.append(name)
         elif want(bn):
@@ -536,9 +585,6 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
         return ((gpre, P[name + ".weight_orig"], gd, N, Cc, k * k, N * k * k, out),
                 dict(add1=add1, mask=mask, mask_slope=0.2, **_scales(tp, name, gd)))
 
-    def dgrad_s1(name, gpre, r, N, Cc, out, k=3, mask=None, add1=None):
-        args, kw = dgrad_s1_call(name, gpre, r, N, Cc, out, k, mask, add1)
-        return K.conv(*args, **kw)
 
     def sn_fix():
         """Corrects and accumulates the raw weight gradients taken since the last call (one launch, on the side stream:
@@ -550,7 +596,7 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
         for name in sn_touched:
             i = SN_INDEX[name]
             s = _lib.SnGradLayer()
-            s.G = rt.gtemp(name, dev, 0).data_ptr()
+            s.G = rt.gtemp(name, dev, 2 * lane).data_ptr()
             s.w = P[name + ".weight_orig"].data_ptr()
             s.u = tp.u_save.data_ptr() + 4 * SN_ROW_OFF[i]
             s.v = tp.v_save.data_ptr() + 4 * SN_COL_OFF[i]
@@ -561,7 +607,7 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
                 if name in sn_pre:
                     s.prescaled = 1                  # (one gradient, already over both sigmas: wgrad_sn)
                 else:
-                    s.G2 = rt.gtemp(name, dev, 1).data_ptr()
+                    s.G2 = rt.gtemp(name, dev, 2 * lane + 1).data_ptr()
                 s.u2 = tp.u_save2.data_ptr() + 4 * SN_ROW_OFF[i]
                 s.v2 = tp.v_save2.data_ptr() + 4 * SN_COL_OFF[i]
                 s.sigma2 = tp.sig2.data_ptr() + 8 * i
@@ -603,7 +649,8 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
     g64 = K.geom_fwd(B, 64, 64, 1, 1, 0)
 
     def decoder_backward(pre, g_out, cats, o1s, o2s, ins, head):
-        """shared by the SEG ('s') and REC ('r') decoders; returns the gradient of x_bot"""
+        """shared by the SEG ('s') and REC ('r') decoders; returns the gradient of x_bot (a generator like its caller: the data
+        gradients of its 3x3 layers are handed out)"""
         t6 = o2s[6]
         in_decoder[0] = True
         if want(head + ".weight"):
@@ -623,10 +670,10 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
             below = o2s[lvl - 1] if lvl > 1 else None      # output of the level below (None: the bottleneck, masked by the caller)
             wgrad_sn(f"{pre}_dconv{lvl}2", gpre2, o1, (r, 3, 1, 1), co, co, 3, yout=o2)
             gpre1 = K.empty_nhwc(B, r, r, co, x)
-            dgrad_s1(f"{pre}_dconv{lvl}2", gpre2, r, co, co, gpre1, mask=o1)
+            yield dgrad_s1_call(f"{pre}_dconv{lvl}2", gpre2, r, co, co, gpre1, mask=o1)
             wgrad_sn(f"{pre}_dconv{lvl}1", gpre1, cat, (r, 3, 1, 1), co, ccat, 3, yout=o1)
             gcat = K.empty_nhwc(B, r, r, ccat, x)
-            dgrad_s1(f"{pre}_dconv{lvl}1", gpre1, r, ccat, co, gcat)
+            yield dgrad_s1_call(f"{pre}_dconv{lvl}1", gpre1, r, ccat, co, gcat)
             cprev = tin.shape[3] if pre == "s" else RUP[lvl - 1][1]
             g_skip[7 - lvl].append(gcat[..., cprev:])
             if pre == "s":
@@ -705,9 +752,9 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
         g_bot_parts.extend(decoders_backward_both())
     else:
         if g_rec is not None:
-            g_bot_parts.append(decoder_backward("r", g_rec, tp.r_cat, tp.r_o1, tp.r_o2, tp.r_in, "rec_out"))
+            g_bot_parts.append((yield from decoder_backward("r", g_rec, tp.r_cat, tp.r_o1, tp.r_o2, tp.r_in, "rec_out")))
         if g_dec is not None:
-            g_bot_parts.append(decoder_backward("s", g_dec, tp.s_cat, tp.s_o1, tp.s_o2, tp.s_in, "dec_out"))
+            g_bot_parts.append((yield from decoder_backward("s", g_dec, tp.s_cat, tp.s_o1, tp.s_o2, tp.s_in, "dec_out")))
     if g_enc is not None:
         if want("enc_out.weight"):
             side.run(lambda: K.wgrad(g_enc, tp.cm, g1, 1, 512, sink.get("enc_out.weight"), 512, 1, db=sink.get("enc_out.bias"), accumulate=True), g_enc)
@@ -760,16 +807,16 @@ def disc_backward(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_exp
         g3 = K.geom_fwd(B, h, h, 3, 1, 1)
         wgrad_sn(f"conv{l}2", gpre2, a, (h, 3, 1, 1), co, co, 3, yout=xl)
         gpre1 = K.empty_nhwc(B, h, h, co, x)
-        dgrad_s1(f"conv{l}2", gpre2, h, co, co, gpre1, mask=a)
+        yield dgrad_s1_call(f"conv{l}2", gpre2, h, co, co, gpre1, mask=a)
         wgrad_sn(f"conv{l}1", gpre1, tin, (h, 3, 1, 1), co, ci, 3, yout=a)
         if l == FLUSH_LEVEL:
             flush_point("trunk_low")
         if l > 1:
             g = K.empty_nhwc(B, h, h, ci, x)
-            dgrad_s1(f"conv{l}1", gpre1, h, ci, co, g)
+            yield dgrad_s1_call(f"conv{l}1", gpre1, h, ci, co, g)
         elif want_input_grad:
             g_in = K.empty_nhwc(B, h, h, 1, x)
-            dgrad_s1("conv11", gpre1, h, 1, co, g_in)
+            yield dgrad_s1_call("conv11", gpre1, h, 1, co, g_in)
 
     # ---- spectral-norm correction of the raw weight gradients, accumulated into the sink
     sn_fix()

@@ -184,11 +184,24 @@ class DStepTape:
                 side.run(lambda: dp.all_reduce_avg(S[2, tail_ofs:]), fork=False)
                 shipped["tail"] = True
 
-        adversarial()                                                                    # task 0
-        self._sync_task(dp, S, 0)
-        restoration()                                                                    # task 1
-        self._sync_task(dp, S, 1)
-        consistency12(consistency34(), ship if dp is not None and EARLY_SHIP else None)  # task 2
+        if DP.LOCKSTEP:
+            # The adversarial pass (tape 1+2) and the first consistency pass (tape 3+4) are independent and of one structure -- image-level
+            # head, pixel-level decoder, trunk: they are advanced together and the data gradients of the same layer go out as ONE launch
+            # (discriminator_path.disc_backward_lockstep).  Every buffer two passes add into sees them in the order of the sequential
+            # schedule (adversarial before consistency; the restoration pass touches none of those): same bits.
+            _none, gin34 = DP.disc_backward_lockstep(
+                ((rt, P, t12, G2["d_e"], G2["d_d"], None, sinks[0], False), dict(dec_export=exp_s, overwrite=first_write)),
+                ((rt, P, t34, G2["c3_e"], G2["c3_d"], None, sink_c, True), dict(overwrite=first_write | dec_first["s"])))
+            self._sync_task(dp, S, 0)
+            restoration()                                                                    # task 1
+            self._sync_task(dp, S, 1)
+            consistency12(gin34, ship if dp is not None and EARLY_SHIP else None)            # task 2, second half
+        else:
+            adversarial()                                                                    # task 0
+            self._sync_task(dp, S, 0)
+            restoration()                                                                    # task 1
+            self._sync_task(dp, S, 1)
+            consistency12(consistency34(), ship if dp is not None and EARLY_SHIP else None)  # task 2
         if shipped["tail"]:
             if dp is not None:
                 _dp_avg(dp, S[2, :tail_ofs], after=self._side_of(dev))

@@ -476,6 +476,40 @@ def test_first_pass_overwrites_task_vectors_same_bits(hip_lib, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("batch", [2, 32])
+def test_paired_launches_of_the_d_step_same_bits(hip_lib, monkeypatch, batch):
+    """Round 6: (a) the two decoders' mirror convs as pairs (discriminator_path.PAIR_DECODERS: forward pass over tape 1+2 and the second
+    consistency pass), (b) the adversarial and the first consistency pass advanced together with the data gradients of the same layer
+    in one launch (LOCKSTEP: disc_backward_lockstep).  Both only change HOW MANY launches carry the same arithmetic: the losses, the
+    three task vectors and the task-specific gradients equal the one-launch-per-layer, one-pass-after-the-other schedule bit for bit,
+    at 2 patches (every deep layer below the merged-halves threshold) and at the BASELINE's 32."""
+    from mtd_gan_amd import discriminator_path as DPm
+    from mtd_gan_amd.module.weight_methods import WeightMethods
+    res = {}
+    for mode in ("plain", "pairs", "pairs+lockstep"):
+        monkeypatch.setattr(DPm, "PAIR_DECODERS", mode != "plain")
+        monkeypatch.setattr(DPm, "LOCKSTEP", mode == "pairs+lockstep")
+        m, full, masks, z = _model(batch)
+        m.Discriminator._inject_masks = [k.clone() for k in masks[:4]]
+        x, y = orc.synthetic_ldct(batch, seed=1234)
+        wm = WeightMethods("pcgrad", n_tasks=3, device=torch.device("cuda"))
+        random.seed(77)
+        losses, _ = m.d_loss(x.cuda(), y.cuda())
+        D = m.Discriminator
+        wm.backward(losses=losses, shared_parameters=list(D.shared_parameters()), task_specific_parameters=list(D.task_specific_parameters()),
+                    last_shared_parameters=list(D.last_shared_parameters()))
+        tape = losses._mtd_tape
+        torch.cuda.synchronize()
+        res[mode] = (losses.detach().clone(), tape.task_vectors.clone(), [p.grad.clone() for p in D.task_specific_parameters()])
+    l0, S0, ts0 = res["plain"]
+    for mode in ("pairs", "pairs+lockstep"):
+        l1, S1, ts1 = res[mode]
+        assert torch.equal(l0, l1), mode
+        assert torch.equal(S0, S1), mode
+        assert all(torch.equal(a, b) for a, b in zip(ts0, ts1)), mode
+
+
+@pytest.mark.gpu
 def test_d_step_task_gradients_b32_vs_reference_samples(hip_lib):
     """The D step at BASELINE size (32 patches): the three per-task shared gradients, the merged gradient PCGrad writes and the
     task-specific gradients, PER TENSOR, against tests/golden/grad_samples_b32.json -- elements of the gradients the REFERENCE
