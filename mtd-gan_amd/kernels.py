@@ -659,6 +659,7 @@ def conv(x, w, geom, N, Cc, w_sn, w_sc, out, **kw):
 
 
 PAIR_CONV = _options.lab("MTD_NO_PAIR_CONV", "0") != "1"
+PAIR_MAX_PIXELS = int(_options.lab("MTD_PAIR_MAX_PIXELS", "0"))      # lab: pairs only on maps of at most this many pixels per launch (0: every pair)
 
 
 def conv_pair(call_a, call_b):
@@ -669,6 +670,7 @@ def conv_pair(call_a, call_b):
     (xb, wb, geom_b, Nb, Ccb, wsnb, wscb, outb), kwb = call_b
     L = _lib.lib()
     if (PAIR_CONV and bytes(geom) == bytes(geom_b) and (N, Cc) == (Nb, Ccb) and N % 64 == 0
+            and (PAIR_MAX_PIXELS == 0 or geom.B * geom.OH * geom.OW <= PAIR_MAX_PIXELS)
             and winograd_takes(geom, N, Cc, kwa) and winograd_takes(geom, N, Cc, kwb)):
         a = _conv_args(xa, wa, geom, N, Cc, wsn, wsc, outa, pack=False, **kwa)
         b = _conv_args(xb, wb, geom, N, Cc, wsnb, wscb, outb, pack=False, **kwb)
