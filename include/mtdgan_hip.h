@@ -127,11 +127,13 @@ int mtd_winograd_weights(const mtd_wino_weight_desc* table_dev, const mtd_wino_w
 int mtd_conv_winograd_ok(const mtd_conv_args* a);
 size_t mtd_conv_winograd_ws_bytes(const mtd_conv_args* a);
 int mtd_conv_winograd(const mtd_conv_args* a, void* stream);
-/* Two convs of ONE shape in one launch (round 6): the mirror layers of the discriminator's pixel-level and restoration decoders
- * (networks.py:420-467: s_dconv{l}k / r_dconv{l}k).  a, b as for mtd_conv_winograd, each with its own operands and workspace
- * (mtd_conv_winograd_ws_bytes of either); same results as two calls of mtd_conv_winograd, bit for bit. */
-int mtd_conv_winograd_pair_ok(const mtd_conv_args* a, const mtd_conv_args* b);
-int mtd_conv_winograd_pair(const mtd_conv_args* a, const mtd_conv_args* b, void* stream);
+/* Two or three convs of ONE shape in one launch (round 6): the mirror layers of the discriminator's pixel-level and restoration
+ * decoders (networks.py:420-467: s_dconv{l}k / r_dconv{l}k) and the data gradients of one layer in backward passes that are advanced
+ * together.  a[0 .. count) as for mtd_conv_winograd, each with its own operands and workspace (mtd_conv_winograd_ws_bytes of any).
+ * The split of K is planned for the group's whole grid (1 / count of the slices per problem): the results equal single calls of
+ * mtd_conv_winograd up to the grouping of the K sum (a few 1e-6), bit for bit where neither splits K. */
+int mtd_conv_winograd_group_ok(const mtd_conv_args* a, int count);
+int mtd_conv_winograd_group(const mtd_conv_args* a, int count, void* stream);
 
 /* ---- Winograd F(3x3, 2x2) for the 4x4 / stride-2 / padding-1 layers (csrc/conv_wino_s2.h; arch/Ours/networks.py:185-215 down1..3:
  * Conv2d(k4, s2, p1) forward and its four-parity data gradient): the forward conv is a 2x2 stride-1 conv over the 4 C channels of

@@ -134,7 +134,7 @@ def _preload_torch_hip_runtime():
 
 
 RECORDER = None      # kernels.LaunchList: while a step is being recorded, the list every launch is appended to
-_NOT_LAUNCHES = ("_half_scale_ok", "_pair_ok", "_ws_bytes", "_blocks", "mtd_version", "_option", "mtd_lab_build", "mtd_prof_", "_override", "_bwd_ok", "_stamps", "_zmask_bytes", "_tail_ok", "_winograd_ok", "_winograd_s2_ok", "_weight_floats", "_kmap", "_plan_cfg", "_pair_ok", "_pair_mode", "_patch_w", "_f4_min_w", "_relu_add_ok")
+_NOT_LAUNCHES = ("_half_scale_ok", "_pair_ok", "_group_ok", "_ws_bytes", "_blocks", "mtd_version", "_option", "mtd_lab_build", "mtd_prof_", "_override", "_bwd_ok", "_stamps", "_zmask_bytes", "_tail_ok", "_winograd_ok", "_winograd_s2_ok", "_weight_floats", "_kmap", "_plan_cfg", "_pair_ok", "_pair_mode", "_patch_w", "_f4_min_w", "_relu_add_ok")
 
 
 class _RecordingLib:
@@ -279,8 +279,8 @@ def lib():
     sig("mtd_conv_winograd_f4_min_w", ci, ci)
     sig("mtd_conv_winograd_ws_bytes", sz, C.POINTER(ConvArgs))
     sig("mtd_conv_winograd", ci, C.POINTER(ConvArgs), vp)
-    sig("mtd_conv_winograd_pair_ok", ci, C.POINTER(ConvArgs), C.POINTER(ConvArgs))
-    sig("mtd_conv_winograd_pair", ci, C.POINTER(ConvArgs), C.POINTER(ConvArgs), vp)
+    sig("mtd_conv_winograd_group_ok", ci, C.POINTER(ConvArgs), ci)
+    sig("mtd_conv_winograd_group", ci, C.POINTER(ConvArgs), ci, vp)
     sig("mtd_winograd_s2_kmap", ci, C.POINTER(Geom), C.POINTER(C.c_int), C.POINTER(C.c_int))
     sig("mtd_winograd_s2_weights", ci, vp, vp, ci, vp)
     sig("mtd_conv_winograd_s2_ok", ci, C.POINTER(ConvArgs), ci)
@@ -307,7 +307,7 @@ EXPORTS = [
     "mtd_conv_c32_bwd_ok", "mtd_conv_c32_bwd_ws_bytes", "mtd_conv_c32_bwd",
     "mtd_spec_mix_zmask_bytes", "mtd_spec_mix_fwd4", "mtd_spec_mix_bwd4",
     "mtd_resfft_block_tail_ok", "mtd_resfft_block_tail", "mtd_conv_c32_bwd_irfft",
-    "mtd_winograd_weight_floats", "mtd_winograd_kmap", "mtd_winograd_weights", "mtd_conv_winograd_ok", "mtd_conv_winograd_ws_bytes", "mtd_conv_winograd", "mtd_conv_winograd_pair_ok", "mtd_conv_winograd_pair",
+    "mtd_winograd_weight_floats", "mtd_winograd_kmap", "mtd_winograd_weights", "mtd_conv_winograd_ok", "mtd_conv_winograd_ws_bytes", "mtd_conv_winograd", "mtd_conv_winograd_group_ok", "mtd_conv_winograd_group",
     "mtd_conv_wgrad_plan_cfg", "mtd_conv_winograd_patch_w", "mtd_conv_winograd_f4_min_w", "mtd_conv_relu_add_ok", "mtd_dropout_mask", "mtd_scale_by", "mtd_scalar_sums", "mtd_zero_multi", "mtd_checksum_multi",
     "mtd_set_option", "mtd_get_option", "mtd_lab_build",
     "mtd_winograd_s2_kmap", "mtd_winograd_s2_weights", "mtd_conv_winograd_s2_ok", "mtd_conv_winograd_s2_ws_bytes", "mtd_conv_winograd_s2",

@@ -589,20 +589,24 @@ __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_kernel(const Wino
     wino_conv_body<NB, LEAN, PX>(wp, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y, (int)gridDim.z);
 }
 
-// Round 6: TWO convs of one shape in one grid -- the mirror layers of the discriminator's pixel-level and restoration decoders
+// Round 6: TWO or THREE convs of one shape in one grid -- the mirror layers of the discriminator's pixel-level and restoration decoders
 // (networks.py:420-467: s_dconv{l}k and r_dconv{l}k have the same channels on the same map; their inputs, weights and epilogue operands
 // differ).  On the 2x2 ... 8x8 maps a single layer fills a fraction of the chip even with its split of K; two of them in one launch are
 // twice the workgroups for one launch latency (and one slab-sum launch for both).  grid.z = 2 x the split of K: the first half of it
 // is problem 0.  (A branch per problem, not an index: a dynamic index into the kernel arguments would put them in scratch.)
-struct WinoMulti { WinoParams p[2]; };
+constexpr int WINO_MULTI_MAX = 3;
+struct WinoMulti { WinoParams p[WINO_MULTI_MAX]; int count; };
 
 template <int NB, bool LEAN = false, int PX = 4>
 __global__ __launch_bounds__(512, LEAN ? 4 : 1) void wino_conv_multi_kernel(const WinoMulti mp) {
-    const int gz = (int)gridDim.z >> 1;
-    const int set = __builtin_amdgcn_readfirstlane((int)blockIdx.z >= gz ? 1 : 0);
+    const int gz = (int)gridDim.z / mp.count;                  // grid.z = count x the split of K: problem s owns [s gz, (s + 1) gz)
+    const int set = __builtin_amdgcn_readfirstlane((int)blockIdx.z / gz);
     const int bz = (int)blockIdx.z - set * gz;
-    if (set == 0) wino_conv_body<NB, LEAN, PX>(mp.p[0], (int)blockIdx.x, (int)blockIdx.y, bz, (int)gridDim.x, (int)gridDim.y, gz);
-    else wino_conv_body<NB, LEAN, PX>(mp.p[1], (int)blockIdx.x, (int)blockIdx.y, bz, (int)gridDim.x, (int)gridDim.y, gz);
+    switch (set) {
+        case 0: wino_conv_body<NB, LEAN, PX>(mp.p[0], (int)blockIdx.x, (int)blockIdx.y, bz, (int)gridDim.x, (int)gridDim.y, gz); break;
+        case 1: wino_conv_body<NB, LEAN, PX>(mp.p[1], (int)blockIdx.x, (int)blockIdx.y, bz, (int)gridDim.x, (int)gridDim.y, gz); break;
+        default: wino_conv_body<NB, LEAN, PX>(mp.p[2], (int)blockIdx.x, (int)blockIdx.y, bz, (int)gridDim.x, (int)gridDim.y, gz); break;
+    }
 }
 
 #include "conv_wino_c32.h"
@@ -652,7 +656,7 @@ int wino_patch_w(const mtd_conv_args& a) {
     return pxw | ((mtd_option(MTD_OPT_WINO_SPLIT) && (a.N % 64) == 0) ? 16 : 0);
 }
 
-WinoPlan wino_plan(const mtd_conv_args& a, int pxcode) {
+WinoPlan wino_plan(const mtd_conv_args& a, int pxcode, int sets = 1) {
     WinoPlan pl{};
     const int px = pxcode & 15;
     const bool split3 = (pxcode & 16) != 0;
@@ -687,7 +691,9 @@ WinoPlan wino_plan(const mtd_conv_args& a, int pxcode) {
     // grids of 64 ... 128 workgroups -- gain more from the second half of the chip than the extra slab costs: 27.45 -> 27.33 ms in four A/B
     // pairs (1: 27.37 / 27.44, 3: 27.42 / 27.40; a cap on the split or a target of 384 / 512 workgroups loses 0.4 ... 1.8 ms)
     static const int env_sk_steps = [] { const char* e = mtd_lab_env("MTD_WINO_SPLITK_MINSTEPS"); return e ? atoi(e) : 2; }();
-    int sk = blocks <= 128 ? (int)(256 / blocks) : 1;
+    // (sets > 1: the group form.s grid holds that many problems and the split of K is planned for the whole grid: wino_group_sets)
+    const long long grid_blocks = blocks * sets;
+    int sk = grid_blocks <= 128 ? (int)(256 / grid_blocks) : 1;
     if (sk > chunks / env_sk_steps) sk = chunks / env_sk_steps;
     if (sk > 16) sk = 16;
     if (sk < 1) sk = 1;
@@ -916,41 +922,58 @@ extern "C" int mtd_conv_winograd(const mtd_conv_args* a, void* stream) {
     return MTD_OK;
 }
 
-// ---- two convs of one shape in ONE launch (wino_conv_multi_kernel): a[0], a[1] as for mtd_conv_winograd, same geometry, N, C,
-// pixel strides of the weights' form; inputs, weights, outputs, epilogue operands and workspaces their own.  The general fp32 kernels
-// only (not the persistent 32-channel kernel, not the split-bf16 form): mtd_conv_winograd_pair_ok says whether a pair qualifies.
-extern "C" int mtd_conv_winograd_pair_ok(const mtd_conv_args* a, const mtd_conv_args* b) {
-    if (!mtd_conv_winograd_ok(a) || !mtd_conv_winograd_ok(b)) return 0;
-    if (__builtin_memcmp(&a->g, &b->g, sizeof(mtd_geom)) != 0 || a->N != b->N || a->C != b->C) return 0;
-    const int pxa = wino_args_px(*a), pxb = wino_args_px(*b);
-    if (pxa != pxb || (pxa & 16) || (a->N % 64)) return 0;
-    if (wino_c32_takes(*a, pxa) || wino_c32_takes(*b, pxb)) return 0;
-    if (!aligned16(a->w) || !aligned16(b->w)) return 0;
-    if ((pxa & 15) == 6 && (a->g.OW % 4)) return 0;
-    // the two problems' slab sums go through ONE launch of the 16-byte epilogue: both need it (else: two single launches)
-    const long long M = geom_pixels(a->g);
-    if (wino_plan(*a, pxa).splitk > 1 && !(splitk_vec_ok(*a, M) && splitk_vec_ok(*b, M))) return 0;
+// ---- two or three convs of one shape in ONE launch (wino_conv_multi_kernel): a[0 .. count) as for mtd_conv_winograd, same geometry, N,
+// C and weight form; inputs, weights, outputs, epilogue operands and workspaces their own.  The general fp32 kernels only (not the
+// persistent 32-channel kernel, not the split-bf16 form): mtd_conv_winograd_group_ok says whether a group qualifies.
+// The group's split of K is planned for the WHOLE grid (count problems: 1 / count of the slices per problem of a single launch -- fewer
+// slabs, and another grouping of the K sum: a group equals single launches up to rounding, a few 1e-6).  Measured in the step for pairs
+// against a plan per problem: 26.15 -> 25.80 ms (three A/B pairs; planning for 3 or 4 problems' worth of grid: +0.2 ms).
+// Lab: MTD_WINO_PAIR_SPLIT = n plans every group as if it held n problems (1: per problem).
+static int wino_group_sets(int count) {
+    static const int v = [] { const char* e = mtd_lab_env("MTD_WINO_PAIR_SPLIT"); return (e && atoi(e) > 0) ? atoi(e) : 0; }();
+    return v > 0 ? v : count;
+}
+
+extern "C" int mtd_conv_winograd_group_ok(const mtd_conv_args* a, int count) {
+    if (!a || count < 2 || count > WINO_MULTI_MAX) return 0;
+    const int px = wino_args_px(a[0]);
+    const long long M = geom_pixels(a[0].g);
+    for (int i = 0; i < count; ++i) {
+        if (!mtd_conv_winograd_ok(&a[i])) return 0;
+        if (__builtin_memcmp(&a[0].g, &a[i].g, sizeof(mtd_geom)) != 0 || a[0].N != a[i].N || a[0].C != a[i].C) return 0;
+        if (wino_args_px(a[i]) != px || wino_c32_takes(a[i], px) || !aligned16(a[i].w)) return 0;
+    }
+    if ((px & 16) || (a[0].N % 64)) return 0;
+    if ((px & 15) == 6 && (a[0].g.OW % 4)) return 0;
+    const WinoPlan pl = wino_plan(a[0], px, wino_group_sets(count));
+    if ((px & 15) == 6 && pl.nb != 2) return 0;
+    // the problems' slab sums go through ONE launch of the 16-byte epilogue: all need it (else: single launches)
+    if (pl.splitk > 1)
+        for (int i = 0; i < count; ++i)
+            if (!splitk_vec_ok(a[i], M)) return 0;
     return 1;
 }
 
-extern "C" int mtd_conv_winograd_pair(const mtd_conv_args* a, const mtd_conv_args* b, void* stream) {
-    if (!mtd_conv_winograd_pair_ok(a, b)) return MTD_EINVAL;
-    const int pxcode = wino_args_px(*a);
+extern "C" int mtd_conv_winograd_group(const mtd_conv_args* a, int count, void* stream) {
+    if (!mtd_conv_winograd_group_ok(a, count)) return MTD_EINVAL;
+    const int pxcode = wino_args_px(a[0]);
     const int px = pxcode & 15;
-    const WinoPlan pl = wino_plan(*a, pxcode);
+    const WinoPlan pl = wino_plan(a[0], pxcode, wino_group_sets(count));
     WinoMulti mp;
-    int rc = wino_fill(a, pl, pxcode, mp.p[0]);
-    if (rc == MTD_OK) rc = wino_fill(b, pl, pxcode, mp.p[1]);
-    if (rc != MTD_OK) return rc;
-    mp.p[1].xcd_order = mp.p[0].xcd_order;
+    mp.count = count;
+    double bytes = 0.0;
+    for (int i = 0; i < WINO_MULTI_MAX; ++i) {
+        const int rc = wino_fill(&a[i < count ? i : 0], pl, pxcode, mp.p[i]);
+        if (rc != MTD_OK) return rc;
+        mp.p[i].xcd_order = mp.p[0].xcd_order;
+        if (i < count) bytes += algorithmic_bytes(&a[i]);
+    }
     const IgemmParams& p = mp.p[0].p;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((mp.p[0].ntiles + WT - 1) / WT, a->N / (32 * pl.nb), 2 * pl.splitk);
+    const dim3 grid((mp.p[0].ntiles + WT - 1) / WT, a[0].N / (32 * pl.nb), count * pl.splitk);
     // (profiler ids 34-37: wino_conv_multi_kernel<2, false, 6>, <2, false, 4>, <4, false, 4>, <2, true, 4>)
-    const int prof = mtd_prof_begin(0, px == 6 ? 34 : (pl.nb == 4 ? 36 : (pl.lean ? 37 : 35)), pl.splitk, 2ll * p.M, a->N, a->C, 9, s,
-                                    algorithmic_bytes(a) + algorithmic_bytes(b));
-    if (px == 6 && pl.nb == 2) MTD_LAUNCH((wino_conv_multi_kernel<2, false, 6>), grid, dim3(512), 0, s, mp);
-    else if (px == 6) { mtd_prof_end(prof, s); return MTD_EINVAL; }
+    const int prof = mtd_prof_begin(0, px == 6 ? 34 : (pl.nb == 4 ? 36 : (pl.lean ? 37 : 35)), pl.splitk, (long long)count * p.M, a[0].N, a[0].C, 9, s, bytes);
+    if (px == 6) MTD_LAUNCH((wino_conv_multi_kernel<2, false, 6>), grid, dim3(512), 0, s, mp);
     else if (pl.nb == 4) MTD_LAUNCH((wino_conv_multi_kernel<4>), grid, dim3(512), 0, s, mp);
     else if (pl.lean) MTD_LAUNCH((wino_conv_multi_kernel<2, true>), grid, dim3(512), 0, s, mp);
     else MTD_LAUNCH((wino_conv_multi_kernel<2>), grid, dim3(512), 0, s, mp);
@@ -958,13 +981,11 @@ extern "C" int mtd_conv_winograd_pair(const mtd_conv_args* a, const mtd_conv_arg
     MTD_LAUNCH_CHECK();
     if (pl.splitk > 1) {
         IgemmMulti em;
-        em.p[0] = mp.p[0].p;
-        em.p[1] = mp.p[1].p;
-        em.p[2] = em.p[3] = mp.p[0].p;                           // (unused rows of the grid: blockIdx.y < 2)
-        const long long total = (long long)p.M * a->N;
+        for (int i = 0; i < MULTI_MAX; ++i) em.p[i] = mp.p[i < count ? i : 0].p;      // (rows of the grid: blockIdx.y < count)
+        const long long total = (long long)p.M * a[0].N;
         int blocks = (int)((total / 4 + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_epilogue_multi_kernel, dim3(blocks, 2), dim3(256), 0, s, em);
+        hipLaunchKernelGGL(splitk_epilogue_multi_kernel, dim3(blocks, count), dim3(256), 0, s, em);
         MTD_LAUNCH_CHECK();
     }
     return MTD_OK;

@@ -453,38 +453,39 @@ def disc_backward(*args, **kw):
         return e.value
 
 
-LOCKSTEP = _options.lab("MTD_LOCKSTEP_PASSES", "1") != "0"
+# 0: one pass after the other; 1: the adversarial and the first consistency pass advanced together (the default); 3 (lab): the
+# restoration pass with them -- measured on one box (three rounds): 26.21 / 25.90 / 26.16 ms: groups of three give most of the pairs' gain back
+LOCKSTEP = int(_options.lab("MTD_LOCKSTEP_PASSES", "1"))
 
 
-def disc_backward_lockstep(pass_a, pass_b):
-    """TWO independent backward passes of one structure (the adversarial pass over tape 1+2 and the consistency pass over tape 3+4:
-    the same heads, decoder and trunk, different tapes and cotangents) advanced together: where both are about to issue the data
-    gradient of the same layer, the two go out as ONE launch (kernels.conv_pair: same weights, two problems in one grid) -- on the
-    4x4 ... 1x1 levels a single pass's launches fill a fraction of the chip.  Everything else each pass issues is issued in that pass's
-    own order, pass a's first; every result equals the two passes run one after the other, bit for bit (their raw weight gradients
-    go to separate temps: lane).  pass_x = (args, keywords) of disc_backward.  Returns both input gradients."""
-    ga = _disc_backward_gen(*pass_a[0], **dict(pass_a[1], lane=0))
-    gb = _disc_backward_gen(*pass_b[0], **dict(pass_b[1], lane=1))
-    res = [None, None]
+def disc_backward_lockstep(passes):
+    """Two or three independent backward passes of one structure (the adversarial and the restoration pass over tape 1+2 and the first
+    consistency pass over tape 3+4: a decoder -- the two decoders are mirrors --, heads and the trunk, different tapes and cotangents)
+    advanced together: where all are about to issue the data gradient of the same layer, those go out as ONE launch
+    (kernels.conv_group: same shape, two or three problems in one grid) -- on the 4x4 ... 1x1 levels a single pass's launches fill a
+    fraction of the chip.  Everything else each pass issues is issued in that pass's own order, the first pass's first; every buffer two
+    passes add into sees them in the order of the list.  Results equal the passes run one after the other up to the group launches'
+    grouping of their K sums (their raw weight gradients go to separate temps: lane).  passes: list of (args, keywords) of
+    disc_backward.  Returns the passes' input gradients."""
+    gens = [_disc_backward_gen(*a, **dict(kw, lane=i)) for i, (a, kw) in enumerate(passes)]
+    res = [None] * len(gens)
 
-    def step(i, g):
+    def step(i):
         try:
-            return next(g)
+            return next(gens[i])
         except StopIteration as e:
             res[i] = e.value
             return None
-    a, b = step(0, ga), step(1, gb)
-    while a is not None or b is not None:
-        if a is not None and b is not None:
-            K.conv_pair(a, b)            # (two launches where the pair does not qualify)
-            a, b = step(0, ga), step(1, gb)
-        elif a is not None:
-            K.conv(*a[0], **a[1])
-            a = step(0, ga)
+    cur = [step(i) for i in range(len(gens))]
+    while any(c is not None for c in cur):
+        live = [i for i, c in enumerate(cur) if c is not None]
+        if len(live) >= 2:
+            K.conv_group([cur[i] for i in live])      # (single launches where the group does not qualify)
         else:
-            K.conv(*b[0], **b[1])
-            b = step(1, gb)
-    return res[0], res[1]
+            K.conv(*cur[live[0]][0], **cur[live[0]][1])
+        for i in live:
+            cur[i] = step(i)
+    return res
 
 
 def _disc_backward_gen(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, dec_export=None, dec_import=None, flush=None,

@@ -663,43 +663,54 @@ PAIR_MAX_PIXELS = int(_options.lab("MTD_PAIR_MAX_PIXELS", "0"))      # lab: pair
 
 
 def conv_pair(call_a, call_b):
-    """Two conv() calls of ONE shape -- the mirror layers of the discriminator's two decoders -- as one launch where both go to
-    the general Winograd kernels (mtd_conv_winograd_pair); two launches otherwise.  call = (args tuple, keyword dict) as conv()
-    takes them.  Same results as two conv() calls, bit for bit."""
-    (xa, wa, geom, N, Cc, wsn, wsc, outa), kwa = call_a
-    (xb, wb, geom_b, Nb, Ccb, wsnb, wscb, outb), kwb = call_b
+    """conv_group of two."""
+    conv_group([call_a, call_b])
+
+
+def conv_group(calls):
+    """Two or three conv() calls of ONE shape -- the mirror layers of the discriminator's two decoders, or the data gradients of one
+    layer in backward passes that are advanced together -- as one launch where all go to the general Winograd kernels
+    (mtd_conv_winograd_group); single launches otherwise.  calls: list of (args tuple, keyword dict) as conv() takes them.  Same
+    results as single conv() calls up to the grouping of the K sum (the group's split of K is planned for its whole grid)."""
+    (x0, w0, geom, N, Cc, _wsn, _wsc, _o0), _kw0 = calls[0]
     L = _lib.lib()
-    if (PAIR_CONV and bytes(geom) == bytes(geom_b) and (N, Cc) == (Nb, Ccb) and N % 64 == 0
-            and (PAIR_MAX_PIXELS == 0 or geom.B * geom.OH * geom.OW <= PAIR_MAX_PIXELS)
-            and winograd_takes(geom, N, Cc, kwa) and winograd_takes(geom, N, Cc, kwb)):
-        a = _conv_args(xa, wa, geom, N, Cc, wsn, wsc, outa, pack=False, **kwa)
-        b = _conv_args(xb, wb, geom, N, Cc, wsnb, wscb, outb, pack=False, **kwb)
-        if L.mtd_conv_winograd_ok(C.byref(a)) and L.mtd_conv_winograd_ok(C.byref(b)):
-            wva, px = winograd_weight_view(wa, N, Cc, wsn, wsc, geom)
-            wvb, pxb = winograd_weight_view(wb, N, Cc, wsnb, wscb, geom)
-            a.w, a.w_st, b.w, b.w_st = wva.data_ptr(), px, wvb.data_ptr(), pxb
+    n = len(calls)
+    same = all(bytes(c[0][2]) == bytes(geom) and (c[0][3], c[0][4]) == (N, Cc) for c in calls[1:])
+    if (PAIR_CONV and 2 <= n <= 3 and same and N % 64 == 0 and (PAIR_MAX_PIXELS == 0 or geom.B * geom.OH * geom.OW <= PAIR_MAX_PIXELS)
+            and all(winograd_takes(geom, N, Cc, c[1]) for c in calls)):
+        arr = (ConvArgs * n)(*[_conv_args(*c[0], pack=False, **c[1]) for c in calls])
+        if all(L.mtd_conv_winograd_ok(C.byref(arr[i])) for i in range(n)):
+            px = 0
+            for i, (args, _kw) in enumerate(calls):
+                wv, px = winograd_weight_view(args[1], N, Cc, args[5], args[6], geom)
+                arr[i].w, arr[i].w_st = wv.data_ptr(), px
             wkey = ("wino", bytes(geom), N, Cc)
             need = _igemm_ws_cache.get(wkey)
             if need is None:
-                need = L.mtd_conv_winograd_ws_bytes(C.byref(a))
+                need = L.mtd_conv_winograd_ws_bytes(C.byref(arr[0]))
                 _igemm_ws_cache[wkey] = need
             if need:
                 need = (need + 255) & ~255
-                ws = workspace(2 * need, xa.device)
-                a.ws, a.ws_bytes, b.ws, b.ws_bytes = ws.data_ptr(), need, ws.data_ptr() + need, need
-            if L.mtd_conv_winograd_pair_ok(C.byref(a), C.byref(b)):
-                if FLOP_COUNT is not None:      # (both _conv_args calls counted the direct form)
-                    saved = 2 * 2.0 * geom.B * geom.OH * geom.OW * N * Cc * (6 if (px & 15) == 6 else 5)
+                ws = workspace(n * need, x0.device)
+                for i in range(n):
+                    arr[i].ws, arr[i].ws_bytes = ws.data_ptr() + i * need, need
+            if L.mtd_conv_winograd_group_ok(arr, n):
+                if FLOP_COUNT is not None:      # (the _conv_args calls counted the direct form, one launch each)
+                    saved = n * 2.0 * geom.B * geom.OH * geom.OW * N * Cc * (6 if (px & 15) == 6 else 5)
                     FLOP_COUNT["conv_mfma"] -= saved
                     FLOP_COUNT["conv_winograd_saved"] = FLOP_COUNT.get("conv_winograd_saved", 0.0) + saved
-                    FLOP_COUNT["launches"] -= 1
-                check(L.mtd_conv_winograd_pair(C.byref(a), C.byref(b), stream_ptr()), "mtd_conv_winograd_pair")
+                    FLOP_COUNT["launches"] -= n - 1
+                check(L.mtd_conv_winograd_group(arr, n, stream_ptr()), "mtd_conv_winograd_group")
                 return
         if FLOP_COUNT is not None:              # (conv() below counts again)
-            FLOP_COUNT["conv_mfma"] -= 2 * 2.0 * geom.B * geom.OH * geom.OW * N * Cc * 9
-            FLOP_COUNT["launches"] -= 2
-    conv(*call_a[0], **kwa)
-    conv(*call_b[0], **kwb)
+            FLOP_COUNT["conv_mfma"] -= n * 2.0 * geom.B * geom.OH * geom.OW * N * Cc * 9
+            FLOP_COUNT["launches"] -= n
+    if n == 3 and PAIR_CONV and same:           # (a group of three that does not qualify: try the first two, the third by itself)
+        conv_group(calls[:2])
+        conv(*calls[2][0], **calls[2][1])
+        return
+    for args, kw in calls:
+        conv(*args, **kw)
 
 
 def conv_relu_add_ok(x, w, geom, N, Cc, w_sn, w_sc, out, **kw):

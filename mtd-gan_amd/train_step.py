@@ -188,12 +188,17 @@ class DStepTape:
             # The adversarial pass (tape 1+2) and the first consistency pass (tape 3+4) are independent and of one structure -- image-level
             # head, pixel-level decoder, trunk: they are advanced together and the data gradients of the same layer go out as ONE launch
             # (discriminator_path.disc_backward_lockstep).  Every buffer two passes add into sees them in the order of the sequential
-            # schedule (adversarial before consistency; the restoration pass touches none of those): same bits.
-            _none, gin34 = DP.disc_backward_lockstep(
-                ((rt, P, t12, G2["d_e"], G2["d_d"], None, sinks[0], False), dict(dec_export=exp_s, overwrite=first_write)),
-                ((rt, P, t34, G2["c3_e"], G2["c3_d"], None, sink_c, True), dict(overwrite=first_write | dec_first["s"])))
-            self._sync_task(dp, S, 0)
-            restoration()                                                                    # task 1
+            # schedule (adversarial before consistency; the restoration pass touches none of those).
+            p_adv = ((rt, P, t12, G2["d_e"], G2["d_d"], None, sinks[0], False), dict(dec_export=exp_s, overwrite=first_write))
+            p_rest = ((rt, P, t12, None, None, G2["r_r"], sinks[1], False), dict(dec_export=exp_r, overwrite=first_write))
+            p_c34 = ((rt, P, t34, G2["c3_e"], G2["c3_d"], None, sink_c, True), dict(overwrite=first_write | dec_first["s"]))
+            if DP.LOCKSTEP == 3:      # (lab: all three; groups of three launches gave most of the pairs' gain back)
+                _n0, _n1, gin34 = DP.disc_backward_lockstep([p_adv, p_rest, p_c34])
+                self._sync_task(dp, S, 0)
+            else:
+                _n0, gin34 = DP.disc_backward_lockstep([p_adv, p_c34])
+                self._sync_task(dp, S, 0)
+                restoration()                                                                # task 1
             self._sync_task(dp, S, 1)
             consistency12(gin34, ship if dp is not None and EARLY_SHIP else None)            # task 2, second half
         else:

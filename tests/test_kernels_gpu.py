@@ -855,38 +855,41 @@ def test_winograd_32_channel_masked_two_output_form(hip_lib, monkeypatch, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nprob", [2, 3])
 @pytest.mark.parametrize("case", [(64, 1024, 512, 2, "fwd"), (64, 512, 512, 4, "fwd"), (64, 1024, 256, 8, "fwd"), (64, 256, 256, 16, "dgrad"),
                                   (64, 512, 1024, 4, "dgrad"), (64, 128, 128, 32, "dgrad"), (32, 64, 64, 64, "fwd"), (64, 128, 1, 64, "fwd")])
-def test_conv_pair_equals_two_launches_bit_for_bit(hip_lib, monkeypatch, case):
+def test_conv_pair_equals_two_launches(hip_lib, monkeypatch, case, nprob):
     """kernels.conv_pair / mtd_conv_winograd_pair (round 6): two convs of one shape -- the mirror layers of the discriminator's two
-    decoders -- in ONE launch of wino_conv_multi_kernel (+ one slab-sum launch for both) against two conv() calls: the same bits, for
-    the forward form (bias, LeakyReLU, per-half 1/sigma) and the data-gradient form (mask, two scales); every split of K the plan picks
-    from the 2x2 to the 64x64 maps; the last case (one output channel) is not a Winograd layer: conv_pair falls back to two launches."""
+    decoders -- in ONE launch of wino_conv_multi_kernel (+ one slab-sum launch for both) against two conv() calls, for the forward form
+    (bias, LeakyReLU, per-half 1/sigma) and the data-gradient form (mask, two scales), from the 2x2 to the 64x64 maps.  The pair's
+    split of K is planned for its whole grid (half the slices per problem): the same products in another grouping of the K sum -- equal
+    to the single launches within 1e-5 of the tensor's largest element (1e-4 under the element-wise measure of tests/_metrics.py; K up to 9 216 products), bit for bit where neither splits K; the pair itself is
+    repeatable.  The last case (one output channel) is not a Winograd layer: conv_pair falls back to two launches."""
     from mtd_gan_amd import kernels as K
     B, Ci, Co, H, what = case
     gen = torch.Generator().manual_seed(53)
     sc = [torch.tensor([0.8], device="cuda"), torch.tensor([1.3], device="cuda")]
     calls, outs = [], {}
-    for form in ("pair", "single"):
+    for form in ("pair", "pair again", "single"):
         gen.manual_seed(53)
         lst = []
-        for i in range(2):
+        for i in range(nprob):
             x = torch.randn(B, H, H, Ci, generator=gen).cuda()
             w = (torch.randn(Co, Ci, 3, 3, generator=gen) * (9 * Ci) ** -0.5).cuda()
             out = torch.full((B, H, H, Co), float("nan"), device="cuda")
             if what == "fwd":
                 bias = torch.randn(Co, generator=gen).cuda()
                 lst.append(((x, w, K.geom_fwd(B, H, H, 3, 1, 1), Co, Ci, Ci * 9, 9, out),
-                            dict(bias=bias, act=K.ACT_LRELU, scale=sc[i], scale2=sc[1 - i], scale_split=(B // 2) * H * H)))
+                            dict(bias=bias, act=K.ACT_LRELU, scale=sc[i % 2], scale2=sc[1 - i % 2], scale_split=(B // 2) * H * H)))
             else:
                 mask = torch.randn(B, H, H, Co, generator=gen).cuda()
                 wt = (torch.randn(Ci, Co, 3, 3, generator=gen) * (9 * Ci) ** -0.5).cuda()       # the layer's OIHW weight: Ci outputs, Co inputs
                 lst.append(((x, wt, K.geom_dgrad_s1(B, H, H, 3, 1), Co, Ci, 9, Co * 9, out),
-                            dict(add1=None, mask=mask, mask_slope=0.2, scale=sc[i], scale2=sc[1 - i], scale_split=(B // 2) * H * H)))
+                            dict(add1=None, mask=mask, mask_slope=0.2, scale=sc[i % 2], scale2=sc[1 - i % 2], scale_split=(B // 2) * H * H)))
         K.FLOP_COUNT = {}
         try:
-            if form == "pair":
-                K.conv_pair(lst[0], lst[1])
+            if form != "single":
+                K.conv_group(lst)                  # (two or three problems: kernels.conv_pair is the group of two)
             else:
                 for args, kw in lst:
                     K.conv(*args, **kw)
@@ -894,11 +897,14 @@ def test_conv_pair_equals_two_launches_bit_for_bit(hip_lib, monkeypatch, case):
             fc, K.FLOP_COUNT = K.FLOP_COUNT, None
         torch.cuda.synchronize()
         outs[form] = ([c[0][7] for c in lst], fc)
-    for a, b in zip(outs["pair"][0], outs["single"][0]):
-        assert not torch.isnan(a).any() and torch.equal(a, b)
+    for a, a2, b in zip(outs["pair"][0], outs["pair again"][0], outs["single"][0]):
+        assert not torch.isnan(a).any() and torch.equal(a, a2)
+        assert relerr(a.cpu(), b.cpu()) < 1e-4 and (a - b).abs().max().item() < 1e-5 * b.abs().max().item()
+        if B * H * H >= 131072:          # (a grid this large is not split either way: the very same sums)
+            assert torch.equal(a, b)
     # the pair is ONE launch where the layer is a Winograd layer (the accounting says so), two otherwise
-    assert outs["single"][1]["launches"] == 2
-    assert outs["pair"][1]["launches"] == (2 if Co == 1 else 1)
+    assert outs["single"][1]["launches"] == nprob
+    assert outs["pair"][1]["launches"] == (nprob if Co == 1 else 1)
     assert outs["pair"][1].get("conv_mfma", 0.0) == pytest.approx(outs["single"][1].get("conv_mfma", 0.0))
 
 

@@ -477,18 +477,19 @@ def test_first_pass_overwrites_task_vectors_same_bits(hip_lib, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("batch", [2, 32])
-def test_paired_launches_of_the_d_step_same_bits(hip_lib, monkeypatch, batch):
+def test_paired_launches_of_the_d_step_same_results(hip_lib, monkeypatch, batch):
     """Round 6: (a) the two decoders' mirror convs as pairs (discriminator_path.PAIR_DECODERS: forward pass over tape 1+2 and the second
     consistency pass), (b) the adversarial and the first consistency pass advanced together with the data gradients of the same layer
-    in one launch (LOCKSTEP: disc_backward_lockstep).  Both only change HOW MANY launches carry the same arithmetic: the losses, the
-    three task vectors and the task-specific gradients equal the one-launch-per-layer, one-pass-after-the-other schedule bit for bit,
-    at 2 patches (every deep layer below the merged-halves threshold) and at the BASELINE's 32."""
+    in one launch (LOCKSTEP: disc_backward_lockstep).  Both only change HOW MANY launches carry the same products (a pair launch plans
+    its split of K for the whole grid: another grouping of the K sums, 1e-6 per layer): the losses, the three task vectors and the
+    task-specific gradients against the one-launch-per-layer, one-pass-after-the-other schedule inside the parity bound (1e-3), at 2
+    patches and at the BASELINE's 32; and the schedule is repeatable bit for bit."""
     from mtd_gan_amd import discriminator_path as DPm
     from mtd_gan_amd.module.weight_methods import WeightMethods
     res = {}
-    for mode in ("plain", "pairs", "pairs+lockstep"):
+    for mode in ("plain", "pairs", "pairs+lockstep", "pairs+lockstep again"):
         monkeypatch.setattr(DPm, "PAIR_DECODERS", mode != "plain")
-        monkeypatch.setattr(DPm, "LOCKSTEP", mode == "pairs+lockstep")
+        monkeypatch.setattr(DPm, "LOCKSTEP", 1 if mode.startswith("pairs+lockstep") else 0)
         m, full, masks, z = _model(batch)
         m.Discriminator._inject_masks = [k.clone() for k in masks[:4]]
         x, y = orc.synthetic_ldct(batch, seed=1234)
@@ -504,9 +505,21 @@ def test_paired_launches_of_the_d_step_same_bits(hip_lib, monkeypatch, batch):
     l0, S0, ts0 = res["plain"]
     for mode in ("pairs", "pairs+lockstep"):
         l1, S1, ts1 = res[mode]
-        assert torch.equal(l0, l1), mode
-        assert torch.equal(S0, S1), mode
-        assert all(torch.equal(a, b) for a, b in zip(ts0, ts1)), mode
+        # (the forward pass's pairs move the losses by rounding; the gradients of the deep ReLU stacks amplify a layer's 1e-6 the way
+        # they amplify every fp32 rounding difference -- the reference's own fp32 path is 5e-3 from its float64 evaluation on the small
+        # deep-layer gradients: measured here 1.8e-4 under the element-wise measure at 32 patches, the parity bound is 1e-3)
+        assert rel(l1, l0) < 1e-5, (mode, rel(l1, l0))
+        for i in range(3):                      # each task vector against its own scale
+            assert rel(S1[i], S0[i]) < 1e-3, (mode, i, rel(S1[i], S0[i]))
+        # the task-specific gradients as ONE vector against its largest element (they are views of one bucket; some of its tensors have
+        # one to nine elements, each a cancelling sum over 10^5 pixels: their own relative error says nothing), and per tensor loosely
+        f0, f1 = torch.cat([t.reshape(-1) for t in ts0]).double(), torch.cat([t.reshape(-1) for t in ts1]).double()
+        assert (f1 - f0).abs().max().item() < 1e-4 * f0.abs().max().item(), (mode, (f1 - f0).abs().max().item(), f0.abs().max().item())
+        for a, b in zip(ts1, ts0):
+            assert (a.double() - b.double()).abs().max().item() <= 2e-2 * b.abs().max().item() + 1e-7 * f0.abs().max().item(), (mode, tuple(b.shape))
+    la, Sa, tsa = res["pairs+lockstep"]
+    lb, Sb, tsb = res["pairs+lockstep again"]
+    assert torch.equal(la, lb) and torch.equal(Sa, Sb) and all(torch.equal(a, b) for a, b in zip(tsa, tsb))
 
 
 @pytest.mark.gpu
