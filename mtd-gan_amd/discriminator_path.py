@@ -439,6 +439,7 @@ class GradSink:
 
 
 FLUSH_LEVEL = 4      # trunk levels 6 .. FLUSH_LEVEL + both bottleneck convs: 91 % of the shared parameters, done 60 % into the trunk
+FLUSH_STAGES = tuple(_options.lab("MTD_DP_SHIP_STAGES", "heads,trunk_low").split(","))      # lab: which of the two early-shipping points are live
 
 
 def disc_backward(*args, **kw):
@@ -640,7 +641,7 @@ def _disc_backward_gen(rt, P, tp, g_enc, g_dec, g_rec, sink, want_input_grad, de
         side.run(fix, fork=False)
 
     def flush_point(stage):
-        if flush is not None:
+        if flush is not None and stage in FLUSH_STAGES:
             sn_fix()
             flush(stage)
 
