@@ -299,3 +299,34 @@ def test_live_pmc_lookup_and_refusals(monkeypatch):
     monkeypatch.setattr(os.path, "exists", lambda p_, _e=os.path.exists: False if p_ == "/opt/rocm/bin/rocprofv3" else _e(p_))
     assert bench.live_pmc_collect("full_step") is None and not started
     assert bench.parse(["--no-live-pmc"]).no_live_pmc and not bench.parse([]).no_live_pmc
+
+
+def test_lockstep_driver_groups_aligned_launches(monkeypatch):
+    """discriminator_path.disc_backward / disc_backward_lockstep (round 6) without a GPU: a backward pass is a generator that hands out
+    its data-gradient launches; run by itself every launch is issued at once, in order; two or three passes advanced together send the
+    launches they hand out at the same step as ONE group (kernels.conv_group), a pass that has more to hand out than the others issues
+    the rest by itself, everything a pass issues on its own stays in that pass's order, and every pass's return value comes back."""
+    from mtd_gan_amd import discriminator_path as DPm
+    from mtd_gan_amd import kernels as K
+    log = []
+
+    def fake_gen(tag, n, lane=0, **_kw):
+        for i in range(n):
+            log.append(("own", tag, i))                # (what a pass issues itself between two hand-outs)
+            yield ((tag, i), {"lane": lane})
+        return "gin-" + tag
+    monkeypatch.setattr(DPm, "_disc_backward_gen", lambda tag, n, **kw: fake_gen(tag, n, **kw))
+    monkeypatch.setattr(K, "conv", lambda *a, **kw: log.append(("conv", a, kw["lane"])))
+    monkeypatch.setattr(K, "conv_group", lambda calls: log.append(("group", [c[0] for c in calls], [c[1]["lane"] for c in calls])))
+    assert DPm.disc_backward("a", 2) == "gin-a"
+    assert log == [("own", "a", 0), ("conv", ("a", 0), 0), ("own", "a", 1), ("conv", ("a", 1), 0)]
+    del log[:]
+    res = DPm.disc_backward_lockstep([(("a", 2), {}), (("b", 3), {})])
+    assert res == ["gin-a", "gin-b"]
+    assert [e for e in log if e[0] != "own"] == [("group", [("a", 0), ("b", 0)], [0, 1]), ("group", [("a", 1), ("b", 1)], [0, 1]),
+                                                  ("conv", ("b", 2), 1)]
+    assert [e for e in log if e[0] == "own" and e[1] == "b"] == [("own", "b", 0), ("own", "b", 1), ("own", "b", 2)]
+    del log[:]
+    res = DPm.disc_backward_lockstep([(("a", 1), {}), (("b", 1), {}), (("c", 2), {})])
+    assert res == ["gin-a", "gin-b", "gin-c"]
+    assert [e for e in log if e[0] != "own"] == [("group", [("a", 0), ("b", 0), ("c", 0)], [0, 1, 2]), ("conv", ("c", 1), 2)]
