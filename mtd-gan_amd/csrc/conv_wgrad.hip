@@ -949,6 +949,40 @@ __global__ __launch_bounds__(256) void wgrad_finish_scalar_kernel(const WgradPar
     }
 }
 
+// The two stages above in ONE launch for the thin layers (round 6: 25 launch pairs per step on the weight-gradient stream): thread
+// (element e = tid & 15, group g = tid >> 4) sums group g of element blockIdx.x * 16 + e, the sixteen group sums meet in LDS and are added
+// in group order -- the association of slab_group_sum_scalar_kernel followed by wgrad_finish_scalar_kernel, bit for bit.  nslab <= 16 gs.
+__global__ __launch_bounds__(256) void wgrad_finish_scalar2_kernel(const WgradParams p, const float* __restrict__ in, int nslab, long long stride_in, int gs) {
+    __shared__ float part[16][17];
+    const mtd_wgrad_args& a = p.a;
+    const mtd_geom& g = a.g;
+    const long long nw = (long long)p.T * a.N * a.C;
+    const long long count = nw + (a.db ? a.N : 0);
+    const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const long long idx = (long long)blockIdx.x * 16 + e;
+    const int ng = (nslab + gs - 1) / gs;
+    float s = 0.f;
+    if (idx < count && grp < ng) s = slab_sum1(in, stride_in, grp * gs, min(nslab, (grp + 1) * gs), idx);
+    part[grp][e] = s;
+    __syncthreads();
+    if (grp != 0 || idx >= count) return;
+    float t = 0.f;
+    for (int k = 0; k < ng; ++k) t += part[k][e];
+    if (idx < nw) {
+        int c = (int)(idx % a.C);
+        long long t2 = idx / a.C;
+        int n = (int)(t2 % a.N);
+        int tap = (int)(t2 / a.N);
+        int ty = tap / g.TW, tx = tap % g.TW;
+        int kidx = (g.ky0 + ty * g.ky_step) * g.KW + (g.kx0 + tx * g.kx_step);
+        float* dst = a.dw + (long long)n * a.w_sn + (long long)c * a.w_sc + kidx;
+        *dst = (a.accumulate & 1) ? (*dst + t) : t;
+    } else {
+        float* dst = a.db + (idx - nw);
+        *dst = (a.accumulate & 2) ? (*dst + t) : t;
+    }
+}
+
 // sum of slabs k0 .. k1-1 at float4 index i4, in slab order; the loads of eight slabs are in flight together (a plain
 // `for k: s += in[k]` loop of unknown length serialises one memory round trip per slab)
 __device__ __forceinline__ f32x4 slab_sum4(const float* __restrict__ in, long long stride_in, int k0, int k1, long long i4) {
@@ -1758,6 +1792,12 @@ static int wgrad_reduce_slabs_impl(const WgradParams& p, const float* cur, int n
         const int bx = (int)((units + 15) / 16);
         if (ns > 128) hipLaunchKernelGGL((wgrad_reduce_finish_kernel<8>), dim3(bx, dw2 ? 2 : 1), dim3(1024), 0, s, p, cur, ns, p.slab_stride, dw2);
         else hipLaunchKernelGGL((wgrad_reduce_finish_kernel<4>), dim3(bx, dw2 ? 2 : 1), dim3(256), 0, s, p, cur, ns, p.slab_stride, dw2);
+        MTD_LAUNCH_CHECK();
+        return MTD_OK;
+    }
+    static const int env_scalar2 = [] { const char* e = mtd_lab_env("MTD_WGRAD_SCALAR2"); return e ? atoi(e) : 1; }();
+    if (env_scalar2 && !vec && !dw2 && ns > GS && ns <= 16 * GS) {          // thin layers: both stages in one launch (same association)
+        hipLaunchKernelGGL(wgrad_finish_scalar2_kernel, dim3((unsigned)((count + 15) / 16)), dim3(256), 0, s, p, cur, ns, p.slab_stride, GS);
         MTD_LAUNCH_CHECK();
         return MTD_OK;
     }

@@ -459,7 +459,7 @@ def disc_backward(*args, **kw):
 LOCKSTEP = int(_options.lab("MTD_LOCKSTEP_PASSES", "1"))
 
 
-def disc_backward_lockstep(passes):
+def disc_backward_lockstep(passes, lead=0):
     """Two or three independent backward passes of one structure (the adversarial and the restoration pass over tape 1+2 and the first
     consistency pass over tape 3+4: a decoder -- the two decoders are mirrors --, heads and the trunk, different tapes and cotangents)
     advanced together: where all are about to issue the data gradient of the same layer, those go out as ONE launch
@@ -468,8 +468,11 @@ def disc_backward_lockstep(passes):
     passes add into sees them in the order of the list.  Results equal the passes run one after the other up to the group launches'
     grouping of their K sums (their raw weight gradients go to separate temps: lane).  passes: list of (args, keywords) of
     disc_backward.  Returns the passes' input gradients."""
-    gens = [_disc_backward_gen(*a, **dict(kw, lane=i)) for i, (a, kw) in enumerate(passes)]
-    res = [None] * len(gens)
+    gens, res = [None] * len(passes), [None] * len(passes)
+
+    def start(i):          # (a pass may be given as a callable: its arguments are then built when it starts -- after `lead`, see below)
+        a, kw = passes[i]() if callable(passes[i]) else passes[i]
+        gens[i] = _disc_backward_gen(*a, **dict(kw, lane=i))
 
     def step(i):
         try:
@@ -477,7 +480,18 @@ def disc_backward_lockstep(passes):
         except StopIteration as e:
             res[i] = e.value
             return None
-    cur = [step(i) for i in range(len(gens))]
+    # lead: the FIRST pass issues its first `lead` hand-outs by itself before the other passes start -- they may read what it leaves
+    # behind (the restoration pass's decoder cotangents, which the second consistency pass sums into its decoder weight gradients)
+    start(0)
+    first = step(0)
+    for _ in range(lead):
+        if first is None:
+            break
+        K.conv(*first[0], **first[1])
+        first = step(0)
+    for i in range(1, len(passes)):
+        start(i)
+    cur = [first] + [step(i) for i in range(1, len(passes))]
     while any(c is not None for c in cur):
         live = [i for i, c in enumerate(cur) if c is not None]
         if len(live) >= 2:

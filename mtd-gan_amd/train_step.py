@@ -195,12 +195,23 @@ class DStepTape:
             if DP.LOCKSTEP == 3:      # (lab: all three; groups of three launches gave most of the pairs' gain back)
                 _n0, _n1, gin34 = DP.disc_backward_lockstep([p_adv, p_rest, p_c34])
                 self._sync_task(dp, S, 0)
+            elif DP.LOCKSTEP == 2:
+                # (lab: the restoration pass and the TRUNK of the second consistency pass too -- the restoration pass goes through its decoder
+                # first, alone: the other pass sums its decoder cotangents)
+                _n0, gin34 = DP.disc_backward_lockstep([p_adv, p_c34])
+                self._sync_task(dp, S, 0)
+                fl = ship if dp is not None and EARLY_SHIP else None
+                DP.disc_backward_lockstep([p_rest, lambda: ((rt, P, t12, G2["c_e"], G2["c_d"], K.clip01_bwd(gin34, r12), sink_c, False),
+                                                            dict(dec_import={**exp_s, **exp_r}, flush=fl, overwrite=dec_first["r"]))], lead=12)      # (12 = the 3x3 layers of its decoder)
+                self._sync_task(dp, S, 1)
+                gin34 = None
             else:
                 _n0, gin34 = DP.disc_backward_lockstep([p_adv, p_c34])
                 self._sync_task(dp, S, 0)
                 restoration()                                                                # task 1
-            self._sync_task(dp, S, 1)
-            consistency12(gin34, ship if dp is not None and EARLY_SHIP else None)            # task 2, second half
+            if DP.LOCKSTEP != 2:
+                self._sync_task(dp, S, 1)
+                consistency12(gin34, ship if dp is not None and EARLY_SHIP else None)        # task 2, second half
         else:
             adversarial()                                                                    # task 0
             self._sync_task(dp, S, 0)

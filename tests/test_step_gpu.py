@@ -487,9 +487,9 @@ def test_paired_launches_of_the_d_step_same_results(hip_lib, monkeypatch, batch)
     from mtd_gan_amd import discriminator_path as DPm
     from mtd_gan_amd.module.weight_methods import WeightMethods
     res = {}
-    for mode in ("plain", "pairs", "pairs+lockstep", "pairs+lockstep again", "pairs+three passes"):
+    for mode in ("plain", "pairs", "pairs+lockstep", "pairs+lockstep again", "pairs+three passes", "pairs+two groups"):
         monkeypatch.setattr(DPm, "PAIR_DECODERS", mode != "plain")
-        monkeypatch.setattr(DPm, "LOCKSTEP", 1 if mode.startswith("pairs+lockstep") else (3 if mode == "pairs+three passes" else 0))
+        monkeypatch.setattr(DPm, "LOCKSTEP", 1 if mode.startswith("pairs+lockstep") else {"pairs+three passes": 3, "pairs+two groups": 2}.get(mode, 0))
         m, full, masks, z = _model(batch)
         m.Discriminator._inject_masks = [k.clone() for k in masks[:4]]
         x, y = orc.synthetic_ldct(batch, seed=1234)
@@ -503,7 +503,7 @@ def test_paired_launches_of_the_d_step_same_results(hip_lib, monkeypatch, batch)
         torch.cuda.synchronize()
         res[mode] = (losses.detach().clone(), tape.task_vectors.clone(), [p.grad.clone() for p in D.task_specific_parameters()])
     l0, S0, ts0 = res["plain"]
-    for mode in ("pairs", "pairs+lockstep", "pairs+three passes"):      # (three passes: the lab option, groups of three launches)
+    for mode in ("pairs", "pairs+lockstep", "pairs+three passes", "pairs+two groups"):      # (three passes / two groups: lab options)
         l1, S1, ts1 = res[mode]
         # (the forward pass's pairs move the losses by rounding; the gradients of the deep ReLU stacks amplify a layer's 1e-6 the way
         # they amplify every fp32 rounding difference -- the reference's own fp32 path is 5e-3 from its float64 evaluation on the small
