@@ -1168,7 +1168,15 @@ WPlan make_wplan(const mtd_wgrad_args& a, const int g_wplan_div = 1) {
     if (T == 1 && a.N % 64 == 0 && a.C % 64 == 0) pl.cfg = 2;
     else if (T <= 4) pl.cfg = 1;
     else if (T <= 9) pl.cfg = (M <= 2048) ? 4 : 0;              // few pixels, many tiles: 3 taps per wave, no pixel split
-    else pl.cfg = (M >= 2048 && a.N % 64 == 0 && a.C % 64 == 0) ? 2 : 4;
+    else {
+        // 4x4 taps (round 6, tools/wgrad_s2_small_probe.py: both halves of a paired pass are one launch now, so down4 has 1024 pixels
+        // and down5 256): 64 x 64 tiles with one tap each from 1024 pixels on (108 us against 140 for 32 x 32 tiles x 3 taps), 32 x 32
+        // tiles with one tap each up to 256 pixels (42 us against 51)
+        static const int env_t16 = [] { const char* e = mtd_lab_env("MTD_WGRAD_T16_PLAN"); return e ? atoi(e) : 1; }();      // (0: round 5's thresholds)
+        if (!env_t16) pl.cfg = (M >= 2048 && a.N % 64 == 0 && a.C % 64 == 0) ? 2 : 4;
+        else if (M >= 1024 && a.N % 64 == 0 && a.C % 64 == 0) pl.cfg = 2;
+        else pl.cfg = (M <= 256) ? 5 : 4;
+    }
     // Winograd F(2x2, 3x3) on ONE 32 x 32 block (conv_wgrad_wino32.h): the generator's 32 -> 32 layers on maps of at least
     // MTD_WGRAD_WINO32_MIN_HW pixels a side (where the row-window kernel is the plan otherwise).  cfg 19; ppw = chunks of 16 tiles per slice.
     static const int env_w32 = [] { const char* e = mtd_lab_env("MTD_WGRAD_WINO32"); return e ? atoi(e) : 1; }();
@@ -1214,7 +1222,7 @@ WPlan make_wplan(const mtd_wgrad_args& a, const int g_wplan_div = 1) {
             return pl;
         }
         pl = WPlan{};
-        pl.cfg = (M >= 2048 && a.N % 64 == 0 && a.C % 64 == 0) ? 2 : 4;
+        pl.cfg = (M >= 1024 && a.N % 64 == 0 && a.C % 64 == 0) ? 2 : ((M <= 256) ? 5 : 4);
     }
     static const int env_s2 = [] { const char* e = mtd_lab_env("MTD_WGRAD_S2"); return e ? atoi(e) : 1; }();
     if (a.g.TH == 4 && a.g.TW == 4 && a.g.in_sy == 2 && a.g.in_sx == 2 && a.g.off_y == -1 && a.g.off_x == -1 && a.g.tap_dy == 1 &&

@@ -330,3 +330,14 @@ def test_lockstep_driver_groups_aligned_launches(monkeypatch):
     res = DPm.disc_backward_lockstep([(("a", 1), {}), (("b", 1), {}), (("c", 2), {})])
     assert res == ["gin-a", "gin-b", "gin-c"]
     assert [e for e in log if e[0] != "own"] == [("group", [("a", 0), ("b", 0), ("c", 0)], [0, 1, 2]), ("conv", ("c", 1), 2)]
+    # lead: the first pass issues its first hand-outs by itself; a pass given as a callable is built only when it starts -- after them
+    del log[:]
+    built = []
+    res = DPm.disc_backward_lockstep([(("a", 3), {}), lambda: (built.append(len(log)) or (("b", 2), {}))], lead=2)
+    assert res == ["gin-a", "gin-b"]
+    assert [e for e in log if e[0] != "own"] == [("conv", ("a", 0), 0), ("conv", ("a", 1), 0), ("group", [("a", 2), ("b", 0)], [0, 1]),
+                                                  ("conv", ("b", 1), 1)]
+    assert built == [log.index(("own", "a", 2)) + 1]      # (built after the lead's launches and what the first pass issued behind them)
+    del log[:]
+    res = DPm.disc_backward_lockstep([(("a", 1), {}), (("b", 1), {})], lead=5)      # (a lead longer than the pass: it runs alone to its end)
+    assert res == ["gin-a", "gin-b"] and [e for e in log if e[0] != "own"] == [("conv", ("a", 0), 0), ("conv", ("b", 0), 1)]

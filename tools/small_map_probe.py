@@ -36,3 +36,34 @@ for B in (64, 32):
             finally:
                 K.igemm_override(-1, -1)
     print(row, flush=True)
+
+# ---- weight gradient of the 4x4 stride-2 layers on small maps under every plan the library can be forced to (mtd_conv_wgrad_override): us per call
+# (kernel + slab sums) and the result against the plan's; both halves of a paired pass in one launch = 64 images (down4: 8x8 -> 4x4, down5: 4x4 -> 2x2)
+from mtd_gan_amd import _lib
+L = _lib.lib()
+s1, s2 = torch.tensor([0.7], device="cuda"), torch.tensor([1.3], device="cuda")
+for (B, IH, N, Cc) in ((64, 8, 512, 512), (64, 4, 512, 512), (32, 8, 512, 512)):
+    OH = IH // 2
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, IH, IH, Cc, generator=g).cuda()
+    gy = torch.randn(B, OH, OH, N, generator=g).cuda()
+    dw = torch.empty(N, Cc, 4, 4, device="cuda"); db = torch.empty(N, device="cuda")
+    geom = K.geom_fwd(B, IH, IH, 4, 2, 1)
+    half = (s1, s2, (B // 2) * OH * OH)
+    call = lambda: K.wgrad(gy, x, geom, N, Cc, dw, Cc * 16, 16, db=db, half=half)
+    call(); torch.cuda.synchronize()
+    ref = dw.clone()
+    row = f"B={B} {IH}x{IH}->{OH}x{OH} M={B * OH * OH:5d}: plan {timed(call):6.1f} us"
+    for cfg in (0, 1, 2, 3, 4, 5, 6, 13):
+        for ns in ((-1, 2, 4) if cfg != 13 else (-1, 1, 2, 4, 8)):
+            L.mtd_conv_wgrad_override(cfg, ns)
+            try:
+                t = timed(call)
+                torch.cuda.synchronize()
+                err = ((dw - ref).abs().max() / ref.abs().max()).item()
+                row += f" | cfg{cfg} S={ns}: {t:5.1f}" + ("" if err < 1e-4 else f" (err {err:.1e})")
+            except Exception as e:
+                row += f" | cfg{cfg} S={ns}: refused"
+            finally:
+                L.mtd_conv_wgrad_override(-1, -1)
+    print(row, flush=True)
