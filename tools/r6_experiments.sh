@@ -271,4 +271,14 @@ python tools/trace_gaps.py $f --steps 4 --top 12 | tee $O/r6_concurrent_timeline
 find $O/prof_conc -name "*.db" -size +30M -delete
 }
 
+# round 6, end of round: the forced data-parallel line beside the plain one and the two-rank rehearsal at the final tree
+exp26() {
+for cfg in "MTD_FORCE_DP=0" "MTD_FORCE_DP=1" "MTD_FORCE_DP=0" "MTD_FORCE_DP=1"; do
+  env $cfg timeout -k 10 300 python bench.py --steps 30 --warmup 8 $NOX 2>/dev/null > $O/fdp_$cfg.json
+  python -c "
+import sys,json; z=json.loads(open('$O/fdp_$cfg.json').read().strip().splitlines()[-1]); print('[$cfg]', z['ms_per_step'], z.get('ms_per_step_collectives_stubbed'), z.get('comm_exposed_ms'), z.get('graph_error'))"
+done | tee $O/exp26_fdp.txt
+bash tools/dp_two_ranks.sh > $O/exp26_dp2.txt 2>&1; grep "dp2\|exit code" $O/exp26_dp2.txt | cut -c1-400
+}
+
 "$@"
