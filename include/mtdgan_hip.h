@@ -290,7 +290,9 @@ int mtd_irfft_rows(const float* T, float* out, int out_ld, const float* add1, in
 
 /* The same three steps for square maps of side S = 128, 256 or 512 (whole-slice inference, reference engine.py:89,129:
  * the generator runs on 512 x 512 images and rfft2 becomes a 512-point transform).  Forward only; spectra are
- * [B][kw 0..S/2][h 0..S-1][Re 32 | Im 32], ortho scaling 1/sqrt(S) per dimension. */
+ * [B][kw 0..S/2][h 0..S-1][Re 32 | Im 32], ortho scaling 1/sqrt(S) per dimension.  mtd_spec_mix_any writes zeros into the
+ * imaginary halves of columns 0 and S/2 of T: mtd_irfft_rows_any does not read them (torch's c2r ignores them too), and the two
+ * columns' real parts come out of one packed transform. */
 int mtd_rfft_rows_any(const float* x, int x_ld, float* R, int B, int S, void* stream);
 int mtd_spec_mix_any(const float* R, const float* w2t, const float* b2, float* T, int B, int S, void* stream);
 int mtd_irfft_rows_any(const float* T, float* out, int out_ld, const float* add1, int add1_ld, const float* add2,

@@ -17,6 +17,8 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ int brev_n(int k, int logS) { return (int)(__brev((unsigned)k) >> (32 - logS)); }
 
 // twiddle table exp(-i * pi * k / (S/2)), k = 0 .. S/2-1, written once per workgroup (cos | sin)
@@ -221,11 +223,25 @@ __global__ __launch_bounds__(NT) void rfft_rows_any_kernel(const float* __restri
 }
 
 // columns + channel mix + columns back: a column (b, kw) per step.  LDS rows are CLD = 33 floats apart (see the header).
+//
+// PACK (round 6): the columns kw = 0 and kw = S/2 of an image hold REAL sequences (the row transform of real data is real there:
+// rfft_rows_any_kernel writes exact zeros into their imaginary halves) and only the REAL part of their way back is ever used
+// (irfft_rows_any_kernel ignores the imaginary parts of columns 0 and S/2, as torch's c2r does) -- so the two go through ONE
+// complex transform each way, like the row pairs of the row kernels: z = x_0 + i x_{S/2}; after the forward transform
+// A[k] = (Z[k] + conj Z[-k]) / 2 and B[k] = (Z[k] - conj Z[-k]) / 2i are the two columns' spectra, both Hermitian, kept IN PLACE (A[k] in
+// row k, B[k] in row S - k, 0 < k < S/2; rows 0 and S/2 hold the real pairs (A, B) as they are); the mix of a row X gives
+// Y(X) = relu(W [Re X; Im X] + b) and Y(conj X) from the same two half sums P (real parts) and Q (imaginary parts) -- P + Q and P - Q --,
+// and what the way back needs is the Hermitian part (Y(X) + conj Y(conj X)) / 2 of the column, whose inverse transform is the real
+// part of the column's; the two Hermitian columns go back as U + i V in one transform, real part = column 0, imaginary part =
+// column S/2.  An image is then S/2 units instead of S/2 + 1: at S = 512 and 8 slices 2 048 units on 256 CUs are eight rounds,
+// 2 056 were nine (the ninth on eight CUs).  A packed unit costs the same MFMAs, two more passes over the column in LDS and two
+// 32 x 32 products on the vector ALU for rows 0 and S/2.  The imaginary halves of columns 0 and S/2 of T are written as zeros.
 constexpr int CLD = 34;        // even (8-byte transform accesses), 2-way bank conflicts for the MFMA operand reads along the frequency index
-template <int S, int NT>
+template <int S, int NT, bool PACK>
 __global__ __launch_bounds__(NT) void spec_mix_any_kernel(const float* __restrict__ R, const float* __restrict__ w2t,
                                                            const float* __restrict__ b2, float* __restrict__ T, int units) {
-    constexpr int logS = Log2<S>::v, NV = (S * 16 + NT - 1) / NT;
+    constexpr int logS = Log2<S>::v, NV = (S * 16 + NT - 1) / NT, nkw = S / 2 + 1;
+    static_assert(NT % 16 == 0, "a thread keeps its 16-byte part of a spectrum row over a unit");
 #ifdef MTD_ANY_EARLY      /* lab: how many of the next column's NV load vectors go out before the mix / before the forward transform */
     constexpr int EARLY = MTD_ANY_EARLY < NV ? MTD_ANY_EARLY : NV;
 #else
@@ -243,31 +259,79 @@ __global__ __launch_bounds__(NT) void spec_mix_any_kernel(const float* __restric
     float* wl = tw + S;                    // w2t [k 64][o 64] + bias [64]
     fill_twiddles(tw, S);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int part = tid & 15;             // which 16 bytes of a 256-byte spectrum row (Re 0..7 | Im 8..15) this thread moves
     for (int i = tid; i < 64 * 64 + 64; i += NT) wl[i] = i < 4096 ? w2t[i] : b2[i - 4096];
+    // unit u -> (image, column); PACK: S/2 units per image, column 0 standing for the pair (0, S/2), and the images' pairs rotated
+    // over the workgroups (with S/2 units per image and a grid of S/2 they would all be workgroup 0's)
+    auto unit_col = [&](int u, int& b) {
+        if (!PACK) { b = u / nkw; return u - b * nkw; }
+        b = u / (S / 2);
+        return (u - b * (S / 2) + b) & (S / 2 - 1);
+    };
+    // a unit's place in a spectrum buffer (uniform over the workgroup: a scalar base) and what this thread adds to its 4 q floats: a
+    // packed unit's imaginary parts (part >= 8) are the REAL halves of column S/2
+    constexpr int PDELTA = (S / 2) * S * 64 - 32;
+    auto unit_base = [&](int u, int& poff) -> long long {
+        int b;
+        const int kw = unit_col(u, b);
+        poff = (PACK && kw == 0 && part >= 8) ? PDELTA : 0;
+        return ((long long)(b * nkw + kw) * S) * 64;
+    };
     f32x4 v[NV];
-    auto issue = [&](int u, int j0, int j1) {
-        const float* src = R + (long long)u * S * 64;
+    auto issue = [&](int un, int j0, int j1) {
+        int poff;
+        const float* src = R + unit_base(un, poff);
 #pragma unroll
         for (int j = j0; j < j1; ++j) {
             const int q = tid + NT * j;
-            if (NV * NT == S * 16 || q < S * 16) v[j] = *reinterpret_cast<const f32x4*>(src + (long long)q * 4);
+            if (NV * NT == S * 16 || q < S * 16) v[j] = *reinterpret_cast<const f32x4*>(src + (q * 4 + poff));
         }
     };
     int u = blockIdx.x;
     if (u < units) issue(u, 0, NV);
     const float sc = rsqrtf((float)S);
     for (; u < units; u += gridDim.x) {
+        int b_cur;
+        const bool packed = PACK && unit_col(u, b_cur) == 0;
+        const int un = u + (int)gridDim.x;
+        const bool more = un < units;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int q = tid + NT * j, h = q >> 4, part = q & 15;
+            const int q = tid + NT * j, h = q >> 4;
             if (NV * NT == S * 16 || q < S * 16) {
                 float* d = (part >= 8 ? im : re) + h * CLD + (part & 7) * 4;
                 d[0] = v[j][0]; d[1] = v[j][1]; d[2] = v[j][2]; d[3] = v[j][3];
             }
         }
         __syncthreads();
-        if (EARLY_TOP > 0 && u + (int)gridDim.x < units) issue(u + gridDim.x, 0, EARLY_TOP);
+        if (EARLY_TOP > 0 && more) issue(un, 0, EARLY_TOP);
         if (!(MTD_ANY_SKIP & 1)) lds_fft<-1, true, CLD, FFT_NT(NT), FFT_UNR, MTD_ANY_FFTV>(re, im, tw, S, logS);
+        // packed unit, rows k and S - k of the transform (bit-reversed places): Z[k], Z[S-k] -> A[k], B[k] (to_spectra) and, after
+        // the mix, the Hermitian columns U[k] (row k), V[k] (row S - k) -> (U + i V)[k], (U + i V)[S-k]
+        auto pair_pass = [&](bool to_spectra) {
+            int e = tid;
+            asm volatile("" : "+v"(e));      // (opaque: the pass's row addresses are not to become invariants of the unit loop, held in registers over it)
+#pragma nounroll
+            for (; e < (S / 2 - 1) * 16; e += NT) {
+                const int p = 1 + (e >> 4), c = (e & 15) * 2;
+                const int rk = brev_n(p, logS) * CLD + c, rm = brev_n(S - p, logS) * CLD + c;
+                const f32x2 kr = *reinterpret_cast<const f32x2*>(re + rk), ki = *reinterpret_cast<const f32x2*>(im + rk);
+                const f32x2 mr = *reinterpret_cast<const f32x2*>(re + rm), mi = *reinterpret_cast<const f32x2*>(im + rm);
+                if (to_spectra) {
+                    *reinterpret_cast<f32x2*>(re + rk) = 0.5f * (kr + mr);
+                    *reinterpret_cast<f32x2*>(im + rk) = 0.5f * (ki - mi);
+                    *reinterpret_cast<f32x2*>(re + rm) = 0.5f * (ki + mi);
+                    *reinterpret_cast<f32x2*>(im + rm) = 0.5f * (mr - kr);
+                } else {
+                    *reinterpret_cast<f32x2*>(re + rk) = kr - mi;
+                    *reinterpret_cast<f32x2*>(im + rk) = ki + mr;
+                    *reinterpret_cast<f32x2*>(re + rm) = kr + mi;
+                    *reinterpret_cast<f32x2*>(im + rm) = mr - ki;
+                }
+            }
+            __syncthreads();
+        };
+        if (packed) pair_pass(true);
         // channel mix at every frequency on the matrix cores: D[o][n] = sum_k W[k][o] * Z[n][k], k = (re 0..31 | im 32..63).
         // A operand: lane (o = l & 31, k = l >> 5) of W from LDS; B operand: lane (n = l & 31, k = l >> 5) of the column.
         // work items = (32-row tile, output half): S / 32 * 2 over the 16 waves; results stay in registers until every
@@ -275,52 +339,123 @@ __global__ __launch_bounds__(NT) void spec_mix_any_kernel(const float* __restric
         // the next column's loads in two halves: one requested here, before the mix (16 registers beside its accumulators: more do
         // not fit a 1024-thread workgroup's 128), the other after it -- with all of them after the mix their way from memory had
         // only the inverse transform to hide under, and 256 CUs asking for 33 MB at once need longer than that (6.28 -> 5.99 ms)
-        if (u + (int)gridDim.x < units) issue(u + gridDim.x, EARLY_TOP, EARLY);
+        if (more && !packed) issue(un, EARLY_TOP, EARLY);      // (a packed unit's two accumulator sets leave no room: all after the mix)
         constexpr int NW = NT / 64, ITEMS = S / 32 * 2, PER = (ITEMS + NW - 1) / NW;
-        f32x16 acc[PER];
+        if (!packed) {
+            f32x16 acc[PER];
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int item = wv + NW * i;
+            for (int i = 0; i < PER; ++i) {
+                const int item = wv + NW * i;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-            if (item < ITEMS && !(MTD_ANY_SKIP & 2)) {
-                const int tile = item % (S / 32), ob = item / (S / 32);
-                const float* zr = re + (tile * 32 + (lane & 31)) * CLD + (lane >> 5);
-                const float* zi = im + (tile * 32 + (lane & 31)) * CLD + (lane >> 5);
-                const float* wp = wl + (lane >> 5) * 64 + ob * 32 + (lane & 31);
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+                if (item < ITEMS && !(MTD_ANY_SKIP & 2)) {
+                    const int tile = item % (S / 32), ob = item / (S / 32);
+                    const float* zr = re + (tile * 32 + (lane & 31)) * CLD + (lane >> 5);
+                    const float* zi = im + (tile * 32 + (lane & 31)) * CLD + (lane >> 5);
+                    const float* wp = wl + (lane >> 5) * 64 + ob * 32 + (lane & 31);
 #pragma unroll 4
-                for (int s2 = 0; s2 < 16; ++s2) acc[i] = mfma32(wp[s2 * 128], zr[s2 * 2], acc[i]);
+                    for (int s2 = 0; s2 < 16; ++s2) acc[i] = mfma32(wp[s2 * 128], zr[s2 * 2], acc[i]);
 #pragma unroll 4
-                for (int s2 = 0; s2 < 16; ++s2) acc[i] = mfma32(wp[(16 + s2) * 128], zi[s2 * 2], acc[i]);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int item = wv + NW * i;
-            if (item < ITEMS) {
-                const int tile = item % (S / 32), ob = item / (S / 32);
-                float* dst = (ob ? im : re) + (tile * 32 + (lane & 31)) * CLD;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int o = mfma32_row(r, lane);
-                    dst[o] = fmaxf(acc[i][r] * sc + wl[4096 + ob * 32 + o], 0.f);
+                    for (int s2 = 0; s2 < 16; ++s2) acc[i] = mfma32(wp[(16 + s2) * 128], zi[s2 * 2], acc[i]);
                 }
             }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int item = wv + NW * i;
+                if (item < ITEMS) {
+                    const int tile = item % (S / 32), ob = item / (S / 32);
+                    // (output channel of accumulator element r: mfma32_row(r, lane) = 4 (lane >> 5) + a constant -- ONE address register each
+                    // for the row and the bias, the sixteen places as immediate offsets)
+                    float* dst = (ob ? im : re) + (tile * 32 + (lane & 31)) * CLD + 4 * (lane >> 5);
+                    const float* bia = wl + 4096 + ob * 32 + 4 * (lane >> 5);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int oc = (r & 3) + 8 * (r >> 2);
+                        dst[oc] = fmaxf(acc[i][r] * sc + bia[oc], 0.f);
+                    }
+                }
+            }
+        } else {
+            // the two half sums apart: P over the real parts, Q over the imaginary parts; Y(X) = relu((P + Q) sc + b), Y(conj X) =
+            // relu((P - Q) sc + b); the row becomes (Y(X) + conj Y(conj X)) / 2.  Rows 0 and S/2 (places 0 and 1) hold two REAL
+            // values (A, B): their results are relu(W_rr A sc + b_r) and relu(W_rr B sc + b_r) (the real part of the mix of a real
+            // vector), 2 x 2 x 32 sums of 32 products by the first 128 threads.
+            // (opaque copies of the thread's indices: what this rare branch derives from them -- sixteen bias and sixteen store addresses --
+            // would otherwise become invariants of the unit loop, computed ahead of it and held, or spilled, over every unit)
+            int tid_p = tid;
+            asm volatile("" : "+v"(tid_p));
+            const int lane_p = tid_p & 63, wv_p = __builtin_amdgcn_readfirstlane(tid_p >> 6);
+            f32x16 outv[PER];
+            float edge = 0.f;
+            if (tid_p < 128) {
+                const float* src = ((tid_p & 32) ? im : re) + (tid_p >> 6) * CLD;
+                const int o = tid_p & 31;
+                float t = 0.f;
+#pragma unroll 8
+                for (int k = 0; k < 32; ++k) t += wl[k * 64 + o] * src[k];
+                edge = fmaxf(t * sc + wl[4096 + o], 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int item = wv_p + NW * i;
+                f32x16 accP, accQ;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accP[r] = accQ[r] = 0.f;
+                if (item < ITEMS && !(MTD_ANY_SKIP & 2)) {
+                    const int tile = item % (S / 32), ob = item / (S / 32);
+                    const float* zr = re + (tile * 32 + (lane_p & 31)) * CLD + (lane_p >> 5);
+                    const float* zi = im + (tile * 32 + (lane_p & 31)) * CLD + (lane_p >> 5);
+                    const float* wp = wl + (lane_p >> 5) * 64 + ob * 32 + (lane_p & 31);
+#pragma unroll 4
+                    for (int s2 = 0; s2 < 16; ++s2) accP = mfma32(wp[s2 * 128], zr[s2 * 2], accP);
+#pragma unroll 4
+                    for (int s2 = 0; s2 < 16; ++s2) accQ = mfma32(wp[(16 + s2) * 128], zi[s2 * 2], accQ);
+                    const float sgn = ob ? -1.f : 1.f;
+                    const float* bia = wl + 4096 + ob * 32 + 4 * (lane_p >> 5);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float bb = bia[(r & 3) + 8 * (r >> 2)];
+                        const float y1 = fmaxf((accP[r] + accQ[r]) * sc + bb, 0.f), y2 = fmaxf((accP[r] - accQ[r]) * sc + bb, 0.f);
+                        outv[i][r] = 0.5f * (y1 + sgn * y2);
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int item = wv_p + NW * i;
+                if (item < ITEMS) {
+                    const int tile = item % (S / 32), ob = item / (S / 32);
+                    const int row = tile * 32 + (lane_p & 31);
+                    float* dst = (ob ? im : re) + row * CLD + 4 * (lane_p >> 5);
+                    if (row >= 2) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dst[(r & 3) + 8 * (r >> 2)] = outv[i][r];
+                    }
+                }
+            }
+            if (tid_p < 128) (((tid_p & 32) ? im : re) + (tid_p >> 6) * CLD)[tid_p & 31] = edge;
         }
         __syncthreads();
+        if (packed) pair_pass(false);
         // the next column's loads: issued here, after the mix (their 32 registers are not live under its accumulators -- with
         // 1024 threads a lane has 128), they land under the inverse transform
-        if (u + (int)gridDim.x < units) issue(u + gridDim.x, EARLY, NV);
+        if (more) {      // (constant bounds in either call: a run-time first index would send the prefetch registers to scratch memory)
+            if (packed) issue(un, EARLY_TOP, NV);
+            else issue(un, EARLY, NV);
+        }
         if (!(MTD_ANY_SKIP & 4)) lds_fft<+1, false, CLD, FFT_NT(NT), FFT_UNR, MTD_ANY_FFTV>(re, im, tw, S, logS);
-        float* dstg = T + (long long)u * S * 64;
+        int poff;
+        float* dstg = T + unit_base(u, poff);
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int q = tid + NT * j, h = q >> 4, part = q & 15;
+            const int q = tid + NT * j, h = q >> 4;
             if (NV * NT == S * 16 || q < S * 16) {
                 const float* d = (part >= 8 ? im : re) + h * CLD + (part & 7) * 4;
                 f32x4 o = {d[0] * sc, d[1] * sc, d[2] * sc, d[3] * sc};
-                *reinterpret_cast<f32x4*>(dstg + (long long)q * 4) = o;
+                *reinterpret_cast<f32x4*>(dstg + (q * 4 + poff)) = o;
+                if (packed) *reinterpret_cast<f32x4*>(dstg + (q * 4 + poff + 32)) = f32x4{0.f, 0.f, 0.f, 0.f};      // (the imaginary halves)
             }
         }
         __syncthreads();
@@ -444,17 +579,24 @@ int launch_rfft_rows(const float* x, int x_ld, float* R, int B, hipStream_t s) {
     return MTD_OK;
 }
 
-template <int S>
-int launch_spec_mix(const float* R, const float* w2t, const float* b2, float* T, int B, hipStream_t s) {
+template <int S, bool PACK>
+int launch_spec_mix_form(const float* R, const float* w2t, const float* b2, float* T, int B, hipStream_t s) {
     const size_t lds = (size_t)2 * S * CLD * 4 + (size_t)S * 4 + (64 * 64 + 64) * 4;
     constexpr int NT = S >= 512 ? MTD_ANY_NT512 : 1024;
-    int rc = set_lds(spec_mix_any_kernel<S, NT>, lds);
+    int rc = set_lds(spec_mix_any_kernel<S, NT, PACK>, lds);
     if (rc != MTD_OK) return rc;
-    const int units = B * (S / 2 + 1);
+    const int units = B * (PACK ? S / 2 : S / 2 + 1);
     const int prof = mtd_prof_begin(2, 1, 1, (long long)B * S * (S / 2 + 1), 64, 64, 0, s, 2.0 * 4.0 * B * S * 64.0 * (S / 2 + 1));
-    MTD_LAUNCH((spec_mix_any_kernel<S, NT>), dim3(persistent_grid(units, lds)), dim3(NT), lds, s, R, w2t, b2, T, units);
+    MTD_LAUNCH((spec_mix_any_kernel<S, NT, PACK>), dim3(persistent_grid(units, lds)), dim3(NT), lds, s, R, w2t, b2, T, units);
     mtd_prof_end(prof, s);
     return MTD_OK;
+}
+
+template <int S>
+int launch_spec_mix(const float* R, const float* w2t, const float* b2, float* T, int B, hipStream_t s) {
+    // (lab library: MTD_ANY_PACK=0 keeps the columns 0 and S/2 as units of their own)
+    static const int env_pack = [] { const char* e = mtd_lab_env("MTD_ANY_PACK"); return e ? atoi(e) : 1; }();
+    return env_pack ? launch_spec_mix_form<S, true>(R, w2t, b2, T, B, s) : launch_spec_mix_form<S, false>(R, w2t, b2, T, B, s);
 }
 
 template <int S>

@@ -281,4 +281,16 @@ done | tee $O/exp26_fdp.txt
 bash tools/dp_two_ranks.sh > $O/exp26_dp2.txt 2>&1; grep "dp2\|exit code" $O/exp26_dp2.txt | cut -c1-400
 }
 
+# round 6, experiment 20: whole-slice column kernel, the two real columns kw = 0 and kw = S/2 of an image through one packed transform (lab library: MTD_ANY_PACK=0 = units of their own)
+exp27() {
+timeout -k 10 500 python -m pytest tests/test_inference_gpu.py -x -q > $O/exp27_tests.log 2>&1 || { tail -40 $O/exp27_tests.log | cut -c1-300; exit 1; }
+tail -2 $O/exp27_tests.log
+for i in 1 2 3; do
+  for cfg in "MTD_ANY_PACK=0" "MTD_ANY_PACK=1"; do
+    ms=$(env MTD_LAB=1 $cfg timeout -k 10 200 python bench.py --workload inference512 --steps 20 --warmup 3 --no-roofline --no-cpu-baseline 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.read().strip().splitlines()[-1])['ms_per_step'])")
+    echo "inference512 [$cfg] $ms ms"
+  done
+done | tee $O/exp27_inf.txt
+}
+
 "$@"
