@@ -176,7 +176,7 @@ template <> struct Log2<1> { static constexpr int v = 0; };
 // rows forward: a pair of image rows (b, h), (b, h + 1) per step -- the two real rows are the real and imaginary part of one
 // complex transform Z; X_h[k] = (Z[k] + conj Z[-k]) / 2, X_{h+1}[k] = (Z[k] - conj Z[-k]) / 2i.  unit u = b * S/2 + h/2.
 template <int S, int NT>
-__global__ __launch_bounds__(NT) void rfft_rows_any_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ R, int units) {
+__global__ __launch_bounds__(NT) void rfft_rows_any_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ R, int units, int rev) {
     constexpr int logS = Log2<S>::v, NV = (S * 16 + NT - 1) / NT, nkw = S / 2 + 1;
     extern __shared__ float lds[];
     float* re = lds;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NT) void rfft_rows_any_kernel(const float* __restri
     const int tid = threadIdx.x;
     f32x4 v[NV];
     auto issue = [&](int u) {
-        const int b = u / (S / 2), h = (u % (S / 2)) * 2;
+        const int uu = rev ? units - 1 - u : u, b = uu / (S / 2), h = (uu % (S / 2)) * 2;
         const float* src = x + ((long long)(b * S + h) * S) * x_ld;           // rows h, h + 1: 2 S consecutive pixels
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(NT) void rfft_rows_any_kernel(const float* __restri
         __syncthreads();
         if (u + (int)gridDim.x < units) issue(u + gridDim.x);                  // lands under this pair's transform
         lds_fft<-1, true, 32, FFT_NT(NT), FFT_UNR>(re, im, tw, S, logS);
-        const int b = u / (S / 2), h = (u % (S / 2)) * 2;
+        const int uu = rev ? units - 1 - u : u, b = uu / (S / 2), h = (uu % (S / 2)) * 2;
         const float sc = 0.5f * rsqrtf((float)S);
         for (int it = tid; it < nkw * 8; it += NT) {
             const int kw = it >> 3, c4 = it & 7;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(NT) void rfft_rows_any_kernel(const float* __restri
 constexpr int CLD = 34;        // even (8-byte transform accesses), 2-way bank conflicts for the MFMA operand reads along the frequency index
 template <int S, int NT, bool PACK>
 __global__ __launch_bounds__(NT) void spec_mix_any_kernel(const float* __restrict__ R, const float* __restrict__ w2t,
-                                                           const float* __restrict__ b2, float* __restrict__ T, int units) {
+                                                           const float* __restrict__ b2, float* __restrict__ T, int units, int rev) {
     constexpr int logS = Log2<S>::v, NV = (S * 16 + NT - 1) / NT, nkw = S / 2 + 1;
     static_assert(NT % 16 == 0, "a thread keeps its 16-byte part of a spectrum row over a unit");
 #ifdef MTD_ANY_EARLY      /* lab: how many of the next column's NV load vectors go out before the mix / before the forward transform */
@@ -263,7 +263,8 @@ __global__ __launch_bounds__(NT) void spec_mix_any_kernel(const float* __restric
     for (int i = tid; i < 64 * 64 + 64; i += NT) wl[i] = i < 4096 ? w2t[i] : b2[i - 4096];
     // unit u -> (image, column); PACK: S/2 units per image, column 0 standing for the pair (0, S/2), and the images' pairs rotated
     // over the workgroups (with S/2 units per image and a grid of S/2 they would all be workgroup 0's)
-    auto unit_col = [&](int u, int& b) {
+    auto unit_col = [&](int uw, int& b) {
+        const int u = rev ? units - 1 - uw : uw;      // (rev: the walk runs from the last image to the first)
         if (!PACK) { b = u / nkw; return u - b * nkw; }
         b = u / (S / 2);
         return (u - b * (S / 2) + b) & (S / 2 - 1);
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(NT) void spec_mix_any_kernel(const float* __restric
 template <int S, int NT>
 __global__ __launch_bounds__(NT) void irfft_rows_any_kernel(const float* __restrict__ T, float* __restrict__ out, int out_ld,
                                                               const float* __restrict__ add1, int add1_ld,
-                                                              const float* __restrict__ add2, int add2_ld, int units) {
+                                                              const float* __restrict__ add2, int add2_ld, int units, int rev) {
     constexpr int logS = Log2<S>::v, nkw = S / 2 + 1, NI = (nkw * 8 + NT - 1) / NT, NV = (S * 16 + NT - 1) / NT;
     extern __shared__ float lds[];
     float* re = lds;
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(NT) void irfft_rows_any_kernel(const float* __restr
     const int tid = threadIdx.x;
     f32x4 t0[NI], t1[NI], t2[NI], t3[NI];
     auto issue = [&](int u) {
-        const int b = u / (S / 2), h = (u % (S / 2)) * 2;
+        const int uu = rev ? units - 1 - u : u, b = uu / (S / 2), h = (uu % (S / 2)) * 2;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int it = tid + NT * j, kw = it >> 3, c4 = it & 7;
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(NT) void irfft_rows_any_kernel(const float* __restr
         __syncthreads();
         if (u + (int)gridDim.x < units) issue(u + gridDim.x);
         lds_fft<+1, false, 32, FFT_NT(NT), FFT_UNR>(re, im, tw, S, logS);
-        const int b = u / (S / 2), h = (u % (S / 2)) * 2;
+        const int uu = rev ? units - 1 - u : u, b = uu / (S / 2), h = (uu % (S / 2)) * 2;
         const long long rowpix = (long long)(b * S + h) * S;                  // rows h, h + 1: 2 S consecutive pixels
         constexpr int CH = NV < 2 ? NV : 2;                                   // residual operands in chunks: 2 x CH vectors in flight
 #pragma nounroll
@@ -557,6 +558,16 @@ int set_lds(K kernel, size_t bytes) {
     return e == hipSuccess ? MTD_OK : (int)e;
 }
 
+// Which of the three kernels walk their lines from the LAST image to the first (bit 0 rows, 1 columns, 2 rows back).  The 256 MB
+// memory-side cache holds what the previous kernel touched last: a kernel that starts where its producer stopped finds part of its
+// input there.  The conv kernels before and after walk forward, so: rows backward, columns forward, rows back backward (5) --
+// 20.24 -> 20.03 ms per 8 slices (six A/B pairs, profiles/r6_ab_experiments.txt item 21); the other seven settings lie between
+// (lab library: MTD_ANY_REV).
+inline int any_rev() {
+    static const int env_rev = [] { const char* e = mtd_lab_env("MTD_ANY_REV"); return e ? atoi(e) : 5; }();
+    return env_rev;
+}
+
 // persistent grid: as many workgroups as fit the chip at this LDS footprint (160 KB per CU, 2048 threads per CU)
 inline int persistent_grid(int units, size_t lds_bytes) {
     int per_cu = (int)((160 * 1024) / (lds_bytes + 1024));
@@ -574,7 +585,7 @@ int launch_rfft_rows(const float* x, int x_ld, float* R, int B, hipStream_t s) {
     if (rc != MTD_OK) return rc;
     const int units = B * S / 2;
     const int prof = mtd_prof_begin(2, 0, 1, (long long)B * S * S, 32, 32, 0, s, 4.0 * B * S * 32.0 * (S + 2.0 * (S / 2 + 1)));
-    MTD_LAUNCH((rfft_rows_any_kernel<S, NT>), dim3(persistent_grid(units, lds)), dim3(NT), lds, s, x, x_ld, R, units);
+    MTD_LAUNCH((rfft_rows_any_kernel<S, NT>), dim3(persistent_grid(units, lds)), dim3(NT), lds, s, x, x_ld, R, units, any_rev() & 1);
     mtd_prof_end(prof, s);
     return MTD_OK;
 }
@@ -587,7 +598,7 @@ int launch_spec_mix_form(const float* R, const float* w2t, const float* b2, floa
     if (rc != MTD_OK) return rc;
     const int units = B * (PACK ? S / 2 : S / 2 + 1);
     const int prof = mtd_prof_begin(2, 1, 1, (long long)B * S * (S / 2 + 1), 64, 64, 0, s, 2.0 * 4.0 * B * S * 64.0 * (S / 2 + 1));
-    MTD_LAUNCH((spec_mix_any_kernel<S, NT, PACK>), dim3(persistent_grid(units, lds)), dim3(NT), lds, s, R, w2t, b2, T, units);
+    MTD_LAUNCH((spec_mix_any_kernel<S, NT, PACK>), dim3(persistent_grid(units, lds)), dim3(NT), lds, s, R, w2t, b2, T, units, (any_rev() >> 1) & 1);
     mtd_prof_end(prof, s);
     return MTD_OK;
 }
@@ -610,7 +621,7 @@ int launch_irfft_rows(const float* T, float* out, int out_ld, const float* add1,
     const int prof = mtd_prof_begin(2, 2, 1, (long long)B * S * S, 32, 32, 0, s,
                                     4.0 * B * S * 32.0 * (2.0 * (S / 2 + 1) + S * (1.0 + (add1 ? 1 : 0) + (add2 ? 1 : 0))));
     MTD_LAUNCH((irfft_rows_any_kernel<S, NT>), dim3(persistent_grid(units, lds)), dim3(NT), lds, s, T, out, out_ld, add1, add1_ld, add2,
-               add2_ld, units);
+               add2_ld, units, (any_rev() >> 2) & 1);
     mtd_prof_end(prof, s);
     return MTD_OK;
 }

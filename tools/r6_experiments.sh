@@ -293,4 +293,16 @@ for i in 1 2 3; do
 done | tee $O/exp27_inf.txt
 }
 
+# round 6, experiment 21: whole-slice spectral kernels walking their lines from the last image to the first (lab library MTD_ANY_REV: bit 0 rows, 1 columns, 2 rows back)
+exp28() {
+MTD_LAB=1 MTD_ANY_REV=7 timeout -k 10 500 python -m pytest tests/test_inference_gpu.py -x -q > $O/exp28_tests.log 2>&1 || { tail -40 $O/exp28_tests.log | cut -c1-300; exit 1; }
+tail -2 $O/exp28_tests.log
+for i in 1 2; do
+  for v in 0 2 6 4 7 5 3 1; do
+    ms=$(env MTD_LAB=1 MTD_ANY_REV=$v timeout -k 10 200 python bench.py --workload inference512 --steps 20 --warmup 3 --no-roofline --no-cpu-baseline 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.read().strip().splitlines()[-1])['ms_per_step'])")
+    echo "inference512 [MTD_ANY_REV=$v] $ms ms"
+  done
+done | tee $O/exp28_inf.txt
+}
+
 "$@"
